@@ -1,0 +1,307 @@
+/*
+ * tetra_gpu.h -- C ABI of the MI355X-native TETRA lower-MAC receive path.
+ *
+ * Drop-in boundary for osmocom/osmo-tetra's PHY + lower MAC (reference paths are
+ * relative to its src/ directory).  Plain C types only; device buffers are raw
+ * device pointers, the stream argument is a hipStream_t passed as void*.
+ *
+ * Three levels, lowest first:
+ *
+ *  1. plan API (device resident, what bench.py times):
+ *       tgpu_plan_*        slots of a batch (offset, burst type, channel) -> one
+ *                          320-byte record per slot in HBM.  Replaces the arithmetic
+ *                          of tetra_burst_rx_cb() (phy/tetra_burst.c:341-379) and
+ *                          tp_sap_udata_ind() (lower_mac/tetra_lower_mac.c:143-357)
+ *                          for many bursts at once.
+ *  2. channel API (host buffers in, callbacks out):
+ *       tetra_burst_sync_in()   same symbol, same struct tetra_rx_state layout and
+ *                          same return values as phy/tetra_burst_sync.c:54-154.
+ *                          Bursts are queued, decoded on the GPU in batches and
+ *                          delivered, in the reference's order, to a callback that
+ *                          has upper_mac_prim_recv()'s contract
+ *                          (tetra_upper_mac.c:549-566).
+ *  3. helpers: record parsing, synthetic burst generation for benchmarks/tests.
+ *
+ * Error convention: functions return 0 on success, a negative TGPU_E* code for
+ * argument/state errors and a positive hipError_t value when the HIP runtime
+ * failed.  tetra_burst_sync_in() keeps the reference's own return values.
+ * There is no CPU fallback: without a usable GPU tgpu_engine_create() fails.
+ */
+#ifndef TETRA_GPU_H
+#define TETRA_GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* types mirrored from the reference (values and layouts are ABI)             */
+/* ------------------------------------------------------------------------- */
+
+/* phy/tetra_burst.h:6-7 */
+#define BLK_1 1
+#define BLK_2 2
+
+/* phy/tetra_burst.h:9-16 */
+enum tp_sap_data_type {
+	TPSAP_T_SB1,
+	TPSAP_T_SB2,
+	TPSAP_T_NDB,
+	TPSAP_T_BBK,
+	TPSAP_T_SCH_HU,
+	TPSAP_T_SCH_F,
+};
+
+/* phy/tetra_burst.h:30-36 */
+enum tetra_train_seq {
+	TETRA_TRAIN_NORM_1,
+	TETRA_TRAIN_NORM_2,
+	TETRA_TRAIN_NORM_3,
+	TETRA_TRAIN_SYNC,
+	TETRA_TRAIN_EXT,
+};
+
+/* tetra_common.h:22-39 */
+enum tetra_log_chan {
+	TETRA_LC_UNKNOWN,
+	TETRA_LC_SCH_F,
+	TETRA_LC_SCH_HD,
+	TETRA_LC_SCH_HU,
+	TETRA_LC_STCH,
+	TETRA_LC_SCH_P8_F,
+	TETRA_LC_SCH_P8_HD,
+	TETRA_LC_SCH_P8_HU,
+	TETRA_LC_AACH,
+	TETRA_LC_TCH,
+	TETRA_LC_BSCH,
+	TETRA_LC_BNCH,
+};
+
+/* tetra_tdma.h:6-12 */
+struct tetra_tdma_time {
+	uint16_t hn;
+	uint32_t sn;
+	uint32_t tn;
+	uint32_t fn;
+	uint32_t mn;
+};
+
+/* phy/tetra_burst_sync.h:6-20 */
+enum rx_state {
+	RX_S_UNLOCKED,
+	RX_S_KNOW_FSTART,
+	RX_S_LOCKED,
+};
+
+struct tetra_rx_state {
+	enum rx_state state;
+	unsigned int bits_in_buf;
+	uint8_t bitbuf[4096];
+	unsigned int bitbuf_start_bitnum;
+	unsigned int next_frame_start_bitnum;
+	void *burst_cb_priv;	/* must hold the struct tgpu_channel* (see tgpu_channel_create) */
+};
+
+#define TETRA_CRC_OK 0x1d0f	/* tetra_common.h:69 */
+#define SCRAMB_INIT  3		/* lower_mac/tetra_scramb.h:14 */
+
+/* ------------------------------------------------------------------------- */
+/* error codes                                                                */
+/* ------------------------------------------------------------------------- */
+#define TGPU_OK         0
+#define TGPU_EINVAL    -1	/* bad argument */
+#define TGPU_ENOMEM    -2
+#define TGPU_ENODEV    -3	/* no usable GPU: there is no CPU fallback */
+#define TGPU_ECAPACITY -4	/* more slots/channels than the plan was created for */
+#define TGPU_ESTATE    -5	/* call order violated (e.g. execute before load) */
+
+const char *tgpu_strerror(int err);
+
+/* ------------------------------------------------------------------------- */
+/* engine: one per process / per GPU                                          */
+/* ------------------------------------------------------------------------- */
+struct tgpu_engine;
+int tgpu_engine_create(struct tgpu_engine **out, int device);
+void tgpu_engine_destroy(struct tgpu_engine *eng);
+
+/* ------------------------------------------------------------------------- */
+/* 1. plan API                                                                */
+/* ------------------------------------------------------------------------- */
+#define TGPU_REC_BYTES    320	/* output record per slot, layout below */
+#define TGPU_SLOT_BYTES   510
+
+struct tgpu_plan;
+
+/* capacity: the largest batch (slots) and channel count the plan will be loaded with */
+int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_chan, struct tgpu_plan **out);
+void tgpu_plan_destroy(struct tgpu_plan *plan);
+
+/*
+ * Describe a batch (host arrays, copied).  slot_off[i]: byte offset of slot i in the
+ * stream buffer later given to tgpu_plan_execute().  slot_type[i]: enum tetra_train_seq
+ * (NORM_1, NORM_2 or SYNC; anything else = skip).  slot_chan[i]: channel index < nchan,
+ * NON-DECREASING in i (slots of one channel are contiguous and in stream order).
+ * chan_code[c]: scrambling code in effect for channel c before its first slot
+ * (tcd->scramb_init, lower_mac/tetra_lower_mac.c:104-113; 0 for a fresh channel).
+ */
+int tgpu_plan_load(struct tgpu_plan *plan, uint32_t nslots, const uint64_t *slot_off,
+		   const uint8_t *slot_type, const uint32_t *slot_chan,
+		   uint32_t nchan, const uint32_t *chan_code);
+
+/*
+ * Run the loaded batch: d_stream (device, 1 bit per byte) -> d_rec (device,
+ * nslots * TGPU_REC_BYTES).  Asynchronous on 'hip_stream'; launches only, no
+ * allocation and no host synchronisation (hipGraph-capturable).
+ */
+int tgpu_plan_execute(struct tgpu_plan *plan, const uint8_t *d_stream, uint8_t *d_rec, void *hip_stream);
+
+/* scrambling code in effect per channel after the batch (device->host copy, synchronises) */
+int tgpu_plan_final_codes(struct tgpu_plan *plan, const uint8_t *d_rec, uint32_t *chan_code_out);
+
+/*
+ * Per-kernel timing with HIP events on the SAME stream the kernels are launched on.
+ * tgpu_plan_execute_prof() is tgpu_plan_execute() plus one event record between stages
+ * (no host synchronisation); tgpu_prof_read() synchronises on the last event and returns
+ * the milliseconds of every stage of every recorded step: ms[step * TGPU_NSTAGES + stage].
+ */
+#define TGPU_NSTAGES 6
+#define TGPU_STAGE_FRONT   0	/* k_front                */
+#define TGPU_STAGE_SB1     1	/* k_vit<SB1>             */
+#define TGPU_STAGE_FILL    2	/* k_fill_* (3 launches)  */
+#define TGPU_STAGE_MASKS   3	/* k_masks                */
+#define TGPU_STAGE_VIT216  4	/* k_vit<216>             */
+#define TGPU_STAGE_VIT432  5	/* k_vit<432>             */
+struct tgpu_prof;
+int tgpu_prof_create(uint32_t max_steps, struct tgpu_prof **out);
+void tgpu_prof_destroy(struct tgpu_prof *prof);
+int tgpu_plan_execute_prof(struct tgpu_plan *plan, const uint8_t *d_stream, uint8_t *d_rec, void *hip_stream,
+			   struct tgpu_prof *prof, uint32_t step);
+int tgpu_prof_read(struct tgpu_prof *prof, uint32_t nsteps, float *ms);
+const char *tgpu_stage_name(int stage);
+
+/* one decoded block of a record, in the reference's terms */
+struct tgpu_block {
+	enum tp_sap_data_type type;
+	int blk_num;
+	int crc_ok;
+	uint16_t crc;
+	uint32_t scrambling_code;
+	uint16_t type1_len;
+	const uint8_t *type1;	/* points into the record, 1 bit per byte */
+};
+
+/*
+ * Split a (host copy of a) record into its blocks in tetra_burst_rx_cb() call order:
+ * SYNC: SB1, BBK, SB2.  NORM_2: BBK, NDB(BLK_1), NDB(BLK_2).  NORM_1: BBK, SCH/F.
+ * Returns the number of blocks (0 for a skipped slot).
+ */
+int tgpu_record_blocks(const uint8_t *rec, struct tgpu_block out[3]);
+
+/* SYNC-PDU fields of a SYNC record (lower_mac/tetra_lower_mac.c:284-297) */
+struct tgpu_sync_info {
+	uint8_t cc, tn, fn, mn;
+	uint16_t mcc, mnc;
+	uint32_t scramb_init;
+};
+int tgpu_record_sync_info(const uint8_t *rec, struct tgpu_sync_info *out);
+
+/* ------------------------------------------------------------------------- */
+/* 2. channel API                                                             */
+/* ------------------------------------------------------------------------- */
+
+/* TMV-SAP UNITDATA indication: what the reference hands to upper_mac_prim_recv()
+ * inside struct tetra_tmvsap_prim + msgb (tetra_prim.h:25-47). */
+struct tgpu_unitdata {
+	enum tp_sap_data_type type;
+	int blk_num;
+	enum tetra_log_chan lchan;
+	int crc_ok;
+	uint16_t crc;
+	uint32_t scrambling_code;
+	struct tetra_tdma_time tdma_time;
+	uint32_t burst_seq;		/* ordinal of the LOCKED burst */
+	enum tetra_train_seq burst_type;
+	uint16_t type1_len;
+	const uint8_t *type1;		/* msg->l1h: borrowed for the call */
+	int traffic;			/* != 0: block is a traffic-channel block (cur_burst.is_traffic value);
+					 * the reference dumps it instead of decoding it
+					 * (lower_mac/tetra_lower_mac.c:198-241); type4 is set, type1 is NULL */
+	const uint8_t *type4;		/* descrambled bits of a traffic block, type345 bits */
+	uint16_t type4_len;
+};
+
+/*
+ * Same contract as upper_mac_prim_recv(): return the number of type-1 bits parsed, or
+ * -1 when done with this block.  'offset' = bits already consumed (msg->head advance,
+ * lower_mac/tetra_lower_mac.c:326-352).  Traffic blocks are delivered once with
+ * offset = UINT32_MAX and the return value is ignored.
+ */
+typedef int (*tgpu_unitdata_cb)(const struct tgpu_unitdata *ud, unsigned int offset, void *priv);
+
+/* sync-layer notifications: what phy/tetra_burst_sync.c prints */
+enum tgpu_sync_event {
+	TGPU_EV_FOUND_SYNC = 1,
+	TGPU_EV_BURST = 2,
+	TGPU_EV_SYNC_MISPLACED = 3,
+	TGPU_EV_NORM_MISPLACED = 4,
+	TGPU_EV_NO_TRAIN = 5,
+};
+typedef void (*tgpu_event_cb)(int event, uint32_t bitnum, uint32_t arg, void *priv);
+
+struct tgpu_channel;
+
+/*
+ * batch_slots: bursts queued before a GPU decode is triggered (1 = decode every burst
+ * immediately, like the reference).  'priv' is passed to both callbacks (the reference
+ * passes tms).  Store the returned pointer in trs->burst_cb_priv.
+ */
+int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unitdata_cb cb,
+			tgpu_event_cb ev, void *priv, struct tgpu_channel **out);
+void tgpu_channel_destroy(struct tgpu_channel *ch);
+
+/* feedback flags of tms->cur_burst (tetra_common.h:51-55).  Either bind the upper MAC's
+ * own variables (read at delivery time, blk1_stolen is also written) ... */
+void tgpu_channel_bind_flags(struct tgpu_channel *ch, int *is_traffic, bool *blk1_stolen, bool *blk2_stolen);
+/* ... or set them from the callback */
+void tgpu_channel_set_traffic(struct tgpu_channel *ch, int is_traffic);
+void tgpu_channel_set_blk2_stolen(struct tgpu_channel *ch, bool stolen);
+
+/* decode and deliver everything queued so far */
+int tgpu_channel_flush(struct tgpu_channel *ch);
+
+/* phy/tetra_burst_sync.c:54 -- same symbol, same semantics */
+int tetra_burst_sync_in(struct tetra_rx_state *trs, uint8_t *bits, unsigned int len);
+
+/* phy/tetra_burst.c:269-339 -- same symbol, same semantics (host) */
+int tetra_find_train_seq(const uint8_t *in, unsigned int end_of_in,
+			 uint32_t mask_of_train_seq, unsigned int *offset);
+
+/* tetra_tdma.c:77-81, lower_mac/tetra_scramb.c:87-99 */
+void tetra_tdma_time_add_tn(struct tetra_tdma_time *tm, uint32_t tn_count);
+uint32_t tetra_scramb_get_init(uint16_t mcc, uint16_t mnc, uint8_t colour);
+
+/* ------------------------------------------------------------------------- */
+/* 3. synthetic downlink generator (TX side of the same chain; host, multi-threaded) */
+/* ------------------------------------------------------------------------- */
+struct tgpu_synth_cfg {
+	uint64_t seed;
+	uint32_t scramb_init;	/* code for every block except SB1 */
+	uint16_t mcc, mnc;
+	uint8_t cc;
+	double ber;		/* i.i.d. flips inside the coded fields only */
+	int null_pdu_header;	/* 1: first 16 payload bits = MAC-RESOURCE null-address header */
+};
+
+/* n slots of the given types (enum tetra_train_seq) into out[n*510]; payload bits of
+ * slot i come from splitmix64(seed + i).  Returns 0. */
+int tgpu_synth_slots(const struct tgpu_synth_cfg *cfg, const uint8_t *types, size_t n,
+		     uint8_t *out, uint8_t *type1_out /* n*288 or NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

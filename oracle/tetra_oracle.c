@@ -854,7 +854,7 @@ void orc_float_to_bits(const float *in, size_t n, uint8_t *out, int afc,
  * without callbacks / allocation / printing, for bench.py's cpu_baseline.
  * ==================================================================== */
 uint64_t orc_bench_decode_slots(const uint8_t *slots, const uint8_t *types, size_t n,
-				uint32_t scramb_init, int use_acc, uint8_t *type1_out)
+				uint32_t scramb_init, int use_acc, uint8_t *type1_out, uint16_t *crc_out)
 {
 	uint64_t ok = 0;
 	struct orc_block_result res;
@@ -862,22 +862,24 @@ uint64_t orc_bench_decode_slots(const uint8_t *slots, const uint8_t *types, size
 	for (size_t i = 0; i < n; i++) {
 		const uint8_t *b = slots + 510 * i;
 		uint8_t *o = type1_out ? type1_out + 288 * i : NULL;
+		uint16_t crcdummy[2], *c = crc_out ? crc_out + 2 * i : crcdummy;
+		c[0] = c[1] = 0;
 		switch (types[i]) {
 		case ORC_TRAIN_SYNC:
-			orc_decode_block(ORC_T_SB1, b + 94, 3, use_acc, &res); ok += (uint64_t)res.crc_ok;
+			orc_decode_block(ORC_T_SB1, b + 94, 3, use_acc, &res); ok += (uint64_t)res.crc_ok; c[0] = res.crc;
 			if (o) memcpy(o + 14, res.type1, 60);
 			orc_decode_block(ORC_T_BBK, b + 252, scramb_init, use_acc, &res);
 			if (o) memcpy(o, res.type1, 14);
-			orc_decode_block(ORC_T_SB2, b + 282, scramb_init, use_acc, &res); ok += (uint64_t)res.crc_ok;
+			orc_decode_block(ORC_T_SB2, b + 282, scramb_init, use_acc, &res); ok += (uint64_t)res.crc_ok; c[1] = res.crc;
 			if (o) memcpy(o + 14 + 124, res.type1, 124);
 			break;
 		case ORC_TRAIN_NORM_2:
 			memcpy(bbk, b + 230, 14); memcpy(bbk + 14, b + 266, 16);
 			orc_decode_block(ORC_T_BBK, bbk, scramb_init, use_acc, &res);
 			if (o) memcpy(o, res.type1, 14);
-			orc_decode_block(ORC_T_NDB, b + 14, scramb_init, use_acc, &res); ok += (uint64_t)res.crc_ok;
+			orc_decode_block(ORC_T_NDB, b + 14, scramb_init, use_acc, &res); ok += (uint64_t)res.crc_ok; c[0] = res.crc;
 			if (o) memcpy(o + 14, res.type1, 124);
-			orc_decode_block(ORC_T_NDB, b + 282, scramb_init, use_acc, &res); ok += (uint64_t)res.crc_ok;
+			orc_decode_block(ORC_T_NDB, b + 282, scramb_init, use_acc, &res); ok += (uint64_t)res.crc_ok; c[1] = res.crc;
 			if (o) memcpy(o + 14 + 124, res.type1, 124);
 			break;
 		case ORC_TRAIN_NORM_1:
@@ -885,7 +887,7 @@ uint64_t orc_bench_decode_slots(const uint8_t *slots, const uint8_t *types, size
 			memcpy(schf, b + 14, 216); memcpy(schf + 216, b + 282, 216);
 			orc_decode_block(ORC_T_BBK, bbk, scramb_init, use_acc, &res);
 			if (o) memcpy(o, res.type1, 14);
-			orc_decode_block(ORC_T_SCH_F, schf, scramb_init, use_acc, &res); ok += (uint64_t)res.crc_ok;
+			orc_decode_block(ORC_T_SCH_F, schf, scramb_init, use_acc, &res); ok += (uint64_t)res.crc_ok; c[0] = res.crc;
 			if (o) memcpy(o + 14, res.type1, 268);
 			break;
 		default:

@@ -239,7 +239,8 @@ void orc_float_to_bits(const float *in, size_t n, uint8_t *out2n, int afc,
 /* ---- CPU baseline: decode n aligned slots of known type, no callbacks -- */
 /* returns number of CRC-OK blocks; types[i] is enum orc_train_seq         */
 uint64_t orc_bench_decode_slots(const uint8_t *slots, const uint8_t *types, size_t n,
-				uint32_t scramb_init, int use_acc, uint8_t *type1_out /* n*288 or NULL */);
+				uint32_t scramb_init, int use_acc, uint8_t *type1_out /* n*288 or NULL */,
+				uint16_t *crc_out /* n*2 or NULL */);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,15 @@
+"""osmo_tetra_amd -- MI355X-native TETRA lower-MAC receive path.
+
+The product is libtetra_gpu.so (HIP kernels for gfx950 + C host code, C ABI in
+include/tetra_gpu.h).  This package is the thin Python plumbing around it: it builds /
+loads the library and wraps the C ABI with ctypes; PyTorch is used only for device
+memory, streams and torch.distributed.  There is no CPU fallback: every decode entry point
+needs the HIP library and a GPU, and fails loudly otherwise.
+"""
+from .binding import (  # noqa: F401
+    LIB_PATH, REC_BYTES, SLOT_BYTES, TRAIN_NORM_1, TRAIN_NORM_2, TRAIN_SYNC,
+    T_SB1, T_SB2, T_NDB, T_BBK, T_SCH_HU, T_SCH_F,
+    Channel, Engine, Plan, Prof, TgpuError, UnitData, RxState, NSTAGES,
+    find_train_seq, lib, parse_records, record_blocks, synth_slots, declared_symbols,
+)
+from .build import build as build_library  # noqa: F401

@@ -1,0 +1,314 @@
+"""ctypes binding of include/tetra_gpu.h (plain C ABI, no torch types in the signatures)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libtetra_gpu.so")
+HEADER = os.path.join(ROOT, "include", "tetra_gpu.h")
+
+REC_BYTES = 320
+SLOT_BYTES = 510
+TRAIN_NORM_1, TRAIN_NORM_2, TRAIN_NORM_3, TRAIN_SYNC, TRAIN_EXT = range(5)
+T_SB1, T_SB2, T_NDB, T_BBK, T_SCH_HU, T_SCH_F = range(6)
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+class TgpuError(RuntimeError):
+    pass
+
+
+class TdmaTime(C.Structure):
+    _fields_ = [("hn", C.c_uint16), ("sn", C.c_uint32), ("tn", C.c_uint32), ("fn", C.c_uint32), ("mn", C.c_uint32)]
+
+
+class RxState(C.Structure):
+    """struct tetra_rx_state, phy/tetra_burst_sync.h:12-20 of the reference"""
+    _fields_ = [("state", C.c_int), ("bits_in_buf", C.c_uint), ("bitbuf", C.c_uint8 * 4096),
+                ("bitbuf_start_bitnum", C.c_uint), ("next_frame_start_bitnum", C.c_uint),
+                ("burst_cb_priv", C.c_void_p)]
+
+
+class Block(C.Structure):
+    _fields_ = [("type", C.c_int), ("blk_num", C.c_int), ("crc_ok", C.c_int), ("crc", C.c_uint16),
+                ("scrambling_code", C.c_uint32), ("type1_len", C.c_uint16), ("type1", u8p)]
+
+
+class SyncInfo(C.Structure):
+    _fields_ = [("cc", C.c_uint8), ("tn", C.c_uint8), ("fn", C.c_uint8), ("mn", C.c_uint8),
+                ("mcc", C.c_uint16), ("mnc", C.c_uint16), ("scramb_init", C.c_uint32)]
+
+
+class UnitData(C.Structure):
+    _fields_ = [("type", C.c_int), ("blk_num", C.c_int), ("lchan", C.c_int), ("crc_ok", C.c_int),
+                ("crc", C.c_uint16), ("scrambling_code", C.c_uint32), ("tdma_time", TdmaTime),
+                ("burst_seq", C.c_uint32), ("burst_type", C.c_int), ("type1_len", C.c_uint16),
+                ("type1", u8p), ("traffic", C.c_int), ("type4", u8p), ("type4_len", C.c_uint16)]
+
+
+class SynthCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("scramb_init", C.c_uint32), ("mcc", C.c_uint16), ("mnc", C.c_uint16),
+                ("cc", C.c_uint8), ("ber", C.c_double), ("null_pdu_header", C.c_int)]
+
+
+UNITDATA_CB = C.CFUNCTYPE(C.c_int, C.POINTER(UnitData), C.c_uint, C.c_void_p)
+EVENT_CB = C.CFUNCTYPE(None, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p)
+
+_lib = None
+
+
+def declared_symbols():
+    """function names declared in include/tetra_gpu.h"""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:struct\s+\w+|enum\s+\w+|int|void|uint32_t|size_t|char)\s*\*?\s*(\w+)\s*\(",
+                       txt, flags=re.M)
+    return sorted(set(n for n in names if n.startswith(("tgpu_", "tetra_"))))
+
+
+def lib():
+    """load libtetra_gpu.so; raises if it has not been built (no silent fallback)"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TgpuError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    L.tgpu_strerror.restype = C.c_char_p
+    L.tgpu_strerror.argtypes = [C.c_int]
+    L.tgpu_engine_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.tgpu_engine_destroy.argtypes = [C.c_void_p]
+    L.tgpu_plan_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.tgpu_plan_destroy.argtypes = [C.c_void_p]
+    L.tgpu_plan_load.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p, C.c_uint32, u32p]
+    L.tgpu_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tgpu_plan_final_codes.argtypes = [C.c_void_p, C.c_void_p, u32p]
+    L.tgpu_prof_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
+    L.tgpu_prof_destroy.argtypes = [C.c_void_p]
+    L.tgpu_plan_execute_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.tgpu_prof_read.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+    L.tgpu_stage_name.restype = C.c_char_p
+    L.tgpu_stage_name.argtypes = [C.c_int]
+    L.tgpu_record_blocks.argtypes = [u8p, C.POINTER(Block)]
+    L.tgpu_record_sync_info.argtypes = [u8p, C.POINTER(SyncInfo)]
+    L.tgpu_channel_create.argtypes = [C.c_void_p, C.c_uint32, UNITDATA_CB, EVENT_CB, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.tgpu_channel_destroy.argtypes = [C.c_void_p]
+    L.tgpu_channel_bind_flags.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_bool), C.POINTER(C.c_bool)]
+    L.tgpu_channel_set_traffic.argtypes = [C.c_void_p, C.c_int]
+    L.tgpu_channel_set_blk2_stolen.argtypes = [C.c_void_p, C.c_bool]
+    L.tgpu_channel_flush.argtypes = [C.c_void_p]
+    L.tetra_burst_sync_in.argtypes = [C.POINTER(RxState), u8p, C.c_uint]
+    L.tetra_find_train_seq.argtypes = [u8p, C.c_uint, C.c_uint32, C.POINTER(C.c_uint)]
+    L.tetra_tdma_time_add_tn.argtypes = [C.POINTER(TdmaTime), C.c_uint32]
+    L.tetra_scramb_get_init.restype = C.c_uint32
+    L.tetra_scramb_get_init.argtypes = [C.c_uint16, C.c_uint16, C.c_uint8]
+    L.tgpu_synth_slots.argtypes = [C.POINTER(SynthCfg), u8p, C.c_size_t, u8p, u8p]
+    _lib = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise TgpuError(f"{what}: {lib().tgpu_strerror(rc).decode()} ({rc})")
+
+
+def _np_u8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _chk(lib().tgpu_engine_create(C.byref(self._h), device), "tgpu_engine_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().tgpu_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class Plan:
+    """batch of slots -> records, device resident (tgpu_plan_*)"""
+
+    def __init__(self, engine, max_slots, max_chan=1):
+        self.engine = engine
+        self._h = C.c_void_p()
+        _chk(lib().tgpu_plan_create(engine._h, max_slots, max_chan, C.byref(self._h)), "tgpu_plan_create")
+        self.nslots = 0
+        self.nchan = 0
+
+    def load(self, slot_off, slot_type, slot_chan=None, chan_code=None):
+        off = np.ascontiguousarray(slot_off, np.uint64)
+        typ = _np_u8(slot_type)
+        n = len(typ)
+        chan = np.zeros(n, np.uint32) if slot_chan is None else np.ascontiguousarray(slot_chan, np.uint32)
+        nchan = int(chan.max()) + 1 if n else 1
+        codes = np.zeros(nchan, np.uint32) if chan_code is None else np.ascontiguousarray(chan_code, np.uint32)
+        nchan = max(nchan, len(codes))
+        assert len(off) == n and len(chan) == n and len(codes) == nchan
+        _chk(lib().tgpu_plan_load(self._h, n, off.ctypes.data_as(u64p), typ.ctypes.data_as(u8p),
+                                  chan.ctypes.data_as(u32p), nchan, codes.ctypes.data_as(u32p)), "tgpu_plan_load")
+        self.nslots, self.nchan = n, nchan
+
+    def execute(self, d_stream_ptr, d_rec_ptr, hip_stream=0):
+        _chk(lib().tgpu_plan_execute(self._h, C.c_void_p(d_stream_ptr), C.c_void_p(d_rec_ptr),
+                                     C.c_void_p(hip_stream)), "tgpu_plan_execute")
+
+    def execute_prof(self, d_stream_ptr, d_rec_ptr, hip_stream, prof, step):
+        _chk(lib().tgpu_plan_execute_prof(self._h, C.c_void_p(d_stream_ptr), C.c_void_p(d_rec_ptr),
+                                          C.c_void_p(hip_stream), prof._h, step), "tgpu_plan_execute_prof")
+
+    def final_codes(self, d_rec_ptr=0):
+        out = np.zeros(self.nchan, np.uint32)
+        _chk(lib().tgpu_plan_final_codes(self._h, C.c_void_p(d_rec_ptr), out.ctypes.data_as(u32p)),
+             "tgpu_plan_final_codes")
+        return out
+
+    def close(self):
+        if self._h:
+            lib().tgpu_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+NSTAGES = 6
+
+
+class Prof:
+    """per-stage HIP-event timing of Plan.execute_prof() (tgpu_prof_*)"""
+
+    def __init__(self, max_steps):
+        self._h = C.c_void_p()
+        self.max_steps = max_steps
+        _chk(lib().tgpu_prof_create(max_steps, C.byref(self._h)), "tgpu_prof_create")
+
+    def read(self, nsteps):
+        ms = np.zeros((nsteps, NSTAGES), np.float32)
+        _chk(lib().tgpu_prof_read(self._h, nsteps, ms.ctypes.data_as(C.POINTER(C.c_float))), "tgpu_prof_read")
+        return ms
+
+    @staticmethod
+    def stage_names():
+        return [lib().tgpu_stage_name(i).decode() for i in range(NSTAGES)]
+
+    def close(self):
+        if self._h:
+            lib().tgpu_prof_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def parse_records(rec):
+    """(n,320) uint8 host array -> dict of numpy views (layout: csrc/tg_layout.h)"""
+    rec = np.ascontiguousarray(rec, np.uint8).reshape(-1, REC_BYTES)
+    return dict(
+        type=rec[:, 0], flags=rec[:, 1], crc_ok=rec[:, 2:4],
+        crc=rec[:, 4:8].copy().view(np.uint16).reshape(-1, 2),
+        code=rec[:, 8:12].copy().view(np.uint32).reshape(-1),
+        slot=rec[:, 12:16].copy().view(np.uint32).reshape(-1),
+        sbf0=rec[:, 16:20].copy().view(np.uint32).reshape(-1),
+        sbf1=rec[:, 20:24].copy().view(np.uint32).reshape(-1),
+        sbcode=rec[:, 24:28].copy().view(np.uint32).reshape(-1),
+        bbk=rec[:, 32:46], bits1=rec[:, 48:316], bits2=rec[:, 176:300],
+    )
+
+
+def record_blocks(rec_row):
+    """one 320-byte record -> list of dicts in tetra_burst_rx_cb() call order (tgpu_record_blocks)"""
+    r = _np_u8(rec_row)
+    blk = (Block * 3)()
+    n = lib().tgpu_record_blocks(r.ctypes.data_as(u8p), blk)
+    out = []
+    for i in range(n):
+        b = blk[i]
+        out.append(dict(type=b.type, blk_num=b.blk_num, crc_ok=b.crc_ok, crc=b.crc, scramb=b.scrambling_code,
+                        type1=bytes(bytearray(b.type1[: b.type1_len]))))
+    return out
+
+
+def find_train_seq(buf, end, mask):
+    buf = _np_u8(buf)
+    assert len(buf) >= end + 22
+    off = C.c_uint(0)
+    rc = lib().tetra_find_train_seq(buf.ctypes.data_as(u8p), end, mask, C.byref(off))
+    return rc, off.value
+
+
+def synth_slots(types, seed=1, scramb_init=0, mcc=262, mnc=42, cc=1, ber=0.0, null_pdu_header=True, want_type1=False):
+    types = _np_u8(types)
+    n = len(types)
+    out = np.zeros((n, SLOT_BYTES), np.uint8)
+    t1 = np.zeros((n, 288), np.uint8) if want_type1 else None
+    cfg = SynthCfg(seed, scramb_init, mcc, mnc, cc, ber, int(null_pdu_header))
+    _chk(lib().tgpu_synth_slots(C.byref(cfg), types.ctypes.data_as(u8p), n, out.ctypes.data_as(u8p),
+                                t1.ctypes.data_as(u8p) if want_type1 else None), "tgpu_synth_slots")
+    return (out, t1) if want_type1 else out
+
+
+class Channel:
+    """tgpu_channel + tetra_burst_sync_in(): host bytes in, upper-MAC style callbacks out"""
+
+    def __init__(self, engine, batch_slots=64, on_unitdata=None, on_event=None):
+        self.engine = engine
+        self.records, self.events = [], []
+        self._user_cb = on_unitdata
+
+        def _cb(udp, offset, priv):
+            ud = udp.contents
+            if offset in (0, 0xFFFFFFFF):
+                d = dict(burst_seq=ud.burst_seq, burst_type=ud.burst_type, type=ud.type, blk_num=ud.blk_num,
+                         lchan=ud.lchan, crc_ok=ud.crc_ok, traffic=ud.traffic, crc=ud.crc,
+                         scramb=ud.scrambling_code, time=(ud.tdma_time.tn, ud.tdma_time.fn, ud.tdma_time.mn))
+                if ud.traffic:
+                    d["type1"] = b""
+                    d["type4"] = bytes(bytearray(ud.type4[: ud.type4_len]))
+                else:
+                    d["type1"] = bytes(bytearray(ud.type1[: ud.type1_len]))
+                self.records.append(d)
+            else:
+                d = self.records[-1]
+            if offset == 0xFFFFFFFF:
+                return -1
+            if self._user_cb is not None:
+                return int(self._user_cb(self, d, offset))
+            return -1
+
+        def _ev(ev, bitnum, arg, priv):
+            self.events.append((ev, bitnum, arg))
+            if on_event is not None:
+                on_event(ev, bitnum, arg)
+
+        self._cb, self._ev = UNITDATA_CB(_cb), EVENT_CB(_ev)
+        self._h = C.c_void_p()
+        _chk(lib().tgpu_channel_create(engine._h, batch_slots, self._cb, self._ev, None, C.byref(self._h)),
+             "tgpu_channel_create")
+        self.trs = RxState()
+        self.trs.burst_cb_priv = self._h
+
+    def set_traffic(self, v):
+        lib().tgpu_channel_set_traffic(self._h, int(v))
+
+    def set_blk2_stolen(self, v):
+        lib().tgpu_channel_set_blk2_stolen(self._h, bool(v))
+
+    def feed(self, stream, chunk=64):
+        """like tetra-rx.c:82-95: read 64 bytes, tetra_burst_sync_in()"""
+        stream = _np_u8(stream)
+        L = lib()
+        base = stream.ctypes.data
+        for o in range(0, len(stream), chunk):
+            n = min(chunk, len(stream) - o)
+            L.tetra_burst_sync_in(C.byref(self.trs), C.cast(base + o, u8p), n)
+
+    def flush(self):
+        _chk(lib().tgpu_channel_flush(self._h), "tgpu_channel_flush")
+
+    def close(self):
+        if self._h:
+            lib().tgpu_channel_destroy(self._h)
+            self._h = C.c_void_p()

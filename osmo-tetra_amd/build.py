@@ -1,0 +1,59 @@
+"""Build recipe for libtetra_gpu.so (HIP kernels for gfx950 + the C host code).
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container; the
+resulting .so stays in-tree (git-ignored) and travels to the GPU box with the snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libtetra_gpu.so")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+HIP_SRCS = ["tg_kernels.hip"]
+C_SRCS = ["tg_host.c", "tg_sync.c", "tg_synth.c"]
+HEADERS = ["tg_layout.h", "vit_core.h", "tg_internal.h", os.path.join(ROOT, "include", "tetra_gpu.h")]
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force=False, verbose=False):
+    hipcc = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
+    srcs = [os.path.join(CSRC, s) for s in HIP_SRCS + C_SRCS]
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _newer(srcs + hdrs + [os.path.abspath(__file__)], LIB):
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + os.path.join(ROCM, "include")]
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    for s in HIP_SRCS:
+        o = os.path.join(OBJ, s + ".o")
+        run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"] + inc +
+            ["-c", os.path.join(CSRC, s), "-o", o])
+        objs.append(o)
+    for s in C_SRCS:
+        o = os.path.join(OBJ, s + ".o")
+        run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"] + inc +
+            ["-c", os.path.join(CSRC, s), "-o", o])
+        objs.append(o)
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lpthread"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

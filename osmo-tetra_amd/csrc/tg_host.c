@@ -1,0 +1,409 @@
+/*
+ * tg_host.c -- engine and plan objects: device memory, batch descriptors and the launch
+ * sequence of the device pipeline.  Plain C on top of the HIP runtime API.
+ *
+ * Launch sequence of tgpu_plan_execute() (all on the caller's stream, no host sync):
+ *   k_front                      every slot  -> packed code words
+ *   k_vit<SB1>                   SYNC slots  -> SB1 type-1 bits, CRC, SYNC-PDU fields, new code
+ *   k_fill_{reduce,scan,apply}   forward-fill of the scrambling code (mask entry per slot)
+ *   k_masks                      scrambling masks for every code in play
+ *   k_vit<216>, k_vit<432>       all remaining blocks + BBK + record headers
+ * This order is feedback loop 1 of SURVEY.md 3.3: SB1 is descrambled with the fixed
+ * code 3, and a CRC-OK SB1 sets the code for everything after it, starting with the
+ * BBK and SB2 of the same burst (lower_mac/tetra_lower_mac.c:179-186, 291-300).
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "tetra_gpu.h"
+#include "tg_layout.h"
+#include "tg_internal.h"
+
+struct tgpu_engine {
+	int device;
+};
+
+struct tgpu_plan {
+	struct tgpu_engine *eng;
+	uint32_t max_slots, max_chan;
+	uint32_t nslots, nchan, nsb, n216, n432;
+	int loaded;
+	/* device */
+	uint64_t *d_slot_off;
+	uint8_t *d_slot_type;
+	uint32_t *d_slot_chan;
+	int32_t *d_slot_sbord;
+	uint32_t *d_list_sb, *d_list_216, *d_list_432;
+	uint32_t *d_packed;
+	uint32_t *d_maskidx;
+	uint32_t *d_masks;
+	uint32_t *d_chan_code;
+	uint32_t *d_sb_ok, *d_sb_code;
+	unsigned long long *d_block_tmp;
+	/* host staging */
+	int32_t *h_sbord;
+	uint32_t *h_list_sb, *h_list_216, *h_list_432;
+	uint32_t *h_last_slot_of_chan;
+};
+
+const char *tgpu_strerror(int err)
+{
+	switch (err) {
+	case TGPU_OK: return "ok";
+	case TGPU_EINVAL: return "invalid argument";
+	case TGPU_ENOMEM: return "out of memory";
+	case TGPU_ENODEV: return "no usable GPU (this library has no CPU fallback)";
+	case TGPU_ECAPACITY: return "batch exceeds plan capacity";
+	case TGPU_ESTATE: return "call order violated";
+	default: break;
+	}
+	if (err > 0)
+		return hipGetErrorString((hipError_t)err);
+	return "unknown error";
+}
+
+int tgpu_engine_create(struct tgpu_engine **out, int device)
+{
+	int n = 0;
+	if (!out)
+		return TGPU_EINVAL;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+		return TGPU_ENODEV;
+	hipError_t e = hipSetDevice(device);
+	if (e != hipSuccess)
+		return (int)e;
+	int rc = tgk_init();
+	if (rc)
+		return rc;
+	struct tgpu_engine *eng = calloc(1, sizeof(*eng));
+	if (!eng)
+		return TGPU_ENOMEM;
+	eng->device = device;
+	*out = eng;
+	return TGPU_OK;
+}
+
+void tgpu_engine_destroy(struct tgpu_engine *eng)
+{
+	free(eng);
+}
+
+#define DALLOC(ptr, bytes) do { size_t b_ = (bytes); hipError_t e_ = hipMalloc((void **)&(ptr), b_ ? b_ : 16); \
+	if (e_ != hipSuccess) { tgpu_plan_destroy(p); return (int)e_; } } while (0)
+
+int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_chan, struct tgpu_plan **out)
+{
+	if (!eng || !out || !max_slots || !max_chan)
+		return TGPU_EINVAL;
+	struct tgpu_plan *p = calloc(1, sizeof(*p));
+	if (!p)
+		return TGPU_ENOMEM;
+	p->eng = eng;
+	p->max_slots = max_slots;
+	p->max_chan = max_chan;
+	const size_t n = max_slots;
+	DALLOC(p->d_slot_off, n * sizeof(uint64_t));
+	DALLOC(p->d_slot_type, n);
+	DALLOC(p->d_slot_chan, n * 4);
+	DALLOC(p->d_slot_sbord, n * 4);
+	DALLOC(p->d_list_sb, n * 4);
+	DALLOC(p->d_list_216, 2 * n * 4);
+	DALLOC(p->d_list_432, n * 4);
+	DALLOC(p->d_packed, n * TG_PACKED_WORDS * 4);
+	DALLOC(p->d_maskidx, n * 4);
+	DALLOC(p->d_masks, (1 + (size_t)max_chan + n) * TG_MASK_WORDS * 4);
+	DALLOC(p->d_chan_code, (size_t)max_chan * 4);
+	DALLOC(p->d_sb_ok, n * 4);
+	DALLOC(p->d_sb_code, n * 4);
+	DALLOC(p->d_block_tmp, ((n + 1023) / 1024 + 1) * sizeof(unsigned long long));
+	p->h_sbord = malloc(n * 4);
+	p->h_list_sb = malloc(n * 4);
+	p->h_list_216 = malloc(2 * n * 4);
+	p->h_list_432 = malloc(n * 4);
+	p->h_last_slot_of_chan = malloc((size_t)max_chan * 4);
+	if (!p->h_sbord || !p->h_list_sb || !p->h_list_216 || !p->h_list_432 || !p->h_last_slot_of_chan) {
+		tgpu_plan_destroy(p);
+		return TGPU_ENOMEM;
+	}
+	*out = p;
+	return TGPU_OK;
+}
+
+void tgpu_plan_destroy(struct tgpu_plan *p)
+{
+	if (!p)
+		return;
+	void *d[] = { p->d_slot_off, p->d_slot_type, p->d_slot_chan, p->d_slot_sbord, p->d_list_sb, p->d_list_216,
+		      p->d_list_432, p->d_packed, p->d_maskidx, p->d_masks, p->d_chan_code, p->d_sb_ok, p->d_sb_code,
+		      p->d_block_tmp };
+	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
+		if (d[i])
+			(void)hipFree(d[i]);
+	free(p->h_sbord);
+	free(p->h_list_sb);
+	free(p->h_list_216);
+	free(p->h_list_432);
+	free(p->h_last_slot_of_chan);
+	free(p);
+}
+
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_off, const uint8_t *slot_type,
+		   const uint32_t *slot_chan, uint32_t nchan, const uint32_t *chan_code)
+{
+	if (!p || (nslots && (!slot_off || !slot_type || !slot_chan)) || !nchan || !chan_code)
+		return TGPU_EINVAL;
+	if (nslots > p->max_slots || nchan > p->max_chan)
+		return TGPU_ECAPACITY;
+	uint32_t nsb = 0, n216 = 0, n432 = 0, prev = 0;
+	for (uint32_t c = 0; c < nchan; c++)
+		p->h_last_slot_of_chan[c] = 0xffffffffu;
+	for (uint32_t i = 0; i < nslots; i++) {
+		if (slot_chan[i] >= nchan || slot_chan[i] < prev)
+			return TGPU_EINVAL;
+		prev = slot_chan[i];
+		p->h_last_slot_of_chan[prev] = i;
+		p->h_sbord[i] = -1;
+		switch (slot_type[i]) {
+		case TETRA_TRAIN_SYNC:
+			p->h_sbord[i] = (int32_t)nsb;
+			p->h_list_sb[nsb++] = i;
+			p->h_list_216[n216++] = (i << 1) | 1;	/* SB2 */
+			break;
+		case TETRA_TRAIN_NORM_2:
+			p->h_list_216[n216++] = (i << 1);
+			p->h_list_216[n216++] = (i << 1) | 1;
+			break;
+		case TETRA_TRAIN_NORM_1:
+			p->h_list_432[n432++] = i;
+			break;
+		default:
+			break;
+		}
+	}
+	if (nslots) {
+		HCHK(hipMemcpy(p->d_slot_off, slot_off, (size_t)nslots * 8, hipMemcpyHostToDevice));
+		HCHK(hipMemcpy(p->d_slot_type, slot_type, nslots, hipMemcpyHostToDevice));
+		HCHK(hipMemcpy(p->d_slot_chan, slot_chan, (size_t)nslots * 4, hipMemcpyHostToDevice));
+		HCHK(hipMemcpy(p->d_slot_sbord, p->h_sbord, (size_t)nslots * 4, hipMemcpyHostToDevice));
+	}
+	if (nsb)
+		HCHK(hipMemcpy(p->d_list_sb, p->h_list_sb, (size_t)nsb * 4, hipMemcpyHostToDevice));
+	if (n216)
+		HCHK(hipMemcpy(p->d_list_216, p->h_list_216, (size_t)n216 * 4, hipMemcpyHostToDevice));
+	if (n432)
+		HCHK(hipMemcpy(p->d_list_432, p->h_list_432, (size_t)n432 * 4, hipMemcpyHostToDevice));
+	HCHK(hipMemcpy(p->d_chan_code, chan_code, (size_t)nchan * 4, hipMemcpyHostToDevice));
+	p->nslots = nslots;
+	p->nchan = nchan;
+	p->nsb = nsb;
+	p->n216 = n216;
+	p->n432 = n432;
+	p->loaded = 1;
+	return TGPU_OK;
+}
+
+struct tgpu_prof {
+	uint32_t max_steps;
+	hipEvent_t *ev;		/* (TGPU_NSTAGES + 1) per step */
+};
+
+int tgpu_prof_create(uint32_t max_steps, struct tgpu_prof **out)
+{
+	if (!out || !max_steps)
+		return TGPU_EINVAL;
+	struct tgpu_prof *pr = calloc(1, sizeof(*pr));
+	if (!pr)
+		return TGPU_ENOMEM;
+	pr->max_steps = max_steps;
+	const size_t n = (size_t)max_steps * (TGPU_NSTAGES + 1);
+	pr->ev = calloc(n, sizeof(hipEvent_t));
+	if (!pr->ev) {
+		free(pr);
+		return TGPU_ENOMEM;
+	}
+	for (size_t i = 0; i < n; i++) {
+		hipError_t e = hipEventCreate(&pr->ev[i]);
+		if (e != hipSuccess) {
+			tgpu_prof_destroy(pr);
+			return (int)e;
+		}
+	}
+	*out = pr;
+	return TGPU_OK;
+}
+
+void tgpu_prof_destroy(struct tgpu_prof *pr)
+{
+	if (!pr)
+		return;
+	if (pr->ev) {
+		const size_t n = (size_t)pr->max_steps * (TGPU_NSTAGES + 1);
+		for (size_t i = 0; i < n; i++)
+			if (pr->ev[i])
+				(void)hipEventDestroy(pr->ev[i]);
+		free(pr->ev);
+	}
+	free(pr);
+}
+
+const char *tgpu_stage_name(int stage)
+{
+	static const char *const names[TGPU_NSTAGES] = { "k_front", "k_vit<SB1>", "k_fill", "k_masks", "k_vit<216>", "k_vit<432>" };
+	return (stage >= 0 && stage < TGPU_NSTAGES) ? names[stage] : "?";
+}
+
+static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream, hipEvent_t *ev)
+{
+	int rc;
+#define MARK(i) do { if (ev) { hipError_t e_ = hipEventRecord(ev[i], (hipStream_t)stream); if (e_ != hipSuccess) return (int)e_; } } while (0)
+	if (!p || !d_stream || !d_rec)
+		return TGPU_EINVAL;
+	if (!p->loaded)
+		return TGPU_ESTATE;
+	MARK(0);
+	if (p->nslots) {
+		if ((rc = tgk_front(d_stream, p->d_slot_off, p->d_slot_type, p->nslots, p->d_packed, d_rec, stream)))
+			return rc;
+	}
+	MARK(1);
+	if (p->nslots) {
+		if ((rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, p->nsb, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
+				  p->d_sb_ok, p->d_sb_code, stream)))
+			return rc;
+	}
+	MARK(2);
+	if (p->nslots) {
+		if ((rc = tgk_fill(p->d_slot_chan, p->d_slot_sbord, p->d_sb_ok, p->nchan, p->nslots, p->d_block_tmp,
+				   p->d_maskidx, stream)))
+			return rc;
+	}
+	MARK(3);
+	if (p->nslots) {
+		if ((rc = tgk_masks(p->d_chan_code, p->nchan, p->d_sb_ok, p->d_sb_code, p->nsb, p->d_masks, stream)))
+			return rc;
+	}
+	MARK(4);
+	if (p->nslots) {
+		if ((rc = tgk_vit(TG_KIND_216, p->d_list_216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
+				  p->d_sb_ok, p->d_sb_code, stream)))
+			return rc;
+	}
+	MARK(5);
+	if (p->nslots) {
+		if ((rc = tgk_vit(TG_KIND_432, p->d_list_432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
+				  p->d_sb_ok, p->d_sb_code, stream)))
+			return rc;
+	}
+	MARK(6);
+#undef MARK
+	return TGPU_OK;
+}
+
+int tgpu_plan_execute(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream)
+{
+	return plan_run(p, d_stream, d_rec, stream, NULL);
+}
+
+int tgpu_plan_execute_prof(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream,
+			   struct tgpu_prof *prof, uint32_t step)
+{
+	if (!prof || step >= prof->max_steps)
+		return TGPU_EINVAL;
+	return plan_run(p, d_stream, d_rec, stream, prof->ev + (size_t)step * (TGPU_NSTAGES + 1));
+}
+
+int tgpu_prof_read(struct tgpu_prof *prof, uint32_t nsteps, float *ms)
+{
+	if (!prof || !ms || nsteps > prof->max_steps)
+		return TGPU_EINVAL;
+	for (uint32_t s = 0; s < nsteps; s++) {
+		hipEvent_t *ev = prof->ev + (size_t)s * (TGPU_NSTAGES + 1);
+		HCHK(hipEventSynchronize(ev[TGPU_NSTAGES]));
+		for (int k = 0; k < TGPU_NSTAGES; k++)
+			HCHK(hipEventElapsedTime(&ms[(size_t)s * TGPU_NSTAGES + k], ev[k], ev[k + 1]));
+	}
+	return TGPU_OK;
+}
+
+int tgpu_plan_final_codes(struct tgpu_plan *p, const uint8_t *d_rec, uint32_t *chan_code_out)
+{
+	if (!p || !chan_code_out || !p->loaded)
+		return TGPU_EINVAL;
+	(void)d_rec;
+	/* code in effect after the batch = mask entry of the channel's last slot */
+	HCHK(hipDeviceSynchronize());
+	for (uint32_t c = 0; c < p->nchan; c++) {
+		uint32_t last = p->h_last_slot_of_chan[c], idx, code;
+		if (last == 0xffffffffu) {
+			HCHK(hipMemcpy(&code, p->d_chan_code + c, 4, hipMemcpyDeviceToHost));
+		} else {
+			HCHK(hipMemcpy(&idx, p->d_maskidx + last, 4, hipMemcpyDeviceToHost));
+			HCHK(hipMemcpy(&code, p->d_masks + (size_t)idx * TG_MASK_WORDS + TG_MW_CODE, 4, hipMemcpyDeviceToHost));
+		}
+		chan_code_out[c] = code;
+	}
+	return TGPU_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* record parsing (host)                                                      */
+/* ------------------------------------------------------------------------- */
+static void fill_block(struct tgpu_block *b, const uint8_t *rec, enum tp_sap_data_type t, int blk_num, int which,
+		       uint16_t n1, uint32_t code)
+{
+	b->type = t;
+	b->blk_num = blk_num;
+	b->crc_ok = rec[TG_REC_CRC_OK + which];
+	memcpy(&b->crc, rec + TG_REC_CRC + 2 * which, 2);
+	b->scrambling_code = code;
+	b->type1_len = n1;
+	b->type1 = rec + (which ? TG_REC_BITS2 : TG_REC_BITS1);
+}
+
+int tgpu_record_blocks(const uint8_t *rec, struct tgpu_block out[3])
+{
+	uint32_t code;
+	memcpy(&code, rec + TG_REC_CODE, 4);
+	struct tgpu_block bbk = { TPSAP_T_BBK, 0, 1, 0, code, 14, rec + TG_REC_BBK };	/* crc_ok=1: tetra_lower_mac.c:270 */
+	switch (rec[TG_REC_TYPE]) {
+	case TETRA_TRAIN_SYNC:		/* phy/tetra_burst.c:350-352 */
+		fill_block(&out[0], rec, TPSAP_T_SB1, BLK_1, 0, 60, SCRAMB_INIT);
+		out[1] = bbk;
+		fill_block(&out[2], rec, TPSAP_T_SB2, BLK_2, 1, 124, code);
+		return 3;
+	case TETRA_TRAIN_NORM_2:	/* :359-361 */
+		out[0] = bbk;
+		fill_block(&out[1], rec, TPSAP_T_NDB, BLK_1, 0, 124, code);
+		fill_block(&out[2], rec, TPSAP_T_NDB, BLK_2, 1, 124, code);
+		return 3;
+	case TETRA_TRAIN_NORM_1:	/* :371-372 */
+		out[0] = bbk;
+		fill_block(&out[1], rec, TPSAP_T_SCH_F, 0, 0, 268, code);
+		return 2;
+	default:
+		return 0;
+	}
+}
+
+int tgpu_record_sync_info(const uint8_t *rec, struct tgpu_sync_info *out)
+{
+	if (!rec || !out || rec[TG_REC_TYPE] != TETRA_TRAIN_SYNC)
+		return TGPU_EINVAL;
+	uint32_t f0, f1, code;
+	memcpy(&f0, rec + TG_REC_SBF0, 4);
+	memcpy(&f1, rec + TG_REC_SBF1, 4);
+	memcpy(&code, rec + TG_REC_SBCODE, 4);
+	out->cc = (uint8_t)f0;
+	out->tn = (uint8_t)(f0 >> 8);
+	out->fn = (uint8_t)(f0 >> 16);
+	out->mn = (uint8_t)(f0 >> 24);
+	out->mcc = (uint16_t)f1;
+	out->mnc = (uint16_t)(f1 >> 16);
+	out->scramb_init = code;
+	return TGPU_OK;
+}

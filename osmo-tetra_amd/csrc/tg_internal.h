@@ -1,0 +1,25 @@
+/* tg_internal.h -- launch layer between the C host code and tg_kernels.hip */
+#ifndef TG_INTERNAL_H
+#define TG_INTERNAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int tgk_init(void);
+int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_off, const uint8_t *d_slot_type,
+	      uint32_t nslots, uint32_t *d_packed, uint8_t *d_rec, void *stream);
+int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
+	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
+	    uint32_t *d_sb_ok, uint32_t *d_sb_code, void *stream);
+int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uint32_t *d_sb_ok,
+	     uint32_t nchan, uint32_t nslots, unsigned long long *d_block_tmp, uint32_t *d_maskidx, void *stream);
+int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
+	      const uint32_t *d_sb_code, uint32_t nsb, uint32_t *d_masks, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

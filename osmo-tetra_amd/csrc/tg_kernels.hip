@@ -1,0 +1,538 @@
+/*
+ * tg_kernels.hip -- the HIP kernels of the TETRA lower-MAC receive path (gfx950).
+ *
+ *   k_front   : slot bytes -> packed, de-interleaved code words   (rows D, I, U of SURVEY 8(a))
+ *   k_vit<>   : descramble + Viterbi + CRC-16 + type-1 output      (rows X, V, C, R, L)
+ *   k_fill_*  : forward-fill of the cell scrambling code           (row L, feedback loop 1)
+ *   k_masks   : scrambling sequence -> masks in code-word layout   (row X)
+ *
+ * No MFMA anywhere: there is no dense contraction on this path.  The trellis kernels
+ * are VALU-bound packed-u16 integer work (one lane per trellis), the front kernel is a
+ * byte gather bounded by HBM.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "tg_layout.h"
+#include "vit_core.h"
+#include "tg_internal.h"
+
+/* ------------------------------------------------------------------------- */
+/* constant tables (uploaded once per process by tgk_init)                   */
+/* ------------------------------------------------------------------------- */
+struct tg_const_tables {
+	uint16_t front_src[3][TG_PACKED_WORDS][32];	/* [NORM_1, NORM_2, SYNC][word][bit] -> slot byte offset */
+	uint16_t mask_pos[TG_MASK_WORDS][32];		/* [mask word][bit] -> position in the LFSR sequence */
+	uint32_t lfsr_lin[432];				/* seq[n] = parity(init & lfsr_lin[n]) */
+	uint32_t sb1_mask[5];				/* SB1 is always scrambled with init 3 */
+	uint16_t crc_lsb[256];
+	uint16_t crc_msb[256];
+};
+
+__constant__ tg_const_tables c_tab;
+
+/* ------------------------------------------------------------------------- */
+/* k_front                                                                   */
+/* ------------------------------------------------------------------------- */
+/*
+ * One wavefront per slot.  Ten gather rounds; in each, lanes 0..31 produce one
+ * packed word and lanes 32..63 the next (one stream byte per lane, collapsed with a
+ * 64-bit ballot).  The 510 slot bytes are fetched from HBM once (4-5 cache lines) and
+ * every further touch is an L1/L2 hit; the 80-byte result goes out as one store.
+ */
+__global__ __launch_bounds__(256)
+void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_off,
+	     const uint8_t *__restrict__ slot_type, uint32_t nslots, uint32_t *__restrict__ packed,
+	     uint8_t *__restrict__ rec)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t half = lane >> 5, bit = lane & 31;
+
+	for (uint32_t slot = wave; slot < nslots; slot += nwaves) {
+		const uint32_t type = __builtin_amdgcn_readfirstlane(slot_type[slot]);
+		uint32_t myword = 0;
+		uint32_t flags = 0;
+		if (type == TG_BURST_NORM_1 || type == TG_BURST_NORM_2 || type == TG_BURST_SYNC) {
+			const uint32_t tix = (type == TG_BURST_SYNC) ? 2 : type;
+			const uint8_t *base = stream + slot_off[slot];
+			uint32_t bytes[10];
+#pragma unroll
+			for (int r = 0; r < 10; r++) {
+				const uint16_t off = c_tab.front_src[tix][2 * r + half][bit];
+				bytes[r] = (off != 0xffff) ? (uint32_t)base[off] : 0u;
+			}
+			uint32_t nonbin = 0;
+#pragma unroll
+			for (int r = 0; r < 10; r++) {
+				const unsigned long long bal = __ballot(bytes[r] & 1);
+				nonbin |= (bytes[r] > 1);
+				myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
+				myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
+			}
+			if (__ballot(nonbin))
+				flags |= TG_FLAG_NONBINARY;
+		} else if (lane == 0) {
+			/* not a burst we decode (NORM_3 / EXT are ignored like phy/tetra_burst.c:374-377):
+			 * no trellis lane will touch this record, mark it */
+			rec[(size_t)slot * TG_REC_BYTES + TG_REC_TYPE] = TG_BURST_NONE;
+		}
+		if (lane == TG_PW_META) {
+			const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
+			myword = type | (flags << 8) | (toff << 16);
+		}
+		if (lane < TG_PACKED_WORDS)
+			packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
+	}
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_vit<KIND>                                                               */
+/* ------------------------------------------------------------------------- */
+template <int KIND> struct vit_cfg;
+template <> struct vit_cfg<TG_KIND_SB1> { enum { NBLK = 10, TYPE1 = 60, MW = 0 }; };
+template <> struct vit_cfg<TG_KIND_216> { enum { NBLK = 18, TYPE1 = 124, MW = TG_MW_216 }; };
+template <> struct vit_cfg<TG_KIND_432> { enum { NBLK = 36, TYPE1 = 268, MW = TG_MW_432 }; };
+
+__device__ __forceinline__ uint32_t spread4(uint32_t nib)
+{
+	/* 4 bits -> 4 bytes of 0/1 (bit 0 -> byte 0) */
+	return ((nib & 15u) * 0x00204081u) & 0x01010101u;
+}
+
+/* MSB-first value of 'len' consecutive decoded bits starting at bit n0 (bits are held
+ * LSB-first in od[]): the reference's bits_to_uint(type2 + n0, len), tetra_common.c:31-39 */
+__device__ __forceinline__ uint32_t field_msb(uint32_t lo, uint32_t hi, int sh, int len)
+{
+	const unsigned long long two = (unsigned long long)lo | ((unsigned long long)hi << 32);
+	const uint32_t f = (uint32_t)(two >> sh) & ((1u << len) - 1);
+	return __builtin_bitreverse32(f) >> (32 - len);
+}
+#define FIELD_MSB(od, n0, len) field_msb((od)[(n0) >> 5], (od)[((n0) >> 5) + 1], (n0) & 31, (len))
+
+template <int KIND>
+__global__ __launch_bounds__(64)
+void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
+	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
+	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
+	   uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code)
+{
+	constexpr int NBLK = vit_cfg<KIND>::NBLK;
+	constexpr int NW = NBLK / 2;			/* code words */
+	constexpr int TYPE1 = vit_cfg<KIND>::TYPE1;
+	constexpr int NOD = (NBLK + 3) / 4;		/* dwords of decoded bits */
+
+	__shared__ uint4 hist[NBLK * 64];
+	__shared__ uint16_t s_crc[512];
+
+	const uint32_t lane = threadIdx.x;
+	for (int i = lane; i < 256; i += 64) {
+		s_crc[i] = c_tab.crc_lsb[i];
+		s_crc[256 + i] = c_tab.crc_msb[i];
+	}
+
+	uint32_t idx = blockIdx.x * 64 + lane;
+	const bool valid = idx < nitems;
+	if (!valid)
+		idx = nitems - 1;
+
+	/* item: SB1 kernel -> position in the SYNC-slot list (items[] = slot ids);
+	 *       216 kernel -> slot<<1 | which;  432 kernel -> slot id */
+	uint32_t slot, which;
+	if (KIND == TG_KIND_216) {
+		const uint32_t it = items[idx];
+		slot = it >> 1;
+		which = it & 1;
+	} else {
+		slot = items[idx];
+		which = 0;
+	}
+
+	const uint32_t *pw = packed + (size_t)slot * TG_PACKED_WORDS + (which ? TG_PW_BLK2 : TG_PW_BLK1);
+	const uint32_t *mw;
+	uint32_t midx = 0;
+	if (KIND == TG_KIND_SB1) {
+		mw = c_tab.sb1_mask;
+	} else {
+		midx = maskidx[slot];
+		mw = masks + (size_t)midx * TG_MASK_WORDS + vit_cfg<KIND>::MW;
+	}
+
+	tg_vit_state v;
+	tg_vit_init(v);
+	uint32_t cur = pw[0] ^ mw[0];
+	tg_vit_leadin(v, cur >> 24);
+
+#pragma unroll 1
+	for (int it = 0; it < NW - 1; it++) {
+		const uint32_t nxt = pw[it + 1] ^ mw[it + 1];
+		uint32_t h[4];
+		tg_vit_block<false>(v, cur, h);
+		hist[(2 * it) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
+		tg_vit_block<false>(v, cur >> 12, h);
+		hist[(2 * it + 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
+		if (KIND == TG_KIND_432 && it == 8)
+			tg_vit_normalize(v);
+		cur = nxt;
+	}
+	{
+		uint32_t h[4];
+		tg_vit_block<false>(v, cur, h);
+		hist[(NBLK - 2) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
+		tg_vit_block<true>(v, cur >> 12, h);
+		hist[(NBLK - 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
+	}
+
+	/* block-wise traceback from state 0 */
+	uint32_t od[NOD + 1];
+#pragma unroll
+	for (int i = 0; i <= NOD; i++)
+		od[i] = 0;
+	{
+		const uint8_t *hb = (const uint8_t *)hist + lane * 16;
+		uint32_t s = 0;
+#pragma unroll
+		for (int b = NBLK - 1; b >= 0; b--) {
+			const uint32_t byte = hb[b * 1024 + s];
+			od[b >> 2] |= byte << ((b & 3) * 8);
+			s = tg_brev4(byte);
+		}
+	}
+
+	/* CRC-16 over type1 + 16 bits = (NBLK-1) bytes + 4 bits (lower_mac/tetra_lower_mac.c:258) */
+	__syncthreads();	/* s_crc visible (single wave, but keep the compiler honest) */
+	uint32_t crc = 0xffff;
+#pragma unroll
+	for (int i = 0; i < NBLK - 1; i++) {
+		const uint32_t byte = (od[i >> 2] >> ((i & 3) * 8)) & 0xff;
+		crc = ((crc << 8) & 0xffff) ^ s_crc[256 + (crc >> 8)] ^ s_crc[byte];
+	}
+	{
+		const uint32_t nib = (od[(NBLK - 1) >> 2] >> (((NBLK - 1) & 3) * 8)) & 15;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			crc ^= ((nib >> i) & 1) << 15;
+			crc = (crc & 0x8000) ? (((crc << 1) ^ 0x1021) & 0xffff) : ((crc << 1) & 0xffff);
+		}
+	}
+	const uint32_t crc_ok = (crc == 0x1d0f);
+
+	if (!valid)
+		return;
+
+	/* ---- outputs ---- */
+	uint8_t *r = rec + (size_t)slot * TG_REC_BYTES;
+	{
+		uint4 *dst = (uint4 *)(r + (which ? TG_REC_BITS2 : TG_REC_BITS1));
+		constexpr int NST = (TYPE1 + 15) / 16;
+#pragma unroll
+		for (int q = 0; q < NST; q++) {
+			const uint32_t hw = (od[q >> 1] >> ((q & 1) * 16)) & 0xffff;
+			uint4 o;
+			o.x = spread4(hw);
+			o.y = spread4(hw >> 4);
+			o.z = spread4(hw >> 8);
+			o.w = (q * 16 + 12 < TYPE1) ? spread4(hw >> 12) : 0u;	/* TYPE1 = 12 mod 16 */
+			dst[q] = o;
+		}
+	}
+	r[TG_REC_CRC_OK + which] = (uint8_t)crc_ok;
+	*(uint16_t *)(r + TG_REC_CRC + 2 * which) = (uint16_t)crc;
+
+	if (KIND == TG_KIND_SB1) {
+		/* SYNC PDU fields, lower_mac/tetra_lower_mac.c:284-297 */
+		const uint32_t cc = FIELD_MSB(od, 4, 6), tn = FIELD_MSB(od, 10, 2) + 1;
+		const uint32_t fn = FIELD_MSB(od, 12, 5), mn = FIELD_MSB(od, 17, 6);
+		const uint32_t mcc = FIELD_MSB(od, 31, 10), mnc = FIELD_MSB(od, 41, 14);
+		const uint32_t code = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3u;
+		*(uint32_t *)(r + TG_REC_SBF0) = cc | (tn << 8) | (fn << 16) | (mn << 24);
+		*(uint32_t *)(r + TG_REC_SBF1) = mcc | (mnc << 16);
+		*(uint32_t *)(r + TG_REC_SBCODE) = code;
+		sb_ok[idx] = crc_ok;
+		sb_code[idx] = code;
+	} else {
+		/* BBK + header are written by the lane that owns the slot's "primary" block:
+		 * SCH/F for NORM_1, BLK1 for NORM_2, SB2 for SYNC */
+		const uint32_t meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
+		const uint32_t btype = meta & 0xff;
+		const bool primary = (KIND == TG_KIND_432) || (btype == TG_BURST_SYNC ? which == 1 : which == 0);
+		if (primary) {
+			const uint32_t bb = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_BBK] ^
+					    masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
+			uint4 o;
+			o.x = spread4(bb);
+			o.y = spread4(bb >> 4);
+			o.z = spread4(bb >> 8);
+			o.w = spread4(bb >> 12) & 0x0000ffffu;	/* 14 type-1 bits (tetra_lower_mac.c:268-274) */
+			*(uint4 *)(r + TG_REC_BBK) = o;
+			r[TG_REC_TYPE] = (uint8_t)btype;
+			r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
+			*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
+			*(uint32_t *)(r + TG_REC_SLOT) = slot;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------- */
+/* scrambling-code forward fill: inclusive running max over (chan<<32 | entry) */
+/* ------------------------------------------------------------------------- */
+#define FILL_BLOCK 1024
+
+__device__ __forceinline__ unsigned long long fill_key(uint32_t i, const uint32_t *slot_chan, const int32_t *slot_sbord,
+						       const uint32_t *sb_ok, uint32_t nchan)
+{
+	const uint32_t ch = slot_chan[i];
+	const int32_t k = slot_sbord[i];
+	/* entry ids: 0 = zero mask, 1+ch = channel carry-in, 1+nchan+k = k-th SYNC slot of the batch */
+	uint32_t e = 1 + ch;
+	if (k >= 0 && sb_ok[k])
+		e = 1 + nchan + (uint32_t)k;
+	return ((unsigned long long)ch << 32) | e;
+}
+
+__device__ __forceinline__ unsigned long long wave_incl_max(unsigned long long v, uint32_t lane)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const unsigned long long o = __shfl_up(v, d);
+		if (lane >= (uint32_t)d && o > v)
+			v = o;
+	}
+	return v;
+}
+
+/* phase 1: per-block maximum */
+__global__ __launch_bounds__(FILL_BLOCK)
+void k_fill_reduce(const uint32_t *slot_chan, const int32_t *slot_sbord, const uint32_t *sb_ok,
+		   uint32_t nchan, uint32_t nslots, unsigned long long *block_max)
+{
+	__shared__ unsigned long long sm[FILL_BLOCK / 64];
+	const uint32_t i = blockIdx.x * FILL_BLOCK + threadIdx.x;
+	unsigned long long v = (i < nslots) ? fill_key(i, slot_chan, slot_sbord, sb_ok, nchan) : 0ull;
+	const uint32_t lane = threadIdx.x & 63;
+	v = wave_incl_max(v, lane);
+	if (lane == 63)
+		sm[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long m = 0;
+		for (int w = 0; w < FILL_BLOCK / 64; w++)
+			m = sm[w] > m ? sm[w] : m;
+		block_max[blockIdx.x] = m;
+	}
+}
+
+/* phase 2: exclusive running max over the block maxima (single workgroup, serial chunks) */
+__global__ __launch_bounds__(64)
+void k_fill_scan(unsigned long long *block_max, uint32_t nblocks)
+{
+	const uint32_t lane = threadIdx.x;
+	unsigned long long carry = 0;
+	for (uint32_t base = 0; base < nblocks; base += 64) {
+		const uint32_t i = base + lane;
+		unsigned long long v = (i < nblocks) ? block_max[i] : 0ull;
+		unsigned long long inc = wave_incl_max(v, lane);
+		unsigned long long exc = __shfl_up(inc, 1);
+		if (lane == 0)
+			exc = 0;
+		if (carry > exc)
+			exc = carry;
+		if (i < nblocks)
+			block_max[i] = exc;
+		const unsigned long long tot = __shfl(inc, 63);
+		if (tot > carry)
+			carry = tot;
+	}
+}
+
+/* phase 3: in-block scan with carry-in, write the mask entry of every slot */
+__global__ __launch_bounds__(FILL_BLOCK)
+void k_fill_apply(const uint32_t *slot_chan, const int32_t *slot_sbord, const uint32_t *sb_ok,
+		  uint32_t nchan, uint32_t nslots, const unsigned long long *block_excl, uint32_t *maskidx)
+{
+	__shared__ unsigned long long sm[FILL_BLOCK / 64];
+	const uint32_t i = blockIdx.x * FILL_BLOCK + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	unsigned long long v = (i < nslots) ? fill_key(i, slot_chan, slot_sbord, sb_ok, nchan) : 0ull;
+	v = wave_incl_max(v, lane);
+	if (lane == 63)
+		sm[w] = v;
+	__syncthreads();
+	unsigned long long pre = block_excl[blockIdx.x];
+	for (uint32_t q = 0; q < w; q++)
+		pre = sm[q] > pre ? sm[q] : pre;
+	if (pre > v)
+		v = pre;
+	if (i < nslots)
+		maskidx[i] = (uint32_t)v;	/* chan is monotone along the array, so the max stays inside the channel */
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_masks: one wavefront per mask-table entry                               */
+/* ------------------------------------------------------------------------- */
+__global__ __launch_bounds__(64)
+void k_masks(const uint32_t *chan_code, uint32_t nchan, const uint32_t *sb_ok, const uint32_t *sb_code,
+	     uint32_t nsb, uint32_t *masks)
+{
+	const uint32_t e = blockIdx.x, lane = threadIdx.x;
+	uint32_t code = 0;
+	if (e >= 1 && e <= nchan)
+		code = chan_code[e - 1];
+	else if (e > nchan) {
+		const uint32_t k = e - 1 - nchan;
+		code = (k < nsb && sb_ok[k]) ? sb_code[k] : 0;
+	}
+	const uint32_t half = lane >> 5, bit = lane & 31;
+	uint32_t myword = 0;
+#pragma unroll
+	for (int r = 0; r < 14; r++) {
+		const uint16_t pos = c_tab.mask_pos[2 * r + half][bit];
+		uint32_t b = 0;
+		if (pos != 0xffff)
+			b = __popc(code & c_tab.lfsr_lin[pos]) & 1;
+		const unsigned long long bal = __ballot(b);
+		myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
+		myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
+	}
+	if (lane == TG_MW_CODE)
+		myword = code;
+	if (lane < TG_MASK_WORDS)
+		masks[(size_t)e * TG_MASK_WORDS + lane] = myword;
+}
+
+/* ------------------------------------------------------------------------- */
+/* host-side launch layer                                                    */
+/* ------------------------------------------------------------------------- */
+static uint32_t lfsr_next(uint32_t *st)
+{
+	/* Fibonacci LFSR of lower_mac/tetra_scramb.c:34-50, taps 32 26 23 22 16 12 11 10 8 7 5 4 2 1 */
+	static const int taps[14] = { 32, 26, 23, 22, 16, 12, 11, 10, 8, 7, 5, 4, 2, 1 };
+	uint32_t s = *st, fb = 0;
+	for (int i = 0; i < 14; i++)
+		fb ^= s >> (32 - taps[i]);
+	fb &= 1;
+	*st = (s >> 1) | (fb << 31);
+	return fb;
+}
+
+static void build_tables(tg_const_tables *t)
+{
+	memset(t, 0, sizeof(*t));
+	const int btypes[3] = { TG_BURST_NORM_1, TG_BURST_NORM_2, TG_BURST_SYNC };
+	for (int x = 0; x < 3; x++)
+		for (int w = 0; w < TG_PACKED_WORDS; w++)
+			for (int p = 0; p < 32; p++) {
+				int o = tg_packed_src(btypes[x], w, p);
+				t->front_src[x][w][p] = (o < 0) ? 0xffff : (uint16_t)o;
+			}
+	/* mask layout: which LFSR output index scrambles each packed bit */
+	for (int w = 0; w < TG_MASK_WORDS; w++)
+		for (int p = 0; p < 32; p++) {
+			int pos = -1;
+			if (w < TG_MW_216)
+				pos = tg_codeword_src(TG_KIND_432, w - TG_MW_432, p);
+			else if (w < TG_MW_BBK)
+				pos = tg_codeword_src(TG_KIND_216, w - TG_MW_216, p);
+			else if (w == TG_MW_BBK)
+				pos = (p < 30) ? p : -1;
+			t->mask_pos[w][p] = (pos < 0) ? 0xffff : (uint16_t)pos;
+		}
+	/* linear form of the LFSR: run it on the 32 unit vectors */
+	for (int b = 0; b < 32; b++) {
+		uint32_t st = 1u << b;
+		for (int n = 0; n < 432; n++)
+			if (lfsr_next(&st))
+				t->lfsr_lin[n] |= 1u << b;
+	}
+	/* SB1 mask for init = 3 (lower_mac/tetra_scramb.h:14) */
+	{
+		uint8_t seq[120];
+		uint32_t st = 3;
+		for (int n = 0; n < 120; n++)
+			seq[n] = (uint8_t)lfsr_next(&st);
+		for (int d = 0; d < 5; d++)
+			for (int p = 0; p < 32; p++) {
+				int j = tg_codeword_src(TG_KIND_SB1, d, p);
+				if (j >= 0 && seq[j])
+					t->sb1_mask[d] |= 1u << p;
+			}
+	}
+	tg_crc16_make_table(t->crc_lsb);
+	for (int x = 0; x < 256; x++) {
+		int rv = 0;
+		for (int i = 0; i < 8; i++)
+			if (x & (1 << i))
+				rv |= 0x80 >> i;
+		t->crc_msb[x] = t->crc_lsb[rv];
+	}
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+extern "C" int tgk_init(void)
+{
+	static tg_const_tables host;
+	build_tables(&host);
+	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &host, sizeof(host)));
+	return 0;
+}
+
+extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_off, const uint8_t *d_slot_type,
+			 uint32_t nslots, uint32_t *d_packed, uint8_t *d_rec, void *stream)
+{
+	if (!nslots)
+		return 0;
+	uint32_t blocks = (nslots + 3) / 4;
+	if (blocks > 256 * 16)
+		blocks = 256 * 16;
+	hipLaunchKernelGGL(k_front, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+			   d_stream, d_slot_off, d_slot_type, nslots, d_packed, d_rec);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
+		       const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
+		       uint32_t *d_sb_ok, uint32_t *d_sb_code, void *stream)
+{
+	if (!nitems)
+		return 0;
+	const dim3 grid((nitems + 63) / 64), block(64);
+	hipStream_t s = (hipStream_t)stream;
+	switch (kind) {
+	case TG_KIND_SB1:
+		hipLaunchKernelGGL(k_vit<TG_KIND_SB1>, grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code);
+		break;
+	case TG_KIND_216:
+		hipLaunchKernelGGL(k_vit<TG_KIND_216>, grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code);
+		break;
+	case TG_KIND_432:
+		hipLaunchKernelGGL(k_vit<TG_KIND_432>, grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code);
+		break;
+	default:
+		return -1;
+	}
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uint32_t *d_sb_ok,
+			uint32_t nchan, uint32_t nslots, unsigned long long *d_block_tmp, uint32_t *d_maskidx, void *stream)
+{
+	if (!nslots)
+		return 0;
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t nblocks = (nslots + FILL_BLOCK - 1) / FILL_BLOCK;
+	hipLaunchKernelGGL(k_fill_reduce, dim3(nblocks), dim3(FILL_BLOCK), 0, s, d_slot_chan, d_slot_sbord, d_sb_ok, nchan, nslots, d_block_tmp);
+	hipLaunchKernelGGL(k_fill_scan, dim3(1), dim3(64), 0, s, d_block_tmp, nblocks);
+	hipLaunchKernelGGL(k_fill_apply, dim3(nblocks), dim3(FILL_BLOCK), 0, s, d_slot_chan, d_slot_sbord, d_sb_ok, nchan, nslots, d_block_tmp, d_maskidx);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
+			 const uint32_t *d_sb_code, uint32_t nsb, uint32_t *d_masks, void *stream)
+{
+	const uint32_t nent = 1 + nchan + nsb;
+	hipLaunchKernelGGL(k_masks, dim3(nent), dim3(64), 0, (hipStream_t)stream, d_chan_code, nchan, d_sb_ok, d_sb_code, nsb, d_masks);
+	return (int)hipGetLastError();
+}

@@ -1,0 +1,178 @@
+/*
+ * tg_layout.h -- data layout shared by the host code and the HIP kernels.
+ *
+ * One TETRA downlink slot is 510 stream bytes (1 bit per byte, the tetra-rx input
+ * format).  Field offsets follow phy/tetra_burst.c:31-47 of the reference, block
+ * parameters lower_mac/tetra_lower_mac.c:55-102.
+ *
+ * Device pipeline:
+ *   front kernel : 510 B slot  -> tg_packed_slot (80 B): code bits de-interleaved and
+ *                  bit-packed, still scrambled, plus classification meta
+ *   viterbi kernels: tg_packed_slot (+ scrambling masks) -> tg_slot_rec (320 B)
+ */
+#ifndef TG_LAYOUT_H
+#define TG_LAYOUT_H
+
+#include <stdint.h>
+
+#define TG_SLOT_BITS      510
+
+/* burst types = enum tetra_train_seq of the reference (phy/tetra_burst.h:30-36) */
+#define TG_BURST_NORM_1   0
+#define TG_BURST_NORM_2   1
+#define TG_BURST_NORM_3   2
+#define TG_BURST_SYNC     3
+#define TG_BURST_NONE     0xff
+
+/* block kinds handled by the trellis kernels */
+#define TG_KIND_SB1   0	/* 120 bits, a=11,  80 type-2 bits, 60 type-1  */
+#define TG_KIND_216   1	/* 216 bits, a=101, 144 type-2,     124 type-1 (NDB, SB2) */
+#define TG_KIND_432   2	/* 432 bits, a=103, 288 type-2,     268 type-1 (SCH/F) */
+
+/* slot field offsets (phy/tetra_burst.c:31-47) */
+#define TG_SB_BLK1_OFF    94
+#define TG_SB_BBK_OFF     252
+#define TG_SB_BLK2_OFF    282
+#define TG_NDB_BLK1_OFF   14
+#define TG_NDB_BBK1_OFF   230
+#define TG_NDB_BBK2_OFF   266
+#define TG_NDB_BLK2_OFF   282
+#define TG_SYNC_TRAIN_OFF 214	/* phy/tetra_burst_sync.c:123 */
+#define TG_NORM_TRAIN_OFF 244	/* phy/tetra_burst_sync.c:133 */
+
+/*
+ * Packed slot: 20 dwords.
+ *   w[0..17]  code words.  A code word carries 24 received type-3 bits (two 8-step
+ *             trellis blocks of 12 bits); word 0 of every block additionally carries
+ *             the first 6 type-3 bits (the 4 lead-in trellis steps) in bits 24..29.
+ *             word d bit p (p<24) = type3[6 + 24*d + p];  word 0 bit 24+q = type3[q].
+ *             NORM_1: SCH/F in w[0..17].  NORM_2: BLK1 w[0..8], BLK2 w[9..17].
+ *             SYNC:   SB1 w[0..4], SB2 w[9..17].
+ *   w[18]     the 30 BBK bits in stream order (bit p = bb(p+1))
+ *   w[19]     meta: burst type | flags<<8 | train_offset<<16
+ */
+#define TG_PACKED_WORDS   20
+#define TG_PW_BLK1        0
+#define TG_PW_BLK2        9
+#define TG_PW_BBK         18
+#define TG_PW_META        19
+
+#define TG_FLAG_NONBINARY 0x01	/* a stream byte other than 0/1 was seen in a coded field */
+
+/* scrambling-mask table entry: 32 dwords, same bit layout as the code words */
+#define TG_MASK_WORDS     32
+#define TG_MW_432         0	/* 18 words */
+#define TG_MW_216         18	/* 9 words  */
+#define TG_MW_BBK         27
+#define TG_MW_CODE        28	/* the scrambling code itself */
+
+/*
+ * Output record, one per slot, fixed 320 bytes (the unit of the RCCL gather).
+ *   @0   u8  burst_type
+ *   @1   u8  flags
+ *   @2   u8  crc_ok[2]      [0]: SB1 / BLK1 / SCH-F   [1]: SB2 / BLK2
+ *   @4   u16 crc[2]
+ *   @8   u32 scrambling code used for BBK/BLK/SB2 (SB1 always uses 3)
+ *   @12  u32 slot id
+ *   @16  u32 SYNC-PDU fields cc | tn<<8 | fn<<16 | mn<<24      (SYNC slots)
+ *   @20  u32 SYNC-PDU fields mcc | mnc<<16
+ *   @24  u32 scrambling code derived from the SYNC PDU
+ *   @32  14 B  BBK type-1 bits (1 bit per byte)
+ *   @48  SB1 (60 B) / BLK1 (124 B) / SCH-F (268 B) type-1 bits
+ *   @176 SB2 / BLK2 (124 B) type-1 bits
+ */
+#define TG_REC_BYTES      320
+#define TG_REC_TYPE       0
+#define TG_REC_FLAGS      1
+#define TG_REC_CRC_OK     2
+#define TG_REC_CRC        4
+#define TG_REC_CODE       8
+#define TG_REC_SLOT       12
+#define TG_REC_SBF0       16
+#define TG_REC_SBF1       20
+#define TG_REC_SBCODE     24
+#define TG_REC_BBK        32
+#define TG_REC_BITS1      48
+#define TG_REC_BITS2      176
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* number of 8-step trellis blocks / type-1 bits / crc span per kind */
+static inline int tg_kind_nblk(int kind)  { return kind == TG_KIND_SB1 ? 10 : kind == TG_KIND_216 ? 18 : 36; }
+static inline int tg_kind_K(int kind)     { return kind == TG_KIND_SB1 ? 120 : kind == TG_KIND_216 ? 216 : 432; }
+static inline int tg_kind_a(int kind)     { return kind == TG_KIND_SB1 ? 11 : kind == TG_KIND_216 ? 101 : 103; }
+static inline int tg_kind_type1(int kind) { return kind == TG_KIND_SB1 ? 60 : kind == TG_KIND_216 ? 124 : 268; }
+
+/*
+ * type-4 (stream order inside a block) index feeding code-word bit (d, p) of a block
+ * of kind 'kind'; -1 when the bit is unused.  Composition of the 2/3 puncturing order,
+ * the block de-interleaver  type3[i] = type4[(a*(i+1)) mod K]
+ * (lower_mac/tetra_interleave.c:36-39,51-59) and the code-word layout above.
+ */
+static inline int tg_codeword_src(int kind, int d, int p)
+{
+	int K = tg_kind_K(kind), a = tg_kind_a(kind), i;
+	if (p < 24)
+		i = 6 + 24 * d + p;
+	else if (d == 0 && p < 30)
+		i = p - 24;
+	else
+		return -1;
+	if (i >= K)
+		return -1;
+	return (a * (i + 1)) % K;
+}
+
+/* slot byte offset of type-4 bit j of the block occupying code words starting at
+ * 'wbase' (TG_PW_BLK1 / TG_PW_BLK2) in a burst of type 'btype' */
+static inline int tg_block_stream_off(int btype, int wbase, int j)
+{
+	if (btype == TG_BURST_SYNC)
+		return (wbase == TG_PW_BLK1) ? TG_SB_BLK1_OFF + j : TG_SB_BLK2_OFF + j;
+	if (btype == TG_BURST_NORM_1)	/* SCH/F = BLK1 || BLK2, phy/tetra_burst.c:367-368 */
+		return (j < 216) ? TG_NDB_BLK1_OFF + j : TG_NDB_BLK2_OFF + (j - 216);
+	return (wbase == TG_PW_BLK1) ? TG_NDB_BLK1_OFF + j : TG_NDB_BLK2_OFF + j;
+}
+
+/* slot byte offset of BBK bit p (phy/tetra_burst.c:351,357-358) */
+static inline int tg_bbk_stream_off(int btype, int p)
+{
+	if (btype == TG_BURST_SYNC)
+		return TG_SB_BBK_OFF + p;
+	return (p < 14) ? TG_NDB_BBK1_OFF + p : TG_NDB_BBK2_OFF + (p - 14);
+}
+
+/*
+ * slot byte offset feeding bit p of packed word w for burst type btype; -1 = none.
+ * This single function defines the front kernel's gather table and the scrambling
+ * mask layout (via tg_packed_seqpos).
+ */
+static inline int tg_packed_src(int btype, int w, int p)
+{
+	int kind, wbase, j;
+	if (w == TG_PW_BBK)
+		return (p < 30) ? tg_bbk_stream_off(btype, p) : -1;
+	if (w >= TG_PW_BBK)
+		return -1;
+	if (btype == TG_BURST_NORM_1) {
+		kind = TG_KIND_432; wbase = TG_PW_BLK1;
+	} else if (btype == TG_BURST_NORM_2) {
+		kind = TG_KIND_216; wbase = (w >= TG_PW_BLK2) ? TG_PW_BLK2 : TG_PW_BLK1;
+	} else if (btype == TG_BURST_SYNC) {
+		if (w >= TG_PW_BLK2) { kind = TG_KIND_216; wbase = TG_PW_BLK2; }
+		else if (w < 5)      { kind = TG_KIND_SB1; wbase = TG_PW_BLK1; }
+		else return -1;
+	} else
+		return -1;
+	j = tg_codeword_src(kind, w - wbase, p);
+	if (j < 0)
+		return -1;
+	return tg_block_stream_off(btype, wbase, j);
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif

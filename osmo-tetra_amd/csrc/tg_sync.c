@@ -1,0 +1,489 @@
+/*
+ * tg_sync.c -- host side of the channel API: the burst synchroniser with the exact
+ * semantics of the reference, burst queueing, and the in-order delivery ("replay") of
+ * GPU-decoded blocks to the upper-MAC callback.
+ *
+ * Mirrors (reference paths under src/):
+ *   tetra_find_train_seq()   phy/tetra_burst.c:269-339   incl. its look-ahead filter quirk
+ *   tetra_burst_sync_in()    phy/tetra_burst_sync.c:38-154
+ *   tetra_burst_rx_cb()      phy/tetra_burst.c:341-379   (block order)
+ *   tp_sap_udata_ind()       lower_mac/tetra_lower_mac.c:143-357  (everything except the
+ *                            descramble/deinterleave/Viterbi/CRC arithmetic, which the GPU did)
+ *   tetra_tdma_time_add_tn() tetra_tdma.c:27-81
+ *
+ * What is sequential stays here, per channel and cheap: TDMA time, cell data, the
+ * is_traffic / blk2_stolen feedback (SURVEY.md 3.3 loops 2 and 3).  What is arithmetic
+ * runs on the GPU for a whole batch of bursts; the GPU decodes every block speculatively
+ * and this file decides what is delivered.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "tetra_gpu.h"
+#include "tg_layout.h"
+
+/* ------------------------------------------------------------------------- */
+/* small reference-compatible helpers                                         */
+/* ------------------------------------------------------------------------- */
+void tetra_tdma_time_add_tn(struct tetra_tdma_time *tm, uint32_t tn_count)
+{
+	/* the three normalisers always run in this order, tetra_tdma.c:27-58 */
+	tm->tn += tn_count;
+	if (tm->tn > 4) {
+		tm->fn += tm->tn / 4;
+		tm->tn %= 4;
+	}
+	if (tm->fn > 18) {
+		tm->mn += tm->fn / 18;
+		tm->fn %= 18;
+	}
+	if (tm->mn > 60)
+		tm->mn %= 60;
+}
+
+uint32_t tetra_scramb_get_init(uint16_t mcc, uint16_t mnc, uint8_t colour)
+{
+	uint32_t v = ((uint32_t)(mcc & 0x3ff) << 20) | ((uint32_t)(mnc & 0x3fff) << 6) | (colour & 0x3f);
+	return (v << 2) | SCRAMB_INIT;
+}
+
+static uint32_t scramb_next(uint32_t *st)
+{
+	/* taps 32 26 23 22 16 12 11 10 8 7 5 4 2 1 -> state bits 0 6 9 10 16 20 21 22 24 25 27 28 30 31 */
+	const uint32_t s = *st;
+	const uint32_t fb = __builtin_parity(s & 0xdb710641u);
+	*st = (s >> 1) | (fb << 31);
+	return fb;
+}
+
+/* training sequences, EN 300 392-2 clause 9.4.4.3 */
+static const uint8_t ts_n[22] = { 1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0 };
+static const uint8_t ts_p[22] = { 0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0 };
+static const uint8_t ts_q[22] = { 1,0,1,1,0,1,1,1,0,0,0,0,0,1,1,0,1,0,1,1,0,1 };
+static const uint8_t ts_x[30] = { 1,0,0,1,1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0,0,0,1,1 };
+static const uint8_t ts_y[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
+
+static uint32_t prefix22(const uint8_t *s)
+{
+	uint32_t v = 0;
+	for (int i = 0; i < 22; i++)
+		v = (v << 1) | s[i];
+	return v;
+}
+
+int tetra_find_train_seq(const uint8_t *in, unsigned int end_of_in, uint32_t mask, unsigned int *offset)
+{
+	/*
+	 * The reference gates every position with a 22-bit window compared against the first
+	 * 22 bits of y, n, p, q, x.  The window is primed with in[0..19] and then fed in[cur+21],
+	 * so it only equals in[cur..cur+21] from cur = 21 on; before that it is the stream with
+	 * in[20] missing.  A hit needs gate AND exact memcmp, tested in the order SYNC, NORM_1,
+	 * NORM_2, NORM_3, EXT, each only if enough bits remain.  All of that is kept.
+	 */
+	const uint32_t g0 = prefix22(ts_y), g1 = prefix22(ts_n), g2 = prefix22(ts_p), g3 = prefix22(ts_q),
+		       g4 = prefix22(ts_x);
+	uint32_t win = 0;
+	for (int i = 0; i < 20; i++)
+		win = (win << 1) | in[i];
+	for (unsigned int cur = 0; cur < end_of_in; cur++) {
+		win = ((win << 1) | in[cur + 21]) & 0x3fffffu;
+		if (win != g0 && win != g1 && win != g2 && win != g3 && win != g4)
+			continue;
+		const unsigned int left = end_of_in - cur;
+		const uint8_t *p = in + cur;
+		int hit = -1;
+		if ((mask & (1u << TETRA_TRAIN_SYNC)) && left >= 38 && !memcmp(p, ts_y, 38))
+			hit = TETRA_TRAIN_SYNC;
+		else if ((mask & (1u << TETRA_TRAIN_NORM_1)) && left >= 22 && !memcmp(p, ts_n, 22))
+			hit = TETRA_TRAIN_NORM_1;
+		else if ((mask & (1u << TETRA_TRAIN_NORM_2)) && left >= 22 && !memcmp(p, ts_p, 22))
+			hit = TETRA_TRAIN_NORM_2;
+		else if ((mask & (1u << TETRA_TRAIN_NORM_3)) && left >= 22 && !memcmp(p, ts_q, 22))
+			hit = TETRA_TRAIN_NORM_3;
+		else if ((mask & (1u << TETRA_TRAIN_EXT)) && left >= 30 && !memcmp(p, ts_x, 30))
+			hit = TETRA_TRAIN_EXT;
+		if (hit >= 0) {
+			*offset = cur;
+			return hit;
+		}
+	}
+	return -1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* channel                                                                    */
+/* ------------------------------------------------------------------------- */
+#define SLOT_STRIDE 512		/* staging stride: 510 rounded up, keeps slots 16-byte aligned */
+
+struct pending {
+	uint32_t burst_seq;
+	uint32_t tn_adds;	/* tetra_tdma_time_add_tn(,1) calls since the previously queued burst */
+	uint8_t type;
+};
+
+struct tgpu_channel {
+	struct tgpu_engine *eng;
+	struct tgpu_plan *plan;
+	uint32_t batch_slots;
+	tgpu_unitdata_cb cb;
+	tgpu_event_cb ev;
+	void *priv;
+
+	/* queue */
+	uint32_t n_pending;
+	struct pending *pend;
+	uint8_t *h_slots;	/* pinned, batch_slots * SLOT_STRIDE */
+	uint8_t *h_rec;		/* pinned, batch_slots * TGPU_REC_BYTES */
+	uint8_t *d_slots, *d_rec;
+	uint64_t *h_off;
+	uint8_t *h_type;
+	uint32_t *h_chan;
+	hipStream_t stream;
+
+	/* what the reference keeps in globals: t_phy_state (phy/tetra_burst_sync.c:34),
+	 * tcd (lower_mac/tetra_lower_mac.c:113) */
+	struct tetra_tdma_time phy_time, cell_time;
+	uint16_t mcc, mnc;
+	uint8_t colour_code;
+	uint32_t scramb_init;
+	uint32_t burst_seq, tn_adds;
+
+	/* tms->cur_burst */
+	int loc_is_traffic;
+	bool loc_blk1, loc_blk2;
+	int *is_traffic;
+	bool *blk1_stolen, *blk2_stolen;
+	int last_error;
+};
+
+int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unitdata_cb cb, tgpu_event_cb ev,
+			void *priv, struct tgpu_channel **out)
+{
+	if (!eng || !out || !batch_slots)
+		return TGPU_EINVAL;
+	struct tgpu_channel *ch = calloc(1, sizeof(*ch));
+	if (!ch)
+		return TGPU_ENOMEM;
+	ch->eng = eng;
+	ch->batch_slots = batch_slots;
+	ch->cb = cb;
+	ch->ev = ev;
+	ch->priv = priv;
+	ch->is_traffic = &ch->loc_is_traffic;
+	ch->blk1_stolen = &ch->loc_blk1;
+	ch->blk2_stolen = &ch->loc_blk2;
+	int rc = tgpu_plan_create(eng, batch_slots, 1, &ch->plan);
+	if (rc) {
+		free(ch);
+		return rc;
+	}
+	const size_t n = batch_slots;
+	hipError_t e = hipSuccess;
+	ch->pend = calloc(n, sizeof(*ch->pend));
+	ch->h_off = calloc(n, sizeof(uint64_t));
+	ch->h_type = calloc(n, 1);
+	ch->h_chan = calloc(n, 4);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_slots, n * SLOT_STRIDE, 0);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_rec, n * TGPU_REC_BYTES, 0);
+	if (e == hipSuccess) e = hipMalloc((void **)&ch->d_slots, n * SLOT_STRIDE);
+	if (e == hipSuccess) e = hipMalloc((void **)&ch->d_rec, n * TGPU_REC_BYTES);
+	if (e == hipSuccess) e = hipStreamCreate(&ch->stream);
+	if (e != hipSuccess || !ch->pend || !ch->h_off || !ch->h_type || !ch->h_chan) {
+		tgpu_channel_destroy(ch);
+		return e != hipSuccess ? (int)e : TGPU_ENOMEM;
+	}
+	for (size_t i = 0; i < n; i++)
+		ch->h_off[i] = i * SLOT_STRIDE;
+	*out = ch;
+	return TGPU_OK;
+}
+
+void tgpu_channel_destroy(struct tgpu_channel *ch)
+{
+	if (!ch)
+		return;
+	if (ch->stream) (void)hipStreamDestroy(ch->stream);
+	if (ch->h_slots) (void)hipHostFree(ch->h_slots);
+	if (ch->h_rec) (void)hipHostFree(ch->h_rec);
+	if (ch->d_slots) (void)hipFree(ch->d_slots);
+	if (ch->d_rec) (void)hipFree(ch->d_rec);
+	tgpu_plan_destroy(ch->plan);
+	free(ch->pend);
+	free(ch->h_off);
+	free(ch->h_type);
+	free(ch->h_chan);
+	free(ch);
+}
+
+void tgpu_channel_bind_flags(struct tgpu_channel *ch, int *is_traffic, bool *blk1_stolen, bool *blk2_stolen)
+{
+	ch->is_traffic = is_traffic ? is_traffic : &ch->loc_is_traffic;
+	ch->blk1_stolen = blk1_stolen ? blk1_stolen : &ch->loc_blk1;
+	ch->blk2_stolen = blk2_stolen ? blk2_stolen : &ch->loc_blk2;
+}
+
+void tgpu_channel_set_traffic(struct tgpu_channel *ch, int is_traffic)
+{
+	*ch->is_traffic = is_traffic;
+}
+
+void tgpu_channel_set_blk2_stolen(struct tgpu_channel *ch, bool stolen)
+{
+	*ch->blk2_stolen = stolen;
+}
+
+/* ------------------------------------------------------------------------- */
+/* delivery: the non-arithmetic part of tp_sap_udata_ind()                    */
+/* ------------------------------------------------------------------------- */
+static int is_bnch(const struct tetra_tdma_time *tm)
+{
+	return tm->fn == 18 && tm->tn == 4 - ((tm->mn + 3) % 4);	/* lower_mac/tetra_lower_mac.c:122-127 */
+}
+
+/* raw type-5 bits of a block inside a queued slot (phy/tetra_burst.c:341-379) */
+static unsigned gather_type5(const uint8_t *slot, int btype, enum tp_sap_data_type t, int blk_num, uint8_t *out)
+{
+	switch (t) {
+	case TPSAP_T_SB1:
+		memcpy(out, slot + TG_SB_BLK1_OFF, 120);
+		return 120;
+	case TPSAP_T_SB2:
+		memcpy(out, slot + TG_SB_BLK2_OFF, 216);
+		return 216;
+	case TPSAP_T_NDB:
+		memcpy(out, slot + (blk_num == BLK_1 ? TG_NDB_BLK1_OFF : TG_NDB_BLK2_OFF), 216);
+		return 216;
+	case TPSAP_T_SCH_F:
+		memcpy(out, slot + TG_NDB_BLK1_OFF, 216);
+		memcpy(out + 216, slot + TG_NDB_BLK2_OFF, 216);
+		return 432;
+	case TPSAP_T_BBK:
+		if (btype == TETRA_TRAIN_SYNC) {
+			memcpy(out, slot + TG_SB_BBK_OFF, 30);
+		} else {
+			memcpy(out, slot + TG_NDB_BBK1_OFF, 14);
+			memcpy(out + 14, slot + TG_NDB_BBK2_OFF, 16);
+		}
+		return 30;
+	default:
+		return 0;
+	}
+}
+
+static void deliver_block(struct tgpu_channel *ch, const struct pending *pd, const uint8_t *slot,
+			  const uint8_t *rec, const struct tgpu_block *b)
+{
+	struct tgpu_unitdata ud;
+	uint8_t type4[432];
+
+	memset(&ud, 0, sizeof(ud));
+	ud.type = b->type;
+	ud.blk_num = b->blk_num;
+	ud.burst_seq = pd->burst_seq;
+	ud.burst_type = (enum tetra_train_seq)pd->type;
+	ud.lchan = TETRA_LC_UNKNOWN;
+
+	ch->cell_time = ch->phy_time;							/* :167 */
+	if (b->type == TPSAP_T_SB2 && is_bnch(&ch->cell_time))				/* :170-173 */
+		ud.lchan = TETRA_LC_BNCH;
+
+	ud.scrambling_code = (b->type == TPSAP_T_SB1) ? SCRAMB_INIT : ch->scramb_init;	/* :179-186 */
+
+	if (*ch->is_traffic && b->type == TPSAP_T_NDB && b->blk_num == BLK_1)		/* :194-195 */
+		*ch->blk1_stolen = true;
+
+	if (*ch->is_traffic && (b->type == TPSAP_T_SCH_F || (b->blk_num == BLK_2 && !*ch->blk2_stolen))) {
+		/* :198-241 -- traffic block: not decoded, handed over as descrambled type-4 bits */
+		unsigned n = gather_type5(slot, pd->type, b->type, b->blk_num, type4);
+		uint32_t st = ud.scrambling_code;
+		for (unsigned i = 0; i < n; i++)
+			type4[i] ^= (uint8_t)scramb_next(&st);
+		ud.traffic = *ch->is_traffic;
+		ud.type4 = type4;
+		ud.type4_len = (uint16_t)n;
+		ud.tdma_time = ch->cell_time;
+		if (ch->cb)
+			ch->cb(&ud, 0xffffffffu, ch->priv);
+		return;
+	}
+
+	ud.crc_ok = b->crc_ok;
+	ud.crc = b->crc;
+	ud.type1_len = b->type1_len;
+	ud.type1 = b->type1;
+
+	switch (b->type) {
+	case TPSAP_T_SB1: {								/* :283-310 */
+		if (ud.crc_ok) {
+			struct tgpu_sync_info si;
+			tgpu_record_sync_info(rec, &si);
+			ch->colour_code = si.cc;
+			ch->cell_time.tn = si.tn;
+			ch->cell_time.fn = si.fn;
+			ch->cell_time.mn = si.mn;
+			ch->mcc = si.mcc;
+			ch->mnc = si.mnc;
+			ch->scramb_init = si.scramb_init;
+		}
+		ch->phy_time = ch->cell_time;
+		ud.lchan = TETRA_LC_BSCH;
+		break;
+	}
+	case TPSAP_T_BBK:
+		ud.lchan = TETRA_LC_AACH;
+		break;
+	case TPSAP_T_SCH_F:
+		ud.lchan = TETRA_LC_SCH_F;
+		break;
+	default:
+		break;
+	}
+
+	/* :326-352; limit computed like the reference: (int)type1_bits - 16 seen as unsigned */
+	uint32_t offset = 0;
+	const uint32_t limit = (uint32_t)((int)b->type1_len - 16);
+	while (offset < limit) {
+		ud.tdma_time = ch->cell_time;
+		int n = ch->cb ? ch->cb(&ud, offset, ch->priv) : -1;
+		if (n <= 0)	/* the reference never terminates on 0; we stop */
+			break;
+		offset += (uint32_t)n;
+	}
+}
+
+int tgpu_channel_flush(struct tgpu_channel *ch)
+{
+	if (!ch)
+		return TGPU_EINVAL;
+	const uint32_t n = ch->n_pending;
+	if (!n)
+		return TGPU_OK;
+	ch->n_pending = 0;
+
+	hipError_t e;
+	int rc;
+	for (uint32_t i = 0; i < n; i++)
+		ch->h_type[i] = ch->pend[i].type;
+	if ((rc = tgpu_plan_load(ch->plan, n, ch->h_off, ch->h_type, ch->h_chan, 1, &ch->scramb_init)))
+		return ch->last_error = rc;
+	if ((e = hipMemcpyAsync(ch->d_slots, ch->h_slots, (size_t)n * SLOT_STRIDE, hipMemcpyHostToDevice, ch->stream)))
+		return ch->last_error = (int)e;
+	if ((rc = tgpu_plan_execute(ch->plan, ch->d_slots, ch->d_rec, ch->stream)))
+		return ch->last_error = rc;
+	if ((e = hipMemcpyAsync(ch->h_rec, ch->d_rec, (size_t)n * TGPU_REC_BYTES, hipMemcpyDeviceToHost, ch->stream)))
+		return ch->last_error = (int)e;
+	if ((e = hipStreamSynchronize(ch->stream)))
+		return ch->last_error = (int)e;
+
+	for (uint32_t i = 0; i < n; i++) {
+		const struct pending *pd = &ch->pend[i];
+		const uint8_t *rec = ch->h_rec + (size_t)i * TGPU_REC_BYTES;
+		const uint8_t *slot = ch->h_slots + (size_t)i * SLOT_STRIDE;
+		struct tgpu_block blk[3];
+		for (uint32_t k = 0; k < pd->tn_adds; k++)
+			tetra_tdma_time_add_tn(&ch->phy_time, 1);			/* phy/tetra_burst_sync.c:113 */
+		int nb = tgpu_record_blocks(rec, blk);
+		for (int k = 0; k < nb; k++)
+			deliver_block(ch, pd, slot, rec, &blk[k]);
+	}
+	return TGPU_OK;
+}
+
+static void queue_burst(struct tgpu_channel *ch, const uint8_t *burst, int type)
+{
+	struct pending *pd = &ch->pend[ch->n_pending];
+	pd->burst_seq = ch->burst_seq;
+	pd->tn_adds = ch->tn_adds;
+	pd->type = (uint8_t)type;
+	ch->tn_adds = 0;
+	memcpy(ch->h_slots + (size_t)ch->n_pending * SLOT_STRIDE, burst, TG_SLOT_BITS);
+	ch->n_pending++;
+	if (ch->n_pending >= ch->batch_slots)
+		tgpu_channel_flush(ch);
+}
+
+/* ------------------------------------------------------------------------- */
+/* tetra_burst_sync_in(): phy/tetra_burst_sync.c:54-154                        */
+/* ------------------------------------------------------------------------- */
+int tetra_burst_sync_in(struct tetra_rx_state *trs, uint8_t *bits, unsigned int len)
+{
+	struct tgpu_channel *ch = trs->burst_cb_priv;
+	unsigned int offs = 0;
+	int rc;
+
+	/* make_bitbuf_space(), :38-52 */
+	unsigned int space = (unsigned int)sizeof(trs->bitbuf) - trs->bits_in_buf;
+	if (space < len) {
+		unsigned int delta = len - space;
+		memmove(trs->bitbuf, trs->bitbuf + delta, trs->bits_in_buf - delta);
+		trs->bits_in_buf -= delta;
+		trs->bitbuf_start_bitnum += delta;
+	}
+	memcpy(trs->bitbuf + trs->bits_in_buf, bits, len);
+	trs->bits_in_buf += len;
+
+	if (trs->state == RX_S_UNLOCKED) {
+		if (trs->bits_in_buf < TG_SLOT_BITS * 2)
+			return (int)len;
+		rc = tetra_find_train_seq(trs->bitbuf, trs->bits_in_buf, 1u << TETRA_TRAIN_SYNC, &offs);
+		if (rc < 0)
+			return rc;
+		if (ch->ev)
+			ch->ev(TGPU_EV_FOUND_SYNC, trs->bitbuf_start_bitnum, offs, ch->priv);
+		trs->state = RX_S_KNOW_FSTART;
+		trs->next_frame_start_bitnum = trs->bitbuf_start_bitnum + offs + 296;
+		return (int)len;
+	}
+
+	if (trs->state == RX_S_KNOW_FSTART) {
+		if (trs->bitbuf_start_bitnum + trs->bits_in_buf < trs->next_frame_start_bitnum)
+			return 0;
+		int skip = (int)(trs->next_frame_start_bitnum - trs->bitbuf_start_bitnum);
+		int keep = (int)trs->bits_in_buf - skip;
+		memmove(trs->bitbuf, trs->bitbuf + skip, (size_t)keep);
+		trs->bits_in_buf = (unsigned int)keep;
+		trs->bitbuf_start_bitnum += (unsigned int)skip;
+		trs->next_frame_start_bitnum += TG_SLOT_BITS;
+		trs->state = RX_S_LOCKED;
+		/* the reference has no break here (:105): the same call goes on as LOCKED */
+	}
+
+	/* RX_S_LOCKED, :106-149 */
+	if (trs->bits_in_buf < TG_SLOT_BITS)
+		return (int)len;
+
+	ch->tn_adds++;				/* tetra_tdma_time_add_tn(&t_phy_state.time, 1), applied at delivery */
+	ch->burst_seq++;
+	if (ch->ev)
+		ch->ev(TGPU_EV_BURST, trs->bitbuf_start_bitnum, trs->bits_in_buf, ch->priv);
+
+	rc = tetra_find_train_seq(trs->bitbuf, trs->bits_in_buf,
+				  (1u << TETRA_TRAIN_NORM_1) | (1u << TETRA_TRAIN_NORM_2) | (1u << TETRA_TRAIN_SYNC), &offs);
+	if (rc == TETRA_TRAIN_SYNC) {
+		if (offs == TG_SYNC_TRAIN_OFF)
+			queue_burst(ch, trs->bitbuf, rc);
+		else {
+			if (ch->ev)
+				ch->ev(TGPU_EV_SYNC_MISPLACED, trs->bitbuf_start_bitnum, offs, ch->priv);
+			trs->state = RX_S_UNLOCKED;
+		}
+	} else if (rc == TETRA_TRAIN_NORM_1 || rc == TETRA_TRAIN_NORM_2) {
+		if (offs == TG_NORM_TRAIN_OFF)
+			queue_burst(ch, trs->bitbuf, rc);
+		else if (ch->ev)
+			ch->ev(TGPU_EV_NORM_MISPLACED, trs->bitbuf_start_bitnum, offs, ch->priv);
+	} else {
+		if (ch->ev)
+			ch->ev(TGPU_EV_NO_TRAIN, trs->bitbuf_start_bitnum, 0, ch->priv);
+		trs->state = RX_S_UNLOCKED;
+	}
+
+	trs->bits_in_buf -= TG_SLOT_BITS;
+	memmove(trs->bitbuf, trs->bitbuf + TG_SLOT_BITS, trs->bits_in_buf);
+	trs->bitbuf_start_bitnum += TG_SLOT_BITS;
+	trs->next_frame_start_bitnum += TG_SLOT_BITS;
+	return (int)len;
+}

@@ -1,0 +1,240 @@
+/*
+ * vit_core.h -- one lane = one trellis: the 16-state Viterbi decoder for the TETRA
+ * rate-1/4 K=5 mother code under 2/3 puncturing, in packed 16-bit arithmetic.
+ *
+ * Replaces (bit-exactly, ties included) what the reference does in
+ *   lower_mac/viterbi.c:6-25 -> lower_mac/viterbi_cch.c:58-66 -> libosmocore
+ *   osmo_conv_decode() (start state 0, 'len' steps + 4 flush steps on erasures,
+ *   traceback from state 0, tie -> predecessor whose oldest bit is 0).
+ *
+ * Design (MI355X-first; compiled for gfx950 by hipcc, and for the host by clang++
+ * in tests/ so the very same code can be checked on a machine without a GPU):
+ *
+ *  - State s = last four input bits, newest in bit 0.  Butterfly j (0..7):
+ *    predecessors j and j+8, successors 2j and 2j+1.  All four generator
+ *    polynomials contain 1 and D^4, so out(j+8,b) = ~out(j,b) and out(j,1) = ~out(j,0):
+ *    with m = Hamming distance of the received bits to out(j,0) and n received bits,
+ *        new[2j]   = min(pm[j] + m,     pm[j+8] + n - m)
+ *        new[2j+1] = min(pm[j] + n - m, pm[j+8] + m)
+ *  - Eight VGPRs Z[0..7]; Z[k] holds states 2k (low half) and 2k+1 (high half).
+ *    Each half: [15:8] path metric, [7:0] the last <=8 decisions of that state's
+ *    survivor.  A butterfly is two v_pk_add_u16 (op_sel broadcasts the predecessor
+ *    half) and one v_pk_min_u16.
+ *  - Tie rule and decision recording in one go: the candidate coming from
+ *    predecessor j+8 gets bit i of the low byte added (i = step index inside the
+ *    current 8-step block).  Bits above i are still clear, bits below i are older
+ *    decisions of the respective survivors, so on equal metrics the j candidate is
+ *    smaller (tie -> j, i.e. oldest bit 0) and the winner's bit i records the choice.
+ *    The low byte travels with the selected predecessor, i.e. it is that survivor's
+ *    decision history (register exchange inside the metric word).
+ *  - Decision d_k (step k) equals input bit u_(k-4).  After 4 lead-in steps every
+ *    8-step block therefore leaves, in each state's low byte, 8 decoded bits of that
+ *    state's survivor; they are extracted (v_perm_b32) to LDS, 16 bytes per block.
+ *    Traceback hops block-wise: byte b of the output = hist[b][s],
+ *    next s = bitreverse4(hist & 15).  len/8 dependent LDS reads instead of len+4.
+ *  - Hamming metrics: spread <= 6 after the lead-in, growth <= 1.5/step, so 8 bits
+ *    suffice for 148 steps; the 292-step SCH/F trellis subtracts the minimum once.
+ */
+#ifndef VIT_CORE_H
+#define VIT_CORE_H
+
+#include <stdint.h>
+
+#if defined(__HIP__) || defined(__HIPCC__)
+#define TG_HD __host__ __device__ __forceinline__
+#else
+#define TG_HD static inline __attribute__((always_inline))
+#endif
+
+typedef unsigned short tg_us2 __attribute__((ext_vector_type(2)));
+
+TG_HD tg_us2 tg_as_us2(uint32_t x) { return __builtin_bit_cast(tg_us2, x); }
+TG_HD uint32_t tg_as_u32(tg_us2 x) { return __builtin_bit_cast(uint32_t, x); }
+TG_HD tg_us2 tg_min(tg_us2 a, tg_us2 b) { return __builtin_elementwise_min(a, b); }
+
+TG_HD uint32_t tg_pack_bytes02(uint32_t z0, uint32_t z1)
+{
+	/* (z0.b0, z0.b2, z1.b0, z1.b2) -> one dword; a single v_perm_b32 on gfx950 */
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_perm(z1, z0, 0x06040200u);
+#else
+	return (z0 & 0xff) | ((z0 >> 8) & 0xff00) | ((z1 & 0xff) << 16) | ((z1 << 8) & 0xff000000u);
+#endif
+}
+
+TG_HD uint32_t tg_brev4(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_bitreverse32(x) >> 28;
+#else
+	x &= 15;
+	return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3);
+#endif
+}
+
+#define TG_VIT_INF   0x4000u	/* metric 64: large enough to lose, small enough not to wrap */
+
+struct tg_vit_state {
+	tg_us2 Z[8];
+};
+
+TG_HD void tg_vit_init(tg_vit_state &v)
+{
+	v.Z[0] = tg_as_us2(TG_VIT_INF << 16);	/* state 0: metric 0, state 1: INF */
+#pragma unroll
+	for (int k = 1; k < 8; k++)
+		v.Z[k] = tg_as_us2(TG_VIT_INF | (TG_VIT_INF << 16));
+}
+
+/*
+ * One add-compare-select step over the 8 butterflies.
+ *   P, Q   : (m, w) << 8 for the two base output classes;  Pt, Qt = P, Q + tie in both halves
+ *   SWMASK : bit j set -> butterfly j uses the swapped pair (w, m)
+ *   QMASK  : bit j set -> butterfly j uses Q/Qt instead of P/Pt
+ */
+template <unsigned SWMASK, unsigned QMASK>
+TG_HD void tg_acs(tg_vit_state &v, tg_us2 P, tg_us2 Pt, tg_us2 Q, tg_us2 Qt)
+{
+	tg_us2 N[8];
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		const tg_us2 za = v.Z[j >> 1], zb = v.Z[4 + (j >> 1)];
+		const tg_us2 a = (j & 1) ? za.yy : za.xx;
+		const tg_us2 b = (j & 1) ? zb.yy : zb.xx;
+		const tg_us2 inc = ((QMASK >> j) & 1) ? Q : P;
+		const tg_us2 inct = ((QMASK >> j) & 1) ? Qt : Pt;
+		const bool sw = (SWMASK >> j) & 1;
+		const tg_us2 x = a + (sw ? inc.yx : inc);
+		const tg_us2 y = b + (sw ? inct : inct.yx);
+		N[j] = tg_min(x, y);
+	}
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		v.Z[j] = N[j];
+}
+
+/* out(j,0) = {0,11,6,13,5,14,3,8} (lower_mac/viterbi_cch.c:35-40): (g1,g2) per butterfly
+ *   j: 0:(0,0) 1:(1,0) 2:(0,1) 3:(1,1) 4:(0,1) 5:(1,1) 6:(0,0) 7:(1,0)
+ * two received bits (g1,g2): base class P = (0,0) {j=0,6}, swapped (1,1) {3,5};
+ *                            base class Q = (1,0) {j=1,7}, swapped (0,1) {2,4}
+ * one received bit (g1):     P = g1=0 {0,2,4,6}, swapped g1=1 {1,3,5,7}             */
+#define TG_SW_A 0x3cu	/* j = 2,3,4,5 */
+#define TG_Q_A  0x96u	/* j = 1,2,4,7 */
+#define TG_SW_B 0xaau	/* j = 1,3,5,7 */
+#define TG_Q_B  0x00u
+
+/* step with two received bits r1 (g1), r2 (g2); f = r1 | r2<<1; tie2 = (1<<i) * 0x10001 */
+TG_HD void tg_step_a(tg_vit_state &v, uint32_t f, uint32_t tie2)
+{
+	const uint32_t s = (f & 1) + (f >> 1);			/* mismatches vs (0,0) */
+	const uint32_t u = ((f & 1) ^ 1) + (f >> 1);		/* mismatches vs (1,0) */
+	const uint32_t P = s * 0xff000100u + 0x02000000u;	/* (s, 2-s) << 8 */
+	const uint32_t Q = u * 0xff000100u + 0x02000000u;
+	tg_acs<TG_SW_A, TG_Q_A>(v, tg_as_us2(P), tg_as_us2(P + tie2), tg_as_us2(Q), tg_as_us2(Q + tie2));
+}
+
+/* step with one received bit r (g1) */
+TG_HD void tg_step_b(tg_vit_state &v, uint32_t r, uint32_t tie2)
+{
+	const uint32_t P = r * 0xff000100u + 0x01000000u;	/* (r, 1-r) << 8 */
+	tg_acs<TG_SW_B, TG_Q_B>(v, tg_as_us2(P), tg_as_us2(P + tie2), tg_as_us2(P), tg_as_us2(P + tie2));
+}
+
+/* flush step: nothing received */
+TG_HD void tg_step_flush(tg_vit_state &v, uint32_t tie2)
+{
+	tg_acs<0, 0>(v, tg_as_us2(0), tg_as_us2(tie2), tg_as_us2(0), tg_as_us2(tie2));
+}
+
+TG_HD void tg_vit_clean(tg_vit_state &v)
+{
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		v.Z[k] = tg_as_us2(tg_as_u32(v.Z[k]) & 0xff00ff00u);
+}
+
+/* the 4 lead-in steps: 6 received bits in bits 0..5 of 'six' */
+TG_HD void tg_vit_leadin(tg_vit_state &v, uint32_t six)
+{
+	tg_step_a(v, six & 3, 0x00010001u);
+	tg_step_b(v, (six >> 2) & 1, 0x00020002u);
+	tg_step_a(v, (six >> 3) & 3, 0x00040004u);
+	tg_step_b(v, (six >> 5) & 1, 0x00080008u);
+	tg_vit_clean(v);
+}
+
+/* one 8-step block on 12 received bits (bits 0..11 of 'tw'); LAST: only the first
+ * 4 steps receive bits (6), the other 4 are the K-1 flush steps. */
+template <bool LAST>
+TG_HD void tg_vit_block(tg_vit_state &v, uint32_t tw, uint32_t h[4])
+{
+	tg_step_a(v, tw & 3, 0x00010001u);
+	tg_step_b(v, (tw >> 2) & 1, 0x00020002u);
+	tg_step_a(v, (tw >> 3) & 3, 0x00040004u);
+	tg_step_b(v, (tw >> 5) & 1, 0x00080008u);
+	if (LAST) {
+		tg_step_flush(v, 0x00100010u);
+		tg_step_flush(v, 0x00200020u);
+		tg_step_flush(v, 0x00400040u);
+		tg_step_flush(v, 0x00800080u);
+	} else {
+		tg_step_a(v, (tw >> 6) & 3, 0x00100010u);
+		tg_step_b(v, (tw >> 8) & 1, 0x00200020u);
+		tg_step_a(v, (tw >> 9) & 3, 0x00400040u);
+		tg_step_b(v, (tw >> 11) & 1, 0x00800080u);
+	}
+#pragma unroll
+	for (int d = 0; d < 4; d++)
+		h[d] = tg_pack_bytes02(tg_as_u32(v.Z[2 * d]), tg_as_u32(v.Z[2 * d + 1]));
+	tg_vit_clean(v);
+}
+
+/* subtract the smallest path metric from all 16 (only between blocks: low bytes are clear) */
+TG_HD void tg_vit_normalize(tg_vit_state &v)
+{
+	tg_us2 m01 = tg_min(v.Z[0], v.Z[1]), m23 = tg_min(v.Z[2], v.Z[3]);
+	tg_us2 m45 = tg_min(v.Z[4], v.Z[5]), m67 = tg_min(v.Z[6], v.Z[7]);
+	tg_us2 m = tg_min(tg_min(m01, m23), tg_min(m45, m67));
+	m = tg_min(m, m.yx);
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		v.Z[k] = v.Z[k] - m;
+}
+
+/* ---- CRC-16/CCITT over the decoded bit string (lower_mac/crc_simple.c:65-82) ---- */
+/* table[x] for x = 8 input bits given LSB-first (bit i of x is the (i+1)-th bit fed) */
+static inline uint16_t tg_crc16_step_bits(uint16_t crc, uint32_t bits_lsb_first, int n)
+{
+	for (int i = 0; i < n; i++) {
+		crc ^= (uint16_t)(((bits_lsb_first >> i) & 1) << 15);
+		crc = (crc & 0x8000) ? (uint16_t)((crc << 1) ^ 0x1021) : (uint16_t)(crc << 1);
+	}
+	return crc;
+}
+
+static inline void tg_crc16_make_table(uint16_t tab[256])
+{
+	for (int x = 0; x < 256; x++)
+		tab[x] = tg_crc16_step_bits(0, (uint32_t)x, 8);
+}
+
+/* crc over nbits = 8*nfull + 4 bits held LSB-first in bytes[]; tab from tg_crc16_make_table.
+ * CRC is linear: crc(state, byte) = crc(state, 0) ^ tab[byte]; crc(state,0) over 8 zero
+ * bits = (state << 8) ^ tabz[state >> 8] where tabz is the classic MSB-first table, which
+ * equals tab[bitrev8(.)]; we fold that by also passing tabm (MSB-first table).            */
+template <typename TabFn>
+TG_HD uint16_t tg_crc16_bytes(const uint8_t *bytes, int nfull, TabFn tab_lsb, TabFn tab_msb)
+{
+	uint16_t crc = 0xffff;
+	for (int i = 0; i < nfull; i++)
+		crc = (uint16_t)((crc << 8) ^ tab_msb(crc >> 8) ^ tab_lsb(bytes[i]));
+	/* trailing 4 bits */
+	uint32_t nib = bytes[nfull] & 15;
+	for (int i = 0; i < 4; i++) {
+		crc ^= (uint16_t)(((nib >> i) & 1) << 15);
+		crc = (crc & 0x8000) ? (uint16_t)((crc << 1) ^ 0x1021) : (uint16_t)(crc << 1);
+	}
+	return crc;
+}
+
+#endif

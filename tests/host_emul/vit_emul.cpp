@@ -1,0 +1,104 @@
+/*
+ * vit_emul.cpp -- compiles the product's per-lane trellis code (osmo-tetra_amd/csrc/vit_core.h)
+ * and its bit layout (tg_layout.h) for the HOST, so that the exact arithmetic the HIP kernels
+ * run can be checked against the oracle on a machine without a GPU.
+ *
+ * TEST INFRASTRUCTURE: lives under tests/, is never loaded by the product library.
+ */
+#include <stdint.h>
+#include <string.h>
+
+#include "tg_layout.h"
+#include "vit_core.h"
+
+static uint16_t crc_lsb[256], crc_msb[256];
+static bool crc_ready;
+
+static void crc_init()
+{
+	if (crc_ready)
+		return;
+	tg_crc16_make_table(crc_lsb);
+	for (int x = 0; x < 256; x++) {
+		int rv = 0;
+		for (int i = 0; i < 8; i++)
+			if (x & (1 << i))
+				rv |= 0x80 >> i;
+		crc_msb[x] = crc_lsb[rv];
+	}
+	crc_ready = true;
+}
+
+/* pack the type-4 bits (already descrambled, stream order inside the block) of one block */
+extern "C" void emul_pack_block(int kind, const uint8_t *type4, uint32_t *words)
+{
+	const int nw = tg_kind_nblk(kind) / 2;
+	for (int d = 0; d < nw; d++) {
+		uint32_t w = 0;
+		for (int p = 0; p < 32; p++) {
+			int j = tg_codeword_src(kind, d, p);
+			if (j >= 0 && (type4[j] & 1))
+				w |= 1u << p;
+		}
+		words[d] = w;
+	}
+}
+
+/* decode one block from packed words; out_bits: type-2 bits (8*nblk of them), returns crc */
+extern "C" unsigned emul_decode_words(int kind, const uint32_t *words, uint8_t *out_bits)
+{
+	crc_init();
+	const int nblk = tg_kind_nblk(kind), nw = nblk / 2;
+	static uint8_t hist[36][16];
+	tg_vit_state v;
+	tg_vit_init(v);
+	tg_vit_leadin(v, words[0] >> 24);
+	for (int it = 0; it < nw; it++) {
+		uint32_t h[4];
+		tg_vit_block<false>(v, words[it], h);
+		memcpy(hist[2 * it], h, 16);
+		if (it == nw - 1)
+			tg_vit_block<true>(v, words[it] >> 12, h);
+		else
+			tg_vit_block<false>(v, words[it] >> 12, h);
+		memcpy(hist[2 * it + 1], h, 16);
+		if (kind == TG_KIND_432 && it == 8)
+			tg_vit_normalize(v);
+	}
+	uint8_t bytes[37] = { 0 };
+	uint32_t s = 0;
+	for (int b = nblk - 1; b >= 0; b--) {
+		uint8_t byte = hist[b][s];
+		bytes[b] = byte;
+		s = tg_brev4(byte);
+	}
+	for (int i = 0; i < 8 * nblk; i++)
+		out_bits[i] = (bytes[i >> 3] >> (i & 7)) & 1;
+	auto tl = [](uint32_t x) -> uint16_t { return crc_lsb[x & 255]; };
+	auto tm = [](uint32_t x) -> uint16_t { return crc_msb[x & 255]; };
+	(void)tm;
+	/* same recurrence as the kernel */
+	uint32_t crc = 0xffff;
+	for (int i = 0; i < nblk - 1; i++)
+		crc = ((crc << 8) & 0xffff) ^ crc_msb[crc >> 8] ^ tl(bytes[i]);
+	uint32_t nib = bytes[nblk - 1] & 15;
+	for (int i = 0; i < 4; i++) {
+		crc ^= ((nib >> i) & 1) << 15;
+		crc = (crc & 0x8000) ? (((crc << 1) ^ 0x1021) & 0xffff) : ((crc << 1) & 0xffff);
+	}
+	return crc;
+}
+
+/* the slot-level gather the front kernel performs (same table function) */
+extern "C" void emul_pack_slot(int btype, const uint8_t *slot, uint32_t *words20)
+{
+	for (int w = 0; w < TG_PACKED_WORDS; w++) {
+		uint32_t x = 0;
+		for (int p = 0; p < 32; p++) {
+			int o = tg_packed_src(btype, w, p);
+			if (o >= 0 && (slot[o] & 1))
+				x |= 1u << p;
+		}
+		words20[w] = x;
+	}
+}

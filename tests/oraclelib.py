@@ -158,7 +158,7 @@ def lib():
     L.orc_float_to_bits.argtypes = [C.POINTER(C.c_float), C.c_size_t, u8p, C.c_int, C.c_float, C.c_float,
                                     C.POINTER(C.c_float)]
     L.orc_bench_decode_slots.restype = C.c_uint64
-    L.orc_bench_decode_slots.argtypes = [u8p, u8p, C.c_size_t, C.c_uint32, C.c_int, u8p]
+    L.orc_bench_decode_slots.argtypes = [u8p, u8p, C.c_size_t, C.c_uint32, C.c_int, u8p, C.POINTER(C.c_uint16)]
     _lib = L
     return L
 
@@ -333,12 +333,16 @@ def run_rx(stream, chunk=64, use_acc=0, upper=None):
     return recs, events
 
 
-def bench_decode_slots(slots, types, scramb_init=0, use_acc=0, want_out=False):
+def bench_decode_slots(slots, types, scramb_init=0, use_acc=0, want_out=False, want_crc=False):
     slots = np.ascontiguousarray(slots, np.uint8)
     types = np.ascontiguousarray(types, np.uint8)
     n = len(types)
     out = np.zeros((n, 288), np.uint8) if want_out else None
-    ok = lib().orc_bench_decode_slots(_p(slots), _p(types), n, scramb_init, use_acc, _p(out) if want_out else None)
+    crc = np.zeros((n, 2), np.uint16) if want_out else None
+    ok = lib().orc_bench_decode_slots(_p(slots), _p(types), n, scramb_init, use_acc, _p(out) if want_out else None,
+                                      crc.ctypes.data_as(C.POINTER(C.c_uint16)) if want_out else None)
+    if want_crc:
+        return ok, out, crc
     return ok, out
 
 

@@ -1,0 +1,341 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle.
+
+Bit-exact bar: type-1 bits, crc16, crc_ok, scrambling code, lchan, TDMA time, call order.
+Run on the GPU box with:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+import oraclelib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (the HIP path has no fallback)")
+    import osmo_tetra_amd as T
+    T.lib()  # must load the in-tree libtetra_gpu.so
+    return T
+
+
+@pytest.fixture(scope="module")
+def eng(T):
+    e = T.Engine(0)
+    yield e
+    e.close()
+
+
+def run_plan(T, eng, slots, types, chan=None, codes=None, stride=510, offsets=None):
+    """slots: (n,510) host array -> parsed records"""
+    import torch
+    n = len(types)
+    if offsets is None:
+        buf = np.zeros(n * stride + 64, np.uint8)
+        offsets = np.arange(n, dtype=np.uint64) * stride
+        for i in range(n):
+            buf[i * stride:i * stride + 510] = slots[i]
+    else:
+        buf = slots
+    d_stream = torch.from_numpy(buf).cuda()
+    d_rec = torch.zeros(max(n, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, max(n, 1), 1 if chan is None else int(max(chan)) + 1)
+    plan.load(offsets, types, chan, codes)
+    plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rec = d_rec.cpu().numpy().reshape(-1, T.REC_BYTES)[:n]
+    codes_out = plan.final_codes()
+    plan.close()
+    return rec, T.parse_records(rec), codes_out
+
+
+def check_against_oracle(T, rec, types, slots, code):
+    ok, want, wcrc = O.bench_decode_slots(slots, types, code, want_out=True, want_crc=True)
+    p = T.parse_records(rec)
+    n1 = types == O.TRAIN_NORM_1
+    n2 = types == O.TRAIN_NORM_2
+    sb = types == O.TRAIN_SYNC
+    assert (p["type"] == types).all()
+    assert (p["bbk"] == want[:, :14]).all()
+    assert (p["bits1"][n1] == want[n1, 14:14 + 268]).all()
+    assert (p["bits1"][n2][:, :124] == want[n2, 14:14 + 124]).all()
+    assert (p["bits2"][n2] == want[n2, 138:138 + 124]).all()
+    assert (p["bits1"][sb][:, :60] == want[sb, 14:14 + 60]).all()
+    assert (p["bits2"][sb] == want[sb, 138:138 + 124]).all()
+    assert (p["crc"][:, 0] == wcrc[:, 0]).all()
+    two = n2 | sb
+    assert (p["crc"][two, 1] == wcrc[two, 1]).all()
+    assert ((p["crc"][:, 0] == 0x1D0F) == (p["crc_ok"][:, 0] == 1)).all()
+    assert ((p["crc"][two, 1] == 0x1D0F) == (p["crc_ok"][two, 1] == 1)).all()
+    return ok, p
+
+
+@pytest.mark.parametrize("ber", [0.0, 0.02, 0.06])
+def test_config2_ndb_parity(T, eng, ber):
+    """BASELINE config 2 at oracle-sized n: aligned NDB slots, scramb_init = 0, BER 0 and noisy (ties!)"""
+    n = 6000
+    rng = np.random.default_rng(7)
+    types = np.where(rng.random(n) < 0.5, O.TRAIN_NORM_1, O.TRAIN_NORM_2).astype(np.uint8)
+    slots = T.synth_slots(types, seed=11, scramb_init=0, ber=ber)
+    rec, p, _ = run_plan(T, eng, slots, types)
+    ok, p = check_against_oracle(T, rec, types, slots, 0)
+    nblocks = int((types == O.TRAIN_NORM_1).sum() + 2 * (types == O.TRAIN_NORM_2).sum())
+    if ber == 0.0:
+        assert ok == nblocks
+    else:
+        assert 0 < ok < nblocks or ber < 0.03
+
+
+def test_garbage_and_extreme_inputs(T, eng):
+    """random bits, all-ones, all-zeros in the coded fields: worst-case metrics and ties everywhere"""
+    rng = np.random.default_rng(3)
+    n = 900
+    types = np.array([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_NORM_2] * (n // 3), np.uint8)
+    slots = rng.integers(0, 2, (n, 510)).astype(np.uint8)
+    slots[0:3] = 0
+    slots[3:6] = 1
+    slots[6:9, ::2] = 0
+    rec, p, _ = run_plan(T, eng, slots, types)
+    # SB1 of garbage essentially never passes CRC, so the code stays 0 for BBK/SB2
+    if (p["crc_ok"][types == O.TRAIN_SYNC, 0] == 0).all():
+        check_against_oracle(T, rec, types, slots, 0)
+
+
+def test_sync_slots_set_scrambling_code(T, eng):
+    """feedback loop 1: a CRC-OK SB1 switches the code for its own BBK/SB2 and everything after"""
+    cells = [(262, 42, 1), (901, 77, 9)]
+    rng = np.random.default_rng(5)
+    parts, types = [], []
+    for (mcc, mnc, cc) in cells:
+        code = O.scramb_get_init(mcc, mnc, cc)
+        ty = np.array([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_NORM_2, O.TRAIN_NORM_2, O.TRAIN_NORM_1] * 6, np.uint8)
+        parts.append(T.synth_slots(ty, seed=int(rng.integers(1 << 30)), scramb_init=code, mcc=mcc, mnc=mnc, cc=cc,
+                                   ber=0.01))
+        types.append(ty)
+    slots, types = np.concatenate(parts), np.concatenate(types)
+    # prepend NDB slots scrambled with code 0: before the first SB the channel has no code
+    pre_t = np.array([O.TRAIN_NORM_2, O.TRAIN_NORM_1], np.uint8)
+    pre = T.synth_slots(pre_t, seed=99, scramb_init=0)
+    slots, types = np.concatenate([pre, slots]), np.concatenate([pre_t, types])
+    rec, p, codes_out = run_plan(T, eng, slots, types)
+    exp_code = np.zeros(len(types), np.uint32)
+    exp_code[2:32] = O.scramb_get_init(*cells[0])
+    exp_code[32:] = O.scramb_get_init(*cells[1])
+    assert (p["code"] == exp_code).all()
+    assert codes_out[0] == O.scramb_get_init(*cells[1])
+    for lo, hi, c in ((0, 2, 0), (2, 32, O.scramb_get_init(*cells[0])), (32, 62, O.scramb_get_init(*cells[1]))):
+        check_against_oracle(T, rec[lo:hi], types[lo:hi], slots[lo:hi], c)
+    sb = np.where(types == O.TRAIN_SYNC)[0]
+    assert (p["crc_ok"][sb, 0] == 1).all()
+    assert (p["sbf1"][sb[0]] & 0xFFFF) == 262 and (p["sbf1"][sb[-1]] >> 16) == 77
+    assert (p["sbcode"][sb] == exp_code[sb]).all()
+
+
+def test_failed_sb1_keeps_previous_code(T, eng):
+    code = O.scramb_get_init(262, 42, 1)
+    ty = np.array([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_SYNC, O.TRAIN_NORM_2], np.uint8)
+    slots = T.synth_slots(ty, seed=3, scramb_init=code)
+    slots[2, 94:214] ^= (np.arange(120) % 3 == 0).astype(np.uint8)   # destroy the second SB1
+    rec, p, _ = run_plan(T, eng, slots, ty)
+    assert p["crc_ok"][2, 0] == 0
+    assert (p["code"] == code).all()
+    check_against_oracle(T, rec, ty, slots, code)
+
+
+def test_multi_channel_plan_and_carry_in(T, eng):
+    """several channels in one batch, each with its own carry-in code (channel-major shards)"""
+    rng = np.random.default_rng(8)
+    cells = [(262, 42, 1), (1, 2, 3), (1023, 16383, 63), (500, 500, 50)]
+    slots, types, chan, codes = [], [], [], []
+    for c, cell in enumerate(cells):
+        code = O.scramb_get_init(*cell)
+        n = int(rng.integers(5, 40))
+        ty = rng.choice([O.TRAIN_NORM_1, O.TRAIN_NORM_2], n).astype(np.uint8)
+        slots.append(T.synth_slots(ty, seed=100 + c, scramb_init=code, ber=0.02))
+        types.append(ty)
+        chan.append(np.full(n, c, np.uint32))
+        codes.append(code)
+    slots, types, chan = np.concatenate(slots), np.concatenate(types), np.concatenate(chan)
+    rec, p, codes_out = run_plan(T, eng, slots, types, chan, np.array(codes, np.uint32))
+    assert (codes_out == np.array(codes, np.uint32)).all()
+    for c, code in enumerate(codes):
+        m = chan == c
+        assert (p["code"][m] == code).all()
+        check_against_oracle(T, rec[m], types[m], slots[m], code)
+
+
+def test_edge_cases(T, eng):
+    import torch
+    # empty batch
+    plan = T.Plan(eng, 4, 1)
+    plan.load(np.zeros(0, np.uint64), np.zeros(0, np.uint8))
+    d = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    plan.execute(d.data_ptr(), d.data_ptr())
+    # capacity / argument errors are reported, not ignored
+    with pytest.raises(T.TgpuError):
+        plan.load(np.zeros(5, np.uint64), np.zeros(5, np.uint8))
+    with pytest.raises(T.TgpuError):
+        plan.load(np.zeros(2, np.uint64), np.zeros(2, np.uint8), np.array([1, 0], np.uint32), np.zeros(2, np.uint32))
+    plan.close()
+    # unaligned, ragged offsets + a skipped slot + plan reuse + a single slot
+    ty = np.array([O.TRAIN_NORM_1, 2, O.TRAIN_NORM_2, O.TRAIN_SYNC], np.uint8)   # 2 = NORM_3: ignored like the reference
+    good = ty != 2
+    slots = np.zeros((4, 510), np.uint8)
+    slots[good] = T.synth_slots(ty[good], seed=1, scramb_init=0)
+    offs = np.array([3, 700, 1213, 2001], np.uint64)
+    buf = np.zeros(2600, np.uint8)
+    for o, s in zip(offs, slots):
+        buf[int(o):int(o) + 510] = s
+    rec, p, _ = run_plan(T, eng, buf, ty, offsets=offs)
+    assert p["type"][1] != O.TRAIN_NORM_1
+    check_against_oracle(T, rec[[0, 2]], ty[[0, 2]], slots[[0, 2]], 0)
+    rec1, p1, _ = run_plan(T, eng, slots[:1], ty[:1])
+    assert (rec1[0, 32:320] == rec[0, 32:320]).all()
+    # non-binary stream bytes are flagged (the reference's contract is 0/1 bytes)
+    bad = slots[:1].copy()
+    bad[0, 100] = 7
+    _, pb, _ = run_plan(T, eng, bad, ty[:1])
+    assert pb["flags"][0] & 1 and not p1["flags"][0] & 1
+
+
+# ---------------------------------------------------------------------------
+# channel API: tetra_burst_sync_in() + callbacks vs the oracle receiver
+# ---------------------------------------------------------------------------
+KEYS = ("burst_seq", "burst_type", "type", "blk_num", "lchan", "crc_ok", "traffic", "crc", "scramb", "time", "type1")
+
+
+def assert_same_records(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        for k in KEYS:
+            if w["traffic"] and k in ("crc", "crc_ok", "type1", "lchan"):
+                continue
+            assert g[k] == w[k], (k, g["burst_seq"], g["type"])
+        if w["traffic"]:
+            assert g["type4"] == w["type4"]
+
+
+@pytest.mark.parametrize("batch", [1, 7, 64])
+@pytest.mark.parametrize("ber", [0.0, 0.03])
+def test_channel_stream_parity(T, eng, batch, ber):
+    stream, _ = synth.frame_stream(seed=21, nframes=6, ber=ber)
+    want, wev = O.run_rx(stream)
+    ch = T.Channel(eng, batch_slots=batch)
+    ch.feed(stream)
+    ch.flush()
+    assert_same_records(ch.records, want)
+    assert ch.events == wev
+    ch.close()
+
+
+def test_channel_relock_and_spurious_training_sequence(T, eng):
+    stream, slots = synth.frame_stream(seed=22, nframes=5)
+    s = stream.copy()
+    pos0 = 100 + 510
+    s[pos0 + 510 * 5 + 244 + 3] ^= 1          # corrupt a NORM training sequence -> loss of lock
+    s[pos0 + 510 * 20 + 50:pos0 + 510 * 20 + 72] = np.array(
+        [1, 1, 0, 1, 0, 0, 0, 0, 1, 1, 1, 0, 1, 0, 0, 1, 1, 1, 0, 1, 0, 0], np.uint8)  # n-sequence inside a payload
+    want, wev = O.run_rx(s)
+    ch = T.Channel(eng, batch_slots=16)
+    ch.feed(s)
+    ch.flush()
+    assert_same_records(ch.records, want)
+    assert ch.events == wev
+    assert any(e[0] == 5 for e in wev) and any(e[0] in (3, 4) for e in wev)
+    ch.close()
+
+
+def test_channel_traffic_feedback(T, eng):
+    """feedback loops 2/3: the callback (standing in for the upper MAC) flags traffic from the AACH
+    and 'block 2 stolen' from block 1; blocks are then dumped / decoded exactly as in the reference"""
+    rng = np.random.default_rng(31)
+    cell = synth.Cell()
+    aach_traffic = np.array([0, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0], np.uint8)
+    parts = [rng.integers(0, 2, 77).astype(np.uint8), synth.make_sb(rng, cell, 1, 1, 1), synth.make_sb(rng, cell, 2, 1, 1)]
+    for i in range(12):
+        a = aach_traffic if i % 3 else None
+        parts.append(synth.make_norm2(rng, cell.code, a) if i % 2 else synth.make_norm1(rng, cell.code, a))
+    parts.append(np.zeros(700, np.uint8))
+    stream = np.concatenate(parts)
+
+    def upper_common(set_traffic, set_stolen, d):
+        if d["type"] == O.T_BBK:
+            set_traffic(5 if d["type1"][1] == 1 else 0)
+            set_stolen(False)
+        elif d["type"] == O.T_NDB and d["blk_num"] == 1 and d["burst_seq"] % 4 == 0:
+            set_stolen(True)
+        return -1
+
+    def o_upper(rx, d, offset):
+        def st(v): rx.is_traffic = v
+        def ss(v): rx.blk2_stolen = int(v)
+        return upper_common(st, ss, d)
+
+    want, _ = O.run_rx(stream, upper=o_upper)
+    assert any(r["traffic"] for r in want) and any(not r["traffic"] and r["type"] == O.T_NDB for r in want)
+
+    def g_upper(chan, d, offset):
+        return upper_common(chan.set_traffic, chan.set_blk2_stolen, d)
+
+    for batch in (1, 5):
+        ch = T.Channel(eng, batch_slots=batch, on_unitdata=g_upper)
+        ch.feed(stream)
+        ch.flush()
+        assert_same_records(ch.records, want)
+        ch.close()
+
+
+def test_channel_multi_pdu_loop(T, eng):
+    """the callback's return value advances the offset like msg->head (tetra_lower_mac.c:326-352)"""
+    stream, _ = synth.frame_stream(seed=23, nframes=2)
+    calls_o, calls_g = [], []
+
+    def o_upper(rx, d, offset):
+        calls_o.append((d["type"], offset))
+        return 40 if d["type"] in (O.T_SCH_F, O.T_NDB) else -1
+
+    def g_upper(ch, d, offset):
+        calls_g.append((d["type"], offset))
+        return 40 if d["type"] in (O.T_SCH_F, O.T_NDB) else -1
+
+    O.run_rx(stream, upper=o_upper)
+    ch = T.Channel(eng, batch_slots=9, on_unitdata=g_upper)
+    ch.feed(stream)
+    ch.flush()
+    ch.close()
+    assert calls_g == calls_o and any(off > 0 for _, off in calls_g)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE size: size-independent properties
+# ---------------------------------------------------------------------------
+def test_config2_full_size_roundtrip(T, eng):
+    """1M NDB bursts (BASELINE config 2): encode -> decode round trip, every CRC OK, and a 2 % BER
+    second pass whose noise-free blocks must still equal the payload"""
+    import torch
+    n = 1_000_000
+    rng = np.random.default_rng(1)
+    types = np.where(rng.random(n) < 0.5, O.TRAIN_NORM_1, O.TRAIN_NORM_2).astype(np.uint8)
+    slots, t1 = T.synth_slots(types, seed=1, scramb_init=0, want_type1=True)
+    d_stream = torch.from_numpy(slots.reshape(-1)).cuda()
+    d_rec = torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(np.arange(n, dtype=np.uint64) * 510, types)
+    plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    p = T.parse_records(d_rec.cpu().numpy().reshape(n, T.REC_BYTES))
+    n1, n2 = types == O.TRAIN_NORM_1, types == O.TRAIN_NORM_2
+    assert (p["crc_ok"][:, 0] == 1).all() and (p["crc_ok"][n2, 1] == 1).all()
+    assert (p["crc"][:, 0] == 0x1D0F).all()
+    assert (p["bits1"][n1] == t1[n1, 14:282]).all()
+    assert (p["bits1"][n2][:, :124] == t1[n2, 14:138]).all()
+    assert (p["bits2"][n2] == t1[n2, 138:262]).all()
+    assert (p["bbk"] == 0).all()
+    # spot-check a slice against the oracle as well
+    sl = slice(500_000, 500_400)
+    rec_sl = np.ascontiguousarray(d_rec.view(n, T.REC_BYTES)[sl].cpu().numpy())
+    check_against_oracle(T, rec_sl, types[sl], slots[sl], 0)
+    plan.close()
