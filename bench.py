@@ -155,11 +155,11 @@ def main():
         "config": {"workload": "BASELINE config 2: per GPU %d NDB bursts (50%% NORM_1 SCH/F, 50%% NORM_2 2xNDB, + AACH), "
                                "scramb_init=0, BER %g, aligned 510-B slots resident in HBM, records left in HBM" % (n, args.ber),
                    "bursts_per_gpu": n, "parallelism": "independent channels per GPU, no data-path collective"},
-        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": float(achieved) / HBM_PEAK_GBS, "traffic": None,
                      "kernel_ms": float(stage_ms[dom]),
                      "stage_ms": {names[i]: float(stage_ms[i]) for i in range(len(names))},
-                     "pipeline_achieved_gbs_per_gpu": pipeline_gbs,
+                     "pipeline_achieved_gbs_per_gpu": float(pipeline_gbs),
                      "note": "achieved = SURVEY 8(d) algorithmic bytes of the bursts this kernel decodes / its mean "
                              "HIP-event duration on the launch stream; VALU-bound packed-u16 trellis, see DESIGN.md"},
     }

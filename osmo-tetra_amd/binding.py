@@ -79,6 +79,9 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise TgpuError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # PyTorch is the device-memory / stream plumbing, so the library must run on the HIP runtime
+    # torch has loaded (same libamdhip64 SONAME): import torch first, never a second runtime.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.tgpu_strerror.restype = C.c_char_p
     L.tgpu_strerror.argtypes = [C.c_int]

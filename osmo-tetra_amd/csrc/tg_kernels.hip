@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "tg_layout.h"
 #include "vit_core.h"
@@ -36,39 +37,75 @@ __constant__ tg_const_tables c_tab;
 /* k_front                                                                   */
 /* ------------------------------------------------------------------------- */
 /*
- * One wavefront per slot.  Ten gather rounds; in each, lanes 0..31 produce one
- * packed word and lanes 32..63 the next (one stream byte per lane, collapsed with a
- * 64-bit ballot).  The 510 slot bytes are fetched from HBM once (4-5 cache lines) and
- * every further touch is an L1/L2 hit; the 80-byte result goes out as one store.
+ * One wavefront per slot, four independent wavefronts per workgroup.
+ *   1. the 510 slot bytes are read from HBM exactly once, as two coalesced (possibly
+ *      unaligned) dwords per lane, and parked in this wave's 512-byte LDS window;
+ *   2. ten gather rounds: every lane picks one byte out of LDS (its offsets for the three
+ *      burst types live in VGPRs for the whole kernel), a 64-bit ballot collapses them:
+ *      lanes 0..31 form one packed word, lanes 32..63 the next;
+ *   3. the 80-byte packed slot goes out as one coalesced store.
+ * The next slot's dwords are requested before the current slot is processed.  LDS
+ * operations of one wave execute in order, so no barrier is needed between the stages.
  */
+typedef uint32_t __attribute__((aligned(1))) tg_u32_unaligned;
+typedef uint16_t __attribute__((aligned(1))) tg_u16_unaligned;
+
+__device__ __forceinline__ void front_fetch(const uint8_t *base, uint32_t lane, uint32_t &d0, uint32_t &d1)
+{
+	d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
+	/* bytes 256..509: the last dword would read 2 bytes past the slot */
+	if (lane < 63)
+		d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
+	else
+		d1 = *(const tg_u16_unaligned *)(base + 508);
+}
+
 __global__ __launch_bounds__(256)
 void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_off,
 	     const uint8_t *__restrict__ slot_type, uint32_t nslots, uint32_t *__restrict__ packed,
 	     uint8_t *__restrict__ rec)
 {
+	__shared__ uint32_t s_slot[4][128];
+
 	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
 	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
 	const uint32_t half = lane >> 5, bit = lane & 31;
+	uint32_t *mine = s_slot[wib];
+	const uint8_t *mine8 = (const uint8_t *)mine;
 
-	for (uint32_t slot = wave; slot < nslots; slot += nwaves) {
+	/* gather offsets of this lane for the three burst types (0xffff = no source bit) */
+	uint32_t off[3][10];
+#pragma unroll
+	for (int t = 0; t < 3; t++)
+#pragma unroll
+		for (int r = 0; r < 10; r++)
+			off[t][r] = c_tab.front_src[t][2 * r + half][bit];
+
+	uint32_t slot = wave;
+	uint32_t d0 = 0, d1 = 0;
+	if (slot < nslots)
+		front_fetch(stream + slot_off[slot], lane, d0, d1);
+
+	for (; slot < nslots; slot += nwaves) {
 		const uint32_t type = __builtin_amdgcn_readfirstlane(slot_type[slot]);
+		mine[lane] = d0;
+		mine[64 + lane] = d1;
+		const uint32_t nxt = slot + nwaves;
+		if (nxt < nslots)
+			front_fetch(stream + slot_off[nxt], lane, d0, d1);
+
 		uint32_t myword = 0;
 		uint32_t flags = 0;
 		if (type == TG_BURST_NORM_1 || type == TG_BURST_NORM_2 || type == TG_BURST_SYNC) {
-			const uint32_t tix = (type == TG_BURST_SYNC) ? 2 : type;
-			const uint8_t *base = stream + slot_off[slot];
-			uint32_t bytes[10];
-#pragma unroll
-			for (int r = 0; r < 10; r++) {
-				const uint16_t off = c_tab.front_src[tix][2 * r + half][bit];
-				bytes[r] = (off != 0xffff) ? (uint32_t)base[off] : 0u;
-			}
 			uint32_t nonbin = 0;
 #pragma unroll
 			for (int r = 0; r < 10; r++) {
-				const unsigned long long bal = __ballot(bytes[r] & 1);
-				nonbin |= (bytes[r] > 1);
+				const uint32_t o = (type == TG_BURST_SYNC) ? off[2][r] : (type == TG_BURST_NORM_2) ? off[1][r] : off[0][r];
+				const uint32_t byte = (o != 0xffff) ? (uint32_t)mine8[o & 511] : 0u;
+				const unsigned long long bal = __ballot(byte & 1);
+				nonbin |= (byte > 1);
 				myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
 				myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
 			}
@@ -112,8 +149,26 @@ __device__ __forceinline__ uint32_t field_msb(uint32_t lo, uint32_t hi, int sh, 
 }
 #define FIELD_MSB(od, n0, len) field_msb((od)[(n0) >> 5], (od)[((n0) >> 5) + 1], (n0) & 31, (len))
 
-template <int KIND>
-__global__ __launch_bounds__(64)
+typedef uint32_t tg_v32 __attribute__((ext_vector_type(32)));
+
+/* byte 's' (0..15) of the 16 history bytes held in four dwords: two v_perm_b32 + one select */
+__device__ __forceinline__ uint32_t hist_byte(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t s)
+{
+	const uint32_t sel = s & 7;
+	const uint32_t lo = __builtin_amdgcn_perm(w1, w0, sel);
+	const uint32_t hi = __builtin_amdgcn_perm(w3, w2, sel);
+	return ((s & 8) ? hi : lo) & 0xff;
+}
+
+/*
+ * HMODE 0: survivor history in LDS (16 B per lane per 8-step block).
+ * HMODE 1: survivor history in VGPRs -- chunks of 32 registers (8 blocks) written through
+ *          the VGPR index mode (s_set_gpr_idx_on) with a wave-uniform block index, read back
+ *          with static indices by the fully unrolled traceback.  No LDS for the trellis at
+ *          all, so occupancy is set by registers: 2 waves/SIMD for SCH/F, 4 for the 216 blocks.
+ */
+template <int KIND, int HMODE>
+__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (KIND == TG_KIND_432 ? 2 : 4))
 void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
@@ -123,8 +178,9 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	constexpr int NW = NBLK / 2;			/* code words */
 	constexpr int TYPE1 = vit_cfg<KIND>::TYPE1;
 	constexpr int NOD = (NBLK + 3) / 4;		/* dwords of decoded bits */
+	constexpr int NCH = (NBLK + 7) / 8;		/* history chunks of 8 blocks */
 
-	__shared__ uint4 hist[NBLK * 64];
+	__shared__ uint4 hist[(HMODE == 0) ? NBLK * 64 : 1];
 	__shared__ uint16_t s_crc[512];
 
 	const uint32_t lane = threadIdx.x;
@@ -165,37 +221,83 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	uint32_t cur = pw[0] ^ mw[0];
 	tg_vit_leadin(v, cur >> 24);
 
-#pragma unroll 1
-	for (int it = 0; it < NW - 1; it++) {
-		const uint32_t nxt = pw[it + 1] ^ mw[it + 1];
-		uint32_t h[4];
-		tg_vit_block<false>(v, cur, h);
-		hist[(2 * it) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-		tg_vit_block<false>(v, cur >> 12, h);
-		hist[(2 * it + 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-		if (KIND == TG_KIND_432 && it == 8)
-			tg_vit_normalize(v);
-		cur = nxt;
-	}
-	{
-		uint32_t h[4];
-		tg_vit_block<false>(v, cur, h);
-		hist[(NBLK - 2) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-		tg_vit_block<true>(v, cur >> 12, h);
-		hist[(NBLK - 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-	}
-
-	/* block-wise traceback from state 0 */
 	uint32_t od[NOD + 1];
 #pragma unroll
 	for (int i = 0; i <= NOD; i++)
 		od[i] = 0;
-	{
+
+	if (HMODE == 0) {
+#pragma unroll 1
+		for (int it = 0; it < NW - 1; it++) {
+			const uint32_t nxt = pw[it + 1] ^ mw[it + 1];
+			uint32_t h[4];
+			tg_vit_block<false>(v, cur, h);
+			hist[(2 * it) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
+			tg_vit_block<false>(v, cur >> 12, h);
+			hist[(2 * it + 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
+			if (KIND == TG_KIND_432 && it == 8)
+				tg_vit_normalize(v);
+			cur = nxt;
+		}
+		{
+			uint32_t h[4];
+			tg_vit_block<false>(v, cur, h);
+			hist[(NBLK - 2) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
+			tg_vit_block<true>(v, cur >> 12, h);
+			hist[(NBLK - 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
+		}
+		/* block-wise traceback from state 0 */
 		const uint8_t *hb = (const uint8_t *)hist + lane * 16;
 		uint32_t s = 0;
 #pragma unroll
 		for (int b = NBLK - 1; b >= 0; b--) {
 			const uint32_t byte = hb[b * 1024 + s];
+			od[b >> 2] |= byte << ((b & 3) * 8);
+			s = tg_brev4(byte);
+		}
+	} else {
+		tg_v32 H[NCH];
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			const int nblk_c = (NBLK - 8 * c >= 8) ? 8 : (NBLK - 8 * c);
+			const int nit = nblk_c / 2;
+			const bool lastchunk = (c == NCH - 1);
+			const int nloop = lastchunk ? nit - 1 : nit;
+#pragma unroll 1
+			for (int it = 0; it < nloop; it++) {
+				const int g = 4 * c + it;
+				const uint32_t nxt = pw[g + 1] ^ mw[g + 1];
+				uint32_t h[4];
+				tg_vit_block<false>(v, cur, h);
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][8 * it + d] = h[d];
+				tg_vit_block<false>(v, cur >> 12, h);
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][8 * it + 4 + d] = h[d];
+				if (KIND == TG_KIND_432 && g == 8)
+					tg_vit_normalize(v);
+				cur = nxt;
+			}
+			if (lastchunk) {
+				uint32_t h[4];
+				tg_vit_block<false>(v, cur, h);
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][8 * (nit - 1) + d] = h[d];
+				tg_vit_block<true>(v, cur >> 12, h);
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][8 * (nit - 1) + 4 + d] = h[d];
+			}
+		}
+		/* block-wise traceback from state 0, all register indices static */
+		uint32_t s = 0;
+#pragma unroll
+		for (int b = NBLK - 1; b >= 0; b--) {
+			const int c = b >> 3, o = 4 * (b & 7);
+			const uint32_t byte = hist_byte(H[c][o], H[c][o + 1], H[c][o + 2], H[c][o + 3], s);
 			od[b >> 2] |= byte << ((b & 3) * 8);
 			s = tg_brev4(byte);
 		}
@@ -469,12 +571,18 @@ static void build_tables(tg_const_tables *t)
 	}
 }
 
+/* survivor-history placement of the trellis kernels: 1 = VGPRs (default), 0 = LDS.
+ * Tuning knob for A/B runs (environment TGPU_HIST_MODE), both are bit-identical. */
+static int tgk_hist_mode = 1;
+
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 extern "C" int tgk_init(void)
 {
 	static tg_const_tables host;
 	build_tables(&host);
+	if (const char *e = getenv("TGPU_HIST_MODE"))
+		tgk_hist_mode = atoi(e) ? 1 : 0;
 	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &host, sizeof(host)));
 	return 0;
 }
@@ -500,19 +608,22 @@ extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const
 		return 0;
 	const dim3 grid((nitems + 63) / 64), block(64);
 	hipStream_t s = (hipStream_t)stream;
+#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code)
+	const int hm = tgk_hist_mode;
 	switch (kind) {
 	case TG_KIND_SB1:
-		hipLaunchKernelGGL(k_vit<TG_KIND_SB1>, grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code);
+		if (hm) VIT_LAUNCH(TG_KIND_SB1, 1); else VIT_LAUNCH(TG_KIND_SB1, 0);
 		break;
 	case TG_KIND_216:
-		hipLaunchKernelGGL(k_vit<TG_KIND_216>, grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code);
+		if (hm) VIT_LAUNCH(TG_KIND_216, 1); else VIT_LAUNCH(TG_KIND_216, 0);
 		break;
 	case TG_KIND_432:
-		hipLaunchKernelGGL(k_vit<TG_KIND_432>, grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code);
+		if (hm) VIT_LAUNCH(TG_KIND_432, 1); else VIT_LAUNCH(TG_KIND_432, 0);
 		break;
 	default:
 		return -1;
 	}
+#undef VIT_LAUNCH
 	return (int)hipGetLastError();
 }
 

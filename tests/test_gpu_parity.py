@@ -121,17 +121,28 @@ def test_sync_slots_set_scrambling_code(T, eng):
     pre = T.synth_slots(pre_t, seed=99, scramb_init=0)
     slots, types = np.concatenate([pre, slots]), np.concatenate([pre_t, types])
     rec, p, codes_out = run_plan(T, eng, slots, types)
+    # expected code per slot: replay the oracle's SB1 decodes (a noisy SB1 may fail its CRC)
     exp_code = np.zeros(len(types), np.uint32)
-    exp_code[2:32] = O.scramb_get_init(*cells[0])
-    exp_code[32:] = O.scramb_get_init(*cells[1])
+    cur, nfail = 0, 0
+    for i, t in enumerate(types):
+        if t == O.TRAIN_SYNC:
+            t1, crc, ok, _ = O.decode_block(O.T_SB1, slots[i][94:214], 3)
+            if ok:
+                f = lambda a, n: int("".join(map(str, t1[a:a + n])), 2)
+                cur = O.scramb_get_init(f(31, 10), f(41, 14), f(4, 6))
+            else:
+                nfail += 1
+        exp_code[i] = cur
     assert (p["code"] == exp_code).all()
     assert codes_out[0] == O.scramb_get_init(*cells[1])
-    for lo, hi, c in ((0, 2, 0), (2, 32, O.scramb_get_init(*cells[0])), (32, 62, O.scramb_get_init(*cells[1]))):
-        check_against_oracle(T, rec[lo:hi], types[lo:hi], slots[lo:hi], c)
+    assert set(exp_code.tolist()) == {0, O.scramb_get_init(*cells[0]), O.scramb_get_init(*cells[1])}
+    # every run of slots that shares a code must match the oracle decoding with that code
+    bounds = [0] + [i for i in range(1, len(types)) if exp_code[i] != exp_code[i - 1]] + [len(types)]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        check_against_oracle(T, rec[lo:hi], types[lo:hi], slots[lo:hi], int(exp_code[lo]))
     sb = np.where(types == O.TRAIN_SYNC)[0]
-    assert (p["crc_ok"][sb, 0] == 1).all()
-    assert (p["sbf1"][sb[0]] & 0xFFFF) == 262 and (p["sbf1"][sb[-1]] >> 16) == 77
-    assert (p["sbcode"][sb] == exp_code[sb]).all()
+    assert int((p["crc_ok"][sb, 0] == 1).sum()) == len(sb) - nfail
+    assert (p["sbf1"][sb[-1]] >> 16) == 77 and (p["sbf1"][sb[-1]] & 0xFFFF) == 901
 
 
 def test_failed_sb1_keeps_previous_code(T, eng):
