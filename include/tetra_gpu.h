@@ -162,6 +162,10 @@ int tgpu_plan_execute(struct tgpu_plan *plan, const uint8_t *d_stream, uint8_t *
 /* scrambling code in effect per channel after the batch (device->host copy, synchronises) */
 int tgpu_plan_final_codes(struct tgpu_plan *plan, const uint8_t *d_rec, uint32_t *chan_code_out);
 
+/* diagnostic: copy the front kernel's packed slots (20 dwords per slot, csrc/tg_layout.h) of the
+ * last executed batch to the host; synchronises the device */
+int tgpu_plan_read_packed(struct tgpu_plan *plan, uint32_t *out_words);
+
 /*
  * Per-kernel timing with HIP events on the SAME stream the kernels are launched on.
  * tgpu_plan_execute_prof() is tgpu_plan_execute() plus one event record between stages

@@ -92,6 +92,7 @@ def lib():
     L.tgpu_plan_load.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p, C.c_uint32, u32p]
     L.tgpu_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_plan_final_codes.argtypes = [C.c_void_p, C.c_void_p, u32p]
+    L.tgpu_plan_read_packed.argtypes = [C.c_void_p, u32p]
     L.tgpu_prof_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_prof_destroy.argtypes = [C.c_void_p]
     L.tgpu_plan_execute_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -167,6 +168,11 @@ class Plan:
     def execute_prof(self, d_stream_ptr, d_rec_ptr, hip_stream, prof, step):
         _chk(lib().tgpu_plan_execute_prof(self._h, C.c_void_p(d_stream_ptr), C.c_void_p(d_rec_ptr),
                                           C.c_void_p(hip_stream), prof._h, step), "tgpu_plan_execute_prof")
+
+    def read_packed(self):
+        out = np.zeros((self.nslots, 20), np.uint32)
+        _chk(lib().tgpu_plan_read_packed(self._h, out.ctypes.data_as(u32p)), "tgpu_plan_read_packed")
+        return out
 
     def final_codes(self, d_rec_ptr=0):
         out = np.zeros(self.nchan, np.uint32)

@@ -186,7 +186,21 @@ int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_of
 		}
 	}
 	if (nslots) {
-		HCHK(hipMemcpy(p->d_slot_off, slot_off, (size_t)nslots * 8, hipMemcpyHostToDevice));
+		/* descriptor = offset | type << 56 (one scalar load per slot in the front kernel) */
+		uint64_t *desc = malloc((size_t)nslots * 8);
+		if (!desc)
+			return TGPU_ENOMEM;
+		for (uint32_t i = 0; i < nslots; i++) {
+			if (slot_off[i] >> 56) {
+				free(desc);
+				return TGPU_EINVAL;
+			}
+			desc[i] = slot_off[i] | ((uint64_t)slot_type[i] << 56);
+		}
+		hipError_t de = hipMemcpy(p->d_slot_off, desc, (size_t)nslots * 8, hipMemcpyHostToDevice);
+		free(desc);
+		if (de != hipSuccess)
+			return (int)de;
 		HCHK(hipMemcpy(p->d_slot_type, slot_type, nslots, hipMemcpyHostToDevice));
 		HCHK(hipMemcpy(p->d_slot_chan, slot_chan, (size_t)nslots * 4, hipMemcpyHostToDevice));
 		HCHK(hipMemcpy(p->d_slot_sbord, p->h_sbord, (size_t)nslots * 4, hipMemcpyHostToDevice));
@@ -267,7 +281,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 		return TGPU_ESTATE;
 	MARK(0);
 	if (p->nslots) {
-		if ((rc = tgk_front(d_stream, p->d_slot_off, p->d_slot_type, p->nslots, p->d_packed, d_rec, stream)))
+		if ((rc = tgk_front(d_stream, p->d_slot_off, p->nslots, p->d_packed, d_rec, stream)))
 			return rc;
 	}
 	MARK(1);
@@ -327,6 +341,16 @@ int tgpu_prof_read(struct tgpu_prof *prof, uint32_t nsteps, float *ms)
 		for (int k = 0; k < TGPU_NSTAGES; k++)
 			HCHK(hipEventElapsedTime(&ms[(size_t)s * TGPU_NSTAGES + k], ev[k], ev[k + 1]));
 	}
+	return TGPU_OK;
+}
+
+int tgpu_plan_read_packed(struct tgpu_plan *p, uint32_t *out_words)
+{
+	if (!p || !out_words || !p->loaded)
+		return TGPU_EINVAL;
+	HCHK(hipDeviceSynchronize());
+	if (p->nslots)
+		HCHK(hipMemcpy(out_words, p->d_packed, (size_t)p->nslots * TG_PACKED_WORDS * 4, hipMemcpyDeviceToHost));
 	return TGPU_OK;
 }
 

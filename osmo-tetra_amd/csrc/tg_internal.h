@@ -9,7 +9,8 @@ extern "C" {
 #endif
 
 int tgk_init(void);
-int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_off, const uint8_t *d_slot_type,
+/* d_slot_desc[i] = byte offset | (uint64_t)burst type << 56 */
+int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 	      uint32_t nslots, uint32_t *d_packed, uint8_t *d_rec, void *stream);
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,

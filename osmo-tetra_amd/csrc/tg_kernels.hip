@@ -39,13 +39,15 @@ __constant__ tg_const_tables c_tab;
 /*
  * One wavefront per slot, four independent wavefronts per workgroup.
  *   1. the 510 slot bytes are read from HBM exactly once, as two coalesced (possibly
- *      unaligned) dwords per lane, and parked in this wave's 512-byte LDS window;
- *   2. ten gather rounds: every lane picks one byte out of LDS (its offsets for the three
- *      burst types live in VGPRs for the whole kernel), a 64-bit ballot collapses them:
- *      lanes 0..31 form one packed word, lanes 32..63 the next;
+ *      unaligned) dwords per lane, and parked in this wave's 512-byte LDS window
+ *      (bytes 510/511 of the window are always zero: "no source" gathers point there);
+ *   2. ten gather rounds: every lane picks one byte out of LDS (its LDS addresses for the
+ *      three burst types live in VGPRs for the whole kernel), a 64-bit ballot collapses
+ *      them: lanes 0..31 form one packed word, lanes 32..63 the next, and v_writelane drops
+ *      the two dwords into lanes 2r and 2r+1 of the output register;
  *   3. the 80-byte packed slot goes out as one coalesced store.
- * The next slot's dwords are requested before the current slot is processed.  LDS
- * operations of one wave execute in order, so no barrier is needed between the stages.
+ * Two slots are kept in flight per wave (dwords of slot i+2 are requested while slot i is
+ * gathered).  LDS operations of one wave execute in order: no barrier between the stages.
  */
 typedef uint32_t __attribute__((aligned(1))) tg_u32_unaligned;
 typedef uint16_t __attribute__((aligned(1))) tg_u16_unaligned;
@@ -60,69 +62,122 @@ __device__ __forceinline__ void front_fetch(const uint8_t *base, uint32_t lane, 
 		d1 = *(const tg_u16_unaligned *)(base + 508);
 }
 
+__device__ __forceinline__ uint32_t front_gather(const uint8_t *lds0, const uint32_t (&addr)[10], uint32_t &nonbin_acc)
+{
+	uint32_t myword = 0;
+	uint32_t bytes[10];
+#pragma unroll
+	for (int r = 0; r < 10; r++)
+		bytes[r] = lds0[addr[r]];	/* ten independent LDS reads in flight */
+#pragma unroll
+	for (int r = 0; r < 10; r++) {
+		const unsigned long long bal = __ballot(bytes[r] != 0);
+		nonbin_acc |= bytes[r];
+		/* the ballot lives in an SGPR pair: drop its halves into lanes 2r, 2r+1.  hipcc pads no
+		 * hazards for inline asm, and v_writelane reading an SGPR a VALU compare has just
+		 * written needs wait states (seen on gfx950: without them the OLD value is read). */
+		asm("s_nop 4\n\tv_writelane_b32 %0, %1, %2\n\tv_writelane_b32 %0, %3, %4"
+		    : "+v"(myword) : "s"((uint32_t)bal), "i"(2 * r), "s"((uint32_t)(bal >> 32)), "i"(2 * r + 1));
+	}
+	return myword;
+}
+
+/* slot descriptor: byte offset in bits 0..55, burst type in bits 56..63 (one SMEM load per slot) */
+#define TG_DESC_TYPE(d) ((uint32_t)((d) >> 56))
+#define TG_DESC_OFF(d)  ((d) & 0x00ffffffffffffffull)
+
+__device__ __forceinline__ void front_process(uint32_t slot, uint32_t type, uint32_t d0, uint32_t d1, uint32_t lane,
+					       uint32_t *mine, const uint8_t *lds0, const uint32_t (&a_n1)[10],
+					       const uint32_t (&a_n2)[10], const uint32_t (&a_sb)[10],
+					       uint32_t *__restrict__ packed, uint8_t *__restrict__ rec)
+{
+	mine[lane] = d0;
+	mine[64 + lane] = d1;
+	uint32_t myword = 0, acc = 0;
+	if (type == TG_BURST_NORM_1)
+		myword = front_gather(lds0, a_n1, acc);
+	else if (type == TG_BURST_NORM_2)
+		myword = front_gather(lds0, a_n2, acc);
+	else if (type == TG_BURST_SYNC)
+		myword = front_gather(lds0, a_sb, acc);
+	else if (lane == 0) {
+		/* not a burst we decode (NORM_3 / EXT are ignored like phy/tetra_burst.c:374-377):
+		 * no trellis lane will touch this record, mark it */
+		rec[(size_t)slot * TG_REC_BYTES + TG_REC_TYPE] = TG_BURST_NONE;
+	}
+	const uint32_t flags = __ballot(acc > 1) ? TG_FLAG_NONBINARY : 0;
+	if (lane == TG_PW_META) {
+		const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
+		myword = type | (flags << 8) | (toff << 16);
+	}
+	if (lane < TG_PACKED_WORDS)
+		packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
+}
+
 __global__ __launch_bounds__(256)
-void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_off,
-	     const uint8_t *__restrict__ slot_type, uint32_t nslots, uint32_t *__restrict__ packed,
-	     uint8_t *__restrict__ rec)
+void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_desc,
+	     uint32_t nslots, uint32_t *__restrict__ packed, uint8_t *__restrict__ rec)
 {
 	__shared__ uint32_t s_slot[4][128];
 
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wib = threadIdx.x >> 6;
-	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t wave = blockIdx.x * 4 + wib;		/* wave-uniform: descriptors come through SMEM */
+	const uint32_t nwaves = gridDim.x * 4;
 	const uint32_t half = lane >> 5, bit = lane & 31;
 	uint32_t *mine = s_slot[wib];
-	const uint8_t *mine8 = (const uint8_t *)mine;
+	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];
 
-	/* gather offsets of this lane for the three burst types (0xffff = no source bit) */
-	uint32_t off[3][10];
+	/* LDS byte address of this lane's source bit per round, for the three burst types */
+	uint32_t a_n1[10], a_n2[10], a_sb[10];
 #pragma unroll
-	for (int t = 0; t < 3; t++)
-#pragma unroll
-		for (int r = 0; r < 10; r++)
-			off[t][r] = c_tab.front_src[t][2 * r + half][bit];
-
-	uint32_t slot = wave;
-	uint32_t d0 = 0, d1 = 0;
-	if (slot < nslots)
-		front_fetch(stream + slot_off[slot], lane, d0, d1);
-
-	for (; slot < nslots; slot += nwaves) {
-		const uint32_t type = __builtin_amdgcn_readfirstlane(slot_type[slot]);
-		mine[lane] = d0;
-		mine[64 + lane] = d1;
-		const uint32_t nxt = slot + nwaves;
-		if (nxt < nslots)
-			front_fetch(stream + slot_off[nxt], lane, d0, d1);
-
-		uint32_t myword = 0;
-		uint32_t flags = 0;
-		if (type == TG_BURST_NORM_1 || type == TG_BURST_NORM_2 || type == TG_BURST_SYNC) {
-			uint32_t nonbin = 0;
-#pragma unroll
-			for (int r = 0; r < 10; r++) {
-				const uint32_t o = (type == TG_BURST_SYNC) ? off[2][r] : (type == TG_BURST_NORM_2) ? off[1][r] : off[0][r];
-				const uint32_t byte = (o != 0xffff) ? (uint32_t)mine8[o & 511] : 0u;
-				const unsigned long long bal = __ballot(byte & 1);
-				nonbin |= (byte > 1);
-				myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
-				myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
-			}
-			if (__ballot(nonbin))
-				flags |= TG_FLAG_NONBINARY;
-		} else if (lane == 0) {
-			/* not a burst we decode (NORM_3 / EXT are ignored like phy/tetra_burst.c:374-377):
-			 * no trellis lane will touch this record, mark it */
-			rec[(size_t)slot * TG_REC_BYTES + TG_REC_TYPE] = TG_BURST_NONE;
-		}
-		if (lane == TG_PW_META) {
-			const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
-			myword = type | (flags << 8) | (toff << 16);
-		}
-		if (lane < TG_PACKED_WORDS)
-			packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
+	for (int r = 0; r < 10; r++) {
+		const uint32_t o0 = c_tab.front_src[0][2 * r + half][bit];
+		const uint32_t o1 = c_tab.front_src[1][2 * r + half][bit];
+		const uint32_t o2 = c_tab.front_src[2][2 * r + half][bit];
+		a_n1[r] = wib * 512 + (o0 == 0xffff ? 510 : o0);
+		a_n2[r] = wib * 512 + (o1 == 0xffff ? 510 : o1);
+		a_sb[r] = wib * 512 + (o2 == 0xffff ? 510 : o2);
 	}
+
+	/* three slots in flight per wave, registers rotated statically (no copies, so a wait only
+	 * ever covers the oldest request): A = slot, B = slot+n, C = slot+2n */
+	const uint64_t none = (uint64_t)TG_BURST_NONE << 56;
+	uint32_t slot = wave;
+	uint64_t da = none, db = none, dc = none;
+	uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0;
+	if (slot < nslots) {
+		da = slot_desc[slot];
+		front_fetch(stream + TG_DESC_OFF(da), lane, a0, a1);
+	}
+	if (slot + nwaves < nslots) {
+		db = slot_desc[slot + nwaves];
+		front_fetch(stream + TG_DESC_OFF(db), lane, b0, b1);
+	}
+	if (slot + 2 * nwaves < nslots) {
+		dc = slot_desc[slot + 2 * nwaves];
+		front_fetch(stream + TG_DESC_OFF(dc), lane, c0, c1);
+	}
+
+#define FRONT_STEP(D, R0, R1)										\
+	{												\
+		if (slot >= nslots)									\
+			break;										\
+		const uint32_t type_ = TG_DESC_TYPE(D);							\
+		const uint32_t x0_ = R0, x1_ = R1;							\
+		if (slot + 3 * nwaves < nslots) {							\
+			D = slot_desc[slot + 3 * nwaves];						\
+			front_fetch(stream + TG_DESC_OFF(D), lane, R0, R1);				\
+		}											\
+		front_process(slot, type_, x0_, x1_, lane, mine, lds0, a_n1, a_n2, a_sb, packed, rec);	\
+		slot += nwaves;										\
+	}
+	for (;;) {
+		FRONT_STEP(da, a0, a1)
+		FRONT_STEP(db, b0, b1)
+		FRONT_STEP(dc, c0, c1)
+	}
+#undef FRONT_STEP
 }
 
 /* ------------------------------------------------------------------------- */
@@ -587,7 +642,7 @@ extern "C" int tgk_init(void)
 	return 0;
 }
 
-extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_off, const uint8_t *d_slot_type,
+extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 			 uint32_t nslots, uint32_t *d_packed, uint8_t *d_rec, void *stream)
 {
 	if (!nslots)
@@ -596,7 +651,7 @@ extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_off, co
 	if (blocks > 256 * 16)
 		blocks = 256 * 16;
 	hipLaunchKernelGGL(k_front, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-			   d_stream, d_slot_off, d_slot_type, nslots, d_packed, d_rec);
+			   d_stream, d_slot_desc, nslots, d_packed, d_rec);
 	return (int)hipGetLastError();
 }
 
