@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts per GPU per step")
     ap.add_argument("--ber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = control-flow check on a box with fewer GPUs than ranks (gather staged through the host)")
     args = ap.parse_args()
 
     import torch
@@ -90,10 +92,15 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     n = args.bursts
     rng = np.random.default_rng(1000 + rank)
@@ -108,23 +115,65 @@ def main():
     prof = T.Prof(args.steps)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # N > 1: the final exchange of the path -- decoded blocks travel to rank 0 in the 48-byte wire
+    # form, one RCCL gather per step, issued on a side stream so that it overlaps the next decode
+    # (each peer->root transfer uses its own xGMI link; see DESIGN.md "Multi-GPU").
+    gather = world > 1
+    if gather:
+        from osmo_tetra_amd import dist as tdist
+        wire = [torch.empty(n * T.WIRE_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        sink = [[torch.empty_like(wire[0]) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+        comm = torch.cuda.Stream()
+        pending = [None, None]
+
+    def step(k, prof_step=None):
+        if gather:
+            b = k & 1
+            if pending[b] is not None:       # the gather that last read this buffer must be done
+                pending[b].wait()
+            plan.set_wire(wire[b].data_ptr())
+        if prof_step is None:
+            plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), stream)
+        else:
+            plan.execute_prof(d_stream.data_ptr(), d_rec.data_ptr(), stream, prof, prof_step)
+        if gather:
+            done = torch.cuda.Event()
+            done.record()
+            with torch.cuda.stream(comm):
+                comm.wait_event(done)
+                if args.backend == "nccl":
+                    _, pending[b] = tdist.gather_wire(wire[b], dst=0, async_op=True, out=sink[b])
+                else:   # debug path: host-staged
+                    comm.synchronize()
+                    _, pending[b] = tdist.gather_wire(wire[b].cpu(), dst=0, async_op=True,
+                                                      out=[t.cpu() for t in sink[b]] if rank == 0 else None)
+
+    def drain():
+        if gather:
+            for b in (0, 1):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), stream)
+    for k in range(args.warmup):
+        step(k)
+    drain()
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        plan.execute_prof(d_stream.data_ptr(), d_rec.data_ptr(), stream, prof, k)
+        step(k, k)
+    drain()
     sync_all()
     el = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -154,7 +203,7 @@ def main():
         "dtype": "u16", "data": "synthetic",
         "config": {"workload": "BASELINE config 2: per GPU %d NDB bursts (50%% NORM_1 SCH/F, 50%% NORM_2 2xNDB, + AACH), "
                                "scramb_init=0, BER %g, aligned 510-B slots resident in HBM, records left in HBM" % (n, args.ber),
-                   "bursts_per_gpu": n, "parallelism": "independent channels per GPU, no data-path collective"},
+                   "bursts_per_gpu": n, "parallelism": "independent channels per GPU; N>1: one RCCL gather of 48-B wire records per step to rank 0, overlapped with the next decode"},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": float(achieved) / HBM_PEAK_GBS, "traffic": None,
                      "kernel_ms": float(stage_ms[dom]),

@@ -162,6 +162,17 @@ int tgpu_plan_execute(struct tgpu_plan *plan, const uint8_t *d_stream, uint8_t *
 /* scrambling code in effect per channel after the batch (device->host copy, synchronises) */
 int tgpu_plan_final_codes(struct tgpu_plan *plan, const uint8_t *d_rec, uint32_t *chan_code_out);
 
+/*
+ * Transport form of the records: 48 bytes per slot, type-1 bits packed 8 per byte (layout in
+ * csrc/tg_layout.h).  When a device buffer of nslots * TGPU_WIRE_BYTES is attached to the plan the
+ * trellis kernels write it alongside the full records; it is what a rank sends to the collecting
+ * rank over xGMI (RCCL gather).  tgpu_wire_unpack() rebuilds a full TGPU_REC_BYTES record on the
+ * host; the slot id and the scrambling code are not transported and are passed in.
+ */
+#define TGPU_WIRE_BYTES 48
+int tgpu_plan_set_wire(struct tgpu_plan *plan, uint8_t *d_wire /* NULL: off */);
+int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_code, uint8_t *rec);
+
 /* diagnostic: copy the front kernel's packed slots (20 dwords per slot, csrc/tg_layout.h) of the
  * last executed batch to the host; synchronises the device */
 int tgpu_plan_read_packed(struct tgpu_plan *plan, uint32_t *out_words);

@@ -92,6 +92,8 @@ def lib():
     L.tgpu_plan_load.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p, C.c_uint32, u32p]
     L.tgpu_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_plan_final_codes.argtypes = [C.c_void_p, C.c_void_p, u32p]
+    L.tgpu_plan_set_wire.argtypes = [C.c_void_p, C.c_void_p]
+    L.tgpu_wire_unpack.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
     L.tgpu_plan_read_packed.argtypes = [C.c_void_p, u32p]
     L.tgpu_prof_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_prof_destroy.argtypes = [C.c_void_p]
@@ -169,6 +171,9 @@ class Plan:
         _chk(lib().tgpu_plan_execute_prof(self._h, C.c_void_p(d_stream_ptr), C.c_void_p(d_rec_ptr),
                                           C.c_void_p(hip_stream), prof._h, step), "tgpu_plan_execute_prof")
 
+    def set_wire(self, d_wire_ptr):
+        _chk(lib().tgpu_plan_set_wire(self._h, C.c_void_p(d_wire_ptr)), "tgpu_plan_set_wire")
+
     def read_packed(self):
         out = np.zeros((self.nslots, 20), np.uint32)
         _chk(lib().tgpu_plan_read_packed(self._h, out.ctypes.data_as(u32p)), "tgpu_plan_read_packed")
@@ -210,6 +215,21 @@ class Prof:
         if self._h:
             lib().tgpu_prof_destroy(self._h)
             self._h = C.c_void_p()
+
+
+WIRE_BYTES = 48
+
+
+def wire_unpack(wire, slot_ids=None, codes=None):
+    """(n,48) wire records -> (n,320) full records (tgpu_wire_unpack)"""
+    wire = np.ascontiguousarray(wire, np.uint8).reshape(-1, WIRE_BYTES)
+    n = len(wire)
+    out = np.zeros((n, REC_BYTES), np.uint8)
+    L = lib()
+    for i in range(n):
+        _chk(L.tgpu_wire_unpack(wire[i].ctypes.data_as(u8p), int(slot_ids[i]) if slot_ids is not None else i,
+                                int(codes[i]) if codes is not None else 0, out[i].ctypes.data_as(u8p)), "tgpu_wire_unpack")
+    return out
 
 
 def parse_records(rec):

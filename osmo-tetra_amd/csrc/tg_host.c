@@ -31,6 +31,7 @@ struct tgpu_plan {
 	uint32_t max_slots, max_chan;
 	uint32_t nslots, nchan, nsb, n216, n432;
 	int loaded;
+	int static_masks;	/* batch has no SYNC slot: mask entries are known at load time */
 	/* device */
 	uint64_t *d_slot_off;
 	uint8_t *d_slot_type;
@@ -43,6 +44,7 @@ struct tgpu_plan {
 	uint32_t *d_chan_code;
 	uint32_t *d_sb_ok, *d_sb_code;
 	unsigned long long *d_block_tmp;
+	uint8_t *d_wire;	/* caller-owned, optional */
 	/* host staging */
 	int32_t *h_sbord;
 	uint32_t *h_list_sb, *h_list_216, *h_list_432;
@@ -212,6 +214,20 @@ int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_of
 	if (n432)
 		HCHK(hipMemcpy(p->d_list_432, p->h_list_432, (size_t)n432 * 4, hipMemcpyHostToDevice));
 	HCHK(hipMemcpy(p->d_chan_code, chan_code, (size_t)nchan * 4, hipMemcpyHostToDevice));
+	p->static_masks = 0;
+	if (nsb == 0 && nslots) {
+		/* no SYNC burst in the batch: every slot keeps its channel's carry-in code, so the
+		 * forward fill degenerates to entry 1 + chan and the masks can be built right now */
+		uint32_t *idx = (uint32_t *)p->h_sbord;
+		for (uint32_t i = 0; i < nslots; i++)
+			idx[i] = 1 + slot_chan[i];
+		HCHK(hipMemcpy(p->d_maskidx, idx, (size_t)nslots * 4, hipMemcpyHostToDevice));
+		int rc = tgk_masks(p->d_chan_code, nchan, p->d_sb_ok, p->d_sb_code, 0, p->d_masks, NULL);
+		if (rc)
+			return rc;
+		HCHK(hipDeviceSynchronize());
+		p->static_masks = 1;
+	}
 	p->nslots = nslots;
 	p->nchan = nchan;
 	p->nsb = nsb;
@@ -285,32 +301,32 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 			return rc;
 	}
 	MARK(1);
-	if (p->nslots) {
+	if (p->nslots && !p->static_masks) {
 		if ((rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, p->nsb, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, stream)))
 			return rc;
 	}
 	MARK(2);
-	if (p->nslots) {
+	if (p->nslots && !p->static_masks) {
 		if ((rc = tgk_fill(p->d_slot_chan, p->d_slot_sbord, p->d_sb_ok, p->nchan, p->nslots, p->d_block_tmp,
 				   p->d_maskidx, stream)))
 			return rc;
 	}
 	MARK(3);
-	if (p->nslots) {
+	if (p->nslots && !p->static_masks) {
 		if ((rc = tgk_masks(p->d_chan_code, p->nchan, p->d_sb_ok, p->d_sb_code, p->nsb, p->d_masks, stream)))
 			return rc;
 	}
 	MARK(4);
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_216, p->d_list_216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, stream)))
 			return rc;
 	}
 	MARK(5);
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_432, p->d_list_432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, stream)))
 			return rc;
 	}
 	MARK(6);
@@ -340,6 +356,67 @@ int tgpu_prof_read(struct tgpu_prof *prof, uint32_t nsteps, float *ms)
 		HCHK(hipEventSynchronize(ev[TGPU_NSTAGES]));
 		for (int k = 0; k < TGPU_NSTAGES; k++)
 			HCHK(hipEventElapsedTime(&ms[(size_t)s * TGPU_NSTAGES + k], ev[k], ev[k + 1]));
+	}
+	return TGPU_OK;
+}
+
+int tgpu_plan_set_wire(struct tgpu_plan *p, uint8_t *d_wire)
+{
+	if (!p)
+		return TGPU_EINVAL;
+	p->d_wire = d_wire;
+	return TGPU_OK;
+}
+
+/* wire record -> full record (host), inverse of the trellis kernels' packing */
+static void unpack_bits(const uint8_t *src, int nbits, uint8_t *dst)
+{
+	for (int i = 0; i < nbits; i++)
+		dst[i] = (src[i >> 3] >> (i & 7)) & 1;
+}
+
+int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_code, uint8_t *rec)
+{
+	if (!wire || !rec)
+		return TGPU_EINVAL;
+	memset(rec, 0, TG_REC_BYTES);
+	const uint8_t type = wire[TG_WIRE_TYPE];
+	rec[TG_REC_TYPE] = type;
+	rec[TG_REC_FLAGS] = wire[TG_WIRE_FLAGS];
+	memcpy(rec + TG_REC_CRC_OK, wire + TG_WIRE_CRC_OK, 2);
+	memcpy(rec + TG_REC_CRC, wire + TG_WIRE_CRC, 4);
+	memcpy(rec + TG_REC_CODE, &scrambling_code, 4);
+	memcpy(rec + TG_REC_SLOT, &slot_id, 4);
+	unpack_bits(wire + TG_WIRE_BBK, 14, rec + TG_REC_BBK);
+	switch (type) {
+	case TETRA_TRAIN_NORM_1:
+		unpack_bits(wire + TG_WIRE_BITS1, 268, rec + TG_REC_BITS1);
+		break;
+	case TETRA_TRAIN_NORM_2:
+		unpack_bits(wire + TG_WIRE_BITS1, 124, rec + TG_REC_BITS1);
+		unpack_bits(wire + TG_WIRE_BITS2, 124, rec + TG_REC_BITS2);
+		break;
+	case TETRA_TRAIN_SYNC: {
+		unpack_bits(wire + TG_WIRE_BITS1, 60, rec + TG_REC_BITS1);
+		unpack_bits(wire + TG_WIRE_BITS2, 124, rec + TG_REC_BITS2);
+		/* SYNC-PDU fields (lower_mac/tetra_lower_mac.c:284-297) from the SB1 bits */
+		const uint8_t *b = rec + TG_REC_BITS1;
+		uint32_t f[6];
+		static const int pos[6][2] = { { 4, 6 }, { 10, 2 }, { 12, 5 }, { 17, 6 }, { 31, 10 }, { 41, 14 } };
+		for (int k = 0; k < 6; k++) {
+			f[k] = 0;
+			for (int i = 0; i < pos[k][1]; i++)
+				f[k] = (f[k] << 1) | b[pos[k][0] + i];
+		}
+		uint32_t f0 = f[0] | ((f[1] + 1) << 8) | (f[2] << 16) | (f[3] << 24), f1 = f[4] | (f[5] << 16);
+		uint32_t code = ((((f[4] & 0x3ff) << 20) | ((f[5] & 0x3fff) << 6) | (f[0] & 0x3f)) << 2) | 3u;
+		memcpy(rec + TG_REC_SBF0, &f0, 4);
+		memcpy(rec + TG_REC_SBF1, &f1, 4);
+		memcpy(rec + TG_REC_SBCODE, &code, 4);
+		break;
+	}
+	default:
+		break;
 	}
 	return TGPU_OK;
 }

@@ -14,7 +14,7 @@ int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 	      uint32_t nslots, uint32_t *d_packed, uint8_t *d_rec, void *stream);
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
-	    uint32_t *d_sb_ok, uint32_t *d_sb_code, void *stream);
+	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */, void *stream);
 int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uint32_t *d_sb_ok,
 	     uint32_t nchan, uint32_t nslots, unsigned long long *d_block_tmp, uint32_t *d_maskidx, void *stream);
 int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (KIND == TG_KIND_432 ? 2 : 4
 void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
-	   uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code)
+	   uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code, uint8_t *__restrict__ wire)
 {
 	constexpr int NBLK = vit_cfg<KIND>::NBLK;
 	constexpr int NW = NBLK / 2;			/* code words */
@@ -398,6 +398,18 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	r[TG_REC_CRC_OK + which] = (uint8_t)crc_ok;
 	*(uint16_t *)(r + TG_REC_CRC + 2 * which) = (uint16_t)crc;
 
+	/* optional bit-packed copy for transport (wave-uniform branch) */
+	uint8_t *wr = wire ? wire + (size_t)slot * TG_WIRE_BYTES : nullptr;
+	if (wr) {
+		uint32_t *wb = (uint32_t *)(wr + (which ? TG_WIRE_BITS2 : TG_WIRE_BITS1));
+		constexpr int NWD = (TYPE1 + 31) / 32;
+#pragma unroll
+		for (int q = 0; q < NWD; q++)
+			wb[q] = (q == NWD - 1) ? (od[q] & ((1u << (TYPE1 & 31)) - 1)) : od[q];
+		wr[TG_WIRE_CRC_OK + which] = (uint8_t)crc_ok;
+		*(uint16_t *)(wr + TG_WIRE_CRC + 2 * which) = (uint16_t)crc;
+	}
+
 	if (KIND == TG_KIND_SB1) {
 		/* SYNC PDU fields, lower_mac/tetra_lower_mac.c:284-297 */
 		const uint32_t cc = FIELD_MSB(od, 4, 6), tn = FIELD_MSB(od, 10, 2) + 1;
@@ -428,6 +440,11 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 			r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
 			*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
 			*(uint32_t *)(r + TG_REC_SLOT) = slot;
+			if (wr) {
+				wr[TG_WIRE_TYPE] = (uint8_t)btype;
+				wr[TG_WIRE_FLAGS] = (uint8_t)(meta >> 8);
+				*(uint32_t *)(wr + TG_WIRE_BBK) = bb & 0x3fff;
+			}
 		}
 	}
 }
@@ -657,13 +674,13 @@ extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 
 extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 		       const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
-		       uint32_t *d_sb_ok, uint32_t *d_sb_code, void *stream)
+		       uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire, void *stream)
 {
 	if (!nitems)
 		return 0;
 	const dim3 grid((nitems + 63) / 64), block(64);
 	hipStream_t s = (hipStream_t)stream;
-#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code)
+#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire)
 	const int hm = tgk_hist_mode;
 	switch (kind) {
 	case TG_KIND_SB1:

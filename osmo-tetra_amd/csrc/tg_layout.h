@@ -95,6 +95,23 @@
 #define TG_REC_BITS1      48
 #define TG_REC_BITS2      176
 
+/*
+ * Wire record, 48 bytes per slot: the same decoded blocks bit-packed (LSB first) for transport
+ * over xGMI (the unit of the RCCL gather when records leave the GPU that decoded them).
+ *   @0  u8 burst_type   @1 u8 flags   @2 u8 crc_ok[2]   @4 u16 crc[2]
+ *   @8  first block:  SB1 (60 bits) / BLK1 (124) / SCH-F (268), bit i of the block = bit i of the field
+ *   @24 second block: SB2 / BLK2 (124 bits)          (SCH-F runs through, 9 dwords from @8)
+ *   @44 u32: BBK type-1 bits in bits 0..13
+ */
+#define TG_WIRE_BYTES     48
+#define TG_WIRE_TYPE      0
+#define TG_WIRE_FLAGS     1
+#define TG_WIRE_CRC_OK    2
+#define TG_WIRE_CRC       4
+#define TG_WIRE_BITS1     8
+#define TG_WIRE_BITS2     24
+#define TG_WIRE_BBK       44
+
 #ifdef __cplusplus
 extern "C" {
 #endif

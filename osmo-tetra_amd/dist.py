@@ -1,0 +1,34 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm,
+"gloo" for the CPU tests).
+
+The path shards by channel: channels are independent, the reference itself runs
+one process per channel.  No collective takes part in decoding; the only exchange is the final
+gather of decoded blocks to the collecting rank, in the 48-byte wire form (tg_layout.h), each
+peer -> root transfer riding its own xGMI link.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_channels(nchan, rank, world):
+    """contiguous, balanced channel-major shard: channels [lo, hi) belong to `rank`"""
+    base, extra = divmod(nchan, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_wire(local, dst=0, group=None, async_op=False, out=None):
+    """Gather equally sized wire-record tensors to `dst`.
+
+    local: uint8 tensor (nslots * 48,) on this rank's device (CUDA for nccl, CPU for gloo).
+    Returns (list_of_tensors_or_None, work_or_None); the list is only filled on `dst`
+    (index = source rank, i.e. channel-shard order)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if rank == dst:
+        if out is None:
+            out = [torch.empty_like(local) for _ in range(world)]
+    else:
+        out = None
+    work = dist.gather(local, gather_list=out, dst=dst, group=group, async_op=async_op)
+    return out, work

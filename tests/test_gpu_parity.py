@@ -350,3 +350,51 @@ def test_config2_full_size_roundtrip(T, eng):
     rec_sl = np.ascontiguousarray(d_rec.view(n, T.REC_BYTES)[sl].cpu().numpy())
     check_against_oracle(T, rec_sl, types[sl], slots[sl], 0)
     plan.close()
+
+
+def test_front_kernel_packing(T, eng):
+    """k_front's packed code words == the layout function both sides are built from (tg_layout.h),
+    for all burst types, odd offsets and the last slot of a buffer (no read past byte 509)"""
+    import torch
+    import emul
+    rng = np.random.default_rng(12)
+    types = np.array([O.TRAIN_NORM_1, O.TRAIN_NORM_2, O.TRAIN_SYNC] * 50 + [O.TRAIN_SYNC], np.uint8)
+    n = len(types)
+    slots = rng.integers(0, 2, (n, 510)).astype(np.uint8)
+    offs = np.cumsum(np.concatenate([[1], 510 + rng.integers(0, 9, n - 1)])).astype(np.uint64)
+    buf = np.zeros(int(offs[-1]) + 510, np.uint8)     # ends exactly with the last slot
+    for o, s in zip(offs, slots):
+        buf[int(o):int(o) + 510] = s
+    d_stream = torch.from_numpy(buf).cuda()
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(offs, types)
+    plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    got = plan.read_packed()
+    for i in range(n):
+        want = emul.pack_slot(int(types[i]), slots[i])
+        assert (got[i, :19] == want[:19]).all(), i
+        assert got[i, 19] & 0xFF == types[i] and (got[i, 19] >> 16) == (214 if types[i] == O.TRAIN_SYNC else 244)
+    plan.close()
+
+
+def test_wire_records_equal_full_records(T, eng):
+    """the 48-byte transport form written by the trellis kernels expands to exactly the 320-byte record"""
+    import torch
+    code = O.scramb_get_init(262, 42, 1)
+    types = np.array([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_NORM_2] * 40, np.uint8)
+    slots = T.synth_slots(types, seed=77, scramb_init=code, ber=0.03)
+    n = len(types)
+    d_stream = torch.from_numpy(slots.reshape(-1)).cuda()
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    d_wire = torch.zeros(n * T.WIRE_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(np.arange(n, dtype=np.uint64) * 510, types, None, np.array([code], np.uint32))
+    plan.set_wire(d_wire.data_ptr())
+    plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+    p = T.parse_records(rec)
+    back = T.wire_unpack(d_wire.cpu().numpy(), slot_ids=np.arange(n), codes=p["code"])
+    assert (back == rec).all()
+    plan.close()
