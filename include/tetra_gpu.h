@@ -300,6 +300,63 @@ void tetra_tdma_time_add_tn(struct tetra_tdma_time *tm, uint32_t tn_count);
 uint32_t tetra_scramb_get_init(uint16_t mcc, uint16_t mnc, uint8_t colour);
 
 /* ------------------------------------------------------------------------- */
+/* 2b. whole-stream burst synchronisation, GPU-assisted (BASELINE config 3)    */
+/* ------------------------------------------------------------------------- */
+/*
+ * For a recorded stream the per-call state machine of tetra_burst_sync_in() is a closed-form
+ * function of byte positions.  tgpu_sync_stream() finds the first lock on the host, lets the GPU
+ * front end (k_front_stream) search every grid slot's window for the first training sequence
+ * (the reference's tetra_find_train_seq() scan, phy/tetra_burst.c:269-339), and walks the result:
+ * the outcome -- which slots reach tetra_burst_rx_cb(), with which burst ordinal, and every sync
+ * event -- is exactly what feeding the stream to tetra_burst_sync_in() 'chunk' bytes at a time gives.
+ * d_stream must have TGPU_STREAM_SLACK readable bytes after 'len'.  The slots then go to the plan API.
+ */
+#define TGPU_STREAM_SLACK 192
+
+struct tgpu_sync_slot {
+	uint64_t off;		/* stream offset of the slot */
+	uint32_t burst_seq;	/* ordinal of the LOCKED burst (1-based) */
+	uint32_t tn_adds;	/* tetra_tdma_time_add_tn(,1) calls since the previously delivered burst */
+	uint8_t type;		/* enum tetra_train_seq */
+};
+
+struct tgpu_sync_event_rec {
+	int32_t ev;		/* enum tgpu_sync_event */
+	uint32_t bitnum;
+	uint32_t arg;
+};
+
+struct tgpu_sync_result {
+	uint32_t nslots;
+	struct tgpu_sync_slot *slots;
+	uint32_t nevents;
+	struct tgpu_sync_event_rec *events;
+	int final_state;	/* enum rx_state after the last byte */
+	uint32_t tail_tn_adds;	/* time steps after the last delivered burst */
+	uint32_t burst_seq;	/* LOCKED bursts seen in total */
+	uint64_t anchor;	/* start of the slot grid the GPU classified */
+};
+
+int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uint8_t *d_stream, uint64_t len,
+		     uint32_t chunk, struct tgpu_sync_result *out, void *hip_stream);
+void tgpu_sync_result_free(struct tgpu_sync_result *r);
+
+/* Deliver records decoded through the plan API (slot table from tgpu_sync_stream(), h_rec = host copy of
+ * the nslots records, h_stream = host copy of the stream) to the channel's callback: the same in-order
+ * replay as tgpu_channel_flush().  tgpu_channel_scramb_init() is the carry-in code for tgpu_plan_load(). */
+int tgpu_channel_deliver(struct tgpu_channel *ch, uint32_t n, const struct tgpu_sync_slot *slots,
+			 const uint8_t *h_stream, const uint8_t *h_rec);
+int tgpu_channel_scramb_init(const struct tgpu_channel *ch, uint32_t *code);
+
+/* the two halves of tgpu_sync_stream(): the GPU classification of 'nslots' grid slots starting at
+ * 'anchor' (one word per slot, layout in csrc/tg_layout.h) and the host walk (cls may be NULL: every
+ * slot is then settled with tetra_find_train_seq() on the bytes -- no GPU needed) */
+int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_t len, uint32_t chunk,
+		       uint64_t anchor, uint32_t nslots, uint32_t *h_cls, void *hip_stream);
+int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor,
+		   const uint32_t *cls, uint32_t ncls, struct tgpu_sync_result *out);
+
+/* ------------------------------------------------------------------------- */
 /* 3. synthetic downlink generator (TX side of the same chain; host, multi-threaded) */
 /* ------------------------------------------------------------------------- */
 struct tgpu_synth_cfg {

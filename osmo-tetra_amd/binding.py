@@ -52,6 +52,20 @@ class UnitData(C.Structure):
                 ("type1", u8p), ("traffic", C.c_int), ("type4", u8p), ("type4_len", C.c_uint16)]
 
 
+class SyncSlot(C.Structure):
+    _fields_ = [("off", C.c_uint64), ("burst_seq", C.c_uint32), ("tn_adds", C.c_uint32), ("type", C.c_uint8)]
+
+
+class SyncEventRec(C.Structure):
+    _fields_ = [("ev", C.c_int32), ("bitnum", C.c_uint32), ("arg", C.c_uint32)]
+
+
+class SyncResult(C.Structure):
+    _fields_ = [("nslots", C.c_uint32), ("slots", C.POINTER(SyncSlot)), ("nevents", C.c_uint32),
+                ("events", C.POINTER(SyncEventRec)), ("final_state", C.c_int), ("tail_tn_adds", C.c_uint32),
+                ("burst_seq", C.c_uint32), ("anchor", C.c_uint64)]
+
+
 class SynthCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("scramb_init", C.c_uint32), ("mcc", C.c_uint16), ("mnc", C.c_uint16),
                 ("cc", C.c_uint8), ("ber", C.c_double), ("null_pdu_header", C.c_int)]
@@ -114,6 +128,12 @@ def lib():
     L.tetra_tdma_time_add_tn.argtypes = [C.POINTER(TdmaTime), C.c_uint32]
     L.tetra_scramb_get_init.restype = C.c_uint32
     L.tetra_scramb_get_init.argtypes = [C.c_uint16, C.c_uint16, C.c_uint8]
+    L.tgpu_channel_deliver.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(SyncSlot), u8p, u8p]
+    L.tgpu_channel_scramb_init.argtypes = [C.c_void_p, u32p]
+    L.tgpu_sync_walk.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, C.c_uint32, C.POINTER(SyncResult)]
+    L.tgpu_sync_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, C.c_void_p]
+    L.tgpu_sync_stream.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
+    L.tgpu_sync_result_free.argtypes = [C.POINTER(SyncResult)]
     L.tgpu_synth_slots.argtypes = [C.POINTER(SynthCfg), u8p, C.c_size_t, u8p, u8p]
     _lib = L
     return L
@@ -279,6 +299,46 @@ def synth_slots(types, seed=1, scramb_init=0, mcc=262, mnc=42, cc=1, ber=0.0, nu
     return (out, t1) if want_type1 else out
 
 
+STREAM_SLACK = 192
+
+
+def _sync_result_to_py(res):
+    slots = [(res.slots[i].off, res.slots[i].type, res.slots[i].burst_seq, res.slots[i].tn_adds) for i in range(res.nslots)]
+    events = [(res.events[i].ev, res.events[i].bitnum, res.events[i].arg) for i in range(res.nevents)]
+    out = dict(slots=slots, events=events, final_state=res.final_state, tail_tn_adds=res.tail_tn_adds,
+               burst_seq=res.burst_seq, anchor=res.anchor)
+    lib().tgpu_sync_result_free(C.byref(res))
+    return out
+
+
+def sync_walk(stream, chunk=64, anchor=0, cls=None):
+    """host half of the stream synchroniser (tgpu_sync_walk); cls=None: every slot settled on the bytes"""
+    stream = _np_u8(stream)
+    res = SyncResult()
+    if cls is not None:
+        cls = np.ascontiguousarray(cls, np.uint32)
+    _chk(lib().tgpu_sync_walk(stream.ctypes.data_as(u8p), len(stream), chunk, anchor,
+                              cls.ctypes.data_as(u32p) if cls is not None else None,
+                              len(cls) if cls is not None else 0, C.byref(res)), "tgpu_sync_walk")
+    return _sync_result_to_py(res)
+
+
+def sync_classify(engine, d_stream_ptr, length, chunk, anchor, nslots, hip_stream=0):
+    out = np.zeros(nslots, np.uint32)
+    _chk(lib().tgpu_sync_classify(engine._h, C.c_void_p(d_stream_ptr), length, chunk, anchor, nslots,
+                                  out.ctypes.data_as(u32p), C.c_void_p(hip_stream)), "tgpu_sync_classify")
+    return out
+
+
+def sync_stream(engine, h_stream, d_stream_ptr, chunk=64, hip_stream=0):
+    """tgpu_sync_stream: host first lock + GPU classification + host walk"""
+    h_stream = _np_u8(h_stream)
+    res = SyncResult()
+    _chk(lib().tgpu_sync_stream(engine._h, h_stream.ctypes.data_as(u8p), C.c_void_p(d_stream_ptr), len(h_stream),
+                                chunk, C.byref(res), C.c_void_p(hip_stream)), "tgpu_sync_stream")
+    return _sync_result_to_py(res)
+
+
 class Channel:
     """tgpu_channel + tetra_burst_sync_in(): host bytes in, upper-MAC style callbacks out"""
 
@@ -336,6 +396,20 @@ class Channel:
 
     def flush(self):
         _chk(lib().tgpu_channel_flush(self._h), "tgpu_channel_flush")
+
+    def scramb_init(self):
+        v = C.c_uint32(0)
+        _chk(lib().tgpu_channel_scramb_init(self._h, C.byref(v)), "tgpu_channel_scramb_init")
+        return v.value
+
+    def deliver(self, slots, h_stream, h_rec):
+        """slots: list of (off, type, burst_seq, tn_adds) from sync_stream(); h_rec: (n,320) host records"""
+        arr = (SyncSlot * len(slots))()
+        for i, (off, t, seq, tn) in enumerate(slots):
+            arr[i].off, arr[i].type, arr[i].burst_seq, arr[i].tn_adds = off, t, seq, tn
+        h_stream, h_rec = _np_u8(h_stream), _np_u8(h_rec)
+        _chk(lib().tgpu_channel_deliver(self._h, len(slots), arr, h_stream.ctypes.data_as(u8p),
+                                        h_rec.ctypes.data_as(u8p)), "tgpu_channel_deliver")
 
     def close(self):
         if self._h:

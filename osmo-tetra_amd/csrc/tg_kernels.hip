@@ -181,6 +181,155 @@ void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 }
 
 /* ------------------------------------------------------------------------- */
+/* k_front_stream: burst-sync correlation + demux on a slot grid               */
+/* ------------------------------------------------------------------------- */
+/*
+ * Stream mode of the front end (BASELINE config 3).  Slots lie on a grid (anchor + 510 n); the
+ * search window of slot n is what the reference's synchroniser would hold when it gets to that
+ * slot while being fed 'chunk' bytes per call (phy/tetra_burst_sync.c:106-120):
+ *     w = min(chunk * ceil((bs + 510) / chunk), len) - bs        (510 .. 573 for chunk = 64)
+ * Per wave and slot: 640 bytes -> LDS; ten 64-bit ballots turn them into a 640-bit string held in
+ * SGPRs; every lane then tests one window position per round against y (38 bits), n and p (22 bits)
+ * with two v_alignbit_b32 -- the first hit in ascending position is tetra_find_train_seq()'s answer
+ * (phy/tetra_burst.c:269-339).  Positions 0..255 are always scanned (the expected hits sit at 214
+ * and 244), the rest only if nothing was found.  If the burst is decodable (SYNC at 214, NORM at 244)
+ * the same LDS window feeds the gather of k_front.
+ */
+__device__ __forceinline__ uint32_t pattern_bits(const uint8_t *seq, int from, int n)
+{
+	uint32_t v = 0;
+	for (int i = 0; i < n; i++)
+		v |= (uint32_t)seq[from + i] << i;
+	return v;
+}
+
+struct tg_stream_params {
+	uint64_t anchor;	/* stream offset of grid slot 0 */
+	uint64_t len;		/* stream length in bytes */
+	uint32_t nslots;
+	uint32_t chunk;		/* bytes per tetra_burst_sync_in() call being emulated */
+	uint32_t y32, y6, n22, p22;
+};
+
+__global__ __launch_bounds__(256)
+void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
+		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls)
+{
+	constexpr int WIN = TG_STREAM_VIEW / 4 + 4;	/* 160 data dwords + one zero pad row */
+	__shared__ uint32_t s_slot[4][WIN];
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t wave = blockIdx.x * 4 + wib;
+	const uint32_t nwaves = gridDim.x * 4;
+	const uint32_t half = lane >> 5, bit = lane & 31;
+	uint32_t *mine = s_slot[wib];
+	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];
+	const uint32_t wbase = wib * WIN * 4;
+	if (lane < 4)
+		mine[TG_STREAM_VIEW / 4 + lane] = 0;	/* "no source" gathers read this */
+
+	uint32_t a_n1[10], a_n2[10], a_sb[10];
+#pragma unroll
+	for (int r = 0; r < 10; r++) {
+		const uint32_t o0 = c_tab.front_src[0][2 * r + half][bit];
+		const uint32_t o1 = c_tab.front_src[1][2 * r + half][bit];
+		const uint32_t o2 = c_tab.front_src[2][2 * r + half][bit];
+		a_n1[r] = wbase + (o0 == 0xffff ? TG_STREAM_VIEW : o0);
+		a_n2[r] = wbase + (o1 == 0xffff ? TG_STREAM_VIEW : o1);
+		a_sb[r] = wbase + (o2 == 0xffff ? TG_STREAM_VIEW : o2);
+	}
+
+	for (uint32_t slot = wave; slot < prm.nslots; slot += nwaves) {
+		const uint64_t bs = prm.anchor + (uint64_t)slot * TG_SLOT_BITS;
+		const uint8_t *base = stream + bs;
+		/* 640 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack) */
+		const uint32_t d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
+		const uint32_t d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
+		const uint32_t d2 = (lane < 32) ? *(const tg_u32_unaligned *)(base + 512 + 4 * lane) : 0u;
+
+		uint64_t fed = ((bs + TG_SLOT_BITS + prm.chunk - 1) / prm.chunk) * prm.chunk;
+		if (fed > prm.len)
+			fed = prm.len;
+		const uint32_t w = (uint32_t)(fed - bs);			/* search window, >= 510 */
+		const uint32_t wv = w < TG_STREAM_VIEW ? w : TG_STREAM_VIEW;	/* what we can see of it */
+
+		mine[lane] = d0;
+		mine[64 + lane] = d1;
+		if (lane < 32)
+			mine[128 + lane] = d2;
+
+		/* bytes -> 640-bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes outside the window read as 0 */
+		unsigned long long B[11];
+		uint32_t anyb = 0;
+#pragma unroll
+		for (int r = 0; r < 10; r++) {
+			uint32_t byte = lds0[wbase + 64 * r + lane];
+			if (64u * r + lane >= wv)
+				byte = 0;
+			anyb |= byte;
+			B[r] = __ballot(byte != 0);
+		}
+		B[10] = 0;
+
+		uint32_t rc = TG_BURST_NONE, offs = 0, flags = 0, early = 0;
+		bool found = false;
+#pragma unroll
+		for (int r = 0; r < 10; r++) {
+			if ((r < 4 || !found) && 64u * r < wv) {
+				const uint32_t c = 64 * r + lane;
+				const uint32_t b0 = (uint32_t)B[r], b1 = (uint32_t)(B[r] >> 32);
+				const uint32_t b2 = (uint32_t)B[r + 1], b3 = (uint32_t)(B[r + 1] >> 32);
+				const uint32_t w0 = half ? b1 : b0, w1 = half ? b2 : b1, w2 = half ? b3 : b2;
+				const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bit);
+				const uint32_t win2 = __builtin_amdgcn_alignbit(w2, w1, bit);
+				const bool isy = (win == prm.y32) && ((win2 & 0x3f) == prm.y6) && (c + 38 <= w);
+				const bool isn = ((win & 0x3fffff) == prm.n22) && (c + 22 <= w);
+				const bool isp = ((win & 0x3fffff) == prm.p22) && (c + 22 <= w);
+				const bool any = isy || isn || isp;
+				if (r == 0)
+					early = __ballot(any && c < 21) != 0;
+				const unsigned long long m = __ballot(any && c >= 21);
+				if (!found && m) {
+					const uint32_t l0 = __builtin_ctzll(m);
+					offs = 64 * r + l0;
+					const uint32_t ty = isy ? TG_BURST_SYNC : isn ? TG_BURST_NORM_1 : TG_BURST_NORM_2;
+					rc = __builtin_amdgcn_readlane(ty, l0);
+					found = true;
+				}
+			}
+		}
+		if (early)
+			flags |= TG_CLS_EARLY21;
+		if (__ballot(anyb > 1))
+			flags |= TG_CLS_NONBINARY;
+		if (!found && w > TG_STREAM_VIEW)
+			flags |= TG_CLS_CLIPPED;
+
+		/* what tetra_burst_sync_in() would hand to tetra_burst_rx_cb() (phy/tetra_burst_sync.c:121-141) */
+		uint32_t dtype = TG_BURST_NONE;
+		if (rc == TG_BURST_SYNC && offs == TG_SYNC_TRAIN_OFF)
+			dtype = TG_BURST_SYNC;
+		else if ((rc == TG_BURST_NORM_1 || rc == TG_BURST_NORM_2) && offs == TG_NORM_TRAIN_OFF)
+			dtype = rc;
+
+		uint32_t myword = 0, acc = 0;
+		if (dtype == TG_BURST_NORM_1)
+			myword = front_gather(lds0, a_n1, acc);
+		else if (dtype == TG_BURST_NORM_2)
+			myword = front_gather(lds0, a_n2, acc);
+		else if (dtype == TG_BURST_SYNC)
+			myword = front_gather(lds0, a_sb, acc);
+		if (lane == TG_PW_META)
+			myword = dtype | (((flags & TG_CLS_NONBINARY) ? TG_FLAG_NONBINARY : 0u) << 8) | (offs << 16);
+		if (lane < TG_PACKED_WORDS)
+			packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
+		if (lane == 0)
+			cls[slot] = rc | (offs << 8) | (flags << 24);
+	}
+}
+
+/* ------------------------------------------------------------------------- */
 /* k_vit<KIND>                                                               */
 /* ------------------------------------------------------------------------- */
 template <int KIND> struct vit_cfg;
@@ -669,6 +818,41 @@ extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 		blocks = 256 * 16;
 	hipLaunchKernelGGL(k_front, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
 			   d_stream, d_slot_desc, nslots, d_packed, d_rec);
+	return (int)hipGetLastError();
+}
+
+static const uint8_t tsq_n[22] = { 1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0 };
+static const uint8_t tsq_p[22] = { 0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0 };
+static const uint8_t tsq_y[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
+
+static uint32_t host_pattern_bits(const uint8_t *seq, int from, int n)
+{
+	uint32_t v = 0;
+	for (int i = 0; i < n; i++)
+		v |= (uint32_t)seq[from + i] << i;
+	return v;
+}
+
+extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
+				uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, void *stream)
+{
+	if (!nslots)
+		return 0;
+	if (!chunk)
+		return -1;
+	tg_stream_params prm;
+	prm.anchor = anchor;
+	prm.len = len;
+	prm.nslots = nslots;
+	prm.chunk = chunk;
+	prm.y32 = host_pattern_bits(tsq_y, 0, 32);
+	prm.y6 = host_pattern_bits(tsq_y, 32, 6);
+	prm.n22 = host_pattern_bits(tsq_n, 0, 22);
+	prm.p22 = host_pattern_bits(tsq_p, 0, 22);
+	uint32_t blocks = (nslots + 3) / 4;
+	if (blocks > 256 * 8)
+		blocks = 256 * 8;
+	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_stream, prm, d_packed, d_cls);
 	return (int)hipGetLastError();
 }
 

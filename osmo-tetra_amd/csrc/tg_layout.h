@@ -57,6 +57,21 @@
 #define TG_PW_BBK         18
 #define TG_PW_META        19
 
+/*
+ * Classification word of the stream front-end (one per grid slot):
+ *   bits 0..7   first training sequence found in the search window (enum tetra_train_seq) or 0xff
+ *   bits 8..23  its offset
+ *   bits 24..31 TG_CLS_* flags
+ * Semantics = tetra_find_train_seq(slot, w, NORM_1|NORM_2|SYNC) of the reference restricted to
+ * positions >= 21; a hit below 21 (where the reference's look-ahead filter is skewed) only raises
+ * TG_CLS_EARLY21 and is settled on the host with the exact routine.
+ */
+#define TG_CLS_EARLY21    0x01	/* a full match exists at an offset < 21 */
+#define TG_CLS_NONBINARY  0x02
+#define TG_CLS_CLIPPED    0x04	/* window longer than the kernel's 640-byte view and nothing found in view */
+#define TG_STREAM_VIEW    640	/* bytes of a slot's search window the kernel looks at */
+#define TG_STREAM_SLACK   192	/* readable bytes the stream buffer must have after its last byte */
+
 #define TG_FLAG_NONBINARY 0x01	/* a stream byte other than 0/1 was seen in a coded field */
 
 /* scrambling-mask table entry: 32 dwords, same bit layout as the code words */

@@ -1,0 +1,377 @@
+/*
+ * tg_stream.c -- burst synchronisation of a whole recorded stream, GPU-assisted.
+ *
+ * tetra_burst_sync_in() (phy/tetra_burst_sync.c:54-154) is a per-call state machine.  For a stream of
+ * 'len' bytes fed 'chunk' bytes per call (tetra-rx.c:82-95 uses 64) its behaviour is a closed-form
+ * function of the byte positions:
+ *   call k has been fed F(k) = min(k*chunk, len) bytes;
+ *   UNLOCKED  : from the first call with >= 1020 buffered bytes, every call looks for the first SYNC
+ *               training sequence in the buffer (which starts at bs and, once 4096 bytes are buffered,
+ *               slides); a hit at p gives next_frame_start = p + 296 (:81);
+ *   KNOW_FSTART: the first LATER call with F(k) >= next_frame_start moves the buffer start there (:93-105)
+ *               and, in the same call, goes on as LOCKED;
+ *   LOCKED    : a call with F(k) - bs >= 510 handles exactly one burst: the search window is everything
+ *               buffered, w = F(k) - bs (:117-120); then bs += 510 (:145-148).
+ * tgpu_sync_walk() evaluates exactly that, slot by slot instead of call by call.  Where a slot lies on
+ * the grid the GPU front end has classified (k_front_stream: first training sequence in the window),
+ * the classification word replaces the byte scan; everything the kernel cannot settle (hits below
+ * offset 21 where the reference's look-ahead filter is skewed, windows larger than its view, slots off
+ * the grid) is settled here with tetra_find_train_seq() on the bytes, i.e. by the reference's own rule.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "tetra_gpu.h"
+#include "tg_layout.h"
+#include "tg_internal.h"
+
+#define MASK_LOCKED ((1u << TETRA_TRAIN_NORM_1) | (1u << TETRA_TRAIN_NORM_2) | (1u << TETRA_TRAIN_SYNC))
+
+struct walk {
+	const uint8_t *s;
+	uint64_t len;
+	uint64_t chunk;
+	uint64_t ncalls;
+	struct tgpu_sync_result *out;
+	uint32_t cap_slots, cap_events;
+};
+
+static inline uint64_t fed(const struct walk *w, uint64_t k)
+{
+	uint64_t f = k * w->chunk;
+	return f > w->len ? w->len : f;
+}
+
+/* first call index whose fed count reaches 'pos' (>= 1); ncalls + 1 if never */
+static inline uint64_t call_reaching(const struct walk *w, uint64_t pos)
+{
+	if (pos > w->len)
+		return w->ncalls + 1;
+	uint64_t k = (pos + w->chunk - 1) / w->chunk;
+	return k ? k : 1;
+}
+
+static int push_event(struct walk *w, int ev, uint64_t bitnum, uint32_t arg)
+{
+	struct tgpu_sync_result *o = w->out;
+	if (o->nevents == w->cap_events) {
+		uint32_t nc = w->cap_events ? w->cap_events * 2 : 1024;
+		void *p = realloc(o->events, (size_t)nc * sizeof(*o->events));
+		if (!p)
+			return TGPU_ENOMEM;
+		o->events = p;
+		w->cap_events = nc;
+	}
+	o->events[o->nevents].ev = ev;
+	o->events[o->nevents].bitnum = (uint32_t)bitnum;
+	o->events[o->nevents].arg = arg;
+	o->nevents++;
+	return 0;
+}
+
+static int push_slot(struct walk *w, uint64_t off, int type, uint32_t seq, uint32_t tn_adds)
+{
+	struct tgpu_sync_result *o = w->out;
+	if (o->nslots == w->cap_slots) {
+		uint32_t nc = w->cap_slots ? w->cap_slots * 2 : 4096;
+		void *p = realloc(o->slots, (size_t)nc * sizeof(*o->slots));
+		if (!p)
+			return TGPU_ENOMEM;
+		o->slots = p;
+		w->cap_slots = nc;
+	}
+	o->slots[o->nslots].off = off;
+	o->slots[o->nslots].burst_seq = seq;
+	o->slots[o->nslots].tn_adds = tn_adds;
+	o->slots[o->nslots].type = (uint8_t)type;
+	o->nslots++;
+	return 0;
+}
+
+/* first start position of the SYNC training sequence in [from, last], UINT64_MAX if none */
+static uint64_t next_sync_seq(const struct walk *w, uint64_t from, uint64_t last)
+{
+	static const uint8_t y[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
+	uint64_t y8;
+	memcpy(&y8, y, 8);
+	if (last + 38 > w->len)
+		last = w->len >= 38 ? w->len - 38 : 0;
+	for (uint64_t p = from; p <= last && p + 38 <= w->len; p++) {
+		uint64_t v;
+		memcpy(&v, w->s + p, 8);
+		if (v == y8 && !memcmp(w->s + p + 8, y + 8, 30))
+			return p;
+	}
+	return UINT64_MAX;
+}
+
+/* the reference's routine on the bytes; the buffer it sees is [pos, pos + n) followed by whatever the
+ * stream holds next (it peeks up to 21 bytes past the window, never using them for a hit) */
+static int exact_find(const struct walk *w, uint64_t pos, uint32_t n, uint32_t mask, unsigned int *offs)
+{
+	if (pos + n + 22 <= w->len)
+		return tetra_find_train_seq(w->s + pos, n, mask, offs);
+	uint8_t *tmp = calloc(1, (size_t)n + 32);
+	if (!tmp)
+		return -1;
+	memcpy(tmp, w->s + pos, (size_t)(w->len - pos < n ? w->len - pos : n));
+	if (pos + n < w->len)
+		memcpy(tmp + n, w->s + pos + n, (size_t)(w->len - pos - n));
+	int rc = tetra_find_train_seq(tmp, n, mask, offs);
+	free(tmp);
+	return rc;
+}
+
+int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor,
+		   const uint32_t *cls, uint32_t ncls, struct tgpu_sync_result *out)
+{
+	/* chunk <= 510: a call never feeds more than a burst consumes, so the 4096-byte buffer can only
+	 * overflow (and drop data) while UNLOCKED -- which is modelled.  tetra-rx.c uses 64. */
+	if (!h_stream || !out || !chunk || chunk > TG_SLOT_BITS)
+		return TGPU_EINVAL;
+	memset(out, 0, sizeof(*out));
+	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, out, 0, 0 };
+	int rc;
+
+	uint64_t bs = 0;	/* bitbuf_start_bitnum */
+	uint64_t k = 0;		/* index of the last call that has run */
+	uint32_t seq = 0, tn_adds = 0;
+	int state = RX_S_UNLOCKED;
+	uint64_t nfs = 0;
+
+	while (k < w.ncalls) {
+		if (state == RX_S_UNLOCKED) {
+			/* calls k+1, k+2, ...: buffer = [b, F(k)), b = max(bs, F(k) - 4096).  The reference
+			 * re-scans the whole buffer on every call; the outcome only depends on where SYNC
+			 * sequences start, so positions are looked at once ('clean_to' = everything before
+			 * it is known to hold no valid hit for the current buffer start). */
+			uint64_t found_p = 0, found_k = 0, found_bs = 0;
+			int found = 0;
+			uint64_t kk = k + 1;
+			uint64_t k1020 = call_reaching(&w, bs + 2 * TG_SLOT_BITS);	/* nothing happens below 1020 buffered bytes */
+			if (kk < k1020)
+				kk = k1020;
+			uint64_t clean_to = bs;
+			for (; kk <= w.ncalls && !found; kk++) {
+				const uint64_t f = fed(&w, kk);
+				const uint64_t b = (f > 4096 && f - 4096 > bs) ? f - 4096 : bs;
+				if (clean_to < b)
+					clean_to = b;
+				if (f - b < 2 * TG_SLOT_BITS || f < 38)
+					continue;	/* only at the stream tail */
+				const uint64_t last = f - 38;
+				while (clean_to <= last) {
+					const uint64_t p = next_sync_seq(&w, clean_to, last);
+					if (p == UINT64_MAX) {
+						clean_to = last + 1;
+						break;
+					}
+					if (p - b >= 21) {
+						found = 1;
+						found_p = p;
+					} else {
+						/* inside the skewed zone of the look-ahead filter: ask the exact routine
+						 * about this very buffer; its answer is final for this call */
+						unsigned int offs;
+						if (exact_find(&w, b, (uint32_t)(f - b), 1u << TETRA_TRAIN_SYNC, &offs) >= 0) {
+							found = 1;
+							found_p = b + offs;
+						} else
+							clean_to = last + 1;
+					}
+					break;
+				}
+				if (found) {
+					found_k = kk;
+					found_bs = b;
+				}
+			}
+			if (!found) {
+				k = w.ncalls;
+				break;
+			}
+			if ((rc = push_event(&w, TGPU_EV_FOUND_SYNC, found_bs, (uint32_t)(found_p - found_bs))))
+				return rc;
+			bs = found_bs;
+			nfs = found_p + 296;
+			k = found_k;
+			state = RX_S_KNOW_FSTART;
+			continue;
+		}
+		if (state == RX_S_KNOW_FSTART) {
+			uint64_t kl = call_reaching(&w, nfs);
+			if (kl <= k)
+				kl = k + 1;
+			if (kl > w.ncalls) {
+				k = w.ncalls;
+				break;
+			}
+			bs = nfs;
+			nfs += TG_SLOT_BITS;
+			state = RX_S_LOCKED;
+			k = kl - 1;	/* the LOCKED branch below may use call kl itself */
+		}
+		/* LOCKED: the next burst is handled by the first call >= k+1 that has 510 bytes of it */
+		uint64_t kj = call_reaching(&w, bs + TG_SLOT_BITS);
+		if (kj <= k)
+			kj = k + 1;
+		if (kj > w.ncalls) {
+			k = w.ncalls;
+			break;
+		}
+		const uint32_t win = (uint32_t)(fed(&w, kj) - bs);
+		k = kj;
+		seq++;
+		tn_adds++;
+		if ((rc = push_event(&w, TGPU_EV_BURST, bs, win)))
+			return rc;
+
+		int type = -1;
+		unsigned int offs = 0;
+		int settled = 0;
+		if (cls && bs >= anchor && (bs - anchor) % TG_SLOT_BITS == 0 && (bs - anchor) / TG_SLOT_BITS < ncls) {
+			const uint32_t cw = cls[(bs - anchor) / TG_SLOT_BITS];
+			const uint32_t flags = cw >> 24;
+			/* window the kernel assumed: the steady-state one */
+			uint64_t f0 = ((bs + TG_SLOT_BITS + chunk - 1) / chunk) * chunk;
+			if (f0 > len)
+				f0 = len;
+			const uint32_t w0 = (uint32_t)(f0 - bs);
+			if (!(flags & TG_CLS_EARLY21)) {
+				if ((cw & 0xff) != TG_BURST_NONE) {
+					/* first hit at an offset >= 21 inside the assumed window: it is the first hit
+					 * of any window that contains it */
+					type = (int)(cw & 0xff);
+					offs = (cw >> 8) & 0xffff;
+					settled = 1;
+				} else if (win == w0 && !(flags & TG_CLS_CLIPPED)) {
+					type = -1;
+					settled = 1;
+				}
+			}
+		}
+		if (!settled)
+			type = exact_find(&w, bs, win, MASK_LOCKED, &offs);
+
+		if (type == TETRA_TRAIN_SYNC) {
+			if (offs == TG_SYNC_TRAIN_OFF) {
+				if ((rc = push_slot(&w, bs, type, seq, tn_adds)))
+					return rc;
+				tn_adds = 0;
+			} else {
+				if ((rc = push_event(&w, TGPU_EV_SYNC_MISPLACED, bs, offs)))
+					return rc;
+				state = RX_S_UNLOCKED;
+			}
+		} else if (type == TETRA_TRAIN_NORM_1 || type == TETRA_TRAIN_NORM_2) {
+			if (offs == TG_NORM_TRAIN_OFF) {
+				if ((rc = push_slot(&w, bs, type, seq, tn_adds)))
+					return rc;
+				tn_adds = 0;
+			} else if ((rc = push_event(&w, TGPU_EV_NORM_MISPLACED, bs, offs)))
+				return rc;
+		} else {
+			if ((rc = push_event(&w, TGPU_EV_NO_TRAIN, bs, 0)))
+				return rc;
+			state = RX_S_UNLOCKED;
+		}
+		bs += TG_SLOT_BITS;
+		nfs += TG_SLOT_BITS;
+	}
+	out->final_state = state;
+	out->tail_tn_adds = tn_adds;
+	out->burst_seq = seq;
+	return TGPU_OK;
+}
+
+void tgpu_sync_result_free(struct tgpu_sync_result *r)
+{
+	if (!r)
+		return;
+	free(r->slots);
+	free(r->events);
+	memset(r, 0, sizeof(*r));
+}
+
+/* first lock of a stream, host only: where the slot grid starts (0 if the stream never locks) */
+static int find_anchor(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t *anchor, int *locks)
+{
+	/* run the walk without classification until the first LOCKED burst: cheap, it stops early */
+	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, NULL, 0, 0 };
+	*locks = 0;
+	uint64_t kk = call_reaching(&w, 2 * TG_SLOT_BITS);
+	for (; kk <= w.ncalls; kk++) {
+		uint64_t f = fed(&w, kk);
+		uint64_t b = f > 4096 ? f - 4096 : 0;
+		if (f - b < 2 * TG_SLOT_BITS)
+			continue;
+		unsigned int offs;
+		if (exact_find(&w, b, (uint32_t)(f - b), 1u << TETRA_TRAIN_SYNC, &offs) >= 0) {
+			*anchor = b + offs + 296;
+			*locks = 1;
+			return TGPU_OK;
+		}
+	}
+	return TGPU_OK;
+}
+
+int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_t len, uint32_t chunk,
+		       uint64_t anchor, uint32_t nslots, uint32_t *h_cls, void *stream)
+{
+	if (!eng || !d_stream || !h_cls || !chunk)
+		return TGPU_EINVAL;
+	if (!nslots)
+		return TGPU_OK;
+	uint32_t *d_cls = NULL, *d_packed = NULL;
+	hipError_t e = hipMalloc((void **)&d_cls, (size_t)nslots * 4);
+	if (e == hipSuccess)
+		e = hipMalloc((void **)&d_packed, (size_t)nslots * TG_PACKED_WORDS * 4);
+	int rc = (int)e;
+	if (!rc)
+		rc = tgk_front_stream(d_stream, anchor, len, nslots, chunk, d_packed, d_cls, stream);
+	if (!rc)
+		rc = (int)hipMemcpyAsync(h_cls, d_cls, (size_t)nslots * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+	if (!rc)
+		rc = (int)hipStreamSynchronize((hipStream_t)stream);
+	if (d_cls)
+		(void)hipFree(d_cls);
+	if (d_packed)
+		(void)hipFree(d_packed);
+	return rc;
+}
+
+int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uint8_t *d_stream, uint64_t len,
+		     uint32_t chunk, struct tgpu_sync_result *out, void *stream)
+{
+	if (!eng || !h_stream || !d_stream || !out || !chunk)
+		return TGPU_EINVAL;
+	uint64_t anchor = 0;
+	int locks = 0;
+	int rc = find_anchor(h_stream, len, chunk, &anchor, &locks);
+	if (rc)
+		return rc;
+	uint32_t *cls = NULL;
+	uint32_t ncls = 0;
+	if (locks && anchor + TG_SLOT_BITS <= len) {
+		uint64_t n = (len - anchor) / TG_SLOT_BITS;
+		if (n > 0xfffffff0u)
+			return TGPU_ECAPACITY;
+		ncls = (uint32_t)n;
+		cls = malloc((size_t)ncls * 4);
+		if (!cls)
+			return TGPU_ENOMEM;
+		rc = tgpu_sync_classify(eng, d_stream, len, chunk, anchor, ncls, cls, stream);
+		if (rc) {
+			free(cls);
+			return rc;
+		}
+	}
+	rc = tgpu_sync_walk(h_stream, len, chunk, anchor, cls, ncls, out);
+	out->anchor = anchor;
+	free(cls);
+	return rc;
+}

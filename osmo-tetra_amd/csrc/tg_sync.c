@@ -392,6 +392,34 @@ int tgpu_channel_flush(struct tgpu_channel *ch)
 	return TGPU_OK;
 }
 
+int tgpu_channel_scramb_init(const struct tgpu_channel *ch, uint32_t *code)
+{
+	if (!ch || !code)
+		return TGPU_EINVAL;
+	*code = ch->scramb_init;
+	return TGPU_OK;
+}
+
+/* deliver records that were decoded outside the channel's own queue (stream / plan API): the same
+ * in-order replay as tgpu_channel_flush(), slot bytes taken from the host copy of the stream */
+int tgpu_channel_deliver(struct tgpu_channel *ch, uint32_t n, const struct tgpu_sync_slot *slots,
+			 const uint8_t *h_stream, const uint8_t *h_rec)
+{
+	if (!ch || (n && (!slots || !h_stream || !h_rec)))
+		return TGPU_EINVAL;
+	for (uint32_t i = 0; i < n; i++) {
+		struct pending pd = { slots[i].burst_seq, slots[i].tn_adds, slots[i].type };
+		const uint8_t *rec = h_rec + (size_t)i * TGPU_REC_BYTES;
+		struct tgpu_block blk[3];
+		for (uint32_t k = 0; k < pd.tn_adds; k++)
+			tetra_tdma_time_add_tn(&ch->phy_time, 1);
+		int nb = tgpu_record_blocks(rec, blk);
+		for (int k = 0; k < nb; k++)
+			deliver_block(ch, &pd, h_stream + slots[i].off, rec, &blk[k]);
+	}
+	return TGPU_OK;
+}
+
 static void queue_burst(struct tgpu_channel *ch, const uint8_t *burst, int type)
 {
 	struct pending *pd = &ch->pend[ch->n_pending];

@@ -398,3 +398,67 @@ def test_wire_records_equal_full_records(T, eng):
     back = T.wire_unpack(d_wire.cpu().numpy(), slot_ids=np.arange(n), codes=p["code"])
     assert (back == rec).all()
     plan.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 3: burst-sync correlation front end on the GPU
+# ---------------------------------------------------------------------------
+def _mutated_stream(seed, nframes=6):
+    rng = np.random.default_rng(seed)
+    stream, slots = synth.frame_stream(seed=seed, nframes=nframes, lead_in=int(rng.integers(0, 200)), ber=0.01)
+    y = np.array([1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1], np.uint8)
+    n = np.array([1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0], np.uint8)
+    p0 = np.flatnonzero((np.lib.stride_tricks.sliding_window_view(stream, 38) == y).all(axis=1))[0] + 296
+    s = stream.copy()
+    for i in rng.choice(len(slots), 5, replace=False):
+        base = p0 + 510 * int(i)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            s[base + (214 if slots[i][0] == O.TRAIN_SYNC else 244) + 4] ^= 1
+        elif kind == 1:
+            s[base + 60:base + 82] = n
+        elif kind == 2:
+            s[base + 300:base + 338] = y
+        else:
+            s[base + int(rng.integers(0, 21)):][:22] = n
+    return s
+
+
+def test_stream_classification_kernel(T, eng):
+    """k_front_stream's classification words == the definition (first y/n/p hit at offset >= 21 of the
+    window the reference would search), checked with a numpy statement of it"""
+    import torch
+    from test_stream_sync_cpu import emul_cls
+    for seed in (3, 4):
+        s = _mutated_stream(seed)
+        res = T.sync_walk(s)
+        anchor = res["slots"][0][0]
+        n = (len(s) - anchor) // 510
+        d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+        got = T.sync_classify(eng, d.data_ptr(), len(s), 64, anchor, n)
+        want = emul_cls(s, anchor, 64)
+        assert (got & 0x05FFFFFF).tolist() == (want & 0x05FFFFFF).tolist()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 5])
+def test_config3_stream_end_to_end(T, eng, seed):
+    """stream -> GPU sync front end -> plan decode -> in-order delivery == oracle tetra-rx equivalent"""
+    import torch
+    s = _mutated_stream(seed, nframes=8)
+    want, wev = O.run_rx(s)
+    d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+    res = T.sync_stream(eng, s, d.data_ptr())
+    assert res["events"] == wev
+    slots = res["slots"]
+    n = len(slots)
+    ch = T.Channel(eng, batch_slots=1)
+    plan = T.Plan(eng, max(n, 1), 1)
+    plan.load(np.array([x[0] for x in slots], np.uint64), np.array([x[1] for x in slots], np.uint8), None,
+              np.array([ch.scramb_init()], np.uint32))
+    d_rec = torch.zeros(max(n, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ch.deliver(slots, s, d_rec.cpu().numpy())
+    assert_same_records(ch.records, want)
+    plan.close()
+    ch.close()

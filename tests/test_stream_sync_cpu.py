@@ -1,0 +1,154 @@
+"""The closed-form stream synchroniser (tgpu_sync_walk, host half of BASELINE config 3) against the
+oracle's call-by-call state machine: same sync events, same bursts handed to the demux, same ordinals.
+cls=None settles every slot with tetra_find_train_seq() on the bytes, so no GPU is needed; a numpy
+emulation of the GPU classification words exercises the cls fast path as well."""
+import numpy as np
+import pytest
+
+import oraclelib as O
+import synth
+
+import osmo_tetra_amd as T
+
+SEQ_N = np.array([1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0], np.uint8)
+SEQ_Y = np.array([1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1], np.uint8)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    T.build_library()
+
+
+def oracle_view(stream, chunk):
+    recs, events = O.run_rx(stream, chunk=chunk)
+    bursts = []
+    for r in recs:
+        if not bursts or bursts[-1][0] != r["burst_seq"]:
+            bursts.append((r["burst_seq"], r["burst_type"]))
+    pos = {}
+    seq = 0
+    for ev, bitnum, arg in events:
+        if ev == 2:
+            seq += 1
+            pos[seq] = bitnum
+    return bursts, events, pos
+
+
+def emul_cls(stream, anchor, chunk, view=640):
+    """numpy statement of k_front_stream's classification words"""
+    L = len(stream)
+    n = (L - anchor) // 510 if L >= anchor + 510 else 0
+    pad = np.concatenate([stream, np.zeros(1024, np.uint8)])
+    out = np.zeros(n, np.uint32)
+    for i in range(n):
+        bs = anchor + 510 * i
+        f = min(-(-(bs + 510) // chunk) * chunk, L)
+        w = f - bs
+        wv = min(w, view)
+        buf = pad[bs:bs + 700].copy()
+        buf[wv:] = 0
+        rc, off, early = 0xFF, 0, 0
+        for c in range(0, wv):
+            t = None
+            if c + 38 <= w and (buf[c:c + 38] == SEQ_Y).all():
+                t = 3
+            elif c + 22 <= w and (buf[c:c + 22] == SEQ_N).all():
+                t = 0
+            elif c + 22 <= w and (buf[c:c + 22] == np.array([0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0])).all():
+                t = 1
+            if t is None:
+                continue
+            if c < 21:
+                early = 1
+                continue
+            rc, off = t, c
+            break
+        flags = early | (4 if (rc == 0xFF and w > view) else 0)
+        out[i] = rc | (off << 8) | (flags << 24)
+    return out
+
+
+def check(stream, chunk=64, with_cls=True):
+    bursts, oev, pos = oracle_view(stream, chunk)
+    res = T.sync_walk(stream, chunk=chunk)
+    assert res["events"] == oev
+    assert [(s[2], s[1]) for s in res["slots"]] == bursts
+    assert all(pos[s[2]] == s[0] & 0xFFFFFFFF for s in res["slots"])
+    # tn_adds: time steps between delivered bursts = difference of ordinals
+    prev = 0
+    for off, t, seq, tn in res["slots"]:
+        assert tn == seq - prev
+        prev = seq
+    if with_cls and res["slots"]:
+        anchor = min(s[0] for s in res["slots"]) % 510 + 510 * 0
+        first = res["slots"][0][0]
+        anchor = first - 510 * (first // 510) if False else first % 510
+        # grid anchored at the first locked slot position (any slot of the grid works as anchor)
+        anchor = first
+        cls = emul_cls(stream, anchor, chunk)
+        res2 = T.sync_walk(stream, chunk=chunk, anchor=anchor, cls=cls)
+        assert res2["events"] == oev and res2["slots"] == res["slots"]
+    return res
+
+
+def test_clean_stream_and_tail_lengths():
+    stream, _ = synth.frame_stream(seed=1, nframes=3)
+    for cut in (0, 1, 63, 64, 65, 509, 700, 1300):
+        check(stream[:len(stream) - cut] if cut else stream)
+    check(stream[:900])       # never locks
+    check(stream[:1100])
+    check(np.zeros(5000, np.uint8))
+
+
+@pytest.mark.parametrize("chunk", [64, 1, 7, 100, 128, 509, 510])
+def test_chunk_sizes(chunk):
+    stream, _ = synth.frame_stream(seed=2, nframes=2, lead_in=37)
+    check(stream, chunk=chunk, with_cls=(chunk <= 128))
+
+
+def test_chunk_above_a_slot_is_rejected():
+    with pytest.raises(T.TgpuError):
+        T.sync_walk(np.zeros(4000, np.uint8), chunk=511)
+
+
+def test_lock_loss_relock_and_spurious_sequences():
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        stream, slots = synth.frame_stream(seed=10 + trial, nframes=4, lead_in=int(rng.integers(0, 300)))
+        s = stream.copy()
+        p0 = np.flatnonzero((np.lib.stride_tricks.sliding_window_view(s, 38) == SEQ_Y).all(axis=1))[0] + 296
+        nsl = len(slots)
+        for _ in range(3):
+            i = int(rng.integers(0, nsl))
+            kind = trial % 4
+            base = p0 + 510 * i
+            if kind == 0:      # corrupt the training sequence -> loss of lock (NORM) / misplaced
+                off = 214 if slots[i][0] == O.TRAIN_SYNC else 244
+                s[base + off + int(rng.integers(0, 22))] ^= 1
+            elif kind == 1:    # spurious n sequence early in the payload -> burst dropped, lock kept
+                s[base + 30:base + 52] = SEQ_N
+            elif kind == 2:    # spurious SYNC sequence in a payload -> "SYNC at offset ?" -> unlock
+                s[base + 40:base + 78] = SEQ_Y
+            else:              # a match inside the first 21 bits of a slot (skewed look-ahead filter zone)
+                s[base + int(rng.integers(0, 21)):][:22] = SEQ_N
+        check(s)
+
+
+def test_sync_sequence_near_buffer_start_after_loss():
+    """after a loss of lock the next SYNC sequence may sit below offset 21 of the new buffer"""
+    stream, slots = synth.frame_stream(seed=33, nframes=3, lead_in=50)
+    p0 = np.flatnonzero((np.lib.stride_tricks.sliding_window_view(stream, 38) == SEQ_Y).all(axis=1))[0] + 296
+    for d in (0, 5, 20, 21, 22):
+        s = stream.copy()
+        s[p0 + 510 * 2 + 244 + 3] ^= 1             # slot 2 (NORM) loses lock; buffer then starts at slot 3
+        s[p0 + 510 * 3 + d:p0 + 510 * 3 + d + 38] = SEQ_Y
+        check(s)
+
+
+def test_long_gap_slides_the_4096_byte_buffer():
+    rng = np.random.default_rng(8)
+    a, _ = synth.frame_stream(seed=40, nframes=1, pad=0)
+    b, _ = synth.frame_stream(seed=41, nframes=2, lead_in=0)
+    gap = rng.integers(0, 2, 9000).astype(np.uint8)
+    check(np.concatenate([a, gap, b]), with_cls=False)
+    check(np.concatenate([a, np.zeros(5003, np.uint8), b]), with_cls=False)
