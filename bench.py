@@ -68,6 +68,59 @@ def cpu_baseline(slots, types, budget_s=12.0):
             "host_cores_available": os.cpu_count()}
 
 
+def bench_config3(args, T, torch, rank, world, local):
+    """BASELINE config 3 (secondary measurement, N=1): one channel, frames of 8 slots
+    [SB, N1, N2, N1, N2, N1, N2, N1], cell code from MCC 262 / MNC 42 / CC 1, 1 % of the slots with a
+    corrupted training sequence (drop / loss of lock / re-lock).  One step = GPU sync front end +
+    host walk + plan load + decode of everything that stays locked."""
+    n = args.bursts
+    rng = np.random.default_rng(7)
+    pat = np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8)
+    types = np.tile(pat, n // 8 + 1)[:n]
+    code = 0x41802A07
+    slots = T.synth_slots(np.concatenate([[3], types]).astype(np.uint8), seed=11, scramb_init=code)
+    bad = np.flatnonzero(rng.random(n) < 0.01) + 1
+    for i in bad:
+        off = 214 if slots[i, 214:252].tolist() == slots[0, 214:252].tolist() else 244
+        slots[i, off + 5] ^= 1
+    stream = np.concatenate([rng.integers(0, 2, 100).astype(np.uint8), slots.reshape(-1), np.zeros(700, np.uint8)])
+    eng = T.Engine(local)
+    d_stream = torch.from_numpy(np.concatenate([stream, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+    d_rec = torch.empty((n + 8) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n + 8, 1)
+    hs = torch.cuda.current_stream().cuda_stream
+    t_sync = t_load = t_exec = 0.0
+    nslots = 0
+    for k in range(args.warmup + args.steps):
+        if k == args.warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t_sync = t_load = t_exec = 0.0
+        a = time.perf_counter()
+        res = T.sync_stream(eng, stream, d_stream.data_ptr(), 64, hs)
+        b = time.perf_counter()
+        sl = res["slot_arr"]
+        plan.load(sl["off"], sl["type"], None, np.zeros(1, np.uint32))
+        c = time.perf_counter()
+        plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), hs)
+        torch.cuda.synchronize()
+        d = time.perf_counter()
+        t_sync += b - a; t_load += c - b; t_exec += d - c
+        nslots = len(sl)
+    el = time.perf_counter() - t0
+    p = T.parse_records(d_rec.view(-1, T.REC_BYTES)[:2048].cpu().numpy())
+    out = {"metric": "decoded bursts/s", "value": n * args.steps / el, "unit": "bursts/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+           "config": {"workload": "BASELINE config 3: %d-burst mixed SB/NDB stream, GPU burst-sync front end, 1%% corrupted "
+                                  "training sequences; step = sync (GPU classify + host walk) + plan load + decode" % n,
+                      "bursts_in_stream": n, "bursts_delivered": nslots, "crc_ok_first_2048": int(p["crc_ok"][:, 0].sum())},
+           "breakdown_ms": {"sync_stream(GPU classify + D2H + host walk, incl. python list conversion)": t_sync / args.steps * 1e3,
+                            "plan_load(host lists + H2D)": t_load / args.steps * 1e3,
+                            "plan_execute(GPU decode)": t_exec / args.steps * 1e3}}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +129,9 @@ def main():
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts per GPU per step")
     ap.add_argument("--ber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3"],
+                    help="config2 (default, the metric's workload): aligned NDB slots; config3: mixed SB/NDB stream "
+                         "through the GPU burst-sync front end, 1%% corrupted training sequences")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = control-flow check on a box with fewer GPUs than ranks (gather staged through the host)")
     args = ap.parse_args()
@@ -101,6 +157,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
+
+    if args.workload == "config3":
+        return bench_config3(args, T, torch, rank, world, local)
 
     n = args.bursts
     rng = np.random.default_rng(1000 + rank)

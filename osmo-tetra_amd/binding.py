@@ -302,11 +302,39 @@ def synth_slots(types, seed=1, scramb_init=0, mcc=262, mnc=42, cc=1, ber=0.0, nu
 STREAM_SLACK = 192
 
 
+SLOT_DTYPE = np.dtype([("off", np.uint64), ("burst_seq", np.uint32), ("tn_adds", np.uint32), ("type", np.uint8)], align=True)
+EVENT_DTYPE = np.dtype([("ev", np.int32), ("bitnum", np.uint32), ("arg", np.uint32)], align=True)
+
+
+class SyncOutcome(dict):
+    """result of the stream synchroniser; 'slot_arr' / 'event_arr' are numpy structured arrays
+    (SLOT_DTYPE / EVENT_DTYPE), 'slots' / 'events' lazily built python tuples (off, type, burst_seq, tn_adds) / (ev, bitnum, arg)"""
+
+    def __missing__(self, key):
+        if key == "slots":
+            a = self["slot_arr"]
+            v = list(zip(a["off"].tolist(), a["type"].tolist(), a["burst_seq"].tolist(), a["tn_adds"].tolist()))
+        elif key == "events":
+            a = self["event_arr"]
+            v = list(zip(a["ev"].tolist(), a["bitnum"].tolist(), a["arg"].tolist()))
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+
 def _sync_result_to_py(res):
-    slots = [(res.slots[i].off, res.slots[i].type, res.slots[i].burst_seq, res.slots[i].tn_adds) for i in range(res.nslots)]
-    events = [(res.events[i].ev, res.events[i].bitnum, res.events[i].arg) for i in range(res.nevents)]
-    out = dict(slots=slots, events=events, final_state=res.final_state, tail_tn_adds=res.tail_tn_adds,
-               burst_seq=res.burst_seq, anchor=res.anchor)
+    assert SLOT_DTYPE.itemsize == C.sizeof(SyncSlot) and EVENT_DTYPE.itemsize == C.sizeof(SyncEventRec)
+    if res.nslots:
+        sa = np.frombuffer(C.string_at(res.slots, res.nslots * SLOT_DTYPE.itemsize), SLOT_DTYPE).copy()
+    else:
+        sa = np.zeros(0, SLOT_DTYPE)
+    if res.nevents:
+        ea = np.frombuffer(C.string_at(res.events, res.nevents * EVENT_DTYPE.itemsize), EVENT_DTYPE).copy()
+    else:
+        ea = np.zeros(0, EVENT_DTYPE)
+    out = SyncOutcome(slot_arr=sa, event_arr=ea, final_state=res.final_state, tail_tn_adds=res.tail_tn_adds,
+                      burst_seq=res.burst_seq, anchor=res.anchor)
     lib().tgpu_sync_result_free(C.byref(res))
     return out
 
@@ -404,12 +432,15 @@ class Channel:
 
     def deliver(self, slots, h_stream, h_rec):
         """slots: list of (off, type, burst_seq, tn_adds) from sync_stream(); h_rec: (n,320) host records"""
-        arr = (SyncSlot * len(slots))()
-        for i, (off, t, seq, tn) in enumerate(slots):
-            arr[i].off, arr[i].type, arr[i].burst_seq, arr[i].tn_adds = off, t, seq, tn
+        if isinstance(slots, np.ndarray) and slots.dtype == SLOT_DTYPE:
+            a = np.ascontiguousarray(slots)
+        else:
+            a = np.zeros(len(slots), SLOT_DTYPE)
+            for i, (off, t, seq, tn) in enumerate(slots):
+                a[i] = (off, seq, tn, t)
         h_stream, h_rec = _np_u8(h_stream), _np_u8(h_rec)
-        _chk(lib().tgpu_channel_deliver(self._h, len(slots), arr, h_stream.ctypes.data_as(u8p),
-                                        h_rec.ctypes.data_as(u8p)), "tgpu_channel_deliver")
+        _chk(lib().tgpu_channel_deliver(self._h, len(a), a.ctypes.data_as(C.POINTER(SyncSlot)),
+                                        h_stream.ctypes.data_as(u8p), h_rec.ctypes.data_as(u8p)), "tgpu_channel_deliver")
 
     def close(self):
         if self._h:

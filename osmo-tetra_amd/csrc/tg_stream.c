@@ -22,7 +22,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
 #include "tetra_gpu.h"
@@ -344,6 +346,13 @@ int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_
 	return rc;
 }
 
+static double now_ms(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uint8_t *d_stream, uint64_t len,
 		     uint32_t chunk, struct tgpu_sync_result *out, void *stream)
 {
@@ -351,6 +360,7 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
 		return TGPU_EINVAL;
 	uint64_t anchor = 0;
 	int locks = 0;
+	const double t0 = now_ms();
 	int rc = find_anchor(h_stream, len, chunk, &anchor, &locks);
 	if (rc)
 		return rc;
@@ -370,8 +380,12 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
 			return rc;
 		}
 	}
+	const double t1 = now_ms();
 	rc = tgpu_sync_walk(h_stream, len, chunk, anchor, cls, ncls, out);
 	out->anchor = anchor;
 	free(cls);
+	if (getenv("TGPU_SYNC_TIMING"))
+		fprintf(stderr, "tgpu_sync_stream: anchor+classify %.3f ms, walk %.3f ms (%u slots, %u events)\n",
+			t1 - t0, now_ms() - t1, out->nslots, out->nevents);
 	return rc;
 }
