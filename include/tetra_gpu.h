@@ -159,6 +159,28 @@ int tgpu_plan_load(struct tgpu_plan *plan, uint32_t nslots, const uint64_t *slot
  */
 int tgpu_plan_execute(struct tgpu_plan *plan, const uint8_t *d_stream, uint8_t *d_rec, void *hip_stream);
 
+/*
+ * Soft input (BASELINE config 5 -- an extension: the reference slices hard in float_to_bits and has no
+ * soft path).  d_soft_stream has the layout of the bit stream (slot offsets of the loaded batch apply)
+ * but holds int8 soft values: positive = bit 0, negative = bit 1, 0 = erasure, |v| <= 127.  The decoder
+ * then maximises the correlation metric (what libosmocore's accelerated osmo_conv_decode does with soft
+ * values) with the same tie rule; BBK bits are the signs.  Records come out in the same format.
+ */
+int tgpu_plan_execute_soft(struct tgpu_plan *plan, const int8_t *d_soft_stream, uint8_t *d_rec, void *hip_stream);
+
+/*
+ * float_to_bits.c on the device: n float32 phase values (units of pi/4) -> 2 n bits, 1 per byte, with
+ * the slicer of float_to_bits.c:33-72 (bit-exact, NaN included).  d_soft (optional, 2 n int8):
+ * soft0 = sat127(rint(64 phi)), soft1 = sat127(rint(64 (2 - |phi|))).
+ * The _afc variant adds the pseudo-AFC of float_to_bits.c:142-146 (-a -f filter_val -F filter_goal): a
+ * sequential IIR, run by one lane in the reference's operation order; *filter_state carries the
+ * filter value across calls (start with 0).  It synchronises the stream.
+ */
+int tgpu_float_to_bits(struct tgpu_engine *eng, const float *d_in, uint64_t n, uint8_t *d_bits, int8_t *d_soft,
+		       void *hip_stream);
+int tgpu_float_to_bits_afc(struct tgpu_engine *eng, const float *d_in, uint64_t n, uint8_t *d_bits, float filter_val,
+			   float filter_goal, float *filter_state, void *hip_stream);
+
 /* scrambling code in effect per channel after the batch (device->host copy, synchronises) */
 int tgpu_plan_final_codes(struct tgpu_plan *plan, const uint8_t *d_rec, uint32_t *chan_code_out);
 

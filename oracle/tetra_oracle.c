@@ -896,3 +896,69 @@ uint64_t orc_bench_decode_slots(const uint8_t *slots, const uint8_t *types, size
 	}
 	return ok;
 }
+
+/* ======================================================================
+ * Soft-input extension (BASELINE config 5).  The reference has NO soft path:
+ * float_to_bits hard-slices (float_to_bits.c:33-72) and viterbi.c:11-23 maps
+ * bits to +-127.  What follows is OUR definition,
+ * restated here so the GPU path has something to be bit-exact against:
+ *   per symbol phi (units of pi/4):  soft0 = sat(rint(64*phi)),
+ *                                    soft1 = sat(rint(64*(2-|phi|))),  sat to [-127,127]
+ *   sign convention of viterbi.c: positive = bit 0, negative = bit 1, 0 = erasure;
+ *   descrambling flips the sign where the scrambling bit is 1;
+ *   decoder = libosmocore's accelerated algorithm (correlation metrics), same tie rule.
+ * Hard-slicing the soft values (bit = soft < 0) gives float_to_bits' output
+ * except at phi = 0, +-2 exactly and NaN (float_to_bits has its own rules there).
+ * ==================================================================== */
+static inline int8_t sat127(float x)
+{
+	if (x != x)
+		return 0;
+	if (x > 127.0f)
+		return 127;
+	if (x < -127.0f)
+		return -127;
+	return (int8_t)__builtin_rintf(x);
+}
+
+void orc_float_to_soft(const float *in, size_t n, int8_t *out2n)
+{
+	for (size_t i = 0; i < n; i++) {
+		float phi = in[i];
+		out2n[2 * i] = sat127(64.0f * phi);
+		out2n[2 * i + 1] = sat127(64.0f * (2.0f - __builtin_fabsf(phi)));
+	}
+}
+
+void orc_decode_block_soft(enum orc_tpsap_type type, const int8_t *soft5, uint32_t scramb_init, struct orc_block_result *res)
+{
+	const struct orc_blk_param *p = &blk_params[type];
+	int8_t t4[432], t3[432];
+	static __thread int8_t mother[288 * 4 + 16];
+	uint8_t seq[432];
+
+	orc_scramb_get_bits(scramb_init, seq, p->type345_bits);
+	for (unsigned i = 0; i < p->type345_bits; i++) {
+		t4[i] = seq[i] ? (int8_t)-soft5[i] : soft5[i];
+		res->type4[i] = (uint8_t)((soft5[i] < 0) ^ seq[i]);	/* hard decision on the received value, then descrambled */
+	}
+	res->crc = 0;
+	res->crc_ok = 0;
+	memset(res->type2, 0, sizeof(res->type2));
+	if (p->interleave_a) {
+		for (uint32_t i = 1; i <= p->type345_bits; i++)
+			t3[i - 1] = t4[(p->interleave_a * i) % p->type345_bits];
+		memset(mother, 0, sizeof(mother));
+		for (uint32_t j = 1; j <= p->type345_bits; j++)
+			mother[punct_k(&punct_defs[ORC_PUNCT_2_3], j) - 1] = t3[j - 1];
+		orc_viterbi_soft(mother, res->type2, p->type2_bits);
+	}
+	if (p->have_crc16) {
+		res->crc = orc_crc16_ccitt_bits(res->type2, p->type1_bits + 16u);
+		res->crc_ok = (res->crc == ORC_CRC_OK);
+	} else if (type == ORC_T_BBK) {
+		res->crc_ok = 1;
+		memcpy(res->type2, res->type4, p->type2_bits);
+	}
+	memcpy(res->type1, res->type2, p->type1_bits);
+}

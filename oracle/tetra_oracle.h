@@ -236,6 +236,11 @@ void orc_tp_sap_udata_ind(struct orc_rx *rx, int type, int blk_num, const uint8_
 void orc_float_to_bits(const float *in, size_t n, uint8_t *out2n, int afc,
 		       float filter_val, float filter_goal, float *filter_state);
 
+/* ---- soft-input extension (config 5; our definition, the reference has none) ---- */
+void orc_float_to_soft(const float *in, size_t n, int8_t *out2n);
+void orc_decode_block_soft(enum orc_tpsap_type type, const int8_t *soft5, uint32_t scramb_init,
+			   struct orc_block_result *res);
+
 /* ---- CPU baseline: decode n aligned slots of known type, no callbacks -- */
 /* returns number of CRC-OK blocks; types[i] is enum orc_train_seq         */
 uint64_t orc_bench_decode_slots(const uint8_t *slots, const uint8_t *types, size_t n,

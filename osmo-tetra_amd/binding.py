@@ -106,6 +106,10 @@ def lib():
     L.tgpu_plan_load.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p, C.c_uint32, u32p]
     L.tgpu_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_plan_final_codes.argtypes = [C.c_void_p, C.c_void_p, u32p]
+    L.tgpu_plan_execute_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tgpu_float_to_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tgpu_float_to_bits_afc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_float, C.c_float,
+                                         C.POINTER(C.c_float), C.c_void_p]
     L.tgpu_plan_set_wire.argtypes = [C.c_void_p, C.c_void_p]
     L.tgpu_wire_unpack.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
     L.tgpu_plan_read_packed.argtypes = [C.c_void_p, u32p]
@@ -154,6 +158,17 @@ class Engine:
         _chk(lib().tgpu_engine_create(C.byref(self._h), device), "tgpu_engine_create")
         self.device = device
 
+    def float_to_bits(self, d_in_ptr, n, d_bits_ptr, d_soft_ptr=0, hip_stream=0):
+        _chk(lib().tgpu_float_to_bits(self._h, C.c_void_p(d_in_ptr), n, C.c_void_p(d_bits_ptr),
+                                      C.c_void_p(d_soft_ptr), C.c_void_p(hip_stream)), "tgpu_float_to_bits")
+
+    def float_to_bits_afc(self, d_in_ptr, n, d_bits_ptr, filter_val=0.0001, filter_goal=0.0, state=0.0, hip_stream=0):
+        st = C.c_float(state)
+        _chk(lib().tgpu_float_to_bits_afc(self._h, C.c_void_p(d_in_ptr), n, C.c_void_p(d_bits_ptr), C.c_float(filter_val),
+                                          C.c_float(filter_goal), C.byref(st), C.c_void_p(hip_stream)),
+             "tgpu_float_to_bits_afc")
+        return st.value
+
     def close(self):
         if self._h:
             lib().tgpu_engine_destroy(self._h)
@@ -186,6 +201,10 @@ class Plan:
     def execute(self, d_stream_ptr, d_rec_ptr, hip_stream=0):
         _chk(lib().tgpu_plan_execute(self._h, C.c_void_p(d_stream_ptr), C.c_void_p(d_rec_ptr),
                                      C.c_void_p(hip_stream)), "tgpu_plan_execute")
+
+    def execute_soft(self, d_soft_ptr, d_rec_ptr, hip_stream=0):
+        _chk(lib().tgpu_plan_execute_soft(self._h, C.c_void_p(d_soft_ptr), C.c_void_p(d_rec_ptr),
+                                          C.c_void_p(hip_stream)), "tgpu_plan_execute_soft")
 
     def execute_prof(self, d_stream_ptr, d_rec_ptr, hip_stream, prof, step):
         _chk(lib().tgpu_plan_execute_prof(self._h, C.c_void_p(d_stream_ptr), C.c_void_p(d_rec_ptr),

@@ -45,6 +45,7 @@ struct tgpu_plan {
 	uint32_t *d_sb_ok, *d_sb_code;
 	unsigned long long *d_block_tmp;
 	uint8_t *d_wire;	/* caller-owned, optional */
+	uint32_t *d_softarea;	/* max_slots * 512 B, allocated on the first soft execute */
 	/* host staging */
 	int32_t *h_sbord;
 	uint32_t *h_list_sb, *h_list_216, *h_list_432;
@@ -140,7 +141,7 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 		return;
 	void *d[] = { p->d_slot_off, p->d_slot_type, p->d_slot_chan, p->d_slot_sbord, p->d_list_sb, p->d_list_216,
 		      p->d_list_432, p->d_packed, p->d_maskidx, p->d_masks, p->d_chan_code, p->d_sb_ok, p->d_sb_code,
-		      p->d_block_tmp };
+		      p->d_block_tmp, p->d_softarea };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
 			(void)hipFree(d[i]);
@@ -287,7 +288,7 @@ const char *tgpu_stage_name(int stage)
 	return (stage >= 0 && stage < TGPU_NSTAGES) ? names[stage] : "?";
 }
 
-static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream, hipEvent_t *ev)
+static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream, hipEvent_t *ev, int soft)
 {
 	int rc;
 #define MARK(i) do { if (ev) { hipError_t e_ = hipEventRecord(ev[i], (hipStream_t)stream); if (e_ != hipSuccess) return (int)e_; } } while (0)
@@ -297,13 +298,22 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 		return TGPU_ESTATE;
 	MARK(0);
 	if (p->nslots) {
-		if ((rc = tgk_front(d_stream, p->d_slot_off, p->nslots, p->d_packed, d_rec, stream)))
+		if (soft) {
+			if (!p->d_softarea) {
+				hipError_t e_ = hipMalloc((void **)&p->d_softarea, (size_t)p->max_slots * TG_SOFT_SLOT_BYTES);
+				if (e_ != hipSuccess)
+					return (int)e_;
+			}
+			if ((rc = tgk_front_soft((const int8_t *)d_stream, p->d_slot_off, p->nslots, p->d_softarea, p->d_packed,
+						 d_rec, stream)))
+				return rc;
+		} else if ((rc = tgk_front(d_stream, p->d_slot_off, p->nslots, p->d_packed, d_rec, stream)))
 			return rc;
 	}
 	MARK(1);
 	if (p->nslots && !p->static_masks) {
 		if ((rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, p->nsb, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, stream)))
 			return rc;
 	}
 	MARK(2);
@@ -320,13 +330,13 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	MARK(4);
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_216, p->d_list_216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, stream)))
 			return rc;
 	}
 	MARK(5);
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_432, p->d_list_432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, stream)))
 			return rc;
 	}
 	MARK(6);
@@ -336,7 +346,37 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 
 int tgpu_plan_execute(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream)
 {
-	return plan_run(p, d_stream, d_rec, stream, NULL);
+	return plan_run(p, d_stream, d_rec, stream, NULL, 0);
+}
+
+int tgpu_plan_execute_soft(struct tgpu_plan *p, const int8_t *d_soft_stream, uint8_t *d_rec, void *stream)
+{
+	return plan_run(p, (const uint8_t *)d_soft_stream, d_rec, stream, NULL, 1);
+}
+
+int tgpu_float_to_bits(struct tgpu_engine *eng, const float *d_in, uint64_t n, uint8_t *d_bits, int8_t *d_soft, void *stream)
+{
+	if (!eng || !d_in || !d_bits)
+		return TGPU_EINVAL;
+	return tgk_float_to_bits(d_in, n, d_bits, d_soft, stream);
+}
+
+int tgpu_float_to_bits_afc(struct tgpu_engine *eng, const float *d_in, uint64_t n, uint8_t *d_bits, float filter_val,
+			   float filter_goal, float *filter_state, void *stream)
+{
+	if (!eng || !d_in || !d_bits || !filter_state)
+		return TGPU_EINVAL;
+	float *d_state = NULL;
+	HCHK(hipMalloc((void **)&d_state, sizeof(float)));
+	int rc = (int)hipMemcpyAsync(d_state, filter_state, sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
+	if (!rc)
+		rc = tgk_float_to_bits_afc(d_in, n, d_bits, filter_val, filter_goal, d_state, stream);
+	if (!rc)
+		rc = (int)hipMemcpyAsync(filter_state, d_state, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream);
+	if (!rc)
+		rc = (int)hipStreamSynchronize((hipStream_t)stream);
+	(void)hipFree(d_state);
+	return rc;
 }
 
 int tgpu_plan_execute_prof(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream,
@@ -344,7 +384,7 @@ int tgpu_plan_execute_prof(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t
 {
 	if (!prof || step >= prof->max_steps)
 		return TGPU_EINVAL;
-	return plan_run(p, d_stream, d_rec, stream, prof->ev + (size_t)step * (TGPU_NSTAGES + 1));
+	return plan_run(p, d_stream, d_rec, stream, prof->ev + (size_t)step * (TGPU_NSTAGES + 1), 0);
 }
 
 int tgpu_prof_read(struct tgpu_prof *prof, uint32_t nsteps, float *ms)

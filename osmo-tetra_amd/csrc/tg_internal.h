@@ -17,7 +17,13 @@ int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uin
 		     uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, void *stream);
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
-	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */, void *stream);
+	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */,
+	    const uint32_t *d_softarea /* NULL: hard input */, void *stream);
+int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc, uint32_t nslots,
+		   uint32_t *d_area, uint32_t *d_packed, uint8_t *d_rec, void *stream);
+int tgk_float_to_bits(const float *d_in, unsigned long long n, uint8_t *d_bits, int8_t *d_soft, void *stream);
+int tgk_float_to_bits_afc(const float *d_in, unsigned long long n, uint8_t *d_bits, float filter_val,
+			  float filter_goal, float *d_state, void *stream);
 int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uint32_t *d_sb_ok,
 	     uint32_t nchan, uint32_t nslots, unsigned long long *d_block_tmp, uint32_t *d_maskidx, void *stream);
 int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,

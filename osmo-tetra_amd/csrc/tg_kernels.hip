@@ -330,6 +330,148 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 }
 
 /* ------------------------------------------------------------------------- */
+/* soft input (BASELINE config 5): float phases -> bits / soft values, soft gather  */
+/* ------------------------------------------------------------------------- */
+/*
+ * k_float_to_bits: the slicer of float_to_bits.c:33-72 (no AFC), 4 symbols per lane:
+ *   phi > 2 -> +3 (0,1)   phi > 0 -> +1 (0,0)   phi < -2 -> -3 (1,1)   else -1 (1,0)   (NaN -> (1,0))
+ * and, optionally, our soft values: soft0 = sat(rint(64 phi)), soft1 = sat(rint(64 (2 - |phi|))).
+ */
+__device__ __forceinline__ uint32_t slice_sym(float f)
+{
+	const uint32_t b0 = !(f > 0.0f);				/* first bit: 1 for the two negative symbols (and NaN) */
+	const uint32_t b1 = (f > 2.0f) || (f < -2.0f);			/* second bit: 1 for the outer symbols */
+	return b0 | (b1 << 8);
+}
+
+__device__ __forceinline__ int32_t sat127(float x)
+{
+	if (x != x)
+		return 0;
+	x = fminf(fmaxf(x, -127.0f), 127.0f);
+	return (int32_t)__builtin_rintf(x);
+}
+
+__device__ __forceinline__ uint32_t soft_sym(float f)
+{
+	const int32_t s0 = sat127(64.0f * f), s1 = sat127(64.0f * (2.0f - fabsf(f)));
+	return ((uint32_t)s0 & 0xff) | (((uint32_t)s1 & 0xff) << 8);
+}
+
+__global__ __launch_bounds__(256)
+void k_float_to_bits(const float *__restrict__ in, unsigned long long n, uint8_t *__restrict__ bits, int8_t *__restrict__ soft)
+{
+	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x * 4;
+	for (unsigned long long i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+		if (i + 4 <= n) {
+			const float4 f = *(const float4 *)(in + i);
+			uint2 o;
+			o.x = slice_sym(f.x) | (slice_sym(f.y) << 16);
+			o.y = slice_sym(f.z) | (slice_sym(f.w) << 16);
+			*(uint2 *)(bits + 2 * i) = o;
+			if (soft) {
+				uint2 q;
+				q.x = soft_sym(f.x) | (soft_sym(f.y) << 16);
+				q.y = soft_sym(f.z) | (soft_sym(f.w) << 16);
+				*(uint2 *)(soft + 2 * i) = q;
+			}
+		} else {
+			for (unsigned long long k = i; k < n; k++) {
+				const uint32_t b = slice_sym(in[k]);
+				bits[2 * k] = (uint8_t)b;
+				bits[2 * k + 1] = (uint8_t)(b >> 8);
+				if (soft) {
+					const uint32_t q = soft_sym(in[k]);
+					soft[2 * k] = (int8_t)q;
+					soft[2 * k + 1] = (int8_t)(q >> 8);
+				}
+			}
+		}
+	}
+}
+
+/*
+ * k_float_to_bits_afc: the pseudo-AFC of float_to_bits.c:142-146 is a sequential IIR with a float state
+ * and a double intermediate, so bit-exactness needs the same operation order: one lane per channel
+ * walks its symbols.  Contraction is switched off explicitly (no fma may be formed).
+ */
+__global__ void k_float_to_bits_afc(const float *__restrict__ in, unsigned long long n, uint8_t *__restrict__ bits,
+				    float filter_val, float filter_goal, float *__restrict__ state)
+{
+#pragma clang fp contract(off)
+	if (blockIdx.x || threadIdx.x)
+		return;
+	float filter = *state;
+	const double keep = 1.0 - (double)filter_val;
+	for (unsigned long long i = 0; i < n; i++) {
+		const float fl = in[i];
+		if ((fl > -5.0f) && (fl < 5.0f)) {
+			const double a = __dmul_rn((double)filter, keep);
+			const float b = __fmul_rn(__fsub_rn(fl, filter_goal), filter_val);
+			filter = (float)__dadd_rn(a, (double)b);
+		}
+		const uint32_t s = slice_sym(__fsub_rn(fl, filter));
+		bits[2 * i] = (uint8_t)s;
+		bits[2 * i + 1] = (uint8_t)(s >> 8);
+	}
+	*state = filter;
+}
+
+/*
+ * k_front_soft: the demux/de-interleave gather of k_front for int8 soft values.  Output per slot:
+ * a 512-byte area, every block as [6 lead-in values, 2 pad][12 values] x NBLK in type-3 order
+ * (first block at 0, second at TG_SOFT_AREA2, BBK at TG_SOFT_BBK), plus the meta word of the packed slot.
+ */
+struct tg_soft_tables {
+	uint16_t src[3][TG_SOFT_SLOT_BYTES];	/* [NORM_1, NORM_2, SYNC][area byte] -> slot byte offset, 0xffff = zero */
+};
+__device__ tg_soft_tables g_soft_tab;
+
+__global__ __launch_bounds__(256)
+void k_front_soft(const int8_t *__restrict__ soft, const uint64_t *__restrict__ slot_desc, uint32_t nslots,
+		  uint32_t *__restrict__ area, uint32_t *__restrict__ packed, uint8_t *__restrict__ rec)
+{
+	__shared__ uint32_t s_slot[4][128];
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t wave = blockIdx.x * 4 + wib;
+	const uint32_t nwaves = gridDim.x * 4;
+	uint32_t *mine = s_slot[wib];
+	const uint8_t *mine8 = (const uint8_t *)mine;
+
+	for (uint32_t slot = wave; slot < nslots; slot += nwaves) {
+		const uint64_t d = slot_desc[slot];
+		const uint32_t type = TG_DESC_TYPE(d);
+		uint32_t d0, d1;
+		front_fetch((const uint8_t *)soft + TG_DESC_OFF(d), lane, d0, d1);
+		mine[lane] = d0;
+		mine[64 + lane] = d1;
+		if (type == TG_BURST_NORM_1 || type == TG_BURST_NORM_2 || type == TG_BURST_SYNC) {
+			const uint32_t tix = (type == TG_BURST_SYNC) ? 2 : type;
+			const uint16_t *tab = g_soft_tab.src[tix];
+#pragma unroll
+			for (int r = 0; r < 2; r++) {
+				const uint32_t q0 = 256 * r + 4 * lane;
+				uint32_t w = 0;
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const uint32_t o = tab[q0 + k];
+					const uint32_t byte = (o == 0xffff) ? 0u : (uint32_t)mine8[o];
+					w |= byte << (8 * k);
+				}
+				area[(size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + 64 * r + lane] = w;
+			}
+		} else if (lane == 0) {
+			rec[(size_t)slot * TG_REC_BYTES + TG_REC_TYPE] = TG_BURST_NONE;
+		}
+		if (lane == 0) {
+			const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
+			packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META] = type | (toff << 16);
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------- */
 /* k_vit<KIND>                                                               */
 /* ------------------------------------------------------------------------- */
 template <int KIND> struct vit_cfg;
@@ -370,13 +512,16 @@ __device__ __forceinline__ uint32_t hist_byte(uint32_t w0, uint32_t w1, uint32_t
  *          the VGPR index mode (s_set_gpr_idx_on) with a wave-uniform block index, read back
  *          with static indices by the fully unrolled traceback.  No LDS for the trellis at
  *          all, so occupancy is set by registers: 2 waves/SIMD for SCH/F, 4 for the 216 blocks.
+ * HMODE 2: soft input (BASELINE config 5): int8 soft values from k_front_soft's per-slot area instead of
+ *          packed bits, 32-bit correlation metrics (tg_svit_*), history in VGPRs as in mode 1.
  */
 template <int KIND, int HMODE>
-__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (KIND == TG_KIND_432 ? 2 : 4))
+__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (HMODE == 2) ? (KIND == TG_KIND_432 ? 1 : 2) : (KIND == TG_KIND_432 ? 2 : 4))
 void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
-	   uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code, uint8_t *__restrict__ wire)
+	   uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code, uint8_t *__restrict__ wire,
+	   const uint32_t *__restrict__ softarea)
 {
 	constexpr int NBLK = vit_cfg<KIND>::NBLK;
 	constexpr int NW = NBLK / 2;			/* code words */
@@ -420,17 +565,82 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		mw = masks + (size_t)midx * TG_MASK_WORDS + vit_cfg<KIND>::MW;
 	}
 
-	tg_vit_state v;
-	tg_vit_init(v);
-	uint32_t cur = pw[0] ^ mw[0];
-	tg_vit_leadin(v, cur >> 24);
-
 	uint32_t od[NOD + 1];
 #pragma unroll
 	for (int i = 0; i <= NOD; i++)
 		od[i] = 0;
 
-	if (HMODE == 0) {
+	tg_vit_state v;
+	uint32_t cur = 0;
+	if (HMODE != 2) {
+		tg_vit_init(v);
+		cur = pw[0] ^ mw[0];
+		tg_vit_leadin(v, cur >> 24);
+	}
+
+	if (HMODE == 2) {
+		/* soft input: 6 dwords (2 blocks of 12 int8) per iteration from this block's soft area */
+		const uint32_t *sw = softarea + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + (which ? TG_SOFT_AREA2 / 4 : 0);
+		tg_svit_state sv;
+		tg_svit_init(sv);
+		{
+			const uint32_t lw[2] = { sw[0], sw[1] };
+			tg_svit_leadin(sv, lw, (mw[0] >> 24) & 0x3f);
+		}
+		uint32_t cw[6];
+#pragma unroll
+		for (int q = 0; q < 6; q++)
+			cw[q] = sw[2 + q];
+		tg_v32 H[NCH];
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			const int nblk_c = (NBLK - 8 * c >= 8) ? 8 : (NBLK - 8 * c);
+			const int nit = nblk_c / 2;
+			const bool lastchunk = (c == NCH - 1);
+			const int nloop = lastchunk ? nit - 1 : nit;
+#pragma unroll 1
+			for (int it = 0; it < nloop; it++) {
+				const int g = 4 * c + it;
+				uint32_t nx[6];
+#pragma unroll
+				for (int q = 0; q < 6; q++)
+					nx[q] = sw[2 + 6 * (g + 1) + q];
+				const uint32_t m = mw[g];
+				uint32_t h[4];
+				tg_svit_block<false>(sv, cw, m & 0xfff, h);
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][8 * it + d] = h[d];
+				tg_svit_block<false>(sv, cw + 3, (m >> 12) & 0xfff, h);
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][8 * it + 4 + d] = h[d];
+#pragma unroll
+				for (int q = 0; q < 6; q++)
+					cw[q] = nx[q];
+			}
+			if (lastchunk) {
+				const uint32_t m = mw[NW - 1];
+				uint32_t h[4];
+				tg_svit_block<false>(sv, cw, m & 0xfff, h);
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][8 * (nit - 1) + d] = h[d];
+				tg_svit_block<true>(sv, cw + 3, (m >> 12) & 0xfff, h);
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][8 * (nit - 1) + 4 + d] = h[d];
+			}
+		}
+		uint32_t s = 0;
+#pragma unroll
+		for (int b = NBLK - 1; b >= 0; b--) {
+			const int c = b >> 3, o = 4 * (b & 7);
+			const uint32_t byte = hist_byte(H[c][o], H[c][o + 1], H[c][o + 2], H[c][o + 3], s);
+			od[b >> 2] |= byte << ((b & 3) * 8);
+			s = tg_brev4(byte);
+		}
+	} else if (HMODE == 0) {
 #pragma unroll 1
 		for (int it = 0; it < NW - 1; it++) {
 			const uint32_t nxt = pw[it + 1] ^ mw[it + 1];
@@ -577,8 +787,17 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		const uint32_t btype = meta & 0xff;
 		const bool primary = (KIND == TG_KIND_432) || (btype == TG_BURST_SYNC ? which == 1 : which == 0);
 		if (primary) {
-			const uint32_t bb = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_BBK] ^
-					    masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
+			uint32_t bbraw;
+			if (HMODE == 2) {
+				/* hard decision of the first 16 BBK soft values: bit = (value < 0) */
+				const uint32_t *sb = softarea + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + TG_SOFT_BBK / 4;
+				bbraw = 0;
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					bbraw |= ((((sb[q] >> 7) & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
+			} else
+				bbraw = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_BBK];
+			const uint32_t bb = bbraw ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
 			uint4 o;
 			o.x = spread4(bb);
 			o.y = spread4(bb >> 4);
@@ -798,9 +1017,42 @@ static int tgk_hist_mode = 1;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+static void build_soft_tables(tg_soft_tables *t)
+{
+	const int btypes[3] = { TG_BURST_NORM_1, TG_BURST_NORM_2, TG_BURST_SYNC };
+	memset(t, 0xff, sizeof(*t));
+	for (int x = 0; x < 3; x++) {
+		const int bt = btypes[x];
+		struct { int kind, base, wbase; } blk[2];
+		int nb = 0;
+		if (bt == TG_BURST_NORM_1) {
+			blk[nb++] = { TG_KIND_432, 0, TG_PW_BLK1 };
+		} else if (bt == TG_BURST_NORM_2) {
+			blk[nb++] = { TG_KIND_216, 0, TG_PW_BLK1 };
+			blk[nb++] = { TG_KIND_216, TG_SOFT_AREA2, TG_PW_BLK2 };
+		} else {
+			blk[nb++] = { TG_KIND_SB1, 0, TG_PW_BLK1 };
+			blk[nb++] = { TG_KIND_216, TG_SOFT_AREA2, TG_PW_BLK2 };
+		}
+		for (int b = 0; b < nb; b++) {
+			const int K = tg_kind_K(blk[b].kind), a = tg_kind_a(blk[b].kind);
+			for (int i = 0; i < K; i++) {
+				const int j = (a * (i + 1)) % K;	/* type3[i] = type4[j] */
+				const int q = blk[b].base + (i < 6 ? i : TG_SOFT_LEADIN_BYTES + (i - 6));
+				t->src[x][q] = (uint16_t)tg_block_stream_off(bt, blk[b].wbase, j);
+			}
+		}
+		for (int p = 0; p < 30; p++)
+			t->src[x][TG_SOFT_BBK + p] = (uint16_t)tg_bbk_stream_off(bt, p);
+	}
+}
+
 extern "C" int tgk_init(void)
 {
 	static tg_const_tables host;
+	static tg_soft_tables shost;
+	build_soft_tables(&shost);
+	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_soft_tab), &shost, sizeof(shost)));
 	build_tables(&host);
 	if (const char *e = getenv("TGPU_HIST_MODE"))
 		tgk_hist_mode = atoi(e) ? 1 : 0;
@@ -856,25 +1108,59 @@ extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64
 	return (int)hipGetLastError();
 }
 
+extern "C" int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc, uint32_t nslots,
+			      uint32_t *d_area, uint32_t *d_packed, uint8_t *d_rec, void *stream)
+{
+	if (!nslots)
+		return 0;
+	uint32_t blocks = (nslots + 3) / 4;
+	if (blocks > 256 * 8)
+		blocks = 256 * 8;
+	hipLaunchKernelGGL(k_front_soft, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_soft, d_slot_desc, nslots,
+			   d_area, d_packed, d_rec);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_float_to_bits(const float *d_in, unsigned long long n, uint8_t *d_bits, int8_t *d_soft, void *stream)
+{
+	if (!n)
+		return 0;
+	unsigned long long blocks = (n / 4 + 255) / 256;
+	if (blocks > 256 * 16)
+		blocks = 256 * 16;
+	if (!blocks)
+		blocks = 1;
+	hipLaunchKernelGGL(k_float_to_bits, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, d_in, n, d_bits, d_soft);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_float_to_bits_afc(const float *d_in, unsigned long long n, uint8_t *d_bits, float filter_val,
+				     float filter_goal, float *d_state, void *stream)
+{
+	hipLaunchKernelGGL(k_float_to_bits_afc, dim3(1), dim3(64), 0, (hipStream_t)stream, d_in, n, d_bits, filter_val,
+			   filter_goal, d_state);
+	return (int)hipGetLastError();
+}
+
 extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 		       const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
-		       uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire, void *stream)
+		       uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire, const uint32_t *d_soft, void *stream)
 {
 	if (!nitems)
 		return 0;
 	const dim3 grid((nitems + 63) / 64), block(64);
 	hipStream_t s = (hipStream_t)stream;
-#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire)
-	const int hm = tgk_hist_mode;
+#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire, d_soft)
+	const int hm = d_soft ? 2 : tgk_hist_mode;
 	switch (kind) {
 	case TG_KIND_SB1:
-		if (hm) VIT_LAUNCH(TG_KIND_SB1, 1); else VIT_LAUNCH(TG_KIND_SB1, 0);
+		if (hm == 2) VIT_LAUNCH(TG_KIND_SB1, 2); else if (hm) VIT_LAUNCH(TG_KIND_SB1, 1); else VIT_LAUNCH(TG_KIND_SB1, 0);
 		break;
 	case TG_KIND_216:
-		if (hm) VIT_LAUNCH(TG_KIND_216, 1); else VIT_LAUNCH(TG_KIND_216, 0);
+		if (hm == 2) VIT_LAUNCH(TG_KIND_216, 2); else if (hm) VIT_LAUNCH(TG_KIND_216, 1); else VIT_LAUNCH(TG_KIND_216, 0);
 		break;
 	case TG_KIND_432:
-		if (hm) VIT_LAUNCH(TG_KIND_432, 1); else VIT_LAUNCH(TG_KIND_432, 0);
+		if (hm == 2) VIT_LAUNCH(TG_KIND_432, 2); else if (hm) VIT_LAUNCH(TG_KIND_432, 1); else VIT_LAUNCH(TG_KIND_432, 0);
 		break;
 	default:
 		return -1;

@@ -72,6 +72,11 @@
 #define TG_STREAM_VIEW    640	/* bytes of a slot's search window the kernel looks at */
 #define TG_STREAM_SLACK   192	/* readable bytes the stream buffer must have after its last byte */
 
+/* soft area of a slot (config 5): int8 values in trellis order, see k_front_soft */
+#define TG_SOFT_SLOT_BYTES 512
+#define TG_SOFT_AREA2      224	/* second block (BLK2 / SB2) */
+#define TG_SOFT_BBK        448	/* 30 BBK values */
+
 #define TG_FLAG_NONBINARY 0x01	/* a stream byte other than 0/1 was seen in a coded field */
 
 /* scrambling-mask table entry: 32 dwords, same bit layout as the code words */

@@ -201,6 +201,131 @@ TG_HD void tg_vit_normalize(tg_vit_state &v)
 		v.Z[k] = v.Z[k] - m;
 }
 
+/* =========================================================================================
+ * Soft-input trellis (BASELINE config 5; the reference has no soft path, the definition is ours:
+ * int8 soft values, positive = bit 0, correlation metrics, same tie rule -- what libosmocore's
+ * accelerated decoder computes when it is handed soft values).
+ *
+ * One state per 32-bit word: metric * 256 + survivor byte.  Butterfly j with correlation
+ * M = sum over received values of value * (+1 if out(j,0) bit is 0, -1 if 1):
+ *     new[2j]   = max(pm[j] + M, pm[j+8] - M)        new[2j+1] = max(pm[j] - M, pm[j+8] + M)
+ * The candidate from predecessor j gets bit i of the low byte added: on equal metrics it is larger,
+ * so the tie goes to j (oldest bit 0) and the winner's bit i says "came from j".  The decoded bit is
+ * the predecessor's oldest bit, i.e. the complement; the byte is inverted when it is extracted, which
+ * makes the history format identical to the hard trellis (same traceback, same CRC, same outputs).
+ * |metric| <= 292 * 254 < 2^17, so metric * 256 fits 32 bits with room for a -2^28 "unreachable".
+ * ========================================================================================= */
+struct tg_svit_state {
+	int32_t Z[16];
+};
+
+#define TG_SVIT_NEG (-(1 << 28))
+
+TG_HD void tg_svit_init(tg_svit_state &v)
+{
+	v.Z[0] = 0;
+#pragma unroll
+	for (int s = 1; s < 16; s++)
+		v.Z[s] = TG_SVIT_NEG;
+}
+
+TG_HD int32_t tg_smax(int32_t a, int32_t b) { return a > b ? a : b; }
+
+/* CLS[j]: 0 -> M = +X, 1 -> M = -X, 2 -> M = +Y, 3 -> M = -Y   (X, Y already scaled by 256) */
+template <unsigned C0, unsigned C1, unsigned C2, unsigned C3, unsigned C4, unsigned C5, unsigned C6, unsigned C7>
+TG_HD void tg_sacs(tg_svit_state &v, int32_t X, int32_t Y, int32_t tie)
+{
+	const unsigned cls[8] = { C0, C1, C2, C3, C4, C5, C6, C7 };
+	const int32_t pos[2] = { X, Y }, neg[2] = { -X, -Y };
+	const int32_t post[2] = { X + tie, Y + tie }, negt[2] = { -X + tie, -Y + tie };
+	int32_t N[16];
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		const int k = cls[j] >> 1;
+		const bool inv = cls[j] & 1;
+		const int32_t a = v.Z[j], b = v.Z[j + 8];
+		/* M = pos[k] (inv: neg[k]) */
+		N[2 * j] = tg_smax(a + (inv ? negt[k] : post[k]), b + (inv ? pos[k] : neg[k]));
+		N[2 * j + 1] = tg_smax(a + (inv ? post[k] : negt[k]), b + (inv ? neg[k] : pos[k]));
+	}
+#pragma unroll
+	for (int s = 0; s < 16; s++)
+		v.Z[s] = N[s];
+}
+
+/* two received values a (g1), b (g2): (g1,g2) per butterfly as in the hard trellis:
+ * j: 0:(0,0) 1:(1,0) 2:(0,1) 3:(1,1) 4:(0,1) 5:(1,1) 6:(0,0) 7:(1,0);  X = a+b, Y = b-a */
+TG_HD void tg_sstep_a(tg_svit_state &v, int32_t a, int32_t b, int32_t tie)
+{
+	tg_sacs<0, 2, 3, 1, 3, 1, 0, 2>(v, (a + b) * 256, (b - a) * 256, tie);
+}
+
+/* one received value a (g1): g1 of butterfly j is j & 1 */
+TG_HD void tg_sstep_b(tg_svit_state &v, int32_t a, int32_t tie)
+{
+	tg_sacs<0, 1, 0, 1, 0, 1, 0, 1>(v, a * 256, 0, tie);
+}
+
+TG_HD void tg_sstep_flush(tg_svit_state &v, int32_t tie)
+{
+	tg_sacs<0, 0, 0, 0, 0, 0, 0, 0>(v, 0, 0, tie);
+}
+
+TG_HD void tg_svit_clean(tg_svit_state &v)
+{
+#pragma unroll
+	for (int s = 0; s < 16; s++)
+		v.Z[s] &= ~0xff;
+}
+
+/* signed byte k of a 3-dword group, sign flipped where the scrambling mask bit is set */
+TG_HD int32_t tg_soft_val(const uint32_t w[3], int k, uint32_t maskbits)
+{
+	const int32_t s = (int32_t)(int8_t)(w[k >> 2] >> ((k & 3) * 8));
+	return ((maskbits >> k) & 1) ? -s : s;
+}
+
+TG_HD void tg_svit_leadin(tg_svit_state &v, const uint32_t w[2], uint32_t mask6)
+{
+	const uint32_t ww[3] = { w[0], w[1], 0 };
+	tg_sstep_a(v, tg_soft_val(ww, 0, mask6), tg_soft_val(ww, 1, mask6), 1);
+	tg_sstep_b(v, tg_soft_val(ww, 2, mask6), 2);
+	tg_sstep_a(v, tg_soft_val(ww, 3, mask6), tg_soft_val(ww, 4, mask6), 4);
+	tg_sstep_b(v, tg_soft_val(ww, 5, mask6), 8);
+	tg_svit_clean(v);
+}
+
+template <bool LAST>
+TG_HD void tg_svit_block(tg_svit_state &v, const uint32_t w[3], uint32_t mask12, uint32_t h[4])
+{
+	tg_sstep_a(v, tg_soft_val(w, 0, mask12), tg_soft_val(w, 1, mask12), 1);
+	tg_sstep_b(v, tg_soft_val(w, 2, mask12), 2);
+	tg_sstep_a(v, tg_soft_val(w, 3, mask12), tg_soft_val(w, 4, mask12), 4);
+	tg_sstep_b(v, tg_soft_val(w, 5, mask12), 8);
+	if (LAST) {
+		tg_sstep_flush(v, 16);
+		tg_sstep_flush(v, 32);
+		tg_sstep_flush(v, 64);
+		tg_sstep_flush(v, 128);
+	} else {
+		tg_sstep_a(v, tg_soft_val(w, 6, mask12), tg_soft_val(w, 7, mask12), 16);
+		tg_sstep_b(v, tg_soft_val(w, 8, mask12), 32);
+		tg_sstep_a(v, tg_soft_val(w, 9, mask12), tg_soft_val(w, 10, mask12), 64);
+		tg_sstep_b(v, tg_soft_val(w, 11, mask12), 128);
+	}
+	/* history bytes, inverted: bit = 1 then means "predecessor j+8", as in the hard trellis */
+#pragma unroll
+	for (int d = 0; d < 4; d++)
+		h[d] = ~(((uint32_t)v.Z[4 * d] & 0xff) | (((uint32_t)v.Z[4 * d + 1] & 0xff) << 8) |
+			 (((uint32_t)v.Z[4 * d + 2] & 0xff) << 16) | (((uint32_t)v.Z[4 * d + 3] & 0xff) << 24));
+	tg_svit_clean(v);
+}
+
+/* byte offset, inside a block's soft area, of the 12 values of trellis block b (after the 8-byte lead-in
+ * group) -- the layout k_front_soft writes: [6 lead-in values, 2 pad][12 values] x NBLK, type-3 order */
+#define TG_SOFT_LEADIN_BYTES 8
+#define TG_SOFT_BLOCK_BYTES  12
+
 /* ---- CRC-16/CCITT over the decoded bit string (lower_mac/crc_simple.c:65-82) ---- */
 /* table[x] for x = 8 input bits given LSB-first (bit i of x is the (i+1)-th bit fed) */
 static inline uint16_t tg_crc16_step_bits(uint16_t crc, uint32_t bits_lsb_first, int n)

@@ -42,3 +42,16 @@ def pack_slot(btype, slot):
     w = np.zeros(20, np.uint32)
     lib().emul_pack_slot(btype, s.ctypes.data_as(u8p), w.ctypes.data_as(u32p))
     return w
+
+
+def decode_block_soft(kind, soft4, maskwords=None):
+    """kind 0/1/2; soft4 = int8 values in type-4 (stream) order.  returns (type2 bits, crc)"""
+    nblk = {0: 10, 1: 18, 2: 36}[kind]
+    s4 = np.ascontiguousarray(soft4, np.int8)
+    area = np.zeros(8 + 12 * nblk + 8, np.int8)
+    out = np.zeros(288, np.uint8)
+    i8p = C.POINTER(C.c_int8)
+    lib().emul_soft_layout(kind, s4.ctypes.data_as(i8p), area.ctypes.data_as(i8p))
+    mw = None if maskwords is None else np.ascontiguousarray(maskwords, np.uint32).ctypes.data_as(u32p)
+    crc = lib().emul_decode_soft(kind, area.ctypes.data_as(i8p), mw, out.ctypes.data_as(u8p))
+    return out, crc

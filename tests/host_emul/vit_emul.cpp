@@ -102,3 +102,55 @@ extern "C" void emul_pack_slot(int btype, const uint8_t *slot, uint32_t *words20
 		words20[w] = x;
 	}
 }
+
+/* ---- soft trellis: type-4 soft values (descrambled = mask 0) -> decoded bits ---- */
+extern "C" void emul_soft_layout(int kind, const int8_t *soft4, int8_t *area /* 8 + 12*nblk */)
+{
+	const int K = tg_kind_K(kind), a = tg_kind_a(kind), nblk = tg_kind_nblk(kind);
+	memset(area, 0, 8 + 12 * nblk);
+	for (int i = 0; i < K; i++) {
+		const int8_t v = soft4[(a * (i + 1)) % K];	/* type3[i] */
+		if (i < 6)
+			area[i] = v;
+		else
+			area[8 + (i - 6)] = v;
+	}
+}
+
+extern "C" unsigned emul_decode_soft(int kind, const int8_t *area, const uint32_t *maskwords, uint8_t *out_bits)
+{
+	crc_init();
+	const int nblk = tg_kind_nblk(kind);
+	static uint8_t hist[36][16];
+	const uint32_t *aw = (const uint32_t *)area;
+	tg_svit_state v;
+	tg_svit_init(v);
+	tg_svit_leadin(v, aw, maskwords ? (maskwords[0] >> 24) & 0x3f : 0);
+	for (int b = 0; b < nblk; b++) {
+		uint32_t h[4];
+		const uint32_t m12 = maskwords ? (maskwords[b >> 1] >> (12 * (b & 1))) & 0xfff : 0;
+		if (b == nblk - 1)
+			tg_svit_block<true>(v, aw + 2 + 3 * b, m12, h);
+		else
+			tg_svit_block<false>(v, aw + 2 + 3 * b, m12, h);
+		memcpy(hist[b], h, 16);
+	}
+	uint8_t bytes[37] = { 0 };
+	uint32_t s = 0;
+	for (int b = nblk - 1; b >= 0; b--) {
+		uint8_t byte = hist[b][s];
+		bytes[b] = byte;
+		s = tg_brev4(byte);
+	}
+	for (int i = 0; i < 8 * nblk; i++)
+		out_bits[i] = (bytes[i >> 3] >> (i & 7)) & 1;
+	uint32_t crc = 0xffff;
+	for (int i = 0; i < nblk - 1; i++)
+		crc = ((crc << 8) & 0xffff) ^ crc_msb[crc >> 8] ^ crc_lsb[bytes[i]];
+	uint32_t nib = bytes[nblk - 1] & 15;
+	for (int i = 0; i < 4; i++) {
+		crc ^= ((nib >> i) & 1) << 15;
+		crc = (crc & 0x8000) ? (((crc << 1) ^ 0x1021) & 0xffff) : ((crc << 1) & 0xffff);
+	}
+	return crc;
+}

@@ -157,6 +157,8 @@ def lib():
     L.orc_tp_sap_udata_ind.argtypes = [C.POINTER(Rx), C.c_int, C.c_int, u8p, C.c_uint]
     L.orc_float_to_bits.argtypes = [C.POINTER(C.c_float), C.c_size_t, u8p, C.c_int, C.c_float, C.c_float,
                                     C.POINTER(C.c_float)]
+    L.orc_float_to_soft.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_int8)]
+    L.orc_decode_block_soft.argtypes = [C.c_int, C.POINTER(C.c_int8), C.c_uint32, C.POINTER(BlockResult)]
     L.orc_bench_decode_slots.restype = C.c_uint64
     L.orc_bench_decode_slots.argtypes = [u8p, u8p, C.c_size_t, C.c_uint32, C.c_int, u8p, C.POINTER(C.c_uint16)]
     _lib = L
@@ -268,6 +270,37 @@ def decode_block(t, type5, scramb_init, use_acc=0):
     n1 = BLK[t][2]
     return (np.frombuffer(res.type1, np.uint8, n1).copy(), res.crc, bool(res.crc_ok),
             np.frombuffer(res.type2, np.uint8, BLK[t][1]).copy())
+
+
+def float_to_soft(phi):
+    phi = np.ascontiguousarray(phi, np.float32)
+    out = np.zeros(2 * len(phi), np.int8)
+    lib().orc_float_to_soft(phi.ctypes.data_as(C.POINTER(C.c_float)), len(phi), out.ctypes.data_as(C.POINTER(C.c_int8)))
+    return out
+
+
+def float_to_bits(phi, afc=False, fval=0.0001, goal=0.0):
+    phi = np.ascontiguousarray(phi, np.float32)
+    out = np.zeros(2 * len(phi), np.uint8)
+    st = C.c_float(0)
+    lib().orc_float_to_bits(phi.ctypes.data_as(C.POINTER(C.c_float)), len(phi), _p(out), int(afc), C.c_float(fval),
+                            C.c_float(goal), C.byref(st))
+    return out
+
+
+def decode_block_soft(t, soft5, scramb_init):
+    soft5 = np.ascontiguousarray(soft5, np.int8)
+    res = BlockResult()
+    lib().orc_decode_block_soft(t, soft5.ctypes.data_as(C.POINTER(C.c_int8)), scramb_init, C.byref(res))
+    n1 = BLK[t][2]
+    return (np.frombuffer(res.type1, np.uint8, n1).copy(), res.crc, bool(res.crc_ok),
+            np.frombuffer(res.type2, np.uint8, BLK[t][1]).copy())
+
+
+def bits_to_phase(bits):
+    """inverse of sym_int2bits (float_to_bits.c:50-72): 00 -> +1, 01 -> +3, 10 -> -1, 11 -> -3"""
+    b = np.asarray(bits, np.int64).reshape(-1, 2)
+    return np.where(b[:, 0] == 0, 1.0, -1.0) * np.where(b[:, 1] == 0, 1.0, 3.0)
 
 
 def build_sync_burst(sb, bb, bkn):

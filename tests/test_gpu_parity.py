@@ -462,3 +462,98 @@ def test_config3_stream_end_to_end(T, eng, seed):
     assert_same_records(ch.records, want)
     plan.close()
     ch.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 5: float phase stream -> bits / soft values -> soft-decision decode
+# ---------------------------------------------------------------------------
+def test_float_to_bits_kernel(T, eng):
+    """device slicer == float_to_bits.c (golden vectors from the real binary) incl. 0, +-2, NaN, inf, and the
+    sequential pseudo-AFC variant; soft values == the oracle's definition"""
+    import json
+    import os
+    import torch
+    refv = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.json")))
+    sig = np.frombuffer(bytes.fromhex(refv["float_to_bits"]["input_f32_hex"]), np.float32).copy()
+    d_in = torch.from_numpy(sig).cuda()
+    n = len(sig)
+    for args, want in refv["float_to_bits"]["runs"]:
+        d_bits = torch.zeros(2 * n, dtype=torch.uint8, device="cuda")
+        if "-a" in args:
+            fv = float(args[args.index("-f") + 1]) if "-f" in args else 0.0001
+            fg = float(args[args.index("-F") + 1]) if "-F" in args else 0.0
+            eng.float_to_bits_afc(d_in.data_ptr(), n, d_bits.data_ptr(), fv, fg)
+        else:
+            eng.float_to_bits(d_in.data_ptr(), n, d_bits.data_ptr())
+            torch.cuda.synchronize()
+        assert O.bitstr(d_bits.cpu().numpy()) == want, args
+    # a longer random stream (vector path + tail) and the soft values
+    rng = np.random.default_rng(6)
+    phi = (rng.choice([-3, -1, 1, 3], 100003) + rng.normal(0, 0.7, 100003)).astype(np.float32)
+    phi[::1000] = 0.0
+    phi[1::1000] = 2.0
+    phi[2::1000] = -2.0
+    phi[3::1000] = np.nan
+    d_in = torch.from_numpy(phi).cuda()
+    d_bits = torch.zeros(2 * len(phi), dtype=torch.uint8, device="cuda")
+    d_soft = torch.zeros(2 * len(phi), dtype=torch.int8, device="cuda")
+    eng.float_to_bits(d_in.data_ptr(), len(phi), d_bits.data_ptr(), d_soft.data_ptr())
+    torch.cuda.synchronize()
+    assert (d_bits.cpu().numpy() == O.float_to_bits(phi)).all()
+    assert (d_soft.cpu().numpy() == O.float_to_soft(phi)).all()
+    st = eng.float_to_bits_afc(d_in.data_ptr(), 5000, d_bits.data_ptr(), 0.01, 0.1)
+    assert (d_bits.cpu().numpy()[:10000] == O.float_to_bits(phi[:5000], True, 0.01, 0.1)).all()
+
+
+@pytest.mark.parametrize("sigma", [0.0, 0.5, 0.9, 1.6])
+def test_config5_soft_decision_parity(T, eng, sigma):
+    """float phases -> soft values (device) -> soft-decision decode == the oracle's soft chain, bit-exact
+    (integer metrics); sigma = 0 additionally equals the hard path"""
+    import torch
+    rng = np.random.default_rng(int(sigma * 10) + 3)
+    code = O.scramb_get_init(262, 42, 1)
+    types = np.array([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_NORM_2, O.TRAIN_NORM_1] * 60, np.uint8)
+    n = len(types)
+    slots = T.synth_slots(types, seed=31, scramb_init=code)
+    bits = slots.reshape(-1)
+    phi = (O.bits_to_phase(bits) + rng.normal(0, sigma, len(bits) // 2)).astype(np.float32)
+    d_phi = torch.from_numpy(phi).cuda()
+    d_bits = torch.zeros(len(bits) + 64, dtype=torch.uint8, device="cuda")
+    d_soft = torch.zeros(len(bits) + 64, dtype=torch.int8, device="cuda")
+    eng.float_to_bits(d_phi.data_ptr(), len(phi), d_bits.data_ptr(), d_soft.data_ptr())
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(np.arange(n, dtype=np.uint64) * 510, types, None, np.array([code], np.uint32))
+    plan.execute_soft(d_soft.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+    p = T.parse_records(rec)
+    soft = d_soft.cpu().numpy()[:len(bits)].reshape(n, 510)
+    assert (soft.reshape(-1) == O.float_to_soft(phi)).all()
+    nok = 0
+    for i in range(n):
+        s = soft[i]
+        t = types[i]
+        if t == O.TRAIN_SYNC:
+            blocks = [(O.T_SB1, s[94:214], 3, p["bits1"][i][:60], 0), (O.T_SB2, s[282:498], code, p["bits2"][i], 1)]
+            bbk = s[252:282]
+        elif t == O.TRAIN_NORM_2:
+            blocks = [(O.T_NDB, s[14:230], code, p["bits1"][i][:124], 0), (O.T_NDB, s[282:498], code, p["bits2"][i], 1)]
+            bbk = np.concatenate([s[230:244], s[266:282]])
+        else:
+            blocks = [(O.T_SCH_F, np.concatenate([s[14:230], s[282:498]]), code, p["bits1"][i], 0)]
+            bbk = np.concatenate([s[230:244], s[266:282]])
+        for bt, sv, c, got, which in blocks:
+            w1, wcrc, wok, _ = O.decode_block_soft(bt, sv, c)
+            assert (got == w1).all(), (i, bt)
+            assert p["crc"][i, which] == wcrc and p["crc_ok"][i, which] == int(wok)
+            nok += wok
+        wb = O.decode_block_soft(O.T_BBK, bbk, code)[0]
+        assert (p["bbk"][i] == wb).all()
+    if sigma == 0.0:
+        d_rec2 = torch.zeros_like(d_rec)
+        plan.execute(d_bits.data_ptr(), d_rec2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert (d_rec2.cpu().numpy().reshape(n, -1)[:, 2:] == rec[:, 2:]).all()
+        assert nok == 60 * 2 + 120 + 60 * 2
+    plan.close()

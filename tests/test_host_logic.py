@@ -127,3 +127,31 @@ def test_slot_packing_matches_block_packing():
                                        ww.ctypes.data_as(emul.u32p))
             nw = {0: 5, 1: 9, 2: 18}[kind]
             assert (w[wbase:wbase + nw] == ww[:nw]).all()
+
+
+@pytest.mark.parametrize("sigma", [0.0, 0.6, 1.2, 4.0])
+def test_soft_kernel_core_on_host_bit_exact(sigma):
+    """the soft trellis (tg_svit_*, config 5) == the oracle's accelerated-decoder restatement on soft values,
+    incl. pure noise and erasures (ties everywhere)"""
+    rng = np.random.default_rng(int(sigma * 10) + 2)
+    for kind, t in ((0, O.T_SB1), (1, O.T_NDB), (2, O.T_SCH_F)):
+        K, n2, n1, a = O.BLK[t]
+        for i in range(40):
+            t5 = O.encode_block(t, rng.integers(0, 2, n1).astype(np.uint8), 0)
+            pad = np.concatenate([t5, np.zeros(K % 2, np.uint8)])
+            soft = O.float_to_soft(O.bits_to_phase(pad) + rng.normal(0, sigma, len(pad) // 2))[:K]
+            if i % 7 == 0:
+                soft = rng.integers(-127, 128, K).astype(np.int8)
+            if i % 11 == 0:
+                soft[rng.random(K) < 0.3] = 0
+            got, crc = emul.decode_block_soft(kind, soft)
+            w1, wcrc, ok, w2 = O.decode_block_soft(t, soft, 0)
+            assert (got[:n2] == w2).all() and crc == wcrc
+
+
+def test_soft_definition_consistent_with_hard_slicer():
+    """away from the decision boundaries the sign of the soft values is float_to_bits' hard decision"""
+    rng = np.random.default_rng(1)
+    phi = (rng.choice([-3, -1, 1, 3], 5000) + rng.normal(0, 0.8, 5000)).astype(np.float32)
+    phi = phi[(np.abs(phi) > 0.02) & (np.abs(np.abs(phi) - 2) > 0.02)]
+    assert ((O.float_to_soft(phi) < 0).astype(np.uint8) == O.float_to_bits(phi)).all()
