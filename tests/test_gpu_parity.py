@@ -557,3 +557,85 @@ def test_config5_soft_decision_parity(T, eng, sigma):
         assert (d_rec2.cpu().numpy().reshape(n, -1)[:, 2:] == rec[:, 2:]).all()
         assert nok == 60 * 2 + 120 + 60 * 2
     plan.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 1 (plumbing) and config 4 (64 channels in 8 shards)
+# ---------------------------------------------------------------------------
+def test_config1_plumbing_stream(T, eng):
+    """64 zero bytes + SB + SB + NDB(SCH/F) + SB + 700 zero bytes: the first SB only gives lock, the second
+    decodes to the reference's golden SYNC PDU"""
+    rng = np.random.default_rng(1)
+    cell = synth.Cell(262, 42, 0)
+    sb = lambda: synth.make_sb(rng, cell, 1, 1, 1)
+    stream = np.concatenate([np.zeros(64, np.uint8), sb(), sb(), synth.make_norm1(rng, cell.code), sb(),
+                             np.zeros(700, np.uint8)])
+    ch = T.Channel(eng, batch_slots=4)
+    ch.feed(stream)
+    ch.flush()
+    want, wev = O.run_rx(stream)
+    assert_same_records(ch.records, want)
+    sb1 = [r for r in ch.records if r["type"] == O.T_SB1]
+    assert len(sb1) == 2 and all(r["crc_ok"] for r in sb1)
+    assert O.bitstr(np.frombuffer(sb1[0]["type1"], np.uint8)) == \
+        "000000000000000010000010000000001000001100000000010101000000"
+    assert sb1[0]["time"] == (1, 1, 1) and ch.records[1]["scramb"] == O.scramb_get_init(262, 42, 0)
+    ch.close()
+
+
+def test_config4_64_channels_in_8_shards(T, eng):
+    """64 independent channel streams (own cell each), sharded 8 per rank; every shard is one multi-channel
+    plan; the wire records of all shards, concatenated in rank order (what the RCCL gather delivers to rank 0),
+    expand to exactly the blocks the oracle decodes channel by channel"""
+    import torch
+    from osmo_tetra_amd import dist as tdist
+    nchan, world = 64, 8
+    streams = []
+    for c in range(nchan):
+        cell = synth.Cell(200 + c, 1000 + 3 * c, c % 64)
+        s, _ = synth.frame_stream(seed=500 + c, nframes=2, cell=cell, ber=0.01, lead_in=100 + c)
+        streams.append(s)
+    gathered = []
+    meta = []
+    for rank in range(world):
+        lo, hi = tdist.shard_channels(nchan, rank, world)
+        parts, offs, types, chans = [], [], [], []
+        base = 0
+        for k, c in enumerate(range(lo, hi)):
+            s = streams[c]
+            d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+            res = T.sync_stream(eng, s, d.data_ptr())
+            sa = res["slot_arr"]
+            offs.append(sa["off"] + base)
+            types.append(sa["type"])
+            chans.append(np.full(len(sa), k, np.uint32))
+            meta.append((c, sa))
+            parts.append(s)
+            base += len(s)
+        big = np.concatenate(parts + [np.zeros(T.STREAM_SLACK, np.uint8)])
+        offs, types, chans = np.concatenate(offs), np.concatenate(types), np.concatenate(chans)
+        n = len(types)
+        d_stream = torch.from_numpy(big).cuda()
+        d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        d_wire = torch.zeros(n * T.WIRE_BYTES, dtype=torch.uint8, device="cuda")
+        plan = T.Plan(eng, n, hi - lo)
+        plan.load(offs, types, chans, np.zeros(hi - lo, np.uint32))
+        plan.set_wire(d_wire.data_ptr())
+        plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        gathered.append(d_wire.cpu().numpy().reshape(n, T.WIRE_BYTES))
+        plan.close()
+    wire = np.concatenate(gathered)
+    pos = 0
+    for c, sa in meta:
+        w = wire[pos:pos + len(sa)]
+        pos += len(sa)
+        want, _ = O.run_rx(streams[c])
+        rec = T.wire_unpack(w)
+        got = []
+        for i in range(len(sa)):
+            for b in T.record_blocks(rec[i]):
+                got.append((int(sa["burst_seq"][i]), b["type"], b["blk_num"], b["crc_ok"], b["crc"], b["type1"]))
+        exp = [(r["burst_seq"], r["type"], r["blk_num"], r["crc_ok"], r["crc"], r["type1"]) for r in want]
+        assert got == exp, c
+    assert pos == len(wire)
