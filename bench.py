@@ -226,10 +226,16 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k, k)
+        step(k)
     drain()
     sync_all()
     el = time.perf_counter() - t0
+
+    # per-stage durations: the same K steps once more with one HIP event between stages on the launch
+    # stream (this serialises k_vit<216> / k_vit<432>, which the timed pass above lets run side by side)
+    for k in range(args.steps):
+        plan.execute_prof(d_stream.data_ptr(), d_rec.data_ptr(), stream, prof, k)
+    torch.cuda.synchronize()
 
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -255,6 +261,11 @@ def main():
     value = world * n * args.steps / el
     pipeline_gbs = value / world * ((n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1]) / n) / 1e9
 
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(names[dom])
+    except Exception:
+        pass
     out = {
         "metric": "decoded bursts/s", "value": value, "unit": "bursts/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
@@ -264,12 +275,14 @@ def main():
                                "scramb_init=0, BER %g, aligned 510-B slots resident in HBM, records left in HBM" % (n, args.ber),
                    "bursts_per_gpu": n, "parallelism": "independent channels per GPU; N>1: one RCCL gather of 48-B wire records per step to rank 0, overlapped with the next decode"},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": float(achieved) / HBM_PEAK_GBS, "traffic": None,
+                     "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": float(stage_ms[dom]),
                      "stage_ms": {names[i]: float(stage_ms[i]) for i in range(len(names))},
                      "pipeline_achieved_gbs_per_gpu": float(pipeline_gbs),
-                     "note": "achieved = SURVEY 8(d) algorithmic bytes of the bursts this kernel decodes / its mean "
-                             "HIP-event duration on the launch stream; VALU-bound packed-u16 trellis, see DESIGN.md"},
+                     "note": "achieved = SURVEY 8(d) algorithmic bytes of the bursts this kernel decodes / its mean HIP-event "
+                             "duration (second pass of the same K steps, one event between stages on the launch stream; the "
+                             "timed pass overlaps the two trellis kernels); traffic = PMC bytes per launch from "
+                             "profiles/traffic.json; the trellis kernels are VALU-issue bound (v_pk_* half rate), see DESIGN.md"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(slots, types)

@@ -46,6 +46,8 @@ struct tgpu_plan {
 	unsigned long long *d_block_tmp;
 	uint8_t *d_wire;	/* caller-owned, optional */
 	uint32_t *d_softarea;	/* max_slots * 512 B, allocated on the first soft execute */
+	hipStream_t side;	/* k_vit<216> and k_vit<432> are independent: they run side by side */
+	hipEvent_t ev_fork, ev_join;
 	/* host staging */
 	int32_t *h_sbord;
 	uint32_t *h_list_sb, *h_list_216, *h_list_432;
@@ -131,6 +133,12 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 		tgpu_plan_destroy(p);
 		return TGPU_ENOMEM;
 	}
+	if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
+		tgpu_plan_destroy(p);
+		return TGPU_ENOMEM;
+	}
 	*out = p;
 	return TGPU_OK;
 }
@@ -139,6 +147,9 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 {
 	if (!p)
 		return;
+	if (p->side) (void)hipStreamDestroy(p->side);
+	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	void *d[] = { p->d_slot_off, p->d_slot_type, p->d_slot_chan, p->d_slot_sbord, p->d_list_sb, p->d_list_216,
 		      p->d_list_432, p->d_packed, p->d_maskidx, p->d_masks, p->d_chan_code, p->d_sb_ok, p->d_sb_code,
 		      p->d_block_tmp, p->d_softarea };
@@ -328,6 +339,17 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 			return rc;
 	}
 	MARK(4);
+	/* the two trellis kernels do not depend on each other: unless per-stage timing was asked for,
+	 * k_vit<432> goes to a side stream (fork/join with events, still capturable) so that the tails
+	 * of the two launches overlap */
+	const int fork = (ev == NULL) && p->n216 && p->n432;
+	if (fork) {
+		hipError_t e_ = hipEventRecord(p->ev_fork, (hipStream_t)stream);
+		if (e_ == hipSuccess)
+			e_ = hipStreamWaitEvent(p->side, p->ev_fork, 0);
+		if (e_ != hipSuccess)
+			return (int)e_;
+	}
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_216, p->d_list_216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
 				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, stream)))
@@ -336,8 +358,16 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	MARK(5);
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_432, p->d_list_432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL,
+				  fork ? (void *)p->side : stream)))
 			return rc;
+	}
+	if (fork) {
+		hipError_t e_ = hipEventRecord(p->ev_join, p->side);
+		if (e_ == hipSuccess)
+			e_ = hipStreamWaitEvent((hipStream_t)stream, p->ev_join, 0);
+		if (e_ != hipSuccess)
+			return (int)e_;
 	}
 	MARK(6);
 #undef MARK

@@ -914,34 +914,43 @@ void k_fill_apply(const uint32_t *slot_chan, const int32_t *slot_sbord, const ui
 /* ------------------------------------------------------------------------- */
 /* k_masks: one wavefront per mask-table entry                               */
 /* ------------------------------------------------------------------------- */
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void k_masks(const uint32_t *chan_code, uint32_t nchan, const uint32_t *sb_ok, const uint32_t *sb_code,
 	     uint32_t nsb, uint32_t *masks)
 {
-	const uint32_t e = blockIdx.x, lane = threadIdx.x;
-	uint32_t code = 0;
-	if (e >= 1 && e <= nchan)
-		code = chan_code[e - 1];
-	else if (e > nchan) {
-		const uint32_t k = e - 1 - nchan;
-		code = (k < nsb && sb_ok[k]) ? sb_code[k] : 0;
-	}
+	/* a wavefront keeps the linear-form masks of its 14 x 64 output bits in registers and walks
+	 * entries wave, wave + nwaves, ...: per entry 14 x (and, popcount, ballot) and one 128-byte store */
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
 	const uint32_t half = lane >> 5, bit = lane & 31;
-	uint32_t myword = 0;
+	const uint32_t nent = 1 + nchan + nsb;
+	uint32_t lin[14];
 #pragma unroll
 	for (int r = 0; r < 14; r++) {
 		const uint16_t pos = c_tab.mask_pos[2 * r + half][bit];
-		uint32_t b = 0;
-		if (pos != 0xffff)
-			b = __popc(code & c_tab.lfsr_lin[pos]) & 1;
-		const unsigned long long bal = __ballot(b);
-		myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
-		myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
+		lin[r] = (pos != 0xffff) ? c_tab.lfsr_lin[pos] : 0u;
 	}
-	if (lane == TG_MW_CODE)
-		myword = code;
-	if (lane < TG_MASK_WORDS)
-		masks[(size_t)e * TG_MASK_WORDS + lane] = myword;
+	for (uint32_t e = wave; e < nent; e += nwaves) {
+		uint32_t code = 0;
+		if (e >= 1 && e <= nchan)
+			code = chan_code[e - 1];
+		else if (e > nchan) {
+			const uint32_t k = e - 1 - nchan;
+			code = sb_ok[k] ? sb_code[k] : 0;
+		}
+		uint32_t myword = 0;
+#pragma unroll
+		for (int r = 0; r < 14; r++) {
+			const unsigned long long bal = __ballot(__popc(code & lin[r]) & 1);
+			myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
+			myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
+		}
+		if (lane == TG_MW_CODE)
+			myword = code;
+		if (lane < TG_MASK_WORDS)
+			masks[(size_t)e * TG_MASK_WORDS + lane] = myword;
+	}
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1186,6 +1195,9 @@ extern "C" int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint
 			 const uint32_t *d_sb_code, uint32_t nsb, uint32_t *d_masks, void *stream)
 {
 	const uint32_t nent = 1 + nchan + nsb;
-	hipLaunchKernelGGL(k_masks, dim3(nent), dim3(64), 0, (hipStream_t)stream, d_chan_code, nchan, d_sb_ok, d_sb_code, nsb, d_masks);
+	uint32_t blocks = (nent + 3) / 4;
+	if (blocks > 2048)
+		blocks = 2048;
+	hipLaunchKernelGGL(k_masks, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_chan_code, nchan, d_sb_ok, d_sb_code, nsb, d_masks);
 	return (int)hipGetLastError();
 }
