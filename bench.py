@@ -121,6 +121,53 @@ def bench_config3(args, T, torch, rank, world, local):
     print(json.dumps(out))
 
 
+def bench_config5(args, T, torch, rank, world, local):
+    """BASELINE config 5 (secondary measurement, N=1): float32 phase stream (sigma 0.6 noise) resident in HBM ->
+    device float_to_bits (hard bits + int8 soft values) -> soft-decision decode of n aligned slots."""
+    n = args.bursts
+    rng = np.random.default_rng(5)
+    pat = np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8)
+    types = np.tile(pat, n // 8 + 1)[:n]
+    code = 0x41802A07
+    slots = T.synth_slots(types, seed=21, scramb_init=code)
+    bits = slots.reshape(-1).astype(np.int64).reshape(-1, 2)
+    phi = np.where(bits[:, 0] == 0, 1.0, -1.0) * np.where(bits[:, 1] == 0, 1.0, 3.0)
+    phi = (phi + rng.normal(0, 0.6, len(phi))).astype(np.float32)
+    eng = T.Engine(local)
+    d_phi = torch.from_numpy(phi).cuda()
+    d_bits = torch.empty(2 * len(phi) + 64, dtype=torch.uint8, device="cuda")
+    d_soft = torch.empty(2 * len(phi) + 64, dtype=torch.int8, device="cuda")
+    d_rec = torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types, None, np.array([code], np.uint32))
+    hs = torch.cuda.current_stream().cuda_stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_f2b = t_dec = 0.0
+    for k in range(args.warmup + args.steps):
+        if k == args.warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t_f2b = t_dec = 0.0
+        ev[0].record()
+        eng.float_to_bits(d_phi.data_ptr(), len(phi), d_bits.data_ptr(), d_soft.data_ptr(), hs)
+        ev[1].record()
+        plan.execute_soft(d_soft.data_ptr(), d_rec.data_ptr(), hs)
+        ev[2].record()
+        torch.cuda.synchronize()
+        t_f2b += ev[0].elapsed_time(ev[1]); t_dec += ev[1].elapsed_time(ev[2])
+    el = time.perf_counter() - t0
+    p = T.parse_records(d_rec.view(-1, T.REC_BYTES)[:4096].cpu().numpy())
+    out = {"metric": "decoded bursts/s", "value": n * args.steps / el, "unit": "bursts/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+           "config": {"workload": "BASELINE config 5: %d bursts as float32 phases (sigma 0.6), device float_to_bits -> int8 soft values "
+                                  "-> soft-decision decode (correlation metrics)" % n,
+                      "crc_ok_blocks_first_4096_slots": int(p["crc_ok"].sum())},
+           "breakdown_ms": {"k_float_to_bits (255 floats in, 510 B bits + 510 B soft out per burst)": t_f2b / args.steps,
+                            "soft decode (k_front_soft + trellis kernels)": t_dec / args.steps}}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +176,7 @@ def main():
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts per GPU per step")
     ap.add_argument("--ber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="config2 (default, the metric's workload): aligned NDB slots; config3: mixed SB/NDB stream "
                          "through the GPU burst-sync front end, 1%% corrupted training sequences")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -160,6 +207,8 @@ def main():
 
     if args.workload == "config3":
         return bench_config3(args, T, torch, rank, world, local)
+    if args.workload == "config5":
+        return bench_config5(args, T, torch, rank, world, local)
 
     n = args.bursts
     rng = np.random.default_rng(1000 + rank)
