@@ -97,7 +97,7 @@ def bench_config3(args, T, torch, rank, world, local):
             t0 = time.perf_counter()
             t_sync = t_load = t_exec = 0.0
         a = time.perf_counter()
-        res = T.sync_stream(eng, stream, d_stream.data_ptr(), 64, hs)
+        res = T.sync_stream(eng, stream, d_stream.data_ptr(), 64, hs, burst_events=False)
         b = time.perf_counter()
         sl = res["slot_arr"]
         plan.load(sl["off"], sl["type"], None, np.zeros(1, np.uint32))

@@ -359,8 +359,9 @@ struct tgpu_sync_result {
 	uint64_t anchor;	/* start of the slot grid the GPU classified */
 };
 
+#define TGPU_SYNC_NO_BURST_EVENTS 1u	/* do not record one TGPU_EV_BURST per locked burst (throughput runs) */
 int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uint8_t *d_stream, uint64_t len,
-		     uint32_t chunk, struct tgpu_sync_result *out, void *hip_stream);
+		     uint32_t chunk, uint32_t flags, struct tgpu_sync_result *out, void *hip_stream);
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
 
 /* Deliver records decoded through the plan API (slot table from tgpu_sync_stream(), h_rec = host copy of
@@ -371,12 +372,14 @@ int tgpu_channel_deliver(struct tgpu_channel *ch, uint32_t n, const struct tgpu_
 int tgpu_channel_scramb_init(const struct tgpu_channel *ch, uint32_t *code);
 
 /* the two halves of tgpu_sync_stream(): the GPU classification of 'nslots' grid slots starting at
- * 'anchor' (one word per slot, layout in csrc/tg_layout.h) and the host walk (cls may be NULL: every
- * slot is then settled with tetra_find_train_seq() on the bytes -- no GPU needed) */
+ * 'anchor' (one word per slot + optionally one uint16 SYNC-sequence summary per slot, layouts in
+ * csrc/tg_layout.h) and the host walk (cls / ysum may be NULL: slots are then settled with
+ * tetra_find_train_seq() on the bytes, re-lock searches scan the bytes -- no GPU needed) */
 int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_t len, uint32_t chunk,
-		       uint64_t anchor, uint32_t nslots, uint32_t *h_cls, void *hip_stream);
+		       uint64_t anchor, uint32_t nslots, uint32_t *h_cls, uint16_t *h_ysum, void *hip_stream);
 int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor,
-		   const uint32_t *cls, uint32_t ncls, struct tgpu_sync_result *out);
+		   const uint32_t *cls, const uint16_t *ysum, uint32_t ncls, uint32_t flags,
+		   struct tgpu_sync_result *out);
 
 /* ------------------------------------------------------------------------- */
 /* 3. synthetic downlink generator (TX side of the same chain; host, multi-threaded) */

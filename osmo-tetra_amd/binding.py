@@ -17,6 +17,7 @@ T_SB1, T_SB2, T_NDB, T_BBK, T_SCH_HU, T_SCH_F = range(6)
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16)
 u64p = C.POINTER(C.c_uint64)
 
 
@@ -134,9 +135,9 @@ def lib():
     L.tetra_scramb_get_init.argtypes = [C.c_uint16, C.c_uint16, C.c_uint8]
     L.tgpu_channel_deliver.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(SyncSlot), u8p, u8p]
     L.tgpu_channel_scramb_init.argtypes = [C.c_void_p, u32p]
-    L.tgpu_sync_walk.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, C.c_uint32, C.POINTER(SyncResult)]
-    L.tgpu_sync_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, C.c_void_p]
-    L.tgpu_sync_stream.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
+    L.tgpu_sync_walk.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u16p, C.c_uint32, C.c_uint32, C.POINTER(SyncResult)]
+    L.tgpu_sync_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, u16p, C.c_void_p]
+    L.tgpu_sync_stream.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
     L.tgpu_sync_result_free.argtypes = [C.POINTER(SyncResult)]
     L.tgpu_synth_slots.argtypes = [C.POINTER(SynthCfg), u8p, C.c_size_t, u8p, u8p]
     _lib = L
@@ -344,45 +345,51 @@ class SyncOutcome(dict):
 
 def _sync_result_to_py(res):
     assert SLOT_DTYPE.itemsize == C.sizeof(SyncSlot) and EVENT_DTYPE.itemsize == C.sizeof(SyncEventRec)
-    if res.nslots:
-        sa = np.frombuffer(C.string_at(res.slots, res.nslots * SLOT_DTYPE.itemsize), SLOT_DTYPE).copy()
-    else:
-        sa = np.zeros(0, SLOT_DTYPE)
-    if res.nevents:
-        ea = np.frombuffer(C.string_at(res.events, res.nevents * EVENT_DTYPE.itemsize), EVENT_DTYPE).copy()
-    else:
-        ea = np.zeros(0, EVENT_DTYPE)
+    def grab(ptr, n, dt):
+        if not n:
+            return np.zeros(0, dt)
+        raw = (C.c_uint8 * (n * dt.itemsize)).from_address(C.addressof(ptr.contents))
+        return np.frombuffer(raw, dt).copy()     # one copy, then the C arrays are freed
+    sa = grab(res.slots, res.nslots, SLOT_DTYPE)
+    ea = grab(res.events, res.nevents, EVENT_DTYPE)
     out = SyncOutcome(slot_arr=sa, event_arr=ea, final_state=res.final_state, tail_tn_adds=res.tail_tn_adds,
                       burst_seq=res.burst_seq, anchor=res.anchor)
     lib().tgpu_sync_result_free(C.byref(res))
     return out
 
 
-def sync_walk(stream, chunk=64, anchor=0, cls=None):
-    """host half of the stream synchroniser (tgpu_sync_walk); cls=None: every slot settled on the bytes"""
+def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None):
+    """host half of the stream synchroniser (tgpu_sync_walk); cls=None: every slot settled on the bytes,
+    ysum=None: re-lock searches scan the bytes"""
     stream = _np_u8(stream)
     res = SyncResult()
     if cls is not None:
         cls = np.ascontiguousarray(cls, np.uint32)
+    if ysum is not None:
+        ysum = np.ascontiguousarray(ysum, np.uint16)
+        assert cls is not None and len(ysum) == len(cls)
     _chk(lib().tgpu_sync_walk(stream.ctypes.data_as(u8p), len(stream), chunk, anchor,
                               cls.ctypes.data_as(u32p) if cls is not None else None,
-                              len(cls) if cls is not None else 0, C.byref(res)), "tgpu_sync_walk")
+                              ysum.ctypes.data_as(u16p) if ysum is not None else None,
+                              len(cls) if cls is not None else 0, 0 if burst_events else 1, C.byref(res)), "tgpu_sync_walk")
     return _sync_result_to_py(res)
 
 
-def sync_classify(engine, d_stream_ptr, length, chunk, anchor, nslots, hip_stream=0):
+def sync_classify(engine, d_stream_ptr, length, chunk, anchor, nslots, hip_stream=0, with_ysum=False):
     out = np.zeros(nslots, np.uint32)
+    ys = np.zeros(nslots, np.uint16) if with_ysum else None
     _chk(lib().tgpu_sync_classify(engine._h, C.c_void_p(d_stream_ptr), length, chunk, anchor, nslots,
-                                  out.ctypes.data_as(u32p), C.c_void_p(hip_stream)), "tgpu_sync_classify")
-    return out
+                                  out.ctypes.data_as(u32p), ys.ctypes.data_as(u16p) if with_ysum else None,
+                                  C.c_void_p(hip_stream)), "tgpu_sync_classify")
+    return (out, ys) if with_ysum else out
 
 
-def sync_stream(engine, h_stream, d_stream_ptr, chunk=64, hip_stream=0):
+def sync_stream(engine, h_stream, d_stream_ptr, chunk=64, hip_stream=0, burst_events=True):
     """tgpu_sync_stream: host first lock + GPU classification + host walk"""
     h_stream = _np_u8(h_stream)
     res = SyncResult()
     _chk(lib().tgpu_sync_stream(engine._h, h_stream.ctypes.data_as(u8p), C.c_void_p(d_stream_ptr), len(h_stream),
-                                chunk, C.byref(res), C.c_void_p(hip_stream)), "tgpu_sync_stream")
+                                chunk, 0 if burst_events else 1, C.byref(res), C.c_void_p(hip_stream)), "tgpu_sync_stream")
     return _sync_result_to_py(res)
 
 

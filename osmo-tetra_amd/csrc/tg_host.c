@@ -33,24 +33,22 @@ struct tgpu_plan {
 	int loaded;
 	int static_masks;	/* batch has no SYNC slot: mask entries are known at load time */
 	/* device */
-	uint64_t *d_slot_off;
-	uint8_t *d_slot_type;
+	uint8_t *d_up, *h_up;	/* upload arena (device / pinned host mirror): one copy per load */
+	size_t up_bytes;
+	uint64_t *d_slot_off;	/* the next seven point into d_up, laid out per load */
 	uint32_t *d_slot_chan;
 	int32_t *d_slot_sbord;
 	uint32_t *d_list_sb, *d_list_216, *d_list_432;
 	uint32_t *d_packed;
 	uint32_t *d_maskidx;
 	uint32_t *d_masks;
-	uint32_t *d_chan_code;
+	uint32_t *d_chan_code;	/* in d_up */
 	uint32_t *d_sb_ok, *d_sb_code;
 	unsigned long long *d_block_tmp;
 	uint8_t *d_wire;	/* caller-owned, optional */
 	uint32_t *d_softarea;	/* max_slots * 512 B, allocated on the first soft execute */
 	hipStream_t side;	/* k_vit<216> and k_vit<432> are independent: they run side by side */
 	hipEvent_t ev_fork, ev_join;
-	/* host staging */
-	int32_t *h_sbord;
-	uint32_t *h_list_sb, *h_list_216, *h_list_432;
 	uint32_t *h_last_slot_of_chan;
 };
 
@@ -96,6 +94,7 @@ void tgpu_engine_destroy(struct tgpu_engine *eng)
 	free(eng);
 }
 
+#define UP_ALIGN 256u
 #define DALLOC(ptr, bytes) do { size_t b_ = (bytes); hipError_t e_ = hipMalloc((void **)&(ptr), b_ ? b_ : 16); \
 	if (e_ != hipSuccess) { tgpu_plan_destroy(p); return (int)e_; } } while (0)
 
@@ -110,26 +109,22 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	p->max_slots = max_slots;
 	p->max_chan = max_chan;
 	const size_t n = max_slots;
-	DALLOC(p->d_slot_off, n * sizeof(uint64_t));
-	DALLOC(p->d_slot_type, n);
-	DALLOC(p->d_slot_chan, n * 4);
-	DALLOC(p->d_slot_sbord, n * 4);
-	DALLOC(p->d_list_sb, n * 4);
-	DALLOC(p->d_list_216, 2 * n * 4);
-	DALLOC(p->d_list_432, n * 4);
+	/* descriptors 8n, chan 4n, sbord 4n, lists <= 8n in total, static mask indices 4n, codes, padding */
+	p->up_bytes = 28 * n + 4 * (size_t)max_chan + 8 * UP_ALIGN;
+	DALLOC(p->d_up, p->up_bytes);
+	if (hipHostMalloc((void **)&p->h_up, p->up_bytes, hipHostMallocDefault) != hipSuccess) {
+		p->h_up = NULL;
+		tgpu_plan_destroy(p);
+		return TGPU_ENOMEM;
+	}
 	DALLOC(p->d_packed, n * TG_PACKED_WORDS * 4);
 	DALLOC(p->d_maskidx, n * 4);
 	DALLOC(p->d_masks, (1 + (size_t)max_chan + n) * TG_MASK_WORDS * 4);
-	DALLOC(p->d_chan_code, (size_t)max_chan * 4);
 	DALLOC(p->d_sb_ok, n * 4);
 	DALLOC(p->d_sb_code, n * 4);
 	DALLOC(p->d_block_tmp, ((n + 1023) / 1024 + 1) * sizeof(unsigned long long));
-	p->h_sbord = malloc(n * 4);
-	p->h_list_sb = malloc(n * 4);
-	p->h_list_216 = malloc(2 * n * 4);
-	p->h_list_432 = malloc(n * 4);
 	p->h_last_slot_of_chan = malloc((size_t)max_chan * 4);
-	if (!p->h_sbord || !p->h_list_sb || !p->h_list_216 || !p->h_list_432 || !p->h_last_slot_of_chan) {
+	if (!p->h_last_slot_of_chan) {
 		tgpu_plan_destroy(p);
 		return TGPU_ENOMEM;
 	}
@@ -150,16 +145,13 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->side) (void)hipStreamDestroy(p->side);
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-	void *d[] = { p->d_slot_off, p->d_slot_type, p->d_slot_chan, p->d_slot_sbord, p->d_list_sb, p->d_list_216,
-		      p->d_list_432, p->d_packed, p->d_maskidx, p->d_masks, p->d_chan_code, p->d_sb_ok, p->d_sb_code,
+	void *d[] = { p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
 		      p->d_block_tmp, p->d_softarea };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
 			(void)hipFree(d[i]);
-	free(p->h_sbord);
-	free(p->h_list_sb);
-	free(p->h_list_216);
-	free(p->h_list_432);
+	if (p->h_up)
+		(void)hipHostFree(p->h_up);
 	free(p->h_last_slot_of_chan);
 	free(p);
 }
@@ -173,67 +165,74 @@ int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_of
 		return TGPU_EINVAL;
 	if (nslots > p->max_slots || nchan > p->max_chan)
 		return TGPU_ECAPACITY;
+	/* pass 1: validate and count, so that the upload arena can be laid out exactly */
 	uint32_t nsb = 0, n216 = 0, n432 = 0, prev = 0;
-	for (uint32_t c = 0; c < nchan; c++)
-		p->h_last_slot_of_chan[c] = 0xffffffffu;
 	for (uint32_t i = 0; i < nslots; i++) {
-		if (slot_chan[i] >= nchan || slot_chan[i] < prev)
+		if (slot_chan[i] >= nchan || slot_chan[i] < prev || (slot_off[i] >> 56))
 			return TGPU_EINVAL;
 		prev = slot_chan[i];
-		p->h_last_slot_of_chan[prev] = i;
-		p->h_sbord[i] = -1;
-		switch (slot_type[i]) {
+		const uint8_t t = slot_type[i];
+		nsb += t == TETRA_TRAIN_SYNC;
+		n216 += (t == TETRA_TRAIN_SYNC) + 2 * (t == TETRA_TRAIN_NORM_2);
+		n432 += t == TETRA_TRAIN_NORM_1;
+	}
+	const int is_static = nsb == 0 && nslots;
+	size_t o = 0;
+#define UP_PLACE(dptr, hptr, type, count) do { dptr = (type *)(p->d_up + o); hptr = (type *)(p->h_up + o); \
+		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
+	uint64_t *h_desc;
+	uint32_t *h_chan, *h_list_sb, *h_list_216, *h_list_432, *h_code, *h_idx, *d_idx_stage;
+	int32_t *h_sbord;
+	UP_PLACE(p->d_slot_off, h_desc, uint64_t, nslots);
+	UP_PLACE(p->d_slot_chan, h_chan, uint32_t, nslots);
+	UP_PLACE(p->d_slot_sbord, h_sbord, int32_t, nslots);
+	UP_PLACE(p->d_list_sb, h_list_sb, uint32_t, nsb);
+	UP_PLACE(p->d_list_216, h_list_216, uint32_t, n216);
+	UP_PLACE(p->d_list_432, h_list_432, uint32_t, n432);
+	UP_PLACE(p->d_chan_code, h_code, uint32_t, nchan);
+	UP_PLACE(d_idx_stage, h_idx, uint32_t, is_static ? nslots : 0);
+#undef UP_PLACE
+	if (o > p->up_bytes)
+		return TGPU_ECAPACITY;	/* cannot happen: sized for the worst case in tgpu_plan_create */
+
+	/* pass 2: fill the pinned mirror */
+	for (uint32_t c = 0; c < nchan; c++)
+		p->h_last_slot_of_chan[c] = 0xffffffffu;
+	uint32_t isb = 0, i216 = 0, i432 = 0;
+	for (uint32_t i = 0; i < nslots; i++) {
+		const uint8_t t = slot_type[i];
+		const uint32_t ch = slot_chan[i];
+		p->h_last_slot_of_chan[ch] = i;
+		/* descriptor = offset | type << 56 (one scalar load per slot in the front kernel) */
+		h_desc[i] = slot_off[i] | ((uint64_t)t << 56);
+		h_chan[i] = ch;
+		h_sbord[i] = -1;
+		switch (t) {
 		case TETRA_TRAIN_SYNC:
-			p->h_sbord[i] = (int32_t)nsb;
-			p->h_list_sb[nsb++] = i;
-			p->h_list_216[n216++] = (i << 1) | 1;	/* SB2 */
+			h_sbord[i] = (int32_t)isb;
+			h_list_sb[isb++] = i;
+			h_list_216[i216++] = (i << 1) | 1;	/* SB2 */
 			break;
 		case TETRA_TRAIN_NORM_2:
-			p->h_list_216[n216++] = (i << 1);
-			p->h_list_216[n216++] = (i << 1) | 1;
+			h_list_216[i216++] = (i << 1);
+			h_list_216[i216++] = (i << 1) | 1;
 			break;
 		case TETRA_TRAIN_NORM_1:
-			p->h_list_432[n432++] = i;
+			h_list_432[i432++] = i;
 			break;
 		default:
 			break;
 		}
+		if (is_static)
+			h_idx[i] = 1 + ch;
 	}
-	if (nslots) {
-		/* descriptor = offset | type << 56 (one scalar load per slot in the front kernel) */
-		uint64_t *desc = malloc((size_t)nslots * 8);
-		if (!desc)
-			return TGPU_ENOMEM;
-		for (uint32_t i = 0; i < nslots; i++) {
-			if (slot_off[i] >> 56) {
-				free(desc);
-				return TGPU_EINVAL;
-			}
-			desc[i] = slot_off[i] | ((uint64_t)slot_type[i] << 56);
-		}
-		hipError_t de = hipMemcpy(p->d_slot_off, desc, (size_t)nslots * 8, hipMemcpyHostToDevice);
-		free(desc);
-		if (de != hipSuccess)
-			return (int)de;
-		HCHK(hipMemcpy(p->d_slot_type, slot_type, nslots, hipMemcpyHostToDevice));
-		HCHK(hipMemcpy(p->d_slot_chan, slot_chan, (size_t)nslots * 4, hipMemcpyHostToDevice));
-		HCHK(hipMemcpy(p->d_slot_sbord, p->h_sbord, (size_t)nslots * 4, hipMemcpyHostToDevice));
-	}
-	if (nsb)
-		HCHK(hipMemcpy(p->d_list_sb, p->h_list_sb, (size_t)nsb * 4, hipMemcpyHostToDevice));
-	if (n216)
-		HCHK(hipMemcpy(p->d_list_216, p->h_list_216, (size_t)n216 * 4, hipMemcpyHostToDevice));
-	if (n432)
-		HCHK(hipMemcpy(p->d_list_432, p->h_list_432, (size_t)n432 * 4, hipMemcpyHostToDevice));
-	HCHK(hipMemcpy(p->d_chan_code, chan_code, (size_t)nchan * 4, hipMemcpyHostToDevice));
+	memcpy(h_code, chan_code, (size_t)nchan * 4);
+	HCHK(hipMemcpy(p->d_up, p->h_up, o, hipMemcpyHostToDevice));
 	p->static_masks = 0;
-	if (nsb == 0 && nslots) {
+	if (is_static) {
 		/* no SYNC burst in the batch: every slot keeps its channel's carry-in code, so the
 		 * forward fill degenerates to entry 1 + chan and the masks can be built right now */
-		uint32_t *idx = (uint32_t *)p->h_sbord;
-		for (uint32_t i = 0; i < nslots; i++)
-			idx[i] = 1 + slot_chan[i];
-		HCHK(hipMemcpy(p->d_maskidx, idx, (size_t)nslots * 4, hipMemcpyHostToDevice));
+		HCHK(hipMemcpyAsync(p->d_maskidx, d_idx_stage, (size_t)nslots * 4, hipMemcpyDeviceToDevice, NULL));
 		int rc = tgk_masks(p->d_chan_code, nchan, p->d_sb_ok, p->d_sb_code, 0, p->d_masks, NULL);
 		if (rc)
 			return rc;

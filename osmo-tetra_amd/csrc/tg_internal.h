@@ -14,7 +14,7 @@ int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 	      uint32_t nslots, uint32_t *d_packed, uint8_t *d_rec, void *stream);
 /* stream mode: grid slot n at anchor + 510 n; writes packed slots and one classification word per slot */
 int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
-		     uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, void *stream);
+		     uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream);
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
 	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */,

@@ -220,7 +220,7 @@ struct tg_stream_params {
 
 __global__ __launch_bounds__(256)
 void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
-		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls)
+		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
 {
 	constexpr int WIN = TG_STREAM_VIEW / 4 + 4;	/* 160 data dwords + one zero pad row */
 	__shared__ uint32_t s_slot[4][WIN];
@@ -260,49 +260,66 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			fed = prm.len;
 		const uint32_t w = (uint32_t)(fed - bs);			/* search window, >= 510 */
 		const uint32_t wv = w < TG_STREAM_VIEW ? w : TG_STREAM_VIEW;	/* what we can see of it */
+		const uint64_t rest = prm.len - bs;
+		const uint32_t vis = rest < TG_STREAM_VIEW ? (uint32_t)rest : TG_STREAM_VIEW;	/* stream bytes in view */
 
 		mine[lane] = d0;
 		mine[64 + lane] = d1;
 		if (lane < 32)
 			mine[128 + lane] = d2;
 
-		/* bytes -> 640-bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes outside the window read as 0 */
+		/* bytes -> 640-bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes past the stream end read as 0
+		 * (every test below bounds itself by the window, so bytes past the window need no masking) */
 		unsigned long long B[11];
 		uint32_t anyb = 0;
 #pragma unroll
 		for (int r = 0; r < 10; r++) {
-			uint32_t byte = lds0[wbase + 64 * r + lane];
-			if (64u * r + lane >= wv)
-				byte = 0;
-			anyb |= byte;
-			B[r] = __ballot(byte != 0);
+			const uint32_t byte = lds0[wbase + 64 * r + lane];
+			anyb |= (64u * r + lane < wv) ? byte : 0u;
+			B[r] = __ballot(byte != 0 && 64u * r + lane < vis);
 		}
 		B[10] = 0;
 
 		uint32_t rc = TG_BURST_NONE, offs = 0, flags = 0, early = 0;
+		uint32_t ys = TG_YS_NONE;	/* where SYNC sequences start inside this slot, window or not */
 		bool found = false;
 #pragma unroll
 		for (int r = 0; r < 10; r++) {
-			if ((r < 4 || !found) && 64u * r < wv) {
+			const bool full = (r < 4 || !found) && 64u * r < wv;
+			if (full || r < 8) {
 				const uint32_t c = 64 * r + lane;
 				const uint32_t b0 = (uint32_t)B[r], b1 = (uint32_t)(B[r] >> 32);
 				const uint32_t b2 = (uint32_t)B[r + 1], b3 = (uint32_t)(B[r + 1] >> 32);
 				const uint32_t w0 = half ? b1 : b0, w1 = half ? b2 : b1, w2 = half ? b3 : b2;
 				const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bit);
 				const uint32_t win2 = __builtin_amdgcn_alignbit(w2, w1, bit);
-				const bool isy = (win == prm.y32) && ((win2 & 0x3f) == prm.y6) && (c + 38 <= w);
-				const bool isn = ((win & 0x3fffff) == prm.n22) && (c + 22 <= w);
-				const bool isp = ((win & 0x3fffff) == prm.p22) && (c + 22 <= w);
-				const bool any = isy || isn || isp;
-				if (r == 0)
-					early = __ballot(any && c < 21) != 0;
-				const unsigned long long m = __ballot(any && c >= 21);
-				if (!found && m) {
-					const uint32_t l0 = __builtin_ctzll(m);
-					offs = 64 * r + l0;
-					const uint32_t ty = isy ? TG_BURST_SYNC : isn ? TG_BURST_NORM_1 : TG_BURST_NORM_2;
-					rc = __builtin_amdgcn_readlane(ty, l0);
-					found = true;
+				const bool y38 = (win == prm.y32) && ((win2 & 0x3f) == prm.y6);
+				if (r < 8) {
+					const unsigned long long my = __ballot(y38 && c < TG_SLOT_BITS && c + 38 <= vis);
+					if (my) {
+						if (ys == TG_YS_NONE)
+							ys = 64 * r + __builtin_ctzll(my);
+						else
+							ys |= TG_YS_MULTI;
+						if (my & (my - 1))
+							ys |= TG_YS_MULTI;
+					}
+				}
+				if (full) {
+					const bool isy = y38 && (c + 38 <= w);
+					const bool isn = ((win & 0x3fffff) == prm.n22) && (c + 22 <= w);
+					const bool isp = ((win & 0x3fffff) == prm.p22) && (c + 22 <= w);
+					const bool any = isy || isn || isp;
+					if (r == 0)
+						early = __ballot(any && c < 21) != 0;
+					const unsigned long long m = __ballot(any && c >= 21);
+					if (!found && m) {
+						const uint32_t l0 = __builtin_ctzll(m);
+						offs = 64 * r + l0;
+						const uint32_t ty = isy ? TG_BURST_SYNC : isn ? TG_BURST_NORM_1 : TG_BURST_NORM_2;
+						rc = __builtin_amdgcn_readlane(ty, l0);
+						found = true;
+					}
 				}
 			}
 		}
@@ -331,8 +348,11 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			myword = dtype | (((flags & TG_CLS_NONBINARY) ? TG_FLAG_NONBINARY : 0u) << 8) | (offs << 16);
 		if (lane < TG_PACKED_WORDS)
 			packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
-		if (lane == 0)
+		if (lane == 0) {
 			cls[slot] = rc | (offs << 8) | (flags << 24);
+			if (ysum)
+				ysum[slot] = (uint16_t)ys;
+		}
 	}
 }
 
@@ -1102,7 +1122,7 @@ static uint32_t host_pattern_bits(const uint8_t *seq, int from, int n)
 }
 
 extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
-				uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, void *stream)
+				uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream)
 {
 	if (!nslots)
 		return 0;
@@ -1120,7 +1140,7 @@ extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64
 	uint32_t blocks = (nslots + 3) / 4;
 	if (blocks > 256 * 8)
 		blocks = 256 * 8;
-	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_stream, prm, d_packed, d_cls);
+	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_stream, prm, d_packed, d_cls, d_ysum);
 	return (int)hipGetLastError();
 }
 

@@ -69,6 +69,11 @@
 #define TG_CLS_EARLY21    0x01	/* a full match exists at an offset < 21 */
 #define TG_CLS_NONBINARY  0x02
 #define TG_CLS_CLIPPED    0x04	/* window longer than the kernel's 640-byte view and nothing found in view */
+/* SYNC-sequence summary of a grid slot (uint16): where the 38-bit y sequence starts inside the slot's own
+ * 510 positions, regardless of any search window -- what an UNLOCKED synchroniser scans for */
+#define TG_YS_NONE        0xffffu	/* no y sequence starts in this slot */
+#define TG_YS_MULTI       0x8000u	/* more than one does; bits 0..8 hold the first */
+#define TG_YS_FIRST(v)    ((v) & 0x1ffu)
 #define TG_STREAM_VIEW    640	/* bytes of a slot's search window the kernel looks at */
 #define TG_STREAM_SLACK   192	/* readable bytes the stream buffer must have after its last byte */
 

@@ -40,6 +40,9 @@ struct walk {
 	uint64_t ncalls;
 	struct tgpu_sync_result *out;
 	uint32_t cap_slots, cap_events;
+	/* optional GPU summary: ysum[g] describes the y sequences starting in [anchor + 510 g, anchor + 510 (g + 1)) */
+	const uint16_t *ysum;
+	uint64_t anchor, nys;
 };
 
 static inline uint64_t fed(const struct walk *w, uint64_t k)
@@ -94,19 +97,59 @@ static int push_slot(struct walk *w, uint64_t off, int type, uint32_t seq, uint3
 	return 0;
 }
 
-/* first start position of the SYNC training sequence in [from, last], UINT64_MAX if none */
-static uint64_t next_sync_seq(const struct walk *w, uint64_t from, uint64_t last)
+/* first start position of the SYNC training sequence in [from, last] by looking at the bytes */
+static uint64_t scan_sync_seq(const struct walk *w, uint64_t from, uint64_t last)
 {
 	static const uint8_t y[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
 	uint64_t y8;
 	memcpy(&y8, y, 8);
-	if (last + 38 > w->len)
-		last = w->len >= 38 ? w->len - 38 : 0;
-	for (uint64_t p = from; p <= last && p + 38 <= w->len; p++) {
+	for (uint64_t p = from; p <= last; p++) {
 		uint64_t v;
 		memcpy(&v, w->s + p, 8);
 		if (v == y8 && !memcmp(w->s + p + 8, y + 8, 30))
 			return p;
+	}
+	return UINT64_MAX;
+}
+
+/* first start position of the SYNC training sequence in [from, last], UINT64_MAX if none.  Grid slots
+ * covered by the GPU summary cost one table look-up; the bytes are only read before the grid, after
+ * it, and inside a slot that holds several sequences when the first one lies before 'from'. */
+static uint64_t next_sync_seq(const struct walk *w, uint64_t from, uint64_t last)
+{
+	if (w->len < 38)
+		return UINT64_MAX;
+	if (last > w->len - 38)
+		last = w->len - 38;
+	uint64_t p = from;
+	while (p <= last) {
+		if (!w->ysum || p < w->anchor) {
+			uint64_t e = last;
+			if (w->ysum && w->nys && e >= w->anchor)
+				e = w->anchor - 1;
+			const uint64_t r = scan_sync_seq(w, p, e);
+			if (r != UINT64_MAX)
+				return r;
+			p = e + 1;
+			continue;
+		}
+		const uint64_t g = (p - w->anchor) / TG_SLOT_BITS;
+		if (g >= w->nys)
+			return scan_sync_seq(w, p, last);
+		const uint64_t s0 = w->anchor + g * TG_SLOT_BITS;
+		const uint32_t v = w->ysum[g];
+		if (v != TG_YS_NONE) {
+			const uint64_t fp = s0 + TG_YS_FIRST(v);
+			if (fp >= p)
+				return fp <= last ? fp : UINT64_MAX;
+			if (v & TG_YS_MULTI) {
+				const uint64_t e = s0 + TG_SLOT_BITS - 1 < last ? s0 + TG_SLOT_BITS - 1 : last;
+				const uint64_t r = scan_sync_seq(w, p, e);
+				if (r != UINT64_MAX)
+					return r;
+			}
+		}
+		p = s0 + TG_SLOT_BITS;
 	}
 	return UINT64_MAX;
 }
@@ -129,18 +172,21 @@ static int exact_find(const struct walk *w, uint64_t pos, uint32_t n, uint32_t m
 }
 
 int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor,
-		   const uint32_t *cls, uint32_t ncls, struct tgpu_sync_result *out)
+		   const uint32_t *cls, const uint16_t *ysum, uint32_t ncls, uint32_t flags, struct tgpu_sync_result *out)
 {
 	/* chunk <= 510: a call never feeds more than a burst consumes, so the 4096-byte buffer can only
 	 * overflow (and drop data) while UNLOCKED -- which is modelled.  tetra-rx.c uses 64. */
 	if (!h_stream || !out || !chunk || chunk > TG_SLOT_BITS)
 		return TGPU_EINVAL;
 	memset(out, 0, sizeof(*out));
-	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, out, 0, 0 };
+	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, out, 0, 0, ysum, anchor, ysum ? ncls : 0 };
 	int rc;
 
 	uint64_t bs = 0;	/* bitbuf_start_bitnum */
 	uint64_t k = 0;		/* index of the last call that has run */
+	uint64_t kceil = 0, fceil = 0, fceil_for = UINT64_MAX;
+	uint64_t gi = 0, grid_for = UINT64_MAX;
+	int ongrid = 0;
 	uint32_t seq = 0, tn_adds = 0;
 	int state = RX_S_UNLOCKED;
 	uint64_t nfs = 0;
@@ -217,42 +263,61 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 			state = RX_S_LOCKED;
 			k = kl - 1;	/* the LOCKED branch below may use call kl itself */
 		}
-		/* LOCKED: the next burst is handled by the first call >= k+1 that has 510 bytes of it */
-		uint64_t kj = call_reaching(&w, bs + TG_SLOT_BITS);
-		if (kj <= k)
-			kj = k + 1;
+		/* LOCKED: the next burst is handled by the first call >= k+1 that has 510 bytes of it.
+		 * kceil / fceil = that call and its fed count when nothing is backlogged, tracked incrementally
+		 * (bs only moves forward) so that the steady state costs no division. */
+		const uint64_t need = bs + TG_SLOT_BITS;
+		if (need > len) {
+			k = w.ncalls;
+			break;
+		}
+		if (fceil_for != bs) {
+			if (fceil_for == UINT64_MAX || bs < fceil_for || need > fceil + 64 * (uint64_t)chunk) {
+				kceil = (need + chunk - 1) / chunk;
+				fceil = kceil * chunk;
+			}
+			while (fceil < need) {
+				fceil += chunk;
+				kceil++;
+			}
+			fceil_for = bs;
+		}
+		uint64_t kj = kceil > k ? kceil : k + 1;
 		if (kj > w.ncalls) {
 			k = w.ncalls;
 			break;
 		}
-		const uint32_t win = (uint32_t)(fed(&w, kj) - bs);
+		const uint64_t fj = (kj == kceil) ? (fceil > len ? len : fceil) : fed(&w, kj);
+		const uint32_t win = (uint32_t)(fj - bs);
 		k = kj;
 		seq++;
 		tn_adds++;
-		if ((rc = push_event(&w, TGPU_EV_BURST, bs, win)))
+		if (!(flags & TGPU_SYNC_NO_BURST_EVENTS) && (rc = push_event(&w, TGPU_EV_BURST, bs, win)))
 			return rc;
 
 		int type = -1;
 		unsigned int offs = 0;
 		int settled = 0;
-		if (cls && bs >= anchor && (bs - anchor) % TG_SLOT_BITS == 0 && (bs - anchor) / TG_SLOT_BITS < ncls) {
-			const uint32_t cw = cls[(bs - anchor) / TG_SLOT_BITS];
-			const uint32_t flags = cw >> 24;
-			/* window the kernel assumed: the steady-state one */
-			uint64_t f0 = ((bs + TG_SLOT_BITS + chunk - 1) / chunk) * chunk;
-			if (f0 > len)
-				f0 = len;
-			const uint32_t w0 = (uint32_t)(f0 - bs);
-			if (!(flags & TG_CLS_EARLY21)) {
-				if ((cw & 0xff) != TG_BURST_NONE) {
-					/* first hit at an offset >= 21 inside the assumed window: it is the first hit
-					 * of any window that contains it */
-					type = (int)(cw & 0xff);
-					offs = (cw >> 8) & 0xffff;
-					settled = 1;
-				} else if (win == w0 && !(flags & TG_CLS_CLIPPED)) {
-					type = -1;
-					settled = 1;
+		if (cls) {
+			if (grid_for != bs) {
+				ongrid = bs >= anchor && (bs - anchor) % TG_SLOT_BITS == 0;
+				gi = ongrid ? (bs - anchor) / TG_SLOT_BITS : 0;
+				grid_for = bs;
+			}
+			if (ongrid && gi < ncls) {
+				const uint32_t cw = cls[gi];
+				const uint32_t cflags = cw >> 24;
+				if (!(cflags & TG_CLS_EARLY21)) {
+					if ((cw & 0xff) != TG_BURST_NONE) {
+						/* first hit at an offset >= 21 inside the window the kernel assumed (the steady-state
+						 * one): it is the first hit of any window that contains it */
+						type = (int)(cw & 0xff);
+						offs = (cw >> 8) & 0xffff;
+						settled = 1;
+					} else if (kj == kceil && !(cflags & TG_CLS_CLIPPED)) {
+						type = -1;	/* same window as the kernel's, and nothing in it */
+						settled = 1;
+					}
 				}
 			}
 		}
@@ -283,6 +348,10 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 		}
 		bs += TG_SLOT_BITS;
 		nfs += TG_SLOT_BITS;
+		if (grid_for + TG_SLOT_BITS == bs) {	/* stay on the grid without dividing */
+			grid_for = bs;
+			gi++;
+		}
 	}
 	out->final_state = state;
 	out->tail_tn_adds = tn_adds;
@@ -303,7 +372,7 @@ void tgpu_sync_result_free(struct tgpu_sync_result *r)
 static int find_anchor(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t *anchor, int *locks)
 {
 	/* run the walk without classification until the first LOCKED burst: cheap, it stops early */
-	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, NULL, 0, 0 };
+	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, NULL, 0, 0, NULL, 0, 0 };
 	*locks = 0;
 	uint64_t kk = call_reaching(&w, 2 * TG_SLOT_BITS);
 	for (; kk <= w.ncalls; kk++) {
@@ -322,21 +391,25 @@ static int find_anchor(const uint8_t *h_stream, uint64_t len, uint32_t chunk, ui
 }
 
 int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_t len, uint32_t chunk,
-		       uint64_t anchor, uint32_t nslots, uint32_t *h_cls, void *stream)
+		       uint64_t anchor, uint32_t nslots, uint32_t *h_cls, uint16_t *h_ysum, void *stream)
 {
 	if (!eng || !d_stream || !h_cls || !chunk)
 		return TGPU_EINVAL;
 	if (!nslots)
 		return TGPU_OK;
 	uint32_t *d_cls = NULL, *d_packed = NULL;
-	hipError_t e = hipMalloc((void **)&d_cls, (size_t)nslots * 4);
+	/* classification words, then (same allocation) the SYNC-sequence summaries */
+	hipError_t e = hipMalloc((void **)&d_cls, (size_t)nslots * 6);
 	if (e == hipSuccess)
 		e = hipMalloc((void **)&d_packed, (size_t)nslots * TG_PACKED_WORDS * 4);
 	int rc = (int)e;
 	if (!rc)
-		rc = tgk_front_stream(d_stream, anchor, len, nslots, chunk, d_packed, d_cls, stream);
+		rc = tgk_front_stream(d_stream, anchor, len, nslots, chunk, d_packed, d_cls,
+				      h_ysum ? (uint16_t *)(d_cls + nslots) : NULL, stream);
 	if (!rc)
 		rc = (int)hipMemcpyAsync(h_cls, d_cls, (size_t)nslots * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+	if (!rc && h_ysum)
+		rc = (int)hipMemcpyAsync(h_ysum, d_cls + nslots, (size_t)nslots * 2, hipMemcpyDeviceToHost, (hipStream_t)stream);
 	if (!rc)
 		rc = (int)hipStreamSynchronize((hipStream_t)stream);
 	if (d_cls)
@@ -354,7 +427,7 @@ static double now_ms(void)
 }
 
 int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uint8_t *d_stream, uint64_t len,
-		     uint32_t chunk, struct tgpu_sync_result *out, void *stream)
+		     uint32_t chunk, uint32_t flags, struct tgpu_sync_result *out, void *stream)
 {
 	if (!eng || !h_stream || !d_stream || !out || !chunk)
 		return TGPU_EINVAL;
@@ -365,23 +438,25 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
 	if (rc)
 		return rc;
 	uint32_t *cls = NULL;
+	uint16_t *ysum = NULL;
 	uint32_t ncls = 0;
 	if (locks && anchor + TG_SLOT_BITS <= len) {
 		uint64_t n = (len - anchor) / TG_SLOT_BITS;
 		if (n > 0xfffffff0u)
 			return TGPU_ECAPACITY;
 		ncls = (uint32_t)n;
-		cls = malloc((size_t)ncls * 4);
+		cls = malloc((size_t)ncls * 6);
 		if (!cls)
 			return TGPU_ENOMEM;
-		rc = tgpu_sync_classify(eng, d_stream, len, chunk, anchor, ncls, cls, stream);
+		ysum = (uint16_t *)(cls + ncls);
+		rc = tgpu_sync_classify(eng, d_stream, len, chunk, anchor, ncls, cls, ysum, stream);
 		if (rc) {
 			free(cls);
 			return rc;
 		}
 	}
 	const double t1 = now_ms();
-	rc = tgpu_sync_walk(h_stream, len, chunk, anchor, cls, ncls, out);
+	rc = tgpu_sync_walk(h_stream, len, chunk, anchor, cls, ysum, ncls, flags, out);
 	out->anchor = anchor;
 	free(cls);
 	if (getenv("TGPU_SYNC_TIMING"))

@@ -428,16 +428,19 @@ def test_stream_classification_kernel(T, eng):
     """k_front_stream's classification words == the definition (first y/n/p hit at offset >= 21 of the
     window the reference would search), checked with a numpy statement of it"""
     import torch
-    from test_stream_sync_cpu import emul_cls
+    from test_stream_sync_cpu import emul_cls, emul_ysum
     for seed in (3, 4):
         s = _mutated_stream(seed)
         res = T.sync_walk(s)
         anchor = res["slots"][0][0]
         n = (len(s) - anchor) // 510
         d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
-        got = T.sync_classify(eng, d.data_ptr(), len(s), 64, anchor, n)
+        got, ys = T.sync_classify(eng, d.data_ptr(), len(s), 64, anchor, n, with_ysum=True)
         want = emul_cls(s, anchor, 64)
         assert (got & 0x05FFFFFF).tolist() == (want & 0x05FFFFFF).tolist()
+        assert ys.tolist() == emul_ysum(s, anchor).tolist()
+        assert (ys != 0xFFFF).sum() >= 3
+        assert T.sync_classify(eng, d.data_ptr(), len(s), 64, anchor, n).tolist() == got.tolist()
 
 
 @pytest.mark.parametrize("seed", [1, 2, 5])

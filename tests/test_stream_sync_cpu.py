@@ -68,6 +68,29 @@ def emul_cls(stream, anchor, chunk, view=640):
     return out
 
 
+def emul_ysum(stream, anchor):
+    """numpy statement of k_front_stream's SYNC-sequence summaries: per grid slot, where the 38-bit y
+    sequence starts inside the slot's own 510 positions (first start, 0x8000 if several, 0xffff if none)"""
+    L = len(stream)
+    n = (L - anchor) // 510 if L >= anchor + 510 else 0
+    out = np.full(n, 0xFFFF, np.uint16)
+    if L < 38:
+        return out
+    win = np.lib.stride_tricks.sliding_window_view(stream, 38)
+    starts = np.nonzero((win == SEQ_Y).all(axis=1))[0]
+    for p in starts:
+        if p < anchor:
+            continue
+        g = (p - anchor) // 510
+        if g >= n or (p - anchor) % 510 + 38 > min(L - (anchor + 510 * g), 640):
+            continue
+        if out[g] == 0xFFFF:
+            out[g] = (p - anchor) % 510
+        else:
+            out[g] |= 0x8000
+    return out
+
+
 def check(stream, chunk=64, with_cls=True):
     bursts, oev, pos = oracle_view(stream, chunk)
     res = T.sync_walk(stream, chunk=chunk)
@@ -88,6 +111,8 @@ def check(stream, chunk=64, with_cls=True):
         cls = emul_cls(stream, anchor, chunk)
         res2 = T.sync_walk(stream, chunk=chunk, anchor=anchor, cls=cls)
         assert res2["events"] == oev and res2["slots"] == res["slots"]
+        res3 = T.sync_walk(stream, chunk=chunk, anchor=anchor, cls=cls, ysum=emul_ysum(stream, anchor))
+        assert res3["events"] == oev and res3["slots"] == res["slots"]
     return res
 
 
@@ -152,3 +177,24 @@ def test_long_gap_slides_the_4096_byte_buffer():
     gap = rng.integers(0, 2, 9000).astype(np.uint8)
     check(np.concatenate([a, gap, b]), with_cls=False)
     check(np.concatenate([a, np.zeros(5003, np.uint8), b]), with_cls=False)
+
+
+def test_many_sync_sequences_per_slot_with_summary():
+    """several y sequences inside one grid slot (the summary's MULTI bit) while lock is lost and regained:
+    the table-driven re-lock search must agree with the byte scan"""
+    rng = np.random.default_rng(77)
+    for trial in range(10):
+        stream, slots = synth.frame_stream(seed=60 + trial, nframes=5, lead_in=int(rng.integers(0, 200)))
+        s = stream.copy()
+        p0 = np.flatnonzero((np.lib.stride_tricks.sliding_window_view(s, 38) == SEQ_Y).all(axis=1))[0] + 296
+        for _ in range(4):
+            i = int(rng.integers(1, len(slots) - 2))
+            base = p0 + 510 * i
+            off = 214 if slots[i][0] == O.TRAIN_SYNC else 244
+            s[base + off + 2] ^= 1                              # lose lock at slot i
+            for d in sorted(rng.integers(0, 470, int(rng.integers(1, 4)))):
+                s[base + 510 + int(d):base + 510 + int(d) + 38] = SEQ_Y   # and litter the next slot with y
+        res = check(s)
+        first = res["slots"][0][0]
+        ys = emul_ysum(s, first)
+        assert (ys[ys != 0xFFFF] & 0x8000).any() or trial > 0
