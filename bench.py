@@ -100,7 +100,7 @@ def bench_config3(args, T, torch, rank, world, local):
         res = T.sync_stream(eng, stream, d_stream.data_ptr(), 64, hs, burst_events=False)
         b = time.perf_counter()
         sl = res["slot_arr"]
-        plan.load(sl["off"], sl["type"], None, np.zeros(1, np.uint32))
+        plan.load_slots(res, 0)
         c = time.perf_counter()
         plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), hs)
         torch.cuda.synchronize()

@@ -370,6 +370,9 @@ void tgpu_sync_result_free(struct tgpu_sync_result *r);
 int tgpu_channel_deliver(struct tgpu_channel *ch, uint32_t n, const struct tgpu_sync_slot *slots,
 			 const uint8_t *h_stream, const uint8_t *h_rec);
 int tgpu_channel_scramb_init(const struct tgpu_channel *ch, uint32_t *code);
+/* tgpu_plan_load() for one channel, reading the slot table of tgpu_sync_stream() in place */
+int tgpu_plan_load_slots(struct tgpu_plan *plan, uint32_t nslots, const struct tgpu_sync_slot *slots,
+			 uint32_t scramb_init);
 
 /* the two halves of tgpu_sync_stream(): the GPU classification of 'nslots' grid slots starting at
  * 'anchor' (one word per slot + optionally one uint16 SYNC-sequence summary per slot, layouts in

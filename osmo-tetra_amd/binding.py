@@ -105,6 +105,7 @@ def lib():
     L.tgpu_plan_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_plan_destroy.argtypes = [C.c_void_p]
     L.tgpu_plan_load.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p, C.c_uint32, u32p]
+    L.tgpu_plan_load_slots.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(SyncSlot), C.c_uint32]
     L.tgpu_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_plan_final_codes.argtypes = [C.c_void_p, C.c_void_p, u32p]
     L.tgpu_plan_execute_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -198,6 +199,14 @@ class Plan:
         _chk(lib().tgpu_plan_load(self._h, n, off.ctypes.data_as(u64p), typ.ctypes.data_as(u8p),
                                   chan.ctypes.data_as(u32p), nchan, codes.ctypes.data_as(u32p)), "tgpu_plan_load")
         self.nslots, self.nchan = n, nchan
+
+    def load_slots(self, outcome, scramb_init=0):
+        """tgpu_plan_load_slots: one channel, slot table of sync_stream()/sync_walk() read in place"""
+        sa = outcome["slot_arr"]
+        assert sa.dtype == SLOT_DTYPE and sa.flags.c_contiguous
+        _chk(lib().tgpu_plan_load_slots(self._h, len(sa), sa.ctypes.data_as(C.POINTER(SyncSlot)), scramb_init),
+             "tgpu_plan_load_slots")
+        self.nslots, self.nchan = len(sa), 1
 
     def execute(self, d_stream_ptr, d_rec_ptr, hip_stream=0):
         _chk(lib().tgpu_plan_execute(self._h, C.c_void_p(d_stream_ptr), C.c_void_p(d_rec_ptr),
@@ -326,9 +335,20 @@ SLOT_DTYPE = np.dtype([("off", np.uint64), ("burst_seq", np.uint32), ("tn_adds",
 EVENT_DTYPE = np.dtype([("ev", np.int32), ("bitnum", np.uint32), ("arg", np.uint32)], align=True)
 
 
+class _ResultOwner:
+    """frees a tgpu_sync_result when the last numpy view onto it is gone"""
+
+    def __init__(self, res):
+        self.res = res
+
+    def __del__(self):
+        lib().tgpu_sync_result_free(C.byref(self.res))
+
+
 class SyncOutcome(dict):
     """result of the stream synchroniser; 'slot_arr' / 'event_arr' are numpy structured arrays
-    (SLOT_DTYPE / EVENT_DTYPE), 'slots' / 'events' lazily built python tuples (off, type, burst_seq, tn_adds) / (ev, bitnum, arg)"""
+    (SLOT_DTYPE / EVENT_DTYPE) viewing the C result in place (freed with the last view), 'slots' / 'events'
+    lazily built python tuples (off, type, burst_seq, tn_adds) / (ev, bitnum, arg)"""
 
     def __missing__(self, key):
         if key == "slots":
@@ -345,16 +365,18 @@ class SyncOutcome(dict):
 
 def _sync_result_to_py(res):
     assert SLOT_DTYPE.itemsize == C.sizeof(SyncSlot) and EVENT_DTYPE.itemsize == C.sizeof(SyncEventRec)
+    owner = _ResultOwner(res)
+
     def grab(ptr, n, dt):
         if not n:
             return np.zeros(0, dt)
         raw = (C.c_uint8 * (n * dt.itemsize)).from_address(C.addressof(ptr.contents))
-        return np.frombuffer(raw, dt).copy()     # one copy, then the C arrays are freed
+        raw._owner = owner                       # the view keeps the C arrays alive
+        return np.frombuffer(raw, dt)
     sa = grab(res.slots, res.nslots, SLOT_DTYPE)
     ea = grab(res.events, res.nevents, EVENT_DTYPE)
     out = SyncOutcome(slot_arr=sa, event_arr=ea, final_state=res.final_state, tail_tn_adds=res.tail_tn_adds,
                       burst_seq=res.burst_seq, anchor=res.anchor)
-    lib().tgpu_sync_result_free(C.byref(res))
     return out
 
 

@@ -158,20 +158,24 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 
 #define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
-int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_off, const uint8_t *slot_type,
-		   const uint32_t *slot_chan, uint32_t nchan, const uint32_t *chan_code)
+/* the three per-slot inputs are read through byte strides so that separate arrays (tgpu_plan_load) and
+ * the slot table of the stream synchroniser (tgpu_plan_load_slots) share one implementation */
+#define SLOT_OFF(i)  (*(const uint64_t *)(off_b + (size_t)(i) * off_st))
+#define SLOT_TYPE(i) (*(type_b + (size_t)(i) * type_st))
+#define SLOT_CHAN(i) (*(const uint32_t *)(chan_b + (size_t)(i) * chan_st))
+static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t *off_b, size_t off_st,
+			     const uint8_t *type_b, size_t type_st, const uint8_t *chan_b, size_t chan_st,
+			     uint32_t nchan, const uint32_t *chan_code)
 {
-	if (!p || (nslots && (!slot_off || !slot_type || !slot_chan)) || !nchan || !chan_code)
-		return TGPU_EINVAL;
 	if (nslots > p->max_slots || nchan > p->max_chan)
 		return TGPU_ECAPACITY;
 	/* pass 1: validate and count, so that the upload arena can be laid out exactly */
 	uint32_t nsb = 0, n216 = 0, n432 = 0, prev = 0;
 	for (uint32_t i = 0; i < nslots; i++) {
-		if (slot_chan[i] >= nchan || slot_chan[i] < prev || (slot_off[i] >> 56))
+		if (SLOT_CHAN(i) >= nchan || SLOT_CHAN(i) < prev || (SLOT_OFF(i) >> 56))
 			return TGPU_EINVAL;
-		prev = slot_chan[i];
-		const uint8_t t = slot_type[i];
+		prev = SLOT_CHAN(i);
+		const uint8_t t = SLOT_TYPE(i);
 		nsb += t == TETRA_TRAIN_SYNC;
 		n216 += (t == TETRA_TRAIN_SYNC) + 2 * (t == TETRA_TRAIN_NORM_2);
 		n432 += t == TETRA_TRAIN_NORM_1;
@@ -200,11 +204,11 @@ int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_of
 		p->h_last_slot_of_chan[c] = 0xffffffffu;
 	uint32_t isb = 0, i216 = 0, i432 = 0;
 	for (uint32_t i = 0; i < nslots; i++) {
-		const uint8_t t = slot_type[i];
-		const uint32_t ch = slot_chan[i];
+		const uint8_t t = SLOT_TYPE(i);
+		const uint32_t ch = SLOT_CHAN(i);
 		p->h_last_slot_of_chan[ch] = i;
 		/* descriptor = offset | type << 56 (one scalar load per slot in the front kernel) */
-		h_desc[i] = slot_off[i] | ((uint64_t)t << 56);
+		h_desc[i] = SLOT_OFF(i) | ((uint64_t)t << 56);
 		h_chan[i] = ch;
 		h_sbord[i] = -1;
 		switch (t) {
@@ -246,6 +250,27 @@ int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_of
 	p->n432 = n432;
 	p->loaded = 1;
 	return TGPU_OK;
+}
+#undef SLOT_OFF
+#undef SLOT_TYPE
+#undef SLOT_CHAN
+
+int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_off, const uint8_t *slot_type,
+		   const uint32_t *slot_chan, uint32_t nchan, const uint32_t *chan_code)
+{
+	if (!p || (nslots && (!slot_off || !slot_type || !slot_chan)) || !nchan || !chan_code)
+		return TGPU_EINVAL;
+	return plan_load_strided(p, nslots, (const uint8_t *)slot_off, 8, slot_type, 1, (const uint8_t *)slot_chan, 4,
+				 nchan, chan_code);
+}
+
+int tgpu_plan_load_slots(struct tgpu_plan *p, uint32_t nslots, const struct tgpu_sync_slot *slots, uint32_t scramb_init)
+{
+	static const uint32_t chan0 = 0;
+	if (!p || (nslots && !slots))
+		return TGPU_EINVAL;
+	return plan_load_strided(p, nslots, (const uint8_t *)&slots->off, sizeof(*slots), &slots->type, sizeof(*slots),
+				 (const uint8_t *)&chan0, 0, 1, &scramb_init);
 }
 
 struct tgpu_prof {

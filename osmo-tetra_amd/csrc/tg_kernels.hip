@@ -543,7 +543,7 @@ __device__ __forceinline__ uint32_t hist_byte(uint32_t w0, uint32_t w1, uint32_t
  *          packed bits, 32-bit correlation metrics (tg_svit_*), history in VGPRs as in mode 1.
  */
 template <int KIND, int HMODE>
-__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (HMODE == 2) ? (KIND == TG_KIND_432 ? 1 : 2) : (KIND == TG_KIND_432 ? 2 : 4))
+__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (HMODE == 2) ? (KIND == TG_KIND_432 ? 1 : 2) : (KIND == TG_KIND_432 ? 3 : 4))
 void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,

@@ -181,6 +181,12 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 	memset(out, 0, sizeof(*out));
 	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, out, 0, 0, ysum, anchor, ysum ? ncls : 0 };
 	int rc;
+	if (ncls) {	/* nearly every grid slot is delivered: reserve once instead of growing by doubling */
+		out->slots = malloc(((size_t)ncls + 16) * sizeof(*out->slots));
+		if (!out->slots)
+			return TGPU_ENOMEM;
+		w.cap_slots = ncls + 16;
+	}
 
 	uint64_t bs = 0;	/* bitbuf_start_bitnum */
 	uint64_t k = 0;		/* index of the last call that has run */
@@ -215,7 +221,18 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 				while (clean_to <= last) {
 					const uint64_t p = next_sync_seq(&w, clean_to, last);
 					if (p == UINT64_MAX) {
-						clean_to = last + 1;
+						/* nothing in this buffer: jump to the call that first sees the next sequence
+						 * of the stream (the calls in between would find nothing either) */
+						const uint64_t pn = next_sync_seq(&w, last + 1, UINT64_MAX - 64);
+						if (pn == UINT64_MAX) {
+							kk = w.ncalls;	/* no SYNC sequence left: UNLOCKED to the end */
+							clean_to = w.len;
+							break;
+						}
+						clean_to = pn;
+						const uint64_t kn = call_reaching(&w, pn + 38);
+						if (kn > kk + 1)
+							kk = kn - 1;	/* the for-loop's increment makes it kn */
 						break;
 					}
 					if (p - b >= 21) {

@@ -456,13 +456,23 @@ def test_config3_stream_end_to_end(T, eng, seed):
     n = len(slots)
     ch = T.Channel(eng, batch_slots=1)
     plan = T.Plan(eng, max(n, 1), 1)
+    ch0_code = ch.scramb_init()
     plan.load(np.array([x[0] for x in slots], np.uint64), np.array([x[1] for x in slots], np.uint8), None,
-              np.array([ch.scramb_init()], np.uint32))
+              np.array([ch0_code], np.uint32))
     d_rec = torch.zeros(max(n, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
     plan.execute(d.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    ch.deliver(slots, s, d_rec.cpu().numpy())
+    rec_a = d_rec.cpu().numpy().copy()
+    ch.deliver(slots, s, rec_a)
     assert_same_records(ch.records, want)
+    # the same batch loaded straight from the slot table, without the per-burst events
+    res2 = T.sync_stream(eng, s, d.data_ptr(), burst_events=False)
+    assert res2["slots"] == slots and [e for e in wev if e[0] != 2] == res2["events"]
+    d_rec.zero_()
+    plan.load_slots(res2, ch0_code)
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (d_rec.cpu().numpy() == rec_a).all()
     plan.close()
     ch.close()
 
