@@ -76,7 +76,21 @@ TG_HD uint32_t tg_brev4(uint32_t x)
 
 struct tg_vit_state {
 	tg_us2 Z[8];
+	uint32_t LP, LQ;	/* branch-metric tables of the two-bit steps, kept in VGPRs (see tg_step_a) */
 };
+
+/* keep a value in a VGPR and hide how it was computed from the optimiser */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TG_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define TG_OPAQUE(x) ((void)0)
+#endif
+
+/* 2-bit entries x(f), f = 0..3, at bits 8 + 2f (low half) and 24 + 2f (high half) of a table word:
+ * (table >> 2f) & 0x03000300 = (lo(f), hi(f)) << 8 */
+#define TG_LUTB(x0, x1, x2, x3) ((uint32_t)((x0) | ((x1) << 2) | ((x2) << 4) | ((x3) << 6)))
+#define TG_LUT(lo, hi) (((lo) << 8) | ((hi) << 24))
+#define TG_KMASK 0x03000300u
 
 TG_HD void tg_vit_init(tg_vit_state &v)
 {
@@ -84,6 +98,11 @@ TG_HD void tg_vit_init(tg_vit_state &v)
 #pragma unroll
 	for (int k = 1; k < 8; k++)
 		v.Z[k] = tg_as_us2(TG_VIT_INF | (TG_VIT_INF << 16));
+	/* f = r1 | r2 << 1:  s = r1 + r2 = 0,1,1,2   u = 1 - r1 + r2 = 1,0,2,1 */
+	v.LP = TG_LUT(TG_LUTB(0, 1, 1, 2), TG_LUTB(2, 1, 1, 0));	/* (s, 2 - s) */
+	v.LQ = TG_LUT(TG_LUTB(1, 0, 2, 1), TG_LUTB(1, 2, 0, 1));	/* (u, 2 - u) */
+	TG_OPAQUE(v.LP);
+	TG_OPAQUE(v.LQ);
 }
 
 /*
@@ -123,27 +142,51 @@ TG_HD void tg_acs(tg_vit_state &v, tg_us2 P, tg_us2 Pt, tg_us2 Q, tg_us2 Qt)
 #define TG_SW_B 0xaau	/* j = 1,3,5,7 */
 #define TG_Q_B  0x00u
 
-/* step with two received bits r1 (g1), r2 (g2); f = r1 | r2<<1; tie2 = (1<<i) * 0x10001 */
-TG_HD void tg_step_a(tg_vit_state &v, uint32_t f, uint32_t tie2)
+/* step with two received bits r1 (g1), r2 (g2); t2 = 2 f, f = r1 | r2<<1; tie2 = (1<<i) * 0x10001.
+ * P = (s, 2-s) << 8 (mismatches vs (0,0)), Q = (u, 2-u) << 8 (vs (1,0)): two table shifts + two masks */
+TG_HD void tg_step_a(tg_vit_state &v, uint32_t t2, uint32_t tie2)
 {
-	const uint32_t s = (f & 1) + (f >> 1);			/* mismatches vs (0,0) */
-	const uint32_t u = ((f & 1) ^ 1) + (f >> 1);		/* mismatches vs (1,0) */
-	const uint32_t P = s * 0xff000100u + 0x02000000u;	/* (s, 2-s) << 8 */
-	const uint32_t Q = u * 0xff000100u + 0x02000000u;
+	const uint32_t P = (v.LP >> t2) & TG_KMASK;
+	const uint32_t Q = (v.LQ >> t2) & TG_KMASK;
 	tg_acs<TG_SW_A, TG_Q_A>(v, tg_as_us2(P), tg_as_us2(P + tie2), tg_as_us2(Q), tg_as_us2(Q + tie2));
 }
 
-/* step with one received bit r (g1) */
-TG_HD void tg_step_b(tg_vit_state &v, uint32_t r, uint32_t tie2)
+/* step with one received bit r (g1); rm = r ? ~0 : 0 (a one-bit signed field extract).
+ * P = (r, 1-r) << 8 = r ? 0x00000100 : 0x01000000 */
+TG_HD void tg_step_b(tg_vit_state &v, uint32_t rm, uint32_t tie2)
 {
-	const uint32_t P = r * 0xff000100u + 0x01000000u;	/* (r, 1-r) << 8 */
+	const uint32_t P = (rm & 0x01000100u) ^ 0x01000000u;
 	tg_acs<TG_SW_B, TG_Q_B>(v, tg_as_us2(P), tg_as_us2(P + tie2), tg_as_us2(P), tg_as_us2(P + tie2));
 }
 
-/* flush step: nothing received */
-TG_HD void tg_step_flush(tg_vit_state &v, uint32_t tie2)
+/* bit k of x as a mask (v_bfe_i32) */
+TG_HD uint32_t tg_bitmask(uint32_t x, int k)
 {
-	tg_acs<0, 0>(v, tg_as_us2(0), tg_as_us2(tie2), tg_as_us2(0), tg_as_us2(tie2));
+	return (uint32_t)((int32_t)(x << (31 - k)) >> 31);
+}
+
+/*
+ * The K-1 = 4 flush steps (steps 4..7 of the last block; nothing received, all branch metrics 0) as a
+ * min tree.  A flush step gives new[2j] = new[2j+1] = min(pm[j], pm[j+8] + tie), so after it only 8
+ * distinct values exist, then 4, 2, 1: the traceback starts in state 0, and state 0 after the last
+ * step is
+ *     m1[j] = min(pm[j], pm[j+8] + T4)   m2[a] = min(m1[a], m1[a+4] + T5)   m3[b] = min(m2[b], m2[b+2] + T6)
+ *     final = min(m3[0], m3[1] + T7)
+ * with exactly the candidates, tie bits and order of the four full steps.  8 adds + 8 mins instead of
+ * 4 x 24; only Z[0]'s low half (state 0) is meaningful afterwards.
+ */
+TG_HD void tg_flush4(tg_vit_state &v)
+{
+	const tg_us2 T4 = tg_as_us2(0x00100010u), T5 = tg_as_us2(0x00200020u);
+	const tg_us2 T6 = tg_as_us2(0x00400040u), T7 = tg_as_us2(0x00800080u);
+	tg_us2 M[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		M[k] = tg_min(v.Z[k], v.Z[k + 4] + T4);		/* (m1[2k], m1[2k+1]) */
+	const tg_us2 N0 = tg_min(M[0], M[2] + T5);		/* (m2[0], m2[1]) */
+	const tg_us2 N1 = tg_min(M[1], M[3] + T5);		/* (m2[2], m2[3]) */
+	const tg_us2 R = tg_min(N0, N1 + T6);			/* (m3[0], m3[1]) */
+	v.Z[0] = tg_min(R, (R + T7).yx);			/* low half: state 0 */
 }
 
 TG_HD void tg_vit_clean(tg_vit_state &v)
@@ -156,10 +199,10 @@ TG_HD void tg_vit_clean(tg_vit_state &v)
 /* the 4 lead-in steps: 6 received bits in bits 0..5 of 'six' */
 TG_HD void tg_vit_leadin(tg_vit_state &v, uint32_t six)
 {
-	tg_step_a(v, six & 3, 0x00010001u);
-	tg_step_b(v, (six >> 2) & 1, 0x00020002u);
-	tg_step_a(v, (six >> 3) & 3, 0x00040004u);
-	tg_step_b(v, (six >> 5) & 1, 0x00080008u);
+	tg_step_a(v, (six << 1) & 6, 0x00010001u);
+	tg_step_b(v, tg_bitmask(six, 2), 0x00020002u);
+	tg_step_a(v, (six >> 2) & 6, 0x00040004u);
+	tg_step_b(v, tg_bitmask(six, 5), 0x00080008u);
 	tg_vit_clean(v);
 }
 
@@ -168,20 +211,17 @@ TG_HD void tg_vit_leadin(tg_vit_state &v, uint32_t six)
 template <bool LAST>
 TG_HD void tg_vit_block(tg_vit_state &v, uint32_t tw, uint32_t h[4])
 {
-	tg_step_a(v, tw & 3, 0x00010001u);
-	tg_step_b(v, (tw >> 2) & 1, 0x00020002u);
-	tg_step_a(v, (tw >> 3) & 3, 0x00040004u);
-	tg_step_b(v, (tw >> 5) & 1, 0x00080008u);
+	tg_step_a(v, (tw << 1) & 6, 0x00010001u);
+	tg_step_b(v, tg_bitmask(tw, 2), 0x00020002u);
+	tg_step_a(v, (tw >> 2) & 6, 0x00040004u);
+	tg_step_b(v, tg_bitmask(tw, 5), 0x00080008u);
 	if (LAST) {
-		tg_step_flush(v, 0x00100010u);
-		tg_step_flush(v, 0x00200020u);
-		tg_step_flush(v, 0x00400040u);
-		tg_step_flush(v, 0x00800080u);
+		tg_flush4(v);
 	} else {
-		tg_step_a(v, (tw >> 6) & 3, 0x00100010u);
-		tg_step_b(v, (tw >> 8) & 1, 0x00200020u);
-		tg_step_a(v, (tw >> 9) & 3, 0x00400040u);
-		tg_step_b(v, (tw >> 11) & 1, 0x00800080u);
+		tg_step_a(v, (tw >> 5) & 6, 0x00100010u);
+		tg_step_b(v, tg_bitmask(tw, 8), 0x00200020u);
+		tg_step_a(v, (tw >> 8) & 6, 0x00400040u);
+		tg_step_b(v, tg_bitmask(tw, 11), 0x00800080u);
 	}
 #pragma unroll
 	for (int d = 0; d < 4; d++)
