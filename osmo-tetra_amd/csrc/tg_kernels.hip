@@ -46,8 +46,8 @@ __constant__ tg_const_tables c_tab;
  *      them: lanes 0..31 form one packed word, lanes 32..63 the next, and v_writelane drops
  *      the two dwords into lanes 2r and 2r+1 of the output register;
  *   3. the 80-byte packed slot goes out as one coalesced store.
- * Two slots are kept in flight per wave (dwords of slot i+2 are requested while slot i is
- * gathered).  LDS operations of one wave execute in order: no barrier between the stages.
+ * Three slots are kept in flight per wave (the dwords of slot i+3 are requested as soon as slot i
+ * is parked in LDS).  LDS operations of one wave execute in order: no barrier between the stages.
  */
 typedef uint32_t __attribute__((aligned(1))) tg_u32_unaligned;
 typedef uint16_t __attribute__((aligned(1))) tg_u16_unaligned;
@@ -55,11 +55,10 @@ typedef uint16_t __attribute__((aligned(1))) tg_u16_unaligned;
 __device__ __forceinline__ void front_fetch(const uint8_t *base, uint32_t lane, uint32_t &d0, uint32_t &d1)
 {
 	d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
-	/* bytes 256..509: the last dword would read 2 bytes past the slot */
-	if (lane < 63)
-		d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
-	else
-		d1 = *(const tg_u16_unaligned *)(base + 508);
+	/* bytes 256..509: lane 63's dword would read 2 bytes past the slot, so it reads bytes 506..509
+	 * instead (fixed up in front_park).  One unconditional load per half: hipcc's s_waitcnt insertion
+	 * counts only loads it knows were issued, and a load under an exec branch is not one of them. */
+	d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane - (lane == 63 ? 2 : 0));
 }
 
 __device__ __forceinline__ uint32_t front_gather(const uint8_t *lds0, const uint32_t (&addr)[10], uint32_t &nonbin_acc)
@@ -93,13 +92,19 @@ __device__ __forceinline__ uint32_t front_swz(uint32_t a)
 	return a ^ (((a >> 7) & 31u) << 2);
 }
 
-__device__ __forceinline__ void front_process(uint32_t slot, uint32_t type, uint32_t d0, uint32_t d1, uint32_t lane,
-					       uint32_t *mine, const uint8_t *lds0, const uint32_t (&a_n1)[10],
+/* stage 1 of a slot: its two dwords go to the wave's LDS window (after this the data registers are free
+ * for the next request); stage 2 (front_process): gather, pack, store */
+__device__ __forceinline__ void front_park(uint32_t *mine, uint32_t lane, uint32_t d0, uint32_t d1)
+{
+	mine[front_swz(4 * lane) >> 2] = d0;
+	mine[front_swz(256 + 4 * lane) >> 2] = (lane == 63) ? (d1 >> 16) : d1;	/* window bytes 510/511 stay zero */
+}
+
+__device__ __forceinline__ void front_process(uint32_t slot, uint32_t type, uint32_t lane,
+					       const uint8_t *lds0, const uint32_t (&a_n1)[10],
 					       const uint32_t (&a_n2)[10], const uint32_t (&a_sb)[10],
 					       uint32_t *__restrict__ packed, uint8_t *__restrict__ rec)
 {
-	mine[front_swz(4 * lane) >> 2] = d0;
-	mine[front_swz(256 + 4 * lane) >> 2] = d1;
 	uint32_t myword = 0, acc = 0;
 	if (type == TG_BURST_NORM_1)
 		myword = front_gather(lds0, a_n1, acc);
@@ -117,8 +122,11 @@ __device__ __forceinline__ void front_process(uint32_t slot, uint32_t type, uint
 		const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
 		myword = type | (flags << 8) | (toff << 16);
 	}
-	if (lane < TG_PACKED_WORDS)
-		packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
+	/* lanes 0..19 store; the others fall outside this 80-byte buffer and are dropped by the range check
+	 * (no exec branch around the store, see front_fetch) */
+	const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)slot * TG_PACKED_WORDS, 0,
+									       TG_PACKED_WORDS * 4, 0x00027000);
+	__builtin_amdgcn_raw_buffer_store_b32(myword, out, lane * 4, 0, 0);
 }
 
 __global__ __launch_bounds__(256)
@@ -166,19 +174,51 @@ void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 		front_fetch(stream + TG_DESC_OFF(dc), lane, c0, c1);
 	}
 
+	/* the descriptor of the slot three sweeps ahead is itself requested one iteration early (dn): its
+	 * scalar load then completes under this iteration's LDS round trip instead of stalling the wave
+	 * right before the data loads that depend on it */
+	uint64_t dn = none;
+	if ((uint64_t)slot + 3ull * nwaves < nslots)
+		dn = slot_desc[slot + 3 * nwaves];
 #define FRONT_STEP(D, R0, R1)										\
 	{												\
 		if (slot >= nslots)									\
 			break;										\
 		const uint32_t type_ = TG_DESC_TYPE(D);							\
-		const uint32_t x0_ = R0, x1_ = R1;							\
-		if (slot + 3 * nwaves < nslots) {							\
-			D = slot_desc[slot + 3 * nwaves];						\
+		front_park(mine, lane, R0, R1);								\
+		if ((uint64_t)slot + 3ull * nwaves < nslots) {						\
+			D = dn;										\
 			front_fetch(stream + TG_DESC_OFF(D), lane, R0, R1);				\
 		}											\
-		front_process(slot, type_, x0_, x1_, lane, mine, lds0, a_n1, a_n2, a_sb, packed, rec);	\
+		if ((uint64_t)slot + 4ull * nwaves < nslots)						\
+			dn = slot_desc[slot + 4 * nwaves];						\
+		front_process(slot, type_, lane, lds0, a_n1, a_n2, a_sb, packed, rec);			\
+		if ((uint64_t)slot + nwaves >= nslots)							\
+			break;										\
 		slot += nwaves;										\
 	}
+	/* main loop: every step has a slot to gather and one to request, nothing is conditional -- the three
+	 * register sets keep their roles across the back edge (no copies), so the s_waitcnt in front of a
+	 * gather covers only that slot's two loads and the younger requests stay in flight.  (With the
+	 * bounds checks inside, hipcc rotated one set through v_mov at the loop latch behind an
+	 * s_waitcnt vmcnt(0): every third slot exposed a full HBM round trip.) */
+#define FRONT_STEP_FULL(D, R0, R1)									\
+	{												\
+		const uint32_t type_ = TG_DESC_TYPE(D);							\
+		front_park(mine, lane, R0, R1);		/* waits for this set's two loads only */	\
+		D = dn;											\
+		front_fetch(stream + TG_DESC_OFF(D), lane, R0, R1);					\
+		dn = slot_desc[(uint64_t)slot + 4ull * nwaves < nslots ? slot + 4 * nwaves : slot];	\
+		front_process(slot, type_, lane, lds0, a_n1, a_n2, a_sb, packed, rec);			\
+		slot += nwaves;										\
+	}
+	while ((uint64_t)slot + 5ull * nwaves < nslots) {
+		FRONT_STEP_FULL(da, a0, a1)
+		FRONT_STEP_FULL(db, b0, b1)
+		FRONT_STEP_FULL(dc, c0, c1)
+	}
+#undef FRONT_STEP_FULL
+	/* tail (at most five slots per wave): the same steps with their bounds checks */
 	for (;;) {
 		FRONT_STEP(da, a0, a1)
 		FRONT_STEP(db, b0, b1)
@@ -472,7 +512,7 @@ void k_front_soft(const int8_t *__restrict__ soft, const uint64_t *__restrict__ 
 		uint32_t d0, d1;
 		front_fetch((const uint8_t *)soft + TG_DESC_OFF(d), lane, d0, d1);
 		mine[lane] = d0;
-		mine[64 + lane] = d1;
+		mine[64 + lane] = (lane == 63) ? (d1 >> 16) : d1;	/* lane 63 fetched bytes 506..509 */
 		if (type == TG_BURST_NORM_1 || type == TG_BURST_NORM_2 || type == TG_BURST_SYNC) {
 			const uint32_t tix = (type == TG_BURST_SYNC) ? 2 : type;
 			const uint16_t *tab = g_soft_tab.src[tix];
@@ -1102,8 +1142,11 @@ extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 	if (!nslots)
 		return 0;
 	uint32_t blocks = (nslots + 3) / 4;
-	if (blocks > 256 * 16)
-		blocks = 256 * 16;
+	uint32_t cap = 256 * 32;	/* measured on MI355X (tools/exp_front_grid.py): 2048 156 us, 4096 154 us, 8192 144 us */
+	if (const char *e = getenv("TGPU_FRONT_BLOCKS"))
+		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
+	if (blocks > cap)
+		blocks = cap;
 	hipLaunchKernelGGL(k_front, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
 			   d_stream, d_slot_desc, nslots, d_packed, d_rec);
 	return (int)hipGetLastError();
