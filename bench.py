@@ -331,7 +331,7 @@ def main():
                      "note": "achieved = SURVEY 8(d) algorithmic bytes of the bursts this kernel decodes / its mean HIP-event "
                              "duration (second pass of the same K steps, one event between stages on the launch stream; the "
                              "timed pass overlaps the two trellis kernels); traffic = PMC bytes per launch from "
-                             "profiles/traffic.json; the trellis kernels are VALU-issue bound (v_pk_* half rate), see DESIGN.md"},
+                             "profiles/traffic.json; the trellis kernels are VALU-issue bound (VALU busy 72 % of the kernel, ~4 cycles per instruction; profiles/r01_config2_rocprofv3.md), see DESIGN.md"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(slots, types)
