@@ -364,6 +364,20 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
 		     uint32_t chunk, uint32_t flags, struct tgpu_sync_result *out, void *hip_stream);
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
 
+/*
+ * The tetra_burst_rx_cb() seam (phy/tetra_burst.c:341-379: void tetra_burst_rx_cb(const uint8_t *burst,
+ * unsigned int len, enum tetra_train_seq type, void *priv)) for a host that keeps the reference's own
+ * tetra_burst_sync.c: hand over the 510 bits of one burst and its training-sequence type; the burst is
+ * queued, decoded with its batch and delivered like a burst found by this library's tetra_burst_sync_in().
+ * tn_steps = tetra_tdma_time_add_tn(&t_phy_state.time, 1) calls since the previous hand-over (the
+ * reference's synchroniser makes one per 510-bit step while LOCKED, phy/tetra_burst_sync.c:113, also for
+ * steps that deliver no burst).  The library keeps t_phy_state.time itself (SYNC PDUs set it, later than in
+ * the reference because decoding is deferred; the delivered tdma_time values are the reference's).
+ * Types other than SYNC / NORM_1 / NORM_2 are ignored like the reference's switch, their steps count.
+ */
+int tgpu_channel_burst_rx(struct tgpu_channel *ch, const uint8_t *burst, unsigned int len,
+			  int /* enum tetra_train_seq */ type, uint32_t tn_steps);
+
 /* Deliver records decoded through the plan API (slot table from tgpu_sync_stream(), h_rec = host copy of
  * the nslots records, h_stream = host copy of the stream) to the channel's callback: the same in-order
  * replay as tgpu_channel_flush().  tgpu_channel_scramb_init() is the carry-in code for tgpu_plan_load(). */

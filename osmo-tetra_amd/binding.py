@@ -105,6 +105,7 @@ def lib():
     L.tgpu_plan_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_plan_destroy.argtypes = [C.c_void_p]
     L.tgpu_plan_load.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p, C.c_uint32, u32p]
+    L.tgpu_channel_burst_rx.argtypes = [C.c_void_p, u8p, C.c_uint, C.c_int, C.c_uint32]
     L.tgpu_plan_load_slots.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(SyncSlot), C.c_uint32]
     L.tgpu_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_plan_final_codes.argtypes = [C.c_void_p, C.c_void_p, u32p]
@@ -477,6 +478,12 @@ class Channel:
         v = C.c_uint32(0)
         _chk(lib().tgpu_channel_scramb_init(self._h, C.byref(v)), "tgpu_channel_scramb_init")
         return v.value
+
+    def burst_rx(self, burst, train_type, tn_steps=1):
+        """the tetra_burst_rx_cb() seam: one 510-bit burst + its training-sequence type"""
+        b = _np_u8(burst)
+        _chk(lib().tgpu_channel_burst_rx(self._h, b.ctypes.data_as(u8p), len(b), int(train_type), int(tn_steps)),
+             "tgpu_channel_burst_rx")
 
     def deliver(self, slots, h_stream, h_rec):
         """slots: list of (off, type, burst_seq, tn_adds) from sync_stream(); h_rec: (n,320) host records"""

@@ -434,6 +434,22 @@ static void queue_burst(struct tgpu_channel *ch, const uint8_t *burst, int type)
 }
 
 /* ------------------------------------------------------------------------- */
+/* the tetra_burst_rx_cb() seam: phy/tetra_burst.c:341-379                     */
+/* ------------------------------------------------------------------------- */
+int tgpu_channel_burst_rx(struct tgpu_channel *ch, const uint8_t *burst, unsigned int len, int type,
+			  uint32_t tn_steps)
+{
+	if (!ch || !burst || len < TG_SLOT_BITS)
+		return TGPU_EINVAL;
+	ch->tn_adds += tn_steps;
+	ch->burst_seq += tn_steps;	/* ordinal of the LOCKED step, as in tetra_burst_sync_in() below */
+	/* NORM_3 / EXT bursts are ignored like the reference's switch (:374-377); their time steps count */
+	if (type == TETRA_TRAIN_SYNC || type == TETRA_TRAIN_NORM_1 || type == TETRA_TRAIN_NORM_2)
+		queue_burst(ch, burst, type);
+	return ch->last_error ? ch->last_error : TGPU_OK;
+}
+
+/* ------------------------------------------------------------------------- */
 /* tetra_burst_sync_in(): phy/tetra_burst_sync.c:54-154                        */
 /* ------------------------------------------------------------------------- */
 int tetra_burst_sync_in(struct tetra_rx_state *trs, uint8_t *bits, unsigned int len)

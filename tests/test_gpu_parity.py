@@ -259,6 +259,39 @@ def test_channel_relock_and_spurious_training_sequence(T, eng):
     ch.close()
 
 
+@pytest.mark.parametrize("batch", [1, 5, 64])
+def test_channel_burst_rx_seam(T, eng, batch):
+    """the tetra_burst_rx_cb() seam: bursts found by a foreign synchroniser (here: the host walk, i.e. what
+    the reference's tetra_burst_sync.c would hand over, with its TDMA step count) decode and deliver exactly
+    like bursts found by the library's own tetra_burst_sync_in()"""
+    stream, _ = synth.frame_stream(seed=23, nframes=5, ber=0.01)
+    s = stream.copy()
+    s[100 + 510 + 510 * 7 + 244 + 5] ^= 1           # one loss of lock in between: steps without a burst
+    want, _ = O.run_rx(s)
+    res = T.sync_walk(s)
+    ch = T.Channel(eng, batch_slots=batch)
+    for off, typ, seq, tn in res["slots"]:
+        ch.burst_rx(s[off:off + 510], typ, tn)
+    ch.flush()
+    assert_same_records(ch.records, want)
+    assert len(want) > 20
+    with pytest.raises(T.TgpuError):
+        ch.burst_rx(s[:100], 0, 1)
+    # a NORM_3 / extension burst is ignored, its time step is not
+    ch2 = T.Channel(eng, batch_slots=4)
+    sl = res["slots"]
+    for i, (off, typ, seq, tn) in enumerate(sl):
+        if i == 3:
+            ch2.burst_rx(s[off:off + 510], 2, tn)    # TETRA_TRAIN_NORM_3
+        else:
+            ch2.burst_rx(s[off:off + 510], typ, tn)
+    ch2.flush()
+    assert sl[3][1] == O.TRAIN_NORM_1
+    assert_same_records(ch2.records, [r for r in want if r["burst_seq"] != sl[3][2]])
+    ch.close()
+    ch2.close()
+
+
 def test_channel_traffic_feedback(T, eng):
     """feedback loops 2/3: the callback (standing in for the upper MAC) flags traffic from the AACH
     and 'block 2 stolen' from block 1; blocks are then dumped / decoded exactly as in the reference"""
