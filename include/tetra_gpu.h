@@ -365,6 +365,15 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
 
 /*
+ * The reference's traffic-channel dump block (lower_mac/tetra_lower_mac.c:213-231, the input format of the
+ * ETSI codec tools): 690 int16 = six frames of marker 0x6b21+i + 114 soft bits (bit 1 -> -127, bit 0 -> +127;
+ * 432 bits in total, the rest 0), made from the descrambled type-4 bits a traffic block is delivered with
+ * (struct tgpu_unitdata.type4 / type4_len).  For a 216-bit half-slot block the reference reads bits 216..431
+ * from an uninitialised local array; here they are bit 0.
+ */
+void tgpu_traffic_block(const uint8_t *type4, unsigned int len, int16_t out[690]);
+
+/*
  * The tetra_burst_rx_cb() seam (phy/tetra_burst.c:341-379: void tetra_burst_rx_cb(const uint8_t *burst,
  * unsigned int len, enum tetra_train_seq type, void *priv)) for a host that keeps the reference's own
  * tetra_burst_sync.c: hand over the 510 bits of one burst and its training-sequence type; the burst is

@@ -694,6 +694,28 @@ void orc_tp_sap_udata_ind(struct orc_rx *rx, int type, int blk_num, const uint8_
 	}
 }
 
+/* lower_mac/tetra_lower_mac.c:213-231: the 690-word block appended to traffic_<usage>_<tsn>.out.
+ * type4[] is a local array there, so for a 216-bit block the words made from bits 216..431 are
+ * whatever the stack held; this restatement takes them as 0 bits (documented deviation from UB). */
+void orc_traffic_block(const uint8_t *type4, unsigned len, int16_t *block)
+{
+	uint8_t t4[432];
+	int i;
+	memset(t4, 0, sizeof(t4));
+	memcpy(t4, type4, len < 432 ? len : 432);
+	memset(block, 0x00, sizeof(int16_t) * 690);
+	for (i = 0; i < 6; i++)
+		block[115 * i] = (int16_t)(0x6b21 + i);
+	for (i = 0; i < 114; i++)
+		block[1 + i] = t4[i] ? -127 : 127;
+	for (i = 0; i < 114; i++)
+		block[116 + i] = t4[114 + i] ? -127 : 127;
+	for (i = 0; i < 114; i++)
+		block[231 + i] = t4[228 + i] ? -127 : 127;
+	for (i = 0; i < 90; i++)
+		block[346 + i] = t4[342 + i] ? -127 : 127;
+}
+
 /* phy/tetra_burst.c:341-379 with the offsets of :31-47 */
 void orc_burst_rx_cb(struct orc_rx *rx, const uint8_t *burst, unsigned len, int type)
 {

@@ -232,6 +232,9 @@ void orc_rx_feed(struct orc_rx *rx, const uint8_t *bits, size_t len, unsigned ch
 void orc_burst_rx_cb(struct orc_rx *rx, const uint8_t *burst, unsigned len, int type);
 void orc_tp_sap_udata_ind(struct orc_rx *rx, int type, int blk_num, const uint8_t *bits, unsigned len);
 
+/* traffic dump block (tetra_lower_mac.c:213-231): 690 int16 from the descrambled type-4 bits of a traffic block */
+void orc_traffic_block(const uint8_t *type4, unsigned len, int16_t *block690);
+
 /* ---- row B: float_to_bits (float_to_bits.c) ---------------------------- */
 void orc_float_to_bits(const float *in, size_t n, uint8_t *out2n, int afc,
 		       float filter_val, float filter_goal, float *filter_state);

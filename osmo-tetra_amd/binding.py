@@ -105,6 +105,8 @@ def lib():
     L.tgpu_plan_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_plan_destroy.argtypes = [C.c_void_p]
     L.tgpu_plan_load.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p, C.c_uint32, u32p]
+    L.tgpu_traffic_block.argtypes = [u8p, C.c_uint, C.POINTER(C.c_int16)]
+    L.tgpu_traffic_block.restype = None
     L.tgpu_channel_burst_rx.argtypes = [C.c_void_p, u8p, C.c_uint, C.c_int, C.c_uint32]
     L.tgpu_plan_load_slots.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(SyncSlot), C.c_uint32]
     L.tgpu_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -378,6 +380,14 @@ def _sync_result_to_py(res):
     ea = grab(res.events, res.nevents, EVENT_DTYPE)
     out = SyncOutcome(slot_arr=sa, event_arr=ea, final_state=res.final_state, tail_tn_adds=res.tail_tn_adds,
                       burst_seq=res.burst_seq, anchor=res.anchor)
+    return out
+
+
+def traffic_block(type4):
+    """tgpu_traffic_block: the reference's 690-word traffic dump block from descrambled type-4 bits"""
+    t = _np_u8(type4)
+    out = np.zeros(690, np.int16)
+    lib().tgpu_traffic_block(t.ctypes.data_as(u8p), len(t), out.ctypes.data_as(C.POINTER(C.c_int16)))
     return out
 
 

@@ -434,6 +434,26 @@ static void queue_burst(struct tgpu_channel *ch, const uint8_t *burst, int type)
 }
 
 /* ------------------------------------------------------------------------- */
+/* traffic dump block: lower_mac/tetra_lower_mac.c:213-231                     */
+/* ------------------------------------------------------------------------- */
+void tgpu_traffic_block(const uint8_t *type4, unsigned int len, int16_t out[690])
+{
+	/* six 115-word frames: marker 0x6b21 + i, then 114 soft bits (the last frame carries 90);
+	 * bit 1 -> -127, bit 0 -> +127; everything else 0 */
+	static const uint16_t first[4] = { 1, 116, 231, 346 }, from[4] = { 0, 114, 228, 342 }, count[4] = { 114, 114, 114, 90 };
+	memset(out, 0, 690 * sizeof(int16_t));
+	for (int i = 0; i < 6; i++)
+		out[115 * i] = (int16_t)(0x6b21 + i);
+	for (int f = 0; f < 4; f++)
+		for (unsigned i = 0; i < count[f]; i++) {
+			const unsigned k = from[f] + i;
+			/* a 216-bit half-slot block leaves bits 216..431 unwritten in the reference (its type4[] is an
+			 * uninitialised local there); they are emitted as bit 0 */
+			out[first[f] + i] = (k < len && type4[k]) ? -127 : 127;
+		}
+}
+
+/* ------------------------------------------------------------------------- */
 /* the tetra_burst_rx_cb() seam: phy/tetra_burst.c:341-379                     */
 /* ------------------------------------------------------------------------- */
 int tgpu_channel_burst_rx(struct tgpu_channel *ch, const uint8_t *burst, unsigned int len, int type,

@@ -272,6 +272,13 @@ def decode_block(t, type5, scramb_init, use_acc=0):
             np.frombuffer(res.type2, np.uint8, BLK[t][1]).copy())
 
 
+def traffic_block(type4):
+    t = np.ascontiguousarray(type4, np.uint8)
+    out = np.zeros(690, np.int16)
+    lib().orc_traffic_block(_p(t), len(t), out.ctypes.data_as(C.POINTER(C.c_int16)))
+    return out
+
+
 def float_to_soft(phi):
     phi = np.ascontiguousarray(phi, np.float32)
     out = np.zeros(2 * len(phi), np.int8)

@@ -155,3 +155,18 @@ def test_soft_definition_consistent_with_hard_slicer():
     phi = (rng.choice([-3, -1, 1, 3], 5000) + rng.normal(0, 0.8, 5000)).astype(np.float32)
     phi = phi[(np.abs(phi) > 0.02) & (np.abs(np.abs(phi) - 2) > 0.02)]
     assert ((O.float_to_soft(phi) < 0).astype(np.uint8) == O.float_to_bits(phi)).all()
+
+
+def test_traffic_dump_block_format():
+    """tgpu_traffic_block == the oracle's restatement of tetra_lower_mac.c:213-231; structure of the block
+    (six 115-word frames, markers 0x6b21+i, +-127 soft bits, 432 bits used, tail zero)"""
+    rng = np.random.default_rng(9)
+    for n in (432, 216):
+        t4 = rng.integers(0, 2, n).astype(np.uint8)
+        got = T.traffic_block(t4)
+        assert got.tolist() == O.traffic_block(t4).tolist()
+        assert [int(got[115 * i]) for i in range(6)] == [0x6b21 + i for i in range(6)]
+        body = np.concatenate([got[1:115], got[116:230], got[231:345], got[346:436]])
+        full = np.concatenate([t4, np.zeros(432 - n, np.uint8)])
+        assert (body == np.where(full == 1, -127, 127)).all()
+        assert not got[436:460].any() and not got[461:575].any() and not got[576:].any()
