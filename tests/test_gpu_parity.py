@@ -685,3 +685,53 @@ def test_config4_64_channels_in_8_shards(T, eng):
         exp = [(r["burst_seq"], r["type"], r["blk_num"], r["crc_ok"], r["crc"], r["type1"]) for r in want]
         assert got == exp, c
     assert pos == len(wire)
+
+
+def test_slot_offsets_beyond_4_gib(T, eng):
+    """maximum sizes: slot offsets are 56-bit; slots parked above the 4 GiB mark of one device buffer decode
+    like the same slots at offset 0 (64-bit address arithmetic in the front end)"""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 6 * 2**30:
+        pytest.skip("needs 6 GiB of free HBM")
+    n = 64
+    rng = np.random.default_rng(77)
+    ty = rng.choice([O.TRAIN_NORM_1, O.TRAIN_NORM_2, O.TRAIN_SYNC], n).astype(np.uint8)
+    slots = T.synth_slots(ty, seed=5, scramb_init=0, ber=0.02)
+    big = torch.zeros(5 * 2**30, dtype=torch.uint8, device="cuda")
+    base = 4 * 2**30 + 12345
+    offs = base + np.arange(n, dtype=np.uint64) * 1021         # ragged, unaligned
+    flat = torch.from_numpy(slots)
+    for i in range(n):
+        big[int(offs[i]):int(offs[i]) + 510] = flat[i].cuda()
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(offs, ty)
+    plan.execute(big.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rec_hi = d_rec.cpu().numpy().reshape(n, T.REC_BYTES).copy()
+    plan.close()
+    del big
+    rec_lo, _, _ = run_plan(T, eng, slots, ty)
+    assert (rec_hi == rec_lo).all()
+    with pytest.raises(T.TgpuError):
+        T.Plan(eng, 1, 1).load(np.array([1 << 56], np.uint64), ty[:1])
+
+
+def test_sync_stream_that_never_locks(T, eng):
+    """a stream without any SYNC training sequence: no GPU classification is launched, no slots, the events
+    are the oracle's (none)"""
+    import torch
+    rng = np.random.default_rng(3)
+    s = rng.integers(0, 2, 20000).astype(np.uint8)
+    want, wev = O.run_rx(s)
+    assert not want
+    d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+    res = T.sync_stream(eng, s, d.data_ptr())
+    assert res["slots"] == [] and res["events"] == wev
+    plan = T.Plan(eng, 4, 1)
+    plan.load_slots(res, 0)
+    d_rec = torch.zeros(4 * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan.execute(d.data_ptr(), d_rec.data_ptr())
+    torch.cuda.synchronize()
+    plan.close()
