@@ -357,11 +357,29 @@ struct tgpu_sync_result {
 	uint32_t tail_tn_adds;	/* time steps after the last delivered burst */
 	uint32_t burst_seq;	/* LOCKED bursts seen in total */
 	uint64_t anchor;	/* start of the slot grid the GPU classified */
+	/* grid mode (TGPU_SYNC_GRID / tgpu_sync_stream_grid): no slot table; bit g of grid_bits = the burst at
+	 * anchor + 510 g is delivered; nslots = bits set; noffgrid = delivered bursts that are not grid slots
+	 * (possible after a re-lock onto a shifted grid): if != 0 the caller falls back to tgpu_sync_stream() */
+	uint32_t *grid_bits;
+	uint32_t ngrid;
+	uint32_t noffgrid;
 };
 
 #define TGPU_SYNC_NO_BURST_EVENTS 1u	/* do not record one TGPU_EV_BURST per locked burst (throughput runs) */
+#define TGPU_SYNC_GRID 2u		/* tgpu_sync_walk(): bitmap over the classified grid instead of a slot table */
 int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uint8_t *d_stream, uint64_t len,
 		     uint32_t chunk, uint32_t flags, struct tgpu_sync_result *out, void *hip_stream);
+/*
+ * The same synchroniser feeding a plan without a host-built slot table: the classification pass packs every
+ * grid slot into the plan's buffer, the host walk marks the delivered ones, and the plan's per-slot arrays and
+ * item lists are built on the device.  Afterwards tgpu_plan_execute(plan, d_stream, d_rec, ...) decodes them:
+ * record g (d_rec + 320 g, d_rec sized for out->ngrid records) belongs to the burst at out->anchor + 510 g and
+ * is valid iff bit g of out->grid_bits is set.  scramb_init: the channel's code before its first slot.
+ * plan: capacity >= (len - anchor) / 510 slots.  If out->noffgrid != 0 the plan is NOT loaded.
+ */
+int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream,
+			  const uint8_t *d_stream, uint64_t len, uint32_t chunk, uint32_t flags, uint32_t scramb_init,
+			  struct tgpu_sync_result *out, void *hip_stream);
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
 
 /*

@@ -64,7 +64,8 @@ class SyncEventRec(C.Structure):
 class SyncResult(C.Structure):
     _fields_ = [("nslots", C.c_uint32), ("slots", C.POINTER(SyncSlot)), ("nevents", C.c_uint32),
                 ("events", C.POINTER(SyncEventRec)), ("final_state", C.c_int), ("tail_tn_adds", C.c_uint32),
-                ("burst_seq", C.c_uint32), ("anchor", C.c_uint64)]
+                ("burst_seq", C.c_uint32), ("anchor", C.c_uint64),
+                ("grid_bits", C.POINTER(C.c_uint32)), ("ngrid", C.c_uint32), ("noffgrid", C.c_uint32)]
 
 
 class SynthCfg(C.Structure):
@@ -142,6 +143,8 @@ def lib():
     L.tgpu_sync_walk.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u16p, C.c_uint32, C.c_uint32, C.POINTER(SyncResult)]
     L.tgpu_sync_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, u16p, C.c_void_p]
     L.tgpu_sync_stream.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
+    L.tgpu_sync_stream_grid.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
     L.tgpu_sync_result_free.argtypes = [C.POINTER(SyncResult)]
     L.tgpu_synth_slots.argtypes = [C.POINTER(SynthCfg), u8p, C.c_size_t, u8p, u8p]
     _lib = L
@@ -376,10 +379,14 @@ def _sync_result_to_py(res):
         raw = (C.c_uint8 * (n * dt.itemsize)).from_address(C.addressof(ptr.contents))
         raw._owner = owner                       # the view keeps the C arrays alive
         return np.frombuffer(raw, dt)
-    sa = grab(res.slots, res.nslots, SLOT_DTYPE)
+    grid = bool(res.grid_bits)
+    sa = grab(res.slots, 0 if grid else res.nslots, SLOT_DTYPE)
     ea = grab(res.events, res.nevents, EVENT_DTYPE)
     out = SyncOutcome(slot_arr=sa, event_arr=ea, final_state=res.final_state, tail_tn_adds=res.tail_tn_adds,
-                      burst_seq=res.burst_seq, anchor=res.anchor)
+                      burst_seq=res.burst_seq, anchor=res.anchor, nslots=res.nslots, ngrid=res.ngrid,
+                      noffgrid=res.noffgrid)
+    if grid:
+        out["grid_bits"] = grab(res.grid_bits, (res.ngrid + 31) // 32, np.dtype(np.uint32))
     return out
 
 
@@ -391,7 +398,27 @@ def traffic_block(type4):
     return out
 
 
-def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None):
+def grid_indices(outcome):
+    """grid mode: indices of the delivered grid slots (set bits of grid_bits), ascending"""
+    bits = np.unpackbits(outcome["grid_bits"].view(np.uint8), bitorder="little")[:outcome["ngrid"]]
+    return np.flatnonzero(bits)
+
+
+def sync_stream_grid(engine, plan, h_stream, d_stream_ptr, chunk=64, hip_stream=0, burst_events=True, scramb_init=0):
+    """tgpu_sync_stream_grid: classification + host walk (bitmap) + device-built plan lists; the plan is loaded
+    (slot = grid slot) unless outcome['noffgrid'] != 0"""
+    h_stream = _np_u8(h_stream)
+    res = SyncResult()
+    _chk(lib().tgpu_sync_stream_grid(engine._h, plan._h, h_stream.ctypes.data_as(u8p), C.c_void_p(d_stream_ptr),
+                                     len(h_stream), chunk, 0 if burst_events else 1, scramb_init, C.byref(res),
+                                     C.c_void_p(hip_stream)), "tgpu_sync_stream_grid")
+    out = _sync_result_to_py(res)
+    if not out["noffgrid"] and out["ngrid"]:
+        plan.nslots, plan.nchan = out["ngrid"], 1
+    return out
+
+
+def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None, grid=False):
     """host half of the stream synchroniser (tgpu_sync_walk); cls=None: every slot settled on the bytes,
     ysum=None: re-lock searches scan the bytes"""
     stream = _np_u8(stream)
@@ -404,7 +431,8 @@ def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None
     _chk(lib().tgpu_sync_walk(stream.ctypes.data_as(u8p), len(stream), chunk, anchor,
                               cls.ctypes.data_as(u32p) if cls is not None else None,
                               ysum.ctypes.data_as(u16p) if ysum is not None else None,
-                              len(cls) if cls is not None else 0, 0 if burst_events else 1, C.byref(res)), "tgpu_sync_walk")
+                              len(cls) if cls is not None else 0, (0 if burst_events else 1) | (2 if grid else 0),
+                              C.byref(res)), "tgpu_sync_walk")
     return _sync_result_to_py(res)
 
 

@@ -47,6 +47,8 @@ struct tgpu_plan {
 	unsigned long long *d_block_tmp;
 	uint8_t *d_wire;	/* caller-owned, optional */
 	uint32_t *d_softarea;	/* max_slots * 512 B, allocated on the first soft execute */
+	uint32_t *d_grid;	/* stream mode: classification words + SYNC summaries, max_slots * 6 B, allocated on first use */
+	int packed_ready;	/* stream mode: d_packed was filled by k_front_stream (slot = grid slot), k_front is skipped */
 	hipStream_t side;	/* k_vit<216> and k_vit<432> are independent: they run side by side */
 	hipEvent_t ev_fork, ev_join;
 	uint32_t *h_last_slot_of_chan;
@@ -146,7 +148,7 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	void *d[] = { p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
-		      p->d_block_tmp, p->d_softarea };
+		      p->d_block_tmp, p->d_softarea, p->d_grid };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
 			(void)hipFree(d[i]);
@@ -243,6 +245,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 		HCHK(hipDeviceSynchronize());
 		p->static_masks = 1;
 	}
+	p->packed_ready = 0;
 	p->nslots = nslots;
 	p->nchan = nchan;
 	p->nsb = nsb;
@@ -254,6 +257,76 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 #undef SLOT_OFF
 #undef SLOT_TYPE
 #undef SLOT_CHAN
+
+/* ---- stream mode (tg_stream.c): slot i of the plan = grid slot i of the classified stream ---- */
+int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packed, uint32_t **d_cls, uint16_t **d_ysum)
+{
+	if (!p || !ngrid)
+		return TGPU_EINVAL;
+	if (ngrid > p->max_slots)
+		return TGPU_ECAPACITY;
+	if (!p->d_grid) {
+		hipError_t e = hipMalloc((void **)&p->d_grid, (size_t)p->max_slots * 6 + 16);
+		if (e != hipSuccess)
+			return (int)e;
+	}
+	p->loaded = 0;
+	*d_packed = p->d_packed;
+	*d_cls = p->d_grid;
+	*d_ysum = (uint16_t *)(p->d_grid + ngrid);
+	return TGPU_OK;
+}
+
+int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t scramb_init, void *stream)
+{
+	if (!p || !ngrid || !h_bits || !p->d_grid)
+		return TGPU_EINVAL;
+	if (ngrid > p->max_slots)
+		return TGPU_ECAPACITY;
+	const size_t nwords = ((size_t)ngrid + 31) / 32, nblk = ((size_t)ngrid + 1023) / 1024;
+	size_t o = 0;
+#define UP_AT(ptr, type, count) do { ptr = (type *)(p->d_up + o); \
+		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
+	uint32_t *d_bits, *d_blk;
+	UP_AT(p->d_chan_code, uint32_t, 1);
+	UP_AT(d_bits, uint32_t, nwords);
+	const size_t upload = o;
+	UP_AT(p->d_slot_chan, uint32_t, ngrid);
+	UP_AT(p->d_slot_sbord, int32_t, ngrid);
+	UP_AT(p->d_list_sb, uint32_t, ngrid);
+	UP_AT(p->d_list_216, uint32_t, 2 * (size_t)ngrid);
+	UP_AT(p->d_list_432, uint32_t, ngrid);
+	UP_AT(d_blk, uint32_t, 3 * (nblk + 1));
+#undef UP_AT
+	p->d_slot_off = NULL;
+	if (o > p->up_bytes)
+		return TGPU_ECAPACITY;
+	*(uint32_t *)p->h_up = scramb_init;
+	memcpy(p->h_up + ((uint8_t *)d_bits - p->d_up), h_bits, nwords * 4);
+	HCHK(hipMemcpyAsync(p->d_up, p->h_up, upload, hipMemcpyHostToDevice, (hipStream_t)stream));
+	int rc = tgk_grid_lists(p->d_grid, d_bits, ngrid, d_blk, p->d_slot_chan, p->d_slot_sbord, p->d_list_sb,
+				p->d_list_216, p->d_list_432, stream);
+	if (rc)
+		return rc;
+	uint32_t tot[3];
+	HCHK(hipMemcpyAsync(tot, d_blk + 3 * nblk, sizeof(tot), hipMemcpyDeviceToHost, (hipStream_t)stream));
+	HCHK(hipStreamSynchronize((hipStream_t)stream));
+	p->h_last_slot_of_chan[0] = 0xffffffffu;
+	for (size_t wd = nwords; wd-- > 0;)
+		if (h_bits[wd]) {
+			p->h_last_slot_of_chan[0] = (uint32_t)(wd * 32 + 31 - (uint32_t)__builtin_clz(h_bits[wd]));
+			break;
+		}
+	p->static_masks = 0;
+	p->packed_ready = 1;
+	p->nslots = ngrid;
+	p->nchan = 1;
+	p->nsb = tot[0];
+	p->n216 = tot[1];
+	p->n432 = tot[2];
+	p->loaded = 1;
+	return TGPU_OK;
+}
 
 int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_off, const uint8_t *slot_type,
 		   const uint32_t *slot_chan, uint32_t nchan, const uint32_t *chan_code)
@@ -329,7 +402,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 #define MARK(i) do { if (ev) { hipError_t e_ = hipEventRecord(ev[i], (hipStream_t)stream); if (e_ != hipSuccess) return (int)e_; } } while (0)
 	if (!p || !d_stream || !d_rec)
 		return TGPU_EINVAL;
-	if (!p->loaded)
+	if (!p->loaded || (soft && p->packed_ready))
 		return TGPU_ESTATE;
 	MARK(0);
 	if (p->nslots) {
@@ -342,7 +415,8 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 			if ((rc = tgk_front_soft((const int8_t *)d_stream, p->d_slot_off, p->nslots, p->d_softarea, p->d_packed,
 						 d_rec, stream)))
 				return rc;
-		} else if ((rc = tgk_front(d_stream, p->d_slot_off, p->nslots, p->d_packed, d_rec, stream)))
+		} else if (!p->packed_ready &&	/* stream mode: k_front_stream has already packed every grid slot */
+			   (rc = tgk_front(d_stream, p->d_slot_off, p->nslots, p->d_packed, d_rec, stream)))
 			return rc;
 	}
 	MARK(1);

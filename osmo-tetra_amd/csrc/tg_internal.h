@@ -29,6 +29,17 @@ int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uin
 int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
 	      const uint32_t *d_sb_code, uint32_t nsb, uint32_t *d_masks, void *stream);
 
+/* stream mode: per-slot arrays and item lists from classification words + "delivered" bitmap;
+ * d_blk: 3 * (ceil(n / 1024) + 1) words, the totals (sb, 216 items, 432 items) end up at d_blk[3 * nblocks] */
+int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uint32_t n, uint32_t *d_blk,
+		   uint32_t *d_slot_chan, int32_t *d_slot_sbord, uint32_t *d_list_sb, uint32_t *d_list_216,
+		   uint32_t *d_list_432, void *stream);
+
+/* plan internals used by the stream synchroniser (tg_stream.c) */
+struct tgpu_plan;
+int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packed, uint32_t **d_cls, uint16_t **d_ysum);
+int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t scramb_init, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1261,6 +1261,129 @@ extern "C" int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord
 	return (int)hipGetLastError();
 }
 
+/* ------------------------------------------------------------------------- */
+/* stream mode: the plan's per-slot arrays and item lists, built on the device  */
+/* ------------------------------------------------------------------------- */
+/*
+ * Grid slot g is decoded iff the host walk marked it delivered (bit g of 'bits'); its burst type is the
+ * classification word's.  Lists keep slot order (the forward fill of the scrambling code relies on the
+ * SYNC ordinals growing with g): counts per 1024-slot block, exclusive scan over the blocks, emit.
+ * blk[] : 3 words per block (sb, 216-items, 432-items), turned into exclusive bases in place; the three
+ * totals follow at blk[3 * nblocks].
+ */
+#define GRID_BLOCK 1024
+
+__device__ __forceinline__ uint32_t grid_type(const uint32_t *cls, const uint32_t *bits, uint32_t g, uint32_t n)
+{
+	if (g >= n || !((bits[g >> 5] >> (g & 31)) & 1))
+		return TG_BURST_NONE;
+	return cls[g] & 0xff;
+}
+
+__global__ __launch_bounds__(GRID_BLOCK)
+void k_grid_count(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ bits, uint32_t n, uint32_t *__restrict__ blk)
+{
+	__shared__ uint32_t sm[GRID_BLOCK / 64][3];
+	const uint32_t g = blockIdx.x * GRID_BLOCK + threadIdx.x;
+	const uint32_t t = grid_type(cls, bits, g, n);
+	const uint32_t nsb = __builtin_popcountll(__ballot(t == TG_BURST_SYNC));
+	const uint32_t nn2 = __builtin_popcountll(__ballot(t == TG_BURST_NORM_2));
+	const uint32_t nn1 = __builtin_popcountll(__ballot(t == TG_BURST_NORM_1));
+	if ((threadIdx.x & 63) == 0) {
+		sm[threadIdx.x >> 6][0] = nsb;
+		sm[threadIdx.x >> 6][1] = nsb + 2 * nn2;
+		sm[threadIdx.x >> 6][2] = nn1;
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		uint32_t a = 0;
+		for (int w = 0; w < GRID_BLOCK / 64; w++)
+			a += sm[w][threadIdx.x];
+		blk[3 * blockIdx.x + threadIdx.x] = a;
+	}
+}
+
+__global__ __launch_bounds__(64)
+void k_grid_scan(uint32_t *blk, uint32_t nblocks)
+{
+	const uint32_t lane = threadIdx.x;
+	for (int c = 0; c < 3; c++) {
+		uint32_t carry = 0;
+		for (uint32_t base = 0; base < nblocks; base += 64) {
+			const uint32_t i = base + lane;
+			const uint32_t v = (i < nblocks) ? blk[3 * i + c] : 0u;
+			uint32_t inc = v;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t o = __shfl_up(inc, d);
+				if (lane >= (uint32_t)d)
+					inc += o;
+			}
+			if (i < nblocks)
+				blk[3 * i + c] = carry + inc - v;
+			carry += __shfl(inc, 63);
+		}
+		if (lane == 0)
+			blk[3 * nblocks + c] = carry;
+	}
+}
+
+__global__ __launch_bounds__(GRID_BLOCK)
+void k_grid_emit(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ bits, uint32_t n,
+		 const uint32_t *__restrict__ blk, uint32_t *__restrict__ slot_chan, int32_t *__restrict__ slot_sbord,
+		 uint32_t *__restrict__ list_sb, uint32_t *__restrict__ list_216, uint32_t *__restrict__ list_432)
+{
+	__shared__ uint32_t sm[GRID_BLOCK / 64][3];
+	const uint32_t g = blockIdx.x * GRID_BLOCK + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t t = grid_type(cls, bits, g, n);
+	const unsigned long long msb = __ballot(t == TG_BURST_SYNC), mn2 = __ballot(t == TG_BURST_NORM_2);
+	const unsigned long long mn1 = __ballot(t == TG_BURST_NORM_1);
+	const unsigned long long below = (1ull << lane) - 1;
+	if (lane == 0) {
+		sm[w][0] = __builtin_popcountll(msb);
+		sm[w][1] = __builtin_popcountll(msb) + 2 * __builtin_popcountll(mn2);
+		sm[w][2] = __builtin_popcountll(mn1);
+	}
+	__syncthreads();
+	uint32_t bsb = blk[3 * blockIdx.x], b216 = blk[3 * blockIdx.x + 1], b432 = blk[3 * blockIdx.x + 2];
+	for (uint32_t q = 0; q < w; q++) {
+		bsb += sm[q][0];
+		b216 += sm[q][1];
+		b432 += sm[q][2];
+	}
+	const uint32_t psb = bsb + __builtin_popcountll(msb & below);
+	const uint32_t p216 = b216 + __builtin_popcountll(msb & below) + 2 * __builtin_popcountll(mn2 & below);
+	const uint32_t p432 = b432 + __builtin_popcountll(mn1 & below);
+	if (g < n) {
+		slot_chan[g] = 0;
+		slot_sbord[g] = (t == TG_BURST_SYNC) ? (int32_t)psb : -1;
+	}
+	if (t == TG_BURST_SYNC) {
+		list_sb[psb] = g;
+		list_216[p216] = (g << 1) | 1;	/* SB2 */
+	} else if (t == TG_BURST_NORM_2) {
+		list_216[p216] = g << 1;
+		list_216[p216 + 1] = (g << 1) | 1;
+	} else if (t == TG_BURST_NORM_1)
+		list_432[p432] = g;
+}
+
+extern "C" int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uint32_t n, uint32_t *d_blk,
+			      uint32_t *d_slot_chan, int32_t *d_slot_sbord, uint32_t *d_list_sb, uint32_t *d_list_216,
+			      uint32_t *d_list_432, void *stream)
+{
+	if (!n)
+		return 0;
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t nblocks = (n + GRID_BLOCK - 1) / GRID_BLOCK;
+	hipLaunchKernelGGL(k_grid_count, dim3(nblocks), dim3(GRID_BLOCK), 0, s, d_cls, d_bits, n, d_blk);
+	hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(64), 0, s, d_blk, nblocks);
+	hipLaunchKernelGGL(k_grid_emit, dim3(nblocks), dim3(GRID_BLOCK), 0, s, d_cls, d_bits, n, d_blk, d_slot_chan, d_slot_sbord,
+			   d_list_sb, d_list_216, d_list_432);
+	return (int)hipGetLastError();
+}
+
 extern "C" int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
 			 const uint32_t *d_sb_code, uint32_t nsb, uint32_t *d_masks, void *stream)
 {

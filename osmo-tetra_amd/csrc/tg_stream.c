@@ -43,7 +43,19 @@ struct walk {
 	/* optional GPU summary: ysum[g] describes the y sequences starting in [anchor + 510 g, anchor + 510 (g + 1)) */
 	const uint16_t *ysum;
 	uint64_t anchor, nys;
+	/* grid mode (TGPU_SYNC_GRID): delivered bursts are marked in a bitmap over the classified grid instead of
+	 * being listed; one that is not a grid slot (or whose classification word disagrees) is only counted */
+	uint32_t *grid_bits;
+	const uint32_t *cls;
+	uint32_t ncls;
+	int cshift;	/* log2(chunk) if chunk is a power of two (tetra-rx.c feeds 64), else -1 */
 };
+
+static inline uint64_t div_chunk(const struct walk *w, uint64_t x)
+{
+	return w->cshift >= 0 ? x >> w->cshift : x / w->chunk;
+}
+
 
 static inline uint64_t fed(const struct walk *w, uint64_t k)
 {
@@ -56,7 +68,7 @@ static inline uint64_t call_reaching(const struct walk *w, uint64_t pos)
 {
 	if (pos > w->len)
 		return w->ncalls + 1;
-	uint64_t k = (pos + w->chunk - 1) / w->chunk;
+	uint64_t k = div_chunk(w, pos + w->chunk - 1);
 	return k ? k : 1;
 }
 
@@ -94,6 +106,19 @@ static int push_slot(struct walk *w, uint64_t off, int type, uint32_t seq, uint3
 	o->slots[o->nslots].tn_adds = tn_adds;
 	o->slots[o->nslots].type = (uint8_t)type;
 	o->nslots++;
+	return 0;
+}
+
+static int deliver_slot(struct walk *w, uint64_t off, int type, uint32_t seq, uint32_t tn_adds, int ongrid, uint64_t gi)
+{
+	if (!w->grid_bits)
+		return push_slot(w, off, type, seq, tn_adds);
+	const unsigned want_offs = (type == TETRA_TRAIN_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
+	if (ongrid && gi < w->ncls && (w->cls[gi] & 0xff) == (uint32_t)type && ((w->cls[gi] >> 8) & 0xffff) == want_offs) {
+		w->grid_bits[gi >> 5] |= 1u << (gi & 31);
+		w->out->nslots++;
+	} else
+		w->out->noffgrid++;
 	return 0;
 }
 
@@ -179,9 +204,18 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 	if (!h_stream || !out || !chunk || chunk > TG_SLOT_BITS)
 		return TGPU_EINVAL;
 	memset(out, 0, sizeof(*out));
-	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, out, 0, 0, ysum, anchor, ysum ? ncls : 0 };
+	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, out, 0, 0, ysum, anchor, ysum ? ncls : 0,
+			  NULL, cls, ncls, (chunk & (chunk - 1)) ? -1 : __builtin_ctz(chunk) };
 	int rc;
-	if (ncls) {	/* nearly every grid slot is delivered: reserve once instead of growing by doubling */
+	if (flags & TGPU_SYNC_GRID) {
+		if (!cls || !ncls)
+			return TGPU_EINVAL;
+		out->grid_bits = calloc(((size_t)ncls + 31) / 32, 4);
+		if (!out->grid_bits)
+			return TGPU_ENOMEM;
+		out->ngrid = ncls;
+		w.grid_bits = out->grid_bits;
+	} else if (ncls) {	/* nearly every grid slot is delivered: reserve once instead of growing by doubling */
 		out->slots = malloc(((size_t)ncls + 16) * sizeof(*out->slots));
 		if (!out->slots)
 			return TGPU_ENOMEM;
@@ -280,6 +314,46 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 			state = RX_S_LOCKED;
 			k = kl - 1;	/* the LOCKED branch below may use call kl itself */
 		}
+		/* LOCKED, steady state: a run of grid slots whose classification word alone says "delivered" (a
+		 * training sequence of the right type at its nominal offset, found at an offset >= 21: the first hit
+		 * of any window that holds it, whatever the backlog).  Per slot: the call that consumes it,
+		 * k = max(k + 1, ceil((bs + 510) / chunk)), the ordinal, the delivery.  Only without per-burst
+		 * events and with a power-of-two chunk; everything else takes the general path below. */
+		if (cls && (flags & TGPU_SYNC_NO_BURST_EVENTS) && w.cshift >= 0) {
+			if (grid_for != bs) {
+				ongrid = bs >= anchor && (bs - anchor) % TG_SLOT_BITS == 0;
+				gi = ongrid ? (bs - anchor) / TG_SLOT_BITS : 0;
+				grid_for = bs;
+			}
+			if (ongrid) {
+				const uint64_t bs0 = bs;
+				while (gi < ncls && bs + TG_SLOT_BITS <= len) {
+					const uint32_t v = cls[gi] & 0x01ffffffu;	/* type, offset, TG_CLS_EARLY21 */
+					if (v != (TETRA_TRAIN_SYNC | TG_SYNC_TRAIN_OFF << 8) && v != (TETRA_TRAIN_NORM_1 | TG_NORM_TRAIN_OFF << 8) &&
+					    v != (TETRA_TRAIN_NORM_2 | TG_NORM_TRAIN_OFF << 8))
+						break;
+					const uint64_t kc = (bs + TG_SLOT_BITS + chunk - 1) >> w.cshift;
+					const uint64_t kj = kc > k ? kc : k + 1;
+					if (kj > w.ncalls)
+						break;
+					k = kj;
+					seq++;
+					tn_adds++;
+					if (w.grid_bits) {
+						w.grid_bits[gi >> 5] |= 1u << (gi & 31);
+						out->nslots++;
+					} else if ((rc = push_slot(&w, bs, (int)(v & 0xff), seq, tn_adds)))
+						return rc;
+					tn_adds = 0;
+					bs += TG_SLOT_BITS;
+					nfs += TG_SLOT_BITS;
+					gi++;
+				}
+				grid_for = bs;
+				if (bs != bs0)
+					continue;
+			}
+		}
 		/* LOCKED: the next burst is handled by the first call >= k+1 that has 510 bytes of it.
 		 * kceil / fceil = that call and its fed count when nothing is backlogged, tracked incrementally
 		 * (bs only moves forward) so that the steady state costs no division. */
@@ -290,7 +364,7 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 		}
 		if (fceil_for != bs) {
 			if (fceil_for == UINT64_MAX || bs < fceil_for || need > fceil + 64 * (uint64_t)chunk) {
-				kceil = (need + chunk - 1) / chunk;
+				kceil = div_chunk(&w, need + chunk - 1);
 				fceil = kceil * chunk;
 			}
 			while (fceil < need) {
@@ -343,7 +417,7 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 
 		if (type == TETRA_TRAIN_SYNC) {
 			if (offs == TG_SYNC_TRAIN_OFF) {
-				if ((rc = push_slot(&w, bs, type, seq, tn_adds)))
+				if ((rc = deliver_slot(&w, bs, type, seq, tn_adds, cls && ongrid && grid_for == bs, gi)))
 					return rc;
 				tn_adds = 0;
 			} else {
@@ -353,7 +427,7 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 			}
 		} else if (type == TETRA_TRAIN_NORM_1 || type == TETRA_TRAIN_NORM_2) {
 			if (offs == TG_NORM_TRAIN_OFF) {
-				if ((rc = push_slot(&w, bs, type, seq, tn_adds)))
+				if ((rc = deliver_slot(&w, bs, type, seq, tn_adds, cls && ongrid && grid_for == bs, gi)))
 					return rc;
 				tn_adds = 0;
 			} else if ((rc = push_event(&w, TGPU_EV_NORM_MISPLACED, bs, offs)))
@@ -382,6 +456,7 @@ void tgpu_sync_result_free(struct tgpu_sync_result *r)
 		return;
 	free(r->slots);
 	free(r->events);
+	free(r->grid_bits);
 	memset(r, 0, sizeof(*r));
 }
 
@@ -389,7 +464,8 @@ void tgpu_sync_result_free(struct tgpu_sync_result *r)
 static int find_anchor(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t *anchor, int *locks)
 {
 	/* run the walk without classification until the first LOCKED burst: cheap, it stops early */
-	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, NULL, 0, 0, NULL, 0, 0 };
+	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, NULL, 0, 0, NULL, 0, 0, NULL, NULL, 0,
+			  (chunk & (chunk - 1)) ? -1 : __builtin_ctz(chunk) };
 	*locks = 0;
 	uint64_t kk = call_reaching(&w, 2 * TG_SLOT_BITS);
 	for (; kk <= w.ncalls; kk++) {
@@ -479,5 +555,64 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
 	if (getenv("TGPU_SYNC_TIMING"))
 		fprintf(stderr, "tgpu_sync_stream: anchor+classify %.3f ms, walk %.3f ms (%u slots, %u events)\n",
 			t1 - t0, now_ms() - t1, out->nslots, out->nevents);
+	return rc;
+}
+
+/*
+ * Stream mode end to end: classification (which also packs every grid slot into the plan's buffer) ->
+ * host walk in grid mode -> the plan's lists are built on the device from the classification words and the
+ * walk's bitmap.  Slot i of the plan is grid slot i: record i of tgpu_plan_execute() belongs to stream offset
+ * out->anchor + 510 i and is valid iff bit i of out->grid_bits is set.  No slot table, no second front-end pass.
+ */
+int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream,
+			  const uint8_t *d_stream, uint64_t len, uint32_t chunk, uint32_t flags, uint32_t scramb_init,
+			  struct tgpu_sync_result *out, void *stream)
+{
+	if (!eng || !plan || !h_stream || !d_stream || !out || !chunk)
+		return TGPU_EINVAL;
+	memset(out, 0, sizeof(*out));
+	uint64_t anchor = 0;
+	int locks = 0;
+	const double t0 = now_ms();
+	int rc = find_anchor(h_stream, len, chunk, &anchor, &locks);
+	if (rc)
+		return rc;
+	if (!locks || anchor + TG_SLOT_BITS > len) {
+		/* never locks (or nothing after the lock): the plain walk settles it, nothing to decode */
+		rc = tgpu_sync_walk(h_stream, len, chunk, anchor, NULL, NULL, 0, flags & ~TGPU_SYNC_GRID, out);
+		out->anchor = anchor;
+		out->noffgrid = out->nslots;	/* anything it found would not be in a plan */
+		return rc;
+	}
+	const uint64_t n = (len - anchor) / TG_SLOT_BITS;
+	if (n > 0xfffffff0u)
+		return TGPU_ECAPACITY;
+	const uint32_t ncls = (uint32_t)n;
+	uint32_t *d_packed, *d_cls;
+	uint16_t *d_ysum;
+	if ((rc = tgpi_plan_grid_begin(plan, ncls, &d_packed, &d_cls, &d_ysum)))
+		return rc;
+	uint32_t *cls = malloc((size_t)ncls * 6);
+	if (!cls)
+		return TGPU_ENOMEM;
+	uint16_t *ysum = (uint16_t *)(cls + ncls);
+	rc = tgk_front_stream(d_stream, anchor, len, ncls, chunk, d_packed, d_cls, d_ysum, stream);
+	if (!rc)
+		rc = (int)hipMemcpyAsync(cls, d_cls, (size_t)ncls * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+	if (!rc)
+		rc = (int)hipMemcpyAsync(ysum, d_ysum, (size_t)ncls * 2, hipMemcpyDeviceToHost, (hipStream_t)stream);
+	if (!rc)
+		rc = (int)hipStreamSynchronize((hipStream_t)stream);
+	const double t1 = now_ms();
+	if (!rc)
+		rc = tgpu_sync_walk(h_stream, len, chunk, anchor, cls, ysum, ncls, flags | TGPU_SYNC_GRID, out);
+	out->anchor = anchor;
+	free(cls);
+	const double t2 = now_ms();
+	if (!rc && !out->noffgrid)
+		rc = tgpi_plan_grid_load(plan, ncls, out->grid_bits, scramb_init, stream);
+	if (getenv("TGPU_SYNC_TIMING"))
+		fprintf(stderr, "tgpu_sync_stream_grid: anchor+classify %.3f ms, walk %.3f ms, device lists %.3f ms (%u of %u grid slots, %u events)\n",
+			t1 - t0, t2 - t1, now_ms() - t2, out->nslots, ncls, out->nevents);
 	return rc;
 }

@@ -735,3 +735,46 @@ def test_sync_stream_that_never_locks(T, eng):
     plan.execute(d.data_ptr(), d_rec.data_ptr())
     torch.cuda.synchronize()
     plan.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 5, 9])
+def test_config3_grid_plan_matches_slot_table_plan(T, eng, seed):
+    """stream mode without a host slot table (tgpu_sync_stream_grid: bitmap from the walk, lists built on the
+    device, packed slots reused from the classification pass) == the slot-table path, record for record"""
+    import torch
+    s = _mutated_stream(seed, nframes=8)
+    d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+    hs = torch.cuda.current_stream().cuda_stream
+    res = T.sync_stream(eng, s, d.data_ptr())
+    slots = res["slots"]
+    n = len(slots)
+    plan = T.Plan(eng, max(n, 1), 1)
+    plan.load_slots(res, 0)
+    d_rec = torch.zeros(max(n, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+    torch.cuda.synchronize()
+    want = d_rec.cpu().numpy().reshape(-1, T.REC_BYTES)
+    codes_want = plan.final_codes().tolist()
+    plan.close()
+
+    ngrid_max = len(s) // 510 + 1
+    gplan = T.Plan(eng, ngrid_max, 1)
+    g = T.sync_stream_grid(eng, gplan, s, d.data_ptr())
+    assert g["events"] == res["events"] and g["anchor"] == res["anchor"]
+    on = [(o - g["anchor"]) // 510 for (o, t, q, tn) in slots if (o - g["anchor"]) % 510 == 0 and o >= g["anchor"]]
+    assert g["noffgrid"] == n - len(on)
+    if g["noffgrid"]:
+        pytest.skip("stream re-locks off the grid: the caller falls back to the slot table")
+    assert T.grid_indices(g).tolist() == on and g["nslots"] == n
+    d_rec2 = torch.zeros(g["ngrid"] * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    gplan.execute(d.data_ptr(), d_rec2.data_ptr(), hs)
+    torch.cuda.synchronize()
+    got = d_rec2.cpu().numpy().reshape(-1, T.REC_BYTES)[on]
+    pw, pg = T.parse_records(want), T.parse_records(got)
+    for k in pw:
+        if k == "slot":
+            continue
+        assert (np.asarray(pw[k]) == np.asarray(pg[k])).all(), k
+    # the scrambling code the channel carries on after the batch
+    assert gplan.final_codes().tolist() == codes_want
+    gplan.close()

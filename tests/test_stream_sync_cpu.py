@@ -113,6 +113,21 @@ def check(stream, chunk=64, with_cls=True):
         assert res2["events"] == oev and res2["slots"] == res["slots"]
         res3 = T.sync_walk(stream, chunk=chunk, anchor=anchor, cls=cls, ysum=emul_ysum(stream, anchor))
         assert res3["events"] == oev and res3["slots"] == res["slots"]
+        # grid mode: the same walk marking delivered grid slots in a bitmap instead of listing them
+        res4 = T.sync_walk(stream, chunk=chunk, anchor=anchor, cls=cls, ysum=emul_ysum(stream, anchor), grid=True)
+        assert res4["events"] == oev and res4["ngrid"] == len(cls)
+        on = [(s[0] - anchor) // 510 for s in res["slots"] if s[0] >= anchor and (s[0] - anchor) % 510 == 0
+              and (s[0] - anchor) // 510 < len(cls)]
+        assert T.grid_indices(res4).tolist() == on
+        assert res4["noffgrid"] == len(res["slots"]) - len(on) and res4["nslots"] == len(on)
+        # without the per-burst events the walk takes its steady-state fast path (power-of-two chunks)
+        quiet = [e for e in oev if e[0] != 2]
+        res5 = T.sync_walk(stream, chunk=chunk, anchor=anchor, cls=cls, ysum=emul_ysum(stream, anchor), burst_events=False)
+        assert res5["events"] == quiet and res5["slots"] == res["slots"]
+        res6 = T.sync_walk(stream, chunk=chunk, anchor=anchor, cls=cls, ysum=emul_ysum(stream, anchor), burst_events=False, grid=True)
+        assert res6["events"] == quiet and T.grid_indices(res6).tolist() == on and res6["noffgrid"] == res4["noffgrid"]
+        for k in ("final_state", "tail_tn_adds", "burst_seq"):
+            assert res5[k] == res[k] and res6[k] == res[k] and res4[k] == res[k]
     return res
 
 
