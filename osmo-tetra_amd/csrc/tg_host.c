@@ -48,6 +48,7 @@ struct tgpu_plan {
 	uint8_t *d_wire;	/* caller-owned, optional */
 	uint32_t *d_softarea;	/* max_slots * 512 B, allocated on the first soft execute */
 	uint32_t *d_grid;	/* stream mode: classification words + SYNC summaries, max_slots * 6 B, allocated on first use */
+	uint32_t *h_grid;	/* pinned host mirror of d_grid */
 	int packed_ready;	/* stream mode: d_packed was filled by k_front_stream (slot = grid slot), k_front is skipped */
 	hipStream_t side;	/* k_vit<216> and k_vit<432> are independent: they run side by side */
 	hipEvent_t ev_fork, ev_join;
@@ -154,6 +155,8 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 			(void)hipFree(d[i]);
 	if (p->h_up)
 		(void)hipHostFree(p->h_up);
+	if (p->h_grid)
+		(void)hipHostFree(p->h_grid);
 	free(p->h_last_slot_of_chan);
 	free(p);
 }
@@ -259,7 +262,8 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 #undef SLOT_CHAN
 
 /* ---- stream mode (tg_stream.c): slot i of the plan = grid slot i of the classified stream ---- */
-int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packed, uint32_t **d_cls, uint16_t **d_ysum)
+int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packed, uint32_t **d_cls, uint16_t **d_ysum,
+			 uint32_t **h_cls, uint16_t **h_ysum)
 {
 	if (!p || !ngrid)
 		return TGPU_EINVAL;
@@ -270,10 +274,16 @@ int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packe
 		if (e != hipSuccess)
 			return (int)e;
 	}
+	if (!p->h_grid && hipHostMalloc((void **)&p->h_grid, (size_t)p->max_slots * 6 + 16, hipHostMallocDefault) != hipSuccess) {
+		p->h_grid = NULL;
+		return TGPU_ENOMEM;
+	}
 	p->loaded = 0;
 	*d_packed = p->d_packed;
 	*d_cls = p->d_grid;
 	*d_ysum = (uint16_t *)(p->d_grid + ngrid);
+	*h_cls = p->h_grid;
+	*h_ysum = (uint16_t *)(p->h_grid + ngrid);
 	return TGPU_OK;
 }
 

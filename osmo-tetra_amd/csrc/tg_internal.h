@@ -37,7 +37,8 @@ int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uint32_t n, ui
 
 /* plan internals used by the stream synchroniser (tg_stream.c) */
 struct tgpu_plan;
-int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packed, uint32_t **d_cls, uint16_t **d_ysum);
+int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packed, uint32_t **d_cls, uint16_t **d_ysum,
+			 uint32_t **h_cls, uint16_t **h_ysum);	/* h_*: pinned mirrors owned by the plan */
 int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t scramb_init, void *stream);
 
 #ifdef __cplusplus

@@ -588,26 +588,19 @@ int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const
 	if (n > 0xfffffff0u)
 		return TGPU_ECAPACITY;
 	const uint32_t ncls = (uint32_t)n;
-	uint32_t *d_packed, *d_cls;
-	uint16_t *d_ysum;
-	if ((rc = tgpi_plan_grid_begin(plan, ncls, &d_packed, &d_cls, &d_ysum)))
+	uint32_t *d_packed, *d_cls, *cls;
+	uint16_t *d_ysum, *ysum;
+	if ((rc = tgpi_plan_grid_begin(plan, ncls, &d_packed, &d_cls, &d_ysum, &cls, &ysum)))
 		return rc;
-	uint32_t *cls = malloc((size_t)ncls * 6);
-	if (!cls)
-		return TGPU_ENOMEM;
-	uint16_t *ysum = (uint16_t *)(cls + ncls);
 	rc = tgk_front_stream(d_stream, anchor, len, ncls, chunk, d_packed, d_cls, d_ysum, stream);
-	if (!rc)
-		rc = (int)hipMemcpyAsync(cls, d_cls, (size_t)ncls * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
-	if (!rc)
-		rc = (int)hipMemcpyAsync(ysum, d_ysum, (size_t)ncls * 2, hipMemcpyDeviceToHost, (hipStream_t)stream);
+	if (!rc)	/* words and summaries are adjacent on both sides: one copy into the plan's pinned mirror */
+		rc = (int)hipMemcpyAsync(cls, d_cls, (size_t)ncls * 6, hipMemcpyDeviceToHost, (hipStream_t)stream);
 	if (!rc)
 		rc = (int)hipStreamSynchronize((hipStream_t)stream);
 	const double t1 = now_ms();
 	if (!rc)
 		rc = tgpu_sync_walk(h_stream, len, chunk, anchor, cls, ysum, ncls, flags | TGPU_SYNC_GRID, out);
 	out->anchor = anchor;
-	free(cls);
 	const double t2 = now_ms();
 	if (!rc && !out->noffgrid)
 		rc = tgpi_plan_grid_load(plan, ncls, out->grid_bits, scramb_init, stream);
