@@ -383,6 +383,20 @@ int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
 
 /*
+ * Block mode -- the unit tp_sap_udata_ind() receives (phy/tetra_burst.h:18, lower_mac/tetra_lower_mac.c:143):
+ * blocks of type-5 bits on their own, without a burst around them.  blk_off[i] = byte offset of block i's
+ * bits (1 bit per byte: 120 for SB1, 216 for SB2/NDB, 168 for SCH/HU, 432 for SCH/F, 30 for BBK) in the
+ * buffer later given to tgpu_plan_execute(); blk_type[i] = enum tp_sap_data_type; blk_code[i] = the
+ * scrambling code in force for it (tcd->scramb_init; ignored for SB1, which always uses 3).  The number of
+ * distinct codes must not exceed the plan's max_chan.  tgpu_plan_execute(plan, d_bits, d_rec, stream) then
+ * writes one 320-byte record per block (same layout as slot records): @0 block type, @2 crc_ok, @4 crc,
+ * @8 code, @12 block index, type-1 bits @48 (BBK: 14 bits @32, crc_ok = 1), SB1 also the SYNC-PDU fields.
+ * This is also the only way in for SCH/HU (lower_mac/tetra_lower_mac.c:80-87), which no downlink burst carries.
+ */
+int tgpu_plan_load_blocks(struct tgpu_plan *plan, uint32_t nblocks, const uint64_t *blk_off,
+			  const uint8_t *blk_type, const uint32_t *blk_code);
+
+/*
  * The reference's traffic-channel dump block (lower_mac/tetra_lower_mac.c:213-231, the input format of the
  * ETSI codec tools): 690 int16 = six frames of marker 0x6b21+i + 114 soft bits (bit 1 -> -127, bit 0 -> +127;
  * 432 bits in total, the rest 0), made from the descrambled type-4 bits a traffic block is delivered with

@@ -109,6 +109,7 @@ def lib():
     L.tgpu_traffic_block.argtypes = [u8p, C.c_uint, C.POINTER(C.c_int16)]
     L.tgpu_traffic_block.restype = None
     L.tgpu_channel_burst_rx.argtypes = [C.c_void_p, u8p, C.c_uint, C.c_int, C.c_uint32]
+    L.tgpu_plan_load_blocks.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p]
     L.tgpu_plan_load_slots.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(SyncSlot), C.c_uint32]
     L.tgpu_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_plan_final_codes.argtypes = [C.c_void_p, C.c_void_p, u32p]
@@ -205,6 +206,16 @@ class Plan:
         _chk(lib().tgpu_plan_load(self._h, n, off.ctypes.data_as(u64p), typ.ctypes.data_as(u8p),
                                   chan.ctypes.data_as(u32p), nchan, codes.ctypes.data_as(u32p)), "tgpu_plan_load")
         self.nslots, self.nchan = n, nchan
+
+    def load_blocks(self, blk_off, blk_type, blk_code):
+        """tgpu_plan_load_blocks: type-5 blocks on their own (enum tp_sap_data_type per block, code per block)"""
+        off = np.ascontiguousarray(blk_off, np.uint64)
+        typ = _np_u8(blk_type)
+        code = np.ascontiguousarray(blk_code, np.uint32)
+        assert len(off) == len(typ) == len(code)
+        _chk(lib().tgpu_plan_load_blocks(self._h, len(typ), off.ctypes.data_as(u64p), typ.ctypes.data_as(u8p),
+                                         code.ctypes.data_as(u32p)), "tgpu_plan_load_blocks")
+        self.nslots, self.nchan = len(typ), 1
 
     def load_slots(self, outcome, scramb_init=0):
         """tgpu_plan_load_slots: one channel, slot table of sync_stream()/sync_walk() read in place"""

@@ -26,6 +26,8 @@ struct tgpu_engine {
 	int device;
 };
 
+#define TGPU_NKINDS 4	/* trellis kinds TG_KIND_SB1 / _216 / _432 / _168; index 4 = BBK in block-mode lists */
+
 struct tgpu_plan {
 	struct tgpu_engine *eng;
 	uint32_t max_slots, max_chan;
@@ -50,6 +52,9 @@ struct tgpu_plan {
 	uint32_t *d_grid;	/* stream mode: classification words + SYNC summaries, max_slots * 6 B, allocated on first use */
 	uint32_t *h_grid;	/* pinned host mirror of d_grid */
 	int packed_ready;	/* stream mode: d_packed was filled by k_front_stream (slot = grid slot), k_front is skipped */
+	int block_mode;		/* tgpu_plan_load_blocks(): items are type-5 blocks, not slots */
+	uint32_t *d_list_168, *d_list_bbk;	/* block mode only (in d_up) */
+	uint32_t n168, nbbk;
 	hipStream_t side;	/* k_vit<216> and k_vit<432> are independent: they run side by side */
 	hipEvent_t ev_fork, ev_join;
 	uint32_t *h_last_slot_of_chan;
@@ -249,6 +254,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 		p->static_masks = 1;
 	}
 	p->packed_ready = 0;
+	p->block_mode = 0;
 	p->nslots = nslots;
 	p->nchan = nchan;
 	p->nsb = nsb;
@@ -329,6 +335,7 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 		}
 	p->static_masks = 0;
 	p->packed_ready = 1;
+	p->block_mode = 0;
 	p->nslots = ngrid;
 	p->nchan = 1;
 	p->nsb = tot[0];
@@ -412,7 +419,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 #define MARK(i) do { if (ev) { hipError_t e_ = hipEventRecord(ev[i], (hipStream_t)stream); if (e_ != hipSuccess) return (int)e_; } } while (0)
 	if (!p || !d_stream || !d_rec)
 		return TGPU_EINVAL;
-	if (!p->loaded || (soft && p->packed_ready))
+	if (!p->loaded || (soft && p->packed_ready) || p->block_mode)
 		return TGPU_ESTATE;
 	MARK(0);
 	if (p->nslots) {
@@ -432,7 +439,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	MARK(1);
 	if (p->nslots && !p->static_masks) {
 		if ((rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, p->nsb, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->block_mode, stream)))
 			return rc;
 	}
 	MARK(2);
@@ -460,13 +467,13 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	}
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_216, p->d_list_216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->block_mode, stream)))
 			return rc;
 	}
 	MARK(5);
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_432, p->d_list_432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL,
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->block_mode,
 				  fork ? (void *)p->side : stream)))
 			return rc;
 	}
@@ -482,8 +489,133 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	return TGPU_OK;
 }
 
+/* ---- block mode: items are type-5 blocks on their own (the unit tp_sap_udata_ind() receives) ---- */
+static int cmp_u32(const void *a, const void *b)
+{
+	const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+	return x < y ? -1 : x > y;
+}
+
+int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t *blk_off, const uint8_t *blk_type,
+			  const uint32_t *blk_code)
+{
+	if (!p || (nblocks && (!blk_off || !blk_type || !blk_code)))
+		return TGPU_EINVAL;
+	if (nblocks > p->max_slots)
+		return TGPU_ECAPACITY;
+	/* the distinct scrambling codes become the mask-table entries 1 + u (what channels are in slot mode) */
+	uint32_t *uniq = malloc(((size_t)nblocks + 1) * 4);
+	if (!uniq)
+		return TGPU_ENOMEM;
+	memcpy(uniq, blk_code, (size_t)nblocks * 4);
+	qsort(uniq, nblocks, 4, cmp_u32);
+	uint32_t nu = 0;
+	for (uint32_t i = 0; i < nblocks; i++)
+		if (!nu || uniq[nu - 1] != uniq[i])
+			uniq[nu++] = uniq[i];
+	if (!nu)
+		uniq[nu++] = 0;
+	if (nu > p->max_chan) {
+		free(uniq);
+		return TGPU_ECAPACITY;
+	}
+	uint32_t cnt[TGPU_NKINDS + 1] = { 0 };
+	for (uint32_t i = 0; i < nblocks; i++) {
+		int x;
+		switch (blk_type[i]) {
+		case TPSAP_T_SB1: x = TG_KIND_SB1; break;
+		case TPSAP_T_SB2: case TPSAP_T_NDB: x = TG_KIND_216; break;
+		case TPSAP_T_SCH_F: x = TG_KIND_432; break;
+		case TPSAP_T_SCH_HU: x = TG_KIND_168; break;
+		case TPSAP_T_BBK: x = TGPU_NKINDS; break;
+		default:
+			free(uniq);
+			return TGPU_EINVAL;
+		}
+		if (blk_off[i] >> 48) {
+			free(uniq);
+			return TGPU_EINVAL;
+		}
+		cnt[x]++;
+	}
+	size_t o = 0;
+#define UP_PLACE(dptr, hptr, type, count) do { dptr = (type *)(p->d_up + o); hptr = (type *)(p->h_up + o); \
+		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
+	uint64_t *h_desc;
+	uint32_t *h_idx, *d_idx, *h_code, *h_list[TGPU_NKINDS + 1], *d_list[TGPU_NKINDS + 1];
+	UP_PLACE(p->d_slot_off, h_desc, uint64_t, nblocks);
+	UP_PLACE(d_idx, h_idx, uint32_t, nblocks);
+	for (int x = 0; x <= TGPU_NKINDS; x++)
+		UP_PLACE(d_list[x], h_list[x], uint32_t, cnt[x]);
+	UP_PLACE(p->d_chan_code, h_code, uint32_t, nu);
+#undef UP_PLACE
+	if (o > p->up_bytes) {
+		free(uniq);
+		return TGPU_ECAPACITY;
+	}
+	uint32_t fill[TGPU_NKINDS + 1] = { 0 };
+	for (uint32_t i = 0; i < nblocks; i++) {
+		int x;
+		switch (blk_type[i]) {
+		case TPSAP_T_SB1: x = TG_KIND_SB1; break;
+		case TPSAP_T_SB2: case TPSAP_T_NDB: x = TG_KIND_216; break;
+		case TPSAP_T_SCH_F: x = TG_KIND_432; break;
+		case TPSAP_T_SCH_HU: x = TG_KIND_168; break;
+		default: x = TGPU_NKINDS; break;
+		}
+		h_desc[i] = blk_off[i] | ((uint64_t)x << 56) | ((uint64_t)blk_type[i] << 48);
+		h_list[x][fill[x]++] = (x == TG_KIND_216) ? (i << 1) : i;	/* k_vit<216> items carry a block-select bit */
+		const uint32_t *hit = bsearch(&blk_code[i], uniq, nu, 4, cmp_u32);
+		h_idx[i] = 1 + (uint32_t)(hit - uniq);
+	}
+	memcpy(h_code, uniq, (size_t)nu * 4);
+	free(uniq);
+	HCHK(hipMemcpy(p->d_up, p->h_up, o, hipMemcpyHostToDevice));
+	HCHK(hipMemcpyAsync(p->d_maskidx, d_idx, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, NULL));
+	int rc = tgk_masks(p->d_chan_code, nu, p->d_sb_ok, p->d_sb_code, 0, p->d_masks, NULL);
+	if (rc)
+		return rc;
+	HCHK(hipDeviceSynchronize());
+	p->d_list_sb = d_list[TG_KIND_SB1];
+	p->d_list_216 = d_list[TG_KIND_216];
+	p->d_list_432 = d_list[TG_KIND_432];
+	p->d_list_168 = d_list[TG_KIND_168];
+	p->d_list_bbk = d_list[TGPU_NKINDS];
+	p->nsb = cnt[TG_KIND_SB1];
+	p->n216 = cnt[TG_KIND_216];
+	p->n432 = cnt[TG_KIND_432];
+	p->n168 = cnt[TG_KIND_168];
+	p->nbbk = cnt[TGPU_NKINDS];
+	p->nslots = nblocks;
+	p->nchan = nu;
+	p->static_masks = 1;
+	p->packed_ready = 0;
+	p->block_mode = 1;
+	p->loaded = 1;
+	return TGPU_OK;
+}
+
+static int plan_run_blocks(struct tgpu_plan *p, const uint8_t *d_bits, uint8_t *d_rec, void *stream)
+{
+	int rc;
+	if (!p->nslots)
+		return TGPU_OK;
+	if ((rc = tgk_front_blocks(d_bits, p->d_slot_off, p->nslots, p->d_packed, stream)))
+		return rc;
+	const struct { int kind; const uint32_t *list; uint32_t n; } run[4] = {
+		{ TG_KIND_432, p->d_list_432, p->n432 }, { TG_KIND_216, p->d_list_216, p->n216 },
+		{ TG_KIND_168, p->d_list_168, p->n168 }, { TG_KIND_SB1, p->d_list_sb, p->nsb } };
+	for (int i = 0; i < 4; i++)
+		if ((rc = tgk_vit(run[i].kind, run[i].list, run[i].n, p->d_packed, p->d_masks, p->d_maskidx, d_rec, p->d_sb_ok,
+				  p->d_sb_code, NULL, NULL, 1, stream)))
+			return rc;
+	return tgk_bbk_blocks(p->d_list_bbk, p->nbbk, p->d_packed, p->d_masks, p->d_maskidx, d_rec, stream);
+}
+
 int tgpu_plan_execute(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream)
 {
+	if (p && p->loaded && p->block_mode)
+		return d_stream && d_rec ? plan_run_blocks(p, d_stream, d_rec, stream) : TGPU_EINVAL;
 	return plan_run(p, d_stream, d_rec, stream, NULL, 0);
 }
 

@@ -22,9 +22,13 @@
 /* ------------------------------------------------------------------------- */
 /* constant tables (uploaded once per process by tgk_init)                   */
 /* ------------------------------------------------------------------------- */
+#define TG_NBLKTYPES 5	/* block-mode front tables: TG_KIND_SB1 / _216 / _432 / _168, then BBK */
+#define TG_BLK_BBK   4
+
 struct tg_const_tables {
 	uint16_t front_src[3][TG_PACKED_WORDS][32];	/* [NORM_1, NORM_2, SYNC][word][bit] -> slot byte offset */
 	uint16_t mask_pos[TG_MASK_WORDS][32];		/* [mask word][bit] -> position in the LFSR sequence */
+	uint16_t blk_src[TG_NBLKTYPES][TG_PACKED_WORDS][32];	/* block mode: [SB1, 216, 432, 168, BBK][word][bit] -> type-5 bit of the block */
 	uint32_t lfsr_lin[432];				/* seq[n] = parity(init & lfsr_lin[n]) */
 	uint32_t sb1_mask[5];				/* SB1 is always scrambled with init 3 */
 	uint16_t crc_lsb[256];
@@ -225,6 +229,94 @@ void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 		FRONT_STEP(dc, c0, c1)
 	}
 #undef FRONT_STEP
+}
+
+__device__ __forceinline__ uint32_t spread4(uint32_t nib)
+{
+	/* 4 bits -> 4 bytes of 0/1 (bit 0 -> byte 0) */
+	return ((nib & 15u) * 0x00204081u) & 0x01010101u;
+}
+
+/* ------------------------------------------------------------------------- */
+/* block mode: one type-5 block per item (the tp_sap_udata_ind() unit)        */
+/* ------------------------------------------------------------------------- */
+/*
+ * k_front_blocks: the front end for blocks that arrive on their own (phy/tetra_burst.c:350-372 hands
+ * tp_sap_udata_ind() one block at a time): wave per block, the block's 30..432 type-5 bytes go to the LDS
+ * window, the same ballot gather as k_front with per-kind tables (de-interleave + 2/3 de-puncture order) fills
+ * code words 0..17 (or the BBK word), word 19 = block type | flags << 8.  Descriptor = byte offset |
+ * (uint64_t)table index << 56 | (uint64_t)tp_sap type << 48.  Reads never go past the block.
+ */
+__global__ __launch_bounds__(256)
+void k_front_blocks(const uint8_t *__restrict__ bits, const uint64_t *__restrict__ desc, uint32_t nblocks,
+		    uint32_t *__restrict__ packed)
+{
+	__shared__ uint32_t s_win[4][128];
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t wave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
+	const uint32_t half = lane >> 5, bit = lane & 31;
+	uint32_t *mine = s_win[wib];
+	const uint8_t *mine8 = (const uint8_t *)mine;
+	static const uint16_t lens[TG_NBLKTYPES] = { 120, 216, 432, 168, 30 };
+
+	for (uint32_t b = wave; b < nblocks; b += nwaves) {
+		const uint64_t d = desc[b];
+		const uint32_t x = (uint32_t)(d >> 56), tptype = (uint32_t)(d >> 48) & 0xff;
+		const uint8_t *base = bits + (d & 0x0000ffffffffffffull);
+		const uint32_t len = lens[x];
+		/* bytes 4 lane .. 4 lane + 3 and 256 + 4 lane ..: whole dwords inside the block, the 2-byte tail of a BBK */
+		uint32_t d0 = 0, d1 = 0;
+		if (4 * lane + 4 <= len)
+			d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
+		else if (4 * lane + 2 <= len)
+			d0 = *(const tg_u16_unaligned *)(base + 4 * lane);
+		if (256 + 4 * lane + 4 <= len)
+			d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
+		mine[lane] = d0;
+		mine[64 + lane] = d1;
+		uint32_t myword = 0, acc = 0;
+#pragma unroll
+		for (int r = 0; r < 10; r++) {
+			const uint32_t o = c_tab.blk_src[x][2 * r + half][bit];
+			const uint32_t byte = (o == 0xffff) ? 0u : (uint32_t)mine8[o];
+			acc |= byte;
+			const unsigned long long bal = __ballot(byte != 0);
+			asm("s_nop 4\n\tv_writelane_b32 %0, %1, %2\n\tv_writelane_b32 %0, %3, %4"
+			    : "+v"(myword) : "s"((uint32_t)bal), "i"(2 * r), "s"((uint32_t)(bal >> 32)), "i"(2 * r + 1));
+		}
+		const uint32_t flags = __ballot(acc > 1) ? TG_FLAG_NONBINARY : 0;
+		if (lane == TG_PW_META)
+			myword = tptype | (flags << 8);
+		if (lane < TG_PACKED_WORDS)
+			packed[(size_t)b * TG_PACKED_WORDS + lane] = myword;
+	}
+}
+
+/* BBK blocks: descramble, keep the first 14 bits (lower_mac/tetra_lower_mac.c:268-274), crc_ok = 1 */
+__global__ __launch_bounds__(256)
+void k_bbk_blocks(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t *__restrict__ packed,
+		  const uint32_t *__restrict__ masks, const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nitems)
+		return;
+	const uint32_t b = items[i];
+	const uint32_t midx = maskidx[b];
+	const uint32_t meta = packed[(size_t)b * TG_PACKED_WORDS + TG_PW_META];
+	const uint32_t bb = packed[(size_t)b * TG_PACKED_WORDS + TG_PW_BBK] ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
+	uint8_t *r = rec + (size_t)b * TG_REC_BYTES;
+	uint4 o;
+	o.x = spread4(bb);
+	o.y = spread4(bb >> 4);
+	o.z = spread4(bb >> 8);
+	o.w = spread4(bb >> 12) & 0x0000ffffu;
+	*(uint4 *)(r + TG_REC_BBK) = o;
+	r[TG_REC_TYPE] = (uint8_t)meta;
+	r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
+	r[TG_REC_CRC_OK] = 1;
+	*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
+	*(uint32_t *)(r + TG_REC_SLOT) = b;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -545,12 +637,7 @@ template <int KIND> struct vit_cfg;
 template <> struct vit_cfg<TG_KIND_SB1> { enum { NBLK = 10, TYPE1 = 60, MW = 0 }; };
 template <> struct vit_cfg<TG_KIND_216> { enum { NBLK = 18, TYPE1 = 124, MW = TG_MW_216 }; };
 template <> struct vit_cfg<TG_KIND_432> { enum { NBLK = 36, TYPE1 = 268, MW = TG_MW_432 }; };
-
-__device__ __forceinline__ uint32_t spread4(uint32_t nib)
-{
-	/* 4 bits -> 4 bytes of 0/1 (bit 0 -> byte 0) */
-	return ((nib & 15u) * 0x00204081u) & 0x01010101u;
-}
+template <> struct vit_cfg<TG_KIND_168> { enum { NBLK = 14, TYPE1 = 92, MW = TG_MW_168 }; };
 
 /* MSB-first value of 'len' consecutive decoded bits starting at bit n0 (bits are held
  * LSB-first in od[]): the reference's bits_to_uint(type2 + n0, len), tetra_common.c:31-39 */
@@ -588,7 +675,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
 	   uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code, uint8_t *__restrict__ wire,
-	   const uint32_t *__restrict__ softarea)
+	   const uint32_t *__restrict__ softarea, int block_mode)
 {
 	constexpr int NBLK = vit_cfg<KIND>::NBLK;
 	constexpr int NW = NBLK / 2;			/* code words */
@@ -847,6 +934,18 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		*(uint32_t *)(r + TG_REC_SBCODE) = code;
 		sb_ok[idx] = crc_ok;
 		sb_code[idx] = code;
+		if (block_mode) {	/* a block on its own: this lane also writes the header */
+			r[TG_REC_TYPE] = (uint8_t)packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
+			*(uint32_t *)(r + TG_REC_CODE) = 3u;
+			*(uint32_t *)(r + TG_REC_SLOT) = slot;
+		}
+	} else if (block_mode) {
+		/* block mode (tgpu_plan_load_blocks): one block per record, no burst around it */
+		const uint32_t meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
+		r[TG_REC_TYPE] = (uint8_t)meta;
+		r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
+		*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
+		*(uint32_t *)(r + TG_REC_SLOT) = slot;
 	} else {
 		/* BBK + header are written by the lane that owns the slot's "primary" block:
 		 * SCH/F for NORM_1, BLK1 for NORM_2, SB2 for SYNC */
@@ -985,16 +1084,16 @@ __global__ __launch_bounds__(256)
 void k_masks(const uint32_t *chan_code, uint32_t nchan, const uint32_t *sb_ok, const uint32_t *sb_code,
 	     uint32_t nsb, uint32_t *masks)
 {
-	/* a wavefront keeps the linear-form masks of its 14 x 64 output bits in registers and walks
-	 * entries wave, wave + nwaves, ...: per entry 14 x (and, popcount, ballot) and one 128-byte store */
+	/* a wavefront keeps the linear-form masks of its 18 x 64 output bits in registers and walks
+	 * entries wave, wave + nwaves, ...: per entry 18 x (and, popcount, ballot) and one 160-byte store */
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
 	const uint32_t half = lane >> 5, bit = lane & 31;
 	const uint32_t nent = 1 + nchan + nsb;
-	uint32_t lin[14];
+	uint32_t lin[TG_MW_ROUNDS];
 #pragma unroll
-	for (int r = 0; r < 14; r++) {
+	for (int r = 0; r < TG_MW_ROUNDS; r++) {
 		const uint16_t pos = c_tab.mask_pos[2 * r + half][bit];
 		lin[r] = (pos != 0xffff) ? c_tab.lfsr_lin[pos] : 0u;
 	}
@@ -1008,7 +1107,7 @@ void k_masks(const uint32_t *chan_code, uint32_t nchan, const uint32_t *sb_ok, c
 		}
 		uint32_t myword = 0;
 #pragma unroll
-		for (int r = 0; r < 14; r++) {
+		for (int r = 0; r < TG_MW_ROUNDS; r++) {
 			const unsigned long long bal = __ballot(__popc(code & lin[r]) & 1);
 			myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
 			myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
@@ -1055,8 +1154,21 @@ static void build_tables(tg_const_tables *t)
 				pos = tg_codeword_src(TG_KIND_216, w - TG_MW_216, p);
 			else if (w == TG_MW_BBK)
 				pos = (p < 30) ? p : -1;
+			else if (w >= TG_MW_168 && w < TG_MW_168 + 7)
+				pos = tg_codeword_src(TG_KIND_168, w - TG_MW_168, p);
 			t->mask_pos[w][p] = (pos < 0) ? 0xffff : (uint16_t)pos;
 		}
+	/* block mode: code-word bit -> type-5 bit of a block handed over on its own */
+	for (int x = 0; x < TG_NBLKTYPES; x++)
+		for (int w = 0; w < TG_PACKED_WORDS; w++)
+			for (int p = 0; p < 32; p++) {
+				int o = -1;
+				if (x == TG_BLK_BBK)
+					o = (w == TG_PW_BBK && p < 30) ? p : -1;
+				else if (w < tg_kind_nblk(x) / 2)
+					o = tg_codeword_src(x, w, p);
+				t->blk_src[x][w][p] = (o < 0) ? 0xffff : (uint16_t)o;
+			}
 	/* linear form of the LFSR: run it on the 32 unit vectors */
 	for (int b = 0; b < 32; b++) {
 		uint32_t st = 1u << b;
@@ -1152,6 +1264,27 @@ extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 	return (int)hipGetLastError();
 }
 
+extern "C" int tgk_front_blocks(const uint8_t *d_bits, const uint64_t *d_desc, uint32_t nblocks, uint32_t *d_packed, void *stream)
+{
+	if (!nblocks)
+		return 0;
+	uint32_t blocks = (nblocks + 3) / 4;
+	if (blocks > 256 * 16)
+		blocks = 256 * 16;
+	hipLaunchKernelGGL(k_front_blocks, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_bits, d_desc, nblocks, d_packed);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_bbk_blocks(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,
+			      const uint32_t *d_maskidx, uint8_t *d_rec, void *stream)
+{
+	if (!nitems)
+		return 0;
+	hipLaunchKernelGGL(k_bbk_blocks, dim3((nitems + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_items, nitems,
+			   d_packed, d_masks, d_maskidx, d_rec);
+	return (int)hipGetLastError();
+}
+
 static const uint8_t tsq_n[22] = { 1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0 };
 static const uint8_t tsq_p[22] = { 0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0 };
 static const uint8_t tsq_y[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
@@ -1223,13 +1356,14 @@ extern "C" int tgk_float_to_bits_afc(const float *d_in, unsigned long long n, ui
 
 extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 		       const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
-		       uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire, const uint32_t *d_soft, void *stream)
+		       uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire, const uint32_t *d_soft, int block_mode,
+		       void *stream)
 {
 	if (!nitems)
 		return 0;
 	const dim3 grid((nitems + 63) / 64), block(64);
 	hipStream_t s = (hipStream_t)stream;
-#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire, d_soft)
+#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire, d_soft, block_mode)
 	const int hm = d_soft ? 2 : tgk_hist_mode;
 	switch (kind) {
 	case TG_KIND_SB1:
@@ -1240,6 +1374,9 @@ extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const
 		break;
 	case TG_KIND_432:
 		if (hm == 2) VIT_LAUNCH(TG_KIND_432, 2); else if (hm) VIT_LAUNCH(TG_KIND_432, 1); else VIT_LAUNCH(TG_KIND_432, 0);
+		break;
+	case TG_KIND_168:	/* hard input only */
+		if (hm == 2) return -1; else if (hm) VIT_LAUNCH(TG_KIND_168, 1); else VIT_LAUNCH(TG_KIND_168, 0);
 		break;
 	default:
 		return -1;

@@ -28,6 +28,7 @@
 #define TG_KIND_SB1   0	/* 120 bits, a=11,  80 type-2 bits, 60 type-1  */
 #define TG_KIND_216   1	/* 216 bits, a=101, 144 type-2,     124 type-1 (NDB, SB2) */
 #define TG_KIND_432   2	/* 432 bits, a=103, 288 type-2,     268 type-1 (SCH/F) */
+#define TG_KIND_168   3	/* 168 bits, a=13,  112 type-2,     92 type-1  (SCH/HU; block mode only) */
 
 /* slot field offsets (phy/tetra_burst.c:31-47) */
 #define TG_SB_BLK1_OFF    94
@@ -84,12 +85,14 @@
 
 #define TG_FLAG_NONBINARY 0x01	/* a stream byte other than 0/1 was seen in a coded field */
 
-/* scrambling-mask table entry: 32 dwords, same bit layout as the code words */
-#define TG_MASK_WORDS     32
+/* scrambling-mask table entry: 40 dwords, same bit layout as the code words */
+#define TG_MASK_WORDS     40
 #define TG_MW_432         0	/* 18 words */
 #define TG_MW_216         18	/* 9 words  */
 #define TG_MW_BBK         27
 #define TG_MW_CODE        28	/* the scrambling code itself */
+#define TG_MW_168         29	/* 7 words  */
+#define TG_MW_ROUNDS      18	/* ballot rounds (two words each) that cover the words above */
 
 /*
  * Output record, one per slot, fixed 320 bytes (the unit of the RCCL gather).
@@ -142,10 +145,10 @@ extern "C" {
 #endif
 
 /* number of 8-step trellis blocks / type-1 bits / crc span per kind */
-static inline int tg_kind_nblk(int kind)  { return kind == TG_KIND_SB1 ? 10 : kind == TG_KIND_216 ? 18 : 36; }
-static inline int tg_kind_K(int kind)     { return kind == TG_KIND_SB1 ? 120 : kind == TG_KIND_216 ? 216 : 432; }
-static inline int tg_kind_a(int kind)     { return kind == TG_KIND_SB1 ? 11 : kind == TG_KIND_216 ? 101 : 103; }
-static inline int tg_kind_type1(int kind) { return kind == TG_KIND_SB1 ? 60 : kind == TG_KIND_216 ? 124 : 268; }
+static inline int tg_kind_nblk(int kind)  { return kind == TG_KIND_SB1 ? 10 : kind == TG_KIND_216 ? 18 : kind == TG_KIND_168 ? 14 : 36; }
+static inline int tg_kind_K(int kind)     { return kind == TG_KIND_SB1 ? 120 : kind == TG_KIND_216 ? 216 : kind == TG_KIND_168 ? 168 : 432; }
+static inline int tg_kind_a(int kind)     { return kind == TG_KIND_SB1 ? 11 : kind == TG_KIND_216 ? 101 : kind == TG_KIND_168 ? 13 : 103; }
+static inline int tg_kind_type1(int kind) { return kind == TG_KIND_SB1 ? 60 : kind == TG_KIND_216 ? 124 : kind == TG_KIND_168 ? 92 : 268; }
 
 /*
  * type-4 (stream order inside a block) index feeding code-word bit (d, p) of a block

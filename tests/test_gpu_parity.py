@@ -778,3 +778,66 @@ def test_config3_grid_plan_matches_slot_table_plan(T, eng, seed):
     # the scrambling code the channel carries on after the batch
     assert gplan.final_codes().tolist() == codes_want
     gplan.close()
+
+
+# ---------------------------------------------------------------------------
+# block mode: the tp_sap_udata_ind() unit, incl. SCH/HU
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("ber", [0.0, 0.03, 0.08])
+def test_block_mode_all_block_types(T, eng, ber):
+    """type-5 blocks on their own (SB1, SB2, NDB, BBK, SCH/HU, SCH/F; several scrambling codes, ragged
+    unaligned offsets, noise -> trellis ties) == the oracle's type-5 -> type-1 chain, bit for bit"""
+    import torch
+    rng = np.random.default_rng(int(ber * 100) + 40)
+    n = 1500
+    kinds = [O.T_SB1, O.T_SB2, O.T_NDB, O.T_BBK, O.T_SCH_HU, O.T_SCH_F]
+    types = rng.choice(kinds, n).astype(np.uint8)
+    codes_pool = np.array([0, 3, 0x41802A07, 0x12345677, 0xFFFFFFFF], np.uint32)
+    codes = codes_pool[rng.integers(0, len(codes_pool), n)]
+    offs, bufs, pos = [], [], 7
+    t5s = []
+    for i in range(n):
+        t = int(types[i])
+        K, n2, n1, a = O.BLK[t]
+        enc_code = 3 if t == O.T_SB1 else int(codes[i])
+        if t == O.T_BBK:
+            t5 = O.encode_bbk(rng.integers(0, 2, 14).astype(np.uint8), enc_code)
+        else:
+            t5 = O.encode_block(t, rng.integers(0, 2, n1).astype(np.uint8), enc_code)
+        t5 = t5 ^ (rng.random(K) < ber).astype(np.uint8)
+        t5s.append(t5)
+        offs.append(pos)
+        bufs.append((pos, t5))
+        pos += K + int(rng.integers(0, 5))
+    buf = np.zeros(pos, np.uint8)                  # no slack after the last block: reads must stay inside
+    for p0, t5 in bufs:
+        buf[p0:p0 + len(t5)] = t5
+    d = torch.from_numpy(buf).cuda()
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 8)
+    plan.load_blocks(np.array(offs, np.uint64), types, codes)
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+    p = T.parse_records(rec)
+    nok = 0
+    for i in range(n):
+        t = int(types[i])
+        K, n2, n1, a = O.BLK[t]
+        code = 3 if t == O.T_SB1 else int(codes[i])
+        assert p["type"][i] == t and p["slot"][i] == i and p["code"][i] == code
+        if t == O.T_BBK:
+            want = (t5s[i] ^ O.scramb_seq(code, 30))[:14]
+            assert (p["bbk"][i] == want).all() and p["crc_ok"][i, 0] == 1
+            continue
+        w1, wcrc, wok, _ = O.decode_block(t, t5s[i], code)
+        assert (p["bits1"][i][:n1] == w1).all(), (i, t)
+        assert p["crc"][i, 0] == wcrc and p["crc_ok"][i, 0] == int(wok)
+        nok += int(wok)
+    assert nok > (0.9 * n * 5 / 6 if ber == 0 else 10)
+    # too many distinct codes for the plan, bad type
+    with pytest.raises(T.TgpuError):
+        T.Plan(eng, 4, 1).load_blocks(np.zeros(2, np.uint64), np.array([2, 2], np.uint8), np.array([1, 2], np.uint32))
+    with pytest.raises(T.TgpuError):
+        plan.load_blocks(np.zeros(1, np.uint64), np.array([9], np.uint8), np.zeros(1, np.uint32))
+    plan.close()

@@ -86,9 +86,9 @@ def test_synth_decodes_in_oracle():
 
 @pytest.mark.parametrize("ber", [0.0, 0.02, 0.05, 0.12, 0.5])
 def test_kernel_core_on_host_bit_exact(ber):
-    """the packed-u16 trellis (vit_core.h) == oracle, ties included, on all three block kinds"""
+    """the packed-u16 trellis (vit_core.h) == oracle, ties included, on all four block kinds"""
     rng = np.random.default_rng(int(ber * 100) + 1)
-    for kind, t in ((0, O.T_SB1), (1, O.T_NDB), (2, O.T_SCH_F)):
+    for kind, t in ((0, O.T_SB1), (1, O.T_NDB), (2, O.T_SCH_F), (3, O.T_SCH_HU)):
         K, n2, n1, a = O.BLK[t]
         for _ in range(150):
             t5 = O.encode_block(t, rng.integers(0, 2, n1).astype(np.uint8), 0)
@@ -101,7 +101,7 @@ def test_kernel_core_on_host_bit_exact(ber):
 
 def test_kernel_core_worst_case_metrics():
     """all-mismatch inputs drive the 8-bit path metrics as high as they can get"""
-    for kind, t in ((0, O.T_SB1), (1, O.T_NDB), (2, O.T_SCH_F)):
+    for kind, t in ((0, O.T_SB1), (1, O.T_NDB), (2, O.T_SCH_F), (3, O.T_SCH_HU)):
         K, n2, n1, a = O.BLK[t]
         for pattern in (np.ones(K, np.uint8), np.zeros(K, np.uint8), (np.arange(K) % 2).astype(np.uint8),
                         (np.arange(K) % 3 == 0).astype(np.uint8)):
