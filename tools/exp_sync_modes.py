@@ -21,3 +21,11 @@ hs = torch.cuda.current_stream().cuda_stream
 for rep in range(3):
     r = T.sync_stream(eng, stream, d_stream.data_ptr(), 64, hs, burst_events=False)
     g = T.sync_stream_grid(eng, plan, stream, d_stream.data_ptr(), 64, hs, burst_events=False)
+# serialised stage times of the decode that follows (HIP events between the launches)
+d_rec = torch.empty((n + 8) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+prof = T.Prof(10)
+for k in range(10):
+    plan.execute_prof(d_stream.data_ptr(), d_rec.data_ptr(), hs, prof, k)
+torch.cuda.synchronize()
+ms = prof.read(10)[3:].mean(axis=0)
+print("decode stages (us):", {nm: round(float(v) * 1e3, 1) for nm, v in zip(T.Prof.stage_names(), ms)})
