@@ -347,10 +347,11 @@ struct tg_stream_params {
 	uint64_t len;		/* stream length in bytes */
 	uint32_t nslots;
 	uint32_t chunk;		/* bytes per tetra_burst_sync_in() call being emulated */
+	int32_t cshift;		/* log2(chunk) when it is a power of two, else -1 */
 	uint32_t y32, y6, n22, p22;
 };
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
 {
@@ -382,12 +383,15 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	for (uint32_t slot = wave; slot < prm.nslots; slot += nwaves) {
 		const uint64_t bs = prm.anchor + (uint64_t)slot * TG_SLOT_BITS;
 		const uint8_t *base = stream + bs;
-		/* 640 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack) */
+		/* 640 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack).  (Requesting the
+		 * next slot before this one is searched was tried: 90 VGPRs instead of 64 cost three waves per SIMD,
+		 * 0.86 ms instead of 0.76 ms per 1 M slots.) */
 		const uint32_t d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
 		const uint32_t d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
 		const uint32_t d2 = (lane < 32) ? *(const tg_u32_unaligned *)(base + 512 + 4 * lane) : 0u;
 
-		uint64_t fed = ((bs + TG_SLOT_BITS + prm.chunk - 1) / prm.chunk) * prm.chunk;
+		uint64_t fed = bs + TG_SLOT_BITS + prm.chunk - 1;
+		fed = prm.cshift >= 0 ? (fed >> prm.cshift) << prm.cshift : (fed / prm.chunk) * prm.chunk;
 		if (fed > prm.len)
 			fed = prm.len;
 		const uint32_t w = (uint32_t)(fed - bs);			/* search window, >= 510 */
@@ -422,10 +426,16 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 				const uint32_t c = 64 * r + lane;
 				const uint32_t b0 = (uint32_t)B[r], b1 = (uint32_t)(B[r] >> 32);
 				const uint32_t b2 = (uint32_t)B[r + 1], b3 = (uint32_t)(B[r + 1] >> 32);
-				const uint32_t w0 = half ? b1 : b0, w1 = half ? b2 : b1, w2 = half ? b3 : b2;
+				const uint32_t w0 = half ? b1 : b0, w1 = half ? b2 : b1;
 				const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bit);
-				const uint32_t win2 = __builtin_amdgcn_alignbit(w2, w1, bit);
-				const bool y38 = (win == prm.y32) && ((win2 & 0x3f) == prm.y6);
+				/* the last 6 bits of the 38-bit SYNC sequence are only looked at where its first 32 match
+				 * (wave-uniform branch: almost never taken outside a SYNC burst's round) */
+				bool y38 = (win == prm.y32);
+				if (__ballot(y38)) {
+					const uint32_t w2 = half ? b3 : b2;
+					const uint32_t win2 = __builtin_amdgcn_alignbit(w2, w1, bit);
+					y38 = y38 && ((win2 & 0x3f) == prm.y6);
+				}
 				if (r < 8) {
 					const unsigned long long my = __ballot(y38 && c < TG_SLOT_BITS && c + 38 <= vis);
 					if (my) {
@@ -1309,6 +1319,7 @@ extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64
 	prm.len = len;
 	prm.nslots = nslots;
 	prm.chunk = chunk;
+	prm.cshift = (chunk & (chunk - 1)) ? -1 : __builtin_ctz(chunk);
 	prm.y32 = host_pattern_bits(tsq_y, 0, 32);
 	prm.y6 = host_pattern_bits(tsq_y, 32, 6);
 	prm.n22 = host_pattern_bits(tsq_n, 0, 22);
