@@ -383,6 +383,17 @@ int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
 
 /*
+ * Optional, off by default: decode the AACH's shortened (30,14) Reed-Muller word instead of keeping its first
+ * 14 received bits like the reference (lower_mac/tetra_lower_mac.c:268-274; tetra_rm3014.c:88-96 is a stub).
+ * Minimum-distance (syndrome / coset-leader) decoding, ties to the numerically smallest error pattern; up to
+ * 3 bit errors are always corrected (d_min = 8).  The number of corrected bits is stored at byte 28 of the
+ * record.  tgpu_rm3014_decode() is the same decoder on the host: rx30 bit 29 = first received bit.
+ */
+int tgpu_plan_set_rm_decode(struct tgpu_plan *plan, int on);
+int tgpu_channel_set_rm_decode(struct tgpu_channel *ch, int on);
+int tgpu_rm3014_decode(uint32_t rx30, uint16_t *data14, unsigned int *nerr);
+
+/*
  * Block mode -- the unit tp_sap_udata_ind() receives (phy/tetra_burst.h:18, lower_mac/tetra_lower_mac.c:143):
  * blocks of type-5 bits on their own, without a burst around them.  blk_off[i] = byte offset of block i's
  * bits (1 bit per byte: 120 for SB1, 216 for SB2/NDB, 168 for SCH/HU, 432 for SCH/F, 30 for BBK) in the

@@ -356,6 +356,35 @@ uint32_t orc_rm3014_compute(uint16_t in)
 	return v;
 }
 
+/* Minimum-distance decoding by exhaustive search (test reference for the product's optional syndrome
+ * decoder; the reference itself has no decoder, tetra_rm3014.c:88-96 is a stub): the codeword closest to
+ * rx30, ties -> the one whose error pattern rx30 ^ cw is numerically smallest. */
+uint16_t orc_rm3014_decode_ml(uint32_t rx30, unsigned *nerr)
+{
+	static uint32_t cw[1 << 14];
+	static int ready;
+	if (!ready) {
+		for (uint32_t d = 0; d < (1u << 14); d++)
+			cw[d] = orc_rm3014_compute((uint16_t)d);
+		ready = 1;
+	}
+	rx30 &= 0x3fffffffu;
+	uint32_t best_e = 0xffffffffu, best_d = 0;
+	int best_w = 99;
+	for (uint32_t d = 0; d < (1u << 14); d++) {
+		const uint32_t e = cw[d] ^ rx30;
+		const int w = __builtin_popcount(e);
+		if (w < best_w || (w == best_w && e < best_e)) {
+			best_w = w;
+			best_e = e;
+			best_d = d;
+		}
+	}
+	if (nerr)
+		*nerr = (unsigned)best_w;
+	return (uint16_t)best_d;
+}
+
 /* ======================================================================
  * row T -- TDMA time.  tetra_tdma.c:27-94.
  * ==================================================================== */

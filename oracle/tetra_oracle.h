@@ -232,6 +232,10 @@ void orc_rx_feed(struct orc_rx *rx, const uint8_t *bits, size_t len, unsigned ch
 void orc_burst_rx_cb(struct orc_rx *rx, const uint8_t *burst, unsigned len, int type);
 void orc_tp_sap_udata_ind(struct orc_rx *rx, int type, int blk_num, const uint8_t *bits, unsigned len);
 
+/* exhaustive minimum-distance decoder of the (30,14) code (no counterpart in the reference; checks the product's
+ * optional decoder).  rx30 bit 29 = first received bit.  Returns the 14 data bits (bit 13 = first). */
+uint16_t orc_rm3014_decode_ml(uint32_t rx30, unsigned *nerr);
+
 /* traffic dump block (tetra_lower_mac.c:213-231): 690 int16 from the descrambled type-4 bits of a traffic block */
 void orc_traffic_block(const uint8_t *type4, unsigned len, int16_t *block690);
 

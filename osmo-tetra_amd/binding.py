@@ -106,6 +106,9 @@ def lib():
     L.tgpu_plan_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_plan_destroy.argtypes = [C.c_void_p]
     L.tgpu_plan_load.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p, C.c_uint32, u32p]
+    L.tgpu_rm3014_decode.argtypes = [C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint)]
+    L.tgpu_plan_set_rm_decode.argtypes = [C.c_void_p, C.c_int]
+    L.tgpu_channel_set_rm_decode.argtypes = [C.c_void_p, C.c_int]
     L.tgpu_traffic_block.argtypes = [u8p, C.c_uint, C.POINTER(C.c_int16)]
     L.tgpu_traffic_block.restype = None
     L.tgpu_channel_burst_rx.argtypes = [C.c_void_p, u8p, C.c_uint, C.c_int, C.c_uint32]
@@ -206,6 +209,9 @@ class Plan:
         _chk(lib().tgpu_plan_load(self._h, n, off.ctypes.data_as(u64p), typ.ctypes.data_as(u8p),
                                   chan.ctypes.data_as(u32p), nchan, codes.ctypes.data_as(u32p)), "tgpu_plan_load")
         self.nslots, self.nchan = n, nchan
+
+    def set_rm_decode(self, on=True):
+        _chk(lib().tgpu_plan_set_rm_decode(self._h, int(bool(on))), "tgpu_plan_set_rm_decode")
 
     def load_blocks(self, blk_off, blk_type, blk_code):
         """tgpu_plan_load_blocks: type-5 blocks on their own (enum tp_sap_data_type per block, code per block)"""
@@ -401,6 +407,13 @@ def _sync_result_to_py(res):
     return out
 
 
+def rm3014_decode(rx30):
+    """tgpu_rm3014_decode: (14 data bits, corrected bit errors) for a received 30-bit AACH word (bit 29 first)"""
+    d, n = C.c_uint16(0), C.c_uint(0)
+    _chk(lib().tgpu_rm3014_decode(int(rx30), C.byref(d), C.byref(n)), "tgpu_rm3014_decode")
+    return int(d.value), int(n.value)
+
+
 def traffic_block(type4):
     """tgpu_traffic_block: the reference's 690-word traffic dump block from descrambled type-4 bits"""
     t = _np_u8(type4)
@@ -504,6 +517,9 @@ class Channel:
              "tgpu_channel_create")
         self.trs = RxState()
         self.trs.burst_cb_priv = self._h
+
+    def set_rm_decode(self, on=True):
+        _chk(lib().tgpu_channel_set_rm_decode(self._h, int(bool(on))), "tgpu_channel_set_rm_decode")
 
     def set_traffic(self, v):
         lib().tgpu_channel_set_traffic(self._h, int(v))

@@ -53,6 +53,7 @@ struct tgpu_plan {
 	uint32_t *h_grid;	/* pinned host mirror of d_grid */
 	int packed_ready;	/* stream mode: d_packed was filled by k_front_stream (slot = grid slot), k_front is skipped */
 	int block_mode;		/* tgpu_plan_load_blocks(): items are type-5 blocks, not slots */
+	int rm_decode;		/* tgpu_plan_set_rm_decode(): correct the BBK with the RM(30,14) decoder */
 	uint32_t *d_list_168, *d_list_bbk;	/* block mode only (in d_up) */
 	uint32_t n168, nbbk;
 	hipStream_t side;	/* k_vit<216> and k_vit<432> are independent: they run side by side */
@@ -439,7 +440,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	MARK(1);
 	if (p->nslots && !p->static_masks) {
 		if ((rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, p->nsb, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->block_mode, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->rm_decode ? TGK_F_RM : 0, stream)))
 			return rc;
 	}
 	MARK(2);
@@ -467,13 +468,13 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	}
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_216, p->d_list_216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->block_mode, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->rm_decode ? TGK_F_RM : 0, stream)))
 			return rc;
 	}
 	MARK(5);
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_432, p->d_list_432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->block_mode,
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->rm_decode ? TGK_F_RM : 0,
 				  fork ? (void *)p->side : stream)))
 			return rc;
 	}
@@ -486,6 +487,22 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	}
 	MARK(6);
 #undef MARK
+	return TGPU_OK;
+}
+
+int tgpu_plan_set_rm_decode(struct tgpu_plan *p, int on)
+{
+	if (!p)
+		return TGPU_EINVAL;
+	if (on) {
+		const uint32_t *t = tgi_rm_leader_table();
+		if (!t)
+			return TGPU_ENOMEM;
+		int rc = tgk_rm_enable(t, tgi_rm_parity());
+		if (rc)
+			return rc;
+	}
+	p->rm_decode = on != 0;
 	return TGPU_OK;
 }
 
@@ -607,9 +624,10 @@ static int plan_run_blocks(struct tgpu_plan *p, const uint8_t *d_bits, uint8_t *
 		{ TG_KIND_168, p->d_list_168, p->n168 }, { TG_KIND_SB1, p->d_list_sb, p->nsb } };
 	for (int i = 0; i < 4; i++)
 		if ((rc = tgk_vit(run[i].kind, run[i].list, run[i].n, p->d_packed, p->d_masks, p->d_maskidx, d_rec, p->d_sb_ok,
-				  p->d_sb_code, NULL, NULL, 1, stream)))
+				  p->d_sb_code, NULL, NULL, TGK_F_BLOCK, stream)))
 			return rc;
-	return tgk_bbk_blocks(p->d_list_bbk, p->nbbk, p->d_packed, p->d_masks, p->d_maskidx, d_rec, stream);
+	return tgk_bbk_blocks(p->d_list_bbk, p->nbbk, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
+			      p->rm_decode ? TGK_F_RM : 0, stream);
 }
 
 int tgpu_plan_execute(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream)

@@ -18,11 +18,11 @@ int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uin
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
 	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */,
-	    const uint32_t *d_softarea /* NULL: hard input */, int block_mode, void *stream);
+	    const uint32_t *d_softarea /* NULL: hard input */, int flags /* TGK_F_* */, void *stream);
 /* block mode: descriptor = byte offset | table index (TG_KIND_* or 4 = BBK) << 56 | tp_sap type << 48 */
 int tgk_front_blocks(const uint8_t *d_bits, const uint64_t *d_desc, uint32_t nblocks, uint32_t *d_packed, void *stream);
 int tgk_bbk_blocks(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,
-		   const uint32_t *d_maskidx, uint8_t *d_rec, void *stream);
+		   const uint32_t *d_maskidx, uint8_t *d_rec, int flags, void *stream);
 int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc, uint32_t nslots,
 		   uint32_t *d_area, uint32_t *d_packed, uint8_t *d_rec, void *stream);
 int tgk_float_to_bits(const float *d_in, unsigned long long n, uint8_t *d_bits, int8_t *d_soft, void *stream);
@@ -38,6 +38,14 @@ int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_
 int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uint32_t n, uint32_t *d_blk,
 		   uint32_t *d_slot_chan, int32_t *d_slot_sbord, uint32_t *d_list_sb, uint32_t *d_list_216,
 		   uint32_t *d_list_432, void *stream);
+
+/* optional RM(30,14) decoder (tg_rm.c): coset-leader table (65536 words, built on first use) and the generator's
+ * parity rows; tgk_rm_enable() uploads both for the kernels (flag TGK_F_RM of tgk_vit / tgk_bbk_blocks) */
+const uint32_t *tgi_rm_leader_table(void);
+const uint16_t *tgi_rm_parity(void);
+int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity);
+#define TGK_F_BLOCK 1	/* tgk_vit flags: items are blocks on their own */
+#define TGK_F_RM    2	/* correct the BBK with the RM(30,14) decoder before its first 14 bits are kept */
 
 /* plan internals used by the stream synchroniser (tg_stream.c) */
 struct tgpu_plan;

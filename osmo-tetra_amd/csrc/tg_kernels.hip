@@ -37,6 +37,23 @@ struct tg_const_tables {
 
 __constant__ tg_const_tables c_tab;
 
+/* optional RM(30,14) decoder of the BBK (tg_rm.c): coset leaders by syndrome, generator parity rows */
+__device__ const uint32_t *g_rm_leader;
+__constant__ uint16_t c_rm_parity[14];
+
+/* bb: bit p = p-th received BBK bit (descrambled).  Returns the corrected word in the same order. */
+__device__ __forceinline__ uint32_t rm3014_correct(uint32_t bb, uint32_t &nerr)
+{
+	const uint32_t rx = __builtin_bitreverse32(bb & 0x3fffffffu) >> 2;	/* codeword bit 29 = first received bit */
+	uint32_t syn = rx & 0xffff;
+#pragma unroll
+	for (int i = 0; i < 14; i++)
+		syn ^= ((rx >> (29 - i)) & 1) ? c_rm_parity[i] : 0u;
+	const uint32_t e = g_rm_leader[syn];
+	nerr = __builtin_popcount(e);
+	return __builtin_bitreverse32(rx ^ e) >> 2;
+}
+
 /* ------------------------------------------------------------------------- */
 /* k_front                                                                   */
 /* ------------------------------------------------------------------------- */
@@ -296,7 +313,7 @@ void k_front_blocks(const uint8_t *__restrict__ bits, const uint64_t *__restrict
 /* BBK blocks: descramble, keep the first 14 bits (lower_mac/tetra_lower_mac.c:268-274), crc_ok = 1 */
 __global__ __launch_bounds__(256)
 void k_bbk_blocks(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t *__restrict__ packed,
-		  const uint32_t *__restrict__ masks, const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec)
+		  const uint32_t *__restrict__ masks, const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec, int kflags)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nitems)
@@ -304,8 +321,12 @@ void k_bbk_blocks(const uint32_t *__restrict__ items, uint32_t nitems, const uin
 	const uint32_t b = items[i];
 	const uint32_t midx = maskidx[b];
 	const uint32_t meta = packed[(size_t)b * TG_PACKED_WORDS + TG_PW_META];
-	const uint32_t bb = packed[(size_t)b * TG_PACKED_WORDS + TG_PW_BBK] ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
+	uint32_t bb = packed[(size_t)b * TG_PACKED_WORDS + TG_PW_BBK] ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
 	uint8_t *r = rec + (size_t)b * TG_REC_BYTES;
+	uint32_t nerr = 0;
+	if (kflags & TGK_F_RM)
+		bb = rm3014_correct(bb, nerr);
+	r[TG_REC_BBK_NERR] = (uint8_t)nerr;
 	uint4 o;
 	o.x = spread4(bb);
 	o.y = spread4(bb >> 4);
@@ -685,9 +706,10 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
 	   uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code, uint8_t *__restrict__ wire,
-	   const uint32_t *__restrict__ softarea, int block_mode)
+	   const uint32_t *__restrict__ softarea, int kflags)
 {
 	constexpr int NBLK = vit_cfg<KIND>::NBLK;
+	const bool block_mode = kflags & TGK_F_BLOCK;
 	constexpr int NW = NBLK / 2;			/* code words */
 	constexpr int TYPE1 = vit_cfg<KIND>::TYPE1;
 	constexpr int NOD = (NBLK + 3) / 4;		/* dwords of decoded bits */
@@ -973,7 +995,11 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 					bbraw |= ((((sb[q] >> 7) & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
 			} else
 				bbraw = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_BBK];
-			const uint32_t bb = bbraw ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
+			uint32_t bb = bbraw ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
+			uint32_t nerr = 0;
+			if (kflags & TGK_F_RM)		/* non-default: minimum-distance decoding of the (30,14) word first */
+				bb = rm3014_correct(bb, nerr);
+			r[TG_REC_BBK_NERR] = (uint8_t)nerr;
 			uint4 o;
 			o.x = spread4(bb);
 			o.y = spread4(bb >> 4);
@@ -1274,6 +1300,18 @@ extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 	return (int)hipGetLastError();
 }
 
+extern "C" int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity)
+{
+	static uint32_t *d_leader;	/* one table per process, never freed */
+	if (!d_leader) {
+		HIPCHK(hipMalloc((void **)&d_leader, 65536 * 4));
+		HIPCHK(hipMemcpy(d_leader, h_leader, 65536 * 4, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_rm_leader), &d_leader, sizeof(d_leader)));
+		HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rm_parity), h_parity, 14 * 2));
+	}
+	return 0;
+}
+
 extern "C" int tgk_front_blocks(const uint8_t *d_bits, const uint64_t *d_desc, uint32_t nblocks, uint32_t *d_packed, void *stream)
 {
 	if (!nblocks)
@@ -1286,12 +1324,12 @@ extern "C" int tgk_front_blocks(const uint8_t *d_bits, const uint64_t *d_desc, u
 }
 
 extern "C" int tgk_bbk_blocks(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,
-			      const uint32_t *d_maskidx, uint8_t *d_rec, void *stream)
+			      const uint32_t *d_maskidx, uint8_t *d_rec, int flags, void *stream)
 {
 	if (!nitems)
 		return 0;
 	hipLaunchKernelGGL(k_bbk_blocks, dim3((nitems + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_items, nitems,
-			   d_packed, d_masks, d_maskidx, d_rec);
+			   d_packed, d_masks, d_maskidx, d_rec, flags);
 	return (int)hipGetLastError();
 }
 
@@ -1367,14 +1405,14 @@ extern "C" int tgk_float_to_bits_afc(const float *d_in, unsigned long long n, ui
 
 extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 		       const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
-		       uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire, const uint32_t *d_soft, int block_mode,
+		       uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire, const uint32_t *d_soft, int flags,
 		       void *stream)
 {
 	if (!nitems)
 		return 0;
 	const dim3 grid((nitems + 63) / 64), block(64);
 	hipStream_t s = (hipStream_t)stream;
-#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire, d_soft, block_mode)
+#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire, d_soft, flags)
 	const int hm = d_soft ? 2 : tgk_hist_mode;
 	switch (kind) {
 	case TG_KIND_SB1:

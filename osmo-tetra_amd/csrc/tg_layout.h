@@ -105,6 +105,7 @@
  *   @16  u32 SYNC-PDU fields cc | tn<<8 | fn<<16 | mn<<24      (SYNC slots)
  *   @20  u32 SYNC-PDU fields mcc | mnc<<16
  *   @24  u32 scrambling code derived from the SYNC PDU
+ *   @28  u8  BBK bit errors corrected by the optional RM(30,14) decoder
  *   @32  14 B  BBK type-1 bits (1 bit per byte)
  *   @48  SB1 (60 B) / BLK1 (124 B) / SCH-F (268 B) type-1 bits
  *   @176 SB2 / BLK2 (124 B) type-1 bits
@@ -119,6 +120,7 @@
 #define TG_REC_SBF0       16
 #define TG_REC_SBF1       20
 #define TG_REC_SBCODE     24
+#define TG_REC_BBK_NERR   28	/* u8: bit errors the optional RM(30,14) decoder corrected in the BBK (0 when it is off) */
 #define TG_REC_BBK        32
 #define TG_REC_BITS1      48
 #define TG_REC_BITS2      176

@@ -225,6 +225,11 @@ void tgpu_channel_bind_flags(struct tgpu_channel *ch, int *is_traffic, bool *blk
 	ch->blk2_stolen = blk2_stolen ? blk2_stolen : &ch->loc_blk2;
 }
 
+int tgpu_channel_set_rm_decode(struct tgpu_channel *ch, int on)
+{
+	return ch ? tgpu_plan_set_rm_decode(ch->plan, on) : TGPU_EINVAL;
+}
+
 void tgpu_channel_set_traffic(struct tgpu_channel *ch, int is_traffic)
 {
 	*ch->is_traffic = is_traffic;

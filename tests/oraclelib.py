@@ -272,6 +272,20 @@ def decode_block(t, type5, scramb_init, use_acc=0):
             np.frombuffer(res.type2, np.uint8, BLK[t][1]).copy())
 
 
+def rm3014_decode_ml(rx30):
+    L = lib()
+    L.orc_rm3014_decode_ml.restype = C.c_uint16
+    n = C.c_uint(0)
+    d = L.orc_rm3014_decode_ml(C.c_uint32(int(rx30)), C.byref(n))
+    return int(d), int(n.value)
+
+
+def rm3014_compute(data14):
+    L = lib()
+    L.orc_rm3014_compute.restype = C.c_uint32
+    return int(L.orc_rm3014_compute(C.c_uint16(int(data14))))
+
+
 def traffic_block(type4):
     t = np.ascontiguousarray(type4, np.uint8)
     out = np.zeros(690, np.int16)

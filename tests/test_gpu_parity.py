@@ -841,3 +841,67 @@ def test_block_mode_all_block_types(T, eng, ber):
     with pytest.raises(T.TgpuError):
         plan.load_blocks(np.zeros(1, np.uint64), np.array([9], np.uint8), np.zeros(1, np.uint32))
     plan.close()
+
+
+def test_rm3014_decode_flag(T, eng):
+    """optional AACH decoding: with the flag on, BBK bit errors are corrected exactly like the oracle's exhaustive
+    minimum-distance decoder (slot mode and block mode); with the flag off the reference's behaviour stays"""
+    import torch
+    rng = np.random.default_rng(91)
+    n = 600
+    ty = rng.choice([O.TRAIN_NORM_1, O.TRAIN_NORM_2], n).astype(np.uint8)   # (a SYNC burst would switch the code)
+    slots = T.synth_slots(ty, seed=9, scramb_init=0)
+    bbk_pos = {}
+    norm_pos = list(range(230, 244)) + list(range(266, 282))
+    nflip = rng.integers(0, 6, n)
+    for i in range(n):
+        pos = bbk_pos.get(int(ty[i]), norm_pos)
+        for b in rng.choice(30, int(nflip[i]), replace=False):
+            slots[i, pos[int(b)]] ^= 1
+    rec_off, p_off, _ = run_plan(T, eng, slots, ty)
+    check_against_oracle(T, rec_off, ty, slots, 0)           # flag off: unchanged reference behaviour
+    assert (rec_off[:, 28] == 0).all()
+    # flag on
+    buf = np.zeros(n * 510 + 64, np.uint8)
+    for i in range(n):
+        buf[i * 510:i * 510 + 510] = slots[i]
+    d = torch.from_numpy(buf).cuda()
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.set_rm_decode(True)
+    plan.load(np.arange(n, dtype=np.uint64) * 510, ty)
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rec_on = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+    p_on = T.parse_records(rec_on)
+    fixed = 0
+    for i in range(n):
+        pos = bbk_pos.get(int(ty[i]), norm_pos)
+        rx = 0
+        for b in range(30):                                  # scramb_init 0 -> mask 0: stream bits are type-4 bits
+            rx |= int(slots[i, pos[b]]) << (29 - b)
+        want, werr = O.rm3014_decode_ml(rx)
+        got = 0
+        for b in range(14):
+            got |= int(p_on["bbk"][i][b]) << (13 - b)
+        assert got == want and rec_on[i, 28] == werr, (i, nflip[i])
+        if nflip[i] <= 3:
+            assert werr == nflip[i]
+            fixed += 1
+    assert fixed > n // 3
+    # everything but the BBK bytes and the error count is the same record
+    same = np.ones(T.REC_BYTES, bool); same[28] = False; same[32:46] = False
+    assert (rec_on[:, same] == rec_off[:, same]).all()
+    plan.close()
+    # block mode
+    bb = np.stack([slots[i, bbk_pos.get(int(ty[i]), norm_pos)] for i in range(n)])
+    dblk = torch.from_numpy(bb.reshape(-1)).cuda()
+    d_rec2 = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    bplan = T.Plan(eng, n, 1)
+    bplan.set_rm_decode(True)
+    bplan.load_blocks(np.arange(n, dtype=np.uint64) * 30, np.full(n, O.T_BBK, np.uint8), np.zeros(n, np.uint32))
+    bplan.execute(dblk.data_ptr(), d_rec2.data_ptr())
+    torch.cuda.synchronize()
+    rec_b = d_rec2.cpu().numpy().reshape(n, T.REC_BYTES)
+    assert (rec_b[:, 32:46] == rec_on[:, 32:46]).all() and (rec_b[:, 28] == rec_on[:, 28]).all()
+    bplan.close()

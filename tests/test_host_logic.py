@@ -170,3 +170,21 @@ def test_traffic_dump_block_format():
         full = np.concatenate([t4, np.zeros(432 - n, np.uint8)])
         assert (body == np.where(full == 1, -127, 127)).all()
         assert not got[436:460].any() and not got[461:575].any() and not got[576:].any()
+
+
+def test_rm3014_decoder_host():
+    """the optional (30,14) decoder (syndrome table) == exhaustive minimum-distance search incl. the tie rule;
+    every pattern of up to 3 bit errors is corrected (d_min = 8)"""
+    rng = np.random.default_rng(30)
+    for _ in range(300):
+        d = int(rng.integers(0, 1 << 14))
+        cw = O.rm3014_compute(d)
+        for nflip in (0, 1, 2, 3):
+            e = 0
+            for b in rng.choice(30, nflip, replace=False):
+                e |= 1 << int(b)
+            got, n = T.rm3014_decode(cw ^ e)
+            assert got == d and n == nflip
+    for _ in range(400):                       # arbitrary words, many of them beyond the guaranteed radius
+        rx = int(rng.integers(0, 1 << 30))
+        assert T.rm3014_decode(rx) == O.rm3014_decode_ml(rx)
