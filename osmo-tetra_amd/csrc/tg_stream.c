@@ -439,7 +439,7 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 		}
 		bs += TG_SLOT_BITS;
 		nfs += TG_SLOT_BITS;
-		if (grid_for + TG_SLOT_BITS == bs) {	/* stay on the grid without dividing */
+		if (ongrid && grid_for + TG_SLOT_BITS == bs) {	/* stay on the grid without dividing */
 			grid_for = bs;
 			gi++;
 		}

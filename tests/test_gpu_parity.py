@@ -905,3 +905,77 @@ def test_rm3014_decode_flag(T, eng):
     rec_b = d_rec2.cpu().numpy().reshape(n, T.REC_BYTES)
     assert (rec_b[:, 32:46] == rec_on[:, 32:46]).all() and (rec_b[:, 28] == rec_on[:, 28]).all()
     bplan.close()
+
+
+def test_fuzz_damaged_streams_end_to_end(T, eng):
+    """random streams with random damage (bit flips, inserted / deleted bytes, spurious training sequences, zeroed
+    stretches, payload noise): channel API (records, events, TDMA time, codes) and the stream-mode plan paths
+    (slot table and grid) all equal the oracle's tetra-rx equivalent"""
+    import torch
+    from test_stream_sync_cpu import SEQ_Y, SEQ_N
+    rng = np.random.default_rng(4242)
+    hs = torch.cuda.current_stream().cuda_stream
+    ngridruns = 0
+    for trial in range(14):
+        stream, _ = synth.frame_stream(seed=int(rng.integers(1, 1 << 30)), nframes=int(rng.integers(2, 6)),
+                                       lead_in=int(rng.integers(0, 600)), pad=int(rng.integers(600, 900)),
+                                       ber=float(rng.choice([0.0, 0.0, 0.02])))
+        s = stream.copy()
+        for _ in range(int(rng.integers(0, 5))):
+            kind = int(rng.integers(0, 6))
+            p = int(rng.integers(0, len(s) - 60))
+            if kind == 0:
+                s[p] ^= 1
+            elif kind == 1:
+                s = np.concatenate([s[:p], rng.integers(0, 2, int(rng.integers(1, 40))).astype(np.uint8), s[p:]])
+            elif kind == 2:
+                s = np.concatenate([s[:p], s[p + int(rng.integers(1, 40)):]])
+            elif kind == 3:
+                s[p:p + 38] = SEQ_Y
+            elif kind == 4:
+                s[p:p + 22] = SEQ_N
+            else:
+                s[p:p + int(rng.integers(1, 200))] = 0
+        s = np.ascontiguousarray(s)
+        want, wev = O.run_rx(s)
+        ch = T.Channel(eng, batch_slots=int(rng.choice([1, 3, 64])))
+        ch.feed(s)
+        ch.flush()
+        assert_same_records(ch.records, want)
+        assert ch.events == wev
+        ch.close()
+        # stream mode: slot table, then grid (when the stream stays on one grid)
+        d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+        res = T.sync_stream(eng, s, d.data_ptr())
+        assert res["events"] == wev
+        n = len(res["slots"])
+        if not n:
+            continue
+        ch2 = T.Channel(eng, batch_slots=1)
+        plan = T.Plan(eng, n, 1)
+        plan.load_slots(res, ch2.scramb_init())
+        d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+        torch.cuda.synchronize()
+        rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+        ch2.deliver(res["slots"], s, rec)
+        assert_same_records(ch2.records, want)
+        ch2.close()
+        plan.close()
+        gplan = T.Plan(eng, len(s) // 510 + 1, 1)
+        g = T.sync_stream_grid(eng, gplan, s, d.data_ptr())
+        assert g["events"] == wev
+        if g["noffgrid"] == 0 and g["ngrid"]:
+            ngridruns += 1
+            on = T.grid_indices(g)
+            assert len(on) == n
+            d_rec2 = torch.zeros(g["ngrid"] * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+            gplan.execute(d.data_ptr(), d_rec2.data_ptr(), hs)
+            torch.cuda.synchronize()
+            got = d_rec2.cpu().numpy().reshape(-1, T.REC_BYTES)[on]
+            pw, pg = T.parse_records(rec), T.parse_records(got)
+            for k in pw:
+                if k != "slot":
+                    assert (np.asarray(pw[k]) == np.asarray(pg[k])).all(), (trial, k)
+        gplan.close()
+    assert ngridruns >= 3

@@ -213,3 +213,31 @@ def test_many_sync_sequences_per_slot_with_summary():
         first = res["slots"][0][0]
         ys = emul_ysum(s, first)
         assert (ys[ys != 0xFFFF] & 0x8000).any() or trial > 0
+
+
+def test_fuzz_random_mutations():
+    """random streams with random damage -- bit flips, inserted / deleted bytes (the slot grid shifts), spurious
+    SYNC and normal training sequences, zeroed stretches -- and random read sizes: every form of the walk
+    (bytes only, classification words, + SYNC summaries, without per-burst events, grid bitmap) == oracle"""
+    rng = np.random.default_rng(2024)
+    for trial in range(70):
+        stream, _ = synth.frame_stream(seed=int(rng.integers(1, 1 << 30)), nframes=int(rng.integers(2, 5)),
+                                       lead_in=int(rng.integers(0, 600)), pad=int(rng.integers(0, 900)))
+        s = stream.copy()
+        for _ in range(int(rng.integers(0, 6))):
+            kind = int(rng.integers(0, 6))
+            p = int(rng.integers(0, len(s) - 60))
+            if kind == 0:
+                s[p] ^= 1
+            elif kind == 1:
+                s = np.concatenate([s[:p], rng.integers(0, 2, int(rng.integers(1, 40))).astype(np.uint8), s[p:]])
+            elif kind == 2:
+                s = np.concatenate([s[:p], s[p + int(rng.integers(1, 40)):]])
+            elif kind == 3:
+                s[p:p + 38] = SEQ_Y
+            elif kind == 4:
+                s[p:p + 22] = SEQ_N
+            else:
+                s[p:p + int(rng.integers(1, 200))] = 0
+        chunk = int(rng.choice([64, 64, 64, 32, 128, 100, 510, 7]))
+        check(s, chunk=chunk, with_cls=(chunk <= 128))
