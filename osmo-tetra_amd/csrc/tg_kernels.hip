@@ -1,14 +1,19 @@
 /*
  * tg_kernels.hip -- the HIP kernels of the TETRA lower-MAC receive path (gfx950).
  *
- *   k_front   : slot bytes -> packed, de-interleaved code words   (rows D, I, U of SURVEY 8(a))
- *   k_vit<>   : descramble + Viterbi + CRC-16 + type-1 output      (rows X, V, C, R, L)
- *   k_fill_*  : forward-fill of the cell scrambling code           (row L, feedback loop 1)
- *   k_masks   : scrambling sequence -> masks in code-word layout   (row X)
+ *   k_front          : slot bytes -> packed, de-interleaved code words   (rows D, I, U of SURVEY 8(a))
+ *   k_front_stream   : the same on a slot grid + training-sequence search  (rows F, S; config 3)
+ *   k_front_blocks   : the same for blocks handed over on their own      (block mode, the tp_sap_udata_ind unit)
+ *   k_front_soft, k_float_to_bits(_afc) : float phases / soft values in   (row B, config 5)
+ *   k_vit<KIND,HMODE>: descramble + Viterbi + CRC-16 + type-1 output      (rows X, V, C, R, L)
+ *   k_bbk_blocks     : BBK blocks of block mode                           (row R)
+ *   k_fill_*         : forward-fill of the cell scrambling code           (row L, feedback loop 1)
+ *   k_masks          : scrambling sequence -> masks in code-word layout   (row X)
+ *   k_grid_*         : stream mode: per-slot arrays and item lists from classification words + bitmap
  *
- * No MFMA anywhere: there is no dense contraction on this path.  The trellis kernels
- * are VALU-bound packed-u16 integer work (one lane per trellis), the front kernel is a
- * byte gather bounded by HBM.
+ * No MFMA anywhere: there is no dense contraction on this path.  The trellis kernels are VALU-issue bound
+ * packed-u16 integer work (one lane per trellis); the front kernels are byte gathers, part HBM, part issue bound
+ * (DESIGN.md section 4).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
