@@ -697,6 +697,136 @@ __device__ __forceinline__ uint32_t hist_byte(uint32_t w0, uint32_t w1, uint32_t
 }
 
 /*
+ * What follows the decoded bits of a block, shared by the trellis kernels and the clean-block fast path:
+ * CRC-16, type-1 bits at one byte per bit, record header / BBK / SYNC-PDU fields, optional wire record.
+ * od[]: decoded type-2 bits, LSB first (bit i = input bit i of the encoder).
+ */
+template <int KIND, int HMODE>
+__device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::NBLK + 3) / 4 + 1], const uint16_t *s_crc, bool valid,
+					    uint32_t slot, uint32_t which, uint32_t idx, uint32_t midx,
+					    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
+					    uint8_t *__restrict__ rec, uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code,
+					    uint8_t *__restrict__ wire, const uint32_t *__restrict__ softarea, int kflags)
+{
+	constexpr int NBLK = vit_cfg<KIND>::NBLK;
+	constexpr int TYPE1 = vit_cfg<KIND>::TYPE1;
+	const bool block_mode = kflags & TGK_F_BLOCK;
+	/* CRC-16 over type1 + 16 bits = (NBLK-1) bytes + 4 bits (lower_mac/tetra_lower_mac.c:258) */
+	uint32_t crc = 0xffff;
+#pragma unroll
+	for (int i = 0; i < NBLK - 1; i++) {
+		const uint32_t byte = (od[i >> 2] >> ((i & 3) * 8)) & 0xff;
+		crc = ((crc << 8) & 0xffff) ^ s_crc[256 + (crc >> 8)] ^ s_crc[byte];
+	}
+	{
+		const uint32_t nib = (od[(NBLK - 1) >> 2] >> (((NBLK - 1) & 3) * 8)) & 15;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			crc ^= ((nib >> i) & 1) << 15;
+			crc = (crc & 0x8000) ? (((crc << 1) ^ 0x1021) & 0xffff) : ((crc << 1) & 0xffff);
+		}
+	}
+	const uint32_t crc_ok = (crc == 0x1d0f);
+
+	if (!valid)
+		return;
+
+	/* ---- outputs ---- */
+	uint8_t *r = rec + (size_t)slot * TG_REC_BYTES;
+	{
+		uint4 *dst = (uint4 *)(r + (which ? TG_REC_BITS2 : TG_REC_BITS1));
+		constexpr int NST = (TYPE1 + 15) / 16;
+#pragma unroll
+		for (int q = 0; q < NST; q++) {
+			const uint32_t hw = (od[q >> 1] >> ((q & 1) * 16)) & 0xffff;
+			uint4 o;
+			o.x = spread4(hw);
+			o.y = spread4(hw >> 4);
+			o.z = spread4(hw >> 8);
+			o.w = (q * 16 + 12 < TYPE1) ? spread4(hw >> 12) : 0u;	/* TYPE1 = 12 mod 16 */
+			dst[q] = o;
+		}
+	}
+	r[TG_REC_CRC_OK + which] = (uint8_t)crc_ok;
+	*(uint16_t *)(r + TG_REC_CRC + 2 * which) = (uint16_t)crc;
+
+	/* optional bit-packed copy for transport (wave-uniform branch) */
+	uint8_t *wr = wire ? wire + (size_t)slot * TG_WIRE_BYTES : nullptr;
+	if (wr) {
+		uint32_t *wb = (uint32_t *)(wr + (which ? TG_WIRE_BITS2 : TG_WIRE_BITS1));
+		constexpr int NWD = (TYPE1 + 31) / 32;
+#pragma unroll
+		for (int q = 0; q < NWD; q++)
+			wb[q] = (q == NWD - 1) ? (od[q] & ((1u << (TYPE1 & 31)) - 1)) : od[q];
+		wr[TG_WIRE_CRC_OK + which] = (uint8_t)crc_ok;
+		*(uint16_t *)(wr + TG_WIRE_CRC + 2 * which) = (uint16_t)crc;
+	}
+
+	if (KIND == TG_KIND_SB1) {
+		/* SYNC PDU fields, lower_mac/tetra_lower_mac.c:284-297 */
+		const uint32_t cc = FIELD_MSB(od, 4, 6), tn = FIELD_MSB(od, 10, 2) + 1;
+		const uint32_t fn = FIELD_MSB(od, 12, 5), mn = FIELD_MSB(od, 17, 6);
+		const uint32_t mcc = FIELD_MSB(od, 31, 10), mnc = FIELD_MSB(od, 41, 14);
+		const uint32_t code = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3u;
+		*(uint32_t *)(r + TG_REC_SBF0) = cc | (tn << 8) | (fn << 16) | (mn << 24);
+		*(uint32_t *)(r + TG_REC_SBF1) = mcc | (mnc << 16);
+		*(uint32_t *)(r + TG_REC_SBCODE) = code;
+		sb_ok[idx] = crc_ok;
+		sb_code[idx] = code;
+		if (block_mode) {	/* a block on its own: this lane also writes the header */
+			r[TG_REC_TYPE] = (uint8_t)packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
+			*(uint32_t *)(r + TG_REC_CODE) = 3u;
+			*(uint32_t *)(r + TG_REC_SLOT) = slot;
+		}
+	} else if (block_mode) {
+		/* block mode (tgpu_plan_load_blocks): one block per record, no burst around it */
+		const uint32_t meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
+		r[TG_REC_TYPE] = (uint8_t)meta;
+		r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
+		*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
+		*(uint32_t *)(r + TG_REC_SLOT) = slot;
+	} else {
+		/* BBK + header are written by the lane that owns the slot's "primary" block:
+		 * SCH/F for NORM_1, BLK1 for NORM_2, SB2 for SYNC */
+		const uint32_t meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
+		const uint32_t btype = meta & 0xff;
+		const bool primary = (KIND == TG_KIND_432) || (btype == TG_BURST_SYNC ? which == 1 : which == 0);
+		if (primary) {
+			uint32_t bbraw;
+			if (HMODE == 2) {
+				/* hard decision of the first 16 BBK soft values: bit = (value < 0) */
+				const uint32_t *sb = softarea + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + TG_SOFT_BBK / 4;
+				bbraw = 0;
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					bbraw |= ((((sb[q] >> 7) & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
+			} else
+				bbraw = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_BBK];
+			uint32_t bb = bbraw ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
+			uint32_t nerr = 0;
+			if (kflags & TGK_F_RM)		/* non-default: minimum-distance decoding of the (30,14) word first */
+				bb = rm3014_correct(bb, nerr);
+			r[TG_REC_BBK_NERR] = (uint8_t)nerr;
+			uint4 o;
+			o.x = spread4(bb);
+			o.y = spread4(bb >> 4);
+			o.z = spread4(bb >> 8);
+			o.w = spread4(bb >> 12) & 0x0000ffffu;	/* 14 type-1 bits (tetra_lower_mac.c:268-274) */
+			*(uint4 *)(r + TG_REC_BBK) = o;
+			r[TG_REC_TYPE] = (uint8_t)btype;
+			r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
+			*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
+			*(uint32_t *)(r + TG_REC_SLOT) = slot;
+			if (wr) {
+				wr[TG_WIRE_TYPE] = (uint8_t)btype;
+				wr[TG_WIRE_FLAGS] = (uint8_t)(meta >> 8);
+				*(uint32_t *)(wr + TG_WIRE_BBK) = bb & 0x3fff;
+			}
+		}
+	}
+}
+
+/*
  * HMODE 0: survivor history in LDS (16 B per lane per 8-step block).
  * HMODE 1: survivor history in VGPRs -- chunks of 32 registers (8 blocks) written through
  *          the VGPR index mode (s_set_gpr_idx_on) with a wave-uniform block index, read back
@@ -714,9 +844,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ softarea, int kflags)
 {
 	constexpr int NBLK = vit_cfg<KIND>::NBLK;
-	const bool block_mode = kflags & TGK_F_BLOCK;
 	constexpr int NW = NBLK / 2;			/* code words */
-	constexpr int TYPE1 = vit_cfg<KIND>::TYPE1;
 	constexpr int NOD = (NBLK + 3) / 4;		/* dwords of decoded bits */
 	constexpr int NCH = (NBLK + 7) / 8;		/* history chunks of 8 blocks */
 
@@ -908,120 +1036,8 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		}
 	}
 
-	/* CRC-16 over type1 + 16 bits = (NBLK-1) bytes + 4 bits (lower_mac/tetra_lower_mac.c:258) */
 	__syncthreads();	/* s_crc visible (single wave, but keep the compiler honest) */
-	uint32_t crc = 0xffff;
-#pragma unroll
-	for (int i = 0; i < NBLK - 1; i++) {
-		const uint32_t byte = (od[i >> 2] >> ((i & 3) * 8)) & 0xff;
-		crc = ((crc << 8) & 0xffff) ^ s_crc[256 + (crc >> 8)] ^ s_crc[byte];
-	}
-	{
-		const uint32_t nib = (od[(NBLK - 1) >> 2] >> (((NBLK - 1) & 3) * 8)) & 15;
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			crc ^= ((nib >> i) & 1) << 15;
-			crc = (crc & 0x8000) ? (((crc << 1) ^ 0x1021) & 0xffff) : ((crc << 1) & 0xffff);
-		}
-	}
-	const uint32_t crc_ok = (crc == 0x1d0f);
-
-	if (!valid)
-		return;
-
-	/* ---- outputs ---- */
-	uint8_t *r = rec + (size_t)slot * TG_REC_BYTES;
-	{
-		uint4 *dst = (uint4 *)(r + (which ? TG_REC_BITS2 : TG_REC_BITS1));
-		constexpr int NST = (TYPE1 + 15) / 16;
-#pragma unroll
-		for (int q = 0; q < NST; q++) {
-			const uint32_t hw = (od[q >> 1] >> ((q & 1) * 16)) & 0xffff;
-			uint4 o;
-			o.x = spread4(hw);
-			o.y = spread4(hw >> 4);
-			o.z = spread4(hw >> 8);
-			o.w = (q * 16 + 12 < TYPE1) ? spread4(hw >> 12) : 0u;	/* TYPE1 = 12 mod 16 */
-			dst[q] = o;
-		}
-	}
-	r[TG_REC_CRC_OK + which] = (uint8_t)crc_ok;
-	*(uint16_t *)(r + TG_REC_CRC + 2 * which) = (uint16_t)crc;
-
-	/* optional bit-packed copy for transport (wave-uniform branch) */
-	uint8_t *wr = wire ? wire + (size_t)slot * TG_WIRE_BYTES : nullptr;
-	if (wr) {
-		uint32_t *wb = (uint32_t *)(wr + (which ? TG_WIRE_BITS2 : TG_WIRE_BITS1));
-		constexpr int NWD = (TYPE1 + 31) / 32;
-#pragma unroll
-		for (int q = 0; q < NWD; q++)
-			wb[q] = (q == NWD - 1) ? (od[q] & ((1u << (TYPE1 & 31)) - 1)) : od[q];
-		wr[TG_WIRE_CRC_OK + which] = (uint8_t)crc_ok;
-		*(uint16_t *)(wr + TG_WIRE_CRC + 2 * which) = (uint16_t)crc;
-	}
-
-	if (KIND == TG_KIND_SB1) {
-		/* SYNC PDU fields, lower_mac/tetra_lower_mac.c:284-297 */
-		const uint32_t cc = FIELD_MSB(od, 4, 6), tn = FIELD_MSB(od, 10, 2) + 1;
-		const uint32_t fn = FIELD_MSB(od, 12, 5), mn = FIELD_MSB(od, 17, 6);
-		const uint32_t mcc = FIELD_MSB(od, 31, 10), mnc = FIELD_MSB(od, 41, 14);
-		const uint32_t code = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3u;
-		*(uint32_t *)(r + TG_REC_SBF0) = cc | (tn << 8) | (fn << 16) | (mn << 24);
-		*(uint32_t *)(r + TG_REC_SBF1) = mcc | (mnc << 16);
-		*(uint32_t *)(r + TG_REC_SBCODE) = code;
-		sb_ok[idx] = crc_ok;
-		sb_code[idx] = code;
-		if (block_mode) {	/* a block on its own: this lane also writes the header */
-			r[TG_REC_TYPE] = (uint8_t)packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
-			*(uint32_t *)(r + TG_REC_CODE) = 3u;
-			*(uint32_t *)(r + TG_REC_SLOT) = slot;
-		}
-	} else if (block_mode) {
-		/* block mode (tgpu_plan_load_blocks): one block per record, no burst around it */
-		const uint32_t meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
-		r[TG_REC_TYPE] = (uint8_t)meta;
-		r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
-		*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
-		*(uint32_t *)(r + TG_REC_SLOT) = slot;
-	} else {
-		/* BBK + header are written by the lane that owns the slot's "primary" block:
-		 * SCH/F for NORM_1, BLK1 for NORM_2, SB2 for SYNC */
-		const uint32_t meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
-		const uint32_t btype = meta & 0xff;
-		const bool primary = (KIND == TG_KIND_432) || (btype == TG_BURST_SYNC ? which == 1 : which == 0);
-		if (primary) {
-			uint32_t bbraw;
-			if (HMODE == 2) {
-				/* hard decision of the first 16 BBK soft values: bit = (value < 0) */
-				const uint32_t *sb = softarea + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + TG_SOFT_BBK / 4;
-				bbraw = 0;
-#pragma unroll
-				for (int q = 0; q < 4; q++)
-					bbraw |= ((((sb[q] >> 7) & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
-			} else
-				bbraw = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_BBK];
-			uint32_t bb = bbraw ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
-			uint32_t nerr = 0;
-			if (kflags & TGK_F_RM)		/* non-default: minimum-distance decoding of the (30,14) word first */
-				bb = rm3014_correct(bb, nerr);
-			r[TG_REC_BBK_NERR] = (uint8_t)nerr;
-			uint4 o;
-			o.x = spread4(bb);
-			o.y = spread4(bb >> 4);
-			o.z = spread4(bb >> 8);
-			o.w = spread4(bb >> 12) & 0x0000ffffu;	/* 14 type-1 bits (tetra_lower_mac.c:268-274) */
-			*(uint4 *)(r + TG_REC_BBK) = o;
-			r[TG_REC_TYPE] = (uint8_t)btype;
-			r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
-			*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
-			*(uint32_t *)(r + TG_REC_SLOT) = slot;
-			if (wr) {
-				wr[TG_WIRE_TYPE] = (uint8_t)btype;
-				wr[TG_WIRE_FLAGS] = (uint8_t)(meta >> 8);
-				*(uint32_t *)(wr + TG_WIRE_BBK) = bb & 0x3fff;
-			}
-		}
-	}
+	vit_finish<KIND, HMODE>(od, s_crc, valid, slot, which, idx, midx, packed, masks, rec, sb_ok, sb_code, wire, softarea, kflags);
 }
 
 /* ------------------------------------------------------------------------- */
