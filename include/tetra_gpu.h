@@ -383,6 +383,16 @@ int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
 
 /*
+ * Optional, off by default: clean-block fast path.  A pre-pass (k_clean) recognises the blocks whose received bits
+ * are exactly a code word -- for those the trellis search can only return that code word (see the kernel's
+ * comment for the argument) -- and finishes them directly; only the other blocks go through the Viterbi kernels.
+ * Records are bit-identical with the flag on or off; throughput becomes input dependent (all blocks clean: the
+ * trellis kernels do nothing; no block clean: the pre-pass is overhead).  Applies to the 216- and 432-bit blocks
+ * of slot / grid plans with hard input.
+ */
+int tgpu_plan_set_fastpath(struct tgpu_plan *plan, int on);
+
+/*
  * Optional, off by default: decode the AACH's shortened (30,14) Reed-Muller word instead of keeping its first
  * 14 received bits like the reference (lower_mac/tetra_lower_mac.c:268-274; tetra_rm3014.c:88-96 is a stub).
  * Minimum-distance (syndrome / coset-leader) decoding, ties to the numerically smallest error pattern; up to

@@ -108,6 +108,7 @@ def lib():
     L.tgpu_plan_load.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p, C.c_uint32, u32p]
     L.tgpu_rm3014_decode.argtypes = [C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint)]
     L.tgpu_plan_set_rm_decode.argtypes = [C.c_void_p, C.c_int]
+    L.tgpu_plan_set_fastpath.argtypes = [C.c_void_p, C.c_int]
     L.tgpu_channel_set_rm_decode.argtypes = [C.c_void_p, C.c_int]
     L.tgpu_traffic_block.argtypes = [u8p, C.c_uint, C.POINTER(C.c_int16)]
     L.tgpu_traffic_block.restype = None
@@ -212,6 +213,9 @@ class Plan:
 
     def set_rm_decode(self, on=True):
         _chk(lib().tgpu_plan_set_rm_decode(self._h, int(bool(on))), "tgpu_plan_set_rm_decode")
+
+    def set_fastpath(self, on=True):
+        _chk(lib().tgpu_plan_set_fastpath(self._h, int(bool(on))), "tgpu_plan_set_fastpath")
 
     def load_blocks(self, blk_off, blk_type, blk_code):
         """tgpu_plan_load_blocks: type-5 blocks on their own (enum tp_sap_data_type per block, code per block)"""

@@ -26,6 +26,8 @@ struct tgpu_engine {
 	int device;
 };
 
+int tgpu_plan_set_fastpath(struct tgpu_plan *p, int on);
+
 #define TGPU_NKINDS 4	/* trellis kinds TG_KIND_SB1 / _216 / _432 / _168; index 4 = BBK in block-mode lists */
 
 struct tgpu_plan {
@@ -54,6 +56,8 @@ struct tgpu_plan {
 	int packed_ready;	/* stream mode: d_packed was filled by k_front_stream (slot = grid slot), k_front is skipped */
 	int block_mode;		/* tgpu_plan_load_blocks(): items are type-5 blocks, not slots */
 	int rm_decode;		/* tgpu_plan_set_rm_decode(): correct the BBK with the RM(30,14) decoder */
+	int fastpath;		/* tgpu_plan_set_fastpath(): k_clean pre-pass, the trellis kernels only see the other blocks */
+	uint32_t *d_dirty;	/* fastpath: [0..1] counters (216, 432), then the two item lists; 4 * (2 + 3 * max_slots) bytes */
 	uint32_t *d_list_168, *d_list_bbk;	/* block mode only (in d_up) */
 	uint32_t n168, nbbk;
 	hipStream_t side;	/* k_vit<216> and k_vit<432> are independent: they run side by side */
@@ -143,6 +147,13 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 		tgpu_plan_destroy(p);
 		return TGPU_ENOMEM;
 	}
+	if (getenv("TGPU_FASTPATH") && atoi(getenv("TGPU_FASTPATH"))) {	/* test knob: fast path on for every plan */
+		int rc = tgpu_plan_set_fastpath(p, 1);
+		if (rc) {
+			tgpu_plan_destroy(p);
+			return rc;
+		}
+	}
 	*out = p;
 	return TGPU_OK;
 }
@@ -155,7 +166,7 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	void *d[] = { p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
-		      p->d_block_tmp, p->d_softarea, p->d_grid };
+		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
 			(void)hipFree(d[i]);
@@ -440,7 +451,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	MARK(1);
 	if (p->nslots && !p->static_masks) {
 		if ((rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, p->nsb, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->rm_decode ? TGK_F_RM : 0, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->rm_decode ? TGK_F_RM : 0, NULL, stream)))
 			return rc;
 	}
 	MARK(2);
@@ -466,16 +477,38 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 		if (e_ != hipSuccess)
 			return (int)e_;
 	}
+	const int kf = p->rm_decode ? TGK_F_RM : 0;
+	const int fast = p->fastpath && !soft;
+	const uint32_t *items216 = p->d_list_216, *items432 = p->d_list_432, *cnt216 = NULL, *cnt432 = NULL;
+	void *s432 = fork ? (void *)p->side : stream;
+	if (fast && p->nslots) {
+		/* blocks that are code words are finished by k_clean; the trellis kernels get the rest, counted on the device */
+		uint32_t *d216 = p->d_dirty + 2, *d432 = d216 + 2 * (size_t)p->max_slots;
+		HCHK(hipMemsetAsync(p->d_dirty, 0, 8, (hipStream_t)stream));
+		if (fork) {	/* the counters are cleared on the caller's stream: order the side stream behind that */
+			HCHK(hipEventRecord(p->ev_fork, (hipStream_t)stream));
+			HCHK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+		}
+		if ((rc = tgk_clean(TG_KIND_216, p->d_list_216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec, p->d_sb_ok,
+				    p->d_sb_code, p->d_wire, d216, p->d_dirty, kf, stream)))
+			return rc;
+		if ((rc = tgk_clean(TG_KIND_432, p->d_list_432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec, p->d_sb_ok,
+				    p->d_sb_code, p->d_wire, d432, p->d_dirty + 1, kf, s432)))
+			return rc;
+		items216 = d216;
+		items432 = d432;
+		cnt216 = p->d_dirty;
+		cnt432 = p->d_dirty + 1;
+	}
 	if (p->nslots) {
-		if ((rc = tgk_vit(TG_KIND_216, p->d_list_216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->rm_decode ? TGK_F_RM : 0, stream)))
+		if ((rc = tgk_vit(TG_KIND_216, items216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, kf, cnt216, stream)))
 			return rc;
 	}
 	MARK(5);
 	if (p->nslots) {
-		if ((rc = tgk_vit(TG_KIND_432, p->d_list_432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->rm_decode ? TGK_F_RM : 0,
-				  fork ? (void *)p->side : stream)))
+		if ((rc = tgk_vit(TG_KIND_432, items432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, kf, cnt432, s432)))
 			return rc;
 	}
 	if (fork) {
@@ -487,6 +520,19 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	}
 	MARK(6);
 #undef MARK
+	return TGPU_OK;
+}
+
+int tgpu_plan_set_fastpath(struct tgpu_plan *p, int on)
+{
+	if (!p)
+		return TGPU_EINVAL;
+	if (on && !p->d_dirty) {
+		hipError_t e = hipMalloc((void **)&p->d_dirty, 4 * (2 + 3 * (size_t)p->max_slots));
+		if (e != hipSuccess)
+			return (int)e;
+	}
+	p->fastpath = on != 0;
 	return TGPU_OK;
 }
 
@@ -624,7 +670,7 @@ static int plan_run_blocks(struct tgpu_plan *p, const uint8_t *d_bits, uint8_t *
 		{ TG_KIND_168, p->d_list_168, p->n168 }, { TG_KIND_SB1, p->d_list_sb, p->nsb } };
 	for (int i = 0; i < 4; i++)
 		if ((rc = tgk_vit(run[i].kind, run[i].list, run[i].n, p->d_packed, p->d_masks, p->d_maskidx, d_rec, p->d_sb_ok,
-				  p->d_sb_code, NULL, NULL, TGK_F_BLOCK, stream)))
+				  p->d_sb_code, NULL, NULL, TGK_F_BLOCK, NULL, stream)))
 			return rc;
 	return tgk_bbk_blocks(p->d_list_bbk, p->nbbk, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
 			      p->rm_decode ? TGK_F_RM : 0, stream);

@@ -18,7 +18,12 @@ int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uin
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
 	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */,
-	    const uint32_t *d_softarea /* NULL: hard input */, int flags /* TGK_F_* */, void *stream);
+	    const uint32_t *d_softarea /* NULL: hard input */, int flags /* TGK_F_* */,
+	    const uint32_t *d_nitems /* NULL, or device-side item count with nitems as its upper bound */, void *stream);
+/* clean-block pre-pass (kinds 216 / 432): finishes the blocks that are code words, lists the others for tgk_vit */
+int tgk_clean(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,
+	      const uint32_t *d_maskidx, uint8_t *d_rec, uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire,
+	      uint32_t *d_dirty_items, uint32_t *d_dirty_count, int flags, void *stream);
 /* block mode: descriptor = byte offset | table index (TG_KIND_* or 4 = BBK) << 56 | tp_sap type << 48 */
 int tgk_front_blocks(const uint8_t *d_bits, const uint64_t *d_desc, uint32_t nblocks, uint32_t *d_packed, void *stream);
 int tgk_bbk_blocks(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,

@@ -42,6 +42,10 @@ struct tg_const_tables {
 
 __constant__ tg_const_tables c_tab;
 
+/* clean-block fast path (k_clean): [0..4095] 12 received bits of an 8-step block -> g1 bits | g2 bits << 8;
+ * [4096..8191] (state << 8 | g1 bits) -> input bits | expected g2 bits << 8 | next state << 12 */
+__device__ uint16_t g_clean_lut[8192];
+
 /* optional RM(30,14) decoder of the BBK (tg_rm.c): coset leaders by syndrome, generator parity rows */
 __device__ const uint32_t *g_rm_leader;
 __constant__ uint16_t c_rm_parity[14];
@@ -827,6 +831,106 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 }
 
 /*
+ * k_clean<KIND>: optional pre-pass (tgpu_plan_set_fastpath).  A block whose received bits are exactly a code word
+ * needs no trellis search: all four generators contain the term 1 and g1 is received at every step, so any other
+ * path differs from the received word at the first step where its input differs -- the zero-distance path is the
+ * unique minimum whatever the tie rule, and the decoder's answer is that path.  Its input bits follow from the g1
+ * stream alone (G1 = 1 + D + D^4: u_k = r1_k ^ u_(k-1) ^ u_(k-4), start state 0), and it is the received word iff
+ * the g2 bits it implies (G2 = 1 + D^2 + D^3 + D^4) equal the received ones.  Per 8-step block two table
+ * look-ups in LDS do both (g_clean_lut).  Clean blocks are finished here (same vit_finish as the trellis kernels);
+ * the others are appended to a list for k_vit, which then reads its item count from the device.
+ * Results are identical with or without this pass.
+ */
+template <int KIND>
+__global__ __launch_bounds__(256)
+void k_clean(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t *__restrict__ packed,
+	     const uint32_t *__restrict__ masks, const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
+	     uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code, uint8_t *__restrict__ wire,
+	     uint32_t *__restrict__ dirty_items, uint32_t *__restrict__ dirty_count, int kflags)
+{
+	constexpr int NBLK = vit_cfg<KIND>::NBLK;
+	constexpr int NW = NBLK / 2;
+	constexpr int NOD = (NBLK + 3) / 4;
+	__shared__ uint16_t s_lut[8192];
+	__shared__ uint16_t s_crc[512];
+	for (int i = threadIdx.x; i < 8192 / 8; i += 256)
+		((uint4 *)s_lut)[i] = ((const uint4 *)g_clean_lut)[i];
+	for (int i = threadIdx.x; i < 256; i += 256) {
+		s_crc[i] = c_tab.crc_lsb[i];
+		s_crc[256 + i] = c_tab.crc_msb[i];
+	}
+	__syncthreads();
+	const uint16_t *lutA = s_lut, *lutB = s_lut + 4096;
+	const uint32_t lane = threadIdx.x & 63;
+
+	for (uint32_t base = blockIdx.x * 256; base < nitems; base += gridDim.x * 256) {
+		uint32_t idx = base + threadIdx.x;
+		const bool valid = idx < nitems;
+		if (!valid)
+			idx = nitems - 1;
+		uint32_t slot, which, item = items[idx];
+		if (KIND == TG_KIND_216) {
+			slot = item >> 1;
+			which = item & 1;
+		} else {
+			slot = item;
+			which = 0;
+		}
+		const uint32_t *pw = packed + (size_t)slot * TG_PACKED_WORDS + (which ? TG_PW_BLK2 : TG_PW_BLK1);
+		const uint32_t midx = maskidx[slot];
+		const uint32_t *mw = masks + (size_t)midx * TG_MASK_WORDS + vit_cfg<KIND>::MW;
+
+		uint32_t od[NOD + 1];
+#pragma unroll
+		for (int i = 0; i <= NOD; i++)
+			od[i] = 0;
+		uint32_t state = 0, dirty = 0;
+		uint32_t cur = pw[0] ^ mw[0];
+		{	/* the four lead-in steps: six received bits, two g2 checks, four input bits */
+			const uint32_t a = lutA[(cur >> 24) & 63];
+			const uint32_t b = lutB[a & 0xff];
+			dirty |= ((b >> 8) ^ (a >> 8)) & 3;
+			od[0] = b & 15;
+			state = tg_brev4(b & 15);
+		}
+#pragma unroll
+		for (int d = 0; d < NW; d++) {
+			if (d)
+				cur = pw[d] ^ mw[d];
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const bool last = (d == NW - 1) && h;		/* four steps + the flush steps */
+				const uint32_t x = (h ? cur >> 12 : cur) & (last ? 0x3fu : 0xfffu);
+				const uint32_t a = lutA[x];
+				const uint32_t b = lutB[(state << 8) | (a & 0xff)];
+				dirty |= ((b >> 8) ^ (a >> 8)) & (last ? 3u : 15u);
+				const uint32_t u = b & (last ? 15u : 255u);
+				constexpr int dummy = 0;
+				(void)dummy;
+				const int upos = 4 + 8 * (2 * d + h);
+				od[upos >> 5] |= u << (upos & 31);
+				if ((upos & 31) > 24 && !last)
+					od[(upos >> 5) + 1] |= u >> (32 - (upos & 31));
+				state = b >> 12;
+			}
+		}
+		/* not a code word: hand the item to the trellis kernel (one atomic per wave) */
+		const bool isdirty = valid && dirty != 0;
+		const unsigned long long dm = __ballot(isdirty);
+		if (dm) {
+			uint32_t pos = 0;
+			if (lane == (uint32_t)__builtin_ctzll(dm))
+				pos = atomicAdd(dirty_count, (uint32_t)__builtin_popcountll(dm));
+			pos = __shfl(pos, __builtin_ctzll(dm));
+			if (isdirty)
+				dirty_items[pos + __builtin_popcountll(dm & ((1ull << lane) - 1))] = item;
+		}
+		vit_finish<KIND, 1>(od, s_crc, valid && dirty == 0, slot, which, idx, midx, packed, masks, rec, sb_ok, sb_code, wire,
+				    nullptr, kflags);
+	}
+}
+
+/*
  * HMODE 0: survivor history in LDS (16 B per lane per 8-step block).
  * HMODE 1: survivor history in VGPRs -- chunks of 32 registers (8 blocks) written through
  *          the VGPR index mode (s_set_gpr_idx_on) with a wave-uniform block index, read back
@@ -841,10 +945,15 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
 	   uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code, uint8_t *__restrict__ wire,
-	   const uint32_t *__restrict__ softarea, int kflags)
+	   const uint32_t *__restrict__ softarea, int kflags, const uint32_t *__restrict__ nitems_dev)
 {
 	constexpr int NBLK = vit_cfg<KIND>::NBLK;
 	constexpr int NW = NBLK / 2;			/* code words */
+	if (nitems_dev) {	/* after k_clean: the list of blocks that still need the trellis was counted on the device */
+		nitems = *nitems_dev;
+		if (blockIdx.x * 64 >= nitems)
+			return;
+	}
 	constexpr int NOD = (NBLK + 3) / 4;		/* dwords of decoded bits */
 	constexpr int NCH = (NBLK + 7) / 8;		/* history chunks of 8 blocks */
 
@@ -1191,6 +1300,33 @@ static uint32_t lfsr_next(uint32_t *st)
 	return fb;
 }
 
+static void build_clean_lut(uint16_t *t)
+{
+	/* received bits of an 8-step block: a(g1,g2) b(g1) a b a b a b -> bits 0,1 | 2 | 3,4 | 5 | 6,7 | 8 | 9,10 | 11 */
+	static const int g1pos[8] = { 0, 2, 3, 5, 6, 8, 9, 11 }, g2pos[4] = { 1, 4, 7, 10 };
+	for (uint32_t x = 0; x < 4096; x++) {
+		uint32_t g1 = 0, g2 = 0;
+		for (int i = 0; i < 8; i++)
+			g1 |= ((x >> g1pos[i]) & 1) << i;
+		for (int i = 0; i < 4; i++)
+			g2 |= ((x >> g2pos[i]) & 1) << i;
+		t[x] = (uint16_t)(g1 | (g2 << 8));
+	}
+	for (uint32_t st = 0; st < 16; st++)
+		for (uint32_t g1 = 0; g1 < 256; g1++) {
+			uint32_t h = st;	/* last four input bits, newest in bit 0 */
+			uint32_t u8 = 0, g2 = 0;
+			for (int k = 0; k < 8; k++) {
+				const uint32_t u = ((g1 >> k) ^ h ^ (h >> 3)) & 1;			/* G1 = 1 + D + D^4 */
+				if (!(k & 1))
+					g2 |= ((u ^ (h >> 1) ^ (h >> 2) ^ (h >> 3)) & 1) << (k >> 1);	/* G2 = 1 + D^2 + D^3 + D^4 */
+				u8 |= u << k;
+				h = ((h << 1) | u) & 15;
+			}
+			t[4096 + (st << 8 | g1)] = (uint16_t)(u8 | (g2 << 8) | (h << 12));
+		}
+}
+
 static void build_tables(tg_const_tables *t)
 {
 	memset(t, 0, sizeof(*t));
@@ -1302,6 +1438,11 @@ extern "C" int tgk_init(void)
 	if (const char *e = getenv("TGPU_HIST_MODE"))
 		tgk_hist_mode = atoi(e) ? 1 : 0;
 	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &host, sizeof(host)));
+	{
+		static uint16_t lut[8192];
+		build_clean_lut(lut);
+		HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_clean_lut), lut, sizeof(lut)));
+	}
 	return 0;
 }
 
@@ -1318,6 +1459,27 @@ extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 		blocks = cap;
 	hipLaunchKernelGGL(k_front, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
 			   d_stream, d_slot_desc, nslots, d_packed, d_rec);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_clean(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,
+			 const uint32_t *d_maskidx, uint8_t *d_rec, uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire,
+			 uint32_t *d_dirty_items, uint32_t *d_dirty_count, int flags, void *stream)
+{
+	if (!nitems)
+		return 0;
+	uint32_t blocks = (nitems + 255) / 256;
+	if (blocks > 256 * 8)
+		blocks = 256 * 8;
+	hipStream_t s = (hipStream_t)stream;
+	if (kind == TG_KIND_216)
+		hipLaunchKernelGGL((k_clean<TG_KIND_216>), dim3(blocks), dim3(256), 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec,
+				   d_sb_ok, d_sb_code, d_wire, d_dirty_items, d_dirty_count, flags);
+	else if (kind == TG_KIND_432)
+		hipLaunchKernelGGL((k_clean<TG_KIND_432>), dim3(blocks), dim3(256), 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec,
+				   d_sb_ok, d_sb_code, d_wire, d_dirty_items, d_dirty_count, flags);
+	else
+		return -1;
 	return (int)hipGetLastError();
 }
 
@@ -1427,13 +1589,13 @@ extern "C" int tgk_float_to_bits_afc(const float *d_in, unsigned long long n, ui
 extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 		       const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
 		       uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire, const uint32_t *d_soft, int flags,
-		       void *stream)
+		       const uint32_t *d_nitems /* NULL, or the device-side item count (nitems = its upper bound) */, void *stream)
 {
 	if (!nitems)
 		return 0;
 	const dim3 grid((nitems + 63) / 64), block(64);
 	hipStream_t s = (hipStream_t)stream;
-#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire, d_soft, flags)
+#define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire, d_soft, flags, d_nitems)
 	const int hm = d_soft ? 2 : tgk_hist_mode;
 	switch (kind) {
 	case TG_KIND_SB1:

@@ -979,3 +979,44 @@ def test_fuzz_damaged_streams_end_to_end(T, eng):
                     assert (np.asarray(pw[k]) == np.asarray(pg[k])).all(), (trial, k)
         gplan.close()
     assert ngridruns >= 3
+
+
+def test_clean_block_fastpath_is_invisible(T, eng):
+    """tgpu_plan_set_fastpath: blocks that are code words skip the trellis, the others do not -- the records are the
+    same bytes as without the flag, for clean input, noisy input and a mixture (some slots clean, some with a single
+    flipped bit in the payload, in the lead-in bits or in the last half block, some heavily damaged), with a SYNC burst
+    switching the scrambling code in between"""
+    import torch
+    rng = np.random.default_rng(123)
+    n = 3000
+    ty = rng.choice([O.TRAIN_NORM_1, O.TRAIN_NORM_2, O.TRAIN_NORM_2, O.TRAIN_SYNC], n).astype(np.uint8)
+    ty[0] = O.TRAIN_SYNC
+    slots = T.synth_slots(ty, seed=77, scramb_init=0x41802A07)   # the code the synthetic SYNC PDUs (262 / 42 / 1) announce
+    kind = rng.integers(0, 5, n)
+    for i in range(n):
+        if kind[i] == 1:                      # one flipped payload bit somewhere
+            slots[i, int(rng.choice(np.r_[14:230, 282:498]))] ^= 1
+        elif kind[i] == 2:                    # heavy noise
+            m = rng.random(510) < 0.05
+            m[214:266] = False
+            slots[i] ^= m.astype(np.uint8)
+        elif kind[i] == 3:                    # first / last bits of the blocks
+            slots[i, int(rng.choice([14, 15, 16, 229, 282, 283, 496, 497]))] ^= 1
+    buf = np.zeros(n * 510 + 64, np.uint8)
+    buf[:n * 510] = slots.reshape(-1)
+    d = torch.from_numpy(buf).cuda()
+    hs = torch.cuda.current_stream().cuda_stream
+    recs = []
+    for fast in (False, True, True):
+        plan = T.Plan(eng, n, 1)
+        plan.set_fastpath(fast)
+        plan.load(np.arange(n, dtype=np.uint64) * 510, ty)
+        d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        for _ in range(2):                    # twice: the device-side counters must reset
+            plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+        torch.cuda.synchronize()
+        recs.append(d_rec.cpu().numpy().reshape(n, T.REC_BYTES).copy())
+        plan.close()
+    assert (recs[0] == recs[1]).all() and (recs[1] == recs[2]).all()
+    p = T.parse_records(recs[1])
+    assert 0.3 * n < int(p["crc_ok"][:, 0].sum()) < n
