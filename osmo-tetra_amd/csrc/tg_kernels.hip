@@ -998,11 +998,19 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	for (int i = 0; i <= NOD; i++)
 		od[i] = 0;
 
+	/* hard input: the block's descrambled code words are fetched in one burst (the 80-byte pitch means every lane
+	 * touches its own cache lines; back to back they are fetched from HBM once) and parked in LDS, one column per
+	 * lane; the trellis loop then has no global loads.  Reading them one per 16 steps instead refetched the same
+	 * lines ~4x (FETCH_SIZE 183 MB for 42 MB of input on 500 k SCH/F blocks). */
+	__shared__ uint32_t s_cw[(HMODE != 2) ? NW * 64 : 1];
 	tg_vit_state v;
 	uint32_t cur = 0;
 	if (HMODE != 2) {
+#pragma unroll
+		for (int g = 0; g < NW; g++)
+			s_cw[g * 64 + lane] = pw[g] ^ mw[g];
 		tg_vit_init(v);
-		cur = pw[0] ^ mw[0];
+		cur = s_cw[lane];
 		tg_vit_leadin(v, cur >> 24);
 	}
 
@@ -1071,7 +1079,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	} else if (HMODE == 0) {
 #pragma unroll 1
 		for (int it = 0; it < NW - 1; it++) {
-			const uint32_t nxt = pw[it + 1] ^ mw[it + 1];
+			const uint32_t nxt = s_cw[(it + 1) * 64 + lane];
 			uint32_t h[4];
 			tg_vit_block<false>(v, cur, h);
 			hist[(2 * it) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -1108,7 +1116,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 #pragma unroll 1
 			for (int it = 0; it < nloop; it++) {
 				const int g = 4 * c + it;
-				const uint32_t nxt = pw[g + 1] ^ mw[g + 1];
+				const uint32_t nxt = s_cw[(g + 1) * 64 + lane];
 				uint32_t h[4];
 				tg_vit_block<false>(v, cur, h);
 #pragma unroll
