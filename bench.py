@@ -341,9 +341,11 @@ def main():
     value = world * n * args.steps / el
     pipeline_gbs = value / world * ((n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1]) / n) / 1e9
 
-    traffic = None
+    traffic = valu_busy = None
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(names[dom])
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        traffic = tj.get(names[dom])
+        valu_busy = tj.get("valu_busy", {}).get(names[dom])
     except Exception:
         pass
     out = {
@@ -356,6 +358,7 @@ def main():
                    "bursts_per_gpu": n, "parallelism": "independent channels per GPU; N>1: one RCCL gather of 48-B wire records per step to rank 0, overlapped with the next decode"},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic,
+                     "valu_busy_frac": valu_busy,   # rocprofv3 SQ_ACTIVE_INST_VALU / kernel cycles of this kernel (profiles/)
                      "kernel_ms": float(stage_ms[dom]),
                      "stage_ms": {names[i]: float(stage_ms[i]) for i in range(len(names))},
                      "pipeline_achieved_gbs_per_gpu": float(pipeline_gbs),
