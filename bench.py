@@ -207,6 +207,10 @@ def main():
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts per GPU per step")
     ap.add_argument("--ber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", default="final", choices=["final", "step"],
+                    help="N>1: 'final' = one RCCL gather of the decoded blocks (48-byte wire records) at the end of the "
+                         "timed region; 'step' = one gather per step, overlapped with the next decode (needs about "
+                         "110 GB/s per xGMI link at the single-GPU decode rate)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="config2 (default, the metric's workload): aligned NDB slots; config3: mixed SB/NDB stream "
                          "through the GPU burst-sync front end, 1%% corrupted training sequences")
@@ -254,9 +258,10 @@ def main():
     prof = T.Prof(args.steps)
     stream = torch.cuda.current_stream().cuda_stream
 
-    # N > 1: the final exchange of the path -- decoded blocks travel to rank 0 in the 48-byte wire
-    # form, one RCCL gather per step, issued on a side stream so that it overlaps the next decode
-    # (each peer->root transfer uses its own xGMI link; see DESIGN.md "Multi-GPU").
+    # N > 1: the final exchange of the path -- decoded blocks travel to rank 0 in the 48-byte wire form (each
+    # peer->root transfer uses its own xGMI link; see DESIGN.md "Multi-GPU").  Default: one gather of the last
+    # batch at the end of the timed region.  --gather step: one gather per step on a side stream, overlapped with
+    # the next decode -- at 2.3e9 bursts/s per GPU that is 110 GB/s per link, more than a link sustains.
     gather = world > 1
     if gather:
         from osmo_tetra_amd import dist as tdist
@@ -264,6 +269,17 @@ def main():
         sink = [[torch.empty_like(wire[0]) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
         comm = torch.cuda.Stream()
         pending = [None, None]
+
+    every_step = gather and args.gather == "step"
+
+    def final_gather(b):
+        """the one exchange of the path: every rank's decoded blocks (wire form) to rank 0"""
+        torch.cuda.synchronize()
+        if args.backend == "nccl":
+            tdist.gather_wire(wire[b], dst=0, out=sink[b])
+            torch.cuda.synchronize()
+        else:   # debug path: host-staged
+            tdist.gather_wire(wire[b].cpu(), dst=0, out=[t.cpu() for t in sink[b]] if rank == 0 else None)
 
     def step(k, prof_step=None):
         if gather:
@@ -275,7 +291,7 @@ def main():
             plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), stream)
         else:
             plan.execute_prof(d_stream.data_ptr(), d_rec.data_ptr(), stream, prof, prof_step)
-        if gather:
+        if every_step:
             done = torch.cuda.Event()
             done.record()
             with torch.cuda.stream(comm):
@@ -303,11 +319,15 @@ def main():
     for k in range(args.warmup):
         step(k)
     drain()
+    if gather and not every_step and args.warmup:
+        final_gather((args.warmup - 1) & 1)      # first use sets up the communicator: keep that out of the timing
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     drain()
+    if gather and not every_step:
+        final_gather((args.steps - 1) & 1)       # inside the timed region
     sync_all()
     el = time.perf_counter() - t0
 
@@ -355,7 +375,11 @@ def main():
         "dtype": "u16", "data": "synthetic",
         "config": {"workload": "BASELINE config 2: per GPU %d NDB bursts (50%% NORM_1 SCH/F, 50%% NORM_2 2xNDB, + AACH), "
                                "scramb_init=0, BER %g, aligned 510-B slots resident in HBM, records left in HBM" % (n, args.ber),
-                   "bursts_per_gpu": n, "parallelism": "independent channels per GPU; N>1: one RCCL gather of 48-B wire records per step to rank 0, overlapped with the next decode"},
+                   "bursts_per_gpu": n, "parallelism": "independent channels per GPU, no collective in decoding; N>1: the decoded blocks of the job's "
+                                  "last batch (48-B wire records) are gathered to rank 0 with one RCCL gather inside the timed "
+                                  "region (--gather step: one gather per step, overlapped)" if args.gather == "final" else
+                                  "independent channels per GPU; N>1: one RCCL gather of 48-B wire records per step to rank 0, "
+                                  "overlapped with the next decode"},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic,
                      "valu_busy_frac": valu_busy,   # rocprofv3 SQ_ACTIVE_INST_VALU / kernel cycles of this kernel (profiles/)
