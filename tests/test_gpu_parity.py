@@ -1020,3 +1020,28 @@ def test_clean_block_fastpath_is_invisible(T, eng):
     assert (recs[0] == recs[1]).all() and (recs[1] == recs[2]).all()
     p = T.parse_records(recs[1])
     assert 0.3 * n < int(p["crc_ok"][:, 0].sum()) < n
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_batch_size_sweep(T, eng, fast):
+    """ragged batch sizes around the kernels' tiling (wave = 64 items, workgroups of 256 / 1024, grid-stride loops,
+    pipelined front end with its tail): every size decodes like the oracle"""
+    rng = np.random.default_rng(5)
+    nmax = 9000
+    ty_all = rng.choice([O.TRAIN_NORM_1, O.TRAIN_NORM_2], nmax).astype(np.uint8)
+    slots_all = T.synth_slots(ty_all, seed=3, scramb_init=0, ber=0.01)
+    for n in (1, 2, 3, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 1023, 1025, 4097, 8193, 9000):
+        ty, slots = ty_all[:n], slots_all[:n]
+        import torch
+        buf = np.zeros(n * 510 + 2, np.uint8)          # 2 bytes of slack only: no read may run far past a slot
+        buf[:n * 510] = slots.reshape(-1)
+        d = torch.from_numpy(buf).cuda()
+        d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        plan = T.Plan(eng, n, 1)
+        plan.set_fastpath(fast)
+        plan.load(np.arange(n, dtype=np.uint64) * 510, ty)
+        plan.execute(d.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+        plan.close()
+        check_against_oracle(T, rec, ty, slots, 0)
