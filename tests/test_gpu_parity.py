@@ -1045,3 +1045,43 @@ def test_batch_size_sweep(T, eng, fast):
         rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
         plan.close()
         check_against_oracle(T, rec, ty, slots, 0)
+
+
+def test_grid_plan_multi_block_scan(T, eng):
+    """a longer stream (several 1024-slot blocks in the device-side list building, lock losses in between):
+    the grid plan's records == the slot-table plan's"""
+    import torch
+    rng = np.random.default_rng(17)
+    stream, slots = synth.frame_stream(seed=77, nframes=700, lead_in=123, pad=800)
+    s = stream.copy()
+    p0 = 123 + 510
+    for i in rng.choice(len(slots), 40, replace=False):
+        off = 214 if slots[int(i)][0] == O.TRAIN_SYNC else 244
+        s[p0 + 510 * int(i) + off + 3] ^= 1
+    d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+    hs = torch.cuda.current_stream().cuda_stream
+    res = T.sync_stream(eng, s, d.data_ptr(), burst_events=False)
+    n = len(res["slots"])
+    assert n > 5000
+    plan = T.Plan(eng, n, 1)
+    plan.load_slots(res, 0)
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+    torch.cuda.synchronize()
+    want = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+    plan.close()
+    gplan = T.Plan(eng, len(s) // 510 + 1, 1)
+    g = T.sync_stream_grid(eng, gplan, s, d.data_ptr(), burst_events=False)
+    assert g["noffgrid"] == 0 and g["nslots"] == n and g["events"] == res["events"]
+    on = T.grid_indices(g)
+    assert on.tolist() == [(o - g["anchor"]) // 510 for (o, t, q, tn) in res["slots"]]
+    d_rec2 = torch.zeros(g["ngrid"] * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    gplan.execute(d.data_ptr(), d_rec2.data_ptr(), hs)
+    torch.cuda.synchronize()
+    got = d_rec2.cpu().numpy().reshape(-1, T.REC_BYTES)[on]
+    pw, pg = T.parse_records(want), T.parse_records(got)
+    for k in pw:
+        if k != "slot":
+            assert (np.asarray(pw[k]) == np.asarray(pg[k])).all(), k
+    assert int(pw["crc_ok"][:, 0].sum()) > 0.9 * n
+    gplan.close()
