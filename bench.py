@@ -118,37 +118,51 @@ def bench_config3(args, T, torch, rank, world, local):
     stream = np.concatenate([rng.integers(0, 2, 100).astype(np.uint8), slots.reshape(-1), np.zeros(700, np.uint8)])
     eng = T.Engine(local)
     d_stream = torch.from_numpy(np.concatenate([stream, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
-    d_rec = torch.empty((n + 8) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
-    plan = T.Plan(eng, n + 8, 1)
+    # double-buffered: the decode of stream k runs on its own HIP stream while stream k+1 is classified (GPU)
+    # and walked (host) -- two plans, two record buffers, two decode streams
+    d_rec = [torch.empty((n + 8) * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    plan = [T.Plan(eng, n + 8, 1) for _ in range(2)]
     hs = torch.cuda.current_stream().cuda_stream
-    t_sync = t_exec = 0.0
+    dec = [torch.cuda.Stream() for _ in range(2)]
+    done = [None, None]
+    t_sync = 0.0
     nslots = 0
     for k in range(args.warmup + args.steps):
         if k == args.warmup:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            t_sync = t_exec = 0.0
+            t_sync = 0.0
+        i = k & 1
+        if done[i] is not None:
+            done[i].synchronize()        # the decode that last used this plan / record buffer
         a = time.perf_counter()
         # classification (packs every grid slot) -> host walk (bitmap) -> plan lists built on the device
-        res = T.sync_stream_grid(eng, plan, stream, d_stream.data_ptr(), 64, hs, burst_events=False, scramb_init=0)
+        res = T.sync_stream_grid(eng, plan[i], stream, d_stream.data_ptr(), 64, hs, burst_events=False, scramb_init=0)
         assert res["noffgrid"] == 0 and res["ngrid"] <= n + 8
-        b = time.perf_counter()
-        plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), hs)
-        torch.cuda.synchronize()
-        c = time.perf_counter()
-        t_sync += b - a; t_exec += c - b
+        t_sync += time.perf_counter() - a
+        plan[i].execute(d_stream.data_ptr(), d_rec[i].data_ptr(), dec[i].cuda_stream)   # lists are complete: sync_stream_grid synchronised hs
+        done[i] = torch.cuda.Event()
+        done[i].record(dec[i])
         nslots = res["nslots"]
+        last = i
+    torch.cuda.synchronize()
     el = time.perf_counter() - t0
     first = T.grid_indices(res)[:2048]
-    p = T.parse_records(d_rec.view(-1, T.REC_BYTES)[torch.from_numpy(first).cuda()].cpu().numpy())
+    p = T.parse_records(d_rec[last].view(-1, T.REC_BYTES)[torch.from_numpy(first).cuda()].cpu().numpy())
+    prof = T.Prof(4)
+    for q in range(4):
+        plan[last].execute_prof(d_stream.data_ptr(), d_rec[last].data_ptr(), hs, prof, q)
+    torch.cuda.synchronize()
+    t_exec = float(prof.read(4)[1:].sum(axis=1).mean()) * 1e-3 * args.steps
     out = {"metric": "decoded bursts/s", "value": n * args.steps / el, "unit": "bursts/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
            "config": {"workload": "BASELINE config 3: %d-burst mixed SB/NDB stream, GPU burst-sync front end, 1%% corrupted "
-                                  "training sequences; step = GPU classification/packing + host walk (bitmap) + device-built lists + decode" % n,
+                                  "training sequences; step = GPU classification/packing + host walk (bitmap) + device-built lists + decode, "
+                                  "the decode of one stream overlapping the synchronisation of the next" % n,
                       "bursts_in_stream": n, "bursts_delivered": nslots, "crc_ok_first_2048": int(p["crc_ok"][:, 0].sum())},
            "breakdown_ms": {"sync_stream_grid(GPU classify+pack, D2H, host walk, device list build)": t_sync / args.steps * 1e3,
-                            "plan_execute(GPU decode)": t_exec / args.steps * 1e3}}
+                            "plan_execute(GPU decode, runs under the next stream's synchronisation)": t_exec / args.steps * 1e3}}
     print(json.dumps(out))
 
 
