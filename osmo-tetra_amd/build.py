@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
         objs.append(o)
     for s in C_SRCS:
         o = os.path.join(OBJ, s + ".o")
-        run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"] + inc +
+        run(["gcc", "-O3", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"] + inc +
             ["-c", os.path.join(CSRC, s), "-o", o])
         objs.append(o)
     run([hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lpthread"])

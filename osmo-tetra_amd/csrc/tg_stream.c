@@ -327,6 +327,32 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 			}
 			if (ongrid) {
 				const uint64_t bs0 = bs;
+				/* 32 slots at a time while nothing is backlogged (k < the call that completes the first of
+				 * them: every slot is then consumed by "its" call, k ends at the last one's) and all 32
+				 * classification words say "delivered": one word of the bitmap, closed-form ordinals */
+				const uint32_t A = TETRA_TRAIN_SYNC | TG_SYNC_TRAIN_OFF << 8, B = TETRA_TRAIN_NORM_1 | TG_NORM_TRAIN_OFF << 8,
+					       C = TETRA_TRAIN_NORM_2 | TG_NORM_TRAIN_OFF << 8;
+				for (;;) {
+				const uint64_t gi_before = gi;
+				while (w.grid_bits && !(gi & 31) && gi + 32 <= ncls && bs + 32ull * TG_SLOT_BITS <= len &&
+				       ((bs + TG_SLOT_BITS + chunk - 1) >> w.cshift) > k) {
+					uint32_t bad = 0;
+					for (int j = 0; j < 32; j++) {
+						const uint32_t v = cls[gi + j] & 0x01ffffffu;
+						bad |= (uint32_t)(v != A) & (uint32_t)(v != B) & (uint32_t)(v != C);
+					}
+					const uint64_t klast = (bs + 32ull * TG_SLOT_BITS + chunk - 1) >> w.cshift;
+					if (bad || klast > w.ncalls)
+						break;
+					w.grid_bits[gi >> 5] = 0xffffffffu;
+					out->nslots += 32;
+					k = klast;
+					seq += 32;
+					tn_adds = 0;
+					bs += 32ull * TG_SLOT_BITS;
+					nfs += 32ull * TG_SLOT_BITS;
+					gi += 32;
+				}
 				while (gi < ncls && bs + TG_SLOT_BITS <= len) {
 					const uint32_t v = cls[gi] & 0x01ffffffu;	/* type, offset, TG_CLS_EARLY21 */
 					if (v != (TETRA_TRAIN_SYNC | TG_SYNC_TRAIN_OFF << 8) && v != (TETRA_TRAIN_NORM_1 | TG_NORM_TRAIN_OFF << 8) &&
@@ -348,6 +374,11 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 					bs += TG_SLOT_BITS;
 					nfs += TG_SLOT_BITS;
 					gi++;
+					if (w.grid_bits && !(gi & 31))
+						break;	/* aligned again: back to the 32-slot steps */
+				}
+				if (gi == gi_before || !w.grid_bits)
+					break;
 				}
 				grid_for = bs;
 				if (bs != bs0)

@@ -241,3 +241,19 @@ def test_fuzz_random_mutations():
                 s[p:p + int(rng.integers(1, 200))] = 0
         chunk = int(rng.choice([64, 64, 64, 32, 128, 100, 510, 7]))
         check(s, chunk=chunk, with_cls=(chunk <= 128))
+
+
+def test_long_runs_take_the_bulk_path():
+    """hundreds of consecutive good slots (the 32-slot bulk step of the grid walk) with lock losses, a misplaced
+    burst and a backlog after each re-lock in between"""
+    rng = np.random.default_rng(99)
+    for trial in range(3):
+        stream, slots = synth.frame_stream(seed=500 + trial, nframes=45, lead_in=int(rng.integers(0, 300)))
+        s = stream.copy()
+        p0 = np.flatnonzero((np.lib.stride_tricks.sliding_window_view(s, 38) == SEQ_Y).all(axis=1))[0] + 296
+        for i in rng.choice(np.arange(40, len(slots) - 40), 3, replace=False):
+            off = 214 if slots[int(i)][0] == O.TRAIN_SYNC else 244
+            s[p0 + 510 * int(i) + off + 4] ^= 1
+        s[p0 + 510 * 100 + 30:p0 + 510 * 100 + 52] = SEQ_N      # spurious n sequence: burst dropped, lock kept
+        res = check(s, chunk=64)
+        assert len(res["slots"]) > 300
