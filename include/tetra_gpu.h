@@ -380,6 +380,15 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
 int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream,
 			  const uint8_t *d_stream, uint64_t len, uint32_t chunk, uint32_t flags, uint32_t scramb_init,
 			  struct tgpu_sync_result *out, void *hip_stream);
+/* the same in two halves, so that the classification of one stream (GPU, asynchronous) can run under the host walk
+ * of another: _begin finds the first lock and launches classification + copy on hip_stream without waiting,
+ * _finish (same plan, stream, h_stream, len, chunk and 'out') waits for them, walks and loads the plan */
+int tgpu_sync_stream_grid_begin(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream,
+				const uint8_t *d_stream, uint64_t len, uint32_t chunk, struct tgpu_sync_result *out,
+				void *hip_stream);
+int tgpu_sync_stream_grid_finish(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream, uint64_t len,
+				 uint32_t chunk, uint32_t flags, uint32_t scramb_init, struct tgpu_sync_result *out,
+				 void *hip_stream);
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
 
 /*

@@ -150,6 +150,10 @@ def lib():
     L.tgpu_sync_stream.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
     L.tgpu_sync_stream_grid.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
+    L.tgpu_sync_stream_grid_begin.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                              C.POINTER(SyncResult), C.c_void_p]
+    L.tgpu_sync_stream_grid_finish.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.POINTER(SyncResult), C.c_void_p]
     L.tgpu_sync_result_free.argtypes = [C.POINTER(SyncResult)]
     L.tgpu_synth_slots.argtypes = [C.POINTER(SynthCfg), u8p, C.c_size_t, u8p, u8p]
     _lib = L
@@ -444,6 +448,28 @@ def sync_stream_grid(engine, plan, h_stream, d_stream_ptr, chunk=64, hip_stream=
     if not out["noffgrid"] and out["ngrid"]:
         plan.nslots, plan.nchan = out["ngrid"], 1
     return out
+
+
+class GridSync:
+    """tgpu_sync_stream_grid in two halves: begin() launches the classification asynchronously, finish() waits,
+    walks on the host and loads the plan (returns the outcome)"""
+
+    def __init__(self, engine, plan, h_stream, d_stream_ptr, chunk=64, hip_stream=0):
+        self.engine, self.plan, self.chunk, self.hip_stream = engine, plan, chunk, hip_stream
+        self.h_stream = _np_u8(h_stream)
+        self.res = SyncResult()
+        _chk(lib().tgpu_sync_stream_grid_begin(engine._h, plan._h, self.h_stream.ctypes.data_as(u8p), C.c_void_p(d_stream_ptr),
+                                               len(self.h_stream), chunk, C.byref(self.res), C.c_void_p(hip_stream)),
+             "tgpu_sync_stream_grid_begin")
+
+    def finish(self, burst_events=True, scramb_init=0):
+        _chk(lib().tgpu_sync_stream_grid_finish(self.engine._h, self.plan._h, self.h_stream.ctypes.data_as(u8p), len(self.h_stream),
+                                                self.chunk, 0 if burst_events else 1, scramb_init, C.byref(self.res),
+                                                C.c_void_p(self.hip_stream)), "tgpu_sync_stream_grid_finish")
+        out = _sync_result_to_py(self.res)
+        if not out["noffgrid"] and out["ngrid"]:
+            self.plan.nslots, self.plan.nchan = out["ngrid"], 1
+        return out
 
 
 def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None, grid=False):

@@ -595,26 +595,20 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
  * walk's bitmap.  Slot i of the plan is grid slot i: record i of tgpu_plan_execute() belongs to stream offset
  * out->anchor + 510 i and is valid iff bit i of out->grid_bits is set.  No slot table, no second front-end pass.
  */
-int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream,
-			  const uint8_t *d_stream, uint64_t len, uint32_t chunk, uint32_t flags, uint32_t scramb_init,
-			  struct tgpu_sync_result *out, void *stream)
+int tgpu_sync_stream_grid_begin(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream,
+				const uint8_t *d_stream, uint64_t len, uint32_t chunk, struct tgpu_sync_result *out, void *stream)
 {
 	if (!eng || !plan || !h_stream || !d_stream || !out || !chunk)
 		return TGPU_EINVAL;
 	memset(out, 0, sizeof(*out));
 	uint64_t anchor = 0;
 	int locks = 0;
-	const double t0 = now_ms();
 	int rc = find_anchor(h_stream, len, chunk, &anchor, &locks);
 	if (rc)
 		return rc;
-	if (!locks || anchor + TG_SLOT_BITS > len) {
-		/* never locks (or nothing after the lock): the plain walk settles it, nothing to decode */
-		rc = tgpu_sync_walk(h_stream, len, chunk, anchor, NULL, NULL, 0, flags & ~TGPU_SYNC_GRID, out);
-		out->anchor = anchor;
-		out->noffgrid = out->nslots;	/* anything it found would not be in a plan */
-		return rc;
-	}
+	out->anchor = anchor;
+	if (!locks || anchor + TG_SLOT_BITS > len)
+		return TGPU_OK;		/* never locks (or nothing after the lock): ngrid stays 0, nothing is launched */
 	const uint64_t n = (len - anchor) / TG_SLOT_BITS;
 	if (n > 0xfffffff0u)
 		return TGPU_ECAPACITY;
@@ -626,8 +620,32 @@ int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const
 	rc = tgk_front_stream(d_stream, anchor, len, ncls, chunk, d_packed, d_cls, d_ysum, stream);
 	if (!rc)	/* words and summaries are adjacent on both sides: one copy into the plan's pinned mirror */
 		rc = (int)hipMemcpyAsync(cls, d_cls, (size_t)ncls * 6, hipMemcpyDeviceToHost, (hipStream_t)stream);
-	if (!rc)
-		rc = (int)hipStreamSynchronize((hipStream_t)stream);
+	out->ngrid = ncls;
+	return rc;
+}
+
+int tgpu_sync_stream_grid_finish(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream, uint64_t len,
+				 uint32_t chunk, uint32_t flags, uint32_t scramb_init, struct tgpu_sync_result *out,
+				 void *stream)
+{
+	if (!eng || !plan || !h_stream || !out || !chunk)
+		return TGPU_EINVAL;
+	const uint64_t anchor = out->anchor;
+	const uint32_t ncls = out->ngrid;
+	int rc;
+	if (!ncls) {
+		/* never locks: the plain walk settles it, nothing to decode */
+		rc = tgpu_sync_walk(h_stream, len, chunk, anchor, NULL, NULL, 0, flags & ~TGPU_SYNC_GRID, out);
+		out->anchor = anchor;
+		out->noffgrid = out->nslots;	/* anything it found would not be in a plan */
+		return rc;
+	}
+	uint32_t *d_packed, *d_cls, *cls;
+	uint16_t *d_ysum, *ysum;
+	if ((rc = tgpi_plan_grid_begin(plan, ncls, &d_packed, &d_cls, &d_ysum, &cls, &ysum)))
+		return rc;
+	const double t0 = now_ms();
+	rc = (int)hipStreamSynchronize((hipStream_t)stream);
 	const double t1 = now_ms();
 	if (!rc)
 		rc = tgpu_sync_walk(h_stream, len, chunk, anchor, cls, ysum, ncls, flags | TGPU_SYNC_GRID, out);
@@ -636,7 +654,17 @@ int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const
 	if (!rc && !out->noffgrid)
 		rc = tgpi_plan_grid_load(plan, ncls, out->grid_bits, scramb_init, stream);
 	if (getenv("TGPU_SYNC_TIMING"))
-		fprintf(stderr, "tgpu_sync_stream_grid: anchor+classify %.3f ms, walk %.3f ms, device lists %.3f ms (%u of %u grid slots, %u events)\n",
+		fprintf(stderr, "tgpu_sync_stream_grid: wait for the classification %.3f ms, walk %.3f ms, device lists %.3f ms (%u of %u grid slots, %u events)\n",
 			t1 - t0, t2 - t1, now_ms() - t2, out->nslots, ncls, out->nevents);
 	return rc;
+}
+
+int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream,
+			  const uint8_t *d_stream, uint64_t len, uint32_t chunk, uint32_t flags, uint32_t scramb_init,
+			  struct tgpu_sync_result *out, void *stream)
+{
+	int rc = tgpu_sync_stream_grid_begin(eng, plan, h_stream, d_stream, len, chunk, out, stream);
+	if (rc)
+		return rc;
+	return tgpu_sync_stream_grid_finish(eng, plan, h_stream, len, chunk, flags, scramb_init, out, stream);
 }

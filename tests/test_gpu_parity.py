@@ -1085,3 +1085,40 @@ def test_grid_plan_multi_block_scan(T, eng):
             assert (np.asarray(pw[k]) == np.asarray(pg[k])).all(), k
     assert int(pw["crc_ok"][:, 0].sum()) > 0.9 * n
     gplan.close()
+
+
+def test_grid_sync_two_halves_in_flight(T, eng):
+    """tgpu_sync_stream_grid_begin/_finish with two streams in flight on their own plans and HIP streams (the
+    software pipeline bench.py --workload config3 runs) == the one-call form, outcome and records"""
+    import torch
+    streams = [_mutated_stream(seed, nframes=6) for seed in (3, 4)]
+    devs = [torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda() for s in streams]
+    hs = torch.cuda.current_stream().cuda_stream
+    want = []
+    for s, d in zip(streams, devs):
+        p = T.Plan(eng, len(s) // 510 + 1, 1)
+        g = T.sync_stream_grid(eng, p, s, d.data_ptr())
+        rec = None
+        if not g["noffgrid"] and g["ngrid"]:
+            r = torch.zeros(g["ngrid"] * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+            p.execute(d.data_ptr(), r.data_ptr(), hs)
+            torch.cuda.synchronize()
+            rec = r.cpu().numpy()
+        want.append((g, rec))
+        p.close()
+    side = [torch.cuda.Stream() for _ in streams]
+    plans = [T.Plan(eng, len(s) // 510 + 1, 1) for s in streams]
+    torch.cuda.synchronize()
+    halves = [T.GridSync(eng, p, s, d.data_ptr(), 64, st.cuda_stream) for p, s, d, st in zip(plans, streams, devs, side)]
+    for h, p, d, st, (g, rec) in zip(halves, plans, devs, side, want):
+        out = h.finish()
+        for k in ("events", "anchor", "ngrid", "noffgrid", "nslots"):
+            assert out[k] == g[k], k
+        if rec is not None:
+            assert T.grid_indices(out).tolist() == T.grid_indices(g).tolist()
+            r = torch.zeros(out["ngrid"] * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            p.execute(d.data_ptr(), r.data_ptr(), st.cuda_stream)
+            torch.cuda.synchronize()
+            assert (r.cpu().numpy() == rec).all()
+        p.close()
