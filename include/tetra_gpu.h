@@ -427,6 +427,35 @@ int tgpu_plan_load_blocks(struct tgpu_plan *plan, uint32_t nblocks, const uint64
 			  const uint8_t *blk_type, const uint32_t *blk_code);
 
 /*
+ * The remaining channel codings of the reference's tables: any of its seven RCPC
+ * puncturers (enum tetra_rcpc_puncturer, lower_mac/tetra_conv_enc.h:17-25, same numbering: 0 = 2/3, 1 = 1/3,
+ * 2 = 292/432, 3 = 148/432, 4 = 112/168, 5 = 72/162, 6 = 38/80) on the rate-1/4 mother code (mother_rate 4,
+ * conv_cch_decode, lower_mac/viterbi_cch.c:58-66) or the rate-1/3 speech code (mother_rate 3, conv_tch_decode,
+ * lower_mac/viterbi_tch.c:56-64), for batches of equally shaped blocks resident in HBM.
+ *
+ * tgpu_conv_execute() replaces, per block, what a caller of the reference writes (conv_enc_test.c:66-70,
+ * tetra_lower_mac.c:249-253):  memset(dp, 0xff, ..); tetra_rcpc_depunct(punct, type3, type3_len, dp);
+ * viterbi_dec_sb1_wrapper(dp, type2, type2_len)  -- start state 0, type2_len steps + 4 flush steps, ties to the
+ * predecessor whose oldest bit is 0.  For the speech code the three de-punctured values of a step follow one
+ * erased value (that code's struct says N = 4 with 3-bit outputs, viterbi_tch.c:49-54).
+ *   d_type3: nblocks x type3_len received bytes, one per bit: 0 -> bit 0, 0xff -> erased, anything else -> bit 1
+ *            (lower_mac/viterbi.c:12-22)
+ *   d_type2: nblocks x type2_len decoded bits, one per byte
+ * Launch only (graph-capturable).  tgpu_conv_create() returns TGPU_EINVAL for an unknown puncturer, a type3_len
+ * whose positions run past type2_len x mother_rate, type2_len > 504 or type2_len mod 8 in {1,2,3}.
+ */
+struct tgpu_conv;
+int tgpu_conv_create(struct tgpu_engine *eng, int punct, int mother_rate, uint32_t type3_len, uint32_t type2_len,
+		     struct tgpu_conv **out);
+int tgpu_conv_execute(struct tgpu_conv *cv, const void *d_type3, uint64_t nblocks, void *d_type2, void *hip_stream);
+void tgpu_conv_destroy(struct tgpu_conv *cv);
+
+/* the reference's puncturing entry points on host buffers, same names, arguments and -EINVAL behaviour
+ * (lower_mac/tetra_conv_enc.c:201-248; 'pu' is enum tetra_rcpc_puncturer) */
+int get_punctured_rate(int pu, uint8_t *in, int len, uint8_t *out);
+int tetra_rcpc_depunct(int pu, const uint8_t *in, int len, uint8_t *out);
+
+/*
  * The reference's traffic-channel dump block (lower_mac/tetra_lower_mac.c:213-231, the input format of the
  * ETSI codec tools): 690 int16 = six frames of marker 0x6b21+i + 114 soft bits (bit 1 -> -127, bit 0 -> +127;
  * 432 bits in total, the rest 0), made from the descrambled type-4 bits a traffic block is delivered with

@@ -134,6 +134,20 @@ int orc_depuncture(enum orc_punct pu, const uint8_t *in, int len, uint8_t *mothe
 	return 0;
 }
 
+/* the speech mother code as an encoder (EN 300 395-2 5.5.2; the reference only holds its trellis tables,
+ * lower_mac/viterbi_tch.c:29-47) -- test generator for the rate-1/3 puncturers */
+void orc_conv_encode_tch(const uint8_t *in, int len, uint8_t *out3)
+{
+	unsigned d1 = 0, d2 = 0, d3 = 0, d4 = 0;
+	for (int n = 0; n < len; n++) {
+		unsigned b = in[n] & 1;
+		out3[3 * n + 0] = (b + d1 + d2 + d3 + d4) & 1;
+		out3[3 * n + 1] = (b + d1 + d3 + d4) & 1;
+		out3[3 * n + 2] = (b + d2 + d4) & 1;
+		d4 = d3; d3 = d2; d2 = d1; d1 = b;
+	}
+}
+
 /* ======================================================================
  * row V -- Viterbi.
  *
@@ -175,10 +189,37 @@ static inline unsigned cch_output(unsigned s, unsigned b)
 	return (g1 << 3) | (g2 << 2) | (g3 << 1) | g4;
 }
 
+/* lower_mac/viterbi_tch.c:29-47: the speech (TCH) mother code G1 = 1+D+D2+D3+D4, G2 = 1+D+D3+D4, G3 = 1+D2+D4.
+ * The reference's struct says N = 4 with 3-bit table entries (:49-54), so libosmocore reads FOUR soft values
+ * per step and the first one (output bit 3) is always expected to be a 0 bit; g1,g2,g3 are values 1..3. */
+static inline unsigned tch_output(unsigned s, unsigned b)
+{
+	unsigned d1 = s & 1, d2 = (s >> 1) & 1, d3 = (s >> 2) & 1, d4 = (s >> 3) & 1;
+	unsigned g1 = (b + d1 + d2 + d3 + d4) & 1;
+	unsigned g2 = (b + d1 + d3 + d4) & 1;
+	unsigned g3 = (b + d2 + d4) & 1;
+	return (g1 << 2) | (g2 << 1) | g3;
+}
+
+static inline unsigned code_output(int code, unsigned s, unsigned b)
+{
+	return code == ORC_CODE_TCH ? tch_output(s, b) : cch_output(s, b);
+}
+
+unsigned orc_code_output(int code, unsigned s, unsigned b)
+{
+	return code_output(code, s & 15, b & 1);
+}
+
 #define VIT_MAX_STEPS (864 + 4)
 #define MAX_AE 0x00ffffffu
 
 int orc_viterbi_generic(const int8_t *in, uint8_t *out, int len)
+{
+	return orc_viterbi_generic_code(ORC_CODE_CCH, in, out, len);
+}
+
+int orc_viterbi_generic_code(int code, const int8_t *in, uint8_t *out, int len)
 {
 	static __thread uint8_t hist[VIT_MAX_STEPS][16];
 	unsigned ae[16], ae_next[16];
@@ -196,7 +237,7 @@ int orc_viterbi_generic(const int8_t *in, uint8_t *out, int len)
 			ae_next[s] = MAX_AE;
 		for (unsigned s = 0; s < 16; s++) {
 			for (int b = 0; b < nb; b++) {
-				unsigned o = cch_output(s, b);
+				unsigned o = code_output(code, s, b);
 				unsigned t = ((s << 1) | b) & 15;
 				unsigned nae = ae[s];
 				unsigned m = 8;
@@ -231,6 +272,11 @@ int orc_viterbi_generic(const int8_t *in, uint8_t *out, int len)
 
 int orc_viterbi_acc(const int8_t *in, uint8_t *out, int len)
 {
+	return orc_viterbi_acc_code(ORC_CODE_CCH, in, out, len);
+}
+
+int orc_viterbi_acc_code(int code, const int8_t *in, uint8_t *out, int len)
+{
 	/* acc state convention: most recent input bit in bit 3 (K-2), so the
 	 * predecessors of state r are 2*(r&7) and 2*(r&7)+1. */
 	static __thread int16_t paths[VIT_MAX_STEPS][16];
@@ -247,7 +293,7 @@ int orc_viterbi_acc(const int8_t *in, uint8_t *out, int len)
 		unsigned prev0 = (r << 1) & 0xe;	/* vstate_lshift(reg, 5, 0) */
 		/* bit-swap into the API convention (newest bit in the LSB) */
 		unsigned ps = ((prev0 & 1) << 3) | ((prev0 & 2) << 1) | ((prev0 & 4) >> 1) | ((prev0 & 8) >> 3);
-		unsigned o = cch_output(ps, val);
+		unsigned o = code_output(code, ps, val);
 		for (int j = 0; j < 4; j++)
 			outs[r][j] = ((o >> (3 - j)) & 1) ? -1 : 1;
 		vals[r] = (uint8_t)val;
@@ -304,6 +350,37 @@ void orc_viterbi_dec_wrapper(const uint8_t *in, uint8_t *out, unsigned sym_count
 		orc_viterbi_acc(vit_inp, out, (int)sym_count);
 	else
 		orc_viterbi_generic(vit_inp, out, (int)sym_count);
+}
+
+/* (f)1: any puncturer on either mother code -- what a caller of the reference writes with its pieces:
+ * memset(dp, 0xff), tetra_rcpc_depunct(pu, type3, type3_len, dp) (conv_enc_test.c:66-68, tetra_lower_mac.c:249-251),
+ * the 0 -> +127 / 0xff -> 0 / else -> -127 map of lower_mac/viterbi.c:12-22, then conv_cch_decode()
+ * (viterbi_cch.c:58-66) or, for the rate-1/3 speech code, conv_tch_decode() (viterbi_tch.c:56-64) with the three
+ * de-punctured values of a step behind one erased value (that code's N = 4, see tch_output). */
+int orc_conv_decode_block(int pu, int mother_rate, const uint8_t *type3, unsigned type3_len, unsigned type2_len,
+			  int use_acc, uint8_t *type2)
+{
+	static __thread uint8_t dp[864 * 4];
+	static __thread int8_t vit_inp[(864 + 4) * 4];
+	const int code = (mother_rate == 3) ? ORC_CODE_TCH : ORC_CODE_CCH;
+
+	if ((unsigned)pu >= 7 || (mother_rate != 3 && mother_rate != 4) || type2_len < 1 || type2_len > 864)
+		return -1;
+	for (uint32_t j = 1; j <= type3_len; j++)
+		if (punct_k(&punct_defs[pu], j) > type2_len * (unsigned)mother_rate)
+			return -1;
+	memset(dp, 0xff, sizeof(dp));
+	orc_depuncture((enum orc_punct)pu, type3, (int)type3_len, dp);
+	memset(vit_inp, 0, sizeof(vit_inp));
+	for (unsigned n = 0; n < type2_len; n++)
+		for (int g = 0; g < mother_rate; g++) {
+			const uint8_t v = dp[n * (unsigned)mother_rate + (unsigned)g];
+			vit_inp[4 * n + (4 - (unsigned)mother_rate) + (unsigned)g] = (v == 0) ? 127 : (v == 0xff ? 0 : -127);
+		}
+	if (use_acc)
+		return orc_viterbi_acc_code(code, vit_inp, type2, (int)type2_len);
+	orc_viterbi_generic_code(code, vit_inp, type2, (int)type2_len);
+	return 0;
 }
 
 void orc_viterbi_soft(const int8_t *sbits_mother, uint8_t *out, unsigned sym_count)

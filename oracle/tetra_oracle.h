@@ -110,6 +110,15 @@ int orc_depuncture(enum orc_punct pu, const uint8_t *in, int len, uint8_t *mothe
 int orc_viterbi_generic(const int8_t *sbits, uint8_t *out, int len);
 /* libosmocore conv_acc.c / conv_acc_generic.c formulation (N=4,K=5)       */
 int orc_viterbi_acc(const int8_t *sbits, uint8_t *out, int len);
+/* the same two algorithms on either mother code (lower_mac/viterbi_cch.c:28-47, viterbi_tch.c:29-47) */
+#define ORC_CODE_CCH 0
+#define ORC_CODE_TCH 1
+unsigned orc_code_output(int code, unsigned state, unsigned bit);
+int orc_viterbi_generic_code(int code, const int8_t *sbits, uint8_t *out, int len);
+int orc_viterbi_acc_code(int code, const int8_t *sbits, uint8_t *out, int len);
+void orc_conv_encode_tch(const uint8_t *in, int len, uint8_t *out3);
+int orc_conv_decode_block(int pu, int mother_rate, const uint8_t *type3, unsigned type3_len, unsigned type2_len,
+			  int use_acc, uint8_t *type2);
 /* viterbi.c:6-25 : ubit/erasure -> sbit map, then the decoder above.
  * use_acc selects which restatement runs (0 = generic).                   */
 void orc_viterbi_dec_wrapper(const uint8_t *in, uint8_t *out, unsigned sym_count, int use_acc);

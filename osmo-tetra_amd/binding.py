@@ -112,6 +112,12 @@ def lib():
     L.tgpu_channel_set_rm_decode.argtypes = [C.c_void_p, C.c_int]
     L.tgpu_traffic_block.argtypes = [u8p, C.c_uint, C.POINTER(C.c_int16)]
     L.tgpu_traffic_block.restype = None
+    L.tgpu_conv_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.tgpu_conv_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.tgpu_conv_destroy.argtypes = [C.c_void_p]
+    L.tgpu_conv_destroy.restype = None
+    L.get_punctured_rate.argtypes = [C.c_int, u8p, C.c_int, u8p]
+    L.tetra_rcpc_depunct.argtypes = [C.c_int, u8p, C.c_int, u8p]
     L.tgpu_channel_burst_rx.argtypes = [C.c_void_p, u8p, C.c_uint, C.c_int, C.c_uint32]
     L.tgpu_plan_load_blocks.argtypes = [C.c_void_p, C.c_uint32, u64p, u8p, u32p]
     L.tgpu_plan_load_slots.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(SyncSlot), C.c_uint32]
@@ -428,6 +434,48 @@ def traffic_block(type4):
     out = np.zeros(690, np.int16)
     lib().tgpu_traffic_block(t.ctypes.data_as(u8p), len(t), out.ctypes.data_as(C.POINTER(C.c_int16)))
     return out
+
+
+class ConvDecoder:
+    """tgpu_conv_*: depuncture + Viterbi for one block shape (any of the reference's puncturers, either
+    mother code), batches resident in HBM"""
+
+    def __init__(self, engine, punct, mother_rate, type3_len, type2_len):
+        self._h = C.c_void_p()
+        self.type3_len, self.type2_len = type3_len, type2_len
+        _chk(lib().tgpu_conv_create(engine._h, punct, mother_rate, type3_len, type2_len, C.byref(self._h)),
+             "tgpu_conv_create")
+
+    def execute(self, d_type3_ptr, nblocks, d_type2_ptr, hip_stream=0):
+        _chk(lib().tgpu_conv_execute(self._h, C.c_void_p(d_type3_ptr), nblocks, C.c_void_p(d_type2_ptr),
+                                     C.c_void_p(hip_stream)), "tgpu_conv_execute")
+
+    def close(self):
+        if self._h:
+            lib().tgpu_conv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def get_punctured_rate(pu, mother, n):
+    """the reference's puncturer under its own name (host buffers); returns (rc, out)"""
+    m = _np_u8(mother)
+    out = np.zeros(n, np.uint8)
+    rc = lib().get_punctured_rate(pu, m.ctypes.data_as(u8p), n, out.ctypes.data_as(u8p))
+    return rc, out
+
+
+def rcpc_depunct(pu, type3, mother_len, fill=0xFF):
+    """tetra_rcpc_depunct under its own name (host buffers); returns (rc, out)"""
+    t = _np_u8(type3)
+    out = np.full(mother_len, fill, np.uint8)
+    rc = lib().tetra_rcpc_depunct(pu, t.ctypes.data_as(u8p), len(t), out.ctypes.data_as(u8p))
+    return rc, out
 
 
 def grid_indices(outcome):

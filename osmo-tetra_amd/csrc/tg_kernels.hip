@@ -10,6 +10,7 @@
  *   k_fill_*         : forward-fill of the cell scrambling code           (row L, feedback loop 1)
  *   k_masks          : scrambling sequence -> masks in code-word layout   (row X)
  *   k_grid_*         : stream mode: per-slot arrays and item lists from classification words + bitmap
+ *   k_conv<CODE,NCH> : generic trellis: any RCPC puncturer on either mother code
  *
  * No MFMA anywhere: there is no dense contraction on this path.  The trellis kernels are VALU-issue bound
  * packed-u16 integer work (one lane per trellis); the front kernels are byte gathers, part HBM, part issue bound
@@ -1158,6 +1159,111 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 }
 
 /* ------------------------------------------------------------------------- */
+/* generic trellis: any RCPC puncturer on either mother code  */
+/* ------------------------------------------------------------------------- */
+/*
+ * k_conv<CODE, NCH>: tetra_rcpc_depunct() + conv_cch_decode() / conv_tch_decode() for a batch of equally
+ * shaped blocks (lower_mac/tetra_conv_enc.c:226-248, viterbi_cch.c:58-66, viterbi_tch.c:56-64).  One lane per
+ * block, 64 blocks per wave.  The wave's 64 * type3_len received bytes (1 bit per byte, 0xff = erased, the
+ * reference's depunct buffer convention) are one contiguous range: copied to LDS with coalesced dwords, read
+ * back one byte per received bit.  The step program (tg_conv.h: which type-3 byte carries g1 / g2 / g3 of each
+ * step) is uniform, so it is fetched with scalar loads and punctured positions cost a scalar branch, no vector
+ * work.  Per step: <= 3 x (LDS byte, 2 compares, 2 selects), 10 packed adds for the four branch-metric pairs
+ * and their tie variants, 24 for the add-compare-select (tg_step_gen).  History: 16 bytes per 8 steps in
+ * VGPRs (NCH chunks of 32 registers, as k_vit), block-wise traceback, decoded bits transposed through the same
+ * LDS range and written out as one contiguous range.  Metrics are renormalised every 64 steps.
+ */
+template <int CODE, int NCH>
+__global__ __launch_bounds__(64)
+void k_conv(const uint8_t *__restrict__ type3, unsigned long long nblocks, uint32_t t3len, uint32_t L,
+	    const uint32_t *__restrict__ steps, uint8_t *__restrict__ type2)
+{
+	extern __shared__ uint32_t s_dyn[];
+	uint8_t *s_in = (uint8_t *)s_dyn;
+	const uint32_t lane = threadIdx.x;
+	const unsigned long long blk0 = (unsigned long long)blockIdx.x * 64ull;
+	const uint32_t nvalid = (nblocks - blk0 < 64ull) ? (uint32_t)(nblocks - blk0) : 64u;
+
+	{	/* stage the received bytes: blk0 * t3len is a multiple of 64, so the range is dword aligned iff the base is */
+		const uint8_t *src = type3 + blk0 * t3len;
+		const uint32_t nbytes = nvalid * t3len;
+		uint32_t done = 0;
+		if (((uintptr_t)type3 & 3) == 0) {
+			const uint32_t ndw = nbytes >> 2;
+			for (uint32_t w = lane; w < ndw; w += 64)
+				s_dyn[w] = ((const uint32_t *)src)[w];
+			done = ndw << 2;
+		}
+		for (uint32_t q = done + lane; q < nbytes; q += 64)
+			s_in[q] = src[q];
+	}
+	__syncthreads();
+
+	const uint8_t *mine = s_in + (lane < nvalid ? lane : 0) * t3len;
+	auto fetch = [&](uint32_t pos) -> uint32_t { return mine[pos]; };
+
+	const uint32_t nblk = (L + 7) >> 3;
+	tg_vit_state v;
+	uint32_t h[4];
+	tg_vit_init(v);
+	tg_conv_block<CODE>(v, steps, 4, fetch, h);
+	tg_v32 H[NCH];
+#pragma unroll
+	for (int c = 0; c < NCH; c++) {
+		if (8u * c < nblk) {
+			if (c)
+				tg_vit_normalize(v);
+			const uint32_t nb = (nblk - 8u * c < 8u) ? nblk - 8u * c : 8u;
+#pragma unroll 1
+			for (uint32_t it = 0; it < nb; it++) {
+				const uint32_t b = 8u * c + it;
+				const uint32_t left = L - 8u * b;
+				tg_conv_block<CODE>(v, steps + 4 + 8 * b, left < 8 ? (int)left : 8, fetch, h);
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][4 * it + d] = h[d];
+			}
+		}
+	}
+
+	__syncthreads();	/* the received bytes are dead: the same LDS range now takes the decoded bits */
+	uint8_t *outl = s_in + lane * L;
+	const bool al = (L & 3) == 0;
+	uint32_t s = 0;
+#pragma unroll
+	for (int b = 8 * NCH - 1; b >= 0; b--) {
+		if ((uint32_t)b < nblk) {
+			const int c = b >> 3, o = 4 * (b & 7);
+			const uint32_t byte = hist_byte(H[c][o], H[c][o + 1], H[c][o + 2], H[c][o + 3], s);
+			const uint32_t nbits = (L - 8u * b < 8u) ? L - 8u * b : 8u;
+			if (al) {	/* L = 0 mod 4: a block holds 8 or 4 bits */
+				*(uint32_t *)(outl + 8 * b) = spread4(byte);
+				if (nbits > 4)
+					*(uint32_t *)(outl + 8 * b + 4) = spread4(byte >> 4);
+			} else {
+				for (uint32_t i = 0; i < nbits; i++)
+					outl[8 * b + i] = (uint8_t)((byte >> i) & 1);
+			}
+			s = tg_brev4(byte);
+		}
+	}
+	__syncthreads();
+	{
+		uint8_t *dst = type2 + blk0 * L;
+		const uint32_t nbytes = nvalid * L;
+		uint32_t done = 0;
+		if (((uintptr_t)type2 & 3) == 0) {
+			const uint32_t ndw = nbytes >> 2;
+			for (uint32_t w = lane; w < ndw; w += 64)
+				((uint32_t *)dst)[w] = s_dyn[w];
+			done = ndw << 2;
+		}
+		for (uint32_t q = done + lane; q < nbytes; q += 64)
+			dst[q] = s_in[q];
+	}
+}
+
+/* ------------------------------------------------------------------------- */
 /* scrambling-code forward fill: inclusive running max over (chan<<32 | entry) */
 /* ------------------------------------------------------------------------- */
 #define FILL_BLOCK 1024
@@ -1622,6 +1728,38 @@ extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const
 		return -1;
 	}
 #undef VIT_LAUNCH
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_conv(int code, const uint8_t *d_type3, unsigned long long nblocks, uint32_t t3len, uint32_t L,
+			const uint32_t *d_steps, uint8_t *d_type2, void *stream)
+{
+	if (!nblocks)
+		return 0;
+	const uint32_t nch = ((L + 7) / 8 + 7) / 8;
+	const uint32_t span = t3len > L ? t3len : L;
+	const size_t lds = ((size_t)64 * span + 3) & ~(size_t)3;
+	const unsigned long long nwg = (nblocks + 63) / 64;
+	if (nch < 1 || nch > 8 || nwg > 0x7fffffffull || lds > 160 * 1024)
+		return -1;
+	hipStream_t s = (hipStream_t)stream;
+	dim3 grid((unsigned)nwg), block(64);
+#define CONV_LAUNCH(C, N) do {											\
+		if (lds > 48 * 1024)										\
+			HIPCHK(hipFuncSetAttribute((const void *)k_conv<C, N>,					\
+						   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));	\
+		hipLaunchKernelGGL((k_conv<C, N>), grid, block, lds, s, d_type3, nblocks, t3len, L, d_steps, d_type2);	\
+	} while (0)
+#define CONV_CODE(C) switch (nch) {										\
+	case 1: CONV_LAUNCH(C, 1); break; case 2: CONV_LAUNCH(C, 2); break; case 3: CONV_LAUNCH(C, 3); break;		\
+	case 4: CONV_LAUNCH(C, 4); break; case 5: CONV_LAUNCH(C, 5); break; case 6: CONV_LAUNCH(C, 6); break;		\
+	case 7: CONV_LAUNCH(C, 7); break; default: CONV_LAUNCH(C, 8); break; }
+	if (code)
+		CONV_CODE(1)
+	else
+		CONV_CODE(0)
+#undef CONV_CODE
+#undef CONV_LAUNCH
 	return (int)hipGetLastError();
 }
 

@@ -242,6 +242,77 @@ TG_HD void tg_vit_normalize(tg_vit_state &v)
 }
 
 /* =========================================================================================
+ * Generic step (k_conv): up to three received bits g1, g2, g3 of one trellis step, each possibly absent
+ * (punctured) or erased, on either mother code.  Same state layout, tie rule and history as above.
+ *
+ * T_k (k = 1..3) = (mismatch if generator k's expected bit is 1, mismatch if it is 0) << 8 in (low, high)
+ * half = 0x00000100 for a received 0, 0x01000000 for a received 1, 0 for nothing.  For a butterfly whose
+ * out(j,0) has generator bits (e1,e2,e3) the pair (m, n - m) is sum_k (e_k ? T_k : swap(T_k)); complementing
+ * all e_k swaps the pair, so four sums (e3 = 0) serve the eight butterflies; the swaps are op_sel bits.
+ * CODE 0: rate-1/4 code (lower_mac/viterbi_cch.c:35-40), g1..g3 of out(j,0) = {0,11,6,13,5,14,3,8} >> 1
+ * CODE 1: rate-1/3 speech code (lower_mac/viterbi_tch.c:34-39), out(j,0) = {0,6,5,3,6,0,3,5}
+ * Both have 1 and D^4 in every generator, which is all the butterfly symmetry needs.
+ * ========================================================================================= */
+template <int CODE>
+TG_HD void tg_step_gen(tg_vit_state &v, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t tie2)
+{
+	const tg_us2 T1 = tg_as_us2(t1), T2 = tg_as_us2(t2), T3s = tg_as_us2(t3).yx, tie = tg_as_us2(tie2);
+	const tg_us2 A = T1.yx + T2.yx, B = T1 + T2.yx;
+	tg_us2 Cn[4], Ct[4];
+	Cn[0] = A + T3s;		/* (e1,e2) = (0,0) */
+	Cn[1] = B.yx + T3s;		/* (0,1) */
+	Cn[2] = B + T3s;		/* (1,0) */
+	Cn[3] = A.yx + T3s;		/* (1,1) */
+#pragma unroll
+	for (int q = 0; q < 4; q++)
+		Ct[q] = Cn[q] + tie;
+	constexpr unsigned pat_cch[8] = { 0, 5, 3, 6, 2, 7, 1, 4 };
+	constexpr unsigned pat_tch[8] = { 0, 6, 5, 3, 6, 0, 3, 5 };
+	tg_us2 N[8];
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		const unsigned p = CODE ? pat_tch[j] : pat_cch[j];
+		const bool sw = p & 1;
+		const unsigned q = ((sw ? ~p : p) >> 1) & 3;
+		const tg_us2 za = v.Z[j >> 1], zb = v.Z[4 + (j >> 1)];
+		const tg_us2 a = (j & 1) ? za.yy : za.xx;
+		const tg_us2 b = (j & 1) ? zb.yy : zb.xx;
+		const tg_us2 x = a + (sw ? Cn[q].yx : Cn[q]);
+		const tg_us2 y = b + (sw ? Ct[q] : Ct[q].yx);
+		N[j] = tg_min(x, y);
+	}
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		v.Z[j] = N[j];
+}
+
+/* received byte -> T: 0 -> a 0 bit, 0xff -> erased, anything else -> a 1 bit (lower_mac/viterbi.c:12-22) */
+TG_HD uint32_t tg_conv_t(uint32_t c)
+{
+	const uint32_t t = (c == 0) ? 0x00000100u : 0x01000000u;
+	return (c == 0xff) ? 0u : t;
+}
+
+/* one history block of the generic trellis: nst (<= 8) steps described by desc[0 .. nst-1] (tg_conv.h);
+ * fetch(pos) returns received byte 'pos' of this lane's type-3 block */
+template <int CODE, typename Fetch>
+TG_HD void tg_conv_block(tg_vit_state &v, const uint32_t *desc, int nst, Fetch fetch, uint32_t h[4])
+{
+	for (int i = 0; i < nst; i++) {
+		const uint32_t d = desc[i];
+		const uint32_t p1 = d & 0x3ff, p2 = (d >> 10) & 0x3ff, p3 = (d >> 20) & 0x3ff;
+		const uint32_t t1 = (p1 != 0x3ff) ? tg_conv_t(fetch(p1)) : 0u;
+		const uint32_t t2 = (p2 != 0x3ff) ? tg_conv_t(fetch(p2)) : 0u;
+		const uint32_t t3 = (p3 != 0x3ff) ? tg_conv_t(fetch(p3)) : 0u;
+		tg_step_gen<CODE>(v, t1, t2, t3, 0x00010001u << i);
+	}
+#pragma unroll
+	for (int d = 0; d < 4; d++)
+		h[d] = tg_pack_bytes02(tg_as_u32(v.Z[2 * d]), tg_as_u32(v.Z[2 * d + 1]));
+	tg_vit_clean(v);
+}
+
+/* =========================================================================================
  * Soft-input trellis (BASELINE config 5; the reference has no soft path, the definition is ours:
  * int8 soft values, positive = bit 0, correlation metrics, same tie rule -- what libosmocore's
  * accelerated decoder computes when it is handed soft values).

@@ -18,7 +18,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        deps = [SRC] + [os.path.join(ROOT, "osmo-tetra_amd", "csrc", h) for h in ("vit_core.h", "tg_layout.h")]
+        deps = [SRC] + [os.path.join(ROOT, "osmo-tetra_amd", "csrc", h) for h in ("vit_core.h", "tg_layout.h", "tg_conv.h")]
         if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
             subprocess.check_call([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared",
                                    "-I" + os.path.join(ROOT, "osmo-tetra_amd", "csrc"), SRC, "-o", LIB])
@@ -55,3 +55,11 @@ def decode_block_soft(kind, soft4, maskwords=None):
     mw = None if maskwords is None else np.ascontiguousarray(maskwords, np.uint32).ctypes.data_as(u32p)
     crc = lib().emul_decode_soft(kind, area.ctypes.data_as(i8p), mw, out.ctypes.data_as(u8p))
     return out, crc
+
+
+def conv_decode(pu, mother, type3, type2_len):
+    """generic trellis: puncturer pu on the rate-1/mother code; None for a rejected shape"""
+    t3 = np.ascontiguousarray(type3, np.uint8)
+    out = np.zeros(type2_len, np.uint8)
+    rc = lib().emul_conv_decode(pu, mother, len(t3), type2_len, t3.ctypes.data_as(u8p), out.ctypes.data_as(u8p))
+    return None if rc else out

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "tg_layout.h"
+#include "tg_conv.h"
 #include "vit_core.h"
 
 static uint16_t crc_lsb[256], crc_msb[256];
@@ -153,4 +154,44 @@ extern "C" unsigned emul_decode_soft(int kind, const int8_t *area, const uint32_
 		crc = (crc & 0x8000) ? (((crc << 1) ^ 0x1021) & 0xffff) : ((crc << 1) & 0xffff);
 	}
 	return crc;
+}
+
+/* the generic trellis (k_conv) for one block: same step programs, step function, normalisation schedule and
+ * block-wise traceback as the kernel.  returns 0, or -1 for a shape the product rejects */
+template <int CODE>
+static void conv_decode(const uint32_t *steps, unsigned L, const uint8_t *type3, uint8_t *type2)
+{
+	static uint8_t hist[64][16];
+	const unsigned nblk = (L + 7) / 8;
+	auto fetch = [&](uint32_t pos) -> uint32_t { return type3[pos]; };
+	tg_vit_state v;
+	uint32_t h[4];
+	tg_vit_init(v);
+	tg_conv_block<CODE>(v, steps, 4, fetch, h);
+	for (unsigned b = 0; b < nblk; b++) {
+		if (b && !(b & 7))
+			tg_vit_normalize(v);
+		const unsigned left = L + 4 - (4 + 8 * b);
+		tg_conv_block<CODE>(v, steps + 4 + 8 * b, left < 8 ? (int)left : 8, fetch, h);
+		memcpy(hist[b], h, 16);
+	}
+	uint32_t s = 0;
+	for (int b = (int)nblk - 1; b >= 0; b--) {
+		const uint32_t byte = hist[b][s];
+		for (unsigned i = 0; i < 8 && 8 * b + i < L; i++)
+			type2[8 * b + i] = (byte >> i) & 1;
+		s = tg_brev4(byte);
+	}
+}
+
+extern "C" int emul_conv_decode(int pu, int mother, unsigned t3len, unsigned L, const uint8_t *type3, uint8_t *type2)
+{
+	static uint32_t steps[TG_CONV_MAX_T2 + 4];
+	if (tg_conv_build_steps(pu, mother, t3len, L, steps))
+		return -1;
+	if (mother == 3)
+		conv_decode<1>(steps, L, type3, type2);
+	else
+		conv_decode<0>(steps, L, type3, type2);
+	return 0;
 }

@@ -128,6 +128,10 @@ def lib():
     L.orc_conv_encode.argtypes = [u8p, C.c_int, u8p]
     L.orc_puncture.argtypes = [C.c_int, u8p, C.c_int, u8p]
     L.orc_depuncture.argtypes = [C.c_int, u8p, C.c_int, u8p]
+    L.orc_conv_encode_tch.argtypes = [u8p, C.c_int, u8p]
+    L.orc_conv_decode_block.argtypes = [C.c_int, C.c_int, u8p, C.c_uint, C.c_uint, C.c_int, u8p]
+    L.orc_code_output.argtypes = [C.c_int, C.c_uint, C.c_uint]
+    L.orc_code_output.restype = C.c_uint
     i8p = C.POINTER(C.c_int8)
     L.orc_viterbi_generic.argtypes = [i8p, u8p, C.c_int]
     L.orc_viterbi_acc.argtypes = [i8p, u8p, C.c_int]
@@ -226,6 +230,31 @@ def depuncture(pu, x, mother_len, fill=0xFF):
     out = np.full(mother_len, fill, np.uint8)
     assert lib().orc_depuncture(pu, _p(x), len(x), _p(out)) == 0
     return out
+
+
+# lower_mac/tetra_conv_enc.c:257-267 (punct_test_params): (type2_len, type3_len, mother rate, puncturer)
+PUNCT_SHAPES = [(80, 120, 4, 0), (292, 432, 4, 2), (148, 432, 4, 3), (144, 216, 4, 0), (112, 168, 4, 0),
+                (288, 432, 4, 0), (112, 168, 3, 4), (72, 162, 3, 5), (38, 80, 3, 6)]
+
+
+def conv_encode_tch(bits):
+    x = np.ascontiguousarray(bits, np.uint8)
+    out = np.zeros(3 * len(x), np.uint8)
+    lib().orc_conv_encode_tch(_p(x), len(x), _p(out))
+    return out
+
+
+def conv_decode_block(pu, mother, type3, type2_len, use_acc=0):
+    """depuncture + Viterbi for any puncturer on either mother code; None for an invalid shape"""
+    x = np.ascontiguousarray(type3, np.uint8)
+    out = np.zeros(type2_len, np.uint8)
+    rc = lib().orc_conv_decode_block(pu, mother, _p(x), len(x), type2_len, use_acc, _p(out))
+    return None if rc else out
+
+
+def conv_encode_block(pu, mother, type2, type3_len):
+    m = conv_encode_tch(type2) if mother == 3 else conv_encode(type2)
+    return puncture(pu, m, type3_len)
 
 
 def viterbi_hard(type3dp, n, use_acc=0):

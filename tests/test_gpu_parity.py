@@ -1122,3 +1122,113 @@ def test_grid_sync_two_halves_in_flight(T, eng):
             torch.cuda.synchronize()
             assert (r.cpu().numpy() == rec).all()
         p.close()
+
+
+# ---------------------------------------------------------------------------
+# the remaining puncturers + the speech trellis: k_conv
+# ---------------------------------------------------------------------------
+def _conv_batch(shape, n, seed):
+    """n noisy type-3 blocks of one shape: mixed BER, erased (0xff) and non-binary bytes"""
+    L, K, mother, pu = shape
+    rng = np.random.default_rng(seed)
+    t2 = rng.integers(0, 2, (n, L)).astype(np.uint8)
+    t2[::3, -4:] = 0
+    t3 = np.stack([O.conv_encode_block(pu, mother, t2[i], K) for i in range(n)])
+    ber = rng.choice([0.0, 0.02, 0.06, 0.15, 0.5], n)[:, None]
+    t3 ^= (rng.random((n, K)) < ber).astype(np.uint8)
+    er = rng.random((n, K)) < np.where(rng.random(n) < 0.2, 0.15, 0.0)[:, None]
+    t3[er] = 0xFF
+    nb = (rng.random((n, K)) < 0.01) & (t3 == 1)
+    t3[nb] = rng.integers(2, 255, int(nb.sum())).astype(np.uint8)
+    return t2, t3
+
+
+@pytest.mark.parametrize("shape", O.PUNCT_SHAPES)
+def test_generic_trellis_all_puncturers(T, eng, shape):
+    """tgpu_conv_execute == depuncture + Viterbi of the oracle (both restated libosmocore algorithms agree, checked
+    on the CPU side) for every (type2, type3, mother code, puncturer) row of tetra_conv_enc.c:257-267; ragged
+    batch sizes, a byte-misaligned input/output base, empty batch"""
+    import torch
+    L, K, mother, pu = shape
+    cv = T.ConvDecoder(eng, pu, mother, K, L)
+    hs = torch.cuda.current_stream().cuda_stream
+    for n, off in ((1, 0), (63, 0), (64, 0), (200, 0), (131, 1)):
+        t2, t3 = _conv_batch(shape, n, seed=n * 31 + pu)
+        d_in = torch.zeros(n * K + 8, dtype=torch.uint8, device="cuda")
+        d_in[off:off + n * K] = torch.from_numpy(t3.reshape(-1)).cuda()
+        d_out = torch.full((n * L + 8,), 7, dtype=torch.uint8, device="cuda")
+        cv.execute(d_in.data_ptr() + off, n, d_out.data_ptr() + off, hs)
+        torch.cuda.synchronize()
+        raw = d_out.cpu().numpy()
+        got = raw[off:off + n * L].reshape(n, L)
+        assert (raw[:off] == 7).all() and (raw[off + n * L:] == 7).all()          # nothing written outside
+        for i in range(n):
+            want = O.conv_decode_block(pu, mother, t3[i], L, 0)
+            assert (got[i] == want).all(), (shape, n, i)
+    cv.execute(0, 0, 0, hs)                                                        # empty batch: no launch
+    cv.close()
+
+
+def test_generic_trellis_on_the_control_channel_shapes(T, eng):
+    """SCH/F, NDB and SB1 blocks (the shapes the specialised k_vit kernels decode) through k_conv after a host-side
+    de-interleave: the type-2 bits of the oracle's block chain, i.e. of block mode"""
+    import torch
+    rng = np.random.default_rng(12)
+    hs = torch.cuda.current_stream().cuda_stream
+    for t, pshape in ((O.T_SCH_F, (288, 432, 4, 0)), (O.T_NDB, (144, 216, 4, 0)), (O.T_SB1, (80, 120, 4, 0))):
+        K, n2, n1, a = O.BLK[t]
+        n = 96
+        t5 = np.stack([O.encode_block(t, rng.integers(0, 2, n1).astype(np.uint8), 0) for _ in range(n)])
+        t5 ^= (rng.random((n, K)) < 0.06).astype(np.uint8)
+        t3 = np.stack([O.deinterleave(K, a, x) for x in t5])
+        cv = T.ConvDecoder(eng, 0, 4, K, n2)
+        d_in = torch.from_numpy(t3.reshape(-1)).cuda()
+        d_out = torch.zeros(n * n2, dtype=torch.uint8, device="cuda")
+        cv.execute(d_in.data_ptr(), n, d_out.data_ptr(), hs)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().reshape(n, n2)
+        for i in range(n):
+            assert (got[i] == O.decode_block(t, t5[i], 0)[3]).all()
+        cv.close()
+
+
+def test_generic_trellis_full_size_roundtrip(T, eng):
+    """size-independent property at a large batch: encode -> puncture -> k_conv gives the data back (noise-free),
+    and with 3 % channel errors every decoded block is a valid trellis path at least as close to the received
+    bits as the transmitted one (checked through re-encoding on the host for a sample)"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    for shape in ((292, 432, 4, 2), (72, 162, 3, 5)):
+        L, K, mother, pu = shape
+        rng = np.random.default_rng(5)
+        base = 512
+        t2 = rng.integers(0, 2, (base, L)).astype(np.uint8)
+        t2[:, -4:] = 0
+        t3 = np.stack([O.conv_encode_block(pu, mother, x, K) for x in t2])
+        reps = 400                                                                 # 204 800 blocks
+        d_in = torch.from_numpy(t3.reshape(-1)).cuda().repeat(reps)
+        n = base * reps
+        d_out = torch.zeros(n * L, dtype=torch.uint8, device="cuda")
+        cv = T.ConvDecoder(eng, pu, mother, K, L)
+        cv.execute(d_in.data_ptr(), n, d_out.data_ptr(), hs)
+        torch.cuda.synchronize()
+        got = d_out.view(reps, base, L)
+        assert bool((got == torch.from_numpy(t2).cuda()[None]).all())
+        flips = (torch.rand(n * K, device="cuda") < 0.03).to(torch.uint8)
+        d_noisy = d_in ^ flips
+        cv.execute(d_noisy.data_ptr(), n, d_out.data_ptr(), hs)
+        torch.cuda.synchronize()
+        rx = d_noisy.view(n, K)[:: n // 64].cpu().numpy()
+        dec = d_out.view(n, L)[:: n // 64].cpu().numpy()
+        for i in range(len(rx)):
+            assert (dec[i] == O.conv_decode_block(pu, mother, rx[i], L, 0)).all()
+            d_dec = int((O.conv_encode_block(pu, mother, dec[i], K) != rx[i]).sum())
+            d_tx = int((t3[(i * (n // 64)) % base] != rx[i]).sum())
+            assert d_dec <= d_tx
+        cv.close()
+
+
+def test_generic_trellis_rejects_bad_shapes(T, eng):
+    for args in ((7, 4, 120, 80), (0, 5, 120, 80), (0, 4, 432, 80), (0, 4, 15, 10), (0, 4, 1200, 800)):
+        with pytest.raises(T.TgpuError):
+            T.ConvDecoder(eng, *args)

@@ -188,3 +188,64 @@ def test_rm3014_decoder_host():
     for _ in range(400):                       # arbitrary words, many of them beyond the guaranteed radius
         rx = int(rng.integers(0, 1 << 30))
         assert T.rm3014_decode(rx) == O.rm3014_decode_ml(rx)
+
+
+def test_tch_code_tables():
+    """the restated speech code has the reference's trellis (spot values of lower_mac/viterbi_tch.c:34-39) and
+    the symmetry the butterfly form needs (every generator holds 1 and D^4)"""
+    out = lambda s, b: O.lib().orc_code_output(1, s, b)
+    assert [out(0, 0), out(0, 1), out(1, 0), out(1, 1), out(3, 0), out(8, 0), out(15, 1)] == [0, 7, 6, 1, 3, 7, 5]
+    for code, full in ((0, 15), (1, 7)):
+        for s in range(8):
+            for b in (0, 1):
+                o = O.lib().orc_code_output(code, s, b)
+                assert O.lib().orc_code_output(code, s, b ^ 1) == o ^ full
+                assert O.lib().orc_code_output(code, s + 8, b) == o ^ full
+
+
+@pytest.mark.parametrize("shape", O.PUNCT_SHAPES)
+def test_generic_trellis_on_host_bit_exact(shape):
+    """k_conv's per-lane code (step programs of tg_conv.h + tg_step_gen) == depuncture + both restated
+    libosmocore decoders, for every (puncturer, mother code) pair of tetra_conv_enc.c:257-267: clean, noisy,
+    pure noise, erased (0xff) and non-binary input bytes"""
+    L, K, mother, pu = shape
+    rng = np.random.default_rng(L * 7 + pu)
+    for i in range(60):
+        t2 = rng.integers(0, 2, L).astype(np.uint8)
+        t2[-4:] = 0 if i % 3 else t2[-4:]
+        t3 = O.conv_encode_block(pu, mother, t2, K)
+        ber = (0.0, 0.03, 0.08, 0.2, 0.5)[i % 5]
+        t3 = t3 ^ (rng.random(K) < ber).astype(np.uint8)
+        if i % 7 == 3:
+            t3[rng.random(K) < 0.2] = 0xFF
+        if i % 11 == 5:
+            t3[t3 == 1] = rng.integers(1, 255, int((t3 == 1).sum())).astype(np.uint8)
+        want = O.conv_decode_block(pu, mother, t3, L, 0)
+        assert (O.conv_decode_block(pu, mother, t3, L, 1) == want).all()
+        got = emul.conv_decode(pu, mother, t3, L)
+        assert (got == want).all()
+        if ber == 0.0 and i % 7 != 3:
+            assert (want == t2).all() or t2[-4:].any()
+
+
+def test_generic_trellis_rejects_what_the_reference_cannot_index():
+    assert emul.conv_decode(7, 4, np.zeros(120, np.uint8), 80) is None          # unknown puncturer (-EINVAL)
+    assert emul.conv_decode(0, 5, np.zeros(120, np.uint8), 80) is None
+    assert emul.conv_decode(0, 4, np.zeros(432, np.uint8), 80) is None          # positions beyond the mother buffer
+    assert O.conv_decode_block(0, 4, np.zeros(432, np.uint8), 80) is None
+    assert emul.conv_decode(0, 4, np.zeros(15, np.uint8), 10) is None            # 10 % 8 = 2: unsupported history tail
+
+
+def test_puncturer_entry_points_host():
+    """get_punctured_rate / tetra_rcpc_depunct of the product (the reference's names) == the oracle's for all
+    seven puncturers; -EINVAL beyond them (lower_mac/tetra_conv_enc.c:209-210,234-235)"""
+    import errno
+    for L, K, mother, pu in O.PUNCT_SHAPES:
+        m = (np.arange(L * mother) % 251).astype(np.uint8)
+        rc, tx = T.get_punctured_rate(pu, m, K)
+        assert rc == 0 and tx.tolist() == O.puncture(pu, m, K).tolist()
+        rc, dp = T.rcpc_depunct(pu, tx, L * mother)
+        assert rc == 0 and dp.tolist() == O.depuncture(pu, tx, L * mother).tolist()
+        assert int((dp != 0xFF).sum()) == K - int((tx == 0xFF).sum())
+    assert T.get_punctured_rate(7, np.zeros(8, np.uint8), 2)[0] == -errno.EINVAL
+    assert T.rcpc_depunct(9, np.zeros(8, np.uint8), 8)[0] == -errno.EINVAL
