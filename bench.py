@@ -221,6 +221,77 @@ def bench_config5(args, T, torch, rank, world, local):
     print(json.dumps(out))
 
 
+def bench_conv(args, T, torch, rank, world, local):
+    """SURVEY 8(f) item 1 (secondary measurement, N=1): the generic trellis kernel on every (type2, type3, mother
+    code, puncturer) row of lower_mac/tetra_conv_enc.c:257-267 -- n blocks of type-3 bits (1 per byte) resident in
+    HBM -> type-2 bits.  value = the TCH/4.8 shape (292/432)."""
+    n = args.bursts
+    shapes = [("BSCH 80/120 r2/3", 80, 120, 4, 0), ("TCH/4.8 292/432", 292, 432, 4, 2), ("TCH/2.4 148/432", 148, 432, 4, 3),
+              ("SCH/HD 144/216 r2/3", 144, 216, 4, 0), ("SCH/HU 112/168 r2/3", 112, 168, 4, 0),
+              ("SCH/F 288/432 r2/3", 288, 432, 4, 0), ("speech class 1 112/168", 112, 168, 3, 4),
+              ("speech class 2 72/162", 72, 162, 3, 5), ("speech class 2 STCH 38/80", 38, 80, 3, 6)]
+    polys = {4: ((0, 1, 4), (0, 2, 3, 4), (0, 1, 2, 4), (0, 1, 3, 4)), 3: ((0, 1, 2, 3, 4), (0, 1, 3, 4), (0, 2, 4))}
+    eng = T.Engine(local)
+    hs = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(8)
+    res = {}
+    base = 4096
+    for name, L, K, mother, pu in shapes:
+        t2 = rng.integers(0, 2, (base, L)).astype(np.uint8)
+        t2[:, -4:] = 0
+        pad = np.concatenate([np.zeros((base, 4), np.uint8), t2], axis=1)
+        m = np.zeros((base, L, mother), np.uint8)
+        for g, taps in enumerate(polys[mother]):
+            for d in taps:
+                m[:, :, g] ^= pad[:, 4 - d:4 - d + L]
+        t3 = np.stack([T.get_punctured_rate(pu, m[i].reshape(-1), K)[1] for i in range(base)])
+        t3 ^= (rng.random(t3.shape) < args.ber).astype(np.uint8)
+        if L == 292:
+            sample = t3.copy()
+        d_in = torch.from_numpy(t3.reshape(-1)).cuda().repeat(-(-n // base))[:n * K].contiguous()
+        d_out = torch.zeros(n * L, dtype=torch.uint8, device="cuda")
+        cv = T.ConvDecoder(eng, pu, mother, K, L)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for k in range(args.warmup + args.steps):
+            if k == args.warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ev[0].record()
+            cv.execute(d_in.data_ptr(), n, d_out.data_ptr(), hs)
+        ev[1].record()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ms = ev[0].elapsed_time(ev[1]) / args.steps
+        got = d_out.view(n, L)[:base].cpu().numpy()
+        res[name] = {"blocks_per_s": n * args.steps / el, "kernel_ms": ms, "trellis_steps_per_s": n * (L + 4) / (ms * 1e-3),
+                     "algorithmic_GBps": n * (K + L) / (ms * 1e-3) / 1e9,
+                     "blocks_equal_to_tx_first_4096": int((got == t2).all(axis=1).sum())}
+        cv.close()
+        del d_in, d_out
+    head = res["TCH/4.8 292/432"]
+    out = {"metric": "decoded blocks/s", "value": head["blocks_per_s"], "unit": "blocks/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["kernel_ms"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+           "config": {"workload": "SURVEY 8(f)1: %d type-3 blocks per shape resident in HBM (1 bit per byte, BER %g) -> "
+                                  "de-puncture + 16-state Viterbi (k_conv) -> type-2 bits; value = TCH/4.8 (292/432)" % (n, args.ber)},
+           "shapes": res}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        import oraclelib as O
+        name, L, K, mother, pu = shapes[1]
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < 10.0:
+            for i in range(256):
+                O.conv_decode_block(pu, mother, sample[(done + i) % base], L, 0)
+            done += 256
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": done / el, "unit": "blocks/s", "cores": 1, "kind": "port",
+                               "sample": "%d TCH/4.8 blocks of the same workload in %.1f s, oracle/tetra_oracle.c (depuncture + generic "
+                                         "libosmocore Viterbi restatement)" % (done, el)}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,7 +304,7 @@ def main():
                     help="N>1: 'final' = one RCCL gather of the decoded blocks (48-byte wire records) at the end of the "
                          "timed region; 'step' = one gather per step, overlapped with the next decode (needs about "
                          "110 GB/s per xGMI link at the single-GPU decode rate)")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "conv"],
                     help="config2 (default, the metric's workload): aligned NDB slots; config3: mixed SB/NDB stream "
                          "through the GPU burst-sync front end, 1%% corrupted training sequences")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -266,6 +337,8 @@ def main():
         return bench_config3(args, T, torch, rank, world, local)
     if args.workload == "config5":
         return bench_config5(args, T, torch, rank, world, local)
+    if args.workload == "conv":
+        return bench_conv(args, T, torch, rank, world, local)
 
     n = args.bursts
     rng = np.random.default_rng(1000 + rank)

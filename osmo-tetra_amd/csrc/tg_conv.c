@@ -18,6 +18,7 @@
 
 struct tgpu_conv {
 	int code;			/* 0: rate-1/4 CCH code, 1: rate-1/3 speech code */
+	int g3;				/* some step receives g3 */
 	uint32_t type3_len, type2_len;
 	uint32_t *d_steps;
 };
@@ -25,7 +26,7 @@ struct tgpu_conv {
 int tgpu_conv_create(struct tgpu_engine *eng, int punct, int mother_rate, uint32_t type3_len, uint32_t type2_len,
 		     struct tgpu_conv **out)
 {
-	uint32_t steps[TG_CONV_MAX_T2 + 4];
+	uint32_t steps[(TG_CONV_MAX_T2 + 4) * TG_CONV_DESC_WORDS];
 
 	if (!eng || !out)
 		return TGPU_EINVAL;
@@ -36,9 +37,10 @@ int tgpu_conv_create(struct tgpu_engine *eng, int punct, int mother_rate, uint32
 	if (!cv)
 		return TGPU_ENOMEM;
 	cv->code = (mother_rate == 3);
+	cv->g3 = tg_conv_uses_g3(steps, type2_len);
 	cv->type3_len = type3_len;
 	cv->type2_len = type2_len;
-	const size_t bytes = (size_t)(type2_len + 4) * sizeof(uint32_t);
+	const size_t bytes = (size_t)(type2_len + 4) * TG_CONV_DESC_WORDS * sizeof(uint32_t);
 	if (hipMalloc((void **)&cv->d_steps, bytes) != hipSuccess) {
 		free(cv);
 		return TGPU_ENOMEM;
@@ -56,7 +58,7 @@ int tgpu_conv_execute(struct tgpu_conv *cv, const void *d_type3, uint64_t nblock
 {
 	if (!cv || (nblocks && (!d_type3 || !d_type2)))
 		return TGPU_EINVAL;
-	return tgk_conv(cv->code, (const uint8_t *)d_type3, nblocks, cv->type3_len, cv->type2_len, cv->d_steps,
+	return tgk_conv(cv->code, cv->g3, (const uint8_t *)d_type3, nblocks, cv->type3_len, cv->type2_len, cv->d_steps,
 			(uint8_t *)d_type2, hip_stream);
 }
 

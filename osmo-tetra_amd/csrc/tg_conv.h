@@ -14,7 +14,11 @@
 #include <stdint.h>
 
 #define TG_CONV_NPUNCT   7
-#define TG_CONV_ABSENT   0x3ffu		/* step descriptor: pos_g1 | pos_g2 << 10 | pos_g3 << 20 */
+/* step descriptor: three dwords, one per generator g1, g2, g3.  For received position p (class byte p >> 2,
+ * field shift 2 * (p & 3), vit_core.h): (p >> 2) << 24 | multiplier 0x800100 >> shift; 0 = nothing received
+ * (the multiplier 0 makes the branch-metric term vanish).  The kernel uses the dword as it is as the 24-bit
+ * multiplier and its top byte as the LDS byte index. */
+#define TG_CONV_DESC_WORDS 3
 #define TG_CONV_MAX_T3   1022u
 #define TG_CONV_MAX_T2   504u		/* 8 * 63 history blocks */
 
@@ -35,7 +39,7 @@ static inline uint32_t tg_conv_mother_pos(int pu, uint32_t j)
 	return d[pu].period * q + d[pu].p[i - 1 - d[pu].t * q];
 }
 
-/* steps[0 .. type2_len + 3]: the last four are the flush steps (nothing received).  0 on success. */
+/* steps[0 .. 3 * (type2_len + 4) - 1]: the last four steps are the flush steps (nothing received).  0 on success. */
 static inline int tg_conv_build_steps(int pu, int mother_rate, uint32_t type3_len, uint32_t type2_len, uint32_t *steps)
 {
 	if (pu < 0 || pu >= TG_CONV_NPUNCT || (mother_rate != 3 && mother_rate != 4))
@@ -44,18 +48,26 @@ static inline int tg_conv_build_steps(int pu, int mother_rate, uint32_t type3_le
 		return -1;
 	if ((type2_len & 7) != 0 && (type2_len & 7) < 4)
 		return -1;	/* the last (partial) history block must hold the state it starts in */
-	for (uint32_t s = 0; s < type2_len + 4; s++)
-		steps[s] = TG_CONV_ABSENT | (TG_CONV_ABSENT << 10) | (TG_CONV_ABSENT << 20);
+	for (uint32_t s = 0; s < (type2_len + 4) * TG_CONV_DESC_WORDS; s++)
+		steps[s] = 0;
 	for (uint32_t j = 1; j <= type3_len; j++) {
 		const uint32_t k = tg_conv_mother_pos(pu, j) - 1;
 		const uint32_t s = k / (uint32_t)mother_rate, g = k % (uint32_t)mother_rate;
 		if (s >= type2_len || g > 2)
 			return -1;
-		const uint32_t sh = 10 * g;
-		if (((steps[s] >> sh) & 0x3ff) != TG_CONV_ABSENT)
+		if (steps[s * TG_CONV_DESC_WORDS + g])
 			return -1;
-		steps[s] = (steps[s] & ~(0x3ffu << sh)) | ((j - 1) << sh);
+		steps[s * TG_CONV_DESC_WORDS + g] = (((j - 1) >> 2) << 24) | (0x800100u >> (2 * ((j - 1) & 3)));
 	}
+	return 0;
+}
+
+/* does any step of the program receive g3?  (selects the kernel variant) */
+static inline int tg_conv_uses_g3(const uint32_t *steps, uint32_t type2_len)
+{
+	for (uint32_t s = 0; s < type2_len + 4; s++)
+		if (steps[s * TG_CONV_DESC_WORDS + 2])
+			return 1;
 	return 0;
 }
 

@@ -33,8 +33,9 @@ int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc, uint32_t n
 int tgk_float_to_bits(const float *d_in, unsigned long long n, uint8_t *d_bits, int8_t *d_soft, void *stream);
 int tgk_float_to_bits_afc(const float *d_in, unsigned long long n, uint8_t *d_bits, float filter_val,
 			  float filter_goal, float *d_state, void *stream);
-/* generic trellis (tg_conv.h step program in d_steps); code 0: rate-1/4 CCH code, 1: rate-1/3 speech code */
-int tgk_conv(int code, const uint8_t *d_type3, unsigned long long nblocks, uint32_t t3len, uint32_t L,
+/* generic trellis (tg_conv.h step program in d_steps); code 0: rate-1/4 CCH code, 1: rate-1/3 speech code;
+ * g3: the program receives g3 somewhere (tg_conv_uses_g3) */
+int tgk_conv(int code, int g3, const uint8_t *d_type3, unsigned long long nblocks, uint32_t t3len, uint32_t L,
 	     const uint32_t *d_steps, uint8_t *d_type2, void *stream);
 int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uint32_t *d_sb_ok,
 	     uint32_t nchan, uint32_t nslots, unsigned long long *d_block_tmp, uint32_t *d_maskidx, void *stream);

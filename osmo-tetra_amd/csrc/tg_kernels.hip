@@ -1162,51 +1162,80 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 /* generic trellis: any RCPC puncturer on either mother code  */
 /* ------------------------------------------------------------------------- */
 /*
- * k_conv<CODE, NCH>: tetra_rcpc_depunct() + conv_cch_decode() / conv_tch_decode() for a batch of equally
+ * k_conv<CODE, NCH, G3>: tetra_rcpc_depunct() + conv_cch_decode() / conv_tch_decode() for a batch of equally
  * shaped blocks (lower_mac/tetra_conv_enc.c:226-248, viterbi_cch.c:58-66, viterbi_tch.c:56-64).  One lane per
  * block, 64 blocks per wave.  The wave's 64 * type3_len received bytes (1 bit per byte, 0xff = erased, the
- * reference's depunct buffer convention) are one contiguous range: copied to LDS with coalesced dwords, read
- * back one byte per received bit.  The step program (tg_conv.h: which type-3 byte carries g1 / g2 / g3 of each
- * step) is uniform, so it is fetched with scalar loads and punctured positions cost a scalar branch, no vector
- * work.  Per step: <= 3 x (LDS byte, 2 compares, 2 selects), 10 packed adds for the four branch-metric pairs
- * and their tie variants, 24 for the add-compare-select (tg_step_gen).  History: 16 bytes per 8 steps in
+ * reference's depunct buffer convention) are one contiguous range: read with coalesced dwords, reduced to 2-bit
+ * classes (0 bit / 1 bit / erased), four to an LDS byte.  The step program (tg_conv.h: which type-3 byte carries
+ * g1 / g2 / g3 of each step) is uniform: it is fetched with scalar loads and all the index / shift / presence
+ * arithmetic runs on the scalar unit.  Per step the vector unit does 3 x (address add, LDS byte read, 24-bit
+ * multiply, mask), 10 packed adds for the four branch-metric pairs and their tie variants and 24 for the
+ * add-compare-select (tg_step_gen).  History: 16 bytes per 8 steps in
  * VGPRs (NCH chunks of 32 registers, as k_vit), block-wise traceback, decoded bits transposed through the same
  * LDS range and written out as one contiguous range.  Metrics are renormalised every 64 steps.
  */
-template <int CODE, int NCH>
+template <int CODE, int NCH, bool G3>
 __global__ __launch_bounds__(64)
 void k_conv(const uint8_t *__restrict__ type3, unsigned long long nblocks, uint32_t t3len, uint32_t L,
-	    const uint32_t *__restrict__ steps, uint8_t *__restrict__ type2)
+	    const uint32_t *__restrict__ steps, uint8_t *__restrict__ type2, uint32_t rawoff)
 {
 	extern __shared__ uint32_t s_dyn[];
 	uint8_t *s_in = (uint8_t *)s_dyn;
 	const uint32_t lane = threadIdx.x;
 	const unsigned long long blk0 = (unsigned long long)blockIdx.x * 64ull;
 	const uint32_t nvalid = (nblocks - blk0 < 64ull) ? (uint32_t)(nblocks - blk0) : 64u;
+	const uint32_t nq = (t3len + 3) >> 2;		/* class bytes per block (LDS row pitch) */
 
-	{	/* stage the received bytes: blk0 * t3len is a multiple of 64, so the range is dword aligned iff the base is */
+	{	/* stage: four received bytes -> one class byte (tg_conv_pack4) */
 		const uint8_t *src = type3 + blk0 * t3len;
-		const uint32_t nbytes = nvalid * t3len;
-		uint32_t done = 0;
-		if (((uintptr_t)type3 & 3) == 0) {
-			const uint32_t ndw = nbytes >> 2;
+		if ((t3len & 3) == 0 && ((uintptr_t)type3 & 3) == 0) {
+			/* rows are whole dwords and blk0 * t3len is a multiple of 64: one flat, coalesced dword range */
+			const uint32_t ndw = nvalid * nq;
 			for (uint32_t w = lane; w < ndw; w += 64)
-				s_dyn[w] = ((const uint32_t *)src)[w];
-			done = ndw << 2;
+				s_in[w] = (uint8_t)tg_conv_pack4(((const uint32_t *)src)[w]);
+		} else {
+			/* odd row length or base: the raw bytes go to a second LDS range first (flat, dwords when the base
+			 * allows), then (row, quad) pairs flat over the wave are reduced from there; the row index by a
+			 * corrected float division (all values < 2^15) */
+			uint8_t *raw = s_in + rawoff;
+			const uint32_t nbytes = nvalid * t3len;
+			uint32_t done = 0;
+			if (((uintptr_t)type3 & 3) == 0) {
+				const uint32_t ndw = nbytes >> 2;
+				for (uint32_t w = lane; w < ndw; w += 64)
+					((uint32_t *)raw)[w] = ((const uint32_t *)src)[w];
+				done = ndw << 2;
+			}
+			for (uint32_t i = done + lane; i < nbytes; i += 64)
+				raw[i] = src[i];
+			__syncthreads();
+			const uint32_t nitem = nvalid * nq;
+			const float inv = 1.0f / (float)nq;
+			for (uint32_t w = lane; w < nitem; w += 64) {
+				uint32_t r = (uint32_t)(((float)w + 0.5f) * inv);
+				r -= (r * nq > w);
+				r += ((r + 1) * nq <= w);
+				const uint32_t q = w - r * nq;
+				const uint8_t *row = raw + r * t3len;
+				/* one (unaligned) LDS dword read; bytes past the row (the raw range has 4 spare bytes) -> erased */
+				uint32_t x;
+				__builtin_memcpy(&x, row + 4 * q, 4);
+				const uint32_t nv = t3len - 4 * q;
+				x |= (nv < 4) ? (0xffffffffu << (8 * nv)) : 0u;
+				s_in[w] = (uint8_t)tg_conv_pack4(x);
+			}
 		}
-		for (uint32_t q = done + lane; q < nbytes; q += 64)
-			s_in[q] = src[q];
 	}
 	__syncthreads();
 
-	const uint8_t *mine = s_in + (lane < nvalid ? lane : 0) * t3len;
-	auto fetch = [&](uint32_t pos) -> uint32_t { return mine[pos]; };
+	const uint8_t *mine = s_in + (lane < nvalid ? lane : 0) * nq;
+	auto fetch = [&](uint32_t q) -> uint32_t { return mine[q]; };
 
 	const uint32_t nblk = (L + 7) >> 3;
 	tg_vit_state v;
 	uint32_t h[4];
 	tg_vit_init(v);
-	tg_conv_block<CODE>(v, steps, 4, fetch, h);
+	tg_conv_block<CODE, G3, 4>(v, steps, 4, fetch, h);
 	tg_v32 H[NCH];
 #pragma unroll
 	for (int c = 0; c < NCH; c++) {
@@ -1218,7 +1247,10 @@ void k_conv(const uint8_t *__restrict__ type3, unsigned long long nblocks, uint3
 			for (uint32_t it = 0; it < nb; it++) {
 				const uint32_t b = 8u * c + it;
 				const uint32_t left = L - 8u * b;
-				tg_conv_block<CODE>(v, steps + 4 + 8 * b, left < 8 ? (int)left : 8, fetch, h);
+				if (left >= 8)
+					tg_conv_block<CODE, G3, 8>(v, steps + 3 * (4 + 8 * b), 8, fetch, h);
+				else
+					tg_conv_block<CODE, G3, 0>(v, steps + 3 * (4 + 8 * b), (int)left, fetch, h);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][4 * it + d] = h[d];
@@ -1731,33 +1763,40 @@ extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const
 	return (int)hipGetLastError();
 }
 
-extern "C" int tgk_conv(int code, const uint8_t *d_type3, unsigned long long nblocks, uint32_t t3len, uint32_t L,
+extern "C" int tgk_conv(int code, int g3, const uint8_t *d_type3, unsigned long long nblocks, uint32_t t3len, uint32_t L,
 			const uint32_t *d_steps, uint8_t *d_type2, void *stream)
 {
 	if (!nblocks)
 		return 0;
 	const uint32_t nch = ((L + 7) / 8 + 7) / 8;
-	const uint32_t span = t3len > L ? t3len : L;
-	const size_t lds = ((size_t)64 * span + 3) & ~(size_t)3;
+	const uint32_t span = (t3len + 3) / 4 > L ? (t3len + 3) / 4 : L;	/* class bytes in, decoded bits out */
+	const uint32_t rawoff = (64 * span + 3) & ~3u;
+	/* rows that are not whole dwords (or an odd base) are staged through a raw copy behind the working range */
+	const bool odd = (t3len & 3) || ((uintptr_t)d_type3 & 3);
+	const size_t lds = (size_t)rawoff + (odd ? ((((size_t)64 * t3len + 3) & ~(size_t)3) + 4) : 0);
 	const unsigned long long nwg = (nblocks + 63) / 64;
 	if (nch < 1 || nch > 8 || nwg > 0x7fffffffull || lds > 160 * 1024)
 		return -1;
 	hipStream_t s = (hipStream_t)stream;
 	dim3 grid((unsigned)nwg), block(64);
-#define CONV_LAUNCH(C, N) do {											\
+#define CONV_LAUNCH(C, N, G) do {											\
 		if (lds > 48 * 1024)										\
-			HIPCHK(hipFuncSetAttribute((const void *)k_conv<C, N>,					\
+			HIPCHK(hipFuncSetAttribute((const void *)k_conv<C, N, G>,				\
 						   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));	\
-		hipLaunchKernelGGL((k_conv<C, N>), grid, block, lds, s, d_type3, nblocks, t3len, L, d_steps, d_type2);	\
+		hipLaunchKernelGGL((k_conv<C, N, G>), grid, block, lds, s, d_type3, nblocks, t3len, L, d_steps, d_type2, rawoff);	\
 	} while (0)
-#define CONV_CODE(C) switch (nch) {										\
-	case 1: CONV_LAUNCH(C, 1); break; case 2: CONV_LAUNCH(C, 2); break; case 3: CONV_LAUNCH(C, 3); break;		\
-	case 4: CONV_LAUNCH(C, 4); break; case 5: CONV_LAUNCH(C, 5); break; case 6: CONV_LAUNCH(C, 6); break;		\
-	case 7: CONV_LAUNCH(C, 7); break; default: CONV_LAUNCH(C, 8); break; }
-	if (code)
-		CONV_CODE(1)
+#define CONV_CODE(C, G) switch (nch) {										\
+	case 1: CONV_LAUNCH(C, 1, G); break; case 2: CONV_LAUNCH(C, 2, G); break; case 3: CONV_LAUNCH(C, 3, G); break;	\
+	case 4: CONV_LAUNCH(C, 4, G); break; case 5: CONV_LAUNCH(C, 5, G); break; case 6: CONV_LAUNCH(C, 6, G); break;	\
+	case 7: CONV_LAUNCH(C, 7, G); break; default: CONV_LAUNCH(C, 8, G); break; }
+	if (code && g3)
+		CONV_CODE(1, true)
+	else if (code)
+		CONV_CODE(1, false)
+	else if (g3)
+		CONV_CODE(0, true)
 	else
-		CONV_CODE(0)
+		CONV_CODE(0, false)
 #undef CONV_CODE
 #undef CONV_LAUNCH
 	return (int)hipGetLastError();

@@ -253,16 +253,23 @@ TG_HD void tg_vit_normalize(tg_vit_state &v)
  * CODE 1: rate-1/3 speech code (lower_mac/viterbi_tch.c:34-39), out(j,0) = {0,6,5,3,6,0,3,5}
  * Both have 1 and D^4 in every generator, which is all the butterfly symmetry needs.
  * ========================================================================================= */
-template <int CODE>
+template <int CODE, bool G3>
 TG_HD void tg_step_gen(tg_vit_state &v, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t tie2)
 {
 	const tg_us2 T1 = tg_as_us2(t1), T2 = tg_as_us2(t2), T3s = tg_as_us2(t3).yx, tie = tg_as_us2(tie2);
 	const tg_us2 A = T1.yx + T2.yx, B = T1 + T2.yx;
 	tg_us2 Cn[4], Ct[4];
-	Cn[0] = A + T3s;		/* (e1,e2) = (0,0) */
-	Cn[1] = B.yx + T3s;		/* (0,1) */
-	Cn[2] = B + T3s;		/* (1,0) */
-	Cn[3] = A.yx + T3s;		/* (1,1) */
+	if (G3) {
+		Cn[0] = A + T3s;	/* (e1,e2) = (0,0) */
+		Cn[1] = B.yx + T3s;	/* (0,1) */
+		Cn[2] = B + T3s;	/* (1,0) */
+		Cn[3] = A.yx + T3s;	/* (1,1) */
+	} else {			/* a puncturer that never keeps g3 (2/3, 292/432, 8/12) */
+		Cn[0] = A;
+		Cn[1] = B.yx;
+		Cn[2] = B;
+		Cn[3] = A.yx;
+	}
 #pragma unroll
 	for (int q = 0; q < 4; q++)
 		Ct[q] = Cn[q] + tie;
@@ -286,25 +293,57 @@ TG_HD void tg_step_gen(tg_vit_state &v, uint32_t t1, uint32_t t2, uint32_t t3, u
 		v.Z[j] = N[j];
 }
 
-/* received byte -> T: 0 -> a 0 bit, 0xff -> erased, anything else -> a 1 bit (lower_mac/viterbi.c:12-22) */
-TG_HD uint32_t tg_conv_t(uint32_t c)
+/*
+ * Received bytes are held as 2-bit classes, four to a byte (byte k of a dword in bits 2k..2k+1):
+ * 0 = erased (0xff), 1 = a 0 bit (0x00), 2 = a 1 bit (anything else) -- lower_mac/viterbi.c:12-22.
+ * SWAR: bit 7 of each byte of nz / nf says "byte != 0" / "byte != 0xff".
+ */
+TG_HD uint32_t tg_conv_pack4(uint32_t x)
 {
-	const uint32_t t = (c == 0) ? 0x00000100u : 0x01000000u;
-	return (c == 0xff) ? 0u : t;
+	const uint32_t nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+	const uint32_t y = ~x;
+	const uint32_t nf = (((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u;
+	const uint32_t q = ((nz ^ 0x80808080u) >> 7) | ((nz & nf) >> 6);
+	return (q | (q >> 6) | (q >> 12) | (q >> 18)) & 0xffu;
 }
 
-/* one history block of the generic trellis: nst (<= 8) steps described by desc[0 .. nst-1] (tg_conv.h);
- * fetch(pos) returns received byte 'pos' of this lane's type-3 block */
-template <int CODE, typename Fetch>
-TG_HD void tg_conv_block(tg_vit_state &v, const uint32_t *desc, int nst, Fetch fetch, uint32_t h[4])
+/* T of a received position from the class byte that holds it and its descriptor dword (tg_conv.h): class bit 0
+ * -> bit 8, class bit 1 -> bit 24 with one 24-bit multiply by 0x800100 >> shift (the two shifted copies of the
+ * byte cannot overlap; the multiply ignores the descriptor's top byte) and one mask */
+TG_HD uint32_t tg_conv_t(uint32_t classbyte, uint32_t desc)
 {
-	for (int i = 0; i < nst; i++) {
-		const uint32_t d = desc[i];
-		const uint32_t p1 = d & 0x3ff, p2 = (d >> 10) & 0x3ff, p3 = (d >> 20) & 0x3ff;
-		const uint32_t t1 = (p1 != 0x3ff) ? tg_conv_t(fetch(p1)) : 0u;
-		const uint32_t t2 = (p2 != 0x3ff) ? tg_conv_t(fetch(p2)) : 0u;
-		const uint32_t t3 = (p3 != 0x3ff) ? tg_conv_t(fetch(p3)) : 0u;
-		tg_step_gen<CODE>(v, t1, t2, t3, 0x00010001u << i);
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __umul24(classbyte, desc) & 0x01000100u;
+#else
+	return (classbyte * (desc & 0xffffffu)) & 0x01000100u;
+#endif
+}
+
+/* one history block of the generic trellis: NST (0: nst_rt, at run time) steps described by desc[] (three
+ * dwords per step, tg_conv.h); fetch(q) returns class byte q (received positions 4q .. 4q+3) of this lane's
+ * type-3 block.  The descriptors are wave-uniform (scalar loads); per generator and step the vector unit does one
+ * address add, one LDS byte read, one multiply and one mask, whether or not that position was punctured.
+ * Two phases, so that the block's reads are in flight before the first add-compare-select needs one. */
+template <int CODE, bool G3, int NST, typename Fetch>
+TG_HD void tg_conv_block(tg_vit_state &v, const uint32_t *desc, int nst_rt, Fetch fetch, uint32_t h[4])
+{
+	const int nst = NST ? NST : nst_rt;
+	uint32_t t[8][3];
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			t[i][k] = 0;
+			if (k < 2 || G3) {
+				const uint32_t d = (i < nst) ? desc[3 * i + k] : 0u;
+				t[i][k] = tg_conv_t(fetch(d >> 24), d);
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		if (i < nst)
+			tg_step_gen<CODE, G3>(v, t[i][0], t[i][1], t[i][2], 0x00010001u << i);
 	}
 #pragma unroll
 	for (int d = 0; d < 4; d++)

@@ -158,21 +158,32 @@ extern "C" unsigned emul_decode_soft(int kind, const int8_t *area, const uint32_
 
 /* the generic trellis (k_conv) for one block: same step programs, step function, normalisation schedule and
  * block-wise traceback as the kernel.  returns 0, or -1 for a shape the product rejects */
-template <int CODE>
-static void conv_decode(const uint32_t *steps, unsigned L, const uint8_t *type3, uint8_t *type2)
+template <int CODE, bool G3>
+static void conv_decode(const uint32_t *steps, unsigned t3len, unsigned L, const uint8_t *type3, uint8_t *type2)
 {
 	static uint8_t hist[64][16];
+	static uint8_t cls[(TG_CONV_MAX_T3 + 3) / 4];
 	const unsigned nblk = (L + 7) / 8;
-	auto fetch = [&](uint32_t pos) -> uint32_t { return type3[pos]; };
+	/* the kernel's staging: four received bytes -> one class byte (positions past the block: erased) */
+	for (unsigned q = 0; q < (t3len + 3) / 4; q++) {
+		uint32_t x = 0xffffffffu;
+		for (unsigned k = 0; k < 4 && 4 * q + k < t3len; k++)
+			x = (x & ~(0xffu << (8 * k))) | ((uint32_t)type3[4 * q + k] << (8 * k));
+		cls[q] = (uint8_t)tg_conv_pack4(x);
+	}
+	auto fetch = [&](uint32_t q) -> uint32_t { return cls[q]; };
 	tg_vit_state v;
 	uint32_t h[4];
 	tg_vit_init(v);
-	tg_conv_block<CODE>(v, steps, 4, fetch, h);
+	tg_conv_block<CODE, G3, 4>(v, steps, 4, fetch, h);
 	for (unsigned b = 0; b < nblk; b++) {
 		if (b && !(b & 7))
 			tg_vit_normalize(v);
 		const unsigned left = L + 4 - (4 + 8 * b);
-		tg_conv_block<CODE>(v, steps + 4 + 8 * b, left < 8 ? (int)left : 8, fetch, h);
+		if (left >= 8)
+			tg_conv_block<CODE, G3, 8>(v, steps + 3 * (4 + 8 * b), 8, fetch, h);
+		else
+			tg_conv_block<CODE, G3, 0>(v, steps + 3 * (4 + 8 * b), (int)left, fetch, h);
 		memcpy(hist[b], h, 16);
 	}
 	uint32_t s = 0;
@@ -186,12 +197,13 @@ static void conv_decode(const uint32_t *steps, unsigned L, const uint8_t *type3,
 
 extern "C" int emul_conv_decode(int pu, int mother, unsigned t3len, unsigned L, const uint8_t *type3, uint8_t *type2)
 {
-	static uint32_t steps[TG_CONV_MAX_T2 + 4];
+	static uint32_t steps[(TG_CONV_MAX_T2 + 4) * TG_CONV_DESC_WORDS];
 	if (tg_conv_build_steps(pu, mother, t3len, L, steps))
 		return -1;
+	const bool g3 = tg_conv_uses_g3(steps, L);
 	if (mother == 3)
-		conv_decode<1>(steps, L, type3, type2);
+		g3 ? conv_decode<1, true>(steps, t3len, L, type3, type2) : conv_decode<1, false>(steps, t3len, L, type3, type2);
 	else
-		conv_decode<0>(steps, L, type3, type2);
+		g3 ? conv_decode<0, true>(steps, t3len, L, type3, type2) : conv_decode<0, false>(steps, t3len, L, type3, type2);
 	return 0;
 }
