@@ -269,12 +269,26 @@ def bench_conv(args, T, torch, rank, world, local):
         cv.close()
         del d_in, d_out
     head = res["TCH/4.8 292/432"]
+    traffic = busy = None
+    try:
+        tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
+        if n == 1_000_000:
+            traffic = tj.get("k_conv<0, 5, false>")
+        busy = tj.get("valu_busy", {}).get("k_conv<0, 5, false>")
+    except (OSError, ValueError):
+        pass
     out = {"metric": "decoded blocks/s", "value": head["blocks_per_s"], "unit": "blocks/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["kernel_ms"], "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
            "config": {"workload": "SURVEY 8(f)1: %d type-3 blocks per shape resident in HBM (1 bit per byte, BER %g) -> "
                                   "de-puncture + 16-state Viterbi (k_conv) -> type-2 bits; value = TCH/4.8 (292/432)" % (n, args.ber)},
-           "shapes": res}
+           "shapes": res,
+           "roofline": {"bound": "hbm", "kernel": "k_conv<0, 5, false> (TCH/4.8)", "achieved": head["algorithmic_GBps"],
+                        "peak": 8000.0, "unit": "GB/s", "frac": head["algorithmic_GBps"] / 8000.0, "traffic": traffic,
+                        "valu_busy_frac": busy, "kernel_ms": head["kernel_ms"],
+                        "note": "achieved = (432 type-3 bytes in + 292 type-2 bytes out) x blocks / mean HIP-event duration of the "
+                                "launches of the timed region; the kernel is VALU-issue bound like the specialised trellis kernels "
+                                "(about 37 vector instructions per trellis step, profiles/r01_conv_rocprofv3.md)"}}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
         import oraclelib as O
