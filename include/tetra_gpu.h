@@ -456,6 +456,18 @@ int get_punctured_rate(int pu, uint8_t *in, int len, uint8_t *out);
 int tetra_rcpc_depunct(int pu, const uint8_t *in, int len, uint8_t *out);
 
 /*
+ * GSMTAP wire format of a decoded block: the message tetra_gsmtap_makemsg() builds
+ * (tetra_gsmtap.c:31-63; called for every CRC-OK block with ts = tdma_time.tn - 1, ss = signal_dbm = snr = 0,
+ * bitdata = msg->l1h, bitlen = msgb_l1len(msg), tetra_upper_mac.c:483-486) -- same arguments, the message goes to
+ * 'out' instead of a msgb: 16-byte GSMTAP v2 header (type TETRA_I1, frame number = ((hn*60)+mn)*18+fn in network
+ * order, channel sub-type) + the bits packed MSB first.  Returns the message length, TGPU_EINVAL if out_size
+ * is too small.  In a tgpu_unitdata_cb: bitdata = ud->type1 + offset, bitlen = ud->type1_len - offset.
+ */
+int tgpu_gsmtap_makemsg(const struct tetra_tdma_time *tm, enum tetra_log_chan lchan, uint8_t ts, uint8_t ss,
+			int8_t signal_dbm, uint8_t snr, const uint8_t *bitdata, unsigned int bitlen,
+			uint8_t *out, size_t out_size);
+
+/*
  * The reference's traffic-channel dump block (lower_mac/tetra_lower_mac.c:213-231, the input format of the
  * ETSI codec tools): 690 int16 = six frames of marker 0x6b21+i + 114 soft bits (bit 1 -> -127, bit 0 -> +127;
  * 432 bits in total, the rest 0), made from the descrambled type-4 bits a traffic block is delivered with

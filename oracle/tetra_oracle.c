@@ -1090,3 +1090,45 @@ void orc_decode_block_soft(enum orc_tpsap_type type, const int8_t *soft5, uint32
 	}
 	memcpy(res->type1, res->type2, p->type1_bits);
 }
+
+/* ======================================================================
+ * (f)3 -- GSMTAP message of a decoded block: tetra_gsmtap.c:31-63 (header fields, osmo_ubit2pbit),
+ * :19-29 (lchan -> GSMTAP_TETRA_* sub-type), tetra_tdma.c:96-99 (frame number).  struct gsmtap_hdr and the
+ * constants are libosmocore's gsmtap.h (un-vendored): version 2, header 16 bytes = {version, hdr_len (words),
+ * type, timeslot, arfcn be16, signal_dbm, snr_db, frame_number be32, sub_type, antenna_nr, sub_slot, res};
+ * GSMTAP_TYPE_TETRA_I1 = 5; GSMTAP_TETRA_BSCH 1, AACH 2, SCH_HU 3, SCH_HD 4, SCH_F 5, BNCH 6, STCH 7, TCH_F 8.
+ * ==================================================================== */
+int orc_gsmtap_makemsg(const struct orc_tdma_time *tm, int lchan, uint8_t ts, uint8_t ss, int8_t signal_dbm,
+		       uint8_t snr, const uint8_t *bits, unsigned bitlen, uint8_t *out)
+{
+	/* enum tetra_log_chan (tetra_common.h:22-39): UNKNOWN 0, SCH_F 1, SCH_HD 2, SCH_HU 3, STCH 4, P8 5..7,
+	 * AACH 8, TCH 9, BSCH 10, BNCH 11 */
+	uint8_t sub = 0;
+	switch (lchan) {
+	case 1: sub = 5; break;
+	case 2: sub = 4; break;
+	case 3: sub = 3; break;
+	case 4: sub = 7; break;
+	case 8: sub = 2; break;
+	case 9: sub = 8; break;
+	case 10: sub = 1; break;
+	case 11: sub = 6; break;
+	}
+	uint32_t fn = (((uint32_t)tm->hn * 60u) + tm->mn) * 18u + tm->fn;
+	unsigned nbytes = (bitlen + 7) / 8;
+	memset(out, 0, 16 + nbytes);
+	out[0] = 2;
+	out[1] = 4;
+	out[2] = 5;
+	out[3] = ts;
+	out[6] = (uint8_t)signal_dbm;
+	out[7] = snr;
+	out[8] = fn >> 24; out[9] = fn >> 16; out[10] = fn >> 8; out[11] = fn;
+	out[12] = sub;
+	out[14] = ss;
+	for (unsigned i = 0; i < bitlen; i++) {
+		unsigned byte = i / 8, bit = 7 - (i % 8);
+		out[16 + byte] |= (uint8_t)((bits[i] & 1) << bit);
+	}
+	return (int)(16 + nbytes);
+}

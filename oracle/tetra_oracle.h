@@ -246,6 +246,8 @@ void orc_tp_sap_udata_ind(struct orc_rx *rx, int type, int blk_num, const uint8_
 uint16_t orc_rm3014_decode_ml(uint32_t rx30, unsigned *nerr);
 
 /* traffic dump block (tetra_lower_mac.c:213-231): 690 int16 from the descrambled type-4 bits of a traffic block */
+int orc_gsmtap_makemsg(const struct orc_tdma_time *tm, int lchan, uint8_t ts, uint8_t ss, int8_t signal_dbm,
+		       uint8_t snr, const uint8_t *bits, unsigned bitlen, uint8_t *out);
 void orc_traffic_block(const uint8_t *type4, unsigned len, int16_t *block690);
 
 /* ---- row B: float_to_bits (float_to_bits.c) ---------------------------- */

@@ -112,6 +112,8 @@ def lib():
     L.tgpu_channel_set_rm_decode.argtypes = [C.c_void_p, C.c_int]
     L.tgpu_traffic_block.argtypes = [u8p, C.c_uint, C.POINTER(C.c_int16)]
     L.tgpu_traffic_block.restype = None
+    L.tgpu_gsmtap_makemsg.argtypes = [C.POINTER(TdmaTime), C.c_int, C.c_uint8, C.c_uint8, C.c_int8, C.c_uint8, u8p, C.c_uint,
+                                      u8p, C.c_size_t]
     L.tgpu_conv_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_conv_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.tgpu_conv_destroy.argtypes = [C.c_void_p]
@@ -476,6 +478,19 @@ def rcpc_depunct(pu, type3, mother_len, fill=0xFF):
     out = np.full(mother_len, fill, np.uint8)
     rc = lib().tetra_rcpc_depunct(pu, t.ctypes.data_as(u8p), len(t), out.ctypes.data_as(u8p))
     return rc, out
+
+
+def gsmtap_makemsg(tm, lchan, ts, bits, ss=0, signal_dbm=0, snr=0, out_size=None):
+    """tgpu_gsmtap_makemsg: the reference's GSMTAP message (header + MSB-first packed bits) as bytes;
+    tm = (hn, sn, tn, fn, mn)"""
+    b = _np_u8(bits)
+    t = TdmaTime(*tm)
+    n = 16 + (len(b) + 7) // 8 if out_size is None else out_size
+    out = np.zeros(max(n, 1), np.uint8)
+    rc = lib().tgpu_gsmtap_makemsg(C.byref(t), lchan, ts, ss, signal_dbm, snr, b.ctypes.data_as(u8p), len(b),
+                                   out.ctypes.data_as(u8p), n)
+    _chk(rc if rc < 0 else 0, "tgpu_gsmtap_makemsg")
+    return out[:rc].tobytes()
 
 
 def grid_indices(outcome):

@@ -128,6 +128,7 @@ def lib():
     L.orc_conv_encode.argtypes = [u8p, C.c_int, u8p]
     L.orc_puncture.argtypes = [C.c_int, u8p, C.c_int, u8p]
     L.orc_depuncture.argtypes = [C.c_int, u8p, C.c_int, u8p]
+    L.orc_gsmtap_makemsg.argtypes = [C.POINTER(TdmaTime), C.c_int, C.c_uint8, C.c_uint8, C.c_int8, C.c_uint8, u8p, C.c_uint, u8p]
     L.orc_conv_encode_tch.argtypes = [u8p, C.c_int, u8p]
     L.orc_conv_decode_block.argtypes = [C.c_int, C.c_int, u8p, C.c_uint, C.c_uint, C.c_int, u8p]
     L.orc_code_output.argtypes = [C.c_int, C.c_uint, C.c_uint]
@@ -235,6 +236,13 @@ def depuncture(pu, x, mother_len, fill=0xFF):
 # lower_mac/tetra_conv_enc.c:257-267 (punct_test_params): (type2_len, type3_len, mother rate, puncturer)
 PUNCT_SHAPES = [(80, 120, 4, 0), (292, 432, 4, 2), (148, 432, 4, 3), (144, 216, 4, 0), (112, 168, 4, 0),
                 (288, 432, 4, 0), (112, 168, 3, 4), (72, 162, 3, 5), (38, 80, 3, 6)]
+
+
+def gsmtap_makemsg(tm, lchan, ts, bits, ss=0, signal_dbm=0, snr=0):
+    b = np.ascontiguousarray(bits, np.uint8)
+    out = np.zeros(16 + (len(b) + 7) // 8, np.uint8)
+    n = lib().orc_gsmtap_makemsg(C.byref(TdmaTime(*tm)), lchan, ts, ss, signal_dbm, snr, _p(b), len(b), _p(out))
+    return out[:n].tobytes()
 
 
 def conv_encode_tch(bits):

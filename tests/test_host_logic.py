@@ -249,3 +249,27 @@ def test_puncturer_entry_points_host():
         assert int((dp != 0xFF).sum()) == K - int((tx == 0xFF).sum())
     assert T.get_punctured_rate(7, np.zeros(8, np.uint8), 2)[0] == -errno.EINVAL
     assert T.rcpc_depunct(9, np.zeros(8, np.uint8), 8)[0] == -errno.EINVAL
+
+
+def test_gsmtap_message():
+    """tgpu_gsmtap_makemsg == the oracle's restatement of tetra_gsmtap.c:31-63, plus the documented structure
+    (GSMTAP v2 header of 16 bytes, type TETRA_I1, frame number in network order, MSB-first packed bits)"""
+    rng = np.random.default_rng(3)
+    for lchan in range(0, 13):
+        for nbits in (0, 1, 7, 8, 14, 60, 124, 268):
+            tm = (int(rng.integers(0, 4)), 0, int(rng.integers(1, 5)), int(rng.integers(1, 19)), int(rng.integers(1, 61)))
+            bits = rng.integers(0, 2, nbits).astype(np.uint8)
+            got = T.gsmtap_makemsg(tm, lchan, tm[2] - 1, bits, ss=int(rng.integers(0, 2)), signal_dbm=-int(rng.integers(0, 110)),
+                                   snr=int(rng.integers(0, 40)))
+            want = O.gsmtap_makemsg(tm, lchan, tm[2] - 1, bits, ss=got[14], signal_dbm=np.int8(got[6]).item() if got[6] < 128 else got[6] - 256,
+                                    snr=got[7])
+            assert got == want
+            assert len(got) == 16 + (nbits + 7) // 8 and got[0] == 2 and got[1] == 4 and got[2] == 5 and got[3] == tm[2] - 1
+            assert int.from_bytes(got[8:12], "big") == ((tm[0] * 60) + tm[4]) * 18 + tm[3]
+            assert got[4:6] == b"\x00\x00" and got[13] == 0 and got[15] == 0
+            assert np.unpackbits(np.frombuffer(got[16:], np.uint8))[:nbits].tolist() == bits.tolist()
+    sub = {1: 5, 2: 4, 3: 3, 4: 7, 8: 2, 9: 8, 10: 1, 11: 6}
+    for lchan in range(0, 13):
+        assert T.gsmtap_makemsg((0, 0, 1, 1, 1), lchan, 0, [1])[12] == sub.get(lchan, 0)
+    with pytest.raises(T.TgpuError):
+        T.gsmtap_makemsg((0, 0, 1, 1, 1), 1, 0, np.ones(100, np.uint8), out_size=20)
