@@ -1004,15 +1004,26 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	 * lane; the trellis loop then has no global loads.  Reading them one per 16 steps instead refetched the same
 	 * lines ~4x (FETCH_SIZE 183 MB for 42 MB of input on 500 k SCH/F blocks). */
 	__shared__ uint32_t s_cw[(HMODE != 2) ? NW * 64 : 1];
+	/* branch-metric table (vit_core.h, tg_bm_entry): six dwords per step pair and received triple */
+	__shared__ __attribute__((aligned(16))) uint32_t s_bm[(HMODE != 2) ? TG_BM_WORDS : 4];
+	auto bm = [&](int p, uint32_t e, uint32_t w[6]) {
+		const uint32_t *q = s_bm + (8 * p + e) * 8;
+		const uint4 a = *(const uint4 *)q;
+		const uint2 b = *(const uint2 *)(q + 4);
+		w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y;
+	};
 	tg_vit_state v;
 	uint32_t cur = 0;
 	if (HMODE != 2) {
+		if (lane < 32)
+			tg_bm_entry(lane >> 3, lane & 7, s_bm + 8 * lane);
 #pragma unroll
 		for (int g = 0; g < NW; g++)
 			s_cw[g * 64 + lane] = pw[g] ^ mw[g];
+		__syncthreads();
 		tg_vit_init(v);
 		cur = s_cw[lane];
-		tg_vit_leadin(v, cur >> 24);
+		tg_vit_leadin_bm(v, cur >> 24, bm);
 	}
 
 	if (HMODE == 2) {
@@ -1082,9 +1093,9 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		for (int it = 0; it < NW - 1; it++) {
 			const uint32_t nxt = s_cw[(it + 1) * 64 + lane];
 			uint32_t h[4];
-			tg_vit_block<false>(v, cur, h);
+			tg_vit_block_bm<false>(v, cur, h, bm);
 			hist[(2 * it) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-			tg_vit_block<false>(v, cur >> 12, h);
+			tg_vit_block_bm<false>(v, cur >> 12, h, bm);
 			hist[(2 * it + 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
 			if (KIND == TG_KIND_432 && it == 8)
 				tg_vit_normalize(v);
@@ -1092,9 +1103,9 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		}
 		{
 			uint32_t h[4];
-			tg_vit_block<false>(v, cur, h);
+			tg_vit_block_bm<false>(v, cur, h, bm);
 			hist[(NBLK - 2) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-			tg_vit_block<true>(v, cur >> 12, h);
+			tg_vit_block_bm<true>(v, cur >> 12, h, bm);
 			hist[(NBLK - 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
 		}
 		/* block-wise traceback from state 0 */
@@ -1119,11 +1130,11 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 				const int g = 4 * c + it;
 				const uint32_t nxt = s_cw[(g + 1) * 64 + lane];
 				uint32_t h[4];
-				tg_vit_block<false>(v, cur, h);
+				tg_vit_block_bm<false>(v, cur, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * it + d] = h[d];
-				tg_vit_block<false>(v, cur >> 12, h);
+				tg_vit_block_bm<false>(v, cur >> 12, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * it + 4 + d] = h[d];
@@ -1133,11 +1144,11 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 			}
 			if (lastchunk) {
 				uint32_t h[4];
-				tg_vit_block<false>(v, cur, h);
+				tg_vit_block_bm<false>(v, cur, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * (nit - 1) + d] = h[d];
-				tg_vit_block<true>(v, cur >> 12, h);
+				tg_vit_block_bm<true>(v, cur >> 12, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * (nit - 1) + 4 + d] = h[d];

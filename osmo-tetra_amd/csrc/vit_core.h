@@ -229,6 +229,77 @@ TG_HD void tg_vit_block(tg_vit_state &v, uint32_t tw, uint32_t h[4])
 	tg_vit_clean(v);
 }
 
+/*
+ * Branch metrics from a table instead of arithmetic.  The received bits enter the trellis in triples: (g1, g2)
+ * of a two-bit step and g1 of the one-bit step after it, bits 3p .. 3p+2 of a 12-bit block word for step pair
+ * p = 0..3.  Everything tg_step_a / tg_step_b derive from such a triple e and the pair's tie bits --
+ * P, P+tie, Q, Q+tie for the first step, P', P'+tie' for the second -- is six dwords: 4 pairs x 8 triples x
+ * 32 bytes = 1 KB, held in LDS by the kernels (entries of one pair lie in eight different bank groups, lanes
+ * with equal triples read the same address: no bank conflicts).  Per step pair the vector unit then does one
+ * field extract and one shift for the address and two LDS reads instead of twelve ALU operations.
+ */
+#define TG_BM_WORDS (4 * 8 * 8)
+
+TG_HD void tg_bm_entry(int p, uint32_t e, uint32_t w[8])
+{
+	const uint32_t LP = TG_LUT(TG_LUTB(0, 1, 1, 2), TG_LUTB(2, 1, 1, 0));
+	const uint32_t LQ = TG_LUT(TG_LUTB(1, 0, 2, 1), TG_LUTB(1, 2, 0, 1));
+	const uint32_t t2 = 2 * (e & 3);
+	const uint32_t tie_a = 0x00010001u << (2 * p), tie_b = tie_a << 1;
+	w[0] = (LP >> t2) & TG_KMASK;
+	w[1] = w[0] + tie_a;
+	w[2] = (LQ >> t2) & TG_KMASK;
+	w[3] = w[2] + tie_a;
+	w[4] = (e & 4) ? 0x00000100u : 0x01000000u;
+	w[5] = w[4] + tie_b;
+	w[6] = w[7] = 0;
+}
+
+TG_HD void tg_bm_build(uint32_t *tab)
+{
+	for (int p = 0; p < 4; p++)
+		for (uint32_t e = 0; e < 8; e++)
+			tg_bm_entry(p, e, tab + (8 * p + e) * 8);
+}
+
+/* one step pair from its table entry */
+TG_HD void tg_step_pair(tg_vit_state &v, const uint32_t w[6])
+{
+	tg_acs<TG_SW_A, TG_Q_A>(v, tg_as_us2(w[0]), tg_as_us2(w[1]), tg_as_us2(w[2]), tg_as_us2(w[3]));
+	tg_acs<TG_SW_B, TG_Q_B>(v, tg_as_us2(w[4]), tg_as_us2(w[5]), tg_as_us2(w[4]), tg_as_us2(w[5]));
+}
+
+/* bm(p, e, w): fetch the six dwords of pair p, triple e.  Same results as tg_vit_leadin / tg_vit_block. */
+template <typename Bm>
+TG_HD void tg_vit_leadin_bm(tg_vit_state &v, uint32_t six, Bm bm)
+{
+	uint32_t w[2][6];
+	bm(0, six & 7, w[0]);
+	bm(1, (six >> 3) & 7, w[1]);
+	tg_step_pair(v, w[0]);
+	tg_step_pair(v, w[1]);
+	tg_vit_clean(v);
+}
+
+template <bool LAST, typename Bm>
+TG_HD void tg_vit_block_bm(tg_vit_state &v, uint32_t tw, uint32_t h[4], Bm bm)
+{
+	constexpr int NP = LAST ? 2 : 4;
+	uint32_t w[NP][6];
+#pragma unroll
+	for (int p = 0; p < NP; p++)
+		bm(p, (tw >> (3 * p)) & 7, w[p]);
+#pragma unroll
+	for (int p = 0; p < NP; p++)
+		tg_step_pair(v, w[p]);
+	if (LAST)
+		tg_flush4(v);
+#pragma unroll
+	for (int d = 0; d < 4; d++)
+		h[d] = tg_pack_bytes02(tg_as_u32(v.Z[2 * d]), tg_as_u32(v.Z[2 * d + 1]));
+	tg_vit_clean(v);
+}
+
 /* subtract the smallest path metric from all 16 (only between blocks: low bytes are clear) */
 TG_HD void tg_vit_normalize(tg_vit_state &v)
 {

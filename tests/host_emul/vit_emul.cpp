@@ -51,17 +51,21 @@ extern "C" unsigned emul_decode_words(int kind, const uint32_t *words, uint8_t *
 	crc_init();
 	const int nblk = tg_kind_nblk(kind), nw = nblk / 2;
 	static uint8_t hist[36][16];
+	/* the kernels' branch-metric table (LDS there) */
+	static uint32_t bmtab[TG_BM_WORDS];
+	tg_bm_build(bmtab);
+	auto bm = [&](int p, uint32_t e, uint32_t w[6]) { memcpy(w, bmtab + (8 * p + e) * 8, 24); };
 	tg_vit_state v;
 	tg_vit_init(v);
-	tg_vit_leadin(v, words[0] >> 24);
+	tg_vit_leadin_bm(v, words[0] >> 24, bm);
 	for (int it = 0; it < nw; it++) {
 		uint32_t h[4];
-		tg_vit_block<false>(v, words[it], h);
+		tg_vit_block_bm<false>(v, words[it], h, bm);
 		memcpy(hist[2 * it], h, 16);
 		if (it == nw - 1)
-			tg_vit_block<true>(v, words[it] >> 12, h);
+			tg_vit_block_bm<true>(v, words[it] >> 12, h, bm);
 		else
-			tg_vit_block<false>(v, words[it] >> 12, h);
+			tg_vit_block_bm<false>(v, words[it] >> 12, h, bm);
 		memcpy(hist[2 * it + 1], h, 16);
 		if (kind == TG_KIND_432 && it == 8)
 			tg_vit_normalize(v);
@@ -205,5 +209,37 @@ extern "C" int emul_conv_decode(int pu, int mother, unsigned t3len, unsigned L, 
 		g3 ? conv_decode<1, true>(steps, t3len, L, type3, type2) : conv_decode<1, false>(steps, t3len, L, type3, type2);
 	else
 		g3 ? conv_decode<0, true>(steps, t3len, L, type3, type2) : conv_decode<0, false>(steps, t3len, L, type3, type2);
+	return 0;
+}
+
+/* arithmetic form (tg_vit_block) vs table form (tg_vit_block_bm) on one random block sequence: 0 if equal */
+extern "C" int emul_bm_selfcheck(uint32_t seed, int nblocks)
+{
+	static uint32_t bmtab[TG_BM_WORDS];
+	tg_bm_build(bmtab);
+	auto bm = [&](int p, uint32_t e, uint32_t w[6]) { memcpy(w, bmtab + (8 * p + e) * 8, 24); };
+	tg_vit_state a, b;
+	tg_vit_init(a);
+	tg_vit_init(b);
+	uint32_t x = seed;
+	tg_vit_leadin(a, x & 63);
+	tg_vit_leadin_bm(b, x & 63, bm);
+	for (int i = 0; i < nblocks; i++) {
+		uint32_t ha[4], hb[4];
+		x = x * 1664525u + 1013904223u;
+		if (i == nblocks - 1) {
+			tg_vit_block<true>(a, x >> 8, ha);
+			tg_vit_block_bm<true>(b, x >> 8, hb, bm);
+		} else {
+			tg_vit_block<false>(a, x >> 8, ha);
+			tg_vit_block_bm<false>(b, x >> 8, hb, bm);
+		}
+		if (memcmp(ha, hb, 16) || memcmp(&a.Z, &b.Z, sizeof(a.Z)))
+			return i + 1;
+		if ((i & 7) == 7) {
+			tg_vit_normalize(a);
+			tg_vit_normalize(b);
+		}
+	}
 	return 0;
 }

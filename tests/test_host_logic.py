@@ -273,3 +273,10 @@ def test_gsmtap_message():
         assert T.gsmtap_makemsg((0, 0, 1, 1, 1), lchan, 0, [1])[12] == sub.get(lchan, 0)
     with pytest.raises(T.TgpuError):
         T.gsmtap_makemsg((0, 0, 1, 1, 1), 1, 0, np.ones(100, np.uint8), out_size=20)
+
+
+def test_branch_metric_table_equals_arithmetic():
+    """tg_vit_block_bm (table look-ups, what the kernels run) == tg_vit_block (the arithmetic it replaces):
+    path metrics and history bytes after every block of random sequences"""
+    for seed in range(1, 200):
+        assert emul.lib().emul_bm_selfcheck(seed * 2654435761 % (1 << 32), 36) == 0

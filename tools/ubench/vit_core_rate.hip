@@ -6,18 +6,34 @@
 #include <stdint.h>
 #include "vit_core.h"
 
+// -DUSE_BM: branch metrics from the LDS table (tg_vit_block_bm) instead of arithmetic
 __global__ __launch_bounds__(64) void k(uint32_t *out, uint32_t seed, int iters)
 {
 	tg_vit_state v;
 	tg_vit_init(v);
 	uint32_t x = seed * (threadIdx.x + 1) + blockIdx.x, acc = 0;
+#ifdef USE_BM
+	__shared__ uint32_t s_bm[TG_BM_WORDS];
+	for (int i = threadIdx.x; i < 32; i += 64)
+		tg_bm_entry(i >> 3, i & 7, s_bm + 8 * i);
+	__syncthreads();
+	auto bm = [&](int p, uint32_t e, uint32_t w[6]) {
+		const uint4 a = *(const uint4 *)(s_bm + (8 * p + e) * 8);
+		const uint2 b = *(const uint2 *)(s_bm + (8 * p + e) * 8 + 4);
+		w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y;
+	};
+#define tg_vit_block tg_vit_block_bm
+#define BMARG , bm
+#else
+#define BMARG
+#endif
 	tg_vit_leadin(v, x & 63);
 	for (int it = 0; it < iters; it++) {
 		uint32_t h[4];
 		x = x * 1664525u + 1013904223u;
-		tg_vit_block<false>(v, x >> 8, h);
+		tg_vit_block<false>(v, x >> 8, h BMARG);
 		acc ^= h[0] ^ h[1] ^ h[2] ^ h[3];
-		tg_vit_block<false>(v, x >> 20, h);
+		tg_vit_block<false>(v, x >> 20, h BMARG);
 		acc += h[0] ^ h[1] ^ h[2] ^ h[3];
 		if ((it & 3) == 3)
 			tg_vit_normalize(v);
