@@ -92,23 +92,33 @@ __device__ __forceinline__ void front_fetch(const uint8_t *base, uint32_t lane, 
 	d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane - (lane == 63 ? 2 : 0));
 }
 
-__device__ __forceinline__ uint32_t front_gather(const uint8_t *lds0, const uint32_t (&addr)[10], uint32_t &nonbin_acc)
+__device__ __forceinline__ uint32_t front_gather(const uint8_t *lds0, const uint32_t (&addr)[10])
 {
 	uint32_t myword = 0;
 	uint32_t bytes[10];
 #pragma unroll
 	for (int r = 0; r < 10; r++)
 		bytes[r] = lds0[addr[r]];	/* ten independent LDS reads in flight */
+	unsigned long long bal[10];
 #pragma unroll
-	for (int r = 0; r < 10; r++) {
-		const unsigned long long bal = __ballot(bytes[r] != 0);
-		nonbin_acc |= bytes[r];
-		/* the ballot lives in an SGPR pair: drop its halves into lanes 2r, 2r+1.  hipcc pads no
-		 * hazards for inline asm, and v_writelane reading an SGPR a VALU compare has just
-		 * written needs wait states (seen on gfx950: without them the OLD value is read). */
-		asm("s_nop 4\n\tv_writelane_b32 %0, %1, %2\n\tv_writelane_b32 %0, %3, %4"
-		    : "+v"(myword) : "s"((uint32_t)bal), "i"(2 * r), "s"((uint32_t)(bal >> 32)), "i"(2 * r + 1));
-	}
+	for (int r = 0; r < 10; r++)
+		bal[r] = __ballot(bytes[r] != 0);
+	/* the ballots live in SGPR pairs: drop their halves into lanes 2r, 2r+1.  hipcc pads no hazards for
+	 * inline asm, and v_writelane reading an SGPR a VALU compare has just written needs wait states (seen
+	 * on gfx950: without them the OLD value is read) -- one s_nop covers the youngest compare, the older
+	 * ones are further back. */
+	asm("s_nop 4\n\t"
+	    "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+	    "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
+	    "v_writelane_b32 %0, %9, 8\n\tv_writelane_b32 %0, %10, 9\n\tv_writelane_b32 %0, %11, 10\n\tv_writelane_b32 %0, %12, 11\n\t"
+	    "v_writelane_b32 %0, %13, 12\n\tv_writelane_b32 %0, %14, 13\n\tv_writelane_b32 %0, %15, 14\n\tv_writelane_b32 %0, %16, 15\n\t"
+	    "v_writelane_b32 %0, %17, 16\n\tv_writelane_b32 %0, %18, 17\n\tv_writelane_b32 %0, %19, 18\n\tv_writelane_b32 %0, %20, 19"
+	    : "+v"(myword)
+	    : "s"((uint32_t)bal[0]), "s"((uint32_t)(bal[0] >> 32)), "s"((uint32_t)bal[1]), "s"((uint32_t)(bal[1] >> 32)),
+	      "s"((uint32_t)bal[2]), "s"((uint32_t)(bal[2] >> 32)), "s"((uint32_t)bal[3]), "s"((uint32_t)(bal[3] >> 32)),
+	      "s"((uint32_t)bal[4]), "s"((uint32_t)(bal[4] >> 32)), "s"((uint32_t)bal[5]), "s"((uint32_t)(bal[5] >> 32)),
+	      "s"((uint32_t)bal[6]), "s"((uint32_t)(bal[6] >> 32)), "s"((uint32_t)bal[7]), "s"((uint32_t)(bal[7] >> 32)),
+	      "s"((uint32_t)bal[8]), "s"((uint32_t)(bal[8] >> 32)), "s"((uint32_t)bal[9]), "s"((uint32_t)(bal[9] >> 32)));
 	return myword;
 }
 
@@ -125,30 +135,32 @@ __device__ __forceinline__ uint32_t front_swz(uint32_t a)
 
 /* stage 1 of a slot: its two dwords go to the wave's LDS window (after this the data registers are free
  * for the next request); stage 2 (front_process): gather, pack, store */
-__device__ __forceinline__ void front_park(uint32_t *mine, uint32_t lane, uint32_t d0, uint32_t d1)
+__device__ __forceinline__ bool front_park(uint32_t *mine, uint32_t lane, uint32_t d0, uint32_t d1)
 {
 	mine[front_swz(4 * lane) >> 2] = d0;
 	mine[front_swz(256 + 4 * lane) >> 2] = (lane == 63) ? (d1 >> 16) : d1;	/* window bytes 510/511 stay zero */
+	/* any of the slot's 510 bytes other than 0 / 1 (the two dwords of the 64 lanes cover exactly the slot) */
+	return __ballot(((d0 | d1) & 0xfefefefeu) != 0) != 0;
 }
 
-__device__ __forceinline__ void front_process(uint32_t slot, uint32_t type, uint32_t lane,
+__device__ __forceinline__ void front_process(uint32_t slot, uint32_t type, uint32_t lane, bool nonbinary,
 					       const uint8_t *lds0, const uint32_t (&a_n1)[10],
 					       const uint32_t (&a_n2)[10], const uint32_t (&a_sb)[10],
 					       uint32_t *__restrict__ packed, uint8_t *__restrict__ rec)
 {
-	uint32_t myword = 0, acc = 0;
+	uint32_t myword = 0;
 	if (type == TG_BURST_NORM_1)
-		myword = front_gather(lds0, a_n1, acc);
+		myword = front_gather(lds0, a_n1);
 	else if (type == TG_BURST_NORM_2)
-		myword = front_gather(lds0, a_n2, acc);
+		myword = front_gather(lds0, a_n2);
 	else if (type == TG_BURST_SYNC)
-		myword = front_gather(lds0, a_sb, acc);
+		myword = front_gather(lds0, a_sb);
 	else if (lane == 0) {
 		/* not a burst we decode (NORM_3 / EXT are ignored like phy/tetra_burst.c:374-377):
 		 * no trellis lane will touch this record, mark it */
 		rec[(size_t)slot * TG_REC_BYTES + TG_REC_TYPE] = TG_BURST_NONE;
 	}
-	const uint32_t flags = __ballot(acc > 1) ? TG_FLAG_NONBINARY : 0;
+	const uint32_t flags = nonbinary ? TG_FLAG_NONBINARY : 0;
 	if (lane == TG_PW_META) {
 		const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
 		myword = type | (flags << 8) | (toff << 16);
@@ -216,14 +228,14 @@ void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 		if (slot >= nslots)									\
 			break;										\
 		const uint32_t type_ = TG_DESC_TYPE(D);							\
-		front_park(mine, lane, R0, R1);								\
+		const bool nb_ = front_park(mine, lane, R0, R1);					\
 		if ((uint64_t)slot + 3ull * nwaves < nslots) {						\
 			D = dn;										\
 			front_fetch(stream + TG_DESC_OFF(D), lane, R0, R1);				\
 		}											\
 		if ((uint64_t)slot + 4ull * nwaves < nslots)						\
 			dn = slot_desc[slot + 4 * nwaves];						\
-		front_process(slot, type_, lane, lds0, a_n1, a_n2, a_sb, packed, rec);			\
+		front_process(slot, type_, lane, nb_, lds0, a_n1, a_n2, a_sb, packed, rec);			\
 		if ((uint64_t)slot + nwaves >= nslots)							\
 			break;										\
 		slot += nwaves;										\
@@ -236,11 +248,11 @@ void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 #define FRONT_STEP_FULL(D, R0, R1)									\
 	{												\
 		const uint32_t type_ = TG_DESC_TYPE(D);							\
-		front_park(mine, lane, R0, R1);		/* waits for this set's two loads only */	\
+		const bool nb_ = front_park(mine, lane, R0, R1);	/* waits for this set's two loads only */ \
 		D = dn;											\
 		front_fetch(stream + TG_DESC_OFF(D), lane, R0, R1);					\
 		dn = slot_desc[(uint64_t)slot + 4ull * nwaves < nslots ? slot + 4 * nwaves : slot];	\
-		front_process(slot, type_, lane, lds0, a_n1, a_n2, a_sb, packed, rec);			\
+		front_process(slot, type_, lane, nb_, lds0, a_n1, a_n2, a_sb, packed, rec);			\
 		slot += nwaves;										\
 	}
 	while ((uint64_t)slot + 5ull * nwaves < nslots) {
@@ -510,13 +522,13 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		else if ((rc == TG_BURST_NORM_1 || rc == TG_BURST_NORM_2) && offs == TG_NORM_TRAIN_OFF)
 			dtype = rc;
 
-		uint32_t myword = 0, acc = 0;
+		uint32_t myword = 0;
 		if (dtype == TG_BURST_NORM_1)
-			myword = front_gather(lds0, a_n1, acc);
+			myword = front_gather(lds0, a_n1);
 		else if (dtype == TG_BURST_NORM_2)
-			myword = front_gather(lds0, a_n2, acc);
+			myword = front_gather(lds0, a_n2);
 		else if (dtype == TG_BURST_SYNC)
-			myword = front_gather(lds0, a_sb, acc);
+			myword = front_gather(lds0, a_sb);
 		if (lane == TG_PW_META)
 			myword = dtype | (((flags & TG_CLS_NONBINARY) ? TG_FLAG_NONBINARY : 0u) << 8) | (offs << 16);
 		if (lane < TG_PACKED_WORDS)

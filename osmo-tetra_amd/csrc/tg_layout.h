@@ -83,7 +83,7 @@
 #define TG_SOFT_AREA2      224	/* second block (BLK2 / SB2) */
 #define TG_SOFT_BBK        448	/* 30 BBK values */
 
-#define TG_FLAG_NONBINARY 0x01	/* a stream byte other than 0/1 was seen in a coded field */
+#define TG_FLAG_NONBINARY 0x01	/* a byte other than 0/1 was seen in the slot (block mode: in the block) */
 
 /* scrambling-mask table entry: 40 dwords, same bit layout as the code words */
 #define TG_MASK_WORDS     40
