@@ -463,8 +463,9 @@ def main():
     dom = int(np.argmax(stage_ms))
     n1 = int((types == T.TRAIN_NORM_1).sum())
     n2 = n - n1
-    units_bytes = {"k_front": n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1], "k_vit<432>": n1 * ALG_BYTES[0],
-                   "k_vit<216>": n2 * ALG_BYTES[1]}
+    # SURVEY 8(d)'s per-burst figure split by the kernel that moves it: the 510 mandated input bytes belong to the
+    # front kernel, the type-1 bits (1 B per bit) + 16 B per block to the trellis kernel that decodes the burst
+    units_bytes = {"k_front": n * 510, "k_vit<432>": n1 * (ALG_BYTES[0] - 510), "k_vit<216>": n2 * (ALG_BYTES[1] - 510)}
     alg = units_bytes.get(names[dom], n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1])
     achieved = alg / (stage_ms[dom] * 1e-3) / 1e9
     value = world * n * args.steps / el
@@ -495,10 +496,13 @@ def main():
                      "kernel_ms": float(stage_ms[dom]),
                      "stage_ms": {names[i]: float(stage_ms[i]) for i in range(len(names))},
                      "pipeline_achieved_gbs_per_gpu": float(pipeline_gbs),
-                     "note": "achieved = SURVEY 8(d) algorithmic bytes of the bursts this kernel decodes / its mean HIP-event "
-                             "duration (second pass of the same K steps, one event between stages on the launch stream; the "
-                             "timed pass overlaps the two trellis kernels); traffic = PMC bytes per launch from "
-                             "profiles/traffic.json; the trellis kernels are VALU-issue bound (VALU busy 72 % of the kernel, ~4 cycles per instruction; profiles/r01_config2_rocprofv3.md), see DESIGN.md"},
+                     "note": "achieved = this kernel's share of the SURVEY 8(d) algorithmic bytes (k_front: the 510 input bytes of every "
+                             "burst; a trellis kernel: type-1 bits at 1 B/bit + 16 B per block of the bursts it decodes) / its mean "
+                             "HIP-event duration (second pass of the same K steps, one event between stages on the launch stream; the "
+                             "timed pass overlaps the two trellis kernels); pipeline_achieved_gbs_per_gpu = all 0.82 kB per burst / "
+                             "step time; traffic = PMC bytes per launch and valu_busy_frac from profiles/traffic.json "
+                             "(profiles/r01_config2_rocprofv3.md): k_front moves 652 MB per launch at 0.56 VALU busy, the trellis "
+                             "kernels are VALU-issue bound (0.72 - 0.82 busy, 28 instructions per trellis step), see DESIGN.md"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(slots, types)
