@@ -1232,3 +1232,24 @@ def test_generic_trellis_rejects_bad_shapes(T, eng):
     for args in ((7, 4, 120, 80), (0, 5, 120, 80), (0, 4, 432, 80), (0, 4, 15, 10), (0, 4, 1200, 800)):
         with pytest.raises(T.TgpuError):
             T.ConvDecoder(eng, *args)
+
+
+@pytest.mark.parametrize("shape", [(504, 756, 4, 0), (344, 1022, 4, 1), (252, 378, 3, 4), (12, 18, 4, 0)])
+def test_generic_trellis_extreme_shapes(T, eng, shape):
+    """the largest block the decoder accepts (63 history blocks, 8 register chunks), the longest type-3 row with a
+    row length that is not a multiple of 4 (raw staging copy, > 64 KB of LDS), a long speech-code block and the
+    smallest block with a partial history block -- against the oracle"""
+    import torch
+    L, K, mother, pu = shape
+    cv = T.ConvDecoder(eng, pu, mother, K, L)
+    hs = torch.cuda.current_stream().cuda_stream
+    n = 150
+    t2, t3 = _conv_batch(shape, n, seed=L + K)
+    d_in = torch.from_numpy(t3.reshape(-1)).cuda()
+    d_out = torch.zeros(n * L, dtype=torch.uint8, device="cuda")
+    cv.execute(d_in.data_ptr(), n, d_out.data_ptr(), hs)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().reshape(n, L)
+    for i in range(n):
+        assert (got[i] == O.conv_decode_block(pu, mother, t3[i], L, 0)).all(), (shape, i)
+    cv.close()
