@@ -146,7 +146,7 @@ __device__ __forceinline__ bool front_park(uint32_t *mine, uint32_t lane, uint32
 __device__ __forceinline__ void front_process(uint32_t slot, uint32_t type, uint32_t lane, bool nonbinary,
 					       const uint8_t *lds0, const uint32_t (&a_n1)[10],
 					       const uint32_t (&a_n2)[10], const uint32_t (&a_sb)[10],
-					       uint32_t *__restrict__ packed, uint8_t *__restrict__ rec)
+					       uint32_t *stage, uint8_t *__restrict__ rec)
 {
 	uint32_t myword = 0;
 	if (type == TG_BURST_NORM_1)
@@ -165,11 +165,20 @@ __device__ __forceinline__ void front_process(uint32_t slot, uint32_t type, uint
 		const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
 		myword = type | (flags << 8) | (toff << 16);
 	}
-	/* lanes 0..19 store; the others fall outside this 80-byte buffer and are dropped by the range check
-	 * (no exec branch around the store, see front_fetch) */
-	const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)slot * TG_PACKED_WORDS, 0,
-									       TG_PACKED_WORDS * 4, 0x00027000);
-	__builtin_amdgcn_raw_buffer_store_b32(myword, out, lane * 4, 0, 0);
+	/* the packed slot waits in the wave's LDS staging row until its group of four is complete (front_flush) */
+	if (lane < TG_PACKED_WORDS)
+		stage[lane] = myword;
+}
+
+/* write cnt (1..4) consecutive packed slots, first = slot index 'first', from the wave's staging area: two
+ * range-checked buffer stores (lanes past cnt * 80 bytes are dropped), 320 contiguous bytes for a full group */
+__device__ __forceinline__ void front_flush(const uint32_t *mo, uint32_t lane, uint32_t first, uint32_t cnt,
+					     uint32_t *__restrict__ packed)
+{
+	const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)first * TG_PACKED_WORDS, 0,
+									       cnt * TG_PACKED_WORDS * 4, 0x00027000);
+	__builtin_amdgcn_raw_buffer_store_b32(mo[lane], out, lane * 4, 0, 0);
+	__builtin_amdgcn_raw_buffer_store_b32(mo[64 + lane], out, 256 + lane * 4, 0, 0);
 }
 
 __global__ __launch_bounds__(256)
@@ -177,6 +186,7 @@ void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	     uint32_t nslots, uint32_t *__restrict__ packed, uint8_t *__restrict__ rec)
 {
 	__shared__ uint32_t s_slot[4][128];
+	__shared__ uint32_t s_out[4][128];	/* per wave: four packed slots (80 dwords) on their way out */
 
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -184,6 +194,7 @@ void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	const uint32_t nwaves = gridDim.x * 4;
 	const uint32_t half = lane >> 5, bit = lane & 31;
 	uint32_t *mine = s_slot[wib];
+	uint32_t *mo = s_out[wib];
 	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];
 
 	/* LDS byte address of this lane's source bit per round, for the three burst types */
@@ -198,76 +209,103 @@ void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 		a_sb[r] = wib * 512 + front_swz(o2 == 0xffff ? 510 : o2);
 	}
 
-	/* three slots in flight per wave, registers rotated statically (no copies, so a wait only
-	 * ever covers the oldest request): A = slot, B = slot+n, C = slot+2n */
+	/*
+	 * Work assignment: a wave takes GROUPS of four consecutive slots (group g = wave, wave + nwaves, ...), one
+	 * slot after the other; position t of its sequence is slot 4 (wave + (t >> 2) nwaves) + (t & 3).  The four
+	 * packed slots of a group leave as 320 contiguous bytes (two store instructions per group instead of one
+	 * 80-byte store per slot), and the slots a wave reads back to back are neighbours in memory.  Measured with
+	 * the stages of this kernel in isolation (tools/ubench/front_buildup.hip): 127 us per 1 M slots with one
+	 * 80-byte store per slot and slots dealt round-robin, 84 us this way -- the per-slot stores, not the
+	 * gathers, were what kept the kernel off the read rate.
+	 */
+	const uint32_t ngroups = (nslots + 3) >> 2;
+	if (wave >= ngroups)
+		return;
+	const uint32_t mygroups = (ngroups - wave + nwaves - 1) / nwaves;
+	uint32_t T = 4 * mygroups;				/* length of this wave's slot sequence */
+	if (wave + (mygroups - 1) * nwaves == ngroups - 1)
+		T -= 4 * ngroups - nslots;			/* the last group of the batch may be short */
+#define SLOT_OF(t) (4u * (wave + ((t) >> 2) * nwaves) + ((t) & 3u))
+
+	/* TG_FRONT_DEPTH slots in flight per wave, registers rotated statically (no copies, so a wait only
+	 * ever covers the oldest request): set k holds sequence position t = k (mod DEPTH) */
+#ifndef TG_FRONT_DEPTH
+#define TG_FRONT_DEPTH 3
+#endif
+	constexpr int DEPTH = TG_FRONT_DEPTH;
 	const uint64_t none = (uint64_t)TG_BURST_NONE << 56;
-	uint32_t slot = wave;
-	uint64_t da = none, db = none, dc = none;
-	uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0;
-	if (slot < nslots) {
-		da = slot_desc[slot];
-		front_fetch(stream + TG_DESC_OFF(da), lane, a0, a1);
-	}
-	if (slot + nwaves < nslots) {
-		db = slot_desc[slot + nwaves];
-		front_fetch(stream + TG_DESC_OFF(db), lane, b0, b1);
-	}
-	if (slot + 2 * nwaves < nslots) {
-		dc = slot_desc[slot + 2 * nwaves];
-		front_fetch(stream + TG_DESC_OFF(dc), lane, c0, c1);
+	uint32_t t = 0;
+	uint64_t dsc[DEPTH];
+	uint32_t r0[DEPTH], r1[DEPTH];
+#pragma unroll
+	for (int k = 0; k < DEPTH; k++) {
+		dsc[k] = none;
+		r0[k] = r1[k] = 0;
+		if ((uint32_t)k < T) {
+			dsc[k] = slot_desc[SLOT_OF((uint32_t)k)];
+			front_fetch(stream + TG_DESC_OFF(dsc[k]), lane, r0[k], r1[k]);
+		}
 	}
 
-	/* the descriptor of the slot three sweeps ahead is itself requested one iteration early (dn): its
-	 * scalar load then completes under this iteration's LDS round trip instead of stalling the wave
-	 * right before the data loads that depend on it */
+	/* the descriptor of the slot DEPTH positions ahead is itself requested one step early (dn): its scalar
+	 * load then completes under this step's LDS round trip instead of stalling the wave right before the
+	 * data loads that depend on it */
 	uint64_t dn = none;
-	if ((uint64_t)slot + 3ull * nwaves < nslots)
-		dn = slot_desc[slot + 3 * nwaves];
+	if ((uint32_t)DEPTH < T)
+		dn = slot_desc[SLOT_OF((uint32_t)DEPTH)];
+#define FRONT_FLUSH_IF(last)										\
+		if ((t & 3u) == 3u || (last))								\
+			front_flush(mo, lane, slot_ - (t & 3u), (t & 3u) + 1u, packed);
 #define FRONT_STEP(D, R0, R1)										\
 	{												\
-		if (slot >= nslots)									\
+		if (t >= T)										\
 			break;										\
+		const uint32_t slot_ = SLOT_OF(t);							\
 		const uint32_t type_ = TG_DESC_TYPE(D);							\
 		const bool nb_ = front_park(mine, lane, R0, R1);					\
-		if ((uint64_t)slot + 3ull * nwaves < nslots) {						\
+		if (t + DEPTH < T) {									\
 			D = dn;										\
 			front_fetch(stream + TG_DESC_OFF(D), lane, R0, R1);				\
 		}											\
-		if ((uint64_t)slot + 4ull * nwaves < nslots)						\
-			dn = slot_desc[slot + 4 * nwaves];						\
-		front_process(slot, type_, lane, nb_, lds0, a_n1, a_n2, a_sb, packed, rec);			\
-		if ((uint64_t)slot + nwaves >= nslots)							\
-			break;										\
-		slot += nwaves;										\
+		if (t + DEPTH + 1 < T)									\
+			dn = slot_desc[SLOT_OF(t + DEPTH + 1)];						\
+		front_process(slot_, type_, lane, nb_, lds0, a_n1, a_n2, a_sb, mo + (t & 3u) * TG_PACKED_WORDS, rec); \
+		FRONT_FLUSH_IF(t + 1 == T)								\
+		t++;											\
 	}
-	/* main loop: every step has a slot to gather and one to request, nothing is conditional -- the three
+	/* main loop: every step has a slot to gather and one to request, nothing is conditional -- the
 	 * register sets keep their roles across the back edge (no copies), so the s_waitcnt in front of a
 	 * gather covers only that slot's two loads and the younger requests stay in flight.  (With the
 	 * bounds checks inside, hipcc rotated one set through v_mov at the loop latch behind an
 	 * s_waitcnt vmcnt(0): every third slot exposed a full HBM round trip.) */
 #define FRONT_STEP_FULL(D, R0, R1)									\
 	{												\
+		const uint32_t slot_ = SLOT_OF(t);							\
 		const uint32_t type_ = TG_DESC_TYPE(D);							\
 		const bool nb_ = front_park(mine, lane, R0, R1);	/* waits for this set's two loads only */ \
 		D = dn;											\
 		front_fetch(stream + TG_DESC_OFF(D), lane, R0, R1);					\
-		dn = slot_desc[(uint64_t)slot + 4ull * nwaves < nslots ? slot + 4 * nwaves : slot];	\
-		front_process(slot, type_, lane, nb_, lds0, a_n1, a_n2, a_sb, packed, rec);			\
-		slot += nwaves;										\
+		dn = slot_desc[SLOT_OF(t + DEPTH + 1)];							\
+		front_process(slot_, type_, lane, nb_, lds0, a_n1, a_n2, a_sb, mo + (t & 3u) * TG_PACKED_WORDS, rec); \
+		FRONT_FLUSH_IF(false)									\
+		t++;											\
 	}
-	while ((uint64_t)slot + 5ull * nwaves < nslots) {
-		FRONT_STEP_FULL(da, a0, a1)
-		FRONT_STEP_FULL(db, b0, b1)
-		FRONT_STEP_FULL(dc, c0, c1)
+	while (t + 2 * DEPTH < T) {	/* the last step of the body requests the descriptor at t + 2 DEPTH */
+#pragma unroll
+		for (int k = 0; k < DEPTH; k++)
+			FRONT_STEP_FULL(dsc[k], r0[k], r1[k])
 	}
 #undef FRONT_STEP_FULL
-	/* tail (at most five slots per wave): the same steps with their bounds checks */
-	for (;;) {
-		FRONT_STEP(da, a0, a1)
-		FRONT_STEP(db, b0, b1)
-		FRONT_STEP(dc, c0, c1)
+	/* tail (at most 2 DEPTH slots per wave): the same steps with their bounds checks */
+	static_assert(DEPTH == 3, "the tail is written out for three register sets");
+	for (;;) {	/* (a loop over the sets with a flag instead of these breaks cost 27 VGPRs and three waves per SIMD) */
+		FRONT_STEP(dsc[0], r0[0], r1[0])
+		FRONT_STEP(dsc[1], r0[1], r1[1])
+		FRONT_STEP(dsc[2], r0[2], r1[2])
 	}
 #undef FRONT_STEP
+#undef FRONT_FLUSH_IF
+#undef SLOT_OF
 }
 
 __device__ __forceinline__ uint32_t spread4(uint32_t nib)
