@@ -501,8 +501,9 @@ def main():
                              "HIP-event duration (second pass of the same K steps, one event between stages on the launch stream; the "
                              "timed pass overlaps the two trellis kernels); pipeline_achieved_gbs_per_gpu = all 0.82 kB per burst / "
                              "step time; traffic = PMC bytes per launch and valu_busy_frac from profiles/traffic.json "
-                             "(profiles/r01_config2_rocprofv3.md): k_front moves 652 MB per launch at 0.56 VALU busy, the trellis "
-                             "kernels are VALU-issue bound (0.72 - 0.82 busy, 28 instructions per trellis step), see DESIGN.md"},
+                             "(profiles/r01_config2_rocprofv3.md): k_front is bound by the memory system (its reads, its writes and the "
+                             "write-back of the previous kernels' records), the trellis kernels are VALU-issue bound (0.72 - 0.82 "
+                             "busy, 28 instructions per trellis step), see DESIGN.md"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(slots, types)
