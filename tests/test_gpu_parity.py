@@ -1253,3 +1253,42 @@ def test_generic_trellis_extreme_shapes(T, eng, shape):
     for i in range(n):
         assert (got[i] == O.conv_decode_block(pu, mother, t3[i], L, 0)).all(), (shape, i)
     cv.close()
+
+
+def test_plan_and_conv_execute_are_graph_capturable(T, eng):
+    """tgpu_plan_execute / tgpu_conv_execute only launch (header contract): captured into a HIP graph on a side
+    stream and replayed, they produce the records / bits of a direct call"""
+    import torch
+    n = 3000
+    rng = np.random.default_rng(77)
+    types = rng.choice([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_NORM_2], n).astype(np.uint8)
+    code = O.scramb_get_init(262, 42, 1)
+    slots = T.synth_slots(types, seed=3, scramb_init=code, ber=0.03)
+    d_stream = torch.from_numpy(slots.reshape(-1)).cuda()
+    plan = T.Plan(eng, n, 1)
+    plan.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types, None, np.array([code], np.uint32))
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    shape = (292, 432, 4, 2)
+    t2, t3 = _conv_batch(shape, 500, seed=5)
+    cv = T.ConvDecoder(eng, shape[3], shape[2], shape[1], shape[0])
+    d_t3 = torch.from_numpy(t3.reshape(-1)).cuda()
+    d_t2 = torch.zeros(500 * shape[0], dtype=torch.uint8, device="cuda")
+    hs = torch.cuda.current_stream().cuda_stream
+    plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), hs)
+    cv.execute(d_t3.data_ptr(), 500, d_t2.data_ptr(), hs)
+    torch.cuda.synchronize()
+    want_rec, want_t2 = d_rec.clone(), d_t2.clone()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        cs = torch.cuda.current_stream().cuda_stream
+        plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), cs)
+        cv.execute(d_t3.data_ptr(), 500, d_t2.data_ptr(), cs)
+    for _ in range(2):
+        d_rec.zero_()
+        d_t2.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert bool((d_rec == want_rec).all()) and bool((d_t2 == want_t2).all())
+    cv.close()
+    plan.close()
