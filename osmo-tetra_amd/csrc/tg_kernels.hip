@@ -214,9 +214,9 @@ void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	 * slot after the other; position t of its sequence is slot 4 (wave + (t >> 2) nwaves) + (t & 3).  The four
 	 * packed slots of a group leave as 320 contiguous bytes (two store instructions per group instead of one
 	 * 80-byte store per slot), and the slots a wave reads back to back are neighbours in memory.  Measured with
-	 * the stages of this kernel in isolation (tools/ubench/front_buildup.hip): 127 us per 1 M slots with one
-	 * 80-byte store per slot and slots dealt round-robin, 84 us this way -- the per-slot stores, not the
-	 * gathers, were what kept the kernel off the read rate.
+	 * the stages of this kernel in isolation (tools/ubench/front_buildup.hip): 126 us per 1 M slots with one
+	 * 80-byte store per slot and slots dealt round-robin, 112 us this way, 97 us without any store -- the
+	 * per-slot stores, not the gathers (3 us), were what kept the kernel off the read rate.
 	 */
 	const uint32_t ngroups = (nslots + 3) >> 2;
 	if (wave >= ngroups)

@@ -42,9 +42,11 @@ __global__ __launch_bounds__(256) void k(const uint8_t *in, const uint64_t *desc
 #define OFF(s) (STAGE >= 5 ? (size_t)((dtmp = DESC(s)) & 0x00ffffffffffffffull) : (size_t)(s) * 510)
 	uint64_t dtmp = 0;
 #define FETCH(R0, R1, s) { const uint8_t *b_ = in + OFF(s); R0 = *(const u32u *)(b_ + 4 * lane); R1 = *(const u32u *)(b_ + 256 + 4 * lane - (lane == 63 ? 2 : 0)); }
-	if (slot + 5 * nwaves >= nslots)
+	if (slot >= nslots)
 		return;
-	FETCH(a0, a1, slot) FETCH(b0, b1, slot + nwaves) FETCH(c0, c1, slot + 2 * nwaves)
+	const uint32_t last = slot + ((nslots - 1 - slot) / nwaves) * nwaves;	/* this wave's last slot */
+#define CL(s) ((s) < nslots ? (s) : last)
+	FETCH(a0, a1, slot) FETCH(b0, b1, CL(slot + nwaves)) FETCH(c0, c1, CL(slot + 2 * nwaves))
 #define STEP(R0, R1)											\
 	{												\
 		uint32_t w_ = R0 ^ R1;									\
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void k(const uint8_t *in, const uint64_t *desc
 			mine[lane] = R0;								\
 			mine[64 + lane] = R1;								\
 		}											\
-		FETCH(R0, R1, slot + 3 * nwaves)							\
+		FETCH(R0, R1, CL(slot + 3 * nwaves))							\
 		ty = (uint32_t)(dtmp >> 56);								\
 		if (STAGE >= 1)										\
 			w_ ^= mine[(lane * 5) & 127];							\
@@ -84,8 +86,12 @@ __global__ __launch_bounds__(256) void k(const uint8_t *in, const uint64_t *desc
 			acc ^= w_;									\
 		slot += nwaves;										\
 	}
-	while ((uint64_t)slot + 5ull * nwaves < nslots) {
-		STEP(a0, a1) STEP(b0, b1) STEP(c0, c1)
+	while (slot < nslots) {		/* every slot is processed; requests past the end re-read the last slot */
+		STEP(a0, a1)
+		if (slot >= nslots) break;
+		STEP(b0, b1)
+		if (slot >= nslots) break;
+		STEP(c0, c1)
 	}
 	if (acc == 0x12345678u) out[0] = acc;
 }
@@ -109,8 +115,9 @@ __global__ __launch_bounds__(256) void k8(const uint8_t *in, uint32_t nslots, ui
 	uint32_t a0, a1, b0, b1, c0, c1;
 	const uint32_t ngroups = nslots / 4;
 	uint32_t g = wave;	/* group index; slot = 4 g + j */
-	if (g + 2 * nwaves >= ngroups)
+	if (g >= ngroups)
 		return;
+	const uint32_t lastg = g + ((ngroups - 1 - g) / nwaves) * nwaves;
 	uint32_t j = 0;
 #define SLOT(gg, jj) ((size_t)(4 * (gg) + (jj)) * 510)
 #define FETCH8(R0, R1, off) { const uint8_t *b_ = in + (off); R0 = *(const u32u *)(b_ + 4 * lane); R1 = *(const u32u *)(b_ + 256 + 4 * lane - (lane == 63 ? 2 : 0)); }
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(256) void k8(const uint8_t *in, uint32_t nslots, ui
 		{											\
 			uint32_t j3 = j + 3, g3 = g;							\
 			if (j3 >= 4) { j3 -= 4; g3 += nwaves; }						\
+			if (g3 >= ngroups) { g3 = lastg; j3 = 3; }					\
 			FETCH8(R0, R1, SLOT(g3, j3))							\
 		}											\
 		uint32_t w_ = 0, by_[10];								\
@@ -145,8 +153,12 @@ __global__ __launch_bounds__(256) void k8(const uint8_t *in, uint32_t nslots, ui
 			g += nwaves;									\
 		}											\
 	}
-	while ((uint64_t)g + 3ull * nwaves < ngroups) {
-		STEP8(a0, a1) STEP8(b0, b1) STEP8(c0, c1)
+	while (g < ngroups) {		/* every group is processed; requests past the end re-read the last slot */
+		STEP8(a0, a1)
+		if (g >= ngroups) break;
+		STEP8(b0, b1)
+		if (g >= ngroups) break;
+		STEP8(c0, c1)
 	}
 	if (a0 == 0x12345678u) out[0] = a0;
 }
