@@ -1292,3 +1292,30 @@ def test_plan_and_conv_execute_are_graph_capturable(T, eng):
         assert bool((d_rec == want_rec).all()) and bool((d_t2 == want_t2).all())
     cv.close()
     plan.close()
+
+
+def test_front_end_pipeline_tails(T, eng, monkeypatch):
+    """k_front with very few waves (TGPU_FRONT_BLOCKS, a test knob of the launcher), so that every wave runs its
+    prologue, the unconditional main loop and the checked tail over sequences of every length: groups of four
+    slots, a short last group, fewer slots than waves -- every batch size from 1 to 150 and a few larger ones"""
+    import torch
+    import emul
+    rng = np.random.default_rng(15)
+    nmax = 700
+    ty_all = rng.choice([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_NORM_2], nmax).astype(np.uint8)
+    slots_all = T.synth_slots(ty_all, seed=9, scramb_init=0)
+    hs = torch.cuda.current_stream().cuda_stream
+    want = [emul.pack_slot(int(ty_all[i]), slots_all[i])[:19] for i in range(nmax)]
+    for blocks in ("1", "2"):
+        monkeypatch.setenv("TGPU_FRONT_BLOCKS", blocks)
+        for n in list(range(1, 151)) + [255, 256, 257, 511, 700]:
+            d = torch.from_numpy(slots_all[:n].reshape(-1).copy()).cuda()
+            plan = T.Plan(eng, n, 1)
+            plan.load(np.arange(n, dtype=np.uint64) * 510, ty_all[:n])
+            d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+            plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+            torch.cuda.synchronize()
+            got = plan.read_packed()
+            plan.close()
+            for i in range(n):
+                assert (got[i, :19] == want[i]).all(), (blocks, n, i)
