@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--gather", default="final", choices=["final", "step"],
                     help="N>1: 'final' = one RCCL gather of the decoded blocks (48-byte wire records) at the end of the "
                          "timed region; 'step' = one gather per step, overlapped with the next decode (needs about "
-                         "110 GB/s per xGMI link at the single-GPU decode rate)")
+                         "120 GB/s per xGMI link at the single-GPU decode rate)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "conv"],
                     help="config2 (default, the metric's workload): aligned NDB slots; config3: mixed SB/NDB stream "
                          "through the GPU burst-sync front end, 1%% corrupted training sequences")
@@ -370,7 +370,7 @@ def main():
     # N > 1: the final exchange of the path -- decoded blocks travel to rank 0 in the 48-byte wire form (each
     # peer->root transfer uses its own xGMI link; see DESIGN.md "Multi-GPU").  Default: one gather of the last
     # batch at the end of the timed region.  --gather step: one gather per step on a side stream, overlapped with
-    # the next decode -- at 2.3e9 bursts/s per GPU that is 110 GB/s per link, more than a link sustains.
+    # the next decode -- at 2.5e9 bursts/s per GPU that is 120 GB/s per link, more than a link sustains.
     gather = world > 1
     if gather:
         from osmo_tetra_amd import dist as tdist
