@@ -163,6 +163,44 @@ __global__ __launch_bounds__(256) void k8(const uint8_t *in, uint32_t nslots, ui
 	if (a0 == 0x12345678u) out[0] = a0;
 }
 
+// group read patterns alone (2040 contiguous bytes per wave and step, two groups in flight, xor-accumulate):
+// W = 16: two 16-byte loads per lane (8-byte aligned addresses), W = 8: four 8-byte loads, W = 4: eight dwords
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef v4u __attribute__((aligned(1))) v4uu;
+typedef v2u __attribute__((aligned(1))) v2uu;
+template <int W>
+__global__ __launch_bounds__(256) void kg(const uint8_t *in, uint32_t nslots, uint32_t *out)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+	const uint32_t ngroups = nslots / 4;
+	uint32_t acc = 0;
+	for (uint32_t g = wave; g < ngroups; g += 2 * nwaves) {
+		for (int q = 0; q < 2; q++) {
+			const uint32_t gg = g + q * nwaves < ngroups ? g + q * nwaves : g;
+			const uint8_t *b = in + (size_t)gg * 2040;
+			if (W == 16) {
+				const v4u x0 = *(const v4uu *)(b + 16 * lane);
+				const v4u x1 = *(const v4uu *)(b + (lane == 63 ? 2024 : 1024 + 16 * lane));
+				acc ^= x0.x ^ x0.y ^ x0.z ^ x0.w ^ x1.x ^ x1.y ^ x1.z ^ x1.w;
+			} else if (W == 8) {
+				for (int k = 0; k < 4; k++) {
+					const uint32_t o = 512 * k + 8 * lane;
+					const v2u x = *(const v2uu *)(b + (o + 8 > 2040 ? 2032 : o));
+					acc ^= x.x ^ x.y;
+				}
+			} else {
+				for (int k = 0; k < 8; k++) {
+					const uint32_t o = 256 * k + 4 * lane;
+					acc ^= *(const u32u *)(b + (o + 4 > 2040 ? 2036 : o));
+				}
+			}
+		}
+	}
+	if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <typename F> static float timeit(F f)
 {
 	hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -188,6 +226,8 @@ int main()
 		 printf("stage %d: %.1f us  %.2f TB/s of input\n", S, ms * 1e3, n * 510.0 / ms / 1e9); }
 #define RUNW(SW, SP) { float ms = timeit([&] { hipLaunchKernelGGL((k<4, SW, SP>), dim3(blocks), dim3(256), 0, 0, d, ds, n, p, o); }); \
 		 printf("stage 4, %d dwords stored at a pitch of %d dwords: %.1f us\n", SW, SP, ms * 1e3); }
+#define RUNG(W) { float ms = timeit([&] { hipLaunchKernelGGL((kg<W>), dim3(blocks), dim3(256), 0, 0, d, n, o); }); printf("group reads, %d bytes per load: %.1f us  %.2f TB/s\n", W, ms * 1e3, n * 510.0 / ms / 1e9); }
+	RUNG(16) RUNG(8) RUNG(4) RUNG(16)
 	RUNW(20, 20) RUNW(16, 16)
 	{ float ms = timeit([&] { hipLaunchKernelGGL(k8, dim3(blocks / 4), dim3(256), 0, 0, d, n, p, o); }); printf("stage 8 (groups of 4 slots, 2048 blocks): %.1f us\n", ms * 1e3); }
 	{ float ms = timeit([&] { hipLaunchKernelGGL(k8, dim3(blocks), dim3(256), 0, 0, d, n, p, o); }); printf("stage 8 (groups of 4 slots, 8192 blocks): %.1f us\n", ms * 1e3); }
