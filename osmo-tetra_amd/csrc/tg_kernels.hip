@@ -687,38 +687,74 @@ void k_front_soft(const int8_t *__restrict__ soft, const uint64_t *__restrict__ 
 	const uint32_t wave = blockIdx.x * 4 + wib;
 	const uint32_t nwaves = gridDim.x * 4;
 	uint32_t *mine = s_slot[wib];
-	const uint8_t *mine8 = (const uint8_t *)mine;
+	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];
 
-	for (uint32_t slot = wave; slot < nslots; slot += nwaves) {
-		const uint64_t d = slot_desc[slot];
-		const uint32_t type = TG_DESC_TYPE(d);
-		uint32_t d0, d1;
-		front_fetch((const uint8_t *)soft + TG_DESC_OFF(d), lane, d0, d1);
-		mine[lane] = d0;
-		mine[64 + lane] = (lane == 63) ? (d1 >> 16) : d1;	/* lane 63 fetched bytes 506..509 */
+	/* this lane assembles area bytes 4 lane .. 4 lane + 3 and 256 + 4 lane ..: their LDS source addresses per burst
+	 * type stay in registers (window byte 510 is zero: "no source") */
+	uint32_t adr[3][8];
+#pragma unroll
+	for (int x = 0; x < 3; x++)
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const uint32_t o = g_soft_tab.src[x][256 * (q >> 2) + 4 * lane + (q & 3)];
+			adr[x][q] = wib * 512 + (o == 0xffff ? 510u : o);
+		}
+
+	/* groups of four neighbouring slots per wave (as k_front), the next slot's two dwords requested before this
+	 * one is gathered; past the end of the sequence the last slot is requested again, so that every step issues
+	 * the same memory operations and the waits stay exact */
+	const uint32_t ngroups = (nslots + 3) >> 2;
+	if (wave >= ngroups)
+		return;
+	const uint32_t mygroups = (ngroups - wave + nwaves - 1) / nwaves;
+	uint32_t T = 4 * mygroups;
+	if (wave + (mygroups - 1) * nwaves == ngroups - 1)
+		T -= 4 * ngroups - nslots;
+#define SLOT_OF(t) (4u * (wave + ((t) >> 2) * nwaves) + ((t) & 3u))
+	uint64_t dcur = slot_desc[SLOT_OF(0u)];
+	uint32_t n0, n1;
+	front_fetch((const uint8_t *)soft + TG_DESC_OFF(dcur), lane, n0, n1);
+	uint64_t dnext = slot_desc[SLOT_OF(T > 1 ? 1u : 0u)];
+	for (uint32_t t = 0; t < T; t++) {
+		const uint32_t slot = SLOT_OF(t);
+		const uint32_t type = TG_DESC_TYPE(dcur);
+		mine[lane] = n0;
+		mine[64 + lane] = (lane == 63) ? (n1 >> 16) : n1;	/* lane 63 fetched bytes 506..509 */
+		dcur = dnext;
+		front_fetch((const uint8_t *)soft + TG_DESC_OFF(dcur), lane, n0, n1);
+		dnext = slot_desc[SLOT_OF(t + 2 < T ? t + 2 : T - 1)];
+		uint32_t w0 = 0, w1 = 0;
 		if (type == TG_BURST_NORM_1 || type == TG_BURST_NORM_2 || type == TG_BURST_SYNC) {
-			const uint32_t tix = (type == TG_BURST_SYNC) ? 2 : type;
-			const uint16_t *tab = g_soft_tab.src[tix];
+			uint32_t by[8];
+			if (type == TG_BURST_NORM_1) {
 #pragma unroll
-			for (int r = 0; r < 2; r++) {
-				const uint32_t q0 = 256 * r + 4 * lane;
-				uint32_t w = 0;
+				for (int q = 0; q < 8; q++)
+					by[q] = lds0[adr[0][q]];
+			} else if (type == TG_BURST_NORM_2) {
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const uint32_t o = tab[q0 + k];
-					const uint32_t byte = (o == 0xffff) ? 0u : (uint32_t)mine8[o];
-					w |= byte << (8 * k);
-				}
-				area[(size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + 64 * r + lane] = w;
+				for (int q = 0; q < 8; q++)
+					by[q] = lds0[adr[1][q]];
+			} else {
+#pragma unroll
+				for (int q = 0; q < 8; q++)
+					by[q] = lds0[adr[2][q]];
 			}
+			w0 = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);
+			w1 = by[4] | (by[5] << 8) | (by[6] << 16) | (by[7] << 24);
 		} else if (lane == 0) {
 			rec[(size_t)slot * TG_REC_BYTES + TG_REC_TYPE] = TG_BURST_NONE;
 		}
-		if (lane == 0) {
-			const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
-			packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META] = type | (toff << 16);
-		}
+		/* no store sits under a branch (exact s_waitcnt, see k_front): an ignored burst type writes zeros to its
+		 * area, which nothing reads, and the meta word goes through a one-dword buffer range (lane 0 only) */
+		uint32_t *dst = area + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4);
+		dst[lane] = w0;
+		dst[64 + lane] = w1;
+		const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
+		const __amdgpu_buffer_rsrc_t mw = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)slot * TG_PACKED_WORDS + TG_PW_META,
+										      0, 4, 0x00027000);
+		__builtin_amdgcn_raw_buffer_store_b32(type | (toff << 16), mw, lane * 4, 0, 0);
 	}
+#undef SLOT_OF
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1765,8 +1801,11 @@ extern "C" int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc,
 	if (!nslots)
 		return 0;
 	uint32_t blocks = (nslots + 3) / 4;
-	if (blocks > 256 * 8)
-		blocks = 256 * 8;
+	uint32_t cap = 256 * 8;
+	if (const char *e = getenv("TGPU_FRONT_BLOCKS"))
+		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
+	if (blocks > cap)
+		blocks = cap;
 	hipLaunchKernelGGL(k_front_soft, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_soft, d_slot_desc, nslots,
 			   d_area, d_packed, d_rec);
 	return (int)hipGetLastError();
