@@ -118,43 +118,79 @@ def bench_config3(args, T, torch, rank, world, local):
     stream = np.concatenate([rng.integers(0, 2, 100).astype(np.uint8), slots.reshape(-1), np.zeros(700, np.uint8)])
     eng = T.Engine(local)
     d_stream = torch.from_numpy(np.concatenate([stream, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
-    # double-buffered: the decode of stream k runs on its own HIP stream while stream k+1 is classified (GPU)
-    # and walked (host) -- two plans, two record buffers, two decode streams
-    d_rec = [torch.empty((n + 8) * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)]
-    plan = [T.Plan(eng, n + 8, 1) for _ in range(2)]
-    hs = torch.cuda.current_stream().cuda_stream
-    dec = [torch.cuda.Stream() for _ in range(2)]
-    cst = [torch.cuda.Stream() for _ in range(2)]
-    done = [None, None]
-    t_sync = 0.0
-    nslots = 0
-    total = args.warmup + args.steps
-    # software pipeline over streams: classification of stream k+1 (GPU) is launched before stream k is walked on
-    # the host; the decode of stream k runs on its own HIP stream under the walk of stream k+1
-    g = [None, None]
-    g[0] = T.GridSync(eng, plan[0], stream, d_stream.data_ptr(), 64, cst[0].cuda_stream)
-    for k in range(total):
-        if k == args.warmup:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+    # W host threads (the reference runs one process per channel; a recording is an independent unit), each with its
+    # own double-buffered pipeline: two plans, two record buffers, two decode streams, two classification streams.
+    # Inside a thread the classification of stream k+1 (GPU) is launched before stream k is walked on the host, and
+    # the decode of stream k runs on its own HIP stream under the walk of stream k+1.
+    import threading
+    W = max(1, min(args.sync_threads, args.steps))
+    share = [args.steps // W + (w < args.steps % W) for w in range(W)]
+    warm = max(2, -(-args.warmup // W))
+    start = threading.Barrier(W + 1)
+    state = {}
+    errors = []
+
+    def worker(w):
+        try:
+            torch.cuda.set_device(local)
+            d_rec = [torch.empty((n + 8) * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            plan = [T.Plan(eng, n + 8, 1) for _ in range(2)]
+            dec = [torch.cuda.Stream() for _ in range(2)]
+            cst = [torch.cuda.Stream() for _ in range(2)]
+            done = [None, None]
+            total = warm + share[w]
+            g = [None, None]
+            g[0] = T.GridSync(eng, plan[0], stream, d_stream.data_ptr(), 64, cst[0].cuda_stream)
             t_sync = 0.0
-        i = k & 1
-        j = i ^ 1
-        if k + 1 < total:
-            if done[j] is not None:
-                done[j].synchronize()    # the decode that last used that plan / record buffer
-            g[j] = T.GridSync(eng, plan[j], stream, d_stream.data_ptr(), 64, cst[j].cuda_stream)
-        a = time.perf_counter()
-        res = g[i].finish(burst_events=False, scramb_init=0)     # wait for the classification, walk, device lists
-        assert res["noffgrid"] == 0 and res["ngrid"] <= n + 8
-        t_sync += time.perf_counter() - a
-        plan[i].execute(d_stream.data_ptr(), d_rec[i].data_ptr(), dec[i].cuda_stream)
-        done[i] = torch.cuda.Event()
-        done[i].record(dec[i])
-        nslots = res["nslots"]
-        last = i
+            res = None
+            last = 0
+            for k in range(total):
+                if k == warm:
+                    for e in done:
+                        if e is not None:
+                            e.synchronize()
+                    start.wait()             # the timed region starts when every thread has warmed up
+                    start.wait()
+                    t_sync = 0.0
+                i = k & 1
+                j = i ^ 1
+                if k + 1 < total:
+                    if done[j] is not None:
+                        done[j].synchronize()    # the decode that last used that plan / record buffer
+                    g[j] = T.GridSync(eng, plan[j], stream, d_stream.data_ptr(), 64, cst[j].cuda_stream)
+                a = time.perf_counter()
+                res = g[i].finish(burst_events=False, scramb_init=0)     # wait for the classification, walk, device lists
+                assert res["noffgrid"] == 0 and res["ngrid"] <= n + 8
+                t_sync += time.perf_counter() - a
+                plan[i].execute(d_stream.data_ptr(), d_rec[i].data_ptr(), dec[i].cuda_stream)
+                done[i] = torch.cuda.Event()
+                done[i].record(dec[i])
+                last = i
+            for e in done:
+                if e is not None:
+                    e.synchronize()
+            state[w] = (res, plan, d_rec, last, t_sync)
+        except Exception as ex:          # pragma: no cover
+            errors.append(ex)
+            start.abort()
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(W)]
+    for th in threads:
+        th.start()
+    start.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    start.wait()
+    for th in threads:
+        th.join()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if errors:
+        raise errors[0]
+    res, plan, d_rec, last, _ = state[0]
+    t_sync = sum(v[4] for v in state.values()) / W
+    nslots = res["nslots"]
+    hs = torch.cuda.current_stream().cuda_stream
     first = T.grid_indices(res)[:2048]
     p = T.parse_records(d_rec[last].view(-1, T.REC_BYTES)[torch.from_numpy(first).cuda()].cpu().numpy())
     prof = T.Prof(4)
@@ -167,9 +203,10 @@ def bench_config3(args, T, torch, rank, world, local):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
            "config": {"workload": "BASELINE config 3: %d-burst mixed SB/NDB stream, GPU burst-sync front end, 1%% corrupted "
                                   "training sequences; step = GPU classification/packing + host walk (bitmap) + device-built lists + decode, "
-                                  "software-pipelined over streams (classification of stream k+1 and decode of stream k under the host walk)" % n,
+                                  "software-pipelined over streams (classification of stream k+1 and decode of stream k under the host walk), "
+                                  "%d host threads each walking its own streams" % (n, W),
                       "bursts_in_stream": n, "bursts_delivered": nslots, "crc_ok_first_2048": int(p["crc_ok"][:, 0].sum())},
-           "breakdown_ms": {"grid sync finish (wait for the classification, host walk, device list build)": t_sync / args.steps * 1e3,
+           "breakdown_ms": {"grid sync finish per stream and thread (wait for the classification, host walk, device list build)": t_sync / max(share) * 1e3,
                             "plan_execute(GPU decode, runs under the next stream's synchronisation)": t_exec / args.steps * 1e3}}
     print(json.dumps(out))
 
@@ -318,6 +355,8 @@ def main():
                     help="N>1: 'final' = one RCCL gather of the decoded blocks (48-byte wire records) at the end of the "
                          "timed region; 'step' = one gather per step, overlapped with the next decode (needs about "
                          "120 GB/s per xGMI link at the single-GPU decode rate)")
+    ap.add_argument("--sync-threads", type=int, default=3,
+                    help="config3: host threads, each synchronising (walking) its own streams")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "conv"],
                     help="config2 (default, the metric's workload): aligned NDB slots; config3: mixed SB/NDB stream "
                          "through the GPU burst-sync front end, 1%% corrupted training sequences")
