@@ -438,6 +438,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 {
 	constexpr int WIN = TG_STREAM_VIEW / 4 + 4;	/* 160 data dwords + one zero pad row */
 	__shared__ uint32_t s_slot[4][WIN];
+	__shared__ uint32_t s_out[4][128];	/* per wave: four packed slots on their way out, then their cls / ysum words */
 
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -447,6 +448,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	uint32_t *mine = s_slot[wib];
 	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];
 	const uint32_t wbase = wib * WIN * 4;
+	uint32_t *mo = s_out[wib];
 	if (lane < 4)
 		mine[TG_STREAM_VIEW / 4 + lane] = 0;	/* "no source" gathers read this */
 
@@ -461,7 +463,17 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		a_sb[r] = wbase + (o2 == 0xffff ? TG_STREAM_VIEW : o2);
 	}
 
-	for (uint32_t slot = wave; slot < prm.nslots; slot += nwaves) {
+	/* groups of four neighbouring grid slots per wave; packed slots, classification words and SYNC summaries are
+	 * staged in LDS and written once per group (as k_front: per-slot stores cost more than the search saves) */
+	const uint32_t ngroups = (prm.nslots + 3) >> 2;
+	if (wave >= ngroups)
+		return;
+	const uint32_t mygroups = (ngroups - wave + nwaves - 1) / nwaves;
+	uint32_t T = 4 * mygroups;
+	if (wave + (mygroups - 1) * nwaves == ngroups - 1)
+		T -= 4 * ngroups - prm.nslots;
+	for (uint32_t t = 0; t < T; t++) {
+		const uint32_t slot = 4u * (wave + (t >> 2) * nwaves) + (t & 3u);
 		const uint64_t bs = prm.anchor + (uint64_t)slot * TG_SLOT_BITS;
 		const uint8_t *base = stream + bs;
 		/* 640 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack).  (Requesting the
@@ -488,14 +500,27 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		/* bytes -> 640-bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes past the stream end read as 0
 		 * (every test below bounds itself by the window, so bytes past the window need no masking) */
 		unsigned long long B[11];
-		uint32_t anyb = 0;
+		if (vis == TG_STREAM_VIEW) {	/* everywhere but at the very end of the stream: no per-lane bound */
 #pragma unroll
-		for (int r = 0; r < 10; r++) {
-			const uint32_t byte = lds0[wbase + 64 * r + lane];
-			anyb |= (64u * r + lane < wv) ? byte : 0u;
-			B[r] = __ballot(byte != 0 && 64u * r + lane < vis);
+			for (int r = 0; r < 10; r++)
+				B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0);
+		} else {
+#pragma unroll
+			for (int r = 0; r < 10; r++)
+				B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0 && 64u * r + lane < vis);
 		}
 		B[10] = 0;
+		/* a byte other than 0 / 1 inside the search window: from the three dwords of the lane (byte k of dword q
+		 * is window byte 256 q + 4 lane + k), bytes at or past the window end masked off */
+		uint32_t anyb;
+		{
+			const uint32_t p0 = 4 * lane, p1 = 256 + 4 * lane, p2 = 512 + 4 * lane;
+			const uint32_t k0 = wv > p0 ? wv - p0 : 0, k1 = wv > p1 ? wv - p1 : 0, k2 = wv > p2 ? wv - p2 : 0;
+			const uint32_t m0 = k0 >= 4 ? 0xffffffffu : ((1u << (8 * k0)) - 1u);
+			const uint32_t m1 = k1 >= 4 ? 0xffffffffu : ((1u << (8 * k1)) - 1u);
+			const uint32_t m2 = k2 >= 4 ? 0xffffffffu : ((1u << (8 * k2)) - 1u);
+			anyb = (((d0 & m0) | (d1 & m1) | (d2 & m2)) & 0xfefefefeu) ? 2u : 0u;
+		}
 
 		uint32_t rc = TG_BURST_NONE, offs = 0, flags = 0, early = 0;
 		uint32_t ys = TG_YS_NONE;	/* where SYNC sequences start inside this slot, window or not */
@@ -529,9 +554,11 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 					}
 				}
 				if (full) {
-					const bool isy = y38 && (c + 38 <= w);
-					const bool isn = ((win & 0x3fffff) == prm.n22) && (c + 22 <= w);
-					const bool isp = ((win & 0x3fffff) == prm.p22) && (c + 22 <= w);
+					/* the window holds at least 510 bytes: rounds 0..6 (c + 38 <= 485) need no bound */
+					const bool in38 = (r < 7) || (c + 38 <= w), in22 = (r < 7) || (c + 22 <= w);
+					const bool isy = y38 && in38;
+					const bool isn = ((win & 0x3fffff) == prm.n22) && in22;
+					const bool isp = ((win & 0x3fffff) == prm.p22) && in22;
 					const bool any = isy || isn || isp;
 					if (r == 0)
 						early = __ballot(any && c < 21) != 0;
@@ -570,14 +597,23 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		if (lane == TG_PW_META)
 			myword = dtype | (((flags & TG_CLS_NONBINARY) ? TG_FLAG_NONBINARY : 0u) << 8) | (offs << 16);
 		if (lane < TG_PACKED_WORDS)
-			packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
+			mo[(t & 3u) * TG_PACKED_WORDS + lane] = myword;
 		if (lane == 0) {
-			cls[slot] = rc | (offs << 8) | (flags << 24);
-			if (ysum)
-				ysum[slot] = (uint16_t)ys;
+			mo[80 + (t & 3u)] = rc | (offs << 8) | (flags << 24);
+			mo[84 + (t & 3u)] = ys;
+		}
+		if ((t & 3u) == 3u || t + 1 == T) {
+			const uint32_t cnt = (t & 3u) + 1u, first = slot - (t & 3u);
+			front_flush(mo, lane, first, cnt, packed);
+			if (lane < cnt) {
+				cls[first + lane] = mo[80 + lane];
+				if (ysum)
+					ysum[first + lane] = (uint16_t)mo[84 + lane];
+			}
 		}
 	}
 }
+
 
 /* ------------------------------------------------------------------------- */
 /* soft input (BASELINE config 5): float phases -> bits / soft values, soft gather  */
