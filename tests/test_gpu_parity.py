@@ -1319,3 +1319,43 @@ def test_front_end_pipeline_tails(T, eng, monkeypatch):
             plan.close()
             for i in range(n):
                 assert (got[i, :19] == want[i]).all(), (blocks, n, i)
+
+
+def test_generic_trellis_random_shapes(T, eng):
+    """random valid (puncturer, mother code, type-2 length, type-3 length) shapes beyond the reference's nine rows:
+    every history-chunk count, partial tail blocks, type-3 lengths of every residue mod 4 -- against the oracle"""
+    import torch
+    rng = np.random.default_rng(2024)
+    hs = torch.cuda.current_stream().cuda_stream
+    done = 0
+    while done < 40:
+        pu = int(rng.integers(0, 7))
+        mother = 3 if pu >= 4 else 4
+        L = int(rng.integers(1, 63)) * 8 + int(rng.choice([0, 0, 4, 5, 6, 7]))
+        if L > 504:
+            continue
+        kmax = 1
+        while kmax < 1022 and O.conv_decode_block(pu, mother, np.zeros(kmax + 1, np.uint8), L, 0) is not None:
+            kmax += 1                                   # longest type-3 length whose positions fit the mother buffer
+        K = int(rng.integers(max(1, kmax - 6), kmax + 1))
+        if O.conv_decode_block(pu, mother, np.zeros(K, np.uint8), L, 0) is None:
+            continue
+        n = int(rng.integers(1, 130))
+        t2 = rng.integers(0, 2, (n, L)).astype(np.uint8)
+        mlen = L * mother
+        t3 = np.zeros((n, K), np.uint8)
+        for i in range(n):
+            m = O.conv_encode_tch(t2[i]) if mother == 3 else O.conv_encode(t2[i])
+            t3[i] = O.puncture(pu, m, K)
+        t3 ^= (rng.random((n, K)) < 0.05).astype(np.uint8)
+        t3[rng.random((n, K)) < 0.02] = 0xFF
+        cv = T.ConvDecoder(eng, pu, mother, K, L)
+        d_in = torch.from_numpy(t3.reshape(-1)).cuda()
+        d_out = torch.zeros(n * L, dtype=torch.uint8, device="cuda")
+        cv.execute(d_in.data_ptr(), n, d_out.data_ptr(), hs)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().reshape(n, L)
+        for i in range(n):
+            assert (got[i] == O.conv_decode_block(pu, mother, t3[i], L, 0)).all(), (pu, mother, L, K, n, i)
+        cv.close()
+        done += 1
