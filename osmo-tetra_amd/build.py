@@ -44,6 +44,7 @@ def build(force=False, verbose=False):
     for s in HIP_SRCS:
         o = os.path.join(OBJ, s + ".o")
         run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"] + inc +
+            os.environ.get("TGPU_HIPCC_FLAGS", "").split() +    # experiment builds (-DTG_...=n)
             ["-c", os.path.join(CSRC, s), "-o", o])
         objs.append(o)
     for s in C_SRCS:

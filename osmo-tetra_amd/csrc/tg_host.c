@@ -259,7 +259,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 		/* no SYNC burst in the batch: every slot keeps its channel's carry-in code, so the
 		 * forward fill degenerates to entry 1 + chan and the masks can be built right now */
 		HCHK(hipMemcpyAsync(p->d_maskidx, d_idx_stage, (size_t)nslots * 4, hipMemcpyDeviceToDevice, NULL));
-		int rc = tgk_masks(p->d_chan_code, nchan, p->d_sb_ok, p->d_sb_code, 0, p->d_masks, NULL);
+		int rc = tgk_masks(p->d_chan_code, nchan, p->d_sb_ok, p->d_sb_code, 0, NULL, NULL, p->d_masks, NULL);
 		if (rc)
 			return rc;
 		HCHK(hipDeviceSynchronize());
@@ -456,13 +456,13 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	}
 	MARK(2);
 	if (p->nslots && !p->static_masks) {
-		if ((rc = tgk_fill(p->d_slot_chan, p->d_slot_sbord, p->d_sb_ok, p->nchan, p->nslots, p->d_block_tmp,
+		if ((rc = tgk_fill(p->d_slot_chan, p->d_slot_sbord, p->d_sb_ok, p->d_sb_code, p->d_list_sb, p->nchan, p->nslots, p->d_block_tmp,
 				   p->d_maskidx, stream)))
 			return rc;
 	}
 	MARK(3);
 	if (p->nslots && !p->static_masks) {
-		if ((rc = tgk_masks(p->d_chan_code, p->nchan, p->d_sb_ok, p->d_sb_code, p->nsb, p->d_masks, stream)))
+		if ((rc = tgk_masks(p->d_chan_code, p->nchan, p->d_sb_ok, p->d_sb_code, p->nsb, p->d_list_sb, p->d_slot_chan, p->d_masks, stream)))
 			return rc;
 	}
 	MARK(4);
@@ -635,7 +635,7 @@ int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t 
 	free(uniq);
 	HCHK(hipMemcpy(p->d_up, p->h_up, o, hipMemcpyHostToDevice));
 	HCHK(hipMemcpyAsync(p->d_maskidx, d_idx, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, NULL));
-	int rc = tgk_masks(p->d_chan_code, nu, p->d_sb_ok, p->d_sb_code, 0, p->d_masks, NULL);
+	int rc = tgk_masks(p->d_chan_code, nu, p->d_sb_ok, p->d_sb_code, 0, NULL, NULL, p->d_masks, NULL);
 	if (rc)
 		return rc;
 	HCHK(hipDeviceSynchronize());

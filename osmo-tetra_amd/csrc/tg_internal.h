@@ -37,10 +37,13 @@ int tgk_float_to_bits_afc(const float *d_in, unsigned long long n, uint8_t *d_bi
  * g3: the program receives g3 somewhere (tg_conv_uses_g3) */
 int tgk_conv(int code, int g3, const uint8_t *d_type3, unsigned long long nblocks, uint32_t t3len, uint32_t L,
 	     const uint32_t *d_steps, uint8_t *d_type2, void *stream);
-int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uint32_t *d_sb_ok,
-	     uint32_t nchan, uint32_t nslots, unsigned long long *d_block_tmp, uint32_t *d_maskidx, void *stream);
+/* d_list_sb: slot of the k-th SYNC slot; a SYNC slot whose code repeats its predecessor's (same channel) shares that entry */
+int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uint32_t *d_sb_ok, const uint32_t *d_sb_code,
+	     const uint32_t *d_list_sb, uint32_t nchan, uint32_t nslots, unsigned long long *d_block_tmp, uint32_t *d_maskidx,
+	     void *stream);
 int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
-	      const uint32_t *d_sb_code, uint32_t nsb, uint32_t *d_masks, void *stream);
+	      const uint32_t *d_sb_code, uint32_t nsb, const uint32_t *d_list_sb, const uint32_t *d_slot_chan,
+	      uint32_t *d_masks, void *stream);
 
 /* stream mode: per-slot arrays and item lists from classification words + "delivered" bitmap;
  * d_blk: 3 * (ceil(n / 1024) + 1) words, the totals (sb, 216 items, 432 items) end up at d_blk[3 * nblocks] */

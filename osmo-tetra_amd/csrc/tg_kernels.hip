@@ -82,6 +82,7 @@ __device__ __forceinline__ uint32_t rm3014_correct(uint32_t bb, uint32_t &nerr)
  */
 typedef uint32_t __attribute__((aligned(1))) tg_u32_unaligned;
 typedef uint16_t __attribute__((aligned(1))) tg_u16_unaligned;
+typedef uint16_t __attribute__((may_alias)) tg_u16_alias;
 
 __device__ __forceinline__ void front_fetch(const uint8_t *base, uint32_t lane, uint32_t &d0, uint32_t &d1)
 {
@@ -432,36 +433,173 @@ struct tg_stream_params {
 	uint32_t y32, y6, n22, p22;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
-		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
+/*
+ * One grid slot through the per-position search: the wave's 640-byte view goes to LDS, ten ballots turn it into a
+ * 640-bit string in SGPRs, every lane tests one window position per round.  This is the exact form for ANY slot
+ * (stream end, windows longer than the slot, bytes other than 0 / 1, nothing found where a burst should be): the
+ * round-1 kernel ran it on every slot (k_front_stream_v1, kept for A/B runs), the packed-bit kernel below hands
+ * it the slots it cannot settle (k_front_stream_fix).
+ */
+__device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ stream, const tg_stream_params &prm, uint32_t slot,
+						  uint32_t lane, uint32_t half, uint32_t bit, uint32_t wbase, uint32_t *mine,
+						  const uint8_t *lds0, const uint32_t (&a_n1)[10], const uint32_t (&a_n2)[10],
+						  const uint32_t (&a_sb)[10], uint32_t &myword, uint32_t &clsword, uint32_t &ysword)
 {
-	constexpr int WIN = TG_STREAM_VIEW / 4 + 4;	/* 160 data dwords + one zero pad row */
-	__shared__ uint32_t s_slot[4][WIN];
-	__shared__ uint32_t s_out[4][128];	/* per wave: four packed slots on their way out, then their cls / ysum words */
+	const uint64_t bs = prm.anchor + (uint64_t)slot * TG_SLOT_BITS;
+	const uint8_t *base = stream + bs;
+	/* 640 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack) */
+	const uint32_t d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
+	const uint32_t d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
+	const uint32_t d2 = (lane < 32) ? *(const tg_u32_unaligned *)(base + 512 + 4 * lane) : 0u;
 
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t wave = blockIdx.x * 4 + wib;
-	const uint32_t nwaves = gridDim.x * 4;
-	const uint32_t half = lane >> 5, bit = lane & 31;
-	uint32_t *mine = s_slot[wib];
-	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];
-	const uint32_t wbase = wib * WIN * 4;
-	uint32_t *mo = s_out[wib];
-	if (lane < 4)
-		mine[TG_STREAM_VIEW / 4 + lane] = 0;	/* "no source" gathers read this */
+	uint64_t fed = bs + TG_SLOT_BITS + prm.chunk - 1;
+	fed = prm.cshift >= 0 ? (fed >> prm.cshift) << prm.cshift : (fed / prm.chunk) * prm.chunk;
+	if (fed > prm.len)
+		fed = prm.len;
+	const uint32_t w = (uint32_t)(fed - bs);			/* search window, >= 510 */
+	const uint32_t wv = w < TG_STREAM_VIEW ? w : TG_STREAM_VIEW;	/* what we can see of it */
+	const uint64_t rest = prm.len - bs;
+	const uint32_t vis = rest < TG_STREAM_VIEW ? (uint32_t)rest : TG_STREAM_VIEW;	/* stream bytes in view */
 
-	uint32_t a_n1[10], a_n2[10], a_sb[10];
+	mine[lane] = d0;
+	mine[64 + lane] = d1;
+	if (lane < 32)
+		mine[128 + lane] = d2;
+
+	/* bytes -> 640-bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes past the stream end read as 0
+	 * (every test below bounds itself by the window, so bytes past the window need no masking) */
+	unsigned long long B[11];
+	if (vis == TG_STREAM_VIEW) {	/* everywhere but at the very end of the stream: no per-lane bound */
+#pragma unroll
+		for (int r = 0; r < 10; r++)
+			B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0);
+	} else {
+#pragma unroll
+		for (int r = 0; r < 10; r++)
+			B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0 && 64u * r + lane < vis);
+	}
+	B[10] = 0;
+	/* a byte other than 0 / 1 inside the search window: from the three dwords of the lane (byte k of dword q
+	 * is window byte 256 q + 4 lane + k), bytes at or past the window end masked off */
+	uint32_t anyb;
+	{
+		const uint32_t p0 = 4 * lane, p1 = 256 + 4 * lane, p2 = 512 + 4 * lane;
+		const uint32_t k0 = wv > p0 ? wv - p0 : 0, k1 = wv > p1 ? wv - p1 : 0, k2 = wv > p2 ? wv - p2 : 0;
+		const uint32_t m0 = k0 >= 4 ? 0xffffffffu : ((1u << (8 * k0)) - 1u);
+		const uint32_t m1 = k1 >= 4 ? 0xffffffffu : ((1u << (8 * k1)) - 1u);
+		const uint32_t m2 = k2 >= 4 ? 0xffffffffu : ((1u << (8 * k2)) - 1u);
+		anyb = (((d0 & m0) | (d1 & m1) | (d2 & m2)) & 0xfefefefeu) ? 2u : 0u;
+	}
+
+	uint32_t rc = TG_BURST_NONE, offs = 0, flags = 0, early = 0;
+	uint32_t ys = TG_YS_NONE;	/* where SYNC sequences start inside this slot, window or not */
+	bool found = false;
 #pragma unroll
 	for (int r = 0; r < 10; r++) {
-		const uint32_t o0 = c_tab.front_src[0][2 * r + half][bit];
-		const uint32_t o1 = c_tab.front_src[1][2 * r + half][bit];
-		const uint32_t o2 = c_tab.front_src[2][2 * r + half][bit];
-		a_n1[r] = wbase + (o0 == 0xffff ? TG_STREAM_VIEW : o0);
-		a_n2[r] = wbase + (o1 == 0xffff ? TG_STREAM_VIEW : o1);
-		a_sb[r] = wbase + (o2 == 0xffff ? TG_STREAM_VIEW : o2);
+		const bool full = (r < 4 || !found) && 64u * r < wv;
+		if (full || r < 8) {
+			const uint32_t c = 64 * r + lane;
+			const uint32_t b0 = (uint32_t)B[r], b1 = (uint32_t)(B[r] >> 32);
+			const uint32_t b2 = (uint32_t)B[r + 1], b3 = (uint32_t)(B[r + 1] >> 32);
+			const uint32_t w0 = half ? b1 : b0, w1 = half ? b2 : b1;
+			const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bit);
+			/* the last 6 bits of the 38-bit SYNC sequence are only looked at where its first 32 match
+			 * (wave-uniform branch: almost never taken outside a SYNC burst's round) */
+			bool y38 = (win == prm.y32);
+			if (__ballot(y38)) {
+				const uint32_t w2 = half ? b3 : b2;
+				const uint32_t win2 = __builtin_amdgcn_alignbit(w2, w1, bit);
+				y38 = y38 && ((win2 & 0x3f) == prm.y6);
+			}
+			if (r < 8) {
+				const unsigned long long my = __ballot(y38 && c < TG_SLOT_BITS && c + 38 <= vis);
+				if (my) {
+					if (ys == TG_YS_NONE)
+						ys = 64 * r + __builtin_ctzll(my);
+					else
+						ys |= TG_YS_MULTI;
+					if (my & (my - 1))
+						ys |= TG_YS_MULTI;
+				}
+			}
+			if (full) {
+				/* the window holds at least 510 bytes: rounds 0..6 (c + 38 <= 485) need no bound */
+				const bool in38 = (r < 7) || (c + 38 <= w), in22 = (r < 7) || (c + 22 <= w);
+				const bool isy = y38 && in38;
+				const bool isn = ((win & 0x3fffff) == prm.n22) && in22;
+				const bool isp = ((win & 0x3fffff) == prm.p22) && in22;
+				const bool any = isy || isn || isp;
+				if (r == 0)
+					early = __ballot(any && c < 21) != 0;
+				const unsigned long long m = __ballot(any && c >= 21);
+				if (!found && m) {
+					const uint32_t l0 = __builtin_ctzll(m);
+					offs = 64 * r + l0;
+					const uint32_t ty = isy ? TG_BURST_SYNC : isn ? TG_BURST_NORM_1 : TG_BURST_NORM_2;
+					rc = __builtin_amdgcn_readlane(ty, l0);
+					found = true;
+				}
+			}
+		}
 	}
+	if (early)
+		flags |= TG_CLS_EARLY21;
+	if (__ballot(anyb > 1))
+		flags |= TG_CLS_NONBINARY;
+	if (!found && w > TG_STREAM_VIEW)
+		flags |= TG_CLS_CLIPPED;
+
+	/* what tetra_burst_sync_in() would hand to tetra_burst_rx_cb() (phy/tetra_burst_sync.c:121-141) */
+	uint32_t dtype = TG_BURST_NONE;
+	if (rc == TG_BURST_SYNC && offs == TG_SYNC_TRAIN_OFF)
+		dtype = TG_BURST_SYNC;
+	else if ((rc == TG_BURST_NORM_1 || rc == TG_BURST_NORM_2) && offs == TG_NORM_TRAIN_OFF)
+		dtype = rc;
+
+	myword = 0;
+	if (dtype == TG_BURST_NORM_1)
+		myword = front_gather(lds0, a_n1);
+	else if (dtype == TG_BURST_NORM_2)
+		myword = front_gather(lds0, a_n2);
+	else if (dtype == TG_BURST_SYNC)
+		myword = front_gather(lds0, a_sb);
+	if (lane == TG_PW_META)
+		myword = dtype | (((flags & TG_CLS_NONBINARY) ? TG_FLAG_NONBINARY : 0u) << 8) | (offs << 16);
+	clsword = rc | (offs << 8) | (flags << 24);
+	ysword = ys;
+}
+
+#define STREAM_SLOT_TABLES(WIN)										\
+	constexpr int WINDW = (WIN);									\
+	__shared__ uint32_t s_slot[4][WINDW];								\
+	const uint32_t lane = threadIdx.x & 63;								\
+	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);				\
+	const uint32_t wave = blockIdx.x * 4 + wib;							\
+	const uint32_t nwaves = gridDim.x * 4;								\
+	const uint32_t half = lane >> 5, bit = lane & 31;						\
+	uint32_t *mine = s_slot[wib];									\
+	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];						\
+	const uint32_t wbase = wib * WINDW * 4;								\
+	if (lane < 4)											\
+		mine[TG_STREAM_VIEW / 4 + lane] = 0;	/* "no source" gathers read this */		\
+	uint32_t a_n1[10], a_n2[10], a_sb[10];								\
+	_Pragma("unroll")										\
+	for (int r = 0; r < 10; r++) {									\
+		const uint32_t o0 = c_tab.front_src[0][2 * r + half][bit];				\
+		const uint32_t o1 = c_tab.front_src[1][2 * r + half][bit];				\
+		const uint32_t o2 = c_tab.front_src[2][2 * r + half][bit];				\
+		a_n1[r] = wbase + (o0 == 0xffff ? TG_STREAM_VIEW : o0);					\
+		a_n2[r] = wbase + (o1 == 0xffff ? TG_STREAM_VIEW : o1);					\
+		a_sb[r] = wbase + (o2 == 0xffff ? TG_STREAM_VIEW : o2);					\
+	}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
+		       uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
+{
+	STREAM_SLOT_TABLES(TG_STREAM_VIEW / 4 + 4)	/* 160 data dwords + one zero pad row */
+	__shared__ uint32_t s_out[4][128];	/* per wave: four packed slots on their way out, then their cls / ysum words */
+	uint32_t *mo = s_out[wib];
 
 	/* groups of four neighbouring grid slots per wave; packed slots, classification words and SYNC summaries are
 	 * staged in LDS and written once per group (as k_front: per-slot stores cost more than the search saves) */
@@ -474,132 +612,12 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		T -= 4 * ngroups - prm.nslots;
 	for (uint32_t t = 0; t < T; t++) {
 		const uint32_t slot = 4u * (wave + (t >> 2) * nwaves) + (t & 3u);
-		const uint64_t bs = prm.anchor + (uint64_t)slot * TG_SLOT_BITS;
-		const uint8_t *base = stream + bs;
-		/* 640 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack).  (Requesting the
-		 * next slot before this one is searched was tried: 90 VGPRs instead of 64 cost three waves per SIMD,
-		 * 0.86 ms instead of 0.76 ms per 1 M slots.) */
-		const uint32_t d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
-		const uint32_t d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
-		const uint32_t d2 = (lane < 32) ? *(const tg_u32_unaligned *)(base + 512 + 4 * lane) : 0u;
-
-		uint64_t fed = bs + TG_SLOT_BITS + prm.chunk - 1;
-		fed = prm.cshift >= 0 ? (fed >> prm.cshift) << prm.cshift : (fed / prm.chunk) * prm.chunk;
-		if (fed > prm.len)
-			fed = prm.len;
-		const uint32_t w = (uint32_t)(fed - bs);			/* search window, >= 510 */
-		const uint32_t wv = w < TG_STREAM_VIEW ? w : TG_STREAM_VIEW;	/* what we can see of it */
-		const uint64_t rest = prm.len - bs;
-		const uint32_t vis = rest < TG_STREAM_VIEW ? (uint32_t)rest : TG_STREAM_VIEW;	/* stream bytes in view */
-
-		mine[lane] = d0;
-		mine[64 + lane] = d1;
-		if (lane < 32)
-			mine[128 + lane] = d2;
-
-		/* bytes -> 640-bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes past the stream end read as 0
-		 * (every test below bounds itself by the window, so bytes past the window need no masking) */
-		unsigned long long B[11];
-		if (vis == TG_STREAM_VIEW) {	/* everywhere but at the very end of the stream: no per-lane bound */
-#pragma unroll
-			for (int r = 0; r < 10; r++)
-				B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0);
-		} else {
-#pragma unroll
-			for (int r = 0; r < 10; r++)
-				B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0 && 64u * r + lane < vis);
-		}
-		B[10] = 0;
-		/* a byte other than 0 / 1 inside the search window: from the three dwords of the lane (byte k of dword q
-		 * is window byte 256 q + 4 lane + k), bytes at or past the window end masked off */
-		uint32_t anyb;
-		{
-			const uint32_t p0 = 4 * lane, p1 = 256 + 4 * lane, p2 = 512 + 4 * lane;
-			const uint32_t k0 = wv > p0 ? wv - p0 : 0, k1 = wv > p1 ? wv - p1 : 0, k2 = wv > p2 ? wv - p2 : 0;
-			const uint32_t m0 = k0 >= 4 ? 0xffffffffu : ((1u << (8 * k0)) - 1u);
-			const uint32_t m1 = k1 >= 4 ? 0xffffffffu : ((1u << (8 * k1)) - 1u);
-			const uint32_t m2 = k2 >= 4 ? 0xffffffffu : ((1u << (8 * k2)) - 1u);
-			anyb = (((d0 & m0) | (d1 & m1) | (d2 & m2)) & 0xfefefefeu) ? 2u : 0u;
-		}
-
-		uint32_t rc = TG_BURST_NONE, offs = 0, flags = 0, early = 0;
-		uint32_t ys = TG_YS_NONE;	/* where SYNC sequences start inside this slot, window or not */
-		bool found = false;
-#pragma unroll
-		for (int r = 0; r < 10; r++) {
-			const bool full = (r < 4 || !found) && 64u * r < wv;
-			if (full || r < 8) {
-				const uint32_t c = 64 * r + lane;
-				const uint32_t b0 = (uint32_t)B[r], b1 = (uint32_t)(B[r] >> 32);
-				const uint32_t b2 = (uint32_t)B[r + 1], b3 = (uint32_t)(B[r + 1] >> 32);
-				const uint32_t w0 = half ? b1 : b0, w1 = half ? b2 : b1;
-				const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bit);
-				/* the last 6 bits of the 38-bit SYNC sequence are only looked at where its first 32 match
-				 * (wave-uniform branch: almost never taken outside a SYNC burst's round) */
-				bool y38 = (win == prm.y32);
-				if (__ballot(y38)) {
-					const uint32_t w2 = half ? b3 : b2;
-					const uint32_t win2 = __builtin_amdgcn_alignbit(w2, w1, bit);
-					y38 = y38 && ((win2 & 0x3f) == prm.y6);
-				}
-				if (r < 8) {
-					const unsigned long long my = __ballot(y38 && c < TG_SLOT_BITS && c + 38 <= vis);
-					if (my) {
-						if (ys == TG_YS_NONE)
-							ys = 64 * r + __builtin_ctzll(my);
-						else
-							ys |= TG_YS_MULTI;
-						if (my & (my - 1))
-							ys |= TG_YS_MULTI;
-					}
-				}
-				if (full) {
-					/* the window holds at least 510 bytes: rounds 0..6 (c + 38 <= 485) need no bound */
-					const bool in38 = (r < 7) || (c + 38 <= w), in22 = (r < 7) || (c + 22 <= w);
-					const bool isy = y38 && in38;
-					const bool isn = ((win & 0x3fffff) == prm.n22) && in22;
-					const bool isp = ((win & 0x3fffff) == prm.p22) && in22;
-					const bool any = isy || isn || isp;
-					if (r == 0)
-						early = __ballot(any && c < 21) != 0;
-					const unsigned long long m = __ballot(any && c >= 21);
-					if (!found && m) {
-						const uint32_t l0 = __builtin_ctzll(m);
-						offs = 64 * r + l0;
-						const uint32_t ty = isy ? TG_BURST_SYNC : isn ? TG_BURST_NORM_1 : TG_BURST_NORM_2;
-						rc = __builtin_amdgcn_readlane(ty, l0);
-						found = true;
-					}
-				}
-			}
-		}
-		if (early)
-			flags |= TG_CLS_EARLY21;
-		if (__ballot(anyb > 1))
-			flags |= TG_CLS_NONBINARY;
-		if (!found && w > TG_STREAM_VIEW)
-			flags |= TG_CLS_CLIPPED;
-
-		/* what tetra_burst_sync_in() would hand to tetra_burst_rx_cb() (phy/tetra_burst_sync.c:121-141) */
-		uint32_t dtype = TG_BURST_NONE;
-		if (rc == TG_BURST_SYNC && offs == TG_SYNC_TRAIN_OFF)
-			dtype = TG_BURST_SYNC;
-		else if ((rc == TG_BURST_NORM_1 || rc == TG_BURST_NORM_2) && offs == TG_NORM_TRAIN_OFF)
-			dtype = rc;
-
-		uint32_t myword = 0;
-		if (dtype == TG_BURST_NORM_1)
-			myword = front_gather(lds0, a_n1);
-		else if (dtype == TG_BURST_NORM_2)
-			myword = front_gather(lds0, a_n2);
-		else if (dtype == TG_BURST_SYNC)
-			myword = front_gather(lds0, a_sb);
-		if (lane == TG_PW_META)
-			myword = dtype | (((flags & TG_CLS_NONBINARY) ? TG_FLAG_NONBINARY : 0u) << 8) | (offs << 16);
+		uint32_t myword, clsword, ys;
+		front_stream_slot(stream, prm, slot, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb, myword, clsword, ys);
 		if (lane < TG_PACKED_WORDS)
 			mo[(t & 3u) * TG_PACKED_WORDS + lane] = myword;
 		if (lane == 0) {
-			mo[80 + (t & 3u)] = rc | (offs << 8) | (flags << 24);
+			mo[80 + (t & 3u)] = clsword;
 			mo[84 + (t & 3u)] = ys;
 		}
 		if ((t & 3u) == 3u || t + 1 == T) {
@@ -614,6 +632,316 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	}
 }
 
+/* classification word of a slot the packed-bit kernel leaves to k_front_stream_fix (never a valid word: offsets stay below 640) */
+#define TG_CLS_DEFER 0xffffffffu
+
+/* second pass of the packed-bit front end: every slot marked TG_CLS_DEFER goes through the exact per-position
+ * search.  A wave scans 64 classification words at a time; marked slots are rare (damaged training sequences,
+ * the end of the stream). */
+__global__ __launch_bounds__(256)
+void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm,
+			uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
+{
+	STREAM_SLOT_TABLES(TG_STREAM_VIEW / 4 + 4)
+	const uint32_t nchunks = (prm.nslots + 63) >> 6;
+	for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
+		const uint32_t s = ch * 64 + lane;
+		unsigned long long m = __ballot(s < prm.nslots && cls[s] == TG_CLS_DEFER);
+		while (m) {
+			const uint32_t slot = ch * 64 + (uint32_t)__builtin_ctzll(m);
+			m &= m - 1;
+			uint32_t myword, clsword, ys;
+			front_stream_slot(stream, prm, slot, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb, myword, clsword, ys);
+			if (lane < TG_PACKED_WORDS)
+				packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
+			if (lane == 0) {
+				cls[slot] = clsword;
+				if (ysum)
+					ysum[slot] = (uint16_t)ys;
+			}
+		}
+	}
+}
+
+/*
+ * k_front_stream: the stream front end on packed bits.
+ *
+ * The grid slots of a stream are contiguous, so a wave takes GROUPS of four neighbouring slots = 2040 contiguous
+ * stream bytes (+ look-ahead), fetched as 16 bytes per lane from a 16-byte aligned base -- the access pattern that
+ * reaches the HBM read rate -- and turned into bits at once: two chained v_dot4_u32_u8 (weights 1,2,4,8 / 16..128)
+ * make 8 bits of 8 bytes.  The group's 2176-bit string is parked in LDS (272 bytes); everything after works on bits:
+ *   - lane (k, i) = (slot of the group, 32-position column) re-aligns its slot: W0..W2 = bits 32 i .. 32 i + 95 of
+ *     slot k (two LDS reads, three v_alignbit_b32); W0 also goes back to LDS as the slot-aligned 512-bit window the
+ *     gather reads;
+ *   - training-sequence search, bit-parallel: t_j = the slot's bit string shifted down by j (one v_alignbit_b32),
+ *     match mask of a sequence = AND of t_j over its 1-bits AND NOT (OR of t_j over its 0-bits); y (38 bits), n
+ *     and p (22 bits) share the t_j: ~100 vector instructions give the exact match masks of all three sequences at
+ *     all 4 x 512 positions (the per-position form needs ~8 per 64 positions and pattern);
+ *   - ballots of the (masked) match words + s_ff1 / v_readlane give, per slot, tetra_find_train_seq()'s answer
+ *     restricted to positions 21..472 (every window holds the slot's own 510 bytes, so a match that ends inside the
+ *     slot is valid whatever the window), the "hit below 21" flag and the SYNC summary of the slot;
+ *   - the de-interleaving gather reads single bytes of the 64-byte window (16 dwords in 16 banks: conflict-free,
+ *     the byte form had 2-3 way conflicts), isolates its bit with a per-lane mask and ballots as before.
+ * Anything this cannot settle exactly -- nothing found up to position 472, a byte other than 0 / 1 in the group, the
+ * last groups of the stream -- is marked TG_CLS_DEFER and redone by k_front_stream_fix with the per-position form.
+ */
+static constexpr uint8_t TSQ_N[22] = { 1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0 };
+static constexpr uint8_t TSQ_P[22] = { 0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0 };
+static constexpr uint8_t TSQ_Y[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
+
+template <int N> static constexpr uint64_t tsq_bits(const uint8_t (&seq)[N])
+{
+	uint64_t v = 0;
+	for (int i = 0; i < N; i++)
+		v |= (uint64_t)seq[i] << i;
+	return v;
+}
+
+#define TG_GROUP_SLOTS   4
+#define TG_GROUP_BYTES   (TG_GROUP_SLOTS * TG_SLOT_BITS)	/* 2040 */
+#define TG_GROUP_LOAD    2176					/* bytes fetched per group: 2 x 1024 + 128 */
+#define TG_FAST_LAST_POS (TG_SLOT_BITS - 38)			/* 472: a 38-bit match starting here still ends inside the slot */
+
+__device__ __forceinline__ uint32_t bytes16_to_bits(const uint4 &x)
+{
+	const uint32_t lo = __builtin_amdgcn_udot4(x.y, 0x80402010u, __builtin_amdgcn_udot4(x.x, 0x08040201u, 0u, false), false);
+	const uint32_t hi = __builtin_amdgcn_udot4(x.w, 0x80402010u, __builtin_amdgcn_udot4(x.z, 0x08040201u, 0u, false), false);
+	return lo | (hi << 8);
+}
+
+/* gather of one slot from its 64-byte bit window: byte reads at the lane's addresses (+ the slot's window offset as
+ * the instruction's immediate), the lane's bit isolated by its mask (four masks to a dword: SDWA picks the byte; all
+ * ten ANDs are issued before the first compare, an SDWA result wants a wait state before it is read), ballots and
+ * writelanes as front_gather */
+template <int KOFF>
+__device__ __forceinline__ uint32_t front_gather_bits(const uint8_t *lds0, const uint32_t (&addr)[10], const uint32_t (&msk)[3])
+{
+	uint32_t myword = 0;
+	uint32_t bytes[10], t[10];
+#pragma unroll
+	for (int r = 0; r < 10; r++)
+		bytes[r] = lds0[addr[r] + KOFF];
+#pragma unroll
+	for (int r = 0; r < 10; r++) {
+		switch (r & 3) {
+		case 0: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(t[r]) : "v"(bytes[r]), "v"(msk[r >> 2])); break;
+		case 1: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(t[r]) : "v"(bytes[r]), "v"(msk[r >> 2])); break;
+		case 2: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(t[r]) : "v"(bytes[r]), "v"(msk[r >> 2])); break;
+		default: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(t[r]) : "v"(bytes[r]), "v"(msk[r >> 2])); break;
+		}
+	}
+	unsigned long long bal[10];
+#pragma unroll
+	for (int r = 0; r < 10; r++)
+		bal[r] = __ballot(t[r] != 0);
+	asm("s_nop 4\n\t"
+	    "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+	    "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
+	    "v_writelane_b32 %0, %9, 8\n\tv_writelane_b32 %0, %10, 9\n\tv_writelane_b32 %0, %11, 10\n\tv_writelane_b32 %0, %12, 11\n\t"
+	    "v_writelane_b32 %0, %13, 12\n\tv_writelane_b32 %0, %14, 13\n\tv_writelane_b32 %0, %15, 14\n\tv_writelane_b32 %0, %16, 15\n\t"
+	    "v_writelane_b32 %0, %17, 16\n\tv_writelane_b32 %0, %18, 17\n\tv_writelane_b32 %0, %19, 18\n\tv_writelane_b32 %0, %20, 19"
+	    : "+v"(myword)
+	    : "s"((uint32_t)bal[0]), "s"((uint32_t)(bal[0] >> 32)), "s"((uint32_t)bal[1]), "s"((uint32_t)(bal[1] >> 32)),
+	      "s"((uint32_t)bal[2]), "s"((uint32_t)(bal[2] >> 32)), "s"((uint32_t)bal[3]), "s"((uint32_t)(bal[3] >> 32)),
+	      "s"((uint32_t)bal[4]), "s"((uint32_t)(bal[4] >> 32)), "s"((uint32_t)bal[5]), "s"((uint32_t)(bal[5] >> 32)),
+	      "s"((uint32_t)bal[6]), "s"((uint32_t)(bal[6] >> 32)), "s"((uint32_t)bal[7]), "s"((uint32_t)(bal[7] >> 32)),
+	      "s"((uint32_t)bal[8]), "s"((uint32_t)(bal[8] >> 32)), "s"((uint32_t)bal[9]), "s"((uint32_t)(bal[9] >> 32)));
+	return myword;
+}
+
+struct tg_group_data {
+	uint4 a, b, c;	/* bytes 16 l .., 1024 + 16 l .., 2048 + 16 min(l, 7) .. of the group's aligned range */
+	uint32_t a0;	/* the group starts a0 bytes into that range */
+	bool fast;	/* all four windows of the group lie inside the stream */
+};
+
+#ifndef TG_STREAM_WPE
+#define TG_STREAM_WPE 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TG_STREAM_WPE, TG_STREAM_WPE)))
+void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
+		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
+{
+	constexpr uint64_t PY = tsq_bits(TSQ_Y), PN = tsq_bits(TSQ_N), PP = tsq_bits(TSQ_P);
+	__shared__ uint32_t s_bits[4][72];	/* per wave: the group's bit string (68 dwords used) */
+	__shared__ uint32_t s_win[4][64];	/* per wave: four slot-aligned 512-bit windows */
+	__shared__ uint32_t s_out[4][128];	/* per wave: four packed slots on their way out, then their cls / ysum words */
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t wave = blockIdx.x * 4 + wib;
+	const uint32_t nwaves = gridDim.x * 4;
+	const uint32_t half = lane >> 5, bit = lane & 31;
+	const uint32_t col = lane & 15;			/* 32-position column of the lane's slot */
+	uint32_t *bits = s_bits[wib];
+	uint32_t *win = s_win[wib];
+	uint32_t *mo = s_out[wib];
+	const uint8_t *lds0 = (const uint8_t *)&s_win[0][0];
+
+	/* gather tables: byte of the window and bit inside it, per round and burst type */
+	uint32_t g_adr[3][10], g_msk[3][3];
+#pragma unroll
+	for (int x = 0; x < 3; x++) {
+		g_msk[x][0] = g_msk[x][1] = g_msk[x][2] = 0;
+#pragma unroll
+		for (int r = 0; r < 10; r++) {
+			const uint32_t o = c_tab.front_src[x][2 * r + half][bit];
+			const bool none = (o == 0xffff);
+			g_adr[x][r] = wib * 256 + (none ? 0u : (o >> 3));
+			asm volatile("" : "+v"(g_adr[x][r]));	/* the whole address in the register: the slot's offset is the immediate */
+			g_msk[x][r >> 2] |= (none ? 0u : (1u << (o & 7))) << (8 * (r & 3));
+		}
+	}
+	/* which positions of the lane's column count: main search 21..472, "early" 0..20, SYNC summary 0..509 */
+	const uint32_t vmain = (col == 0) ? 0xffe00000u : (col == 14) ? 0x01ffffffu : (col == 15) ? 0u : 0xffffffffu;
+	const uint32_t vearly = (col == 0) ? 0x001fffffu : 0u;
+	const uint32_t vys = (col == 15) ? 0x3fffffffu : 0xffffffffu;
+	const uint32_t pos0 = (lane >> 4) * TG_SLOT_BITS + 32 * col;	/* first bit of the column inside the group */
+
+	const uint32_t ngroups = (prm.nslots + 3) >> 2;
+	if (wave >= ngroups)
+		return;
+
+	/* request a group: 16 bytes per lane from the 16-byte aligned address below the group's first byte.  Groups the
+	 * fast path may not touch (their windows or the exact form's 640-byte views reach past the stream) fetch group 0
+	 * instead, so that every step issues the same loads */
+	auto fetch = [&](uint32_t g, tg_group_data &d) {
+		const uint64_t gb = prm.anchor + (uint64_t)g * TG_GROUP_BYTES;
+		d.fast = gb + TG_GROUP_BYTES + TG_STREAM_VIEW <= prm.len;
+		const uint8_t *p = stream + (d.fast ? gb : prm.anchor);
+		d.a0 = (uint32_t)((uintptr_t)p & 15);
+		const uint8_t *base16 = p - d.a0;
+		d.a = *(const uint4 *)(base16 + 16 * lane);
+		d.b = *(const uint4 *)(base16 + 1024 + 16 * lane);
+		d.c = *(const uint4 *)(base16 + 2048 + 16 * (lane < 7 ? lane : 7));
+	};
+
+	auto work = [&](uint32_t g, const tg_group_data &cur) {
+		/* bytes other than 0 / 1 anywhere in the group: not for this kernel */
+		const uint32_t orall = cur.a.x | cur.a.y | cur.a.z | cur.a.w | cur.b.x | cur.b.y | cur.b.z | cur.b.w |
+				       cur.c.x | cur.c.y | cur.c.z | cur.c.w;
+		const bool defer_all = !cur.fast || __ballot((orall & 0xfefefefeu) != 0) != 0;
+
+		/* bytes -> bits -> LDS */
+		{
+			tg_u16_alias *b16 = (tg_u16_alias *)bits;
+			b16[lane] = (uint16_t)bytes16_to_bits(cur.a);
+			b16[64 + lane] = (uint16_t)bytes16_to_bits(cur.b);
+			if (lane < 8)
+				b16[128 + lane] = (uint16_t)bytes16_to_bits(cur.c);
+		}
+		/* the lane's column of its slot: 96 bits from position pos0 + a0 of the string */
+		uint32_t W0, W1, W2;
+		{
+			const uint32_t p = pos0 + cur.a0;
+			const uint32_t *q = bits + (p >> 5);
+			const uint32_t D0 = q[0], D1 = q[1], D2 = q[2], D3 = q[3];
+			W0 = __builtin_amdgcn_alignbit(D1, D0, p);
+			W1 = __builtin_amdgcn_alignbit(D2, D1, p);
+			W2 = __builtin_amdgcn_alignbit(D3, D2, p);
+		}
+		win[lane] = W0;
+
+		/* match masks of the three sequences at the column's 32 positions */
+		uint32_t gy = 0xffffffffu, hy = 0, gnn = 0xffffffffu, hn = 0, gp = 0xffffffffu, hp = 0;
+#pragma unroll
+		for (int j = 0; j < 38; j++) {
+			const uint32_t t = (j == 0) ? W0 : (j < 32) ? __builtin_amdgcn_alignbit(W1, W0, j)
+					 : (j == 32) ? W1 : __builtin_amdgcn_alignbit(W2, W1, j - 32);
+			if ((PY >> j) & 1) gy &= t; else hy |= t;
+			if (j < 22) {
+				if ((PN >> j) & 1) gnn &= t; else hn |= t;
+				if ((PP >> j) & 1) gp &= t; else hp |= t;
+			}
+		}
+		const uint32_t my = gy & ~hy & vys, mn = gnn & ~hn, mp = gp & ~hp;
+		const uint32_t any = my | mn | mp;
+		const unsigned long long A = __ballot((any & vmain) != 0);
+		const unsigned long long E = __ballot((any & vearly) != 0);
+		const unsigned long long Y = __ballot(my != 0);
+
+		/* per slot: first column with a hit -> its match words (LDS crossbar) -> first position, which sequence;
+		 * lanes 0..3 do this for slots 0..3 of the group (the others compute along) */
+		const uint32_t sl = lane & 3;
+		const uint32_t a = (uint32_t)(A >> (16 * sl)) & 0xffffu;
+		const uint32_t i0 = __builtin_ctz(a | 0x10000u);
+		const uint32_t src = 4 * (16 * sl + (i0 & 15));
+		const uint32_t vm = (i0 == 0) ? 0xffe00000u : (i0 == 14) ? 0x01ffffffu : 0xffffffffu;
+		const uint32_t sy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)my) & vm;
+		const uint32_t sn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)mn) & vm;
+		const uint32_t sp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)mp) & vm;
+		const uint32_t b = __builtin_ctz(sy | sn | sp | 0x80000000u);
+		const uint32_t offs = 32 * i0 + b;
+		const uint32_t rc = ((sy >> b) & 1) ? TG_BURST_SYNC : ((sn >> b) & 1) ? TG_BURST_NORM_1 : TG_BURST_NORM_2;
+		const uint32_t early = (uint32_t)(E >> (16 * sl)) & 1u;
+		const uint32_t yb = (uint32_t)(Y >> (16 * sl)) & 0xffffu;
+		const uint32_t j0 = __builtin_ctz(yb | 0x10000u);
+		const uint32_t yv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * (16 * sl + (j0 & 15))), (int)my);
+		uint32_t ys = 32 * j0 + __builtin_ctz(yv | 0x80000000u);
+		if ((yb & (yb - 1)) | (yv & (yv - 1)))
+			ys |= TG_YS_MULTI;
+		if (!yb)
+			ys = TG_YS_NONE;
+		const bool defer = defer_all || a == 0;
+		uint32_t dtype = TG_BURST_NONE;
+		if (rc == TG_BURST_SYNC ? offs == TG_SYNC_TRAIN_OFF : offs == TG_NORM_TRAIN_OFF)
+			dtype = rc;
+		if (defer)
+			dtype = TG_BURST_NONE;
+		const uint32_t clsword = defer ? TG_CLS_DEFER : (rc | (offs << 8) | (early ? (uint32_t)TG_CLS_EARLY21 << 24 : 0u));
+		const uint32_t meta = defer ? 0u : (dtype | (offs << 16));
+
+		const uint32_t first = 4u * g;
+		const uint32_t cnt = (prm.nslots - first < 4u) ? prm.nslots - first : 4u;
+#define STREAM_SLOT_K(K)												\
+		{													\
+			const uint32_t dt = __builtin_amdgcn_readlane(dtype, (K));					\
+			uint32_t myword = 0;										\
+			if (dt == TG_BURST_NORM_1)									\
+				myword = front_gather_bits<64 * (K)>(lds0, g_adr[0], g_msk[0]);				\
+			else if (dt == TG_BURST_NORM_2)									\
+				myword = front_gather_bits<64 * (K)>(lds0, g_adr[1], g_msk[1]);				\
+			else if (dt == TG_BURST_SYNC)									\
+				myword = front_gather_bits<64 * (K)>(lds0, g_adr[2], g_msk[2]);				\
+			if (lane < TG_PACKED_WORDS)									\
+				mo[(K) * TG_PACKED_WORDS + lane] = myword;						\
+		}
+		STREAM_SLOT_K(0)
+		STREAM_SLOT_K(1)
+		STREAM_SLOT_K(2)
+		STREAM_SLOT_K(3)
+#undef STREAM_SLOT_K
+		if (lane < 4) {
+			mo[lane * TG_PACKED_WORDS + TG_PW_META] = meta;
+			mo[80 + lane] = clsword;
+			mo[84 + lane] = ys;
+		}
+		front_flush(mo, lane, first, cnt, packed);
+		if (lane < cnt) {
+			cls[first + lane] = mo[80 + lane];
+			if (ysum)
+				ysum[first + lane] = (uint16_t)mo[84 + lane];
+		}
+	};
+
+	/* two register sets with fixed roles: the next group is requested before this one is worked on, no copies */
+	tg_group_data dA, dB;
+	uint32_t g = wave;
+	fetch(g, dA);
+	for (;;) {
+		const uint32_t gB = g + nwaves;
+		fetch(gB < ngroups ? gB : g, dB);
+		work(g, dA);
+		if (gB >= ngroups)
+			break;
+		const uint32_t gA = gB + nwaves;
+		fetch(gA < ngroups ? gA : gB, dA);
+		work(gB, dB);
+		if (gA >= ngroups)
+			break;
+		g = gA;
+	}
+}
 
 /* ------------------------------------------------------------------------- */
 /* soft input (BASELINE config 5): float phases -> bits / soft values, soft gather  */
@@ -1433,14 +1761,27 @@ void k_conv(const uint8_t *__restrict__ type3, unsigned long long nblocks, uint3
 /* ------------------------------------------------------------------------- */
 #define FILL_BLOCK 1024
 
+/*
+ * A decoded SYNC slot brings its own mask-table entry only when its code is news: the k-th SYNC slot of the batch is
+ * "redundant" when the one before it (same channel) decoded to the same code -- the running maximum then keeps the
+ * earlier entry, k_masks never computes this one, and all the slots of a cell share one 160-byte entry (a 1 M-slot
+ * recording used to build and read 125 k identical ones).
+ */
+__device__ __forceinline__ bool sb_redundant(uint32_t k, const uint32_t *sb_ok, const uint32_t *sb_code,
+					     const uint32_t *list_sb, const uint32_t *slot_chan)
+{
+	return k > 0 && sb_ok[k - 1] && sb_code[k] == sb_code[k - 1] && slot_chan[list_sb[k]] == slot_chan[list_sb[k - 1]];
+}
+
 __device__ __forceinline__ unsigned long long fill_key(uint32_t i, const uint32_t *slot_chan, const int32_t *slot_sbord,
-						       const uint32_t *sb_ok, uint32_t nchan)
+						       const uint32_t *sb_ok, const uint32_t *sb_code, const uint32_t *list_sb,
+						       uint32_t nchan)
 {
 	const uint32_t ch = slot_chan[i];
 	const int32_t k = slot_sbord[i];
 	/* entry ids: 0 = zero mask, 1+ch = channel carry-in, 1+nchan+k = k-th SYNC slot of the batch */
 	uint32_t e = 1 + ch;
-	if (k >= 0 && sb_ok[k])
+	if (k >= 0 && sb_ok[k] && !sb_redundant((uint32_t)k, sb_ok, sb_code, list_sb, slot_chan))
 		e = 1 + nchan + (uint32_t)k;
 	return ((unsigned long long)ch << 32) | e;
 }
@@ -1458,12 +1799,12 @@ __device__ __forceinline__ unsigned long long wave_incl_max(unsigned long long v
 
 /* phase 1: per-block maximum */
 __global__ __launch_bounds__(FILL_BLOCK)
-void k_fill_reduce(const uint32_t *slot_chan, const int32_t *slot_sbord, const uint32_t *sb_ok,
-		   uint32_t nchan, uint32_t nslots, unsigned long long *block_max)
+void k_fill_reduce(const uint32_t *slot_chan, const int32_t *slot_sbord, const uint32_t *sb_ok, const uint32_t *sb_code,
+		   const uint32_t *list_sb, uint32_t nchan, uint32_t nslots, unsigned long long *block_max)
 {
 	__shared__ unsigned long long sm[FILL_BLOCK / 64];
 	const uint32_t i = blockIdx.x * FILL_BLOCK + threadIdx.x;
-	unsigned long long v = (i < nslots) ? fill_key(i, slot_chan, slot_sbord, sb_ok, nchan) : 0ull;
+	unsigned long long v = (i < nslots) ? fill_key(i, slot_chan, slot_sbord, sb_ok, sb_code, list_sb, nchan) : 0ull;
 	const uint32_t lane = threadIdx.x & 63;
 	v = wave_incl_max(v, lane);
 	if (lane == 63)
@@ -1477,38 +1818,47 @@ void k_fill_reduce(const uint32_t *slot_chan, const int32_t *slot_sbord, const u
 	}
 }
 
-/* phase 2: exclusive running max over the block maxima (single workgroup, serial chunks) */
-__global__ __launch_bounds__(64)
+/* phase 2: exclusive running max over the block maxima (one workgroup, 1024 maxima per pass) */
+__global__ __launch_bounds__(FILL_BLOCK)
 void k_fill_scan(unsigned long long *block_max, uint32_t nblocks)
 {
-	const uint32_t lane = threadIdx.x;
+	__shared__ unsigned long long sm[FILL_BLOCK / 64];
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	unsigned long long carry = 0;
-	for (uint32_t base = 0; base < nblocks; base += 64) {
-		const uint32_t i = base + lane;
-		unsigned long long v = (i < nblocks) ? block_max[i] : 0ull;
-		unsigned long long inc = wave_incl_max(v, lane);
+	for (uint32_t base = 0; base < nblocks; base += FILL_BLOCK) {
+		const uint32_t i = base + threadIdx.x;
+		const unsigned long long v = (i < nblocks) ? block_max[i] : 0ull;
+		const unsigned long long inc = wave_incl_max(v, lane);
+		if (lane == 63)
+			sm[w] = inc;
+		__syncthreads();
+		unsigned long long pre = carry, tot = carry;
+		for (uint32_t q = 0; q < FILL_BLOCK / 64; q++) {
+			if (q < w)
+				pre = sm[q] > pre ? sm[q] : pre;
+			tot = sm[q] > tot ? sm[q] : tot;
+		}
 		unsigned long long exc = __shfl_up(inc, 1);
 		if (lane == 0)
 			exc = 0;
-		if (carry > exc)
-			exc = carry;
+		if (pre > exc)
+			exc = pre;
 		if (i < nblocks)
 			block_max[i] = exc;
-		const unsigned long long tot = __shfl(inc, 63);
-		if (tot > carry)
-			carry = tot;
+		carry = tot;
+		__syncthreads();
 	}
 }
 
 /* phase 3: in-block scan with carry-in, write the mask entry of every slot */
 __global__ __launch_bounds__(FILL_BLOCK)
-void k_fill_apply(const uint32_t *slot_chan, const int32_t *slot_sbord, const uint32_t *sb_ok,
-		  uint32_t nchan, uint32_t nslots, const unsigned long long *block_excl, uint32_t *maskidx)
+void k_fill_apply(const uint32_t *slot_chan, const int32_t *slot_sbord, const uint32_t *sb_ok, const uint32_t *sb_code,
+		  const uint32_t *list_sb, uint32_t nchan, uint32_t nslots, const unsigned long long *block_excl, uint32_t *maskidx)
 {
 	__shared__ unsigned long long sm[FILL_BLOCK / 64];
 	const uint32_t i = blockIdx.x * FILL_BLOCK + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	unsigned long long v = (i < nslots) ? fill_key(i, slot_chan, slot_sbord, sb_ok, nchan) : 0ull;
+	unsigned long long v = (i < nslots) ? fill_key(i, slot_chan, slot_sbord, sb_ok, sb_code, list_sb, nchan) : 0ull;
 	v = wave_incl_max(v, lane);
 	if (lane == 63)
 		sm[w] = v;
@@ -1527,10 +1877,12 @@ void k_fill_apply(const uint32_t *slot_chan, const int32_t *slot_sbord, const ui
 /* ------------------------------------------------------------------------- */
 __global__ __launch_bounds__(256)
 void k_masks(const uint32_t *chan_code, uint32_t nchan, const uint32_t *sb_ok, const uint32_t *sb_code,
-	     uint32_t nsb, uint32_t *masks)
+	     uint32_t nsb, const uint32_t *list_sb, const uint32_t *slot_chan, uint32_t *masks)
 {
-	/* a wavefront keeps the linear-form masks of its 18 x 64 output bits in registers and walks
-	 * entries wave, wave + nwaves, ...: per entry 18 x (and, popcount, ballot) and one 160-byte store */
+	/* a wavefront keeps the linear-form masks of its 18 x 64 output bits in registers, looks at 64 entries at a
+	 * time and builds the ones a slot can point at: entry 0, the channel carry-ins, and the SYNC slots that decoded
+	 * (CRC) to a code other than their predecessor's (sb_redundant) -- per built entry 18 x (and, popcount, ballot)
+	 * and one 160-byte store */
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1542,25 +1894,34 @@ void k_masks(const uint32_t *chan_code, uint32_t nchan, const uint32_t *sb_ok, c
 		const uint16_t pos = c_tab.mask_pos[2 * r + half][bit];
 		lin[r] = (pos != 0xffff) ? c_tab.lfsr_lin[pos] : 0u;
 	}
-	for (uint32_t e = wave; e < nent; e += nwaves) {
-		uint32_t code = 0;
+	for (uint32_t e0 = wave * 64; e0 < nent; e0 += nwaves * 64) {
+		const uint32_t e = e0 + lane;
+		uint32_t mycode = 0;
+		bool need = e < nent;
 		if (e >= 1 && e <= nchan)
-			code = chan_code[e - 1];
-		else if (e > nchan) {
+			mycode = chan_code[e - 1];
+		else if (e > nchan && e < nent) {
 			const uint32_t k = e - 1 - nchan;
-			code = sb_ok[k] ? sb_code[k] : 0;
+			need = sb_ok[k] && !sb_redundant(k, sb_ok, sb_code, list_sb, slot_chan);
+			mycode = sb_code[k];
 		}
-		uint32_t myword = 0;
+		unsigned long long todo = __ballot(need);
+		while (todo) {
+			const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+			todo &= todo - 1;
+			const uint32_t code = __builtin_amdgcn_readlane(mycode, l);
+			uint32_t myword = 0;
 #pragma unroll
-		for (int r = 0; r < TG_MW_ROUNDS; r++) {
-			const unsigned long long bal = __ballot(__popc(code & lin[r]) & 1);
-			myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
-			myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
+			for (int r = 0; r < TG_MW_ROUNDS; r++) {
+				const unsigned long long bal = __ballot(__popc(code & lin[r]) & 1);
+				myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
+				myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
+			}
+			if (lane == TG_MW_CODE)
+				myword = code;
+			if (lane < TG_MASK_WORDS)
+				masks[(size_t)(e0 + l) * TG_MASK_WORDS + lane] = myword;
 		}
-		if (lane == TG_MW_CODE)
-			myword = code;
-		if (lane < TG_MASK_WORDS)
-			masks[(size_t)e * TG_MASK_WORDS + lane] = myword;
 	}
 }
 
@@ -1824,10 +2185,27 @@ extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64
 	prm.y6 = host_pattern_bits(tsq_y, 32, 6);
 	prm.n22 = host_pattern_bits(tsq_n, 0, 22);
 	prm.p22 = host_pattern_bits(tsq_p, 0, 22);
-	uint32_t blocks = (nslots + 3) / 4;
-	if (blocks > 256 * 8)
-		blocks = 256 * 8;
-	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_stream, prm, d_packed, d_cls, d_ysum);
+	const char *ev = getenv("TGPU_STREAM_V1");	/* =1: the per-position kernel on every slot (A/B runs) */
+	const int v1 = ev ? atoi(ev) : 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (v1 || nslots < 16) {	/* (a handful of slots: the packed-bit kernel's group fetch wants 2176 readable bytes) */
+		uint32_t blocks = (nslots + 3) / 4;
+		if (blocks > 256 * 8)
+			blocks = 256 * 8;
+		hipLaunchKernelGGL(k_front_stream_v1, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum);
+		return (int)hipGetLastError();
+	}
+	uint32_t blocks = ((nslots + 3) / 4 + 3) / 4;	/* a wave per group of four slots */
+	uint32_t cap = 256 * 8;
+	if (const char *e = getenv("TGPU_FRONT_BLOCKS"))
+		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
+	if (blocks > cap)
+		blocks = cap;
+	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum);
+	uint32_t fblocks = ((nslots + 63) / 64 + 3) / 4;	/* a wave per 64 classification words */
+	if (fblocks > 256 * 32)
+		fblocks = 256 * 32;
+	hipLaunchKernelGGL(k_front_stream_fix, dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum);
 	return (int)hipGetLastError();
 }
 
@@ -1938,16 +2316,19 @@ extern "C" int tgk_conv(int code, int g3, const uint8_t *d_type3, unsigned long 
 	return (int)hipGetLastError();
 }
 
-extern "C" int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uint32_t *d_sb_ok,
-			uint32_t nchan, uint32_t nslots, unsigned long long *d_block_tmp, uint32_t *d_maskidx, void *stream)
+extern "C" int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uint32_t *d_sb_ok, const uint32_t *d_sb_code,
+			const uint32_t *d_list_sb, uint32_t nchan, uint32_t nslots, unsigned long long *d_block_tmp,
+			uint32_t *d_maskidx, void *stream)
 {
 	if (!nslots)
 		return 0;
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t nblocks = (nslots + FILL_BLOCK - 1) / FILL_BLOCK;
-	hipLaunchKernelGGL(k_fill_reduce, dim3(nblocks), dim3(FILL_BLOCK), 0, s, d_slot_chan, d_slot_sbord, d_sb_ok, nchan, nslots, d_block_tmp);
-	hipLaunchKernelGGL(k_fill_scan, dim3(1), dim3(64), 0, s, d_block_tmp, nblocks);
-	hipLaunchKernelGGL(k_fill_apply, dim3(nblocks), dim3(FILL_BLOCK), 0, s, d_slot_chan, d_slot_sbord, d_sb_ok, nchan, nslots, d_block_tmp, d_maskidx);
+	hipLaunchKernelGGL(k_fill_reduce, dim3(nblocks), dim3(FILL_BLOCK), 0, s, d_slot_chan, d_slot_sbord, d_sb_ok, d_sb_code, d_list_sb,
+			   nchan, nslots, d_block_tmp);
+	hipLaunchKernelGGL(k_fill_scan, dim3(1), dim3(FILL_BLOCK), 0, s, d_block_tmp, nblocks);
+	hipLaunchKernelGGL(k_fill_apply, dim3(nblocks), dim3(FILL_BLOCK), 0, s, d_slot_chan, d_slot_sbord, d_sb_ok, d_sb_code, d_list_sb,
+			   nchan, nslots, d_block_tmp, d_maskidx);
 	return (int)hipGetLastError();
 }
 
@@ -1993,29 +2374,46 @@ void k_grid_count(const uint32_t *__restrict__ cls, const uint32_t *__restrict__
 	}
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(GRID_BLOCK)
 void k_grid_scan(uint32_t *blk, uint32_t nblocks)
 {
-	const uint32_t lane = threadIdx.x;
-	for (int c = 0; c < 3; c++) {
-		uint32_t carry = 0;
-		for (uint32_t base = 0; base < nblocks; base += 64) {
-			const uint32_t i = base + lane;
-			const uint32_t v = (i < nblocks) ? blk[3 * i + c] : 0u;
-			uint32_t inc = v;
+	/* exclusive prefix sums of the three per-block counts, 1024 blocks per pass, totals behind the last block */
+	__shared__ uint32_t sm[GRID_BLOCK / 64][3];
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	uint32_t carry[3] = { 0, 0, 0 };
+	for (uint32_t base = 0; base < nblocks; base += GRID_BLOCK) {
+		const uint32_t i = base + threadIdx.x;
+		uint32_t v[3], inc[3];
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			v[c] = (i < nblocks) ? blk[3 * i + c] : 0u;
+			inc[c] = v[c];
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t o = __shfl_up(inc, d);
+				const uint32_t o = __shfl_up(inc[c], d);
 				if (lane >= (uint32_t)d)
-					inc += o;
+					inc[c] += o;
+			}
+			if (lane == 63)
+				sm[w][c] = inc[c];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			uint32_t pre = carry[c], tot = carry[c];
+			for (uint32_t q = 0; q < GRID_BLOCK / 64; q++) {
+				if (q < w)
+					pre += sm[q][c];
+				tot += sm[q][c];
 			}
 			if (i < nblocks)
-				blk[3 * i + c] = carry + inc - v;
-			carry += __shfl(inc, 63);
+				blk[3 * i + c] = pre + inc[c] - v[c];
+			carry[c] = tot;
 		}
-		if (lane == 0)
-			blk[3 * nblocks + c] = carry;
+		__syncthreads();
 	}
+	if (threadIdx.x < 3)
+		blk[3 * nblocks + threadIdx.x] = carry[threadIdx.x];
 }
 
 __global__ __launch_bounds__(GRID_BLOCK)
@@ -2068,19 +2466,21 @@ extern "C" int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uin
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t nblocks = (n + GRID_BLOCK - 1) / GRID_BLOCK;
 	hipLaunchKernelGGL(k_grid_count, dim3(nblocks), dim3(GRID_BLOCK), 0, s, d_cls, d_bits, n, d_blk);
-	hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(64), 0, s, d_blk, nblocks);
+	hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(GRID_BLOCK), 0, s, d_blk, nblocks);
 	hipLaunchKernelGGL(k_grid_emit, dim3(nblocks), dim3(GRID_BLOCK), 0, s, d_cls, d_bits, n, d_blk, d_slot_chan, d_slot_sbord,
 			   d_list_sb, d_list_216, d_list_432);
 	return (int)hipGetLastError();
 }
 
 extern "C" int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
-			 const uint32_t *d_sb_code, uint32_t nsb, uint32_t *d_masks, void *stream)
+			 const uint32_t *d_sb_code, uint32_t nsb, const uint32_t *d_list_sb, const uint32_t *d_slot_chan,
+			 uint32_t *d_masks, void *stream)
 {
 	const uint32_t nent = 1 + nchan + nsb;
-	uint32_t blocks = (nent + 3) / 4;
+	uint32_t blocks = ((nent + 63) / 64 + 3) / 4;	/* a wave per 64 entries */
 	if (blocks > 2048)
 		blocks = 2048;
-	hipLaunchKernelGGL(k_masks, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_chan_code, nchan, d_sb_ok, d_sb_code, nsb, d_masks);
+	hipLaunchKernelGGL(k_masks, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_chan_code, nchan, d_sb_ok, d_sb_code, nsb,
+			   d_list_sb, d_slot_chan, d_masks);
 	return (int)hipGetLastError();
 }

@@ -122,10 +122,12 @@ static int deliver_slot(struct walk *w, uint64_t off, int type, uint32_t seq, ui
 	return 0;
 }
 
+static const uint8_t tsq_y38[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
+
 /* first start position of the SYNC training sequence in [from, last] by looking at the bytes */
 static uint64_t scan_sync_seq(const struct walk *w, uint64_t from, uint64_t last)
 {
-	static const uint8_t y[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
+	const uint8_t *y = tsq_y38;
 	uint64_t y8;
 	memcpy(&y8, y, 8);
 	for (uint64_t p = from; p <= last; p++) {
@@ -165,9 +167,12 @@ static uint64_t next_sync_seq(const struct walk *w, uint64_t from, uint64_t last
 		const uint32_t v = w->ysum[g];
 		if (v != TG_YS_NONE) {
 			const uint64_t fp = s0 + TG_YS_FIRST(v);
-			if (fp >= p)
+			/* the kernel reads any non-zero byte as 1: a summary entry is a candidate, the bytes decide (a
+			 * sequence with a byte other than 0 / 1 in it is none for the reference's memcmp()) */
+			const int real = !memcmp(w->s + fp, tsq_y38, 38);
+			if (fp >= p && real)
 				return fp <= last ? fp : UINT64_MAX;
-			if (v & TG_YS_MULTI) {
+			if ((v & TG_YS_MULTI) || !real) {
 				const uint64_t e = s0 + TG_SLOT_BITS - 1 < last ? s0 + TG_SLOT_BITS - 1 : last;
 				const uint64_t r = scan_sync_seq(w, p, e);
 				if (r != UINT64_MAX)
@@ -338,7 +343,7 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 				       ((bs + TG_SLOT_BITS + chunk - 1) >> w.cshift) > k) {
 					uint32_t bad = 0;
 					for (int j = 0; j < 32; j++) {
-						const uint32_t v = cls[gi + j] & 0x01ffffffu;
+						const uint32_t v = cls[gi + j] & 0x03ffffffu;
 						bad |= (uint32_t)(v != A) & (uint32_t)(v != B) & (uint32_t)(v != C);
 					}
 					const uint64_t klast = (bs + 32ull * TG_SLOT_BITS + chunk - 1) >> w.cshift;
@@ -354,7 +359,7 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 					gi += 32;
 				}
 				while (gi < ncls && bs + TG_SLOT_BITS <= len) {
-					const uint32_t v = cls[gi] & 0x01ffffffu;	/* type, offset, TG_CLS_EARLY21 */
+					const uint32_t v = cls[gi] & 0x03ffffffu;	/* type, offset, TG_CLS_EARLY21, TG_CLS_NONBINARY */
 					if (v != (TETRA_TRAIN_SYNC | TG_SYNC_TRAIN_OFF << 8) && v != (TETRA_TRAIN_NORM_1 | TG_NORM_TRAIN_OFF << 8) &&
 					    v != (TETRA_TRAIN_NORM_2 | TG_NORM_TRAIN_OFF << 8))
 						break;
@@ -429,7 +434,9 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 			if (ongrid && gi < ncls) {
 				const uint32_t cw = cls[gi];
 				const uint32_t cflags = cw >> 24;
-				if (!(cflags & TG_CLS_EARLY21)) {
+				/* (a byte other than 0 / 1 in the window: the kernel read it as 1, the reference's memcmp() matches
+				 * nothing with it -- settled on the bytes like a hit below offset 21) */
+				if (!(cflags & (TG_CLS_EARLY21 | TG_CLS_NONBINARY))) {
 					if ((cw & 0xff) != TG_BURST_NONE) {
 						/* first hit at an offset >= 21 inside the window the kernel assumed (the steady-state
 						 * one): it is the first hit of any window that contains it */

@@ -476,6 +476,87 @@ def test_stream_classification_kernel(T, eng):
         assert T.sync_classify(eng, d.data_ptr(), len(s), 64, anchor, n).tolist() == got.tolist()
 
 
+def _hostile_stream(T, seed, nslots, lead_in, shift=True):
+    """a long mixed stream with everything the search has to get right: damaged training sequences, spurious
+    n / p / y sequences anywhere in a slot (below offset 21, past offset 472, across slot boundaries), bytes
+    other than 0 / 1, a missing and an extra byte (the grid then runs beside the bursts)"""
+    rng = np.random.default_rng(seed)
+    pat = np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8)
+    types = np.tile(pat, nslots // 8 + 1)[:nslots]
+    slots = T.synth_slots(np.concatenate([[3], types]).astype(np.uint8), seed=seed, scramb_init=0x41802A07, ber=0.01)
+    s = np.concatenate([rng.integers(0, 2, lead_in).astype(np.uint8), slots.reshape(-1), np.zeros(700, np.uint8)])
+    y = np.array([1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1], np.uint8)
+    n = np.array([1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0], np.uint8)
+    p = np.array([0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0], np.uint8)
+    base0 = lead_in + 510
+    for i in rng.choice(nslots - 2, nslots // 12, replace=False):
+        base = base0 + 510 * int(i)
+        kind = int(rng.integers(0, 9))
+        seq = (y, n, p)[int(rng.integers(0, 3))]
+        if kind == 0:
+            s[base + (214 if types[i] == 3 else 244) + int(rng.integers(0, 22))] ^= 1
+        elif kind == 1:
+            s[base + int(rng.integers(0, 21)):][:len(seq)] = seq          # below the look-ahead bound
+        elif kind == 2:
+            s[base + int(rng.integers(21, 214)):][:len(seq)] = seq        # before the real one
+        elif kind == 3:
+            s[base + int(rng.integers(440, 515)):][:len(seq)] = seq       # end of the slot / across the boundary
+        elif kind == 4:
+            s[base + int(rng.integers(0, 510))] = int(rng.choice([2, 3, 0x80, 0xff]))
+        elif kind == 5:
+            s[base + (214 if types[i] == 3 else 244) + 3] = 2             # training sequence with a non-binary byte
+        elif kind == 6:
+            s[base + int(rng.integers(290, 470)):][:38] = y               # second SYNC sequence in the slot
+        elif kind == 7:
+            o = int(rng.integers(22, 200))
+            s[base + o:][:22] = n
+            s[base + o + 30:][:38] = y
+        else:
+            s[base + 214:base + 252] = y                                   # SYNC sequence where a NORM burst has none
+    if shift:
+        s = np.delete(s, base0 + 510 * (nslots // 2) + 77)                    # one byte lost ...
+        s = np.insert(s, base0 + 510 * (3 * nslots // 4) + 300, 1)           # ... and one gained later
+    return s
+
+
+@pytest.mark.parametrize("seed,lead_in,chunk", [(1, 100, 64), (2, 7, 64), (3, 333, 100), (4, 1000, 510), (5, 41, 1)])
+def test_stream_front_packed_bits_equals_per_position(T, eng, seed, lead_in, chunk, monkeypatch):
+    """k_front_stream (packed bits, bit-parallel search, + k_front_stream_fix) == k_front_stream_v1 (the per-position
+    form on every slot): classification words, SYNC summaries and packed slots, bit for bit, on hostile streams of
+    every 16-byte alignment class"""
+    import torch
+    nsl = 3000
+    s = _hostile_stream(T, seed, nsl, lead_in, shift=bool(seed & 1))      # (even seeds stay on one grid: packed slots compared)
+    anchor = lead_in + 510 + seed            # deliberately any alignment, on or off the burst grid
+    n = (len(s) - anchor) // 510
+    d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TGPU_STREAM_V1", mode)
+        cls, ys = T.sync_classify(eng, d.data_ptr(), len(s), chunk, anchor, n, with_ysum=True)
+        plan = T.Plan(eng, n + 8, 1)
+        g = T.GridSync(eng, plan, s, d.data_ptr(), chunk)
+        res = g.finish(burst_events=False)
+        packed = plan.read_packed() if res["ngrid"] and not res["noffgrid"] else None
+        out[mode] = (cls, ys, packed, res)
+        plan.close()
+    a, b = out["1"], out["0"]
+    assert (a[0] == b[0]).all(), np.flatnonzero(a[0] != b[0])[:10]
+    assert (a[1] == b[1]).all(), np.flatnonzero(a[1] != b[1])[:10]
+    assert (a[0] & 0xff != 0xff).sum() > n // 2                 # most slots carry a burst ...
+    assert ((a[0] >> 24) & 1).sum() > 0 and ((a[0] >> 25) & 1).sum() > 0   # ... and the hard cases are in there
+    assert (a[2] is None) == (b[2] is None) and (a[2] is None) == bool(seed & 1)
+    if a[2] is not None:
+        assert (a[2] == b[2]).all(), np.flatnonzero((a[2] != b[2]).any(axis=1))[:10]
+    assert a[3]["events"] == b[3]["events"] and a[3]["nslots"] == b[3]["nslots"]
+    # and the synchroniser built on it == the oracle's tetra_burst_sync_in() on the same bytes: events (lock, loss of
+    # lock, misplaced sequences, every burst with its window) and the bursts handed on
+    if chunk >= 21:
+        _, wev = O.run_rx(s, chunk=chunk)
+        res = T.sync_stream(eng, s, d.data_ptr(), chunk)
+        assert res["events"] == wev
+
+
 @pytest.mark.parametrize("seed", [1, 2, 5])
 def test_config3_stream_end_to_end(T, eng, seed):
     """stream -> GPU sync front end -> plan decode -> in-order delivery == oracle tetra-rx equivalent"""
