@@ -4,17 +4,22 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (config.workload): BASELINE.json configs[1] -- per GPU 1,000,000 synthetic NDB bursts
-(50 % NORM_1 = one 432-bit SCH/F block, 50 % NORM_2 = two 216-bit blocks, plus the AACH of
-every burst), scramb_init = 0, aligned 510-byte slots, 1 bit per byte, already resident in HBM.
-One step = one pass of the whole device pipeline (front gather, code fill, masks, both trellis
-kernels) over the batch; output records stay in HBM.  Ranks own independent channels (weak
-scaling, no data-path collective); value = bursts of all ranks / max-over-ranks time.
+Default workload (config.workload) = BASELINE.json's metric: the SB+NDB mix through the burst-sync front end
+(config 3's composition): per GPU a 1,000,000-slot recorded channel, frames of 8 slots
+[SB, N1, N2, N1, N2, N1, N2, N1], cell scrambling code learnt from SB1, 1 % of the slots with a damaged training
+sequence (dropped burst, loss of lock, re-lock), 1 bit per byte, resident in HBM.  One step = one pass of the whole
+path over that recording: GPU training-sequence search + demux/de-interleave of every grid slot, the reference's
+synchroniser walk (host, tetra_burst_sync_in() semantics at 64-byte feeds), device-built lists, SB1 -> code fill ->
+masks -> both trellis kernels; records stay in HBM.  value counts DELIVERED bursts (what tetra_burst_rx_cb() would
+have been handed), not grid slots.  Recordings are independent units (the reference runs one process per channel):
+W host threads each walk their own recordings, software-pipelined against the GPU.
 
 The JSON line also carries
-  roofline     : the dominant kernel's algorithmic bytes / its HIP-event duration vs HBM peak
-  cpu_baseline : the oracle (CPU restatement of the reference) timed on this box, 1 thread,
-                 on a bounded sample of the same workload
+  roofline     : the dominant kernel's algorithmic bytes / its HIP-event duration vs HBM peak (+ PMC traffic)
+  cpu_baseline : the oracle's receiver (CPU restatement of tetra-rx's path) on the same stream, 64-byte feeds,
+                 one thread, with the Viterbi the reference really runs (libosmocore's accelerated form) and the
+                 generic one beside it
+  config2      : BASELINE configs[1] (1 M aligned NDB bursts, no sync front end) as a secondary measurement
 """
 import argparse
 import json
@@ -100,30 +105,90 @@ def cpu_baseline(slots, types, budget_s=12.0, all_cores_s=4.0):
     return out
 
 
-def bench_config3(args, T, torch, rank, world, local):
-    """BASELINE config 3 (secondary measurement, N=1): one channel, frames of 8 slots
-    [SB, N1, N2, N1, N2, N1, N2, N1], cell code from MCC 262 / MNC 42 / CC 1, 1 % of the slots with a
-    corrupted training sequence (drop / loss of lock / re-lock).  One step = GPU sync front end +
-    host walk + plan load + decode of everything that stays locked."""
-    n = args.bursts
-    rng = np.random.default_rng(7)
+def cpu_baseline_stream(stream, budget_s=7.0):
+    """the oracle's receiver (orc_rx_feed: synchroniser + lower MAC, no callbacks, 64-byte feeds like tetra-rx.c:82-95)
+    on a prefix of the same stream; one thread; both restated libosmocore decoders"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import oraclelib as O
+    lib = O.lib()
+    build = "gcc -O3 (prebuilt)"
+    try:
+        tmp = os.path.join(tempfile.gettempdir(), "liboracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-std=gnu11",
+                               os.path.join(ROOT, "oracle", "tetra_oracle.c"), "-o", tmp],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        nat = C.CDLL(tmp)
+        nat.orc_rx_init.argtypes = lib.orc_rx_init.argtypes
+        nat.orc_rx_feed.argtypes = lib.orc_rx_feed.argtypes
+        lib, build = nat, "gcc -O3 -march=native"
+    except Exception:
+        pass
+    res = {}
+    for acc in (1, 0):
+        # size the sample from a short probe so that the leg stays inside its budget
+        n = 2000 * 510
+        rate = None
+        for _ in range(2):
+            rx = O.Rx()
+            lib.orc_rx_init(C.byref(rx), O.UPPER_CB(), O.EVENT_CB(), None)
+            rx.use_acc = acc
+            piece = np.ascontiguousarray(stream[:min(n, len(stream))])
+            t0 = time.perf_counter()
+            lib.orc_rx_feed(C.byref(rx), O._p(piece), len(piece), 64)
+            el = time.perf_counter() - t0
+            rate = rx.burst_seq / el
+            n = int(min(len(stream), max(n, rate * budget_s * 510)))
+        res[acc] = (rate, int(rx.burst_seq), el)
+    return {"value": res[1][0], "unit": "bursts/s", "cores": 1, "kind": "port",
+            "sample": f"{res[1][1]} bursts delivered from the first {res[1][1] * 510 // 1000} kB of the same stream in "
+                      f"{res[1][2]:.1f} s: oracle/tetra_oracle.c receiver ({build}; synchroniser + demux + descramble + "
+                      f"de-interleave + de-puncture + Viterbi + CRC, no callbacks / printing), 64-byte feeds, one thread, "
+                      f"libosmocore's accelerated Viterbi restated (what osmo_conv_decode() dispatches N=4, K=5 to)",
+            "generic_viterbi": {"value": res[0][0], "unit": "bursts/s",
+                                "sample": f"{res[0][1]} bursts in {res[0][2]:.1f} s with the generic conv.c form instead"},
+            "host_cores_available": os.cpu_count()}
+
+
+def host_threads_default():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:        # a container may see every core of the box and still be throttled to a few of them
+        q, per_us = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per_us))))
+    except Exception:
+        pass
+    return n
+
+
+def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1):
+    """config 3's stream: 100 random lead-in bits, a lock-only SB, n slots in frames of 8, 1 % damaged training
+    sequences, 700 pad bytes"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    rng = np.random.default_rng(7 + seed)
     pat = np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8)
     types = np.tile(pat, n // 8 + 1)[:n]
-    code = 0x41802A07
-    slots = T.synth_slots(np.concatenate([[3], types]).astype(np.uint8), seed=11, scramb_init=code)
+    code = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3
+    slots = T.synth_slots(np.concatenate([[3], types]).astype(np.uint8), seed=11 + seed, scramb_init=code,
+                          mcc=mcc, mnc=mnc, cc=cc)
     bad = np.flatnonzero(rng.random(n) < 0.01) + 1
+    y = slots[0, 214:252].tolist()
     for i in bad:
-        off = 214 if slots[i, 214:252].tolist() == slots[0, 214:252].tolist() else 244
+        off = 214 if slots[i, 214:252].tolist() == y else 244
         slots[i, off + 5] ^= 1
     stream = np.concatenate([rng.integers(0, 2, 100).astype(np.uint8), slots.reshape(-1), np.zeros(700, np.uint8)])
+    return stream, types, code
+
+
+def bench_mix(args, T, torch, dist, rank, world, local):
+    """the metric's workload (BASELINE configs[2] composition; with N ranks every GPU has its own recordings)"""
+    n = args.bursts
+    stream, types, code = make_mix_stream(T, n, rank, mnc=42 + rank)
     eng = T.Engine(local)
     d_stream = torch.from_numpy(np.concatenate([stream, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
-    # W host threads (the reference runs one process per channel; a recording is an independent unit), each with its
-    # own double-buffered pipeline: two plans, two record buffers, two decode streams, two classification streams.
-    # Inside a thread the classification of stream k+1 (GPU) is launched before stream k is walked on the host, and
-    # the decode of stream k runs on its own HIP stream under the walk of stream k+1.
     import threading
-    W = max(1, min(args.sync_threads, args.steps))
+    W = args.sync_threads if args.sync_threads > 0 else max(1, min(6, host_threads_default() // max(1, world)))
+    W = max(1, min(W, args.steps))
     share = [args.steps // W + (w < args.steps % W) for w in range(W)]
     warm = max(2, -(-args.warmup // W))
     start = threading.Barrier(W + 1)
@@ -142,6 +207,7 @@ def bench_config3(args, T, torch, rank, world, local):
             g = [None, None]
             g[0] = T.GridSync(eng, plan[0], stream, d_stream.data_ptr(), 64, cst[0].cuda_stream)
             t_sync = 0.0
+            delivered = 0
             res = None
             last = 0
             for k in range(total):
@@ -152,6 +218,7 @@ def bench_config3(args, T, torch, rank, world, local):
                     start.wait()             # the timed region starts when every thread has warmed up
                     start.wait()
                     t_sync = 0.0
+                    delivered = 0
                 i = k & 1
                 j = i ^ 1
                 if k + 1 < total:
@@ -162,6 +229,7 @@ def bench_config3(args, T, torch, rank, world, local):
                 res = g[i].finish(burst_events=False, scramb_init=0)     # wait for the classification, walk, device lists
                 assert res["noffgrid"] == 0 and res["ngrid"] <= n + 8
                 t_sync += time.perf_counter() - a
+                delivered += res["nslots"]
                 plan[i].execute(d_stream.data_ptr(), d_rec[i].data_ptr(), dec[i].cuda_stream)
                 done[i] = torch.cuda.Event()
                 done[i].record(dec[i])
@@ -169,7 +237,7 @@ def bench_config3(args, T, torch, rank, world, local):
             for e in done:
                 if e is not None:
                     e.synchronize()
-            state[w] = (res, plan, d_rec, last, t_sync)
+            state[w] = (res, plan, d_rec, last, t_sync, delivered)
         except Exception as ex:          # pragma: no cover
             errors.append(ex)
             start.abort()
@@ -179,36 +247,110 @@ def bench_config3(args, T, torch, rank, world, local):
         th.start()
     start.wait()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     start.wait()
     for th in threads:
         th.join()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if errors:
         raise errors[0]
-    res, plan, d_rec, last, _ = state[0]
+    delivered = sum(v[5] for v in state.values())
+    if world > 1:
+        t = torch.tensor([el, float(delivered)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        el, delivered = float(tmax[0].item()), int(t[1].item())
+    if rank != 0:
+        return None
+    res, plan, d_rec, last, _, _ = state[0]
     t_sync = sum(v[4] for v in state.values()) / W
-    nslots = res["nslots"]
     hs = torch.cuda.current_stream().cuda_stream
+
+    # correctness guard on the timed output: a sample of the delivered bursts against the oracle (checker only) --
+    # type-1 bits, BBK, CRC words and flags of the first 2048 delivered grid slots of the last decoded stream
     first = T.grid_indices(res)[:2048]
     p = T.parse_records(d_rec[last].view(-1, T.REC_BYTES)[torch.from_numpy(first).cuda()].cpu().numpy())
-    prof = T.Prof(4)
-    for q in range(4):
+    check = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oraclelib as O
+        anchor = res["anchor"]
+        sl = np.stack([stream[anchor + 510 * int(g):anchor + 510 * int(g) + 510] for g in first])
+        ty = p["type"].astype(np.uint8)
+        ok, want, wcrc = O.bench_decode_slots(sl, ty, code, use_acc=1, want_out=True, want_crc=True)
+        n1, n2, sb = ty == 0, ty == 1, ty == 3
+        good = (p["bbk"] == want[:, :14]).all() and (p["bits1"][n1] == want[n1, 14:282]).all() and \
+            (p["bits1"][n2][:, :124] == want[n2, 14:138]).all() and (p["bits2"][n2] == want[n2, 138:262]).all() and \
+            (p["bits1"][sb][:, :60] == want[sb, 14:74]).all() and (p["bits2"][sb] == want[sb, 138:262]).all() and \
+            (p["crc"][:, 0] == wcrc[:, 0]).all() and (p["crc"][n2 | sb, 1] == wcrc[n2 | sb, 1]).all() and \
+            (n1 | n2 | sb).all()
+        assert good, "decoded records differ from the oracle"
+        check = "type-1 bits, BBK and CRC words of %d delivered bursts equal the oracle's" % len(first)
+
+    # per-kernel durations (HIP events on the launch stream, after the timed region)
+    us_front, us_fix = T.sync_front_prof(eng, plan[last ^ 1], d_stream.data_ptr(), len(stream), res["anchor"], 64, 10, hs)
+    prof = T.Prof(8)
+    for q in range(8):
         plan[last].execute_prof(d_stream.data_ptr(), d_rec[last].data_ptr(), hs, prof, q)
     torch.cuda.synchronize()
-    t_exec = float(prof.read(4)[1:].sum(axis=1).mean()) * 1e-3 * args.steps
-    out = {"metric": "decoded bursts/s", "value": n * args.steps / el, "unit": "bursts/s", "n_gpus": 1,
+    st = prof.read(8)[2:].mean(axis=0)      # ms per stage (k_front is skipped in stream mode: stage 0 is empty)
+    names = T.Prof.stage_names()
+    kern_ms = {"k_front_stream": us_front * 1e-3, "k_front_stream_fix": us_fix * 1e-3}
+    for i in range(1, len(names)):
+        kern_ms[names[i]] = float(st[i])
+    dom = max(kern_ms, key=kern_ms.get)
+    ngrid = res["ngrid"]
+    tyd = p["type"]
+    # delivered bursts by type (whole stream): SB 1/8, N1 4/8, N2 3/8 of the delivered ones (the damage is uniform)
+    nd = res["nslots"]
+    n_sb, n_n1, n_n2 = nd // 8, nd // 2, nd - nd // 8 - nd // 2
+    # 510 B in per slot the front end looks at; type-1 bits at 1 B/bit + 16 B per block out
+    alg = {"k_front_stream": ngrid * 510, "k_front_stream_fix": 0,
+           "k_vit<SB1>": n_sb * (60 + 16), "k_fill": 0, "k_masks": 0,
+           "k_vit<216>": n_n2 * (14 + 124 + 124 + 3 * 16) + n_sb * (14 + 124 + 2 * 16),
+           "k_vit<432>": n_n1 * (14 + 268 + 2 * 16)}
+    achieved = alg[dom] / (kern_ms[dom] * 1e-3) / 1e9
+    traffic = valu_busy = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        traffic = tj.get("mix", {}).get(dom)
+        valu_busy = tj.get("mix_valu_busy", {}).get(dom)
+    except Exception:
+        pass
+    value = delivered / el
+    out = {"metric": "decoded bursts/s", "value": value, "unit": "bursts/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-           "config": {"workload": "BASELINE config 3: %d-burst mixed SB/NDB stream, GPU burst-sync front end, 1%% corrupted "
-                                  "training sequences; step = GPU classification/packing + host walk (bitmap) + device-built lists + decode, "
-                                  "software-pipelined over streams (classification of stream k+1 and decode of stream k under the host walk), "
-                                  "%d host threads each walking its own streams" % (n, W),
-                      "bursts_in_stream": n, "bursts_delivered": nslots, "crc_ok_first_2048": int(p["crc_ok"][:, 0].sum())},
-           "breakdown_ms": {"grid sync finish per stream and thread (wait for the classification, host walk, device list build)": t_sync / max(share) * 1e3,
-                            "plan_execute(GPU decode, runs under the next stream's synchronisation)": t_exec / args.steps * 1e3}}
-    print(json.dumps(out))
+           "config": {"workload": "SB+NDB mix through the burst-sync front end (BASELINE configs[2] composition): per GPU a %d-slot "
+                                  "recorded channel, frames [SB,N1,N2,N1,N2,N1,N2,N1], cell code from SB1, 1%% damaged training "
+                                  "sequences, resident in HBM; step = one pass over the recording (GPU sequence search + demux of every "
+                                  "grid slot, host synchroniser walk at 64-byte feeds, device lists, SB1 / fill / masks / trellis); "
+                                  "value = delivered bursts/s; %d host threads per GPU each walking its own recordings" % (n, W),
+                      "slots_per_recording": n, "grid_slots": int(ngrid), "delivered_per_recording": int(nd),
+                      "host_threads_per_gpu": W, "parallelism": "independent recordings per GPU, no collective in decoding",
+                      "check": check},
+           "breakdown_ms": {"sync finish per recording and thread (wait for the classification, host walk, device list build)":
+                            t_sync / max(share) * 1e3,
+                            "gpu kernels per recording (serialised, HIP events)": kern_ms},
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
+                        "kernel_ms": kern_ms[dom],
+                        "pipeline_achieved_gbs_per_gpu": float(value / world * 820 / 1e9),
+                        "note": "achieved = the dominant kernel's share of SURVEY 8(d)'s algorithmic bytes (k_front_stream: the 510 "
+                                "input bytes of every grid slot; a trellis kernel: type-1 bits at 1 B/bit + 16 B per block of the "
+                                "bursts it decodes) / its mean HIP-event duration on its launch stream, measured after the timed "
+                                "region; traffic = PMC bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes) and "
+                                "valu_busy_frac from profiles/traffic.json of the same command; every kernel of this path is bound by "
+                                "vector-instruction issue, not by HBM (DESIGN.md section 4)"}}
+    return out
 
 
 def bench_config5(args, T, torch, rank, world, local):
@@ -343,25 +485,106 @@ def bench_conv(args, T, torch, rank, world, local):
     print(json.dumps(out))
 
 
+def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_cpu=True):
+    """BASELINE configs[1]: per GPU n aligned NDB bursts (50 % NORM_1 / 50 % NORM_2), scramb_init 0, no SYNC slot, no
+    sync front end; returns the result dict on rank 0"""
+    n = args.bursts
+    rng = np.random.default_rng(1000 + rank)
+    types = np.where(rng.random(n) < 0.5, T.TRAIN_NORM_1, T.TRAIN_NORM_2).astype(np.uint8)
+    slots = T.synth_slots(types, seed=1 + rank, scramb_init=0, ber=args.ber)
+
+    eng = T.Engine(local)
+    d_stream = torch.from_numpy(slots.reshape(-1)).cuda()
+    d_rec = torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types)
+    prof = T.Prof(steps)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(warmup):
+        plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), stream)
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), stream)
+    sync_all()
+    el = time.perf_counter() - t0
+
+    # per-stage durations: the same K steps once more with one HIP event between stages on the launch stream
+    for k in range(steps):
+        plan.execute_prof(d_stream.data_ptr(), d_rec.data_ptr(), stream, prof, k)
+    torch.cuda.synchronize()
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # correctness guard on the timed output: every block must have passed its CRC at BER 0
+    p = T.parse_records(d_rec.view(n, T.REC_BYTES)[:4096].cpu().numpy())
+    if args.ber == 0.0:
+        two = types[:4096] == T.TRAIN_NORM_2
+        assert (p["crc_ok"][:, 0] == 1).all() and (p["crc_ok"][two, 1] == 1).all(), "decode failed"
+
+    ms = prof.read(steps)  # (steps, stages) milliseconds from HIP events on the launch stream
+    stage_ms = ms[min(2, steps - 1):].mean(axis=0)
+    names = T.Prof.stage_names()
+    dom = int(np.argmax(stage_ms))
+    n1 = int((types == T.TRAIN_NORM_1).sum())
+    n2 = n - n1
+    units_bytes = {"k_front": n * 510, "k_vit<432>": n1 * (ALG_BYTES[0] - 510), "k_vit<216>": n2 * (ALG_BYTES[1] - 510)}
+    alg = units_bytes.get(names[dom], n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1])
+    achieved = alg / (stage_ms[dom] * 1e-3) / 1e9
+    value = world * n * steps / el
+    traffic = valu_busy = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        traffic = tj.get(names[dom])
+        valu_busy = tj.get("valu_busy", {}).get(names[dom])
+    except Exception:
+        pass
+    out = {
+        "metric": "decoded bursts/s", "value": value, "unit": "bursts/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u16", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: per GPU %d NDB bursts (50%% NORM_1 SCH/F, 50%% NORM_2 2xNDB, + AACH), "
+                               "scramb_init=0, BER %g, aligned 510-B slots resident in HBM, no sync front end, records left in HBM" % (n, args.ber),
+                   "bursts_per_gpu": n, "parallelism": "independent channels per GPU, no collective in decoding"},
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
+                     "kernel_ms": float(stage_ms[dom]),
+                     "stage_ms": {names[i]: float(stage_ms[i]) for i in range(len(names))},
+                     "pipeline_achieved_gbs_per_gpu": float(value / world * ((n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1]) / n) / 1e9)},
+    }
+    if rank == 0 and world == 1 and with_cpu and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(slots, types)
+    plan.close()
+    return out if rank == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts per GPU per step")
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=18)
+    ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts (slots) per GPU per step")
     ap.add_argument("--ber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", default="final", choices=["final", "step"],
-                    help="N>1: 'final' = one RCCL gather of the decoded blocks (48-byte wire records) at the end of the "
-                         "timed region; 'step' = one gather per step, overlapped with the next decode (needs about "
-                         "120 GB/s per xGMI link at the single-GPU decode rate)")
-    ap.add_argument("--sync-threads", type=int, default=3,
-                    help="config3: host threads, each synchronising (walking) its own streams")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5", "conv"],
-                    help="config2 (default, the metric's workload): aligned NDB slots; config3: mixed SB/NDB stream "
-                         "through the GPU burst-sync front end, 1%% corrupted training sequences")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 object of the default run")
+    ap.add_argument("--sync-threads", type=int, default=0,
+                    help="mix: host threads per GPU, each synchronising (walking) its own recordings (0 = min(6, usable cores / ranks))")
+    ap.add_argument("--workload", default="mix", choices=["mix", "config3", "config2", "config5", "conv"],
+                    help="mix (default, = config3: the metric's workload): SB+NDB recordings through the GPU burst-sync front end, "
+                         "1%% damaged training sequences; config2: aligned NDB slots, no front end; config5: float phases -> "
+                         "soft-decision decode; conv: the generic trellis kernel")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo = control-flow check on a box with fewer GPUs than ranks (gather staged through the host)")
+                    help="gloo = control-flow check on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import torch
@@ -386,166 +609,21 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    if args.workload == "config3":
-        return bench_config3(args, T, torch, rank, world, local)
     if args.workload == "config5":
         return bench_config5(args, T, torch, rank, world, local)
     if args.workload == "conv":
         return bench_conv(args, T, torch, rank, world, local)
-
-    n = args.bursts
-    rng = np.random.default_rng(1000 + rank)
-    types = np.where(rng.random(n) < 0.5, T.TRAIN_NORM_1, T.TRAIN_NORM_2).astype(np.uint8)
-    slots = T.synth_slots(types, seed=1 + rank, scramb_init=0, ber=args.ber)
-
-    eng = T.Engine(local)
-    d_stream = torch.from_numpy(slots.reshape(-1)).cuda()
-    d_rec = torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
-    plan = T.Plan(eng, n, 1)
-    plan.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types)
-    prof = T.Prof(args.steps)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    # N > 1: the final exchange of the path -- decoded blocks travel to rank 0 in the 48-byte wire form (each
-    # peer->root transfer uses its own xGMI link; see DESIGN.md "Multi-GPU").  Default: one gather of the last
-    # batch at the end of the timed region.  --gather step: one gather per step on a side stream, overlapped with
-    # the next decode -- at 2.5e9 bursts/s per GPU that is 120 GB/s per link, more than a link sustains.
-    gather = world > 1
-    if gather:
-        from osmo_tetra_amd import dist as tdist
-        wire = [torch.empty(n * T.WIRE_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        sink = [[torch.empty_like(wire[0]) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
-        comm = torch.cuda.Stream()
-        pending = [None, None]
-
-    every_step = gather and args.gather == "step"
-
-    def final_gather(b):
-        """the one exchange of the path: every rank's decoded blocks (wire form) to rank 0"""
-        torch.cuda.synchronize()
-        if args.backend == "nccl":
-            tdist.gather_wire(wire[b], dst=0, out=sink[b])
-            torch.cuda.synchronize()
-        else:   # debug path: host-staged
-            tdist.gather_wire(wire[b].cpu(), dst=0, out=[t.cpu() for t in sink[b]] if rank == 0 else None)
-
-    def step(k, prof_step=None):
-        if gather:
-            b = k & 1
-            if pending[b] is not None:       # the gather that last read this buffer must be done
-                pending[b].wait()
-            plan.set_wire(wire[b].data_ptr())
-        if prof_step is None:
-            plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), stream)
-        else:
-            plan.execute_prof(d_stream.data_ptr(), d_rec.data_ptr(), stream, prof, prof_step)
-        if every_step:
-            done = torch.cuda.Event()
-            done.record()
-            with torch.cuda.stream(comm):
-                comm.wait_event(done)
-                if args.backend == "nccl":
-                    _, pending[b] = tdist.gather_wire(wire[b], dst=0, async_op=True, out=sink[b])
-                else:   # debug path: host-staged
-                    comm.synchronize()
-                    _, pending[b] = tdist.gather_wire(wire[b].cpu(), dst=0, async_op=True,
-                                                      out=[t.cpu() for t in sink[b]] if rank == 0 else None)
-
-    def drain():
-        if gather:
-            for b in (0, 1):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for k in range(args.warmup):
-        step(k)
-    drain()
-    if gather and not every_step and args.warmup:
-        final_gather((args.warmup - 1) & 1)      # first use sets up the communicator: keep that out of the timing
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    drain()
-    if gather and not every_step:
-        final_gather((args.steps - 1) & 1)       # inside the timed region
-    sync_all()
-    el = time.perf_counter() - t0
-
-    # per-stage durations: the same K steps once more with one HIP event between stages on the launch
-    # stream (this serialises k_vit<216> / k_vit<432>, which the timed pass above lets run side by side)
-    for k in range(args.steps):
-        plan.execute_prof(d_stream.data_ptr(), d_rec.data_ptr(), stream, prof, k)
-    torch.cuda.synchronize()
-
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
-    # correctness guard on the timed output: every block must have passed its CRC at BER 0
-    p = T.parse_records(d_rec.view(n, T.REC_BYTES)[:4096].cpu().numpy())
-    if args.ber == 0.0:
-        two = types[:4096] == T.TRAIN_NORM_2
-        assert (p["crc_ok"][:, 0] == 1).all() and (p["crc_ok"][two, 1] == 1).all(), "decode failed"
-
-    ms = prof.read(args.steps)  # (steps, stages) milliseconds from HIP events on the launch stream
-    stage_ms = ms.mean(axis=0)
-    names = T.Prof.stage_names()
-    dom = int(np.argmax(stage_ms))
-    n1 = int((types == T.TRAIN_NORM_1).sum())
-    n2 = n - n1
-    # SURVEY 8(d)'s per-burst figure split by the kernel that moves it: the 510 mandated input bytes belong to the
-    # front kernel, the type-1 bits (1 B per bit) + 16 B per block to the trellis kernel that decodes the burst
-    units_bytes = {"k_front": n * 510, "k_vit<432>": n1 * (ALG_BYTES[0] - 510), "k_vit<216>": n2 * (ALG_BYTES[1] - 510)}
-    alg = units_bytes.get(names[dom], n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1])
-    achieved = alg / (stage_ms[dom] * 1e-3) / 1e9
-    value = world * n * args.steps / el
-    pipeline_gbs = value / world * ((n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1]) / n) / 1e9
-
-    traffic = valu_busy = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        traffic = tj.get(names[dom])
-        valu_busy = tj.get("valu_busy", {}).get(names[dom])
-    except Exception:
-        pass
-    out = {
-        "metric": "decoded bursts/s", "value": value, "unit": "bursts/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u16", "data": "synthetic",
-        "config": {"workload": "BASELINE config 2: per GPU %d NDB bursts (50%% NORM_1 SCH/F, 50%% NORM_2 2xNDB, + AACH), "
-                               "scramb_init=0, BER %g, aligned 510-B slots resident in HBM, records left in HBM" % (n, args.ber),
-                   "bursts_per_gpu": n, "parallelism": "independent channels per GPU, no collective in decoding; N>1: the decoded blocks of the job's "
-                                  "last batch (48-B wire records) are gathered to rank 0 with one RCCL gather inside the timed "
-                                  "region (--gather step: one gather per step, overlapped)" if args.gather == "final" else
-                                  "independent channels per GPU; N>1: one RCCL gather of 48-B wire records per step to rank 0, "
-                                  "overlapped with the next decode"},
-        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic,
-                     "valu_busy_frac": valu_busy,   # rocprofv3 SQ_ACTIVE_INST_VALU / kernel cycles of this kernel (profiles/)
-                     "kernel_ms": float(stage_ms[dom]),
-                     "stage_ms": {names[i]: float(stage_ms[i]) for i in range(len(names))},
-                     "pipeline_achieved_gbs_per_gpu": float(pipeline_gbs),
-                     "note": "achieved = this kernel's share of the SURVEY 8(d) algorithmic bytes (k_front: the 510 input bytes of every "
-                             "burst; a trellis kernel: type-1 bits at 1 B/bit + 16 B per block of the bursts it decodes) / its mean "
-                             "HIP-event duration (second pass of the same K steps, one event between stages on the launch stream; the "
-                             "timed pass overlaps the two trellis kernels); pipeline_achieved_gbs_per_gpu = all 0.82 kB per burst / "
-                             "step time; traffic = PMC bytes per launch and valu_busy_frac from profiles/traffic.json "
-                             "(profiles/r01_config2_rocprofv3.md): k_front is bound by the memory system (its reads, its writes and the "
-                             "write-back of the previous kernels' records), the trellis kernels are VALU-issue bound (0.72 - 0.82 "
-                             "busy, 28 instructions per trellis step), see DESIGN.md"},
-    }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(slots, types)
+    if args.workload == "config2":
+        out = bench_config2(args, T, torch, dist, rank, world, local, args.steps, args.warmup)
+    else:
+        out = bench_mix(args, T, torch, dist, rank, world, local)
+        if rank == 0 and world == 1:
+            if not args.no_cpu_baseline:
+                stream, _, _ = make_mix_stream(T, min(args.bursts, 400_000), rank, mnc=42 + rank)
+                out["cpu_baseline"] = cpu_baseline_stream(stream)
+            if not args.no_secondary:
+                c2 = bench_config2(args, T, torch, dist, rank, world, local, 40, 10, with_cpu=False)
+                out["config2"] = {k: c2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline")}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

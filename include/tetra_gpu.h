@@ -390,6 +390,11 @@ int tgpu_sync_stream_grid_finish(struct tgpu_engine *eng, struct tgpu_plan *plan
 				 uint32_t chunk, uint32_t flags, uint32_t scramb_init, struct tgpu_sync_result *out,
 				 void *hip_stream);
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
+/* measurement aid: the stream front end of a grid (anchor + 510 n) alone, nrep times on hip_stream with HIP events
+ * around its launches: us[0] = k_front_stream, us[1] = k_front_stream_fix (mean microseconds).  The plan's grid
+ * buffers are the scratch; the plan is left unloaded. */
+int tgpu_sync_front_prof(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *d_stream, uint64_t len,
+			 uint32_t chunk, uint64_t anchor, uint32_t nrep, float us[2], void *hip_stream);
 
 /*
  * Optional, off by default: clean-block fast path.  A pre-pass (k_clean) recognises the blocks whose received bits

@@ -163,6 +163,8 @@ def lib():
     L.tgpu_sync_stream_grid_finish.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.POINTER(SyncResult), C.c_void_p]
     L.tgpu_sync_result_free.argtypes = [C.POINTER(SyncResult)]
+    L.tgpu_sync_front_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
+                                       C.POINTER(C.c_float), C.c_void_p]
     L.tgpu_synth_slots.argtypes = [C.POINTER(SynthCfg), u8p, C.c_size_t, u8p, u8p]
     _lib = L
     return L
@@ -511,6 +513,14 @@ def sync_stream_grid(engine, plan, h_stream, d_stream_ptr, chunk=64, hip_stream=
     if not out["noffgrid"] and out["ngrid"]:
         plan.nslots, plan.nchan = out["ngrid"], 1
     return out
+
+
+def sync_front_prof(engine, plan, d_stream_ptr, length, anchor, chunk=64, nrep=10, hip_stream=0):
+    """tgpu_sync_front_prof: mean microseconds of (k_front_stream, k_front_stream_fix) over nrep runs"""
+    us = (C.c_float * 2)()
+    _chk(lib().tgpu_sync_front_prof(engine._h, plan._h, C.c_void_p(d_stream_ptr), length, chunk, anchor, nrep, us,
+                                    C.c_void_p(hip_stream)), "tgpu_sync_front_prof")
+    return float(us[0]), float(us[1])
 
 
 class GridSync:

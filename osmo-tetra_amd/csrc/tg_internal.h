@@ -15,6 +15,9 @@ int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 /* stream mode: grid slot n at anchor + 510 n; writes packed slots and one classification word per slot */
 int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
 		     uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream);
+int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
+			uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream,
+			void *ev_mid /* hipEvent_t recorded between the packed-bit kernel and its fix-up pass, or NULL */);
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
 	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */,

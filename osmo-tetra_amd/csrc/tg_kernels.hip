@@ -2168,8 +2168,18 @@ static uint32_t host_pattern_bits(const uint8_t *seq, int from, int n)
 	return v;
 }
 
+extern "C" int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
+				   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream, void *ev_mid);
+
 extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
 				uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream)
+{
+	return tgk_front_stream_ev(d_stream, anchor, len, nslots, chunk, d_packed, d_cls, d_ysum, stream, NULL);
+}
+
+/* ev_mid (optional hipEvent_t): recorded between the packed-bit kernel and its fix-up pass (per-kernel timing) */
+extern "C" int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
+				   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream, void *ev_mid)
 {
 	if (!nslots)
 		return 0;
@@ -2193,6 +2203,8 @@ extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64
 		if (blocks > 256 * 8)
 			blocks = 256 * 8;
 		hipLaunchKernelGGL(k_front_stream_v1, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum);
+		if (ev_mid)
+			HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
 		return (int)hipGetLastError();
 	}
 	uint32_t blocks = ((nslots + 3) / 4 + 3) / 4;	/* a wave per group of four slots */
@@ -2202,6 +2214,8 @@ extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64
 	if (blocks > cap)
 		blocks = cap;
 	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum);
+	if (ev_mid)
+		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
 	uint32_t fblocks = ((nslots + 63) / 64 + 3) / 4;	/* a wave per 64 classification words */
 	if (fblocks > 256 * 32)
 		fblocks = 256 * 32;

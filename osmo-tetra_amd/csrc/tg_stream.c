@@ -167,9 +167,11 @@ static uint64_t next_sync_seq(const struct walk *w, uint64_t from, uint64_t last
 		const uint32_t v = w->ysum[g];
 		if (v != TG_YS_NONE) {
 			const uint64_t fp = s0 + TG_YS_FIRST(v);
-			/* the kernel reads any non-zero byte as 1: a summary entry is a candidate, the bytes decide (a
-			 * sequence with a byte other than 0 / 1 in it is none for the reference's memcmp()) */
-			const int real = !memcmp(w->s + fp, tsq_y38, 38);
+			/* the kernel reads any non-zero byte as 1: where this slot's or the next one's window holds a byte other
+			 * than 0 / 1 a summary entry is only a candidate and the bytes decide (such a sequence is none for
+			 * the reference's memcmp()) */
+			const int doubt = !w->cls || g + 1 >= w->ncls || (((w->cls[g] | w->cls[g + 1]) >> 24) & TG_CLS_NONBINARY);
+			const int real = !doubt || !memcmp(w->s + fp, tsq_y38, 38);
 			if (fp >= p && real)
 				return fp <= last ? fp : UINT64_MAX;
 			if ((v & TG_YS_MULTI) || !real) {
@@ -663,6 +665,47 @@ int tgpu_sync_stream_grid_finish(struct tgpu_engine *eng, struct tgpu_plan *plan
 	if (getenv("TGPU_SYNC_TIMING"))
 		fprintf(stderr, "tgpu_sync_stream_grid: wait for the classification %.3f ms, walk %.3f ms, device lists %.3f ms (%u of %u grid slots, %u events)\n",
 			t1 - t0, t2 - t1, now_ms() - t2, out->nslots, ncls, out->nevents);
+	return rc;
+}
+
+int tgpu_sync_front_prof(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *d_stream, uint64_t len,
+			 uint32_t chunk, uint64_t anchor, uint32_t nrep, float us[2], void *stream)
+{
+	if (!eng || !plan || !d_stream || !chunk || !nrep || !us || anchor + TG_SLOT_BITS > len)
+		return TGPU_EINVAL;
+	const uint64_t n = (len - anchor) / TG_SLOT_BITS;
+	if (n > 0xfffffff0u)
+		return TGPU_ECAPACITY;
+	uint32_t *d_packed, *d_cls, *cls;
+	uint16_t *d_ysum, *ysum;
+	int rc = tgpi_plan_grid_begin(plan, (uint32_t)n, &d_packed, &d_cls, &d_ysum, &cls, &ysum);
+	if (rc)
+		return rc;
+	hipEvent_t ev[3] = { NULL, NULL, NULL };
+	for (int i = 0; i < 3 && !rc; i++)
+		rc = (int)hipEventCreate(&ev[i]);
+	double acc[2] = { 0, 0 };
+	for (uint32_t r = 0; r < nrep && !rc; r++) {
+		rc = (int)hipEventRecord(ev[0], (hipStream_t)stream);
+		if (!rc)
+			rc = tgk_front_stream_ev(d_stream, anchor, len, (uint32_t)n, chunk, d_packed, d_cls, d_ysum, stream, ev[1]);
+		if (!rc)
+			rc = (int)hipEventRecord(ev[2], (hipStream_t)stream);
+		if (!rc)
+			rc = (int)hipEventSynchronize(ev[2]);
+		float a = 0, b = 0;
+		if (!rc)
+			rc = (int)hipEventElapsedTime(&a, ev[0], ev[1]);
+		if (!rc)
+			rc = (int)hipEventElapsedTime(&b, ev[1], ev[2]);
+		acc[0] += a;
+		acc[1] += b;
+	}
+	for (int i = 0; i < 3; i++)
+		if (ev[i])
+			(void)hipEventDestroy(ev[i]);
+	us[0] = (float)(acc[0] * 1e3 / nrep);
+	us[1] = (float)(acc[1] * 1e3 / nrep);
 	return rc;
 }
 
