@@ -269,6 +269,9 @@ struct tgpu_unitdata {
 					 * (lower_mac/tetra_lower_mac.c:198-241); type4 is set, type1 is NULL */
 	const uint8_t *type4;		/* descrambled bits of a traffic block, type345 bits */
 	uint16_t type4_len;
+	struct tetra_tdma_time time_str;/* the PHY clock when the block came in (tetra_lower_mac.c:167-168): the time the
+					 * reference's "<NAME> <time> type1: ..." line shows -- for an SB1 block the value
+					 * from before its SYNC PDU moved the clock (tdma_time holds the one after) */
 };
 
 /*
@@ -286,6 +289,7 @@ enum tgpu_sync_event {
 	TGPU_EV_SYNC_MISPLACED = 3,
 	TGPU_EV_NORM_MISPLACED = 4,
 	TGPU_EV_NO_TRAIN = 5,
+	TGPU_EV_ERROR = 6,	/* a queued batch could not be decoded: bitnum = the error, arg = bursts / blocks lost */
 };
 typedef void (*tgpu_event_cb)(int event, uint32_t bitnum, uint32_t arg, void *priv);
 
@@ -307,8 +311,29 @@ void tgpu_channel_bind_flags(struct tgpu_channel *ch, int *is_traffic, bool *blk
 void tgpu_channel_set_traffic(struct tgpu_channel *ch, int is_traffic);
 void tgpu_channel_set_blk2_stolen(struct tgpu_channel *ch, bool stolen);
 
-/* decode and deliver everything queued so far */
+/* decode and deliver everything queued so far.  A batch that cannot be decoded (HIP or plan error) is given up:
+ * its time steps still advance the channel's clock, the error is kept (also when the flush was an automatic one
+ * inside tetra_burst_sync_in(), whose return value has no room for it): tgpu_channel_flush() returns it from then
+ * on, tgpu_channel_last_error() reads it, the event callback gets TGPU_EV_ERROR. */
 int tgpu_channel_flush(struct tgpu_channel *ch);
+int tgpu_channel_last_error(const struct tgpu_channel *ch);
+void tgpu_channel_clear_error(struct tgpu_channel *ch);
+
+/*
+ * The lower-MAC seam under the reference's own signatures (phy/tetra_burst.h:18, phy/tetra_burst.c:341), priv = the
+ * struct tgpu_channel * (the reference passes tms).  libosmo-tetra-phy.a links against this library unchanged: it
+ * finds tp_sap_udata_ind and tetra_tdma_time_add_tn here and brings its own t_phy_state (ours is a weak definition
+ * of the same object, phy/tetra_burst_sync.c:34, used when that file is not linked).  Blocks are queued and decoded
+ * on the GPU in batches (SCH/HU included); an SB1 block is decoded before tp_sap_udata_ind() returns, so the code
+ * and time it brings apply to the next block as in the reference; the rest is delivered when the queue fills, at
+ * the next SB1 or by tgpu_channel_flush().  Delivery = the channel's tgpu_unitdata_cb, same order, same contents.
+ */
+struct tetra_phy_state {
+	struct tetra_tdma_time time;
+};
+extern struct tetra_phy_state t_phy_state;
+void tp_sap_udata_ind(enum tp_sap_data_type type, int blk_num, const uint8_t *bits, unsigned int len, void *priv);
+void tetra_burst_rx_cb(const uint8_t *burst, unsigned int len, enum tetra_train_seq type, void *priv);
 
 /* phy/tetra_burst_sync.c:54 -- same symbol, same semantics */
 int tetra_burst_sync_in(struct tetra_rx_state *trs, uint8_t *bits, unsigned int len);
@@ -367,6 +392,11 @@ struct tgpu_sync_result {
 
 #define TGPU_SYNC_NO_BURST_EVENTS 1u	/* do not record one TGPU_EV_BURST per locked burst (throughput runs) */
 #define TGPU_SYNC_GRID 2u		/* tgpu_sync_walk(): bitmap over the classified grid instead of a slot table */
+#define TGPU_SYNC_PER_CALL 4u		/* tgpu_sync_walk(): the reference's state machine call by call on the bytes (slow, for checks) */
+/* feed sizes (bytes per tetra_burst_sync_in() call being emulated) the synchroniser's closed form covers; tetra-rx.c
+ * feeds 64.  Outside this range (1 .. 510 is accepted) tgpu_sync_walk() runs the per-call form instead. */
+#define TGPU_SYNC_CHUNK_MIN 21u
+#define TGPU_SYNC_CHUNK_MAX 296u
 int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uint8_t *d_stream, uint64_t len,
 		     uint32_t chunk, uint32_t flags, struct tgpu_sync_result *out, void *hip_stream);
 /*
@@ -459,6 +489,30 @@ void tgpu_conv_destroy(struct tgpu_conv *cv);
  * (lower_mac/tetra_conv_enc.c:201-248; 'pu' is enum tetra_rcpc_puncturer) */
 int get_punctured_rate(int pu, uint8_t *in, int len, uint8_t *out);
 int tetra_rcpc_depunct(int pu, const uint8_t *in, int len, uint8_t *out);
+
+/*
+ * ACELP bit re-ordering (lower_mac/tch_reordering.c:94-140) as an operation.  The class
+ * position tables (EN 300 395-2 Table 4: three lists of 1-based positions inside one codec frame of
+ * ncls[0] + ncls[1] + ncls[2] bits) are the CALLER's data -- none ships with this library.
+ *   tgpu_acelp_build_map(): the index map of one direction, src_of_dst[2 * nbits]: to_codec != 0 = the reference's
+ *       tetra_acelp_type2_to_codec() (class order -> two codec frames), 0 = tetra_acelp_codec_to_acelp().  Returns
+ *       the block length 2 * nbits.  The reference's index arithmetic, also for tables that are no permutation (its
+ *       own is not): later entries win, a destination nobody names gets -1 (left untouched when the map is applied),
+ *       an entry 0 (out[-1] / in[-1] in the reference) is skipped.
+ *   tgpu_reorder_*(): any such map applied to nblocks blocks of nbits bytes (1 bit per byte) resident in HBM,
+ *       launch only.  Destinations with source -1 keep what d_out held.
+ *   tetra_acelp_type2_to_codec() / tetra_acelp_codec_to_acelp(): the reference's entry points (same names and
+ *       arguments) on host buffers, using the tables given to tgpu_acelp_set_tables(); they abort() with a
+ *       message when none was given.
+ */
+struct tgpu_reorder;
+int tgpu_acelp_build_map(const uint8_t *const cls[3], const unsigned int ncls[3], int to_codec, int32_t *src_of_dst);
+int tgpu_reorder_create(struct tgpu_engine *eng, const int32_t *src_of_dst, uint32_t nbits, struct tgpu_reorder **out);
+int tgpu_reorder_execute(struct tgpu_reorder *r, const uint8_t *d_in, uint64_t nblocks, uint8_t *d_out, void *hip_stream);
+void tgpu_reorder_destroy(struct tgpu_reorder *r);
+int tgpu_acelp_set_tables(const uint8_t *const cls[3], const unsigned int ncls[3]);
+void tetra_acelp_type2_to_codec(const uint8_t *in, uint8_t *out);
+void tetra_acelp_codec_to_acelp(const uint8_t *in, uint8_t *out);
 
 /*
  * GSMTAP wire format of a decoded block: the message tetra_gsmtap_makemsg() builds

@@ -738,6 +738,7 @@ void orc_tp_sap_udata_ind(struct orc_rx *rx, int type, int blk_num, const uint8_
 	rec.type1_len = p->type1_bits;
 
 	rx->cell_time = rx->phy_time;					/* :167 */
+	rec.time_str = rx->cell_time;					/* :168 */
 	if (type == ORC_T_SB2 && is_bnch(&rx->cell_time))		/* :170-173 */
 		rec.lchan = ORC_LC_BNCH;
 
@@ -820,6 +821,43 @@ void orc_traffic_block(const uint8_t *type4, unsigned len, int16_t *block)
 		block[231 + i] = t4[228 + i] ? -127 : 127;
 	for (i = 0; i < 90; i++)
 		block[346 + i] = t4[342 + i] ? -127 : 127;
+}
+
+/*
+ * lower_mac/tch_reordering.c:94-117 / :119-140 as an OPERATION: the class position tables (EN 300 395-2 Table 4,
+ * 1-based positions inside a 137-bit codec frame) are the caller's data.  The type-2 bits of a full-rate speech
+ * block hold the classes one after the other, every position twice (frame 0, frame 1).
+ */
+void orc_acelp_type2_to_codec(const uint8_t *in, uint8_t *out, const uint8_t *const cls[3], const unsigned ncls[3])
+{
+	const int nbits = (int)(ncls[0] + ncls[1] + ncls[2]);
+	const uint8_t *cur = in;
+	for (int c = 0; c < 3; c++) {
+		for (unsigned bit = 0; bit < ncls[c]; bit++)
+			for (int frame = 0; frame < 2; frame++) {
+				/* a table entry 0 (the reference's class-0 table is one initialiser short) indexes
+				 * out[-1] there: skipped here, the in-bounds index of frame 1 is kept */
+				const int idx = frame * nbits + (int)cls[c][bit] - 1;
+				if (idx >= 0)
+					out[idx] = cur[2 * bit + frame];
+			}
+		cur += 2 * ncls[c];
+	}
+}
+
+void orc_acelp_codec_to_acelp(const uint8_t *in, uint8_t *out, const uint8_t *const cls[3], const unsigned ncls[3])
+{
+	const int nbits = (int)(ncls[0] + ncls[1] + ncls[2]);
+	uint8_t *cur = out;
+	for (int c = 0; c < 3; c++) {
+		for (unsigned bit = 0; bit < ncls[c]; bit++)
+			for (int frame = 0; frame < 2; frame++) {
+				const int idx = frame * nbits + (int)cls[c][bit] - 1;
+				if (idx >= 0)	/* (the reference reads in[-1] for an entry 0: left as it was here) */
+					cur[2 * bit + frame] = in[idx];
+			}
+		cur += 2 * ncls[c];
+	}
 }
 
 /* phy/tetra_burst.c:341-379 with the offsets of :31-47 */

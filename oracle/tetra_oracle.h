@@ -13,8 +13,11 @@
  * Parity status:
  *   - rows X (scrambler), C (CRC-16), R/E (RM(30,14) encoder), F (training
  *     sequence search), D (burst demux), T (TDMA time), E (burst builders),
- *     B (float_to_bits): pinned against the REAL reference objects compiled
- *     into oracle/_ref/ (see oracle/Makefile) and against tests/golden/.
+ *     B (float_to_bits), the ubit -> sbit map of viterbi.c:6-25 (0 -> +127,
+ *     0xff -> 0, anything else -> -127, flush steps = 0) and the ACELP
+ *     re-ordering of tch_reordering.c: pinned against the REAL reference
+ *     objects compiled into oracle/_ref/ (see oracle/Makefile) and against
+ *     tests/golden/.
  *   - rows I (interleaver), U (puncturer), E (conv. encoder), S (sync state
  *     machine), L (lower MAC orchestration): the reference files need
  *     libosmocore headers that are absent here, so they are pinned by the
@@ -30,6 +33,13 @@
  *     by the reference's loop-back test (conv_enc_test.c:336-349); for NOISY
  *     input: PARITY UNPINNED (no libosmocore in this container, no reference
  *     test holds a noisy vector).
+ *
+ * In one line per row, what NO reference output pins (restatement + properties
+ * only): I block (de)interleaver, U puncturers, the two convolutional
+ * encoders, S tetra_burst_sync_in(), L tp_sap_udata_ind() orchestration, V the
+ * add-compare-select / tie rule / traceback of osmo_conv_decode() on noisy
+ * input, the GSMTAP header constants.  Everything else above is pinned by a
+ * real reference object.
  */
 #ifndef TETRA_ORACLE_H
 #define TETRA_ORACLE_H
@@ -189,6 +199,9 @@ struct orc_record {
 	uint16_t type1_len;
 	uint8_t  type1[268];
 	uint8_t  type4[432];		/* descrambled bits (what the traffic dump is made of) */
+	struct orc_tdma_time time_str;	/* tcd->time as copied from t_phy_state at entry (:167-168): what the
+					 * reference's "<NAME> <time> type1:" line prints, also for an SB1 block
+					 * whose SYNC PDU then moves the clock */
 };
 
 /* upper-MAC stand-in.  Same contract as upper_mac_prim_recv()
@@ -249,6 +262,9 @@ uint16_t orc_rm3014_decode_ml(uint32_t rx30, unsigned *nerr);
 int orc_gsmtap_makemsg(const struct orc_tdma_time *tm, int lchan, uint8_t ts, uint8_t ss, int8_t signal_dbm,
 		       uint8_t snr, const uint8_t *bits, unsigned bitlen, uint8_t *out);
 void orc_traffic_block(const uint8_t *type4, unsigned len, int16_t *block690);
+/* ACELP bit re-ordering (lower_mac/tch_reordering.c:94-140) with caller-supplied class position tables */
+void orc_acelp_type2_to_codec(const uint8_t *in, uint8_t *out, const uint8_t *const cls[3], const unsigned ncls[3]);
+void orc_acelp_codec_to_acelp(const uint8_t *in, uint8_t *out, const uint8_t *const cls[3], const unsigned ncls[3]);
 
 /* ---- row B: float_to_bits (float_to_bits.c) ---------------------------- */
 void orc_float_to_bits(const float *in, size_t n, uint8_t *out2n, int afc,

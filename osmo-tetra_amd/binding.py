@@ -50,7 +50,8 @@ class UnitData(C.Structure):
     _fields_ = [("type", C.c_int), ("blk_num", C.c_int), ("lchan", C.c_int), ("crc_ok", C.c_int),
                 ("crc", C.c_uint16), ("scrambling_code", C.c_uint32), ("tdma_time", TdmaTime),
                 ("burst_seq", C.c_uint32), ("burst_type", C.c_int), ("type1_len", C.c_uint16),
-                ("type1", u8p), ("traffic", C.c_int), ("type4", u8p), ("type4_len", C.c_uint16)]
+                ("type1", u8p), ("traffic", C.c_int), ("type4", u8p), ("type4_len", C.c_uint16),
+                ("time_str", TdmaTime)]
 
 
 class SyncSlot(C.Structure):
@@ -85,7 +86,7 @@ def declared_symbols():
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+)?(?:struct\s+\w+|enum\s+\w+|int|void|uint32_t|size_t|char)\s*\*?\s*(\w+)\s*\(",
                        txt, flags=re.M)
-    return sorted(set(n for n in names if n.startswith(("tgpu_", "tetra_"))))
+    return sorted(set(n for n in names if n.startswith(("tgpu_", "tetra_", "tp_sap_", "get_punctured"))))
 
 
 def lib():
@@ -163,6 +164,15 @@ def lib():
     L.tgpu_sync_stream_grid_finish.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.POINTER(SyncResult), C.c_void_p]
     L.tgpu_sync_result_free.argtypes = [C.POINTER(SyncResult)]
+    L.tgpu_acelp_build_map.argtypes = [C.POINTER(u8p), C.POINTER(C.c_uint), C.c_int, C.POINTER(C.c_int32)]
+    L.tgpu_acelp_set_tables.argtypes = [C.POINTER(u8p), C.POINTER(C.c_uint)]
+    L.tetra_acelp_type2_to_codec.argtypes = [u8p, u8p]
+    L.tetra_acelp_type2_to_codec.restype = None
+    L.tetra_acelp_codec_to_acelp.argtypes = [u8p, u8p]
+    L.tetra_acelp_codec_to_acelp.restype = None
+    L.tgpu_reorder_create.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.tgpu_reorder_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.tgpu_reorder_destroy.argtypes = [C.c_void_p]
     L.tgpu_sync_front_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
                                        C.POINTER(C.c_float), C.c_void_p]
     L.tgpu_synth_slots.argtypes = [C.POINTER(SynthCfg), u8p, C.c_size_t, u8p, u8p]
@@ -466,6 +476,65 @@ class ConvDecoder:
             pass
 
 
+def _acelp_tables(cls):
+    arrs = [np.ascontiguousarray(c, np.uint8) for c in cls]
+    ptrs = (u8p * 3)(*[a.ctypes.data_as(u8p) for a in arrs])
+    ns = (C.c_uint * 3)(*[len(a) for a in arrs])
+    return arrs, ptrs, ns
+
+
+def acelp_build_map(cls, to_codec):
+    """tgpu_acelp_build_map: index map (source position per destination, -1 = none) of one direction of the ACELP
+    re-ordering for the caller's class position tables cls = (class0, class1, class2)"""
+    arrs, ptrs, ns = _acelp_tables(cls)
+    m = np.zeros(2 * sum(len(a) for a in arrs), np.int32)
+    rc = lib().tgpu_acelp_build_map(ptrs, ns, int(bool(to_codec)), m.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc < 0:
+        _chk(rc, "tgpu_acelp_build_map")
+    assert rc == len(m)
+    return m
+
+
+def acelp_set_tables(cls):
+    arrs, ptrs, ns = _acelp_tables(cls)
+    _chk(lib().tgpu_acelp_set_tables(ptrs, ns), "tgpu_acelp_set_tables")
+
+
+def acelp_type2_to_codec(bits, out=None):
+    """the reference's tetra_acelp_type2_to_codec() (host buffers, tables from acelp_set_tables)"""
+    b = _np_u8(bits)
+    o = np.zeros(len(b), np.uint8) if out is None else out
+    lib().tetra_acelp_type2_to_codec(b.ctypes.data_as(u8p), o.ctypes.data_as(u8p))
+    return o
+
+
+def acelp_codec_to_acelp(bits, out=None):
+    b = _np_u8(bits)
+    o = np.zeros(len(b), np.uint8) if out is None else out
+    lib().tetra_acelp_codec_to_acelp(b.ctypes.data_as(u8p), o.ctypes.data_as(u8p))
+    return o
+
+
+class Reorder:
+    """tgpu_reorder_*: a fixed index map applied to batches of blocks resident in HBM"""
+
+    def __init__(self, engine, src_of_dst):
+        self._h = C.c_void_p()
+        m = np.ascontiguousarray(src_of_dst, np.int32)
+        self.nbits = len(m)
+        _chk(lib().tgpu_reorder_create(engine._h, m.ctypes.data_as(C.POINTER(C.c_int32)), len(m), C.byref(self._h)),
+             "tgpu_reorder_create")
+
+    def execute(self, d_in_ptr, nblocks, d_out_ptr, hip_stream=0):
+        _chk(lib().tgpu_reorder_execute(self._h, C.c_void_p(d_in_ptr), nblocks, C.c_void_p(d_out_ptr),
+                                        C.c_void_p(hip_stream)), "tgpu_reorder_execute")
+
+    def close(self):
+        if self._h:
+            lib().tgpu_reorder_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 def get_punctured_rate(pu, mother, n):
     """the reference's puncturer under its own name (host buffers); returns (rc, out)"""
     m = _np_u8(mother)
@@ -594,7 +663,8 @@ class Channel:
             if offset in (0, 0xFFFFFFFF):
                 d = dict(burst_seq=ud.burst_seq, burst_type=ud.burst_type, type=ud.type, blk_num=ud.blk_num,
                          lchan=ud.lchan, crc_ok=ud.crc_ok, traffic=ud.traffic, crc=ud.crc,
-                         scramb=ud.scrambling_code, time=(ud.tdma_time.tn, ud.tdma_time.fn, ud.tdma_time.mn))
+                         scramb=ud.scrambling_code, time=(ud.tdma_time.tn, ud.tdma_time.fn, ud.tdma_time.mn),
+                         time_str=(ud.time_str.tn, ud.time_str.fn, ud.time_str.mn))
                 if ud.traffic:
                     d["type1"] = b""
                     d["type4"] = bytes(bytearray(ud.type4[: ud.type4_len]))

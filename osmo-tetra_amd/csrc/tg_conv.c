@@ -17,6 +17,7 @@
 #include "tg_internal.h"
 
 struct tgpu_conv {
+	struct tgpu_engine *eng;
 	int code;			/* 0: rate-1/4 CCH code, 1: rate-1/3 speech code */
 	int g3;				/* some step receives g3 */
 	uint32_t type3_len, type2_len;
@@ -33,9 +34,13 @@ int tgpu_conv_create(struct tgpu_engine *eng, int punct, int mother_rate, uint32
 	*out = NULL;
 	if (tg_conv_build_steps(punct, mother_rate, type3_len, type2_len, steps))
 		return TGPU_EINVAL;
+	int brc = tgpi_engine_bind(eng);
+	if (brc)
+		return brc;
 	struct tgpu_conv *cv = calloc(1, sizeof(*cv));
 	if (!cv)
 		return TGPU_ENOMEM;
+	cv->eng = eng;
 	cv->code = (mother_rate == 3);
 	cv->g3 = tg_conv_uses_g3(steps, type2_len);
 	cv->type3_len = type3_len;
@@ -58,6 +63,9 @@ int tgpu_conv_execute(struct tgpu_conv *cv, const void *d_type3, uint64_t nblock
 {
 	if (!cv || (nblocks && (!d_type3 || !d_type2)))
 		return TGPU_EINVAL;
+	int brc = tgpi_engine_bind(cv->eng);
+	if (brc)
+		return brc;
 	return tgk_conv(cv->code, cv->g3, (const uint8_t *)d_type3, nblocks, cv->type3_len, cv->type2_len, cv->d_steps,
 			(uint8_t *)d_type2, hip_stream);
 }

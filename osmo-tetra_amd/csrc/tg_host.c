@@ -28,6 +28,20 @@ struct tgpu_engine {
 
 int tgpu_plan_set_fastpath(struct tgpu_plan *p, int on);
 
+/* HIP's current device is per thread: every entry point that allocates, copies or launches makes the engine's
+ * device current first (a host with one thread per channel, or engines on several GPUs in one process) */
+int tgpi_engine_bind(const struct tgpu_engine *eng)
+{
+	int cur = -1;
+	if (!eng)
+		return TGPU_EINVAL;
+	if (hipGetDevice(&cur) == hipSuccess && cur == eng->device)
+		return TGPU_OK;
+	hipError_t e = hipSetDevice(eng->device);
+	return e == hipSuccess ? TGPU_OK : (int)e;
+}
+#define BIND(eng) do { int b_ = tgpi_engine_bind(eng); if (b_) return b_; } while (0)
+
 #define TGPU_NKINDS 4	/* trellis kinds TG_KIND_SB1 / _216 / _432 / _168; index 4 = BBK in block-mode lists */
 
 struct tgpu_plan {
@@ -115,6 +129,7 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 {
 	if (!eng || !out || !max_slots || !max_chan)
 		return TGPU_EINVAL;
+	BIND(eng);
 	struct tgpu_plan *p = calloc(1, sizeof(*p));
 	if (!p)
 		return TGPU_ENOMEM;
@@ -189,6 +204,8 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 			     const uint8_t *type_b, size_t type_st, const uint8_t *chan_b, size_t chan_st,
 			     uint32_t nchan, const uint32_t *chan_code)
 {
+	if (p)
+		BIND(p->eng);
 	if (nslots > p->max_slots || nchan > p->max_chan)
 		return TGPU_ECAPACITY;
 	/* pass 1: validate and count, so that the upload arena can be laid out exactly */
@@ -285,6 +302,7 @@ int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packe
 {
 	if (!p || !ngrid)
 		return TGPU_EINVAL;
+	BIND(p->eng);
 	if (ngrid > p->max_slots)
 		return TGPU_ECAPACITY;
 	if (!p->d_grid) {
@@ -309,6 +327,7 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 {
 	if (!p || !ngrid || !h_bits || !p->d_grid)
 		return TGPU_EINVAL;
+	BIND(p->eng);
 	if (ngrid > p->max_slots)
 		return TGPU_ECAPACITY;
 	const size_t nwords = ((size_t)ngrid + 31) / 32, nblk = ((size_t)ngrid + 1023) / 1024;
@@ -431,6 +450,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 #define MARK(i) do { if (ev) { hipError_t e_ = hipEventRecord(ev[i], (hipStream_t)stream); if (e_ != hipSuccess) return (int)e_; } } while (0)
 	if (!p || !d_stream || !d_rec)
 		return TGPU_EINVAL;
+	BIND(p->eng);
 	if (!p->loaded || (soft && p->packed_ready) || p->block_mode)
 		return TGPU_ESTATE;
 	MARK(0);
@@ -527,6 +547,7 @@ int tgpu_plan_set_fastpath(struct tgpu_plan *p, int on)
 {
 	if (!p)
 		return TGPU_EINVAL;
+	BIND(p->eng);
 	if (on && !p->d_dirty) {
 		hipError_t e = hipMalloc((void **)&p->d_dirty, 4 * (2 + 3 * (size_t)p->max_slots));
 		if (e != hipSuccess)
@@ -540,6 +561,7 @@ int tgpu_plan_set_rm_decode(struct tgpu_plan *p, int on)
 {
 	if (!p)
 		return TGPU_EINVAL;
+	BIND(p->eng);
 	if (on) {
 		const uint32_t *t = tgi_rm_leader_table();
 		if (!t)
@@ -564,6 +586,7 @@ int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t 
 {
 	if (!p || (nblocks && (!blk_off || !blk_type || !blk_code)))
 		return TGPU_EINVAL;
+	BIND(p->eng);
 	if (nblocks > p->max_slots)
 		return TGPU_ECAPACITY;
 	/* the distinct scrambling codes become the mask-table entries 1 + u (what channels are in slot mode) */
@@ -661,6 +684,7 @@ int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t 
 static int plan_run_blocks(struct tgpu_plan *p, const uint8_t *d_bits, uint8_t *d_rec, void *stream)
 {
 	int rc;
+	BIND(p->eng);
 	if (!p->nslots)
 		return TGPU_OK;
 	if ((rc = tgk_front_blocks(d_bits, p->d_slot_off, p->nslots, p->d_packed, stream)))
@@ -692,6 +716,7 @@ int tgpu_float_to_bits(struct tgpu_engine *eng, const float *d_in, uint64_t n, u
 {
 	if (!eng || !d_in || !d_bits)
 		return TGPU_EINVAL;
+	BIND(eng);
 	return tgk_float_to_bits(d_in, n, d_bits, d_soft, stream);
 }
 
@@ -700,6 +725,7 @@ int tgpu_float_to_bits_afc(struct tgpu_engine *eng, const float *d_in, uint64_t 
 {
 	if (!eng || !d_in || !d_bits || !filter_state)
 		return TGPU_EINVAL;
+	BIND(eng);
 	float *d_state = NULL;
 	HCHK(hipMalloc((void **)&d_state, sizeof(float)));
 	int rc = (int)hipMemcpyAsync(d_state, filter_state, sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
@@ -799,6 +825,7 @@ int tgpu_plan_read_packed(struct tgpu_plan *p, uint32_t *out_words)
 {
 	if (!p || !out_words || !p->loaded)
 		return TGPU_EINVAL;
+	BIND(p->eng);
 	HCHK(hipDeviceSynchronize());
 	if (p->nslots)
 		HCHK(hipMemcpy(out_words, p->d_packed, (size_t)p->nslots * TG_PACKED_WORDS * 4, hipMemcpyDeviceToHost));
@@ -809,6 +836,7 @@ int tgpu_plan_final_codes(struct tgpu_plan *p, const uint8_t *d_rec, uint32_t *c
 {
 	if (!p || !chan_code_out || !p->loaded)
 		return TGPU_EINVAL;
+	BIND(p->eng);
 	(void)d_rec;
 	/* code in effect after the batch = mask entry of the channel's last slot */
 	HCHK(hipDeviceSynchronize());

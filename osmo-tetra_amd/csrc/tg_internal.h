@@ -48,6 +48,10 @@ int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_
 	      const uint32_t *d_sb_code, uint32_t nsb, const uint32_t *d_list_sb, const uint32_t *d_slot_chan,
 	      uint32_t *d_masks, void *stream);
 
+/* out[b][j] = in[b][src[j]] for src[j] >= 0 (tg_reorder.c) */
+int tgk_reorder(const uint8_t *d_in, unsigned long long nblocks, uint32_t nbits, const int32_t *d_src, uint8_t *d_out,
+		void *stream);
+
 /* stream mode: per-slot arrays and item lists from classification words + "delivered" bitmap;
  * d_blk: 3 * (ceil(n / 1024) + 1) words, the totals (sb, 216 items, 432 items) end up at d_blk[3 * nblocks] */
 int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uint32_t n, uint32_t *d_blk,
@@ -61,6 +65,10 @@ const uint16_t *tgi_rm_parity(void);
 int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity);
 #define TGK_F_BLOCK 1	/* tgk_vit flags: items are blocks on their own */
 #define TGK_F_RM    2	/* correct the BBK with the RM(30,14) decoder before its first 14 bits are kept */
+
+/* make the engine's device the calling thread's current HIP device (every allocating / launching entry point does) */
+struct tgpu_engine;
+int tgpi_engine_bind(const struct tgpu_engine *eng);
 
 /* plan internals used by the stream synchroniser (tg_stream.c) */
 struct tgpu_plan;

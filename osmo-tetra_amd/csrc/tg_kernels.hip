@@ -1757,6 +1757,39 @@ void k_conv(const uint8_t *__restrict__ type3, unsigned long long nblocks, uint3
 }
 
 /* ------------------------------------------------------------------------- */
+/* k_reorder: a fixed index map applied to every block of a batch (ACELP re-ordering, tg_reorder.c)  */
+/* ------------------------------------------------------------------------- */
+/* out[b][j] = in[b][src[j]] where src[j] >= 0; destinations without a source keep what d_out held (the reference's
+ * behaviour for a table that names a position never, lower_mac/tch_reordering.c:94-117).  One lane per output byte:
+ * stores are consecutive, loads stay inside the block's row. */
+__global__ __launch_bounds__(256)
+void k_reorder(const uint8_t *__restrict__ in, unsigned long long nblocks, uint32_t nbits, const int32_t *__restrict__ src,
+	       uint8_t *__restrict__ out)
+{
+	const unsigned long long total = nblocks * nbits;
+	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+		const unsigned long long b = i / nbits;
+		const uint32_t j = (uint32_t)(i - b * nbits);
+		const int32_t s = src[j];
+		if (s >= 0)
+			out[i] = in[b * nbits + (uint32_t)s];
+	}
+}
+
+extern "C" int tgk_reorder(const uint8_t *d_in, unsigned long long nblocks, uint32_t nbits, const int32_t *d_src, uint8_t *d_out,
+			   void *stream)
+{
+	if (!nblocks)
+		return 0;
+	unsigned long long blocks = (nblocks * nbits + 255) / 256;
+	if (blocks > 256 * 32)
+		blocks = 256 * 32;
+	hipLaunchKernelGGL(k_reorder, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, d_in, nblocks, nbits, d_src, d_out);
+	return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
 /* scrambling-code forward fill: inclusive running max over (chan<<32 | entry) */
 /* ------------------------------------------------------------------------- */
 #define FILL_BLOCK 1024

@@ -203,6 +203,84 @@ static int exact_find(const struct walk *w, uint64_t pos, uint32_t n, uint32_t m
 	return rc;
 }
 
+/*
+ * The reference's state machine call by call (phy/tetra_burst_sync.c:54-154 on a 4096-byte window that slides over
+ * the stream), every search on the bytes.  This is what the closed form below is checked against; the walk itself
+ * uses it for feed sizes outside the range the closed form was derived for (below 21 a sequence rejected in the
+ * skewed look-ahead zone can become acceptable when the window slides; above 296 a call can push the window past
+ * the expected frame start).  Where the reference itself would compute a negative memmove() offset the input is
+ * refused (TGPU_EINVAL) rather than guessed at.
+ */
+static int walk_per_call(struct walk *w, uint32_t flags, uint64_t anchor)
+{
+	uint64_t bs = 0, nfs = 0, in_buf = 0;
+	uint32_t seq = 0, tn_adds = 0;
+	int state = RX_S_UNLOCKED, rc;
+	unsigned int offs = 0;
+	for (uint64_t k = 1; k <= w->ncalls; k++) {
+		const uint64_t n = fed(w, k) - fed(w, k - 1);
+		if (4096 - in_buf < n) {	/* make_bitbuf_space(), :38-52 */
+			const uint64_t delta = n - (4096 - in_buf);
+			in_buf -= delta;
+			bs += delta;
+		}
+		in_buf += n;
+		if (state == RX_S_UNLOCKED) {
+			if (in_buf < 2 * TG_SLOT_BITS)
+				continue;
+			if (exact_find(w, bs, (uint32_t)in_buf, 1u << TETRA_TRAIN_SYNC, &offs) < 0)
+				continue;
+			if ((rc = push_event(w, TGPU_EV_FOUND_SYNC, bs, offs)))
+				return rc;
+			state = RX_S_KNOW_FSTART;
+			nfs = bs + offs + 296;
+			continue;
+		}
+		if (state == RX_S_KNOW_FSTART) {
+			if (bs + in_buf < nfs)
+				continue;
+			if (nfs < bs)
+				return TGPU_EINVAL;	/* the reference's offset would be negative here */
+			in_buf -= nfs - bs;
+			bs = nfs;
+			nfs += TG_SLOT_BITS;
+			state = RX_S_LOCKED;
+		}
+		if (in_buf < TG_SLOT_BITS)
+			continue;
+		seq++;
+		tn_adds++;
+		if (!(flags & TGPU_SYNC_NO_BURST_EVENTS) && (rc = push_event(w, TGPU_EV_BURST, bs, (uint32_t)in_buf)))
+			return rc;
+		const int type = exact_find(w, bs, (uint32_t)in_buf, MASK_LOCKED, &offs);
+		const int ongrid = w->cls && bs >= anchor && (bs - anchor) % TG_SLOT_BITS == 0;
+		const uint64_t gi = ongrid ? (bs - anchor) / TG_SLOT_BITS : 0;
+		if (type == TETRA_TRAIN_SYNC || type == TETRA_TRAIN_NORM_1 || type == TETRA_TRAIN_NORM_2) {
+			if (offs == (type == TETRA_TRAIN_SYNC ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF)) {
+				if ((rc = deliver_slot(w, bs, type, seq, tn_adds, ongrid, gi)))
+					return rc;
+				tn_adds = 0;
+			} else {
+				if ((rc = push_event(w, type == TETRA_TRAIN_SYNC ? TGPU_EV_SYNC_MISPLACED : TGPU_EV_NORM_MISPLACED, bs, offs)))
+					return rc;
+				if (type == TETRA_TRAIN_SYNC)
+					state = RX_S_UNLOCKED;
+			}
+		} else {
+			if ((rc = push_event(w, TGPU_EV_NO_TRAIN, bs, 0)))
+				return rc;
+			state = RX_S_UNLOCKED;
+		}
+		in_buf -= TG_SLOT_BITS;
+		bs += TG_SLOT_BITS;
+		nfs += TG_SLOT_BITS;
+	}
+	w->out->final_state = state;
+	w->out->tail_tn_adds = tn_adds;
+	w->out->burst_seq = seq;
+	return TGPU_OK;
+}
+
 int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor,
 		   const uint32_t *cls, const uint16_t *ysum, uint32_t ncls, uint32_t flags, struct tgpu_sync_result *out)
 {
@@ -228,6 +306,9 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 			return TGPU_ENOMEM;
 		w.cap_slots = ncls + 16;
 	}
+
+	if (chunk < TGPU_SYNC_CHUNK_MIN || chunk > TGPU_SYNC_CHUNK_MAX || (flags & TGPU_SYNC_PER_CALL))
+		return walk_per_call(&w, flags, anchor);
 
 	uint64_t bs = 0;	/* bitbuf_start_bitnum */
 	uint64_t k = 0;		/* index of the last call that has run */
@@ -530,6 +611,9 @@ int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_
 		return TGPU_EINVAL;
 	if (!nslots)
 		return TGPU_OK;
+	int brc = tgpi_engine_bind(eng);
+	if (brc)
+		return brc;
 	uint32_t *d_cls = NULL, *d_packed = NULL;
 	/* classification words, then (same allocation) the SYNC-sequence summaries */
 	hipError_t e = hipMalloc((void **)&d_cls, (size_t)nslots * 6);

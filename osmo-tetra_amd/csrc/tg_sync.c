@@ -24,6 +24,7 @@
 
 #include "tetra_gpu.h"
 #include "tg_layout.h"
+#include "tg_internal.h"
 
 /* ------------------------------------------------------------------------- */
 /* small reference-compatible helpers                                         */
@@ -157,6 +158,26 @@ struct tgpu_channel {
 	int *is_traffic;
 	bool *blk1_stolen, *blk2_stolen;
 	int last_error;
+
+	/* block queue of the tp_sap_udata_ind() seam (allocated on first use) */
+	struct tgpu_plan *bplan;
+	uint32_t bq_cap, bq_n;
+	struct bq_item *bq;
+	uint8_t *bq_bits;	/* pinned, bq_cap * BQ_STRIDE */
+	uint8_t *bq_rec;	/* pinned, bq_cap * TGPU_REC_BYTES */
+	uint8_t *d_bq_bits, *d_bq_rec;
+	uint64_t *bq_off;
+	uint8_t *bq_type;
+	uint32_t *bq_code;
+};
+
+#define BQ_STRIDE 432u
+
+struct bq_item {
+	uint8_t type;			/* enum tp_sap_data_type */
+	uint8_t blk_num;
+	uint16_t len;
+	struct tetra_tdma_time time;	/* t_phy_state.time when the block was handed over (tetra_lower_mac.c:167) */
 };
 
 int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unitdata_cb cb, tgpu_event_cb ev,
@@ -164,6 +185,9 @@ int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unit
 {
 	if (!eng || !out || !batch_slots)
 		return TGPU_EINVAL;
+	int brc = tgpi_engine_bind(eng);
+	if (brc)
+		return brc;
 	struct tgpu_channel *ch = calloc(1, sizeof(*ch));
 	if (!ch)
 		return TGPU_ENOMEM;
@@ -211,6 +235,15 @@ void tgpu_channel_destroy(struct tgpu_channel *ch)
 	if (ch->d_slots) (void)hipFree(ch->d_slots);
 	if (ch->d_rec) (void)hipFree(ch->d_rec);
 	tgpu_plan_destroy(ch->plan);
+	if (ch->bq_bits) (void)hipHostFree(ch->bq_bits);
+	if (ch->bq_rec) (void)hipHostFree(ch->bq_rec);
+	if (ch->d_bq_bits) (void)hipFree(ch->d_bq_bits);
+	if (ch->d_bq_rec) (void)hipFree(ch->d_bq_rec);
+	if (ch->bplan) tgpu_plan_destroy(ch->bplan);
+	free(ch->bq);
+	free(ch->bq_off);
+	free(ch->bq_type);
+	free(ch->bq_code);
 	free(ch->pend);
 	free(ch->h_off);
 	free(ch->h_type);
@@ -278,8 +311,27 @@ static unsigned gather_type5(const uint8_t *slot, int btype, enum tp_sap_data_ty
 	}
 }
 
+/* SYNC-PDU fields of a record (slot mode: a SYNC burst's record; block mode: an SB1 block's record) */
+static void sync_info_of(const uint8_t *rec, struct tgpu_sync_info *out)
+{
+	uint32_t f0, f1, code;
+	memcpy(&f0, rec + TG_REC_SBF0, 4);
+	memcpy(&f1, rec + TG_REC_SBF1, 4);
+	memcpy(&code, rec + TG_REC_SBCODE, 4);
+	out->cc = (uint8_t)f0;
+	out->tn = (uint8_t)(f0 >> 8);
+	out->fn = (uint8_t)(f0 >> 16);
+	out->mn = (uint8_t)(f0 >> 24);
+	out->mcc = (uint16_t)f1;
+	out->mnc = (uint16_t)(f1 >> 16);
+	out->scramb_init = code;
+}
+
+/* slot != NULL: the block sits in a queued burst; else raw5 / nraw5 are the block's own type-5 bits (block queue).
+ * phy_time: the channel's clock, or the reference's global t_phy_state.time for the tp_sap_udata_ind() seam. */
 static void deliver_block(struct tgpu_channel *ch, const struct pending *pd, const uint8_t *slot,
-			  const uint8_t *rec, const struct tgpu_block *b)
+			  const uint8_t *rec, const struct tgpu_block *b, const uint8_t *raw5, unsigned nraw5,
+			  struct tetra_tdma_time *phy_time)
 {
 	struct tgpu_unitdata ud;
 	uint8_t type4[432];
@@ -291,7 +343,8 @@ static void deliver_block(struct tgpu_channel *ch, const struct pending *pd, con
 	ud.burst_type = (enum tetra_train_seq)pd->type;
 	ud.lchan = TETRA_LC_UNKNOWN;
 
-	ch->cell_time = ch->phy_time;							/* :167 */
+	ch->cell_time = *phy_time;							/* :167 */
+	ud.time_str = ch->cell_time;							/* :168 */
 	if (b->type == TPSAP_T_SB2 && is_bnch(&ch->cell_time))				/* :170-173 */
 		ud.lchan = TETRA_LC_BNCH;
 
@@ -302,7 +355,13 @@ static void deliver_block(struct tgpu_channel *ch, const struct pending *pd, con
 
 	if (*ch->is_traffic && (b->type == TPSAP_T_SCH_F || (b->blk_num == BLK_2 && !*ch->blk2_stolen))) {
 		/* :198-241 -- traffic block: not decoded, handed over as descrambled type-4 bits */
-		unsigned n = gather_type5(slot, pd->type, b->type, b->blk_num, type4);
+		unsigned n;
+		if (slot)
+			n = gather_type5(slot, pd->type, b->type, b->blk_num, type4);
+		else {
+			n = nraw5 < 432 ? nraw5 : 432;
+			memcpy(type4, raw5, n);
+		}
 		uint32_t st = ud.scrambling_code;
 		for (unsigned i = 0; i < n; i++)
 			type4[i] ^= (uint8_t)scramb_next(&st);
@@ -324,7 +383,7 @@ static void deliver_block(struct tgpu_channel *ch, const struct pending *pd, con
 	case TPSAP_T_SB1: {								/* :283-310 */
 		if (ud.crc_ok) {
 			struct tgpu_sync_info si;
-			tgpu_record_sync_info(rec, &si);
+			sync_info_of(rec, &si);
 			ch->colour_code = si.cc;
 			ch->cell_time.tn = si.tn;
 			ch->cell_time.fn = si.fn;
@@ -333,7 +392,7 @@ static void deliver_block(struct tgpu_channel *ch, const struct pending *pd, con
 			ch->mnc = si.mnc;
 			ch->scramb_init = si.scramb_init;
 		}
-		ch->phy_time = ch->cell_time;
+		*phy_time = ch->cell_time;						/* :302 */
 		ud.lchan = TETRA_LC_BSCH;
 		break;
 	}
@@ -359,30 +418,45 @@ static void deliver_block(struct tgpu_channel *ch, const struct pending *pd, con
 	}
 }
 
-int tgpu_channel_flush(struct tgpu_channel *ch)
+static int flush_blocks(struct tgpu_channel *ch);
+
+static int channel_fail(struct tgpu_channel *ch, int rc, uint32_t arg)
 {
-	if (!ch)
-		return TGPU_EINVAL;
+	ch->last_error = rc;
+	if (ch->ev)
+		ch->ev(TGPU_EV_ERROR, (uint32_t)rc, arg, ch->priv);
+	return rc;
+}
+
+/* decode the queued bursts on the GPU; on failure the batch is given up, but not silently: its time steps still
+ * advance the channel's clock (later bursts keep the reference's TDMA time), last_error stays set until
+ * tgpu_channel_clear_error(), and the event callback gets TGPU_EV_ERROR(error, bursts lost) */
+static int flush_slots(struct tgpu_channel *ch)
+{
 	const uint32_t n = ch->n_pending;
 	if (!n)
 		return TGPU_OK;
-	ch->n_pending = 0;
-
-	hipError_t e;
+	hipError_t e = hipSuccess;
 	int rc;
+	if ((rc = tgpi_engine_bind(ch->eng)))
+		return channel_fail(ch, rc, n);
 	for (uint32_t i = 0; i < n; i++)
 		ch->h_type[i] = ch->pend[i].type;
-	if ((rc = tgpu_plan_load(ch->plan, n, ch->h_off, ch->h_type, ch->h_chan, 1, &ch->scramb_init)))
-		return ch->last_error = rc;
-	if ((e = hipMemcpyAsync(ch->d_slots, ch->h_slots, (size_t)n * SLOT_STRIDE, hipMemcpyHostToDevice, ch->stream)))
-		return ch->last_error = (int)e;
-	if ((rc = tgpu_plan_execute(ch->plan, ch->d_slots, ch->d_rec, ch->stream)))
-		return ch->last_error = rc;
-	if ((e = hipMemcpyAsync(ch->h_rec, ch->d_rec, (size_t)n * TGPU_REC_BYTES, hipMemcpyDeviceToHost, ch->stream)))
-		return ch->last_error = (int)e;
-	if ((e = hipStreamSynchronize(ch->stream)))
-		return ch->last_error = (int)e;
-
+	rc = tgpu_plan_load(ch->plan, n, ch->h_off, ch->h_type, ch->h_chan, 1, &ch->scramb_init);
+	if (!rc && (e = hipMemcpyAsync(ch->d_slots, ch->h_slots, (size_t)n * SLOT_STRIDE, hipMemcpyHostToDevice, ch->stream)))
+		rc = (int)e;
+	if (!rc)
+		rc = tgpu_plan_execute(ch->plan, ch->d_slots, ch->d_rec, ch->stream);
+	if (!rc && (e = hipMemcpyAsync(ch->h_rec, ch->d_rec, (size_t)n * TGPU_REC_BYTES, hipMemcpyDeviceToHost, ch->stream)))
+		rc = (int)e;
+	if (!rc && (e = hipStreamSynchronize(ch->stream)))
+		rc = (int)e;
+	ch->n_pending = 0;
+	if (rc) {
+		for (uint32_t i = 0; i < n; i++)
+			tetra_tdma_time_add_tn(&ch->phy_time, ch->pend[i].tn_adds);
+		return channel_fail(ch, rc, n);
+	}
 	for (uint32_t i = 0; i < n; i++) {
 		const struct pending *pd = &ch->pend[i];
 		const uint8_t *rec = ch->h_rec + (size_t)i * TGPU_REC_BYTES;
@@ -392,9 +466,31 @@ int tgpu_channel_flush(struct tgpu_channel *ch)
 			tetra_tdma_time_add_tn(&ch->phy_time, 1);			/* phy/tetra_burst_sync.c:113 */
 		int nb = tgpu_record_blocks(rec, blk);
 		for (int k = 0; k < nb; k++)
-			deliver_block(ch, pd, slot, rec, &blk[k]);
+			deliver_block(ch, pd, slot, rec, &blk[k], NULL, 0, &ch->phy_time);
 	}
 	return TGPU_OK;
+}
+
+int tgpu_channel_flush(struct tgpu_channel *ch)
+{
+	if (!ch)
+		return TGPU_EINVAL;
+	int rc = flush_slots(ch);
+	int rc2 = flush_blocks(ch);
+	if (rc || rc2)
+		return rc ? rc : rc2;
+	return ch->last_error;		/* sticky: a batch an earlier automatic flush lost is reported here too */
+}
+
+int tgpu_channel_last_error(const struct tgpu_channel *ch)
+{
+	return ch ? ch->last_error : TGPU_EINVAL;
+}
+
+void tgpu_channel_clear_error(struct tgpu_channel *ch)
+{
+	if (ch)
+		ch->last_error = TGPU_OK;
 }
 
 int tgpu_channel_scramb_init(const struct tgpu_channel *ch, uint32_t *code)
@@ -420,7 +516,7 @@ int tgpu_channel_deliver(struct tgpu_channel *ch, uint32_t n, const struct tgpu_
 			tetra_tdma_time_add_tn(&ch->phy_time, 1);
 		int nb = tgpu_record_blocks(rec, blk);
 		for (int k = 0; k < nb; k++)
-			deliver_block(ch, &pd, h_stream + slots[i].off, rec, &blk[k]);
+			deliver_block(ch, &pd, h_stream + slots[i].off, rec, &blk[k], NULL, 0, &ch->phy_time);
 	}
 	return TGPU_OK;
 }
@@ -435,7 +531,7 @@ static void queue_burst(struct tgpu_channel *ch, const uint8_t *burst, int type)
 	memcpy(ch->h_slots + (size_t)ch->n_pending * SLOT_STRIDE, burst, TG_SLOT_BITS);
 	ch->n_pending++;
 	if (ch->n_pending >= ch->batch_slots)
-		tgpu_channel_flush(ch);
+		(void)flush_slots(ch);	/* a failure is kept in last_error and reported through TGPU_EV_ERROR */
 }
 
 /* ------------------------------------------------------------------------- */
@@ -472,6 +568,147 @@ int tgpu_channel_burst_rx(struct tgpu_channel *ch, const uint8_t *burst, unsigne
 	if (type == TETRA_TRAIN_SYNC || type == TETRA_TRAIN_NORM_1 || type == TETRA_TRAIN_NORM_2)
 		queue_burst(ch, burst, type);
 	return ch->last_error ? ch->last_error : TGPU_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* tp_sap_udata_ind() / tetra_burst_rx_cb() under the reference's own signatures */
+/* ------------------------------------------------------------------------- */
+/*
+ * libosmo-tetra-phy.a (phy/tetra_burst_sync.o + phy/tetra_burst.o) references two symbols it does not define:
+ * tp_sap_udata_ind (phy/tetra_burst.h:18) and tetra_tdma_time_add_tn.  Both are exported here, so a host can keep the
+ * reference's PHY objects unchanged and link this library in place of libosmo-tetra-mac.a: priv = the
+ * struct tgpu_channel * (where the reference passes tms).  The reference's lower MAC reads and, after a good SYNC
+ * PDU, writes the global t_phy_state.time (tetra_lower_mac.c:167,302), which phy/tetra_burst_sync.c:34 defines; the
+ * definition below is weak, i.e. the PHY object's own one is used when it is linked, and this one when the host has
+ * no such object.
+ *
+ * Blocks are queued and decoded in batches (block mode of the plan: tgpu_plan_load_blocks).  An SB1 block ends its
+ * batch and is decoded before tp_sap_udata_ind() returns: the scrambling code and the time it brings are in force
+ * for the very next block (the BBK and SB2 of the same burst), exactly as in the reference.  Everything else is
+ * delivered when the queue is full, with the next SB1, or by tgpu_channel_flush().
+ */
+struct tetra_phy_state t_phy_state __attribute__((weak));
+
+static int bq_alloc(struct tgpu_channel *ch)
+{
+	if (ch->bq)
+		return TGPU_OK;
+	const size_t n = (size_t)ch->batch_slots * 3 + 3;
+	int rc = tgpu_plan_create(ch->eng, (uint32_t)n, 4, &ch->bplan);
+	if (rc)
+		return rc;
+	hipError_t e = hipSuccess;
+	ch->bq = calloc(n, sizeof(*ch->bq));
+	ch->bq_off = calloc(n, sizeof(uint64_t));
+	ch->bq_type = calloc(n, 1);
+	ch->bq_code = calloc(n, 4);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->bq_bits, n * BQ_STRIDE, 0);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->bq_rec, n * TGPU_REC_BYTES, 0);
+	if (e == hipSuccess) e = hipMalloc((void **)&ch->d_bq_bits, n * BQ_STRIDE);
+	if (e == hipSuccess) e = hipMalloc((void **)&ch->d_bq_rec, n * TGPU_REC_BYTES);
+	if (e != hipSuccess || !ch->bq || !ch->bq_off || !ch->bq_type || !ch->bq_code)
+		return e != hipSuccess ? (int)e : TGPU_ENOMEM;
+	for (size_t i = 0; i < n; i++)
+		ch->bq_off[i] = i * BQ_STRIDE;
+	ch->bq_cap = (uint32_t)n;
+	return TGPU_OK;
+}
+
+static int flush_blocks(struct tgpu_channel *ch)
+{
+	const uint32_t n = ch->bq_n;
+	if (!n)
+		return TGPU_OK;
+	hipError_t e = hipSuccess;
+	for (uint32_t i = 0; i < n; i++) {
+		ch->bq_type[i] = ch->bq[i].type;
+		ch->bq_code[i] = ch->scramb_init;	/* the code in force: an SB1 only ever ends a batch */
+	}
+	int rc = tgpu_plan_load_blocks(ch->bplan, n, ch->bq_off, ch->bq_type, ch->bq_code);
+	if (!rc && (e = hipMemcpyAsync(ch->d_bq_bits, ch->bq_bits, (size_t)n * BQ_STRIDE, hipMemcpyHostToDevice, ch->stream)))
+		rc = (int)e;
+	if (!rc)
+		rc = tgpu_plan_execute(ch->bplan, ch->d_bq_bits, ch->d_bq_rec, ch->stream);
+	if (!rc && (e = hipMemcpyAsync(ch->bq_rec, ch->d_bq_rec, (size_t)n * TGPU_REC_BYTES, hipMemcpyDeviceToHost, ch->stream)))
+		rc = (int)e;
+	if (!rc && (e = hipStreamSynchronize(ch->stream)))
+		rc = (int)e;
+	ch->bq_n = 0;
+	if (rc)
+		return channel_fail(ch, rc, n);
+	static const uint16_t t1len[6] = { 60, 124, 124, 14, 92, 268 };
+	for (uint32_t i = 0; i < n; i++) {
+		const struct bq_item *it = &ch->bq[i];
+		const uint8_t *rec = ch->bq_rec + (size_t)i * TGPU_REC_BYTES;
+		struct tgpu_block b;
+		struct pending pd = { ch->burst_seq, 0, TETRA_TRAIN_SYNC };
+		memset(&b, 0, sizeof(b));
+		b.type = (enum tp_sap_data_type)it->type;
+		b.blk_num = it->blk_num;
+		b.crc_ok = rec[TG_REC_CRC_OK];
+		memcpy(&b.crc, rec + TG_REC_CRC, 2);
+		memcpy(&b.scrambling_code, rec + TG_REC_CODE, 4);
+		b.type1_len = t1len[it->type];
+		b.type1 = rec + (it->type == TPSAP_T_BBK ? TG_REC_BBK : TG_REC_BITS1);
+		struct tetra_tdma_time tm = it->time;
+		deliver_block(ch, &pd, NULL, rec, &b, ch->bq_bits + (size_t)i * BQ_STRIDE, it->len, &tm);
+		if (it->type == TPSAP_T_SB1)
+			t_phy_state.time = tm;		/* tetra_lower_mac.c:302 (deliver_block wrote it on a good CRC) */
+	}
+	return TGPU_OK;
+}
+
+void tp_sap_udata_ind(enum tp_sap_data_type type, int blk_num, const uint8_t *bits, unsigned int len, void *priv)
+{
+	static const uint16_t t5len[6] = { 120, 216, 216, 30, 168, 432 };	/* lower_mac/tetra_lower_mac.c:55-102 */
+	struct tgpu_channel *ch = priv;
+	if (!ch || !bits)
+		return;
+	if ((unsigned)type > TPSAP_T_SCH_F || len != t5len[type]) {
+		(void)channel_fail(ch, TGPU_EINVAL, 0);
+		return;
+	}
+	int rc = bq_alloc(ch);
+	if (rc) {
+		(void)channel_fail(ch, rc, 0);
+		return;
+	}
+	struct bq_item *it = &ch->bq[ch->bq_n];
+	it->type = (uint8_t)type;
+	it->blk_num = (uint8_t)blk_num;
+	it->len = (uint16_t)len;
+	it->time = t_phy_state.time;
+	memcpy(ch->bq_bits + (size_t)ch->bq_n * BQ_STRIDE, bits, len);
+	ch->bq_n++;
+	if (type == TPSAP_T_SB1 || ch->bq_n >= ch->bq_cap)
+		(void)flush_blocks(ch);
+}
+
+/* phy/tetra_burst.c:341-379: a burst is handed to the lower MAC block by block */
+void tetra_burst_rx_cb(const uint8_t *burst, unsigned int len, enum tetra_train_seq type, void *priv)
+{
+	uint8_t bbk[30], both[432];
+	if (!burst || len < TG_SLOT_BITS)
+		return;
+	if (type == TETRA_TRAIN_SYNC) {
+		tp_sap_udata_ind(TPSAP_T_SB1, BLK_1, burst + TG_SB_BLK1_OFF, 120, priv);
+		tp_sap_udata_ind(TPSAP_T_BBK, 0, burst + TG_SB_BBK_OFF, 30, priv);
+		tp_sap_udata_ind(TPSAP_T_SB2, BLK_2, burst + TG_SB_BLK2_OFF, 216, priv);
+		return;
+	}
+	if (type != TETRA_TRAIN_NORM_1 && type != TETRA_TRAIN_NORM_2)
+		return;		/* uplink training sequences: ignored */
+	memcpy(bbk, burst + TG_NDB_BBK1_OFF, 14);
+	memcpy(bbk + 14, burst + TG_NDB_BBK2_OFF, 16);
+	tp_sap_udata_ind(TPSAP_T_BBK, 0, bbk, 30, priv);
+	if (type == TETRA_TRAIN_NORM_2) {
+		tp_sap_udata_ind(TPSAP_T_NDB, BLK_1, burst + TG_NDB_BLK1_OFF, 216, priv);
+		tp_sap_udata_ind(TPSAP_T_NDB, BLK_2, burst + TG_NDB_BLK2_OFF, 216, priv);
+	} else {
+		memcpy(both, burst + TG_NDB_BLK1_OFF, 216);
+		memcpy(both + 216, burst + TG_NDB_BLK2_OFF, 216);
+		tp_sap_udata_ind(TPSAP_T_SCH_F, 0, both, 432, priv);
+	}
 }
 
 /* ------------------------------------------------------------------------- */

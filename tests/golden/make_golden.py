@@ -140,6 +140,32 @@ def main():
         os.close(devnull)
     out["build_burst"] = builds
 
+    # --- viterbi.c: the ubit -> sbit map in front of the decoder (recorded by ref_glue.c's conv_cch_decode) ---
+    vw = []
+    for n in (80, 144, 288, 7):
+        u = rng.choice([0, 1, 0xff, 2, 0x80, 0x7f], 4 * n, p=[.4, .4, .1, .04, .03, .03]).astype(np.uint8)
+        out_bits = np.zeros(n + 8, np.uint8)
+        R.ref_glue_set_decoder(None)
+        R.viterbi_dec_sb1_wrapper(O._p(u), O._p(out_bits), n)
+        assert R.ref_glue_vit_n() == n
+        rec = np.ctypeslib.as_array(R.ref_glue_vit_input(), ((n + 4) * 4,)).copy()
+        vw.append([n, u.tobytes().hex(), rec.astype(np.int8).tobytes().hex()])
+    out["viterbi_wrapper"] = vw
+
+    # --- tch_reordering.c: in/out pairs of both directions ----------------
+    ac = {"type2_to_codec": [], "codec_to_acelp": []}
+    for _ in range(6):     # (padded buffers: a table entry 0 makes the reference index [-1])
+        b = np.zeros(274 + 16, np.uint8)
+        b[8:282] = rng.integers(0, 2, 274)
+        o = np.full(274 + 16, 7, np.uint8)
+        R.tetra_acelp_type2_to_codec(C.cast(b[8:].ctypes.data, O.u8p), C.cast(o[8:].ctypes.data, O.u8p))
+        ac["type2_to_codec"].append([bs(b[8:282]), bs(o[8:282])])
+        o = np.full(274 + 16, 7, np.uint8)
+        b[7] = 7           # what codec_to_acelp reads at in[-1] stays recognisable
+        R.tetra_acelp_codec_to_acelp(C.cast(b[8:].ctypes.data, O.u8p), C.cast(o[8:].ctypes.data, O.u8p))
+        ac["codec_to_acelp"].append([bs(b[8:282]), bs(o[8:282])])
+    out["acelp_reorder"] = ac
+
     # --- float_to_bits binary ----------------------------------------------
     f2b = O.ref_float_to_bits()
     fl = []

@@ -64,6 +64,7 @@ class Record(C.Structure):
         ("type1_len", C.c_uint16),
         ("type1", C.c_uint8 * 268),
         ("type4", C.c_uint8 * 432),
+        ("time_str", TdmaTime),
     ]
 
 
@@ -330,6 +331,52 @@ def traffic_block(type4):
     return out
 
 
+def _acelp_args(cls):
+    arrs = [np.ascontiguousarray(c, np.uint8) for c in cls]
+    ptrs = (u8p * 3)(*[_p(a) for a in arrs])
+    ns = (C.c_uint * 3)(*[len(a) for a in arrs])
+    return arrs, ptrs, ns
+
+
+def acelp_type2_to_codec(bits, cls, fill=0):
+    """lower_mac/tch_reordering.c:94-117 with the class position tables cls = (class0, class1, class2)"""
+    arrs, ptrs, ns = _acelp_args(cls)
+    n = 2 * sum(len(a) for a in arrs)
+    b = np.ascontiguousarray(bits, np.uint8)
+    assert len(b) == n
+    out = np.full(n, fill, np.uint8)
+    lib().orc_acelp_type2_to_codec(_p(b), _p(out), ptrs, ns)
+    return out
+
+
+def acelp_codec_to_acelp(bits, cls, fill=0):
+    arrs, ptrs, ns = _acelp_args(cls)
+    n = 2 * sum(len(a) for a in arrs)
+    b = np.ascontiguousarray(bits, np.uint8)
+    assert len(b) == n
+    out = np.full(n, fill, np.uint8)
+    lib().orc_acelp_codec_to_acelp(_p(b), _p(out), ptrs, ns)
+    return out
+
+
+def ref_acelp_tables():
+    """the class position tables of the REAL lower_mac/tch_reordering.c object, read off its behaviour (unit vectors
+    through tetra_acelp_codec_to_acelp); None when oracle/_ref is not built.  Class sizes 51 / 56 / 30 are the
+    #defines of tch_reordering.c:27,55,79."""
+    R = ref()
+    if R is None:
+        return None
+    n = 274
+    # codec_to_acelp reads one position per table entry: label every position of frame 0 with its own number
+    # (an entry 0 reads in[-1]: padded buffer, label 0 there) and read the table off the output
+    buf = np.zeros(n + 16, np.uint8)
+    buf[8:8 + 137] = np.arange(1, 138)
+    out = np.zeros(n, np.uint8)
+    R.tetra_acelp_codec_to_acelp(C.cast(buf[8:].ctypes.data, u8p), _p(out))
+    pos = out[0::2]
+    return [pos[:51].copy(), pos[51:107].copy(), pos[107:137].copy()]
+
+
 def float_to_soft(phi):
     phi = np.ascontiguousarray(phi, np.float32)
     out = np.zeros(2 * len(phi), np.int8)
@@ -390,7 +437,8 @@ def record_to_dict(r):
     n = r.type1_len
     return dict(burst_seq=r.burst_seq, burst_type=r.burst_type, type=r.type, blk_num=r.blk_num, lchan=r.lchan,
                 crc_ok=r.crc_ok, traffic=r.traffic_dumped, crc=r.crc, scramb=r.scrambling_code,
-                time=(r.time.tn, r.time.fn, r.time.mn), type1=bytes(r.type1[:n]),
+                time=(r.time.tn, r.time.fn, r.time.mn), time_str=(r.time_str.tn, r.time_str.fn, r.time_str.mn),
+                type1=bytes(r.type1[:n]),
                 type4=bytes(r.type4[:BLK[r.type][0]]))
 
 
@@ -471,6 +519,11 @@ def ref():
     R.tetra_find_train_seq.argtypes = [u8p, C.c_uint, C.c_uint32, C.POINTER(C.c_uint)]
     R.tetra_burst_rx_cb.argtypes = [u8p, C.c_uint, C.c_int, C.c_void_p]
     R.tetra_tdma_time_add_tn.argtypes = [C.POINTER(TdmaTime), C.c_uint32]
+    R.viterbi_dec_sb1_wrapper.argtypes = [u8p, u8p, C.c_uint]
+    R.tetra_acelp_type2_to_codec.argtypes = [u8p, u8p]
+    R.tetra_acelp_codec_to_acelp.argtypes = [u8p, u8p]
+    R.ref_glue_set_decoder.argtypes = [C.c_void_p]
+    R.ref_glue_vit_input.restype = C.POINTER(C.c_int8)
     R.ref_glue_get.restype = C.POINTER(RefCall)
     R.ref_glue_get.argtypes = [C.c_int]
     R.tetra_rm3014_init()

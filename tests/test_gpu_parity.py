@@ -215,7 +215,7 @@ def test_edge_cases(T, eng):
 # ---------------------------------------------------------------------------
 # channel API: tetra_burst_sync_in() + callbacks vs the oracle receiver
 # ---------------------------------------------------------------------------
-KEYS = ("burst_seq", "burst_type", "type", "blk_num", "lchan", "crc_ok", "traffic", "crc", "scramb", "time", "type1")
+KEYS = ("burst_seq", "burst_type", "type", "blk_num", "lchan", "crc_ok", "traffic", "crc", "scramb", "time", "type1", "time_str")
 
 
 def assert_same_records(got, want):
@@ -1440,3 +1440,87 @@ def test_generic_trellis_random_shapes(T, eng):
             assert (got[i] == O.conv_decode_block(pu, mother, t3[i], L, 0)).all(), (pu, mother, L, K, n, i)
         cv.close()
         done += 1
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_acelp_reordering_on_device(T, eng, seed):
+    """tgpu_reorder_* with the maps of tgpu_acelp_build_map() == the oracle's restatement of
+    lower_mac/tch_reordering.c:94-140 on batches of blocks, both directions, tables that are permutations and
+    tables damaged like the reference's own; with the real object's tables where oracle/_ref is there"""
+    import torch
+    from test_host_logic import _acelp_tables
+    cases = [_acelp_tables(seed)]
+    if seed == 0 and O.ref_acelp_tables() is not None:
+        cases.append((O.ref_acelp_tables(), 137))
+    rng = np.random.default_rng(50 + seed)
+    for cls, nbits in cases:
+        nb = int(rng.integers(1000, 5000))
+        x = rng.integers(0, 2, (nb, 2 * nbits)).astype(np.uint8)
+        d_in = torch.from_numpy(x).cuda()
+        for to_codec in (True, False):
+            r = T.Reorder(eng, T.acelp_build_map(cls, to_codec))
+            d_out = torch.full((nb, 2 * nbits), 7, dtype=torch.uint8, device="cuda")
+            r.execute(d_in.data_ptr(), nb, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy()
+            f = O.acelp_type2_to_codec if to_codec else O.acelp_codec_to_acelp
+            for i in rng.choice(nb, 40, replace=False):
+                assert got[i].tolist() == f(x[i], cls, fill=7).tolist()
+            r.close()
+
+
+def _reference_stdout_lines(records):
+    """what tetra-rx prints for these tp_sap_udata_ind() calls (lower_mac/tetra_lower_mac.c:258-266): 'CRC COMP' line
+    per CRC-protected block, and the type-1 bits of the good ones with the block's name and TDMA time"""
+    names = {O.T_SB1: "SB1", O.T_SB2: "SB2", O.T_NDB: "NDB", O.T_SCH_HU: "SCH/HU", O.T_SCH_F: "SCH/F"}
+    out = []
+    for r in records:
+        if r["type"] == O.T_BBK or r["traffic"]:
+            continue
+        if r["crc_ok"]:
+            tn, fn, mn = r["time_str"]
+            out.append("CRC COMP: 0x%04x OK" % r["crc"])
+            out.append("%s %02u/%02u/%u/%03u type1: %s" % (names[r["type"]], mn, fn, tn, 0, "".join(str(b) for b in r["type1"])))
+        else:
+            out.append("CRC COMP: 0x%04x WRONG" % r["crc"])
+    return out
+
+
+@pytest.mark.parametrize("seam,with_ref_obj", [("sync_in", False), ("rx_cb", False), ("rx_cb", True)])
+def test_c_consumer_links_and_prints_reference_observables(T, eng, seam, with_ref_obj, tmp_path):
+    """a plain C translation unit against include/tetra_gpu.h, linked with -ltetra_gpu (tools/tetra_rx_gpu.c), fed a
+    capture: its stdout == the lines tetra-rx would print for the oracle's decode of the same capture ('CRC COMP: ...
+    OK|WRONG', '<NAME> <time> type1: <bits>'), through tetra_burst_sync_in() and through the reference-signature
+    tetra_burst_rx_cb() / tp_sap_udata_ind() seam -- the latter also with the reference's own phy/tetra_burst.o
+    linked in front of the library (its tetra_burst_rx_cb() then calls this library's tp_sap_udata_ind())"""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler on this box")
+    obj = os.path.join(root, "oracle", "_ref", "tetra_burst.o")
+    if with_ref_obj and not os.path.exists(obj):
+        pytest.skip("oracle/_ref/tetra_burst.o not built (needs /root/reference)")
+    exe = str(tmp_path / "tetra_rx_gpu")
+    libdir = os.path.join(root, "osmo-tetra_amd")
+    cmd = [gcc, "-O2", "-Wall", os.path.join(root, "tools", "tetra_rx_gpu.c")] + ([obj] if with_ref_obj else []) + \
+        ["-I" + os.path.join(root, "include"), "-L" + libdir, "-ltetra_gpu", "-Wl,-rpath," + libdir, "-o", exe]
+    subprocess.check_call(cmd)
+    stream, _ = synth.frame_stream(seed=31, nframes=10, ber=0.035)
+    s = stream.copy()
+    s[100 + 510 + 510 * 9 + 244 + 7] ^= 1            # a loss of lock and a re-lock in between
+    cap = tmp_path / "capture.bits"
+    s.tofile(cap)
+    want, wev = O.run_rx(s)
+    r = subprocess.run([exe, str(cap), "--seam", seam, "--batch", "7"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("CRC COMP", "SB", "NDB", "SCH"))]
+    assert lines == _reference_stdout_lines(want)
+    nok = sum(1 for x in want if x["crc_ok"] and x["type"] != O.T_BBK)
+    assert nok >= 30 and any(not x["crc_ok"] for x in want)
+    assert "%d CRC OK" % nok in r.stderr
+    if with_ref_obj:      # the reference's burst builders print at load... no: its tetra_burst_rx_cb ran -- nothing else to see
+        assert "found SYNC training sequence in bit #" in r.stdout
+    assert r.stderr.count("####") == sum(1 for e in wev if e[0] in (3, 4, 5))

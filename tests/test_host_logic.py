@@ -280,3 +280,59 @@ def test_branch_metric_table_equals_arithmetic():
     path metrics and history bytes after every block of random sequences"""
     for seed in range(1, 200):
         assert emul.lib().emul_bm_selfcheck(seed * 2654435761 % (1 << 32), 36) == 0
+
+
+def _acelp_tables(seed):
+    """synthetic class position tables (the real ones are EN 300 395-2 data and stay with the caller): a random split
+    of 1..nbits into three classes, optionally damaged the way the reference's own table is (a position listed twice,
+    an entry 0)"""
+    rng = np.random.default_rng(seed)
+    nbits = int(rng.integers(20, 138))
+    perm = rng.permutation(nbits) + 1
+    a, b = sorted(rng.choice(np.arange(1, nbits), 2, replace=False))
+    cls = [perm[:a].astype(np.uint8), perm[a:b].astype(np.uint8), perm[b:].astype(np.uint8)]
+    if seed & 1:
+        cls[1][0] = cls[0][0]
+        cls[0][-1] = 0
+    return cls, nbits
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_acelp_reordering_host_entry_points(seed):
+    """tetra_acelp_type2_to_codec() / tetra_acelp_codec_to_acelp() (the reference's names, caller-supplied tables) and
+    the index maps behind them == the oracle's restatement of lower_mac/tch_reordering.c:94-140"""
+    cls, nbits = _acelp_tables(seed)
+    T.acelp_set_tables(cls)
+    rng = np.random.default_rng(100 + seed)
+    m1, m0 = T.acelp_build_map(cls, True), T.acelp_build_map(cls, False)
+    for _ in range(4):
+        b = rng.integers(0, 2, 2 * nbits).astype(np.uint8)
+        want = O.acelp_type2_to_codec(b, cls, fill=7)
+        got = T.acelp_type2_to_codec(b, out=np.full(2 * nbits, 7, np.uint8))
+        assert got.tolist() == want.tolist()
+        assert np.where(m1 >= 0, b[np.maximum(m1, 0)], 7).tolist() == want.tolist()
+        want = O.acelp_codec_to_acelp(b, cls, fill=7)
+        got = T.acelp_codec_to_acelp(b, out=np.full(2 * nbits, 7, np.uint8))
+        assert got.tolist() == want.tolist()
+        assert np.where(m0 >= 0, b[np.maximum(m0, 0)], 7).tolist() == want.tolist()
+    if not seed & 1:   # a proper table: the two directions are inverse permutations
+        assert sorted(m1.tolist()) == list(range(2 * nbits)) and (m0[m1] == np.arange(2 * nbits)).all()
+
+
+def test_acelp_reordering_with_the_reference_tables():
+    """with the class tables of the real lower_mac/tch_reordering.c object (read off its behaviour, build container
+    and GPU box only) the product's entry points give the real functions' outputs"""
+    cls = O.ref_acelp_tables()
+    if cls is None:
+        pytest.skip("oracle/_ref not built")
+    import ctypes as C
+    R = O.ref()
+    T.acelp_set_tables(cls)
+    rng = np.random.default_rng(9)
+    for _ in range(5):
+        b = np.zeros(274 + 16, np.uint8)
+        b[8:282] = rng.integers(0, 2, 274)
+        want = np.full(274 + 16, 7, np.uint8)
+        R.tetra_acelp_type2_to_codec(C.cast(b[8:].ctypes.data, O.u8p), C.cast(want[8:].ctypes.data, O.u8p))
+        got = T.acelp_type2_to_codec(b[8:282].copy(), out=np.full(274, 7, np.uint8))
+        assert got.tolist() == want[8:282].tolist()
