@@ -1170,3 +1170,49 @@ int orc_gsmtap_makemsg(const struct orc_tdma_time *tm, int lchan, uint8_t ts, ui
 	}
 	return (int)(16 + nbytes);
 }
+
+/* the soft chain on n aligned slots of int8 soft values (510 per slot, slot layout of the hard path): the batch form
+ * of orc_decode_block_soft() for full-size parity runs */
+uint64_t orc_bench_decode_slots_soft(const int8_t *slots, const uint8_t *types, size_t n, uint32_t scramb_init,
+				     uint8_t *type1_out, uint16_t *crc_out)
+{
+	uint64_t ok = 0;
+	struct orc_block_result res;
+	int8_t bbk[30], schf[432];
+	for (size_t i = 0; i < n; i++) {
+		const int8_t *b = slots + 510 * i;
+		uint8_t *o = type1_out ? type1_out + 288 * i : NULL;
+		uint16_t crcdummy[2], *c = crc_out ? crc_out + 2 * i : crcdummy;
+		c[0] = c[1] = 0;
+		switch (types[i]) {
+		case ORC_TRAIN_SYNC:
+			orc_decode_block_soft(ORC_T_SB1, b + 94, 3, &res); ok += (uint64_t)res.crc_ok; c[0] = res.crc;
+			if (o) memcpy(o + 14, res.type1, 60);
+			orc_decode_block_soft(ORC_T_BBK, b + 252, scramb_init, &res);
+			if (o) memcpy(o, res.type1, 14);
+			orc_decode_block_soft(ORC_T_SB2, b + 282, scramb_init, &res); ok += (uint64_t)res.crc_ok; c[1] = res.crc;
+			if (o) memcpy(o + 14 + 124, res.type1, 124);
+			break;
+		case ORC_TRAIN_NORM_2:
+			memcpy(bbk, b + 230, 14); memcpy(bbk + 14, b + 266, 16);
+			orc_decode_block_soft(ORC_T_BBK, bbk, scramb_init, &res);
+			if (o) memcpy(o, res.type1, 14);
+			orc_decode_block_soft(ORC_T_NDB, b + 14, scramb_init, &res); ok += (uint64_t)res.crc_ok; c[0] = res.crc;
+			if (o) memcpy(o + 14, res.type1, 124);
+			orc_decode_block_soft(ORC_T_NDB, b + 282, scramb_init, &res); ok += (uint64_t)res.crc_ok; c[1] = res.crc;
+			if (o) memcpy(o + 14 + 124, res.type1, 124);
+			break;
+		case ORC_TRAIN_NORM_1:
+			memcpy(bbk, b + 230, 14); memcpy(bbk + 14, b + 266, 16);
+			memcpy(schf, b + 14, 216); memcpy(schf + 216, b + 282, 216);
+			orc_decode_block_soft(ORC_T_BBK, bbk, scramb_init, &res);
+			if (o) memcpy(o, res.type1, 14);
+			orc_decode_block_soft(ORC_T_SCH_F, schf, scramb_init, &res); ok += (uint64_t)res.crc_ok; c[0] = res.crc;
+			if (o) memcpy(o + 14, res.type1, 268);
+			break;
+		default:
+			break;
+		}
+	}
+	return ok;
+}

@@ -280,6 +280,8 @@ void orc_decode_block_soft(enum orc_tpsap_type type, const int8_t *soft5, uint32
 uint64_t orc_bench_decode_slots(const uint8_t *slots, const uint8_t *types, size_t n,
 				uint32_t scramb_init, int use_acc, uint8_t *type1_out /* n*288 or NULL */,
 				uint16_t *crc_out /* n*2 or NULL */);
+uint64_t orc_bench_decode_slots_soft(const int8_t *slots, const uint8_t *types, size_t n, uint32_t scramb_init,
+				     uint8_t *type1_out, uint16_t *crc_out);
 
 #ifdef __cplusplus
 }

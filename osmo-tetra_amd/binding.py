@@ -614,7 +614,7 @@ class GridSync:
         return out
 
 
-def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None, grid=False):
+def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None, grid=False, per_call=False):
     """host half of the stream synchroniser (tgpu_sync_walk); cls=None: every slot settled on the bytes,
     ysum=None: re-lock searches scan the bytes"""
     stream = _np_u8(stream)
@@ -627,7 +627,7 @@ def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None
     _chk(lib().tgpu_sync_walk(stream.ctypes.data_as(u8p), len(stream), chunk, anchor,
                               cls.ctypes.data_as(u32p) if cls is not None else None,
                               ysum.ctypes.data_as(u16p) if ysum is not None else None,
-                              len(cls) if cls is not None else 0, (0 if burst_events else 1) | (2 if grid else 0),
+                              len(cls) if cls is not None else 0, (0 if burst_events else 1) | (2 if grid else 0) | (4 if per_call else 0),
                               C.byref(res)), "tgpu_sync_walk")
     return _sync_result_to_py(res)
 

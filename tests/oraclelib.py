@@ -485,6 +485,20 @@ def bench_decode_slots(slots, types, scramb_init=0, use_acc=0, want_out=False, w
     return ok, out
 
 
+def bench_decode_slots_soft(soft_slots, types, scramb_init=0):
+    """(ok count, type-1 bits laid out as bench_decode_slots, crc words) of the oracle's soft chain"""
+    s = np.ascontiguousarray(soft_slots, np.int8)
+    types = np.ascontiguousarray(types, np.uint8)
+    n = len(types)
+    out = np.zeros((n, 288), np.uint8)
+    crc = np.zeros((n, 2), np.uint16)
+    L = lib()
+    L.orc_bench_decode_slots_soft.restype = C.c_uint64
+    ok = L.orc_bench_decode_slots_soft(s.ctypes.data_as(C.POINTER(C.c_int8)), _p(types), C.c_size_t(n), C.c_uint32(scramb_init),
+                                       _p(out), crc.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return ok, out, crc
+
+
 # ---------------------------------------------------------------------------
 # the real reference objects (this container only)
 # ---------------------------------------------------------------------------

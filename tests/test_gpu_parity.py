@@ -89,8 +89,25 @@ def test_config2_ndb_parity(T, eng, ber):
         assert 0 < ok < nblocks or ber < 0.03
 
 
+def _codes_in_force(slots, types, code0=0):
+    """the scrambling code the reference would use for BBK / BLK / SB2 of every slot (oracle): a SYNC slot whose SB1
+    passes its CRC sets it from the SYNC PDU, starting with its own BBK and SB2 (tetra_lower_mac.c:291-300)"""
+    codes = np.zeros(len(types), np.uint32)
+    cur = code0
+    for i, t in enumerate(types):
+        if t == O.TRAIN_SYNC:
+            t1, _, ok, _ = O.decode_block(O.T_SB1, slots[i][94:214], 3)
+            if ok:
+                f = lambda a, n: int("".join(str(int(b)) for b in t1[a:a + n]), 2)
+                cur = O.scramb_get_init(f(31, 10), f(41, 14), f(4, 6))
+        codes[i] = cur
+    return codes
+
+
 def test_garbage_and_extreme_inputs(T, eng):
-    """random bits, all-ones, all-zeros in the coded fields: worst-case metrics and ties everywhere"""
+    """random bits, all-ones, all-zeros in the coded fields: worst-case metrics and ties everywhere; checked
+    unconditionally -- whatever code an SB1 of garbage produces (one that passes its CRC switches the code, and a
+    planted valid SB1 in the middle does so for sure) is what the oracle decodes the following slots with"""
     rng = np.random.default_rng(3)
     n = 900
     types = np.array([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_NORM_2] * (n // 3), np.uint8)
@@ -98,10 +115,14 @@ def test_garbage_and_extreme_inputs(T, eng):
     slots[0:3] = 0
     slots[3:6] = 1
     slots[6:9, ::2] = 0
+    good = T.synth_slots(np.array([O.TRAIN_SYNC], np.uint8), seed=5, scramb_init=O.scramb_get_init(901, 77, 9), mcc=901, mnc=77, cc=9)
+    slots[450, 94:214] = good[0, 94:214]           # one valid SB1 among the garbage: the code changes here
     rec, p, _ = run_plan(T, eng, slots, types)
-    # SB1 of garbage essentially never passes CRC, so the code stays 0 for BBK/SB2
-    if (p["crc_ok"][types == O.TRAIN_SYNC, 0] == 0).all():
-        check_against_oracle(T, rec, types, slots, 0)
+    codes = _codes_in_force(slots, types)
+    assert (p["code"] == codes).all() and len(set(codes.tolist())) >= 2
+    for c in sorted(set(codes.tolist())):
+        m = codes == c
+        check_against_oracle(T, rec[m], types[m], slots[m], int(c))
 
 
 def test_sync_slots_set_scrambling_code(T, eng):
@@ -1524,3 +1545,94 @@ def test_c_consumer_links_and_prints_reference_observables(T, eng, seam, with_re
     if with_ref_obj:      # the reference's burst builders print at load... no: its tetra_burst_rx_cb ran -- nothing else to see
         assert "found SYNC training sequence in bit #" in r.stdout
     assert r.stderr.count("####") == sum(1 for e in wev if e[0] in (3, 4, 5))
+
+
+def _mix_stream(T, n, seed, code_cell=(262, 42, 1), ber=0.02):
+    """BASELINE config 3 at size n: lead-in, lock-only SB, frames [SB,N1,N2,N1,N2,N1,N2,N1], 1 % of the slots with a
+    damaged training sequence, payload noise"""
+    rng = np.random.default_rng(seed)
+    pat = np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8)
+    types = np.tile(pat, n // 8 + 1)[:n]
+    mcc, mnc, cc = code_cell
+    code = O.scramb_get_init(mcc, mnc, cc)
+    slots = T.synth_slots(np.concatenate([[3], types]).astype(np.uint8), seed=seed, scramb_init=code, mcc=mcc, mnc=mnc, cc=cc, ber=ber)
+    y = slots[0, 214:252].tolist()
+    for i in np.flatnonzero(rng.random(n) < 0.01) + 1:
+        off = 214 if slots[i, 214:252].tolist() == y else 244
+        slots[i, off + int(rng.integers(0, 22))] ^= 1
+    return np.concatenate([rng.integers(0, 2, 100).astype(np.uint8), slots.reshape(-1), np.zeros(700, np.uint8)]), code
+
+
+def test_config3_full_size_stream_against_the_oracle(T, eng):
+    """BASELINE config 3 at 100 000 slots through the GPU front end + grid plan: the synchroniser's events == the
+    oracle receiver's (every lock loss and re-lock of ~1000 damaged slots), every delivered burst's type-1 bits,
+    BBK and CRC words == the oracle's decode, the number of tp_sap_udata_ind() deliveries matches"""
+    import torch
+    n = 100_000
+    s, code = _mix_stream(T, n, 77)
+    d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+    hs = torch.cuda.current_stream().cuda_stream
+    plan = T.Plan(eng, n + 8, 1)
+    g = T.sync_stream_grid(eng, plan, s, d.data_ptr(), 64, hs, burst_events=False)
+    assert g["noffgrid"] == 0 and 0.9 * n < g["nslots"] < n
+    d_rec = torch.zeros(g["ngrid"] * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+    torch.cuda.synchronize()
+    idx = T.grid_indices(g)
+    rec = d_rec.cpu().numpy().reshape(-1, T.REC_BYTES)[idx]
+    # the oracle's receiver on the same bytes: events and delivery count
+    nrec = [0]
+    want_ev = []
+    import ctypes as C
+    rx = O.Rx()
+    ucb = O.UPPER_CB(lambda rxp, recp, off, priv: (nrec.__setitem__(0, nrec[0] + (off in (0, 0xFFFFFFFF))), -1)[1])
+    ecb = O.EVENT_CB(lambda ev, bitnum, arg, priv: want_ev.append((ev, bitnum, arg)) if ev != 2 else None)
+    O.lib().orc_rx_init(C.byref(rx), ucb, ecb, None)
+    rx.use_acc = 1
+    O.lib().orc_rx_feed(C.byref(rx), O._p(s), len(s), 64)
+    assert g["events"] == want_ev and len(want_ev) > 1500
+    p = T.parse_records(rec)
+    ty = p["type"].astype(np.uint8)
+    assert nrec[0] == int(3 * ((ty == 3).sum() + (ty == 1).sum()) + 2 * (ty == 0).sum()) and rx.burst_seq >= len(idx)
+    slots = np.stack([s[g["anchor"] + 510 * int(k):g["anchor"] + 510 * int(k) + 510] for k in idx])
+    ok, p2 = check_against_oracle(T, rec, ty, slots, code)
+    assert 0.3 * nrec[0] < ok < nrec[0]
+    plan.close()
+
+
+def test_config5_full_size_soft_decode_against_the_oracle(T, eng):
+    """BASELINE config 5 at 100 000 slots: float phases (sigma 0.7) -> device float_to_bits (hard bits == the
+    reference slicer's, soft values == the oracle's) -> soft-decision decode == the oracle's soft chain on every block"""
+    import torch
+    n = 100_000
+    rng = np.random.default_rng(55)
+    code = O.scramb_get_init(262, 42, 1)
+    pat = np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8)
+    types = np.tile(pat, n // 8 + 1)[:n]
+    slots = T.synth_slots(types, seed=41, scramb_init=code)
+    bits = slots.reshape(-1)
+    phi = (O.bits_to_phase(bits) + rng.normal(0, 0.7, len(bits) // 2)).astype(np.float32)
+    d_phi = torch.from_numpy(phi).cuda()
+    d_bits = torch.zeros(len(bits) + 64, dtype=torch.uint8, device="cuda")
+    d_soft = torch.zeros(len(bits) + 64, dtype=torch.int8, device="cuda")
+    eng.float_to_bits(d_phi.data_ptr(), len(phi), d_bits.data_ptr(), d_soft.data_ptr())
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(np.arange(n, dtype=np.uint64) * 510, types, None, np.array([code], np.uint32))
+    plan.execute_soft(d_soft.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (d_bits.cpu().numpy()[:len(bits)] == O.float_to_bits(phi)).all()
+    soft = d_soft.cpu().numpy()[:len(bits)]
+    assert (soft == O.float_to_soft(phi)).all()
+    rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+    p = T.parse_records(rec)
+    ok, want, wcrc = O.bench_decode_slots_soft(soft.reshape(n, 510), types, code)
+    n1, n2, sb = types == 0, types == 1, types == 3
+    assert (p["bbk"] == want[:, :14]).all()
+    assert (p["bits1"][n1] == want[n1, 14:282]).all()
+    assert (p["bits1"][n2][:, :124] == want[n2, 14:138]).all() and (p["bits2"][n2] == want[n2, 138:262]).all()
+    assert (p["bits1"][sb][:, :60] == want[sb, 14:74]).all() and (p["bits2"][sb] == want[sb, 138:262]).all()
+    assert (p["crc"][:, 0] == wcrc[:, 0]).all() and (p["crc"][n2 | sb, 1] == wcrc[n2 | sb, 1]).all()
+    nblk = int(2 * (n2 | sb).sum() + n1.sum())
+    assert int(p["crc_ok"][:, 0].sum() + p["crc_ok"][n2 | sb, 1].sum()) == ok and 0.3 * nblk < ok < nblk
+    plan.close()

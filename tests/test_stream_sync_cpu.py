@@ -257,3 +257,28 @@ def test_long_runs_take_the_bulk_path():
         s[p0 + 510 * 100 + 30:p0 + 510 * 100 + 52] = SEQ_N      # spurious n sequence: burst dropped, lock kept
         res = check(s, chunk=64)
         assert len(res["slots"]) > 300
+
+
+def test_per_call_form_equals_closed_form_and_oracle():
+    """tgpu_sync_walk()'s two forms -- the reference's state machine call by call (used outside feed sizes 21..296,
+    or on request) and the closed form -- give the same slot table and events on damaged streams, and both are the
+    oracle's; feed sizes below 21 and above 296 go through the per-call form by themselves"""
+    rng = np.random.default_rng(808)
+    for trial in range(6):
+        stream, slots = synth.frame_stream(seed=300 + trial, nframes=5, lead_in=int(rng.integers(0, 300)))
+        s = stream.copy()
+        for i in rng.choice(len(slots), 4, replace=False):
+            base = int(np.flatnonzero((np.lib.stride_tricks.sliding_window_view(s, 38) == SEQ_Y).all(axis=1))[0]) + 296 + 510 * int(i)
+            k = int(rng.integers(0, 3))
+            if k == 0:
+                s[base + 244 + 3] ^= 1
+            elif k == 1:
+                s[base + int(rng.integers(0, 20)):][:22] = SEQ_N
+            else:
+                s[base + 300:base + 338] = SEQ_Y
+        for chunk in (64, 21, 296, 150):
+            a = T.sync_walk(s, chunk=chunk)
+            b = T.sync_walk(s, chunk=chunk, per_call=True)
+            assert a["slots"] == b["slots"] and a["events"] == b["events"]
+        for chunk in (5, 20, 297, 400):
+            check(s, chunk=chunk, with_cls=False)
