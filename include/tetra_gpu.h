@@ -388,6 +388,7 @@ struct tgpu_sync_result {
 	uint32_t *grid_bits;
 	uint32_t ngrid;
 	uint32_t noffgrid;
+	uint32_t grid_base;	/* multi-channel batches (tgpu_sync_multi_*): record index of this channel's grid slot 0 */
 };
 
 #define TGPU_SYNC_NO_BURST_EVENTS 1u	/* do not record one TGPU_EV_BURST per locked burst (throughput runs) */
@@ -420,6 +421,32 @@ int tgpu_sync_stream_grid_finish(struct tgpu_engine *eng, struct tgpu_plan *plan
 				 uint32_t chunk, uint32_t flags, uint32_t scramb_init, struct tgpu_sync_result *out,
 				 void *hip_stream);
 void tgpu_sync_result_free(struct tgpu_sync_result *r);
+/*
+ * Several recorded channels in one batch (BASELINE config 4: a GPU's share of the channels; the reference runs one
+ * process per channel, src/receiver1:1-10).  The channels' streams lie in one device buffer (channel c at byte d_off,
+ * at least 2304 readable bytes behind the last one) and are also in host memory for the synchroniser walks.
+ *   begin : first lock of every channel (host), ONE classification launch over all grids, one copy back (async)
+ *   finish: waits, walks every channel (up to nthreads host threads), builds one plan batch on the device: record
+ *           index of grid slot i of channel c = out[c].grid_base + i, valid iff bit i of out[c].grid_bits;
+ *           channel c's carry-in code = scramb_init; a channel that re-locks off its grid (out[c].noffgrid != 0)
+ *           is left out of the batch (decode it through tgpu_sync_stream()).  out = nchan results, each to be
+ *           released with tgpu_sync_result_free().  Then tgpu_plan_execute(plan, d_base, d_rec, stream).
+ * The plan needs max_slots >= the padded grid total (tgpu_sync_multi_ngrid) and max_chan >= nchan (<= 64).
+ */
+struct tgpu_multi_chan {
+	const uint8_t *h_stream;	/* host copy of the channel's stream */
+	uint64_t d_off;			/* where it starts in the device buffer */
+	uint64_t len;
+	uint32_t scramb_init;		/* code in force before the first SYNC burst (0 for a fresh channel) */
+};
+struct tgpu_sync_multi;
+int tgpu_sync_multi_begin(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+			  const uint8_t *d_base, uint32_t chunk, struct tgpu_sync_multi **out, void *hip_stream);
+int tgpu_sync_multi_finish(struct tgpu_sync_multi *st, uint32_t flags, unsigned int nthreads, struct tgpu_sync_result *out,
+			   void *hip_stream);
+uint32_t tgpu_sync_multi_ngrid(const struct tgpu_sync_multi *st);
+void tgpu_sync_multi_free(struct tgpu_sync_multi *st);
+
 /* measurement aid: the stream front end of a grid (anchor + 510 n) alone, nrep times on hip_stream with HIP events
  * around its launches: us[0] = k_front_stream, us[1] = k_front_stream_fix (mean microseconds).  The plan's grid
  * buffers are the scratch; the plan is left unloaded. */

@@ -66,7 +66,12 @@ class SyncResult(C.Structure):
     _fields_ = [("nslots", C.c_uint32), ("slots", C.POINTER(SyncSlot)), ("nevents", C.c_uint32),
                 ("events", C.POINTER(SyncEventRec)), ("final_state", C.c_int), ("tail_tn_adds", C.c_uint32),
                 ("burst_seq", C.c_uint32), ("anchor", C.c_uint64),
-                ("grid_bits", C.POINTER(C.c_uint32)), ("ngrid", C.c_uint32), ("noffgrid", C.c_uint32)]
+                ("grid_bits", C.POINTER(C.c_uint32)), ("ngrid", C.c_uint32), ("noffgrid", C.c_uint32),
+                ("grid_base", C.c_uint32)]
+
+
+class MultiChan(C.Structure):
+    _fields_ = [("h_stream", u8p), ("d_off", C.c_uint64), ("len", C.c_uint64), ("scramb_init", C.c_uint32)]
 
 
 class SynthCfg(C.Structure):
@@ -164,6 +169,12 @@ def lib():
     L.tgpu_sync_stream_grid_finish.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.POINTER(SyncResult), C.c_void_p]
     L.tgpu_sync_result_free.argtypes = [C.POINTER(SyncResult)]
+    L.tgpu_sync_multi_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(MultiChan), C.c_void_p, C.c_uint32,
+                                        C.POINTER(C.c_void_p), C.c_void_p]
+    L.tgpu_sync_multi_finish.argtypes = [C.c_void_p, C.c_uint32, C.c_uint, C.POINTER(SyncResult), C.c_void_p]
+    L.tgpu_sync_multi_ngrid.argtypes = [C.c_void_p]
+    L.tgpu_sync_multi_ngrid.restype = C.c_uint32
+    L.tgpu_sync_multi_free.argtypes = [C.c_void_p]
     L.tgpu_acelp_build_map.argtypes = [C.POINTER(u8p), C.POINTER(C.c_uint), C.c_int, C.POINTER(C.c_int32)]
     L.tgpu_acelp_set_tables.argtypes = [C.POINTER(u8p), C.POINTER(C.c_uint)]
     L.tetra_acelp_type2_to_codec.argtypes = [u8p, u8p]
@@ -429,7 +440,7 @@ def _sync_result_to_py(res):
     ea = grab(res.events, res.nevents, EVENT_DTYPE)
     out = SyncOutcome(slot_arr=sa, event_arr=ea, final_state=res.final_state, tail_tn_adds=res.tail_tn_adds,
                       burst_seq=res.burst_seq, anchor=res.anchor, nslots=res.nslots, ngrid=res.ngrid,
-                      noffgrid=res.noffgrid)
+                      noffgrid=res.noffgrid, grid_base=res.grid_base)
     if grid:
         out["grid_bits"] = grab(res.grid_bits, (res.ngrid + 31) // 32, np.dtype(np.uint32))
     return out
@@ -582,6 +593,49 @@ def sync_stream_grid(engine, plan, h_stream, d_stream_ptr, chunk=64, hip_stream=
     if not out["noffgrid"] and out["ngrid"]:
         plan.nslots, plan.nchan = out["ngrid"], 1
     return out
+
+
+class MultiSync:
+    """tgpu_sync_multi_*: several recorded channels (host copies `streams`, device copies at d_base + d_offs[c]) in one
+    grid / one plan batch.  finish() returns one outcome per channel; record index of grid slot i of channel c =
+    outcome['grid_base'] + i"""
+
+    def __init__(self, engine, plan, streams, d_base_ptr, d_offs, chunk=64, hip_stream=0, codes=None):
+        self.engine, self.plan, self.hip_stream = engine, plan, hip_stream
+        self.streams = [_np_u8(x) for x in streams]
+        n = len(self.streams)
+        self._ch = (MultiChan * n)()
+        for c, x in enumerate(self.streams):
+            self._ch[c].h_stream = x.ctypes.data_as(u8p)
+            self._ch[c].d_off = int(d_offs[c])
+            self._ch[c].len = len(x)
+            self._ch[c].scramb_init = int(codes[c]) if codes is not None else 0
+        self._h = C.c_void_p()
+        _chk(lib().tgpu_sync_multi_begin(engine._h, plan._h, n, self._ch, C.c_void_p(d_base_ptr), chunk, C.byref(self._h),
+                                         C.c_void_p(hip_stream)), "tgpu_sync_multi_begin")
+        self.ngrid = lib().tgpu_sync_multi_ngrid(self._h)
+
+    def finish(self, burst_events=False, nthreads=4):
+        n = len(self.streams)
+        res = (SyncResult * n)()
+        try:
+            _chk(lib().tgpu_sync_multi_finish(self._h, 0 if burst_events else 1, nthreads, res, C.c_void_p(self.hip_stream)),
+                 "tgpu_sync_multi_finish")
+        finally:
+            lib().tgpu_sync_multi_free(self._h)
+            self._h = C.c_void_p()
+        out = []
+        for c in range(n):
+            r = SyncResult()
+            C.memmove(C.byref(r), C.byref(res[c]), C.sizeof(SyncResult))
+            out.append(_sync_result_to_py(r))
+        if self.ngrid:
+            self.plan.nslots, self.plan.nchan = self.ngrid, n
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().tgpu_sync_multi_free(self._h)
 
 
 def sync_front_prof(engine, plan, d_stream_ptr, length, anchor, chunk=64, nrep=10, hip_stream=0):

@@ -77,6 +77,7 @@ struct tgpu_plan {
 	hipStream_t side;	/* k_vit<216> and k_vit<432> are independent: they run side by side */
 	hipEvent_t ev_fork, ev_join;
 	uint32_t *h_last_slot_of_chan;
+	struct tg_chan_ent *d_chan_tab, *h_chan_tab;	/* multi-channel stream mode: channel table (64 entries) */
 };
 
 const char *tgpu_strerror(int err)
@@ -181,7 +182,7 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	void *d[] = { p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
-		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty };
+		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
 			(void)hipFree(d[i]);
@@ -189,6 +190,8 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 		(void)hipHostFree(p->h_up);
 	if (p->h_grid)
 		(void)hipHostFree(p->h_grid);
+	if (p->h_chan_tab)
+		(void)hipHostFree(p->h_chan_tab);
 	free(p->h_last_slot_of_chan);
 	free(p);
 }
@@ -323,19 +326,41 @@ int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packe
 	return TGPU_OK;
 }
 
-int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t scramb_init, void *stream)
+/* device copy of a channel table for the multi-channel stream mode (owned by the plan, <= 64 entries) */
+int tgpi_plan_chan_table(struct tgpu_plan *p, const struct tg_chan_ent *ents, uint32_t nchan, struct tg_chan_ent **d_out,
+			 void *stream)
 {
-	if (!p || !ngrid || !h_bits || !p->d_grid)
+	if (!p || !ents || !nchan || nchan > 64 || nchan > p->max_chan || !d_out)
 		return TGPU_EINVAL;
 	BIND(p->eng);
-	if (ngrid > p->max_slots)
+	if (!p->d_chan_tab)
+		HCHK(hipMalloc((void **)&p->d_chan_tab, 64 * sizeof(struct tg_chan_ent)));
+	if (!p->h_chan_tab && hipHostMalloc((void **)&p->h_chan_tab, 64 * sizeof(struct tg_chan_ent), hipHostMallocDefault) != hipSuccess) {
+		p->h_chan_tab = NULL;
+		return TGPU_ENOMEM;
+	}
+	memcpy(p->h_chan_tab, ents, (size_t)nchan * sizeof(*ents));
+	HCHK(hipMemcpyAsync(p->d_chan_tab, p->h_chan_tab, (size_t)nchan * sizeof(*ents), hipMemcpyHostToDevice, (hipStream_t)stream));
+	*d_out = p->d_chan_tab;
+	return TGPU_OK;
+}
+
+/* nchan == 1, ents == NULL: one channel owning the whole grid.  Otherwise ents = the table given to
+ * tgpi_plan_chan_table() (channel c: grid slots gbase .. gbase + ncls - 1), codes[c] = its carry-in scrambling code */
+int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t nchan, const uint32_t *codes,
+			const struct tg_chan_ent *ents, void *stream)
+{
+	if (!p || !ngrid || !h_bits || !p->d_grid || !nchan || !codes || (ents && !p->d_chan_tab))
+		return TGPU_EINVAL;
+	BIND(p->eng);
+	if (ngrid > p->max_slots || nchan > p->max_chan)
 		return TGPU_ECAPACITY;
 	const size_t nwords = ((size_t)ngrid + 31) / 32, nblk = ((size_t)ngrid + 1023) / 1024;
 	size_t o = 0;
 #define UP_AT(ptr, type, count) do { ptr = (type *)(p->d_up + o); \
 		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
 	uint32_t *d_bits, *d_blk;
-	UP_AT(p->d_chan_code, uint32_t, 1);
+	UP_AT(p->d_chan_code, uint32_t, nchan);
 	UP_AT(d_bits, uint32_t, nwords);
 	const size_t upload = o;
 	UP_AT(p->d_slot_chan, uint32_t, ngrid);
@@ -348,27 +373,32 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 	p->d_slot_off = NULL;
 	if (o > p->up_bytes)
 		return TGPU_ECAPACITY;
-	*(uint32_t *)p->h_up = scramb_init;
+	memcpy(p->h_up, codes, (size_t)nchan * 4);
 	memcpy(p->h_up + ((uint8_t *)d_bits - p->d_up), h_bits, nwords * 4);
 	HCHK(hipMemcpyAsync(p->d_up, p->h_up, upload, hipMemcpyHostToDevice, (hipStream_t)stream));
 	int rc = tgk_grid_lists(p->d_grid, d_bits, ngrid, d_blk, p->d_slot_chan, p->d_slot_sbord, p->d_list_sb,
-				p->d_list_216, p->d_list_432, stream);
+				p->d_list_216, p->d_list_432, ents ? p->d_chan_tab : NULL, ents ? nchan : 1, stream);
 	if (rc)
 		return rc;
 	uint32_t tot[3];
 	HCHK(hipMemcpyAsync(tot, d_blk + 3 * nblk, sizeof(tot), hipMemcpyDeviceToHost, (hipStream_t)stream));
 	HCHK(hipStreamSynchronize((hipStream_t)stream));
-	p->h_last_slot_of_chan[0] = 0xffffffffu;
-	for (size_t wd = nwords; wd-- > 0;)
-		if (h_bits[wd]) {
-			p->h_last_slot_of_chan[0] = (uint32_t)(wd * 32 + 31 - (uint32_t)__builtin_clz(h_bits[wd]));
-			break;
-		}
+	/* last delivered slot of every channel (tgpu_plan_final_codes) */
+	for (uint32_t c = 0; c < nchan; c++) {
+		const size_t w0 = ents ? ents[c].gbase / 32 : 0;
+		const size_t w1 = ents ? (c + 1 < nchan ? ents[c + 1].gbase / 32 : nwords) : nwords;
+		p->h_last_slot_of_chan[c] = 0xffffffffu;
+		for (size_t wd = w1; wd-- > w0;)
+			if (h_bits[wd]) {
+				p->h_last_slot_of_chan[c] = (uint32_t)(wd * 32 + 31 - (uint32_t)__builtin_clz(h_bits[wd]));
+				break;
+			}
+	}
 	p->static_masks = 0;
 	p->packed_ready = 1;
 	p->block_mode = 0;
 	p->nslots = ngrid;
-	p->nchan = 1;
+	p->nchan = nchan;
 	p->nsb = tot[0];
 	p->n216 = tot[1];
 	p->n432 = tot[2];

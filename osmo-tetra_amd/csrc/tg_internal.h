@@ -18,6 +18,14 @@ int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uin
 int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
 			uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream,
 			void *ev_mid /* hipEvent_t recorded between the packed-bit kernel and its fix-up pass, or NULL */);
+/* several channels in one grid (BASELINE config 4): channel c owns grid slots gbase .. gbase + ncls - 1, gbase a
+ * multiple of 32 (padding slots behind ncls are classified "nothing"); its stream lies at byte d_off of d_base */
+struct tg_chan_ent {
+	uint64_t d_off, anchor, len;
+	uint32_t gbase, ncls;
+};
+int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots,
+			   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream, void *ev_mid);
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
 	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */,
@@ -56,7 +64,7 @@ int tgk_reorder(const uint8_t *d_in, unsigned long long nblocks, uint32_t nbits,
  * d_blk: 3 * (ceil(n / 1024) + 1) words, the totals (sb, 216 items, 432 items) end up at d_blk[3 * nblocks] */
 int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uint32_t n, uint32_t *d_blk,
 		   uint32_t *d_slot_chan, int32_t *d_slot_sbord, uint32_t *d_list_sb, uint32_t *d_list_216,
-		   uint32_t *d_list_432, void *stream);
+		   uint32_t *d_list_432, const struct tg_chan_ent *d_chan /* NULL: one channel */, uint32_t nchan, void *stream);
 
 /* optional RM(30,14) decoder (tg_rm.c): coset-leader table (65536 words, built on first use) and the generator's
  * parity rows; tgk_rm_enable() uploads both for the kernels (flag TGK_F_RM of tgk_vit / tgk_bbk_blocks) */
@@ -74,7 +82,11 @@ int tgpi_engine_bind(const struct tgpu_engine *eng);
 struct tgpu_plan;
 int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packed, uint32_t **d_cls, uint16_t **d_ysum,
 			 uint32_t **h_cls, uint16_t **h_ysum);	/* h_*: pinned mirrors owned by the plan */
-int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t scramb_init, void *stream);
+int tgpi_plan_chan_table(struct tgpu_plan *p, const struct tg_chan_ent *ents, uint32_t nchan, struct tg_chan_ent **d_out,
+			 void *stream);
+/* ents == NULL, nchan == 1: one channel owns the grid; else the table given to tgpi_plan_chan_table() */
+int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t nchan, const uint32_t *codes,
+			const struct tg_chan_ent *ents, void *stream);
 
 #ifdef __cplusplus
 }

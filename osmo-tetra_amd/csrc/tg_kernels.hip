@@ -431,7 +431,20 @@ struct tg_stream_params {
 	uint32_t chunk;		/* bytes per tetra_burst_sync_in() call being emulated */
 	int32_t cshift;		/* log2(chunk) when it is a power of two, else -1 */
 	uint32_t y32, y6, n22, p22;
+	/* several recorded channels in one grid (BASELINE config 4: a GPU's share of the channels in one batch): channel
+	 * c owns grid slots gbase .. gbase + ncls - 1 (gbase a multiple of 32, the slots up to the next channel's gbase
+	 * are padding and never decoded); its stream lies at byte d_off of the buffer, anchor / len are relative to it */
+	const struct tg_chan_ent *chan;
+	uint32_t nchan;		/* 0: one stream, the fields above */
 };
+
+/* channel of grid slot 'slot' (nchan <= 64: one table word per lane, a ballot counts the channels that start at or
+ * before the slot); wave-uniform */
+__device__ __forceinline__ uint32_t chan_of_slot(const tg_chan_ent *chan, uint32_t nchan, uint32_t slot, uint32_t lane)
+{
+	const uint32_t gb = lane < nchan ? chan[lane].gbase : 0xffffffffu;
+	return (uint32_t)__builtin_popcountll(__ballot(gb <= slot)) - 1u;
+}
 
 /*
  * One grid slot through the per-position search: the wave's 640-byte view goes to LDS, ten ballots turn it into a
@@ -651,7 +664,22 @@ void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm
 			const uint32_t slot = ch * 64 + (uint32_t)__builtin_ctzll(m);
 			m &= m - 1;
 			uint32_t myword, clsword, ys;
-			front_stream_slot(stream, prm, slot, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb, myword, clsword, ys);
+			if (prm.nchan) {
+				const uint32_t c = chan_of_slot(prm.chan, prm.nchan, slot, lane);
+				const uint32_t i = slot - prm.chan[c].gbase;
+				if (i >= prm.chan[c].ncls) {	/* padding behind a channel's last slot: nothing there */
+					myword = 0;
+					clsword = TG_BURST_NONE;
+					ys = TG_YS_NONE;
+				} else {
+					tg_stream_params q = prm;
+					q.anchor = prm.chan[c].anchor;
+					q.len = prm.chan[c].len;
+					front_stream_slot(stream + prm.chan[c].d_off, q, i, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb,
+							  myword, clsword, ys);
+				}
+			} else
+				front_stream_slot(stream, prm, slot, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb, myword, clsword, ys);
 			if (lane < TG_PACKED_WORDS)
 				packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
 			if (lane == 0) {
@@ -806,9 +834,20 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	 * fast path may not touch (their windows or the exact form's 640-byte views reach past the stream) fetch group 0
 	 * instead, so that every step issues the same loads */
 	auto fetch = [&](uint32_t g, tg_group_data &d) {
-		const uint64_t gb = prm.anchor + (uint64_t)g * TG_GROUP_BYTES;
-		d.fast = gb + TG_GROUP_BYTES + TG_STREAM_VIEW <= prm.len;
-		const uint8_t *p = stream + (d.fast ? gb : prm.anchor);
+		uint64_t gb, first;
+		if (prm.nchan) {	/* which channel the group belongs to: its stream, its grid origin */
+			const uint32_t c = chan_of_slot(prm.chan, prm.nchan, 4u * g, lane);
+			const uint32_t i0 = 4u * g - prm.chan[c].gbase;
+			first = prm.chan[c].d_off + prm.chan[c].anchor;
+			gb = first + (uint64_t)i0 * TG_SLOT_BITS;
+			d.fast = i0 + 4u <= prm.chan[c].ncls &&
+				 prm.chan[c].anchor + (uint64_t)i0 * TG_SLOT_BITS + TG_GROUP_BYTES + TG_STREAM_VIEW <= prm.chan[c].len;
+		} else {
+			first = prm.anchor;
+			gb = prm.anchor + (uint64_t)g * TG_GROUP_BYTES;
+			d.fast = gb + TG_GROUP_BYTES + TG_STREAM_VIEW <= prm.len;
+		}
+		const uint8_t *p = stream + (d.fast ? gb : first);
 		d.a0 = (uint32_t)((uintptr_t)p & 15);
 		const uint8_t *base16 = p - d.a0;
 		d.a = *(const uint4 *)(base16 + 16 * lane);
@@ -2210,6 +2249,46 @@ extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64
 	return tgk_front_stream_ev(d_stream, anchor, len, nslots, chunk, d_packed, d_cls, d_ysum, stream, NULL);
 }
 
+static void stream_patterns(tg_stream_params &prm, uint32_t chunk);
+
+/* several channels in one grid: d_chan = device copy of nchan (<= 64) tg_chan_ent, nslots = the grid's total size */
+extern "C" int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots,
+				      uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream, void *ev_mid)
+{
+	if (!nslots)
+		return 0;
+	if (!chunk || !nchan || nchan > 64 || (nslots & 31))
+		return -1;
+	tg_stream_params prm;
+	memset(&prm, 0, sizeof(prm));
+	prm.nslots = nslots;
+	prm.chan = d_chan;
+	prm.nchan = nchan;
+	stream_patterns(prm, chunk);
+	hipStream_t s = (hipStream_t)stream;
+	uint32_t blocks = ((nslots + 3) / 4 + 3) / 4;
+	if (blocks > 256 * 8)
+		blocks = 256 * 8;
+	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, s, d_base, prm, d_packed, d_cls, d_ysum);
+	if (ev_mid)
+		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
+	uint32_t fblocks = ((nslots + 63) / 64 + 3) / 4;
+	if (fblocks > 256 * 32)
+		fblocks = 256 * 32;
+	hipLaunchKernelGGL(k_front_stream_fix, dim3(fblocks), dim3(256), 0, s, d_base, prm, d_packed, d_cls, d_ysum);
+	return (int)hipGetLastError();
+}
+
+static void stream_patterns(tg_stream_params &prm, uint32_t chunk)
+{
+	prm.chunk = chunk;
+	prm.cshift = (chunk & (chunk - 1)) ? -1 : __builtin_ctz(chunk);
+	prm.y32 = host_pattern_bits(tsq_y, 0, 32);
+	prm.y6 = host_pattern_bits(tsq_y, 32, 6);
+	prm.n22 = host_pattern_bits(tsq_n, 0, 22);
+	prm.p22 = host_pattern_bits(tsq_p, 0, 22);
+}
+
 /* ev_mid (optional hipEvent_t): recorded between the packed-bit kernel and its fix-up pass (per-kernel timing) */
 extern "C" int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
 				   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream, void *ev_mid)
@@ -2219,15 +2298,11 @@ extern "C" int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uin
 	if (!chunk)
 		return -1;
 	tg_stream_params prm;
+	memset(&prm, 0, sizeof(prm));
 	prm.anchor = anchor;
 	prm.len = len;
 	prm.nslots = nslots;
-	prm.chunk = chunk;
-	prm.cshift = (chunk & (chunk - 1)) ? -1 : __builtin_ctz(chunk);
-	prm.y32 = host_pattern_bits(tsq_y, 0, 32);
-	prm.y6 = host_pattern_bits(tsq_y, 32, 6);
-	prm.n22 = host_pattern_bits(tsq_n, 0, 22);
-	prm.p22 = host_pattern_bits(tsq_p, 0, 22);
+	stream_patterns(prm, chunk);
 	const char *ev = getenv("TGPU_STREAM_V1");	/* =1: the per-position kernel on every slot (A/B runs) */
 	const int v1 = ev ? atoi(ev) : 0;
 	hipStream_t s = (hipStream_t)stream;
@@ -2466,9 +2541,13 @@ void k_grid_scan(uint32_t *blk, uint32_t nblocks)
 __global__ __launch_bounds__(GRID_BLOCK)
 void k_grid_emit(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ bits, uint32_t n,
 		 const uint32_t *__restrict__ blk, uint32_t *__restrict__ slot_chan, int32_t *__restrict__ slot_sbord,
-		 uint32_t *__restrict__ list_sb, uint32_t *__restrict__ list_216, uint32_t *__restrict__ list_432)
+		 uint32_t *__restrict__ list_sb, uint32_t *__restrict__ list_216, uint32_t *__restrict__ list_432,
+		 const tg_chan_ent *__restrict__ chan, uint32_t nchan)
 {
 	__shared__ uint32_t sm[GRID_BLOCK / 64][3];
+	__shared__ uint32_t s_gbase[64];
+	if (threadIdx.x < 64)
+		s_gbase[threadIdx.x] = (chan && threadIdx.x < nchan) ? chan[threadIdx.x].gbase : 0xffffffffu;
 	const uint32_t g = blockIdx.x * GRID_BLOCK + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const uint32_t t = grid_type(cls, bits, g, n);
@@ -2491,7 +2570,10 @@ void k_grid_emit(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ 
 	const uint32_t p216 = b216 + __builtin_popcountll(msb & below) + 2 * __builtin_popcountll(mn2 & below);
 	const uint32_t p432 = b432 + __builtin_popcountll(mn1 & below);
 	if (g < n) {
-		slot_chan[g] = 0;
+		uint32_t c = 0;		/* channels own consecutive slot ranges: the last one that starts at or before g */
+		for (uint32_t q = 1; q < nchan; q++)
+			c += s_gbase[q] <= g;
+		slot_chan[g] = c;
 		slot_sbord[g] = (t == TG_BURST_SYNC) ? (int32_t)psb : -1;
 	}
 	if (t == TG_BURST_SYNC) {
@@ -2506,7 +2588,7 @@ void k_grid_emit(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ 
 
 extern "C" int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uint32_t n, uint32_t *d_blk,
 			      uint32_t *d_slot_chan, int32_t *d_slot_sbord, uint32_t *d_list_sb, uint32_t *d_list_216,
-			      uint32_t *d_list_432, void *stream)
+			      uint32_t *d_list_432, const struct tg_chan_ent *d_chan, uint32_t nchan, void *stream)
 {
 	if (!n)
 		return 0;
@@ -2515,7 +2597,7 @@ extern "C" int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uin
 	hipLaunchKernelGGL(k_grid_count, dim3(nblocks), dim3(GRID_BLOCK), 0, s, d_cls, d_bits, n, d_blk);
 	hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(GRID_BLOCK), 0, s, d_blk, nblocks);
 	hipLaunchKernelGGL(k_grid_emit, dim3(nblocks), dim3(GRID_BLOCK), 0, s, d_cls, d_bits, n, d_blk, d_slot_chan, d_slot_sbord,
-			   d_list_sb, d_list_216, d_list_432);
+			   d_list_sb, d_list_216, d_list_432, d_chan, nchan);
 	return (int)hipGetLastError();
 }
 

@@ -27,6 +27,8 @@
 #include <time.h>
 #include <string.h>
 
+#include <pthread.h>
+
 #include "tetra_gpu.h"
 #include "tg_layout.h"
 #include "tg_internal.h"
@@ -745,7 +747,7 @@ int tgpu_sync_stream_grid_finish(struct tgpu_engine *eng, struct tgpu_plan *plan
 	out->anchor = anchor;
 	const double t2 = now_ms();
 	if (!rc && !out->noffgrid)
-		rc = tgpi_plan_grid_load(plan, ncls, out->grid_bits, scramb_init, stream);
+		rc = tgpi_plan_grid_load(plan, ncls, out->grid_bits, 1, &scramb_init, NULL, stream);
 	if (getenv("TGPU_SYNC_TIMING"))
 		fprintf(stderr, "tgpu_sync_stream_grid: wait for the classification %.3f ms, walk %.3f ms, device lists %.3f ms (%u of %u grid slots, %u events)\n",
 			t1 - t0, t2 - t1, now_ms() - t2, out->nslots, ncls, out->nevents);
@@ -791,6 +793,190 @@ int tgpu_sync_front_prof(struct tgpu_engine *eng, struct tgpu_plan *plan, const 
 	us[0] = (float)(acc[0] * 1e3 / nrep);
 	us[1] = (float)(acc[1] * 1e3 / nrep);
 	return rc;
+}
+
+/*
+ * Several recorded channels in ONE grid and one plan batch (BASELINE config 4: a GPU's share of the channels).
+ * begin: first lock of every channel on the host, one classification launch over all of them, one copy back;
+ * finish: the synchroniser walks (one per channel, on up to nthreads host threads -- channels are independent,
+ * the reference runs a process per channel), one bitmap, device-built lists with the channel of every slot.
+ * Record index of grid slot i of channel c = out[c].grid_base + i.
+ */
+struct tgpu_sync_multi {
+	struct tgpu_engine *eng;
+	struct tgpu_plan *plan;
+	uint32_t nchan, chunk, ngrid;
+	struct tgpu_multi_chan *ch;
+	struct tg_chan_ent *ent;
+	int *locks;
+};
+
+void tgpu_sync_multi_free(struct tgpu_sync_multi *st)
+{
+	if (!st)
+		return;
+	free(st->ch);
+	free(st->ent);
+	free(st->locks);
+	free(st);
+}
+
+int tgpu_sync_multi_begin(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+			  const uint8_t *d_base, uint32_t chunk, struct tgpu_sync_multi **out, void *stream)
+{
+	if (!eng || !plan || !nchan || nchan > 64 || !ch || !d_base || !chunk || !out)
+		return TGPU_EINVAL;
+	*out = NULL;
+	struct tgpu_sync_multi *st = calloc(1, sizeof(*st));
+	if (!st)
+		return TGPU_ENOMEM;
+	st->eng = eng;
+	st->plan = plan;
+	st->nchan = nchan;
+	st->chunk = chunk;
+	st->ch = malloc((size_t)nchan * sizeof(*ch));
+	st->ent = calloc(nchan, sizeof(*st->ent));
+	st->locks = calloc(nchan, sizeof(int));
+	int rc = (st->ch && st->ent && st->locks) ? TGPU_OK : TGPU_ENOMEM;
+	if (!rc)
+		memcpy(st->ch, ch, (size_t)nchan * sizeof(*ch));
+	uint64_t total = 0;
+	for (uint32_t c = 0; c < nchan && !rc; c++) {
+		uint64_t anchor = 0;
+		if (!ch[c].h_stream) {
+			rc = TGPU_EINVAL;
+			break;
+		}
+		rc = find_anchor(ch[c].h_stream, ch[c].len, chunk, &anchor, &st->locks[c]);
+		uint64_t n = 0;
+		if (!rc && st->locks[c] && anchor + TG_SLOT_BITS <= ch[c].len)
+			n = (ch[c].len - anchor) / TG_SLOT_BITS;
+		else
+			st->locks[c] = 0;
+		st->ent[c].d_off = ch[c].d_off;
+		st->ent[c].anchor = anchor;
+		st->ent[c].len = ch[c].len;
+		st->ent[c].gbase = (uint32_t)total;
+		st->ent[c].ncls = (uint32_t)n;
+		total += (n + 31) & ~(uint64_t)31;
+		if (total > 0xfffffff0u)
+			rc = TGPU_ECAPACITY;
+	}
+	st->ngrid = (uint32_t)total;
+	if (!rc && st->ngrid) {
+		uint32_t *d_packed, *d_cls, *cls;
+		uint16_t *d_ysum, *ysum;
+		struct tg_chan_ent *d_tab;
+		rc = tgpi_plan_grid_begin(plan, st->ngrid, &d_packed, &d_cls, &d_ysum, &cls, &ysum);
+		if (!rc)
+			rc = tgpi_plan_chan_table(plan, st->ent, nchan, &d_tab, stream);
+		if (!rc)
+			rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum, stream, NULL);
+		if (!rc)
+			rc = (int)hipMemcpyAsync(cls, d_cls, (size_t)st->ngrid * 6, hipMemcpyDeviceToHost, (hipStream_t)stream);
+	}
+	if (rc) {
+		tgpu_sync_multi_free(st);
+		return rc;
+	}
+	*out = st;
+	return TGPU_OK;
+}
+
+struct multi_job {
+	struct tgpu_sync_multi *st;
+	const uint32_t *cls;
+	const uint16_t *ysum;
+	uint32_t flags;
+	struct tgpu_sync_result *out;
+	volatile uint32_t next;
+	volatile int rc;
+};
+
+static void *multi_worker(void *arg)
+{
+	struct multi_job *j = arg;
+	for (;;) {
+		const uint32_t c = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+		if (c >= j->st->nchan)
+			return NULL;
+		const struct tgpu_multi_chan *ch = &j->st->ch[c];
+		const struct tg_chan_ent *e = &j->st->ent[c];
+		int rc;
+		if (e->ncls)
+			rc = tgpu_sync_walk(ch->h_stream, ch->len, j->st->chunk, e->anchor, j->cls + e->gbase, j->ysum + e->gbase,
+					    e->ncls, j->flags | TGPU_SYNC_GRID, &j->out[c]);
+		else {	/* never locks: nothing of it is in the grid */
+			rc = tgpu_sync_walk(ch->h_stream, ch->len, j->st->chunk, e->anchor, NULL, NULL, 0, j->flags & ~TGPU_SYNC_GRID,
+					    &j->out[c]);
+			j->out[c].noffgrid = j->out[c].nslots;
+		}
+		j->out[c].anchor = e->anchor;
+		j->out[c].grid_base = e->gbase;
+		if (rc)
+			j->rc = rc;
+	}
+}
+
+int tgpu_sync_multi_finish(struct tgpu_sync_multi *st, uint32_t flags, unsigned int nthreads, struct tgpu_sync_result *out,
+			   void *stream)
+{
+	if (!st || !out)
+		return TGPU_EINVAL;
+	memset(out, 0, (size_t)st->nchan * sizeof(*out));
+	int rc = (int)hipStreamSynchronize((hipStream_t)stream);
+	if (rc)
+		return rc;
+	uint32_t *d_packed, *d_cls, *cls = NULL;
+	uint16_t *d_ysum, *ysum = NULL;
+	if (st->ngrid && (rc = tgpi_plan_grid_begin(st->plan, st->ngrid, &d_packed, &d_cls, &d_ysum, &cls, &ysum)))
+		return rc;
+	struct multi_job job = { st, cls, ysum, flags, out, 0, 0 };
+	if (nthreads > st->nchan)
+		nthreads = st->nchan;
+	if (nthreads <= 1)
+		multi_worker(&job);
+	else {
+		pthread_t th[64];
+		unsigned int started = 0;
+		if (nthreads > 64)
+			nthreads = 64;
+		for (unsigned int i = 0; i + 1 < nthreads; i++)
+			if (!pthread_create(&th[started], NULL, multi_worker, &job))
+				started++;
+		multi_worker(&job);
+		for (unsigned int i = 0; i < started; i++)
+			pthread_join(th[i], NULL);
+	}
+	if (job.rc)
+		return job.rc;
+	if (!st->ngrid)
+		return TGPU_OK;
+	/* one bitmap over the whole grid (channel grids start at multiples of 32 slots) */
+	uint32_t *bits = calloc(((size_t)st->ngrid + 31) / 32, 4);
+	uint32_t *codes = malloc((size_t)st->nchan * 4);
+	if (!bits || !codes) {
+		free(bits);
+		free(codes);
+		return TGPU_ENOMEM;
+	}
+	uint32_t off = 0;
+	for (uint32_t c = 0; c < st->nchan; c++) {
+		codes[c] = st->ch[c].scramb_init;
+		if (out[c].grid_bits && !out[c].noffgrid)
+			memcpy(bits + st->ent[c].gbase / 32, out[c].grid_bits, (((size_t)st->ent[c].ncls + 31) / 32) * 4);
+		off += out[c].noffgrid;
+	}
+	rc = tgpi_plan_grid_load(st->plan, st->ngrid, bits, st->nchan, codes, st->ent, stream);
+	free(bits);
+	free(codes);
+	(void)off;
+	return rc;
+}
+
+uint32_t tgpu_sync_multi_ngrid(const struct tgpu_sync_multi *st)
+{
+	return st ? st->ngrid : 0;
 }
 
 int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const uint8_t *h_stream,

@@ -1636,3 +1636,64 @@ def test_config5_full_size_soft_decode_against_the_oracle(T, eng):
     nblk = int(2 * (n2 | sb).sum() + n1.sum())
     assert int(p["crc_ok"][:, 0].sum() + p["crc_ok"][n2 | sb, 1].sum()) == ok and 0.3 * nblk < ok < nblk
     plan.close()
+
+
+def test_config4_channels_in_one_grid_batch(T, eng):
+    """BASELINE config 4's per-GPU share as ONE batch (tgpu_sync_multi_*): eight recorded channels of different cells,
+    lengths, lead-ins and damage in one device buffer -> one classification launch, one walk per channel (host
+    threads), one multi-channel plan.  Every channel's events and delivered bursts == the oracle receiver's on that
+    channel alone, records == the single-channel grid path's, final codes per channel"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    cells = [(262, 42, 1), (901, 77, 9), (234, 14, 33), (1, 2, 3), (262, 42, 2), (505, 1, 60), (208, 10, 5), (222, 99, 7)]
+    streams, offs, o = [], [], 0
+    rng = np.random.default_rng(404)
+    for c, cell in enumerate(cells):
+        nsl = int(rng.integers(40, 1500)) if c != 3 else 2          # (one channel with next to nothing in it)
+        st, _ = _mix_stream(T, nsl, 900 + c, cell, ber=0.02)
+        if c == 5:
+            st = st[:len(st) - 700 - 200]                            # a channel that ends in the middle of a burst
+        streams.append(st)
+        offs.append(o)
+        o += (len(st) + T.STREAM_SLACK + 15) & ~15
+    buf = np.zeros(o + 4096, np.uint8)
+    for st, f in zip(streams, offs):
+        buf[f:f + len(st)] = st
+    d = torch.from_numpy(buf).cuda()
+    ntot = sum((len(st) // 510 + 32) for st in streams)
+    plan = T.Plan(eng, ntot, len(cells))
+    ms = T.MultiSync(eng, plan, streams, d.data_ptr(), offs, 64, hs)
+    outs = ms.finish(burst_events=True, nthreads=3)
+    d_rec = torch.zeros(max(ms.ngrid, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+    torch.cuda.synchronize()
+    rec = d_rec.cpu().numpy().reshape(-1, T.REC_BYTES)
+    codes = plan.final_codes()
+    ndeliv = 0
+    for c, (st, out) in enumerate(zip(streams, outs)):
+        _, wev = O.run_rx(st)
+        assert out["events"] == wev, c
+        assert out["noffgrid"] == 0
+        # the same channel alone through the single-channel grid path
+        p1 = T.Plan(eng, len(st) // 510 + 8, 1)
+        dd = torch.from_numpy(np.concatenate([st, np.zeros(T.STREAM_SLACK + 2304, np.uint8)])).cuda()
+        g = T.sync_stream_grid(eng, p1, st, dd.data_ptr(), 64, hs)
+        assert g["events"] == wev and g["nslots"] == out["nslots"] and g["anchor"] == out["anchor"]
+        if g["ngrid"]:
+            r1 = torch.zeros(g["ngrid"] * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+            p1.execute(dd.data_ptr(), r1.data_ptr(), hs)
+            torch.cuda.synchronize()
+            idx = T.grid_indices(g)
+            assert idx.tolist() == T.grid_indices(out).tolist()
+            a = r1.cpu().numpy().reshape(-1, T.REC_BYTES)[idx]
+            b = rec[out["grid_base"] + idx]
+            pa, pb = T.parse_records(a), T.parse_records(b)
+            for k in pa:
+                if k != "slot":
+                    assert (np.asarray(pa[k]) == np.asarray(pb[k])).all(), (c, k)
+            assert (pb["slot"] == out["grid_base"] + idx).all()
+            assert int(codes[c]) == int(p1.final_codes()[0])
+            ndeliv += len(idx)
+        p1.close()
+    assert ndeliv > 3000
+    plan.close()
