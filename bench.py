@@ -161,7 +161,7 @@ def host_threads_default():
     return n
 
 
-def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1):
+def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1):  # noqa: D401
     """config 3's stream: 100 random lead-in bits, a lock-only SB, n slots in frames of 8, 1 % damaged training
     sequences, 700 pad bytes"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -181,137 +181,237 @@ def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1):
 
 
 def bench_mix(args, T, torch, dist, rank, world, local):
-    """the metric's workload (BASELINE configs[2] composition; with N ranks every GPU has its own recordings)"""
-    n = args.bursts
-    stream, types, code = make_mix_stream(T, n, rank, mnc=42 + rank)
-    eng = T.Engine(local)
-    d_stream = torch.from_numpy(np.concatenate([stream, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+    """the metric's workload (BASELINE configs[2] composition, laid out as configs[3]'s per-GPU share): every GPU has
+    C recorded channels of its own, all of them in one batch per step"""
+    import queue
     import threading
-    W = args.sync_threads if args.sync_threads > 0 else max(1, min(6, host_threads_default() // max(1, world)))
+    n, C = args.bursts, max(1, args.channels)
+    per = n // C
+    streams, codes = [], []
+    for c in range(C):
+        g = rank * C + c
+        st, _, code = make_mix_stream(T, per, g, mnc=42 + g, cc=1 + g % 60)
+        streams.append(st)
+        codes.append(code)
+    offs, o = [], 0
+    for st in streams:
+        offs.append(o)
+        o += (len(st) + T.STREAM_SLACK + 15) & ~15
+    buf = np.zeros(o + 4096, np.uint8)
+    for st, f in zip(streams, offs):
+        buf[f:f + len(st)] = st
+    eng = T.Engine(local)
+    d_base = torch.from_numpy(buf).cuda()
+    cap = sum(len(st) // 510 + 32 for st in streams)
+    W = args.sync_threads if args.sync_threads > 0 else max(1, min(8, host_threads_default() // max(1, world)))
     W = max(1, min(W, args.steps))
-    share = [args.steps // W + (w < args.steps % W) for w in range(W)]
-    warm = max(2, -(-args.warmup // W))
-    start = threading.Barrier(W + 1)
-    state = {}
-    errors = []
+    gather = world > 1
+    nccl = args.backend == "nccl"
 
-    def worker(w):
-        try:
-            torch.cuda.set_device(local)
-            d_rec = [torch.empty((n + 8) * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)]
-            plan = [T.Plan(eng, n + 8, 1) for _ in range(2)]
-            dec = [torch.cuda.Stream() for _ in range(2)]
-            cst = [torch.cuda.Stream() for _ in range(2)]
-            done = [None, None]
-            total = warm + share[w]
-            g = [None, None]
-            g[0] = T.GridSync(eng, plan[0], stream, d_stream.data_ptr(), 64, cst[0].cuda_stream)
-            t_sync = 0.0
-            delivered = 0
-            res = None
-            last = 0
-            for k in range(total):
-                if k == warm:
-                    for e in done:
-                        if e is not None:
-                            e.synchronize()
-                    start.wait()             # the timed region starts when every thread has warmed up
+    # per-thread resources, kept over both phases
+    res_t = []
+    for w in range(W):
+        r = {"rec": [torch.empty(cap * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)],
+             "plan": [T.Plan(eng, cap, C) for _ in range(2)],
+             "dec": [torch.cuda.Stream() for _ in range(2)], "cst": [torch.cuda.Stream() for _ in range(2)]}
+        if gather:
+            r["wire"] = [torch.full((cap * T.WIRE_BYTES,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            r["sent"] = [None, None]         # CUDA event: the gather that last read this wire buffer is done
+        res_t.append(r)
+    if gather:
+        comm = torch.cuda.Stream()
+        sink = [[torch.empty(cap * T.WIRE_BYTES, dtype=torch.uint8, device="cuda" if nccl else "cpu") for _ in range(world)]
+                for _ in range(2)] if rank == 0 else [None, None]
+
+    def run_phase(nsteps, nwarm, with_gather):
+        """nwarm + nsteps steps per rank, dealt round-robin to the W threads; returns (seconds, delivered bursts, state)"""
+        total = nwarm + nsteps
+        start = threading.Barrier(W + 1)
+        ready = [threading.Event() for _ in range(total)]     # step s has been launched (its CUDA event recorded)
+        info = [None] * total
+        state, errors = {}, []
+
+        def worker(w):
+            try:
+                torch.cuda.set_device(local)
+                r = res_t[w]
+                mine = list(range(w, total, W))
+                done = [None, None]
+                ms = [None, None]
+                t_sync, delivered, outs, last = 0.0, 0, None, 0
+                if mine:
+                    ms[0] = T.MultiSync(eng, r["plan"][0], streams, d_base.data_ptr(), offs, 64, r["cst"][0].cuda_stream, codes=None)
+                for k, s_id in enumerate(mine):
+                    if s_id >= nwarm and (k == 0 or mine[k - 1] < nwarm):
+                        for e in done:
+                            if e is not None:
+                                e.synchronize()
+                        start.wait()             # the timed region starts when every thread has warmed up
+                        start.wait()
+                        t_sync, delivered = 0.0, 0
+                    i, j = k & 1, (k & 1) ^ 1
+                    if k + 1 < len(mine):
+                        if done[j] is not None:
+                            done[j].synchronize()    # the decode that last used that plan / record buffer
+                        ms[j] = T.MultiSync(eng, r["plan"][j], streams, d_base.data_ptr(), offs, 64, r["cst"][j].cuda_stream)
+                    a = time.perf_counter()
+                    outs = ms[i].finish(burst_events=False, nthreads=args.walk_threads)
+                    assert all(x["noffgrid"] == 0 for x in outs)
+                    t_sync += time.perf_counter() - a
+                    delivered += sum(x["nslots"] for x in outs)
+                    if with_gather:
+                        if r["sent"][i] is not None:
+                            r["dec"][i].wait_event(r["sent"][i])
+                        r["plan"][i].set_wire(r["wire"][i].data_ptr())
+                    else:
+                        r["plan"][i].set_wire(0)
+                    r["plan"][i].execute(d_base.data_ptr(), r["rec"][i].data_ptr(), r["dec"][i].cuda_stream)
+                    done[i] = torch.cuda.Event()
+                    done[i].record(r["dec"][i])
+                    if with_gather:
+                        info[s_id] = (w, i, done[i])
+                        ready[s_id].set()
+                    last = i
+                if not any(s >= nwarm for s in mine):      # a thread without a timed step still meets the barrier
                     start.wait()
-                    t_sync = 0.0
-                    delivered = 0
-                i = k & 1
-                j = i ^ 1
-                if k + 1 < total:
-                    if done[j] is not None:
-                        done[j].synchronize()    # the decode that last used that plan / record buffer
-                    g[j] = T.GridSync(eng, plan[j], stream, d_stream.data_ptr(), 64, cst[j].cuda_stream)
-                a = time.perf_counter()
-                res = g[i].finish(burst_events=False, scramb_init=0)     # wait for the classification, walk, device lists
-                assert res["noffgrid"] == 0 and res["ngrid"] <= n + 8
-                t_sync += time.perf_counter() - a
-                delivered += res["nslots"]
-                plan[i].execute(d_stream.data_ptr(), d_rec[i].data_ptr(), dec[i].cuda_stream)
-                done[i] = torch.cuda.Event()
-                done[i].record(dec[i])
-                last = i
-            for e in done:
-                if e is not None:
-                    e.synchronize()
-            state[w] = (res, plan, d_rec, last, t_sync, delivered)
-        except Exception as ex:          # pragma: no cover
-            errors.append(ex)
-            start.abort()
+                    start.wait()
+                for e in done:
+                    if e is not None:
+                        e.synchronize()
+                state[w] = (outs, last, t_sync, delivered, len([s for s in mine if s >= nwarm]))
+            except Exception as ex:          # pragma: no cover
+                errors.append(ex)
+                for e in ready:
+                    e.set()
+                start.abort()
 
-    threads = [threading.Thread(target=worker, args=(w,)) for w in range(W)]
-    for th in threads:
-        th.start()
-    start.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+        def gatherer():
+            """every step's decoded blocks (wire records) to rank 0, in step order, on a stream of its own: the
+            collective of step s waits for that step's decode only, and runs under the decodes that follow"""
+            try:
+                torch.cuda.set_device(local)
+                for s_id in range(total):
+                    ready[s_id].wait()
+                    if errors:
+                        return
+                    w, i, ev = info[s_id]
+                    wire = res_t[w]["wire"][i]
+                    if nccl:
+                        with torch.cuda.stream(comm):
+                            comm.wait_event(ev)
+                            dist.gather(wire, gather_list=sink[s_id & 1] if rank == 0 else None, dst=0)
+                            sent = torch.cuda.Event()
+                            sent.record(comm)
+                        res_t[w]["sent"][i] = sent
+                    else:   # control-flow check on a box with fewer GPUs than ranks: staged through the host
+                        ev.synchronize()
+                        dist.gather(wire.cpu(), gather_list=sink[s_id & 1] if rank == 0 else None, dst=0)
+                if nccl:
+                    comm.synchronize()
+            except Exception as ex:          # pragma: no cover
+                errors.append(ex)
+
+        threads = [threading.Thread(target=worker, args=(w,)) for w in range(W)]
+        gth = threading.Thread(target=gatherer) if with_gather else None
+        for th in threads:
+            th.start()
+        if gth:
+            gth.start()
+        start.wait()
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    start.wait()
-    for th in threads:
-        th.join()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        start.wait()
+        for th in threads:
+            th.join()
+        if gth:
+            gth.join()
         torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if errors:
-        raise errors[0]
-    delivered = sum(v[5] for v in state.values())
-    if world > 1:
-        t = torch.tensor([el, float(delivered)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        el, delivered = float(tmax[0].item()), int(t[1].item())
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if errors:
+            raise errors[0]
+        return el, sum(v[3] for v in state.values()), state
+
+    def reduce(el, delivered):
+        if world > 1:
+            t = torch.tensor([el, float(delivered)], dtype=torch.float64, device="cuda" if nccl else "cpu")
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return float(tmax[0].item()), int(t[1].item())
+        return el, delivered
+
+    warm = max(2 * W, args.warmup)
+    el, delivered, state = run_phase(args.steps, warm, False)
+    el, delivered = reduce(el, delivered)
+    decode_only = {"value": delivered / el, "ms_per_step": el / args.steps * 1e3, "bursts_delivered": delivered}
+    gathered = None
+    if gather:
+        el_g, del_g, state = run_phase(args.steps, warm, True)
+        el_g, del_g = reduce(el_g, del_g)
+        ngrid_r = sum((len(st) - 100) // 510 for st in streams)
+        per_rank_mb = cap * T.WIRE_BYTES / 1e6
+        gathered = {"value": del_g / el_g, "ms_per_step": el_g / args.steps * 1e3, "bursts_delivered": del_g,
+                    "bytes_per_rank_and_step": cap * T.WIRE_BYTES,
+                    "link_arithmetic": "every peer sends %.1f MB per step (%d grid slots x %d B wire record, undelivered slots "
+                                       "included) to rank 0 over its own xGMI link: %.1f GB/s per link at the gathered step time, "
+                                       "%.1f GB/s at the decode-only step time (one link direction ~ 64 GB/s by spec, 7 links into "
+                                       "rank 0); rank 0 takes in %.1f GB/s in total"
+                                       % (per_rank_mb, cap, T.WIRE_BYTES, per_rank_mb / (el_g / args.steps * 1e3),
+                                          per_rank_mb / (el / args.steps * 1e3), (world - 1) * per_rank_mb / (el_g / args.steps * 1e3))}
     if rank != 0:
         return None
-    res, plan, d_rec, last, _, _ = state[0]
-    t_sync = sum(v[4] for v in state.values()) / W
+    outs, last, _, _, _ = state[0]
+    r0 = res_t[0]
+    t_sync = sum(v[2] / max(1, v[4]) for v in state.values()) / W
     hs = torch.cuda.current_stream().cuda_stream
 
-    # correctness guard on the timed output: a sample of the delivered bursts against the oracle (checker only) --
-    # type-1 bits, BBK, CRC words and flags of the first 2048 delivered grid slots of the last decoded stream
-    first = T.grid_indices(res)[:2048]
-    p = T.parse_records(d_rec[last].view(-1, T.REC_BYTES)[torch.from_numpy(first).cuda()].cpu().numpy())
+    # correctness guard on the timed output: a sample of the delivered bursts of every channel against the oracle
+    # (checker only) -- type-1 bits, BBK and CRC words of up to 512 delivered grid slots per channel
     check = None
+    rec_all = r0["rec"][last].view(-1, T.REC_BYTES)
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oraclelib as O
-        anchor = res["anchor"]
-        sl = np.stack([stream[anchor + 510 * int(g):anchor + 510 * int(g) + 510] for g in first])
-        ty = p["type"].astype(np.uint8)
-        ok, want, wcrc = O.bench_decode_slots(sl, ty, code, use_acc=1, want_out=True, want_crc=True)
-        n1, n2, sb = ty == 0, ty == 1, ty == 3
-        good = (p["bbk"] == want[:, :14]).all() and (p["bits1"][n1] == want[n1, 14:282]).all() and \
-            (p["bits1"][n2][:, :124] == want[n2, 14:138]).all() and (p["bits2"][n2] == want[n2, 138:262]).all() and \
-            (p["bits1"][sb][:, :60] == want[sb, 14:74]).all() and (p["bits2"][sb] == want[sb, 138:262]).all() and \
-            (p["crc"][:, 0] == wcrc[:, 0]).all() and (p["crc"][n2 | sb, 1] == wcrc[n2 | sb, 1]).all() and \
-            (n1 | n2 | sb).all()
-        assert good, "decoded records differ from the oracle"
-        check = "type-1 bits, BBK and CRC words of %d delivered bursts equal the oracle's" % len(first)
+        nchk = 0
+        for c, (st, out) in enumerate(zip(streams, outs)):
+            first = T.grid_indices(out)[:512]
+            p = T.parse_records(rec_all[torch.from_numpy(out["grid_base"] + first).cuda()].cpu().numpy())
+            anchor = out["anchor"]
+            sl = np.stack([st[anchor + 510 * int(g):anchor + 510 * int(g) + 510] for g in first])
+            ty = p["type"].astype(np.uint8)
+            ok, want, wcrc = O.bench_decode_slots(sl, ty, codes[c], use_acc=1, want_out=True, want_crc=True)
+            n1, n2, sb = ty == 0, ty == 1, ty == 3
+            good = (p["bbk"] == want[:, :14]).all() and (p["bits1"][n1] == want[n1, 14:282]).all() and \
+                (p["bits1"][n2][:, :124] == want[n2, 14:138]).all() and (p["bits2"][n2] == want[n2, 138:262]).all() and \
+                (p["bits1"][sb][:, :60] == want[sb, 14:74]).all() and (p["bits2"][sb] == want[sb, 138:262]).all() and \
+                (p["crc"][:, 0] == wcrc[:, 0]).all() and (p["crc"][n2 | sb, 1] == wcrc[n2 | sb, 1]).all() and \
+                (n1 | n2 | sb).all() and (p["code"][~sb] == codes[c]).all()
+            assert good, "decoded records of channel %d differ from the oracle" % c
+            nchk += len(first)
+        check = "type-1 bits, BBK, CRC words and scrambling codes of %d delivered bursts (all %d channels) equal the oracle's" % (nchk, C)
 
-    # per-kernel durations (HIP events on the launch stream, after the timed region)
-    us_front, us_fix = T.sync_front_prof(eng, plan[last ^ 1], d_stream.data_ptr(), len(stream), res["anchor"], 64, 10, hs)
+    # per-kernel durations (HIP events on the launch stream, after the timed region): the front end on channel 0's
+    # share is not representative -- time the batch's own launches
+    us_front, us_fix = T.sync_front_prof_multi(eng, r0["plan"][last ^ 1], streams, d_base.data_ptr(), offs, 64, 10, hs)
     prof = T.Prof(8)
     for q in range(8):
-        plan[last].execute_prof(d_stream.data_ptr(), d_rec[last].data_ptr(), hs, prof, q)
+        r0["plan"][last].execute_prof(d_base.data_ptr(), r0["rec"][last].data_ptr(), hs, prof, q)
     torch.cuda.synchronize()
-    st = prof.read(8)[2:].mean(axis=0)      # ms per stage (k_front is skipped in stream mode: stage 0 is empty)
+    st_ms = prof.read(8)[2:].mean(axis=0)      # ms per stage (k_front is skipped in stream mode: stage 0 is empty)
     names = T.Prof.stage_names()
     kern_ms = {"k_front_stream": us_front * 1e-3, "k_front_stream_fix": us_fix * 1e-3}
     for i in range(1, len(names)):
-        kern_ms[names[i]] = float(st[i])
+        kern_ms[names[i]] = float(st_ms[i])
     dom = max(kern_ms, key=kern_ms.get)
-    ngrid = res["ngrid"]
-    tyd = p["type"]
-    # delivered bursts by type (whole stream): SB 1/8, N1 4/8, N2 3/8 of the delivered ones (the damage is uniform)
-    nd = res["nslots"]
-    n_sb, n_n1, n_n2 = nd // 8, nd // 2, nd - nd // 8 - nd // 2
+    ngrid = sum(x["ngrid"] for x in outs)
+    nd = sum(x["nslots"] for x in outs)
+    n_sb, n_n1, n_n2 = nd // 8, nd // 2, nd - nd // 8 - nd // 2     # delivered bursts by type (the damage is uniform)
     # SURVEY 8(d): 510 B in per slot the front end looks at; type-1 bits at 1 B/bit + 16 B per block out
     alg = {"k_front_stream": ngrid * 510, "k_front_stream_fix": 0,
            "k_vit<SB1>": n_sb * (60 + 16), "k_fill": 0, "k_masks": 0,
@@ -325,31 +425,38 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         valu_busy = tj.get("mix_valu_busy", {}).get(dom)
     except Exception:
         pass
-    value = delivered / el
+    head = gathered if gathered else decode_only
+    value = head["value"]
     out = {"metric": "decoded bursts/s", "value": value, "unit": "bursts/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-           "config": {"workload": "SB+NDB mix through the burst-sync front end (BASELINE configs[2] composition): per GPU a %d-slot "
-                                  "recorded channel, frames [SB,N1,N2,N1,N2,N1,N2,N1], cell code from SB1, 1%% damaged training "
-                                  "sequences, resident in HBM; step = one pass over the recording (GPU sequence search + demux of every "
-                                  "grid slot, host synchroniser walk at 64-byte feeds, device lists, SB1 / fill / masks / trellis); "
-                                  "value = delivered bursts/s; %d host threads per GPU each walking its own recordings" % (n, W),
-                      "slots_per_recording": n, "grid_slots": int(ngrid), "delivered_per_recording": int(nd),
-                      "host_threads_per_gpu": W, "parallelism": "independent recordings per GPU, no collective in decoding",
+           "config": {"workload": "SB+NDB mix through the burst-sync front end (BASELINE configs[2] composition in configs[3]'s layout): "
+                                  "per GPU %d recorded channels of %d slots each (own cell each), frames [SB,N1,N2,N1,N2,N1,N2,N1], cell "
+                                  "code from SB1, 1%% damaged training sequences, resident in HBM; step = one pass over all of a GPU's "
+                                  "channels as ONE batch (GPU sequence search + demux of every grid slot, host synchroniser walks at "
+                                  "64-byte feeds, device lists, SB1 / fill / masks / trellis); value = delivered bursts/s%s; %d host "
+                                  "threads per GPU, each pipelining its own steps" %
+                                  (C, per, ", every step's decoded blocks gathered to rank 0 (40-B wire records, RCCL, overlapped)" if gathered else "", W),
+                      "channels_per_gpu": C, "slots_per_channel": per, "grid_slots_per_step": int(ngrid),
+                      "delivered_per_step": int(nd), "host_threads_per_gpu": W,
+                      "parallelism": "channels sharded over GPUs (8 per GPU), no collective in decoding" +
+                                     ("; one RCCL gather of wire records per step to rank 0, on its own stream" if gathered else ""),
                       "check": check},
-           "breakdown_ms": {"sync finish per recording and thread (wait for the classification, host walk, device list build)":
-                            t_sync / max(share) * 1e3,
-                            "gpu kernels per recording (serialised, HIP events)": kern_ms},
+           "breakdown_ms": {"sync finish per step and thread (wait for the classification, host walks, device list build)": t_sync * 1e3,
+                            "gpu kernels per step (serialised, HIP events)": kern_ms},
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
                         "kernel_ms": kern_ms[dom],
-                        "pipeline_achieved_gbs_per_gpu": float(value / world * 820 / 1e9),
+                        "pipeline_achieved_gbs_per_gpu": float(decode_only["value"] / world * 820 / 1e9),
                         "note": "achieved = the dominant kernel's share of SURVEY 8(d)'s algorithmic bytes (k_front_stream: the 510 "
                                 "input bytes of every grid slot; a trellis kernel: type-1 bits at 1 B/bit + 16 B per block of the "
                                 "bursts it decodes) / its mean HIP-event duration on its launch stream, measured after the timed "
                                 "region; traffic = PMC bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes) and "
                                 "valu_busy_frac from profiles/traffic.json of the same command; every kernel of this path is bound by "
                                 "vector-instruction issue, not by HBM (DESIGN.md section 4)"}}
+    if gathered:
+        out["decode_only"] = decode_only
+        out["gathered"] = gathered
     return out
 
 
@@ -577,8 +684,10 @@ def main():
     ap.add_argument("--ber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 object of the default run")
+    ap.add_argument("--channels", type=int, default=8, help="mix: recorded channels per GPU (BASELINE config 4: 8), all in one batch")
+    ap.add_argument("--walk-threads", type=int, default=1, help="mix: host threads inside one step's synchroniser walks")
     ap.add_argument("--sync-threads", type=int, default=0,
-                    help="mix: host threads per GPU, each synchronising (walking) its own recordings (0 = min(6, usable cores / ranks))")
+                    help="mix: host threads per GPU, each synchronising (walking) its own recordings (0 = min(8, usable cores / ranks))")
     ap.add_argument("--workload", default="mix", choices=["mix", "config3", "config2", "config5", "conv"],
                     help="mix (default, = config3: the metric's workload): SB+NDB recordings through the GPU burst-sync front end, "
                          "1%% damaged training sequences; config2: aligned NDB slots, no front end; config5: float phases -> "

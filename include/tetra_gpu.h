@@ -185,15 +185,18 @@ int tgpu_float_to_bits_afc(struct tgpu_engine *eng, const float *d_in, uint64_t 
 int tgpu_plan_final_codes(struct tgpu_plan *plan, const uint8_t *d_rec, uint32_t *chan_code_out);
 
 /*
- * Transport form of the records: 48 bytes per slot, type-1 bits packed 8 per byte (layout in
- * csrc/tg_layout.h).  When a device buffer of nslots * TGPU_WIRE_BYTES is attached to the plan the
- * trellis kernels write it alongside the full records; it is what a rank sends to the collecting
- * rank over xGMI (RCCL gather).  tgpu_wire_unpack() rebuilds a full TGPU_REC_BYTES record on the
- * host; the slot id and the scrambling code are not transported and are passed in.
+ * Transport form of the records: 40 bytes per slot = ten dwords -- header (burst type, flags, the 14 BBK bits), the
+ * type-1 bits packed LSB first, the CRC words (crc_ok is not carried: it is crc == 0x1d0f); layout in
+ * csrc/tg_layout.h.  When a device buffer of nslots * TGPU_WIRE_BYTES is attached to the plan the trellis kernels
+ * write it alongside the full records; it is what a rank sends to the collecting rank over xGMI (RCCL gather).
+ * Slots a batch does not decode are not written: clear the buffer to 0xff once.  tgpu_wire_unpack() rebuilds a full
+ * TGPU_REC_BYTES record on the host (burst type 0xff for a slot that holds nothing); the slot id and the scrambling
+ * code are not transported and are passed in.  tgpu_wire_pack() is the host form of what the kernels write.
  */
-#define TGPU_WIRE_BYTES 48
+#define TGPU_WIRE_BYTES 40
 int tgpu_plan_set_wire(struct tgpu_plan *plan, uint8_t *d_wire /* NULL: off */);
 int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_code, uint8_t *rec);
+int tgpu_wire_pack(const uint8_t *rec, uint8_t *wire);
 
 /* diagnostic: copy the front kernel's packed slots (20 dwords per slot, csrc/tg_layout.h) of the
  * last executed batch to the host; synchronises the device */
@@ -446,6 +449,9 @@ int tgpu_sync_multi_finish(struct tgpu_sync_multi *st, uint32_t flags, unsigned 
 			   void *hip_stream);
 uint32_t tgpu_sync_multi_ngrid(const struct tgpu_sync_multi *st);
 void tgpu_sync_multi_free(struct tgpu_sync_multi *st);
+/* measurement aid, as tgpu_sync_front_prof() for a multi-channel batch */
+int tgpu_sync_front_prof_multi(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+			       const uint8_t *d_base, uint32_t chunk, uint32_t nrep, float us[2], void *hip_stream);
 
 /* measurement aid: the stream front end of a grid (anchor + 510 n) alone, nrep times on hip_stream with HIP events
  * around its launches: us[0] = k_front_stream, us[1] = k_front_stream_fix (mean microseconds).  The plan's grid

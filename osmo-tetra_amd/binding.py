@@ -175,6 +175,8 @@ def lib():
     L.tgpu_sync_multi_ngrid.argtypes = [C.c_void_p]
     L.tgpu_sync_multi_ngrid.restype = C.c_uint32
     L.tgpu_sync_multi_free.argtypes = [C.c_void_p]
+    L.tgpu_sync_front_prof_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(MultiChan), C.c_void_p, C.c_uint32,
+                                             C.c_uint32, C.POINTER(C.c_float), C.c_void_p]
     L.tgpu_acelp_build_map.argtypes = [C.POINTER(u8p), C.POINTER(C.c_uint), C.c_int, C.POINTER(C.c_int32)]
     L.tgpu_acelp_set_tables.argtypes = [C.POINTER(u8p), C.POINTER(C.c_uint)]
     L.tetra_acelp_type2_to_codec.argtypes = [u8p, u8p]
@@ -328,11 +330,11 @@ class Prof:
             self._h = C.c_void_p()
 
 
-WIRE_BYTES = 48
+WIRE_BYTES = 40
 
 
 def wire_unpack(wire, slot_ids=None, codes=None):
-    """(n,48) wire records -> (n,320) full records (tgpu_wire_unpack)"""
+    """(n,40) wire records -> (n,320) full records (tgpu_wire_unpack)"""
     wire = np.ascontiguousarray(wire, np.uint8).reshape(-1, WIRE_BYTES)
     n = len(wire)
     out = np.zeros((n, REC_BYTES), np.uint8)
@@ -340,6 +342,16 @@ def wire_unpack(wire, slot_ids=None, codes=None):
     for i in range(n):
         _chk(L.tgpu_wire_unpack(wire[i].ctypes.data_as(u8p), int(slot_ids[i]) if slot_ids is not None else i,
                                 int(codes[i]) if codes is not None else 0, out[i].ctypes.data_as(u8p)), "tgpu_wire_unpack")
+    return out
+
+
+def wire_pack(rec):
+    """(n,320) full records -> (n,40) wire records (tgpu_wire_pack: the host form of what the trellis kernels write)"""
+    rec = np.ascontiguousarray(rec, np.uint8).reshape(-1, REC_BYTES)
+    out = np.zeros((len(rec), WIRE_BYTES), np.uint8)
+    L = lib()
+    for i in range(len(rec)):
+        _chk(L.tgpu_wire_pack(rec[i].ctypes.data_as(u8p), out[i].ctypes.data_as(u8p)), "tgpu_wire_pack")
     return out
 
 
@@ -636,6 +648,20 @@ class MultiSync:
     def __del__(self):
         if getattr(self, "_h", None):
             lib().tgpu_sync_multi_free(self._h)
+
+
+def sync_front_prof_multi(engine, plan, streams, d_base_ptr, d_offs, chunk=64, nrep=10, hip_stream=0):
+    """tgpu_sync_front_prof_multi: mean microseconds of (k_front_stream, k_front_stream_fix) on a multi-channel batch"""
+    xs = [_np_u8(x) for x in streams]
+    ch = (MultiChan * len(xs))()
+    for c, x in enumerate(xs):
+        ch[c].h_stream = x.ctypes.data_as(u8p)
+        ch[c].d_off = int(d_offs[c])
+        ch[c].len = len(x)
+    us = (C.c_float * 2)()
+    _chk(lib().tgpu_sync_front_prof_multi(engine._h, plan._h, len(xs), ch, C.c_void_p(d_base_ptr), chunk, nrep, us,
+                                          C.c_void_p(hip_stream)), "tgpu_sync_front_prof_multi")
+    return float(us[0]), float(us[1])
 
 
 def sync_front_prof(engine, plan, d_stream_ptr, length, anchor, chunk=64, nrep=10, hip_stream=0):

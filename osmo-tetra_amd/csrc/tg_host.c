@@ -805,30 +805,78 @@ static void unpack_bits(const uint8_t *src, int nbits, uint8_t *dst)
 		dst[i] = (src[i >> 3] >> (i & 7)) & 1;
 }
 
+static void pack_bits(const uint8_t *src, int nbits, uint32_t *dst)
+{
+	for (int i = 0; i < nbits; i++)
+		if (src[i])
+			dst[i >> 5] |= 1u << (i & 31);
+}
+
+/* full record -> wire record (host): what the trellis kernels write next to the record when a wire buffer is set */
+int tgpu_wire_pack(const uint8_t *rec, uint8_t *wire)
+{
+	if (!rec || !wire)
+		return TGPU_EINVAL;
+	uint32_t w[TG_WIRE_WORDS];
+	uint16_t crc[2];
+	memset(w, 0, sizeof(w));
+	memcpy(crc, rec + TG_REC_CRC, 4);
+	const uint8_t type = rec[TG_REC_TYPE];
+	uint32_t bbk = 0;
+	pack_bits(rec + TG_REC_BBK, 14, &bbk);
+	w[0] = type | ((uint32_t)rec[TG_REC_FLAGS] << 8) | (bbk << 16);
+	switch (type) {
+	case TETRA_TRAIN_NORM_1:
+		pack_bits(rec + TG_REC_BITS1, 268, w + TG_WIRE_W_BITS1);
+		w[TG_WIRE_W_CRC] |= (uint32_t)crc[0] << TG_WIRE_SCHF_CRC_SHIFT;
+		break;
+	case TETRA_TRAIN_NORM_2:
+	case TETRA_TRAIN_SYNC:
+		pack_bits(rec + TG_REC_BITS1, type == TETRA_TRAIN_SYNC ? 60 : 124, w + TG_WIRE_W_BITS1);
+		pack_bits(rec + TG_REC_BITS2, 124, w + TG_WIRE_W_BITS2);
+		w[TG_WIRE_W_CRC] = crc[0] | ((uint32_t)crc[1] << 16);
+		break;
+	default:
+		memset(w, 0xff, sizeof(w));
+		break;
+	}
+	memcpy(wire, w, sizeof(w));
+	return TGPU_OK;
+}
+
 int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_code, uint8_t *rec)
 {
 	if (!wire || !rec)
 		return TGPU_EINVAL;
+	uint32_t w[TG_WIRE_WORDS];
+	memcpy(w, wire, sizeof(w));
 	memset(rec, 0, TG_REC_BYTES);
-	const uint8_t type = wire[TG_WIRE_TYPE];
+	const uint8_t type = (uint8_t)w[0];
 	rec[TG_REC_TYPE] = type;
-	rec[TG_REC_FLAGS] = wire[TG_WIRE_FLAGS];
-	memcpy(rec + TG_REC_CRC_OK, wire + TG_WIRE_CRC_OK, 2);
-	memcpy(rec + TG_REC_CRC, wire + TG_WIRE_CRC, 4);
+	if (type != TETRA_TRAIN_NORM_1 && type != TETRA_TRAIN_NORM_2 && type != TETRA_TRAIN_SYNC) {
+		rec[TG_REC_TYPE] = TG_BURST_NONE;
+		return TGPU_OK;
+	}
+	rec[TG_REC_FLAGS] = (uint8_t)(w[0] >> 8);
 	memcpy(rec + TG_REC_CODE, &scrambling_code, 4);
 	memcpy(rec + TG_REC_SLOT, &slot_id, 4);
-	unpack_bits(wire + TG_WIRE_BBK, 14, rec + TG_REC_BBK);
-	switch (type) {
-	case TETRA_TRAIN_NORM_1:
-		unpack_bits(wire + TG_WIRE_BITS1, 268, rec + TG_REC_BITS1);
-		break;
-	case TETRA_TRAIN_NORM_2:
-		unpack_bits(wire + TG_WIRE_BITS1, 124, rec + TG_REC_BITS1);
-		unpack_bits(wire + TG_WIRE_BITS2, 124, rec + TG_REC_BITS2);
-		break;
-	case TETRA_TRAIN_SYNC: {
-		unpack_bits(wire + TG_WIRE_BITS1, 60, rec + TG_REC_BITS1);
-		unpack_bits(wire + TG_WIRE_BITS2, 124, rec + TG_REC_BITS2);
+	const uint32_t bbk = w[0] >> 16;
+	unpack_bits((const uint8_t *)&bbk, 14, rec + TG_REC_BBK);
+	uint16_t crc[2] = { 0, 0 };
+	if (type == TETRA_TRAIN_NORM_1) {
+		unpack_bits((const uint8_t *)(w + TG_WIRE_W_BITS1), 268, rec + TG_REC_BITS1);
+		crc[0] = (uint16_t)(w[TG_WIRE_W_CRC] >> TG_WIRE_SCHF_CRC_SHIFT);
+		rec[TG_REC_CRC_OK] = crc[0] == TG_CRC_OK;
+	} else {
+		unpack_bits((const uint8_t *)(w + TG_WIRE_W_BITS1), type == TETRA_TRAIN_SYNC ? 60 : 124, rec + TG_REC_BITS1);
+		unpack_bits((const uint8_t *)(w + TG_WIRE_W_BITS2), 124, rec + TG_REC_BITS2);
+		crc[0] = (uint16_t)w[TG_WIRE_W_CRC];
+		crc[1] = (uint16_t)(w[TG_WIRE_W_CRC] >> 16);
+		rec[TG_REC_CRC_OK] = crc[0] == TG_CRC_OK;
+		rec[TG_REC_CRC_OK + 1] = crc[1] == TG_CRC_OK;
+	}
+	memcpy(rec + TG_REC_CRC, crc, 4);
+	if (type == TETRA_TRAIN_SYNC) {
 		/* SYNC-PDU fields (lower_mac/tetra_lower_mac.c:284-297) from the SB1 bits */
 		const uint8_t *b = rec + TG_REC_BITS1;
 		uint32_t f[6];
@@ -843,10 +891,6 @@ int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_
 		memcpy(rec + TG_REC_SBF0, &f0, 4);
 		memcpy(rec + TG_REC_SBF1, &f1, 4);
 		memcpy(rec + TG_REC_SBCODE, &code, 4);
-		break;
-	}
-	default:
-		break;
 	}
 	return TGPU_OK;
 }

@@ -833,15 +833,26 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	/* request a group: 16 bytes per lane from the 16-byte aligned address below the group's first byte.  Groups the
 	 * fast path may not touch (their windows or the exact form's 640-byte views reach past the stream) fetch group 0
 	 * instead, so that every step issues the same loads */
+	/* multi-channel batches: the channel a wave is in changes a handful of times over its groups, so its table entry
+	 * is kept in scalar registers and looked up again only when a group falls outside [cg0, cg1) */
+	uint32_t cg0 = 1, cg1 = 0, cncls = 0;
+	uint64_t cfirst = 0, cspan = 0;		/* stream offset of the channel's grid slot 0; bytes from there to its end */
 	auto fetch = [&](uint32_t g, tg_group_data &d) {
 		uint64_t gb, first;
-		if (prm.nchan) {	/* which channel the group belongs to: its stream, its grid origin */
-			const uint32_t c = chan_of_slot(prm.chan, prm.nchan, 4u * g, lane);
-			const uint32_t i0 = 4u * g - prm.chan[c].gbase;
-			first = prm.chan[c].d_off + prm.chan[c].anchor;
+		if (prm.nchan) {
+			const uint32_t s0 = 4u * g;
+			if (s0 < cg0 || s0 >= cg1) {
+				const uint32_t c = chan_of_slot(prm.chan, prm.nchan, s0, lane);
+				cg0 = prm.chan[c].gbase;
+				cg1 = c + 1 < prm.nchan ? prm.chan[c + 1].gbase : prm.nslots;
+				cncls = prm.chan[c].ncls;
+				cfirst = prm.chan[c].d_off + prm.chan[c].anchor;
+				cspan = prm.chan[c].len - prm.chan[c].anchor;
+			}
+			const uint32_t i0 = s0 - cg0;
+			first = cfirst;
 			gb = first + (uint64_t)i0 * TG_SLOT_BITS;
-			d.fast = i0 + 4u <= prm.chan[c].ncls &&
-				 prm.chan[c].anchor + (uint64_t)i0 * TG_SLOT_BITS + TG_GROUP_BYTES + TG_STREAM_VIEW <= prm.chan[c].len;
+			d.fast = i0 + 4u <= cncls && (uint64_t)i0 * TG_SLOT_BITS + TG_GROUP_BYTES + TG_STREAM_VIEW <= cspan;
 		} else {
 			first = prm.anchor;
 			gb = prm.anchor + (uint64_t)g * TG_GROUP_BYTES;
@@ -1244,16 +1255,28 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 	r[TG_REC_CRC_OK + which] = (uint8_t)crc_ok;
 	*(uint16_t *)(r + TG_REC_CRC + 2 * which) = (uint16_t)crc;
 
-	/* optional bit-packed copy for transport (wave-uniform branch) */
-	uint8_t *wr = wire ? wire + (size_t)slot * TG_WIRE_BYTES : nullptr;
+	/* optional bit-packed copy for transport (wave-uniform branch): tg_layout.h "Wire record".  The lanes of a slot
+	 * write disjoint bytes: each block its payload words and its half (SCH/F: its field) of w[9], the primary lane
+	 * the header word */
+	uint32_t *wr = wire ? (uint32_t *)(wire + (size_t)slot * TG_WIRE_BYTES) : nullptr;
 	if (wr) {
-		uint32_t *wb = (uint32_t *)(wr + (which ? TG_WIRE_BITS2 : TG_WIRE_BITS1));
+		uint32_t *wb = wr + (which ? TG_WIRE_W_BITS2 : TG_WIRE_W_BITS1);
 		constexpr int NWD = (TYPE1 + 31) / 32;
+		if (KIND == TG_KIND_432) {
 #pragma unroll
-		for (int q = 0; q < NWD; q++)
-			wb[q] = (q == NWD - 1) ? (od[q] & ((1u << (TYPE1 & 31)) - 1)) : od[q];
-		wr[TG_WIRE_CRC_OK + which] = (uint8_t)crc_ok;
-		*(uint16_t *)(wr + TG_WIRE_CRC + 2 * which) = (uint16_t)crc;
+			for (int q = 0; q < NWD - 1; q++)
+				wb[q] = od[q];
+			wb[NWD - 1] = (od[NWD - 1] & ((1u << (TYPE1 & 31)) - 1)) | (crc << TG_WIRE_SCHF_CRC_SHIFT);
+		} else {
+#pragma unroll
+			for (int q = 0; q < NWD; q++)
+				wb[q] = (q == NWD - 1) ? (od[q] & ((1u << (TYPE1 & 31)) - 1)) : od[q];
+			((uint16_t *)(wr + TG_WIRE_W_CRC))[which] = (uint16_t)crc;
+			if (KIND == TG_KIND_SB1) {	/* SB1 fills w[1..2]; w[3..4] are nobody else's */
+				wr[3] = 0;
+				wr[4] = 0;
+			}
+		}
 	}
 
 	if (KIND == TG_KIND_SB1) {
@@ -1311,11 +1334,8 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 			r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
 			*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
 			*(uint32_t *)(r + TG_REC_SLOT) = slot;
-			if (wr) {
-				wr[TG_WIRE_TYPE] = (uint8_t)btype;
-				wr[TG_WIRE_FLAGS] = (uint8_t)(meta >> 8);
-				*(uint32_t *)(wr + TG_WIRE_BBK) = bb & 0x3fff;
-			}
+			if (wr)
+				wr[0] = btype | (((meta >> 8) & 0xff) << 8) | ((bb & 0x3fff) << 16);
 		}
 	}
 }

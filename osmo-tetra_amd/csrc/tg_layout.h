@@ -126,21 +126,25 @@
 #define TG_REC_BITS2      176
 
 /*
- * Wire record, 48 bytes per slot: the same decoded blocks bit-packed (LSB first) for transport
- * over xGMI (the unit of the RCCL gather when records leave the GPU that decoded them).
- *   @0  u8 burst_type   @1 u8 flags   @2 u8 crc_ok[2]   @4 u16 crc[2]
- *   @8  first block:  SB1 (60 bits) / BLK1 (124) / SCH-F (268), bit i of the block = bit i of the field
- *   @24 second block: SB2 / BLK2 (124 bits)          (SCH-F runs through, 9 dwords from @8)
- *   @44 u32: BBK type-1 bits in bits 0..13
+ * Wire record, 40 bytes per slot = 10 dwords: the same decoded blocks bit-packed (LSB first) for transport over
+ * xGMI (the unit of the RCCL gather when records leave the GPU that decoded them).
+ *   w[0]     burst type (byte 0, 0xff = nothing) | flags (byte 1, TG_FLAG_*) | BBK type-1 bits << 16 (14 bits)
+ *   w[1..9]  NORM_1: SCH/F 268 bits (w[9] bits 0..11 are its last 12), crc[0] in w[9] bits 12..27
+ *            NORM_2: BLK1 124 bits in w[1..4], BLK2 in w[5..8], w[9] = crc[0] | crc[1] << 16
+ *            SYNC  : SB1 60 bits in w[1..2], SB2 in w[5..8], w[9] = crc[0] | crc[1] << 16
+ * 282 payload bits + flags + the CRC words; crc_ok is not carried, it is crc == 0x1d0f (lower_mac/crc_simple.h,
+ * TETRA_CRC_OK).  (The 48-byte form of round 1 spent 8 bytes on byte-sized fields.)  The slot id and the
+ * scrambling code are the receiver's knowledge (position in the gathered array, channel state):
+ * tgpu_wire_unpack() takes them as arguments.  Slots the batch does not decode are not written: clear the buffer
+ * to 0xff once.
  */
-#define TG_WIRE_BYTES     48
-#define TG_WIRE_TYPE      0
-#define TG_WIRE_FLAGS     1
-#define TG_WIRE_CRC_OK    2
-#define TG_WIRE_CRC       4
-#define TG_WIRE_BITS1     8
-#define TG_WIRE_BITS2     24
-#define TG_WIRE_BBK       44
+#define TG_WIRE_BYTES     40
+#define TG_WIRE_WORDS     10
+#define TG_WIRE_W_BITS1   1	/* first block from w[1] */
+#define TG_WIRE_W_BITS2   5	/* second block (216-bit kinds) from w[5] */
+#define TG_WIRE_W_CRC     9
+#define TG_WIRE_SCHF_CRC_SHIFT 12
+#define TG_CRC_OK         0x1d0f
 
 #ifdef __cplusplus
 extern "C" {

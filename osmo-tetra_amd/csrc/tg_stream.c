@@ -974,6 +974,53 @@ int tgpu_sync_multi_finish(struct tgpu_sync_multi *st, uint32_t flags, unsigned 
 	return rc;
 }
 
+int tgpu_sync_front_prof_multi(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+			       const uint8_t *d_base, uint32_t chunk, uint32_t nrep, float us[2], void *stream)
+{
+	struct tgpu_sync_multi *st = NULL;
+	if (!nrep || !us)
+		return TGPU_EINVAL;
+	int rc = tgpu_sync_multi_begin(eng, plan, nchan, ch, d_base, chunk, &st, stream);	/* (also the warm-up run) */
+	if (rc)
+		return rc;
+	us[0] = us[1] = 0;
+	uint32_t *d_packed, *d_cls, *cls;
+	uint16_t *d_ysum, *ysum;
+	struct tg_chan_ent *d_tab = NULL;
+	hipEvent_t ev[3] = { NULL, NULL, NULL };
+	if (st->ngrid) {
+		rc = tgpi_plan_grid_begin(plan, st->ngrid, &d_packed, &d_cls, &d_ysum, &cls, &ysum);
+		if (!rc)
+			rc = tgpi_plan_chan_table(plan, st->ent, nchan, &d_tab, stream);
+		for (int i = 0; i < 3 && !rc; i++)
+			rc = (int)hipEventCreate(&ev[i]);
+		double acc[2] = { 0, 0 };
+		for (uint32_t r = 0; r < nrep && !rc; r++) {
+			float a = 0, b = 0;
+			rc = (int)hipEventRecord(ev[0], (hipStream_t)stream);
+			if (!rc)
+				rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum, stream, ev[1]);
+			if (!rc)
+				rc = (int)hipEventRecord(ev[2], (hipStream_t)stream);
+			if (!rc)
+				rc = (int)hipEventSynchronize(ev[2]);
+			if (!rc)
+				rc = (int)hipEventElapsedTime(&a, ev[0], ev[1]);
+			if (!rc)
+				rc = (int)hipEventElapsedTime(&b, ev[1], ev[2]);
+			acc[0] += a;
+			acc[1] += b;
+		}
+		for (int i = 0; i < 3; i++)
+			if (ev[i])
+				(void)hipEventDestroy(ev[i]);
+		us[0] = (float)(acc[0] * 1e3 / nrep);
+		us[1] = (float)(acc[1] * 1e3 / nrep);
+	}
+	tgpu_sync_multi_free(st);
+	return rc;
+}
+
 uint32_t tgpu_sync_multi_ngrid(const struct tgpu_sync_multi *st)
 {
 	return st ? st->ngrid : 0;

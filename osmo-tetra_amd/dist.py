@@ -3,7 +3,7 @@
 
 The path shards by channel: channels are independent, the reference itself runs
 one process per channel.  No collective takes part in decoding; the only exchange is the final
-gather of decoded blocks to the collecting rank, in the 48-byte wire form (tg_layout.h), each
+gather of decoded blocks to the collecting rank, in the 40-byte wire form (tg_layout.h), each
 peer -> root transfer riding its own xGMI link.
 """
 import torch
@@ -20,7 +20,7 @@ def shard_channels(nchan, rank, world):
 def gather_wire(local, dst=0, group=None, async_op=False, out=None):
     """Gather equally sized wire-record tensors to `dst`.
 
-    local: uint8 tensor (nslots * 48,) on this rank's device (CUDA for nccl, CPU for gloo).
+    local: uint8 tensor (nslots * 40,) on this rank's device (CUDA for nccl, CPU for gloo).
     Returns (list_of_tensors_or_None, work_or_None); the list is only filled on `dst`
     (index = source rank, i.e. channel-shard order)."""
     world = dist.get_world_size(group)

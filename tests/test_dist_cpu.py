@@ -19,17 +19,38 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _fake_wire(chan, nslots):
-    """deterministic wire records of one channel (content is arbitrary but well-formed)"""
-    rng = np.random.default_rng(1000 + chan)
-    w = np.zeros((nslots, T.WIRE_BYTES), np.uint8)
-    types = rng.choice([T.TRAIN_NORM_1, T.TRAIN_NORM_2, T.TRAIN_SYNC], nslots)
-    w[:, 0] = types
-    w[:, 2:4] = 1
-    w[:, 8:44] = rng.integers(0, 256, (nslots, 36))
-    w[:, 44] = rng.integers(0, 256, nslots)
-    w[:, 45] = rng.integers(0, 64, nslots)
-    return w
+def _channel_records(chan, nslots):
+    """REAL decoded records of one channel, made on the CPU: synthetic slots of the channel's cell (noisy, so that
+    blocks fail their CRC too) decoded by the oracle, laid out as the 320-byte records the trellis kernels write"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oraclelib as O
+    mcc, mnc, cc = 262, 42 + chan, 1 + chan % 60
+    code = O.scramb_get_init(mcc, mnc, cc)
+    types = np.array([3, 0, 1, 0, 1, 0, 1, 0] * (nslots // 8 + 1), np.uint8)[:nslots]
+    slots = T.synth_slots(types, seed=300 + chan, scramb_init=code, mcc=mcc, mnc=mnc, cc=cc, ber=0.04)
+    ok, want, wcrc = O.bench_decode_slots(slots, types, code, use_acc=1, want_out=True, want_crc=True)
+    rec = np.zeros((nslots, T.REC_BYTES), np.uint8)
+    rec[:, 0] = types
+    two = types != 0
+    rec[:, 2] = wcrc[:, 0] == 0x1D0F
+    rec[two, 3] = wcrc[two, 1] == 0x1D0F
+    rec[:, 4:8] = wcrc.view(np.uint8).reshape(nslots, 4)
+    rec[~two, 6:8] = 0
+    rec[:, 8:12] = np.full(nslots, code, np.uint32).view(np.uint8).reshape(nslots, 4)
+    rec[:, 12:16] = np.arange(nslots, dtype=np.uint32).view(np.uint8).reshape(nslots, 4)
+    rec[:, 32:46] = want[:, :14]
+    n1, n2, sb = types == 0, types == 1, types == 3
+    rec[n1, 48:316] = want[n1, 14:282]
+    rec[n2, 48:172] = want[n2, 14:138]
+    rec[sb, 48:108] = want[sb, 14:74]
+    rec[two, 176:300] = want[two, 138:262]
+    return rec, code
+
+
+def _real_wire(chan, nslots):
+    rec, _ = _channel_records(chan, nslots)
+    return T.wire_pack(rec)
 
 
 def _worker(rank, world, port, nchan, nslots, q):
@@ -41,7 +62,7 @@ def _worker(rank, world, port, nchan, nslots, q):
     per = max(tdist.shard_channels(nchan, r, world)[1] - tdist.shard_channels(nchan, r, world)[0] for r in range(world))
     local = np.zeros((per * nslots, T.WIRE_BYTES), np.uint8)
     for k, c in enumerate(range(lo, hi)):
-        local[k * nslots:(k + 1) * nslots] = _fake_wire(c, nslots)
+        local[k * nslots:(k + 1) * nslots] = _real_wire(c, nslots)
     out, work = tdist.gather_wire(torch.from_numpy(local.reshape(-1)), dst=0, async_op=True)
     work.wait()
     if rank == 0:
@@ -81,15 +102,16 @@ def test_gloo_gather_of_wire_records_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = np.concatenate([_fake_wire(c, nslots) for c in range(nchan)])
-    assert (got == want).all()
-    # the collecting rank expands wire records to full records on the host
-    rec = T.wire_unpack(got[:50], slot_ids=np.arange(50), codes=np.full(50, 0x41802A07, np.uint32))
-    p = T.parse_records(rec)
-    assert (p["type"] == got[:50, 0]).all() and (p["code"] == 0x41802A07).all()
-    n1 = got[:50, 0] == T.TRAIN_NORM_1
-    bits = np.unpackbits(got[:50, 8:44], axis=1, bitorder="little")
-    assert (p["bits1"][n1] == bits[n1, :268]).all()
-    n2 = got[:50, 0] == T.TRAIN_NORM_2
-    assert (p["bits1"][n2][:, :124] == bits[n2, :124]).all() and (p["bits2"][n2] == bits[n2, 128:252]).all()
-    assert (p["bbk"] == np.unpackbits(got[:50, 44:46], axis=1, bitorder="little")[:, :14]).all()
+    # the collecting rank expands the gathered wire records to full records on the host: every channel's blocks are
+    # the oracle's decode of that channel (type-1 bits, BBK, CRC words, crc_ok, SYNC-PDU fields of the SYNC bursts)
+    nbad = 0
+    for c in range(nchan):
+        rec, code = _channel_records(c, nslots)
+        w = got[c * nslots:(c + 1) * nslots]
+        back = T.wire_unpack(w, slot_ids=np.arange(nslots), codes=np.full(nslots, code, np.uint32))
+        sb = rec[:, 0] == 3
+        assert (back[:, :16] == rec[:, :16]).all() and (back[:, 28:] == rec[:, 28:]).all()
+        p = T.parse_records(back)
+        assert (p["sbcode"][sb & (p["crc_ok"][:, 0] == 1)] == code).all()
+        nbad += int((p["crc_ok"][:, 0] == 0).sum())
+    assert nbad > 0

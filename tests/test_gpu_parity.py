@@ -433,7 +433,8 @@ def test_front_kernel_packing(T, eng):
 
 
 def test_wire_records_equal_full_records(T, eng):
-    """the 48-byte transport form written by the trellis kernels expands to exactly the 320-byte record"""
+    """the 40-byte transport form written by the trellis kernels expands to exactly the 320-byte record, and is
+    byte for byte what the host packer makes of that record (every byte of a decoded slot's wire record is written)"""
     import torch
     code = O.scramb_get_init(262, 42, 1)
     types = np.array([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_NORM_2] * 40, np.uint8)
@@ -441,7 +442,7 @@ def test_wire_records_equal_full_records(T, eng):
     n = len(types)
     d_stream = torch.from_numpy(slots.reshape(-1)).cuda()
     d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
-    d_wire = torch.zeros(n * T.WIRE_BYTES, dtype=torch.uint8, device="cuda")
+    d_wire = torch.full((n * T.WIRE_BYTES,), 0xA5, dtype=torch.uint8, device="cuda")
     plan = T.Plan(eng, n, 1)
     plan.load(np.arange(n, dtype=np.uint64) * 510, types, None, np.array([code], np.uint32))
     plan.set_wire(d_wire.data_ptr())
@@ -449,8 +450,11 @@ def test_wire_records_equal_full_records(T, eng):
     torch.cuda.synchronize()
     rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
     p = T.parse_records(rec)
-    back = T.wire_unpack(d_wire.cpu().numpy(), slot_ids=np.arange(n), codes=p["code"])
+    wire = d_wire.cpu().numpy().reshape(n, T.WIRE_BYTES)
+    back = T.wire_unpack(wire, slot_ids=np.arange(n), codes=p["code"])
     assert (back == rec).all()
+    assert (wire == T.wire_pack(rec)).all()
+    assert 0 < int(p["crc_ok"].sum()) < 2 * n          # good and failed blocks both in there
     plan.close()
 
 
