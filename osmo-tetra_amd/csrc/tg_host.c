@@ -78,6 +78,7 @@ struct tgpu_plan {
 	hipEvent_t ev_fork, ev_join;
 	uint32_t *h_last_slot_of_chan;
 	struct tg_chan_ent *d_chan_tab, *h_chan_tab;	/* multi-channel stream mode: channel table (64 entries) */
+	uint32_t *d_defer;	/* stream mode: slots the packed-bit front end hands to its exact pass (count + list) */
 };
 
 const char *tgpu_strerror(int err)
@@ -182,7 +183,7 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	void *d[] = { p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
-		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab };
+		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab, p->d_defer };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
 			(void)hipFree(d[i]);
@@ -313,6 +314,11 @@ int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packe
 		if (e != hipSuccess)
 			return (int)e;
 	}
+	if (!p->d_defer) {
+		hipError_t e = hipMalloc((void **)&p->d_defer, TG_DEFER_WORDS(p->max_slots) * 4);
+		if (e != hipSuccess)
+			return (int)e;
+	}
 	if (!p->h_grid && hipHostMalloc((void **)&p->h_grid, (size_t)p->max_slots * 6 + 16, hipHostMallocDefault) != hipSuccess) {
 		p->h_grid = NULL;
 		return TGPU_ENOMEM;
@@ -324,6 +330,11 @@ int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packe
 	*h_cls = p->h_grid;
 	*h_ysum = (uint16_t *)(p->h_grid + ngrid);
 	return TGPU_OK;
+}
+
+uint32_t *tgpi_plan_defer_scratch(struct tgpu_plan *p)
+{
+	return p ? p->d_defer : NULL;
 }
 
 /* device copy of a channel table for the multi-channel stream mode (owned by the plan, <= 64 entries) */

@@ -12,12 +12,13 @@ int tgk_init(void);
 /* d_slot_desc[i] = byte offset | (uint64_t)burst type << 56 */
 int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 	      uint32_t nslots, uint32_t *d_packed, uint8_t *d_rec, void *stream);
-/* stream mode: grid slot n at anchor + 510 n; writes packed slots and one classification word per slot */
+/* stream mode: grid slot n at anchor + 510 n; writes packed slots and one classification word per slot.
+ * d_defer: scratch of TG_DEFER_WORDS(nslots) dwords (the slots the packed-bit pass hands to the exact pass);
+ * ev_mid: hipEvent_t recorded between the two passes, or NULL */
+#define TG_DEFER_WORDS(nslots) ((size_t)(nslots) + 16)
 int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
-		     uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream);
-int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
-			uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream,
-			void *ev_mid /* hipEvent_t recorded between the packed-bit kernel and its fix-up pass, or NULL */);
+		     uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer,
+		     void *stream, void *ev_mid);
 /* several channels in one grid (BASELINE config 4): channel c owns grid slots gbase .. gbase + ncls - 1, gbase a
  * multiple of 32 (padding slots behind ncls are classified "nothing"); its stream lies at byte d_off of d_base */
 struct tg_chan_ent {
@@ -25,7 +26,8 @@ struct tg_chan_ent {
 	uint32_t gbase, ncls;
 };
 int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots,
-			   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream, void *ev_mid);
+			   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer,
+			   void *stream, void *ev_mid);
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
 	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */,
@@ -82,6 +84,7 @@ int tgpi_engine_bind(const struct tgpu_engine *eng);
 struct tgpu_plan;
 int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packed, uint32_t **d_cls, uint16_t **d_ysum,
 			 uint32_t **h_cls, uint16_t **h_ysum);	/* h_*: pinned mirrors owned by the plan */
+uint32_t *tgpi_plan_defer_scratch(struct tgpu_plan *p);	/* TG_DEFER_WORDS(max_slots) dwords, after tgpi_plan_grid_begin() */
 int tgpi_plan_chan_table(struct tgpu_plan *p, const struct tg_chan_ent *ents, uint32_t nchan, struct tg_chan_ent **d_out,
 			 void *stream);
 /* ents == NULL, nchan == 1: one channel owns the grid; else the table given to tgpi_plan_chan_table() */

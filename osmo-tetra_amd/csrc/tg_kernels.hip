@@ -648,21 +648,21 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
 /* classification word of a slot the packed-bit kernel leaves to k_front_stream_fix (never a valid word: offsets stay below 640) */
 #define TG_CLS_DEFER 0xffffffffu
 
-/* second pass of the packed-bit front end: every slot marked TG_CLS_DEFER goes through the exact per-position
- * search.  A wave scans 64 classification words at a time; marked slots are rare (damaged training sequences,
- * the end of the stream). */
+/* second pass of the packed-bit front end: every slot the first pass deferred (it appended them to a list: defer[0] =
+ * count, slots from defer[TG_DEFER_LIST]) goes through the exact per-position search, one wave per list entry at a
+ * time.  Deferred slots are rare (damaged training sequences, the end of a stream); the grid is sized for about one
+ * entry per wave, a wave takes entries wave, wave + nwaves, ... */
+#define TG_DEFER_LIST 16
 __global__ __launch_bounds__(256)
 void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm,
-			uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
+			uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
+			const uint32_t *__restrict__ defer)
 {
 	STREAM_SLOT_TABLES(TG_STREAM_VIEW / 4 + 4)
-	const uint32_t nchunks = (prm.nslots + 63) >> 6;
-	for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
-		const uint32_t s = ch * 64 + lane;
-		unsigned long long m = __ballot(s < prm.nslots && cls[s] == TG_CLS_DEFER);
-		while (m) {
-			const uint32_t slot = ch * 64 + (uint32_t)__builtin_ctzll(m);
-			m &= m - 1;
+	const uint32_t count = defer[0];
+	for (uint32_t e = wave; e < count; e += nwaves) {
+		{
+			const uint32_t slot = defer[TG_DEFER_LIST + e];
 			uint32_t myword, clsword, ys;
 			if (prm.nchan) {
 				const uint32_t c = chan_of_slot(prm.chan, prm.nchan, slot, lane);
@@ -788,7 +788,8 @@ struct tg_group_data {
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TG_STREAM_WPE, TG_STREAM_WPE)))
 void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
-		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
+		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
+		    uint32_t *__restrict__ defer)
 {
 	constexpr uint64_t PY = tsq_bits(TSQ_Y), PN = tsq_bits(TSQ_N), PP = tsq_bits(TSQ_P);
 	__shared__ uint32_t s_bits[4][72];	/* per wave: the group's bit string (68 dwords used) */
@@ -932,14 +933,14 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			ys |= TG_YS_MULTI;
 		if (!yb)
 			ys = TG_YS_NONE;
-		const bool defer = defer_all || a == 0;
+		const bool dfr = defer_all || a == 0;
 		uint32_t dtype = TG_BURST_NONE;
 		if (rc == TG_BURST_SYNC ? offs == TG_SYNC_TRAIN_OFF : offs == TG_NORM_TRAIN_OFF)
 			dtype = rc;
-		if (defer)
+		if (dfr)
 			dtype = TG_BURST_NONE;
-		const uint32_t clsword = defer ? TG_CLS_DEFER : (rc | (offs << 8) | (early ? (uint32_t)TG_CLS_EARLY21 << 24 : 0u));
-		const uint32_t meta = defer ? 0u : (dtype | (offs << 16));
+		const uint32_t clsword = dfr ? TG_CLS_DEFER : (rc | (offs << 8) | (early ? (uint32_t)TG_CLS_EARLY21 << 24 : 0u));
+		const uint32_t meta = dfr ? 0u : (dtype | (offs << 16));
 
 		const uint32_t first = 4u * g;
 		const uint32_t cnt = (prm.nslots - first < 4u) ? prm.nslots - first : 4u;
@@ -965,6 +966,17 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			mo[lane * TG_PACKED_WORDS + TG_PW_META] = meta;
 			mo[80 + lane] = clsword;
 			mo[84 + lane] = ys;
+		}
+		{	/* slots this pass could not settle: onto the list of k_front_stream_fix (one atomic per group that has any) */
+			const uint32_t dm = (uint32_t)__ballot(lane < cnt && dfr) & 15u;
+			if (dm) {
+				uint32_t pos = 0;
+				if (lane == 0)
+					pos = atomicAdd(defer, (uint32_t)__builtin_popcount(dm));
+				pos = __builtin_amdgcn_readfirstlane(pos);
+				if (lane < 4 && ((dm >> lane) & 1))
+					defer[TG_DEFER_LIST + pos + __builtin_popcount(dm & ((1u << lane) - 1))] = first + lane;
+			}
 		}
 		front_flush(mo, lane, first, cnt, packed);
 		if (lane < cnt) {
@@ -1249,6 +1261,9 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 			o.y = spread4(hw >> 4);
 			o.z = spread4(hw >> 8);
 			o.w = (q * 16 + 12 < TYPE1) ? spread4(hw >> 12) : 0u;	/* TYPE1 = 12 mod 16 */
+#ifdef TG_EXP_NOSTORE
+			if (q == 0 || hw == 0x12345u)
+#endif
 			dst[q] = o;
 		}
 	}
@@ -2260,20 +2275,34 @@ static uint32_t host_pattern_bits(const uint8_t *seq, int from, int n)
 	return v;
 }
 
-extern "C" int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
-				   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream, void *ev_mid);
-
-extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
-				uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream)
-{
-	return tgk_front_stream_ev(d_stream, anchor, len, nslots, chunk, d_packed, d_cls, d_ysum, stream, NULL);
-}
-
 static void stream_patterns(tg_stream_params &prm, uint32_t chunk);
+
+/* both passes of the packed-bit front end; d_defer: scratch of TG_DEFER_WORDS(nslots) dwords (count + list) */
+static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &prm, uint32_t *d_packed, uint32_t *d_cls,
+			       uint16_t *d_ysum, uint32_t *d_defer, hipStream_t s, void *ev_mid)
+{
+	const uint32_t nslots = prm.nslots;
+	uint32_t blocks = ((nslots + 3) / 4 + 3) / 4;	/* a wave per group of four slots */
+	uint32_t cap = 256 * 8;
+	if (const char *e = getenv("TGPU_FRONT_BLOCKS"))
+		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
+	if (blocks > cap)
+		blocks = cap;
+	HIPCHK(hipMemsetAsync(d_defer, 0, 4, s));
+	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
+	if (ev_mid)
+		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
+	uint32_t fblocks = (nslots / 128 + 3) / 4 + 1;	/* about a wave per deferred slot at 1 % of them */
+	if (fblocks > 256 * 16)
+		fblocks = 256 * 16;
+	hipLaunchKernelGGL(k_front_stream_fix, dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
+	return (int)hipGetLastError();
+}
 
 /* several channels in one grid: d_chan = device copy of nchan (<= 64) tg_chan_ent, nslots = the grid's total size */
 extern "C" int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots,
-				      uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream, void *ev_mid)
+				      uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer,
+				      void *stream, void *ev_mid)
 {
 	if (!nslots)
 		return 0;
@@ -2285,18 +2314,7 @@ extern "C" int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_cha
 	prm.chan = d_chan;
 	prm.nchan = nchan;
 	stream_patterns(prm, chunk);
-	hipStream_t s = (hipStream_t)stream;
-	uint32_t blocks = ((nslots + 3) / 4 + 3) / 4;
-	if (blocks > 256 * 8)
-		blocks = 256 * 8;
-	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, s, d_base, prm, d_packed, d_cls, d_ysum);
-	if (ev_mid)
-		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
-	uint32_t fblocks = ((nslots + 63) / 64 + 3) / 4;
-	if (fblocks > 256 * 32)
-		fblocks = 256 * 32;
-	hipLaunchKernelGGL(k_front_stream_fix, dim3(fblocks), dim3(256), 0, s, d_base, prm, d_packed, d_cls, d_ysum);
-	return (int)hipGetLastError();
+	return launch_stream_front(d_base, prm, d_packed, d_cls, d_ysum, d_defer, (hipStream_t)stream, ev_mid);
 }
 
 static void stream_patterns(tg_stream_params &prm, uint32_t chunk)
@@ -2310,8 +2328,9 @@ static void stream_patterns(tg_stream_params &prm, uint32_t chunk)
 }
 
 /* ev_mid (optional hipEvent_t): recorded between the packed-bit kernel and its fix-up pass (per-kernel timing) */
-extern "C" int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
-				   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, void *stream, void *ev_mid)
+extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
+				uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer,
+				void *stream, void *ev_mid)
 {
 	if (!nslots)
 		return 0;
@@ -2335,20 +2354,7 @@ extern "C" int tgk_front_stream_ev(const uint8_t *d_stream, uint64_t anchor, uin
 			HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
 		return (int)hipGetLastError();
 	}
-	uint32_t blocks = ((nslots + 3) / 4 + 3) / 4;	/* a wave per group of four slots */
-	uint32_t cap = 256 * 8;
-	if (const char *e = getenv("TGPU_FRONT_BLOCKS"))
-		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
-	if (blocks > cap)
-		blocks = cap;
-	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum);
-	if (ev_mid)
-		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
-	uint32_t fblocks = ((nslots + 63) / 64 + 3) / 4;	/* a wave per 64 classification words */
-	if (fblocks > 256 * 32)
-		fblocks = 256 * 32;
-	hipLaunchKernelGGL(k_front_stream_fix, dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum);
-	return (int)hipGetLastError();
+	return launch_stream_front(d_stream, prm, d_packed, d_cls, d_ysum, d_defer, s, ev_mid);
 }
 
 extern "C" int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc, uint32_t nslots,

@@ -616,15 +616,17 @@ int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_
 	int brc = tgpi_engine_bind(eng);
 	if (brc)
 		return brc;
-	uint32_t *d_cls = NULL, *d_packed = NULL;
+	uint32_t *d_cls = NULL, *d_packed = NULL, *d_defer = NULL;
 	/* classification words, then (same allocation) the SYNC-sequence summaries */
 	hipError_t e = hipMalloc((void **)&d_cls, (size_t)nslots * 6);
 	if (e == hipSuccess)
 		e = hipMalloc((void **)&d_packed, (size_t)nslots * TG_PACKED_WORDS * 4);
+	if (e == hipSuccess)
+		e = hipMalloc((void **)&d_defer, TG_DEFER_WORDS(nslots) * 4);
 	int rc = (int)e;
 	if (!rc)
 		rc = tgk_front_stream(d_stream, anchor, len, nslots, chunk, d_packed, d_cls,
-				      h_ysum ? (uint16_t *)(d_cls + nslots) : NULL, stream);
+				      h_ysum ? (uint16_t *)(d_cls + nslots) : NULL, d_defer, stream, NULL);
 	if (!rc)
 		rc = (int)hipMemcpyAsync(h_cls, d_cls, (size_t)nslots * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
 	if (!rc && h_ysum)
@@ -635,6 +637,8 @@ int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_
 		(void)hipFree(d_cls);
 	if (d_packed)
 		(void)hipFree(d_packed);
+	if (d_defer)
+		(void)hipFree(d_defer);
 	return rc;
 }
 
@@ -712,7 +716,7 @@ int tgpu_sync_stream_grid_begin(struct tgpu_engine *eng, struct tgpu_plan *plan,
 	uint16_t *d_ysum, *ysum;
 	if ((rc = tgpi_plan_grid_begin(plan, ncls, &d_packed, &d_cls, &d_ysum, &cls, &ysum)))
 		return rc;
-	rc = tgk_front_stream(d_stream, anchor, len, ncls, chunk, d_packed, d_cls, d_ysum, stream);
+	rc = tgk_front_stream(d_stream, anchor, len, ncls, chunk, d_packed, d_cls, d_ysum, tgpi_plan_defer_scratch(plan), stream, NULL);
 	if (!rc)	/* words and summaries are adjacent on both sides: one copy into the plan's pinned mirror */
 		rc = (int)hipMemcpyAsync(cls, d_cls, (size_t)ncls * 6, hipMemcpyDeviceToHost, (hipStream_t)stream);
 	out->ngrid = ncls;
@@ -774,7 +778,8 @@ int tgpu_sync_front_prof(struct tgpu_engine *eng, struct tgpu_plan *plan, const 
 	for (uint32_t r = 0; r < nrep && !rc; r++) {
 		rc = (int)hipEventRecord(ev[0], (hipStream_t)stream);
 		if (!rc)
-			rc = tgk_front_stream_ev(d_stream, anchor, len, (uint32_t)n, chunk, d_packed, d_cls, d_ysum, stream, ev[1]);
+			rc = tgk_front_stream(d_stream, anchor, len, (uint32_t)n, chunk, d_packed, d_cls, d_ysum,
+					      tgpi_plan_defer_scratch(plan), stream, ev[1]);
 		if (!rc)
 			rc = (int)hipEventRecord(ev[2], (hipStream_t)stream);
 		if (!rc)
@@ -871,7 +876,8 @@ int tgpu_sync_multi_begin(struct tgpu_engine *eng, struct tgpu_plan *plan, uint3
 		if (!rc)
 			rc = tgpi_plan_chan_table(plan, st->ent, nchan, &d_tab, stream);
 		if (!rc)
-			rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum, stream, NULL);
+			rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
+						    tgpi_plan_defer_scratch(plan), stream, NULL);
 		if (!rc)
 			rc = (int)hipMemcpyAsync(cls, d_cls, (size_t)st->ngrid * 6, hipMemcpyDeviceToHost, (hipStream_t)stream);
 	}
@@ -999,7 +1005,8 @@ int tgpu_sync_front_prof_multi(struct tgpu_engine *eng, struct tgpu_plan *plan, 
 			float a = 0, b = 0;
 			rc = (int)hipEventRecord(ev[0], (hipStream_t)stream);
 			if (!rc)
-				rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum, stream, ev[1]);
+				rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
+							    tgpi_plan_defer_scratch(plan), stream, ev[1]);
 			if (!rc)
 				rc = (int)hipEventRecord(ev[2], (hipStream_t)stream);
 			if (!rc)
