@@ -42,6 +42,7 @@ int tgpi_engine_bind(const struct tgpu_engine *eng)
 }
 #define BIND(eng) do { int b_ = tgpi_engine_bind(eng); if (b_) return b_; } while (0)
 
+#define TGPU_SMALL_PLAN 256u	/* plans up to this many slots keep their descriptors in mapped host memory */
 #define TGPU_NKINDS 4	/* trellis kinds TG_KIND_SB1 / _216 / _432 / _168; index 4 = BBK in block-mode lists */
 
 struct tgpu_plan {
@@ -50,6 +51,8 @@ struct tgpu_plan {
 	uint32_t nslots, nchan, nsb, n216, n432;
 	int loaded;
 	int static_masks;	/* batch has no SYNC slot: mask entries are known at load time */
+	int static_pending;	/* ... and the copy of the indices + the mask kernel still have to run (first execute) */
+	int up_mapped;		/* small plans: the upload arena is pinned host memory the kernels read in place */
 	/* device */
 	uint8_t *d_up, *h_up;	/* upload arena (device / pinned host mirror): one copy per load */
 	size_t up_bytes;
@@ -59,6 +62,7 @@ struct tgpu_plan {
 	uint32_t *d_list_sb, *d_list_216, *d_list_432;
 	uint32_t *d_packed;
 	uint32_t *d_maskidx;
+	uint32_t *d_idx_stage;	/* static batches: the mask indices as uploaded (copied to d_maskidx by the first execute) */
 	uint32_t *d_masks;
 	uint32_t *d_chan_code;	/* in d_up */
 	uint32_t *d_sb_ok, *d_sb_code;
@@ -141,12 +145,23 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	const size_t n = max_slots;
 	/* descriptors 8n, chan 4n, sbord 4n, lists <= 8n in total, static mask indices 4n, codes, padding */
 	p->up_bytes = 28 * n + 4 * (size_t)max_chan + 8 * UP_ALIGN;
-	DALLOC(p->d_up, p->up_bytes);
-	if (hipHostMalloc((void **)&p->h_up, p->up_bytes, hipHostMallocDefault) != hipSuccess) {
+	/* small plans (the drop-in channel API at small batch sizes: a flush is a round trip, and every copy in it costs
+	 * more than the bytes): descriptors and lists stay in pinned host memory and the kernels read them in place */
+	p->up_mapped = max_slots <= TGPU_SMALL_PLAN && !getenv("TGPU_NO_ZERO_COPY");
+	if (hipHostMalloc((void **)&p->h_up, p->up_bytes, p->up_mapped ? hipHostMallocMapped : hipHostMallocDefault) != hipSuccess) {
 		p->h_up = NULL;
 		tgpu_plan_destroy(p);
 		return TGPU_ENOMEM;
 	}
+	if (p->up_mapped) {
+		hipError_t e_ = hipHostGetDevicePointer((void **)&p->d_up, p->h_up, 0);
+		if (e_ != hipSuccess) {
+			p->d_up = NULL;
+			tgpu_plan_destroy(p);
+			return (int)e_;
+		}
+	} else
+		DALLOC(p->d_up, p->up_bytes);
 	DALLOC(p->d_packed, n * TG_PACKED_WORDS * 4);
 	DALLOC(p->d_maskidx, n * 4);
 	DALLOC(p->d_masks, (1 + (size_t)max_chan + n) * TG_MASK_WORDS * 4);
@@ -182,7 +197,7 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->side) (void)hipStreamDestroy(p->side);
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-	void *d[] = { p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
+	void *d[] = { p->up_mapped ? NULL : p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
 		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab, p->d_defer };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
@@ -274,18 +289,14 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 			h_idx[i] = 1 + ch;
 	}
 	memcpy(h_code, chan_code, (size_t)nchan * 4);
-	HCHK(hipMemcpy(p->d_up, p->h_up, o, hipMemcpyHostToDevice));
-	p->static_masks = 0;
-	if (is_static) {
-		/* no SYNC burst in the batch: every slot keeps its channel's carry-in code, so the
-		 * forward fill degenerates to entry 1 + chan and the masks can be built right now */
-		HCHK(hipMemcpyAsync(p->d_maskidx, d_idx_stage, (size_t)nslots * 4, hipMemcpyDeviceToDevice, NULL));
-		int rc = tgk_masks(p->d_chan_code, nchan, p->d_sb_ok, p->d_sb_code, 0, NULL, NULL, p->d_masks, NULL);
-		if (rc)
-			return rc;
-		HCHK(hipDeviceSynchronize());
-		p->static_masks = 1;
-	}
+	if (!p->up_mapped)
+		HCHK(hipMemcpy(p->d_up, p->h_up, o, hipMemcpyHostToDevice));
+	/* no SYNC burst in the batch: every slot keeps its channel's carry-in code, so the forward fill degenerates to
+	 * entry 1 + chan and the masks depend on the carry-in codes alone: one index copy + k_masks over 1 + nchan entries,
+	 * issued on the caller's stream in front of the first execute (static_pending) */
+	p->static_masks = is_static;
+	p->static_pending = is_static;
+	p->d_idx_stage = d_idx_stage;
 	p->packed_ready = 0;
 	p->block_mode = 0;
 	p->nslots = nslots;
@@ -386,7 +397,8 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 		return TGPU_ECAPACITY;
 	memcpy(p->h_up, codes, (size_t)nchan * 4);
 	memcpy(p->h_up + ((uint8_t *)d_bits - p->d_up), h_bits, nwords * 4);
-	HCHK(hipMemcpyAsync(p->d_up, p->h_up, upload, hipMemcpyHostToDevice, (hipStream_t)stream));
+	if (!p->up_mapped)
+		HCHK(hipMemcpyAsync(p->d_up, p->h_up, upload, hipMemcpyHostToDevice, (hipStream_t)stream));
 	int rc = tgk_grid_lists(p->d_grid, d_bits, ngrid, d_blk, p->d_slot_chan, p->d_slot_sbord, p->d_list_sb,
 				p->d_list_216, p->d_list_432, ents ? p->d_chan_tab : NULL, ents ? nchan : 1, stream);
 	if (rc)
@@ -406,6 +418,7 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 			}
 	}
 	p->static_masks = 0;
+	p->static_pending = 0;
 	p->packed_ready = 1;
 	p->block_mode = 0;
 	p->nslots = ngrid;
@@ -494,6 +507,13 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	BIND(p->eng);
 	if (!p->loaded || (soft && p->packed_ready) || p->block_mode)
 		return TGPU_ESTATE;
+	if (p->static_pending && p->nslots) {
+		HCHK(hipMemcpyAsync(p->d_maskidx, p->d_idx_stage, (size_t)p->nslots * 4,
+				    hipMemcpyDefault, (hipStream_t)stream));
+		if ((rc = tgk_masks(p->d_chan_code, p->nchan, p->d_sb_ok, p->d_sb_code, 0, NULL, NULL, p->d_masks, stream)))
+			return rc;
+		p->static_pending = 0;
+	}
 	MARK(0);
 	if (p->nslots) {
 		if (soft) {
@@ -530,7 +550,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	/* the two trellis kernels do not depend on each other: unless per-stage timing was asked for,
 	 * k_vit<432> goes to a side stream (fork/join with events, still capturable) so that the tails
 	 * of the two launches overlap */
-	const int fork = (ev == NULL) && p->n216 && p->n432;
+	const int fork = (ev == NULL) && p->n216 && p->n432 && p->nslots > 4096;	/* (a small batch gains nothing from the side stream) */
 	if (fork) {
 		hipError_t e_ = hipEventRecord(p->ev_fork, (hipStream_t)stream);
 		if (e_ == hipSuccess)
@@ -697,8 +717,9 @@ int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t 
 	}
 	memcpy(h_code, uniq, (size_t)nu * 4);
 	free(uniq);
-	HCHK(hipMemcpy(p->d_up, p->h_up, o, hipMemcpyHostToDevice));
-	HCHK(hipMemcpyAsync(p->d_maskidx, d_idx, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, NULL));
+	if (!p->up_mapped)
+		HCHK(hipMemcpy(p->d_up, p->h_up, o, hipMemcpyHostToDevice));
+	HCHK(hipMemcpyAsync(p->d_maskidx, d_idx, (size_t)nblocks * 4, hipMemcpyDefault, NULL));
 	int rc = tgk_masks(p->d_chan_code, nu, p->d_sb_ok, p->d_sb_code, 0, NULL, NULL, p->d_masks, NULL);
 	if (rc)
 		return rc;
@@ -716,6 +737,7 @@ int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t 
 	p->nslots = nblocks;
 	p->nchan = nu;
 	p->static_masks = 1;
+	p->static_pending = 0;
 	p->packed_ready = 0;
 	p->block_mode = 1;
 	p->loaded = 1;

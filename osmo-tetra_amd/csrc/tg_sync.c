@@ -158,6 +158,7 @@ struct tgpu_channel {
 	int *is_traffic;
 	bool *blk1_stolen, *blk2_stolen;
 	int last_error;
+	int zero_copy;		/* h_slots / h_rec are mapped: d_slots / d_rec alias them */
 
 	/* block queue of the tp_sap_udata_ind() seam (allocated on first use) */
 	struct tgpu_plan *bplan;
@@ -210,10 +211,18 @@ int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unit
 	ch->h_off = calloc(n, sizeof(uint64_t));
 	ch->h_type = calloc(n, 1);
 	ch->h_chan = calloc(n, 4);
-	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_slots, n * SLOT_STRIDE, 0);
-	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_rec, n * TGPU_REC_BYTES, 0);
-	if (e == hipSuccess) e = hipMalloc((void **)&ch->d_slots, n * SLOT_STRIDE);
-	if (e == hipSuccess) e = hipMalloc((void **)&ch->d_rec, n * TGPU_REC_BYTES);
+	/* small batches are round trips: the bursts stay in pinned host memory, the kernels read them and write the
+	 * records in place over PCIe (no copy operations in a flush); larger ones go through device buffers */
+	ch->zero_copy = batch_slots <= 64 && !getenv("TGPU_NO_ZERO_COPY");
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_slots, n * SLOT_STRIDE + 64, ch->zero_copy ? hipHostMallocMapped : 0);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_rec, n * TGPU_REC_BYTES, ch->zero_copy ? hipHostMallocMapped : 0);
+	if (ch->zero_copy) {
+		if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ch->d_slots, ch->h_slots, 0);
+		if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ch->d_rec, ch->h_rec, 0);
+	} else {
+		if (e == hipSuccess) e = hipMalloc((void **)&ch->d_slots, n * SLOT_STRIDE + 64);
+		if (e == hipSuccess) e = hipMalloc((void **)&ch->d_rec, n * TGPU_REC_BYTES);
+	}
 	if (e == hipSuccess) e = hipStreamCreate(&ch->stream);
 	if (e != hipSuccess || !ch->pend || !ch->h_off || !ch->h_type || !ch->h_chan) {
 		tgpu_channel_destroy(ch);
@@ -232,8 +241,8 @@ void tgpu_channel_destroy(struct tgpu_channel *ch)
 	if (ch->stream) (void)hipStreamDestroy(ch->stream);
 	if (ch->h_slots) (void)hipHostFree(ch->h_slots);
 	if (ch->h_rec) (void)hipHostFree(ch->h_rec);
-	if (ch->d_slots) (void)hipFree(ch->d_slots);
-	if (ch->d_rec) (void)hipFree(ch->d_rec);
+	if (ch->d_slots && !ch->zero_copy) (void)hipFree(ch->d_slots);
+	if (ch->d_rec && !ch->zero_copy) (void)hipFree(ch->d_rec);
 	tgpu_plan_destroy(ch->plan);
 	if (ch->bq_bits) (void)hipHostFree(ch->bq_bits);
 	if (ch->bq_rec) (void)hipHostFree(ch->bq_rec);
@@ -443,11 +452,13 @@ static int flush_slots(struct tgpu_channel *ch)
 	for (uint32_t i = 0; i < n; i++)
 		ch->h_type[i] = ch->pend[i].type;
 	rc = tgpu_plan_load(ch->plan, n, ch->h_off, ch->h_type, ch->h_chan, 1, &ch->scramb_init);
-	if (!rc && (e = hipMemcpyAsync(ch->d_slots, ch->h_slots, (size_t)n * SLOT_STRIDE, hipMemcpyHostToDevice, ch->stream)))
+	if (!rc && !ch->zero_copy &&
+	    (e = hipMemcpyAsync(ch->d_slots, ch->h_slots, (size_t)n * SLOT_STRIDE, hipMemcpyHostToDevice, ch->stream)))
 		rc = (int)e;
 	if (!rc)
 		rc = tgpu_plan_execute(ch->plan, ch->d_slots, ch->d_rec, ch->stream);
-	if (!rc && (e = hipMemcpyAsync(ch->h_rec, ch->d_rec, (size_t)n * TGPU_REC_BYTES, hipMemcpyDeviceToHost, ch->stream)))
+	if (!rc && !ch->zero_copy &&
+	    (e = hipMemcpyAsync(ch->h_rec, ch->d_rec, (size_t)n * TGPU_REC_BYTES, hipMemcpyDeviceToHost, ch->stream)))
 		rc = (int)e;
 	if (!rc && (e = hipStreamSynchronize(ch->stream)))
 		rc = (int)e;
