@@ -38,7 +38,7 @@ def main():
     print(f"# rocprofv3 summary of {os.path.basename(d.rstrip('/'))}\n")
     t = os.path.join(d, "trace", "trace_results.db")
     if os.path.exists(t):
-        print("## kernel trace (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline`)\n")
+        print("## kernel trace (rocprofv3 --kernel-trace --stats, command in the title line)\n")
         print(trace_stats(t))
         print()
     for db in sorted(glob.glob(os.path.join(d, "pmc_*", "pmc_results.db"))):

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the rocprofv3 summaries of tools/prof_run.sh:
+   python tools/prof_to_traffic.py gpurun_out/prof_<mix tag> gpurun_out/prof_<config2 tag>
+bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the x2 is the gfx950 FETCH_SIZE correction of
+MI355X_MICROARCH.md); VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = {"k_vit<0, 1>": "k_vit<SB1>", "k_vit<1, 1>": "k_vit<216>", "k_vit<2, 1>": "k_vit<432>"}
+
+
+def read(path):
+    vals = {}
+    for line in open(os.path.join(path, "summary.md")):
+        m = re.match(r"\| (.+?) \| (\w+) \| ([0-9.e+]+) \| (\d+) \|", line)
+        if m:
+            vals.setdefault(NAMES.get(m.group(1), m.group(1)), {})[m.group(2)] = float(m.group(3))
+    return vals
+
+
+def derive(vals):
+    traffic, busy = {}, {}
+    for k, v in vals.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v and v["FETCH_SIZE"] > 1000:
+            traffic[k] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+        if "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE", 0) > 0:
+            busy[k] = round(v["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v["GRBM_GUI_ACTIVE"] / 8), 3)
+    return traffic, busy
+
+
+def main():
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    tj = json.load(open(path))
+    mix_t, mix_b = derive(read(sys.argv[1]))
+    tj["mix"] = {k: mix_t[k] for k in mix_t if k.startswith(("k_front_stream", "k_vit"))}
+    tj["mix_valu_busy"] = {k: mix_b[k] for k in mix_b if k.startswith(("k_front_stream", "k_vit"))}
+    tj["_mix_provenance"] = ("round 2: rocprofv3 --pmc passes (tools/prof_run.sh %s mix) on `python bench.py --steps 12 --warmup 6 "
+                             "--sync-threads 2 --no-cpu-baseline --no-secondary`; summary in profiles/r02_mix_rocprofv3.md"
+                             % os.path.basename(sys.argv[1]).replace("prof_", ""))
+    if len(sys.argv) > 2:
+        c2_t, c2_b = derive(read(sys.argv[2]))
+        for k in ("k_front", "k_vit<216>", "k_vit<432>"):
+            if k in c2_t:
+                tj[k] = c2_t[k]
+            if k in c2_b:
+                tj.setdefault("valu_busy", {})[k] = c2_b[k]
+        tj["_provenance"] = ("round 2: the same recipe on `python bench.py --workload config2 --steps 12 --warmup 6 --no-cpu-baseline` "
+                             "(profiles/r02_config2_rocprofv3.md); bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+    json.dump(tj, open(path, "w"), indent=1)
+    print(json.dumps({k: tj[k] for k in ("mix", "mix_valu_busy")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
