@@ -843,12 +843,19 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		if (prm.nchan) {
 			const uint32_t s0 = 4u * g;
 			if (s0 < cg0 || s0 >= cg1) {
+				/* (readfirstlane: the values are wave-uniform and must live in scalar registers, so that the wait
+				 * for these loads stays inside this rarely taken branch and does not drain the prefetch) */
 				const uint32_t c = chan_of_slot(prm.chan, prm.nchan, s0, lane);
-				cg0 = prm.chan[c].gbase;
-				cg1 = c + 1 < prm.nchan ? prm.chan[c + 1].gbase : prm.nslots;
-				cncls = prm.chan[c].ncls;
-				cfirst = prm.chan[c].d_off + prm.chan[c].anchor;
-				cspan = prm.chan[c].len - prm.chan[c].anchor;
+				const tg_chan_ent e = prm.chan[c];
+				const uint32_t nxt = c + 1 < prm.nchan ? prm.chan[c + 1].gbase : prm.nslots;
+				cg0 = __builtin_amdgcn_readfirstlane(e.gbase);
+				cg1 = __builtin_amdgcn_readfirstlane(nxt);
+				cncls = __builtin_amdgcn_readfirstlane(e.ncls);
+				const uint64_t f = e.d_off + e.anchor, sp = e.len - e.anchor;
+				cfirst = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)f) |
+					 ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(f >> 32)) << 32);
+				cspan = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)sp) |
+					((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32)) << 32);
 			}
 			const uint32_t i0 = s0 - cg0;
 			first = cfirst;
