@@ -42,6 +42,7 @@ int tgpi_engine_bind(const struct tgpu_engine *eng)
 }
 #define BIND(eng) do { int b_ = tgpi_engine_bind(eng); if (b_) return b_; } while (0)
 
+#define TGPU_BURST_MAX_DEFAULT 2048u	/* batches up to this many slots go through k_burst (measured crossover) */
 #define TGPU_SMALL_PLAN 256u	/* plans up to this many slots keep their descriptors in mapped host memory */
 #define TGPU_NKINDS 4	/* trellis kinds TG_KIND_SB1 / _216 / _432 / _168; index 4 = BBK in block-mode lists */
 
@@ -498,6 +499,12 @@ const char *tgpu_stage_name(int stage)
 	return (stage >= 0 && stage < TGPU_NSTAGES) ? names[stage] : "?";
 }
 
+static uint32_t tgpi_burst_max(void)
+{
+	const char *e = getenv("TGPU_BURST_MAX");	/* read every time: tests switch it */
+	return e ? (uint32_t)atoi(e) : TGPU_BURST_MAX_DEFAULT;
+}
+
 static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream, hipEvent_t *ev, int soft)
 {
 	int rc;
@@ -507,6 +514,16 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	BIND(p->eng);
 	if (!p->loaded || (soft && p->packed_ready) || p->block_mode)
 		return TGPU_ESTATE;
+	/* small batches: one workgroup per burst, trellis states across lanes, two launches (k_burst).
+	 * TGPU_BURST_MAX = largest batch that takes this path (0 = never) */
+	if (!soft && !ev && !p->packed_ready && !p->rm_decode && !p->d_wire && !p->fastpath && p->nslots &&
+	    p->nslots <= tgpi_burst_max()) {
+		if ((rc = tgk_burst(d_stream, p->d_slot_off, p->d_slot_chan, p->d_chan_code, p->nslots, p->nsb != 0, p->d_sb_ok,
+				    p->d_sb_code, d_rec, p->d_maskidx, p->d_masks, stream)))
+			return rc;
+		p->static_pending = 0;
+		return TGPU_OK;
+	}
 	if (p->static_pending && p->nslots) {
 		HCHK(hipMemcpyAsync(p->d_maskidx, p->d_idx_stage, (size_t)p->nslots * 4,
 				    hipMemcpyDefault, (hipStream_t)stream));

@@ -37,6 +37,11 @@ int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *
 int tgk_clean(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,
 	      const uint32_t *d_maskidx, uint8_t *d_rec, uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire,
 	      uint32_t *d_dirty_items, uint32_t *d_dirty_count, int flags, void *stream);
+/* small batches: one workgroup per burst, the trellis states across lanes; two launches per batch (SB1 pass first
+ * when the batch holds a SYNC slot).  d_sb_ok / d_sb_code are indexed by SLOT here. */
+int tgk_burst(const uint8_t *d_stream, const uint64_t *d_slot_desc, const uint32_t *d_slot_chan,
+	      const uint32_t *d_chan_code, uint32_t nslots, int have_sync, uint32_t *d_sb_ok, uint32_t *d_sb_code,
+	      uint8_t *d_rec, uint32_t *d_maskidx, uint32_t *d_masks, void *stream);
 /* block mode: descriptor = byte offset | table index (TG_KIND_* or 4 = BBK) << 56 | tp_sap type << 48 */
 int tgk_front_blocks(const uint8_t *d_bits, const uint64_t *d_desc, uint32_t nblocks, uint32_t *d_packed, void *stream);
 int tgk_bbk_blocks(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,

@@ -1701,6 +1701,282 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 }
 
 /* ------------------------------------------------------------------------- */
+/* k_burst: one workgroup per burst, the 16 states of a trellis across 16 lanes (small batches) */
+/* ------------------------------------------------------------------------- */
+/*
+ * The kernel shape BASELINE.json's north star names: one workgroup per burst, its type-5 bits staged in LDS, the
+ * 16-state add-compare-select as a butterfly ACROSS LANES.  It exists for small batches (the drop-in channel API
+ * with a handful of bursts per flush), where the lane-per-trellis kernels leave 63 of 64 lanes idle and a flush is a
+ * chain of eight launches: here a flush is two (k_burst<true> for the SB1 blocks of the SYNC slots, then k_burst<false>
+ * for everything), and a 432-bit block takes 296 x ~100 cycles instead of 296 x 28 dependent instructions.
+ *
+ *   - the slot's 510 bytes -> LDS; every thread de-interleaves, de-punctures (2/3: the order of the bits is the
+ *     type-3 order) and descrambles its share of a block: r[i] = byte[(a (i + 1)) mod K] != 0, XOR bit (same position)
+ *     of the scrambling sequence in its linear form (parity(code & lfsr_lin[pos]), lower_mac/tetra_scramb.c:34-50);
+ *   - the scrambling code of the slot = the SYNC PDU of the latest SYNC slot at or before it (same channel) whose SB1
+ *     passed its CRC, else the channel's carry-in (lower_mac/tetra_lower_mac.c:179-186, 291-300): pass 1 leaves
+ *     (crc_ok, code) per SYNC slot, pass 2's workgroups look backwards through them -- no forward-fill launches;
+ *   - trellis: lane s of a 16-lane row holds state s as metric << 8 | survivor byte (the lane-per-trellis word, one
+ *     state per lane).  Per step: the words of the two predecessors s >> 1 and (s >> 1) + 8 come over the LDS
+ *     crossbar (ds_bpermute_b32), the one from the predecessor whose oldest bit is 1 gets the step's tie / decision
+ *     bit added, v_min_u32 selects: same tie rule and register-exchange history as vit_core.h, so the 8-step
+ *     blocks, the 16 history bytes per block (here: one ds_write_b8 per lane) and the block-wise traceback are the
+ *     same too.  Row 0 of wave 0 decodes the slot's first block, row 1 the second, side by side;
+ *   - CRC-16 (table form), type-1 bits at one byte per bit, BBK, header: the record of the lane-per-trellis path,
+ *     byte for byte (tests/test_gpu_parity.py::test_burst_kernel_equals_batch_kernels).
+ */
+/* block parameters per kind on the device (tg_layout.h's host inlines: lower_mac/tetra_lower_mac.c:55-102) */
+__device__ __forceinline__ uint32_t tgb_K(int kind)    { return kind == TG_KIND_SB1 ? 120u : kind == TG_KIND_216 ? 216u : 432u; }
+__device__ __forceinline__ uint32_t tgb_a(int kind)    { return kind == TG_KIND_SB1 ? 11u : kind == TG_KIND_216 ? 101u : 103u; }
+__device__ __forceinline__ uint32_t tgb_nblk(int kind) { return kind == TG_KIND_SB1 ? 10u : kind == TG_KIND_216 ? 18u : 36u; }
+__device__ __forceinline__ uint32_t tgb_t1(int kind)   { return kind == TG_KIND_SB1 ? 60u : kind == TG_KIND_216 ? 124u : 268u; }
+
+__device__ __forceinline__ uint32_t tgb_out_g12(uint32_t p, uint32_t u)
+{
+	/* (g1, g2) of the transition from state p with input u: out(j, 0) = {0,11,6,13,5,14,3,8} (lower_mac/viterbi_cch.c:35-40),
+	 * g1 = bit 3, g2 = bit 2; complemented for u = 1 and for p >= 8 (every generator holds 1 and D^4) */
+	const uint32_t tab = 0x83e5d6b0u;			/* nibble j = out(j, 0) */
+	uint32_t o = (tab >> (4 * (p & 7))) & 15u;
+	if (u)
+		o ^= 15u;
+	if (p & 8)
+		o ^= 15u;
+	return o >> 2;						/* bit 1 = g1, bit 0 = g2 */
+}
+
+template <bool SB1_PASS>
+__global__ __launch_bounds__(256)
+void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_desc, const uint32_t *__restrict__ slot_chan,
+	     const uint32_t *__restrict__ chan_code, uint32_t nslots, uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code,
+	     uint8_t *__restrict__ rec, uint32_t *__restrict__ maskidx, uint32_t *__restrict__ masks)
+{
+	__shared__ uint32_t s_slot32[128];
+	__shared__ uint8_t s_r[2][432 + 16];		/* received type-3 bits per block, descrambled */
+	__shared__ uint8_t s_hist[2][36][16];
+	__shared__ uint8_t s_od[2][40];			/* decoded bytes (8 bits per trellis block) */
+	__shared__ uint32_t s_code, s_nonbin;
+	uint8_t *s_slot = (uint8_t *)s_slot32;
+	const uint32_t i = blockIdx.x, tid = threadIdx.x;
+	const uint64_t d = slot_desc[i];
+	const uint32_t type = TG_DESC_TYPE(d);
+	const uint8_t *base = stream + TG_DESC_OFF(d);
+	uint8_t *r = rec + (size_t)i * TG_REC_BYTES;
+	if (SB1_PASS && type != TG_BURST_SYNC)
+		return;
+	if (type != TG_BURST_SYNC && type != TG_BURST_NORM_1 && type != TG_BURST_NORM_2) {
+		if (tid == 0)
+			r[TG_REC_TYPE] = TG_BURST_NONE;
+		return;
+	}
+	if (tid == 0)
+		s_nonbin = 0;
+	__syncthreads();
+	{	/* the slot -> LDS (byte loads: any alignment), non-binary test */
+		const uint32_t b0 = base[2 * tid < 510 ? 2 * tid : 509], b1 = base[2 * tid + 1 < 510 ? 2 * tid + 1 : 509];
+		if (2 * tid < 510)
+			s_slot[2 * tid] = (uint8_t)b0;
+		if (2 * tid + 1 < 510)
+			s_slot[2 * tid + 1] = (uint8_t)b1;
+		if ((b0 | b1) > 1)
+			s_nonbin = 1;
+	}
+	/* the code in force for this slot: look backwards through the SYNC slots of the batch (pass 1 left their results) */
+	if (tid == 0) {
+		const uint32_t ch = slot_chan[i];
+		uint32_t code = chan_code[ch];
+		if (!SB1_PASS)
+			for (int j = (int)i; j >= 0 && slot_chan[j] == ch; j--)
+				if (TG_DESC_TYPE(slot_desc[j]) == TG_BURST_SYNC && sb_ok[j]) {
+					code = sb_code[j];
+					break;
+				}
+		s_code = code;
+	}
+	__syncthreads();
+	const uint32_t code = s_code;
+
+	/* blocks of this burst: kind and where its type-4 bits sit in the slot (phy/tetra_burst.c:31-47) */
+	int kind[2] = { -1, -1 };
+	uint32_t o1[2] = { 0, 0 }, o2[2] = { 0, 0 }, bcode[2] = { code, code };
+	if (type == TG_BURST_SYNC) {
+		kind[0] = TG_KIND_SB1; o1[0] = TG_SB_BLK1_OFF; bcode[0] = 3;		/* lower_mac/tetra_scramb.h:14 */
+		if (!SB1_PASS) { kind[1] = TG_KIND_216; o1[1] = TG_SB_BLK2_OFF; }
+	} else if (type == TG_BURST_NORM_2) {
+		kind[0] = TG_KIND_216; o1[0] = TG_NDB_BLK1_OFF;
+		kind[1] = TG_KIND_216; o1[1] = TG_NDB_BLK2_OFF;
+	} else {
+		kind[0] = TG_KIND_432; o1[0] = TG_NDB_BLK1_OFF; o2[0] = TG_NDB_BLK2_OFF;
+	}
+#pragma unroll
+	for (int b = 0; b < 2; b++) {
+		if (kind[b] < 0)
+			continue;
+		const uint32_t K = tgb_K(kind[b]), a = tgb_a(kind[b]);
+		for (uint32_t t3 = tid; t3 < K; t3 += 256) {
+			const uint32_t j = (a * (t3 + 1)) % K;		/* type3[i] = type4[(a (i + 1)) mod K] */
+			const uint32_t byte = s_slot[j < 216 ? o1[b] + j : o2[b] + j - 216];
+			s_r[b][t3] = (uint8_t)((byte != 0) ^ (__popc(bcode[b] & c_tab.lfsr_lin[j]) & 1));
+		}
+	}
+	__syncthreads();
+
+	const uint32_t lane = tid & 63;
+	if (tid < 64) {		/* wave 0: row 0 = first block, row 1 = second */
+		const uint32_t row = lane >> 4, st = lane & 15;
+		const int mykind = row < 2 ? kind[row] : -1;
+		const uint32_t nblk = mykind >= 0 ? tgb_nblk(mykind) : 0;
+		const uint32_t nblk_max = max(kind[0] >= 0 ? tgb_nblk(kind[0]) : 0u, kind[1] >= 0 ? tgb_nblk(kind[1]) : 0u);
+		const uint8_t *rr = s_r[row & 1];
+		const uint32_t p0 = st >> 1, u = st & 1;
+		const int ia = (int)(4 * ((lane & 48) + p0)), ib = (int)(4 * ((lane & 48) + p0 + 8));
+		const uint32_t e0 = tgb_out_g12(p0, u);		/* expected (g1, g2) coming from predecessor p0; from p0 + 8: the complement */
+		uint32_t W = (st == 0) ? 0u : (1000u << 8);
+		auto step2 = [&](uint32_t r1, uint32_t r2, uint32_t tie) {	/* two received bits (g1, g2) */
+			const uint32_t x0 = ((r1 << 1) | r2) ^ e0;
+			const uint32_t d0 = (x0 & 1) + (x0 >> 1), d1 = 2 - d0;
+			const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute(ia, (int)W), wb = (uint32_t)__builtin_amdgcn_ds_bpermute(ib, (int)W);
+			const uint32_t x = wa + (d0 << 8), y = wb + (d1 << 8) + tie;
+			W = x < y ? x : y;
+		};
+		auto step1 = [&](uint32_t r1, uint32_t tie) {			/* one received bit (g1) */
+			const uint32_t d0 = r1 ^ (e0 >> 1), d1 = 1 - d0;
+			const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute(ia, (int)W), wb = (uint32_t)__builtin_amdgcn_ds_bpermute(ib, (int)W);
+			const uint32_t x = wa + (d0 << 8), y = wb + (d1 << 8) + tie;
+			W = x < y ? x : y;
+		};
+		auto step0 = [&](uint32_t tie) {					/* flush step: nothing received */
+			const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute(ia, (int)W), wb = (uint32_t)__builtin_amdgcn_ds_bpermute(ib, (int)W);
+			const uint32_t y = wb + tie;
+			W = wa < y ? wa : y;
+		};
+		/* four lead-in steps (type-3 bits 0..5), then blocks of eight steps on twelve bits (vit_core.h) */
+		step2(rr[0], rr[1], 1);
+		step1(rr[2], 2);
+		step2(rr[3], rr[4], 4);
+		step1(rr[5], 8);
+		W &= ~0xffu;
+		for (uint32_t b = 0; b < nblk_max; b++) {
+			const uint8_t *q = rr + 6 + 12 * (b < nblk ? b : 0);
+			const bool last = (b + 1 == nblk);
+			step2(q[0], q[1], 1);
+			step1(q[2], 2);
+			step2(q[3], q[4], 4);
+			step1(q[5], 8);
+			if (last) {
+				step0(16); step0(32); step0(64); step0(128);
+			} else {
+				step2(q[6], q[7], 16);
+				step1(q[8], 32);
+				step2(q[9], q[10], 64);
+				step1(q[11], 128);
+			}
+			if (b < nblk)
+				s_hist[row & 1][b][st] = (uint8_t)W;
+			W &= ~0xffu;
+		}
+		/* block-wise traceback from state 0 (row leaders) */
+		if (st == 0 && mykind >= 0) {
+			uint32_t sidx = 0;
+			for (int b = (int)nblk - 1; b >= 0; b--) {
+				const uint32_t byte = s_hist[row][b][sidx];
+				s_od[row][b] = (uint8_t)byte;
+				sidx = tg_brev4(byte);
+			}
+		}
+	}
+	__syncthreads();
+
+	/* CRC-16 per block (thread 0 / 1), then the record */
+	__shared__ uint32_t s_crcv[2], s_okv[2];
+	if (tid < 2 && kind[tid] >= 0) {
+		const uint32_t nblk = tgb_nblk(kind[tid]);
+		uint32_t crc = 0xffff;
+		for (uint32_t k = 0; k + 1 < nblk; k++)
+			crc = ((crc << 8) & 0xffff) ^ c_tab.crc_msb[crc >> 8] ^ c_tab.crc_lsb[s_od[tid][k]];
+		const uint32_t nib = s_od[tid][nblk - 1] & 15;
+		for (int k = 0; k < 4; k++) {
+			crc ^= ((nib >> k) & 1) << 15;
+			crc = (crc & 0x8000) ? (((crc << 1) ^ 0x1021) & 0xffff) : ((crc << 1) & 0xffff);
+		}
+		s_crcv[tid] = crc;
+		s_okv[tid] = (crc == 0x1d0f);
+	}
+	__syncthreads();
+	if (SB1_PASS) {
+		if (tid == 0) {
+			const uint8_t *od = s_od[0];
+			uint32_t w0 = od[0] | (od[1] << 8) | (od[2] << 16) | ((uint32_t)od[3] << 24);
+			uint32_t w1 = od[4] | (od[5] << 8) | (od[6] << 16) | ((uint32_t)od[7] << 24);
+			const uint32_t ow[3] = { w0, w1, 0 };
+			const uint32_t cc = FIELD_MSB(ow, 4, 6), mcc = FIELD_MSB(ow, 31, 10), mnc = FIELD_MSB(ow, 41, 14);
+			sb_ok[i] = s_okv[0];
+			sb_code[i] = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3u;
+		}
+		return;
+	}
+	/* type-1 bits at one byte per bit: block 0 at @48, block 1 at @176 */
+#pragma unroll
+	for (int b = 0; b < 2; b++) {
+		if (kind[b] < 0)
+			continue;
+		const uint32_t n1 = tgb_t1(kind[b]);
+		const uint32_t span = (n1 + 15) & ~15u;			/* the batch kernels store whole 16-byte groups, zero padded */
+		uint8_t *dst = r + (b ? TG_REC_BITS2 : TG_REC_BITS1);
+		for (uint32_t k = tid; k < span; k += 256)
+			dst[k] = k < n1 ? (uint8_t)((s_od[b][k >> 3] >> (k & 7)) & 1) : 0;
+	}
+	if (tid < 32) {		/* BBK: 30 bits in stream order, descrambled, the first 14 kept (tetra_lower_mac.c:268-274) */
+		uint8_t bit = 0;
+		if (tid < 14) {
+			const uint32_t pos = (type == TG_BURST_SYNC) ? TG_SB_BBK_OFF + tid : TG_NDB_BBK1_OFF + tid;
+			bit = (uint8_t)((s_slot[pos] != 0) ^ (__popc(code & c_tab.lfsr_lin[tid]) & 1));
+		}
+		if (tid < 16)
+			r[TG_REC_BBK + tid] = bit;
+	}
+	if (tid == 0) {
+		r[TG_REC_TYPE] = (uint8_t)type;
+		r[TG_REC_FLAGS] = s_nonbin ? TG_FLAG_NONBINARY : 0;
+		r[TG_REC_CRC_OK] = (uint8_t)s_okv[0];
+		r[TG_REC_CRC_OK + 1] = kind[1] >= 0 ? (uint8_t)s_okv[1] : 0;
+		*(uint16_t *)(r + TG_REC_CRC) = (uint16_t)s_crcv[0];
+		*(uint16_t *)(r + TG_REC_CRC + 2) = kind[1] >= 0 ? (uint16_t)s_crcv[1] : 0;
+		*(uint32_t *)(r + TG_REC_CODE) = code;
+		*(uint32_t *)(r + TG_REC_SLOT) = i;
+		r[TG_REC_BBK_NERR] = 0;
+		maskidx[i] = i;		/* what tgpu_plan_final_codes() reads: the code in force at this slot */
+		masks[(size_t)i * TG_MASK_WORDS + TG_MW_CODE] = code;
+		if (type == TG_BURST_SYNC) {
+			const uint8_t *od = s_od[0];
+			uint32_t w0 = od[0] | (od[1] << 8) | (od[2] << 16) | ((uint32_t)od[3] << 24);
+			uint32_t w1 = od[4] | (od[5] << 8) | (od[6] << 16) | ((uint32_t)od[7] << 24);
+			const uint32_t ow[3] = { w0, w1, 0 };
+			const uint32_t cc = FIELD_MSB(ow, 4, 6), tn = FIELD_MSB(ow, 10, 2) + 1;
+			const uint32_t fn = FIELD_MSB(ow, 12, 5), mn = FIELD_MSB(ow, 17, 6);
+			const uint32_t mcc = FIELD_MSB(ow, 31, 10), mnc = FIELD_MSB(ow, 41, 14);
+			*(uint32_t *)(r + TG_REC_SBF0) = cc | (tn << 8) | (fn << 16) | (mn << 24);
+			*(uint32_t *)(r + TG_REC_SBF1) = mcc | (mnc << 16);
+			*(uint32_t *)(r + TG_REC_SBCODE) = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3u;
+		}
+	}
+}
+
+extern "C" int tgk_burst(const uint8_t *d_stream, const uint64_t *d_slot_desc, const uint32_t *d_slot_chan,
+			 const uint32_t *d_chan_code, uint32_t nslots, int have_sync, uint32_t *d_sb_ok, uint32_t *d_sb_code,
+			 uint8_t *d_rec, uint32_t *d_maskidx, uint32_t *d_masks, void *stream)
+{
+	if (!nslots)
+		return 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (have_sync)
+		hipLaunchKernelGGL((k_burst<true>), dim3(nslots), dim3(256), 0, s, d_stream, d_slot_desc, d_slot_chan, d_chan_code, nslots,
+				   d_sb_ok, d_sb_code, d_rec, d_maskidx, d_masks);
+	hipLaunchKernelGGL((k_burst<false>), dim3(nslots), dim3(256), 0, s, d_stream, d_slot_desc, d_slot_chan, d_chan_code, nslots,
+			   d_sb_ok, d_sb_code, d_rec, d_maskidx, d_masks);
+	return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
 /* generic trellis: any RCPC puncturer on either mother code  */
 /* ------------------------------------------------------------------------- */
 /*

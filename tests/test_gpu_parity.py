@@ -406,9 +406,10 @@ def test_config2_full_size_roundtrip(T, eng):
     plan.close()
 
 
-def test_front_kernel_packing(T, eng):
+def test_front_kernel_packing(T, eng, monkeypatch):
     """k_front's packed code words == the layout function both sides are built from (tg_layout.h),
     for all burst types, odd offsets and the last slot of a buffer (no read past byte 509)"""
+    monkeypatch.setenv("TGPU_BURST_MAX", "0")        # (small batches would bypass k_front)
     import torch
     import emul
     rng = np.random.default_rng(12)
@@ -1129,9 +1130,11 @@ def test_clean_block_fastpath_is_invisible(T, eng):
 
 
 @pytest.mark.parametrize("fast", [False, True])
-def test_batch_size_sweep(T, eng, fast):
+def test_batch_size_sweep(T, eng, fast, monkeypatch):
     """ragged batch sizes around the kernels' tiling (wave = 64 items, workgroups of 256 / 1024, grid-stride loops,
-    pipelined front end with its tail): every size decodes like the oracle"""
+    pipelined front end with its tail): every size decodes like the oracle (the lane-per-trellis kernels at every
+    size: the workgroup-per-burst path of small batches is switched off here, it has its own test)"""
+    monkeypatch.setenv("TGPU_BURST_MAX", "0")
     rng = np.random.default_rng(5)
     nmax = 9000
     ty_all = rng.choice([O.TRAIN_NORM_1, O.TRAIN_NORM_2], nmax).astype(np.uint8)
@@ -1404,6 +1407,7 @@ def test_front_end_pipeline_tails(T, eng, monkeypatch):
     """k_front with very few waves (TGPU_FRONT_BLOCKS, a test knob of the launcher), so that every wave runs its
     prologue, the unconditional main loop and the checked tail over sequences of every length: groups of four
     slots, a short last group, fewer slots than waves -- every batch size from 1 to 150 and a few larger ones"""
+    monkeypatch.setenv("TGPU_BURST_MAX", "0")        # (small batches would bypass k_front)
     import torch
     import emul
     rng = np.random.default_rng(15)
@@ -1701,3 +1705,76 @@ def test_config4_channels_in_one_grid_batch(T, eng):
         p1.close()
     assert ndeliv > 3000
     plan.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 16, 33, 200, 1500])
+def test_burst_kernel_equals_batch_kernels(T, eng, n, monkeypatch):
+    """k_burst (one workgroup per burst, trellis states across lanes; the path of small batches) writes the very
+    records the lane-per-trellis batch kernels write -- every byte -- and both are the oracle's decode: mixed burst
+    types with SYNC slots that switch the code mid-batch (a valid cell, a failed SB1, a second cell), two channels
+    with carry-in codes, payload noise up to garbage, an ignored burst type, misaligned slot offsets"""
+    import torch
+    rng = np.random.default_rng(100 + n)
+    cells = [(262, 42, 1), (901, 77, 9)]
+    codes = [O.scramb_get_init(*c) for c in cells]
+    for trial in range(6 if n < 100 else 2):
+        ty = rng.choice([O.TRAIN_SYNC, O.TRAIN_NORM_1, O.TRAIN_NORM_2], n, p=[0.3, 0.35, 0.35]).astype(np.uint8)
+        cut = int(rng.integers(0, n + 1))                      # channel 0: slots < cut, channel 1: the rest
+        chan = (np.arange(n) >= cut).astype(np.uint32)
+        slots = np.zeros((n, 510), np.uint8)
+        cur = [codes[0], 0]                                    # carry-in codes: channel 0 knows its cell, channel 1 does not
+        carry = np.array(cur, np.uint32)
+        for i in range(n):
+            c = int(chan[i])
+            cell = cells[int(rng.integers(0, 2))]
+            ber = float(rng.choice([0.0, 0.02, 0.08, 0.5]))
+            if ty[i] == O.TRAIN_SYNC:
+                code_i = O.scramb_get_init(*cell)
+                sl = T.synth_slots(ty[i:i + 1], seed=int(rng.integers(1, 1 << 30)), scramb_init=code_i, mcc=cell[0], mnc=cell[1], cc=cell[2], ber=ber)
+            else:
+                sl = T.synth_slots(ty[i:i + 1], seed=int(rng.integers(1, 1 << 30)), scramb_init=int(cur[c]), ber=ber)
+            slots[i] = sl[0]
+            if ty[i] == O.TRAIN_SYNC and O.decode_block(O.T_SB1, sl[0][94:214], 3)[2]:
+                cur[c] = O.scramb_get_init(*cell)
+        if n >= 3 and trial == 0:
+            ty[n // 2] = 2                                      # TETRA_TRAIN_NORM_3: ignored
+        stride = 510 + int(rng.integers(0, 7))
+        off0 = int(rng.integers(0, 5))
+        buf = np.zeros(off0 + n * stride + 8, np.uint8)
+        offs = off0 + np.arange(n, dtype=np.uint64) * stride
+        for i in range(n):
+            buf[int(offs[i]):int(offs[i]) + 510] = slots[i]
+        if trial == 1:
+            buf[int(offs[0]) + 300] = 7                         # a non-binary byte: flag + "anything else is a 1"
+        d = torch.from_numpy(buf).cuda()
+        out = {}
+        for mode, mx in (("burst", "100000"), ("batch", "0")):
+            monkeypatch.setenv("TGPU_BURST_MAX", mx)
+            d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+            plan = T.Plan(eng, n, 2)
+            plan.load(offs, ty, chan, carry)
+            plan.execute(d.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            out[mode] = (d_rec.cpu().numpy().reshape(n, T.REC_BYTES), plan.final_codes().tolist())
+            plan.close()
+        a, b = out["burst"], out["batch"]
+        assert (a[0] == b[0]).all(), (n, trial, np.argwhere(a[0] != b[0])[:8].tolist())
+        assert a[1] == b[1]
+        # ... and the oracle's, slot by slot with the code the oracle has in force
+        keep = ty != 2
+        exp = np.zeros(n, np.uint32)
+        cur = [int(carry[0]), int(carry[1])]
+        sl_in = np.stack([buf[int(offs[i]):int(offs[i]) + 510] for i in range(n)])
+        for i in range(n):
+            c = int(chan[i])
+            if ty[i] == O.TRAIN_SYNC:
+                t1, _, ok, _ = O.decode_block(O.T_SB1, (sl_in[i][94:214] != 0).astype(np.uint8), 3)
+                if ok:
+                    f = lambda x, k: int("".join(str(int(v)) for v in t1[x:x + k]), 2)
+                    cur[c] = O.scramb_get_init(f(31, 10), f(41, 14), f(4, 6))
+            exp[i] = cur[c]
+        p = T.parse_records(a[0])
+        assert (p["code"][keep] == exp[keep]).all()
+        for cval in sorted(set(exp[keep].tolist())):
+            m = keep & (exp == cval)
+            check_against_oracle(T, a[0][m], ty[m], (sl_in[m] != 0).astype(np.uint8), int(cval))

@@ -48,8 +48,13 @@ int main(int argc, char **argv)
 		fprintf(stderr, "no GPU\n");
 		return 1;
 	}
-	const unsigned batches[] = { 1, 64, 1024, 16384 };
-	for (unsigned b = 0; b < sizeof(batches) / sizeof(batches[0]); b++) {
+	unsigned batches[32] = { 1, 64, 1024, 16384 }, nb = 4;
+	if (argc > 2) {		/* chan_bench N b1 b2 ...: the batch sizes to try */
+		nb = 0;
+		for (int a = 2; a < argc && nb < 32; a++)
+			batches[nb++] = (unsigned)atoi(argv[a]);
+	}
+	for (unsigned b = 0; b < nb; b++) {
 		struct tgpu_channel *ch;
 		struct tetra_rx_state trs;
 		memset(&trs, 0, sizeof(trs));
@@ -57,7 +62,7 @@ int main(int argc, char **argv)
 			return 1;
 		trs.burst_cb_priv = ch;
 		nblocks = ncrc = 0;
-		const size_t use = batches[b] == 1 ? len / 8 : len;	/* synchronous mode is slow: shorter sample */
+		const size_t use = batches[b] < 16 ? len / 8 : len;	/* near-synchronous modes are slow: shorter sample */
 		const double t0 = now();
 		for (size_t o = 0; o < use; o += 64)
 			tetra_burst_sync_in(&trs, stream + o, (unsigned)(use - o < 64 ? use - o : 64));
