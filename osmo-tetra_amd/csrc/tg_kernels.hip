@@ -1472,7 +1472,7 @@ void k_clean(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t
  *          packed bits, 32-bit correlation metrics (tg_svit_*), history in VGPRs as in mode 1.
  */
 template <int KIND, int HMODE>
-__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (HMODE == 2) ? (KIND == TG_KIND_432 ? 1 : 2) : (KIND == TG_KIND_432 ? 3 : 4))
+__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (HMODE == 2) ? (KIND == TG_KIND_432 ? 2 : 4) : (KIND == TG_KIND_432 ? 3 : 4))
 void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
@@ -1536,7 +1536,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	 * lines ~4x (FETCH_SIZE 183 MB for 42 MB of input on 500 k SCH/F blocks). */
 	__shared__ uint32_t s_cw[(HMODE != 2) ? NW * 64 : 1];
 	/* branch-metric table (vit_core.h, tg_bm_entry): six dwords per step pair and received triple */
-	__shared__ __attribute__((aligned(16))) uint32_t s_bm[(HMODE != 2) ? TG_BM_WORDS : 4];
+	__shared__ __attribute__((aligned(16))) uint32_t s_bm[(HMODE != 2) ? TG_BM_WORDS : TG_PSOFT_TAB];
 	auto bm = [&](int p, uint32_t e, uint32_t w[6]) {
 		const uint32_t *q = s_bm + (8 * p + e) * 8;
 		const uint4 a = *(const uint4 *)q;
@@ -1558,18 +1558,30 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	}
 
 	if (HMODE == 2) {
-		/* soft input: 6 dwords (2 blocks of 12 int8) per iteration from this block's soft area */
+		/* soft input: 6 dwords (2 x 12 int8 = 16 trellis steps) per iteration from this block's soft area; the packed
+		 * 16-bit soft trellis of vit_core.h (tg_pvit_*), branch metrics from the 512-entry table in LDS */
+		for (int i = lane; i < TG_PSOFT_TAB; i += 64)
+			s_bm[i] = tg_psoft_entry(i);
+		__syncthreads();
+		auto tab = [&](uint32_t idx) { return s_bm[idx]; };
 		const uint32_t *sw = softarea + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + (which ? TG_SOFT_AREA2 / 4 : 0);
-		tg_svit_state sv;
-		tg_svit_init(sv);
+		tg_pvit_state sv;
+		tg_pvit_init(sv);
 		{
 			const uint32_t lw[2] = { sw[0], sw[1] };
-			tg_svit_leadin(sv, lw, (mw[0] >> 24) & 0x3f);
+			tg_pvit_leadin(sv, lw, (mw[0] >> 24) & 0x3f, tab);
 		}
-		uint32_t cw[6];
+		/* software pipeline: the values (and mask word) of iteration g + 2 are loaded from global memory during
+		 * iteration g; the table entries of a block are fetched from LDS while the block before it runs (the
+		 * scheduling barriers keep the compiler from sinking the LDS reads to their first use) */
+		uint32_t cw[6], nx[6], m = mw[0], nm = mw[NW > 1 ? 1 : 0];
 #pragma unroll
-		for (int q = 0; q < 6; q++)
+		for (int q = 0; q < 6; q++) {
 			cw[q] = sw[2 + q];
+			nx[q] = sw[2 + (NW > 1 ? 6 : 0) + q];
+		}
+		uint32_t ta[12], tb[12];
+		tg_psoft_fetch<0, 12>(cw, m & 0xfff, tab, ta);
 		tg_v32 H[NCH];
 #pragma unroll
 		for (int c = 0; c < NCH; c++) {
@@ -1580,44 +1592,56 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 #pragma unroll 1
 			for (int it = 0; it < nloop; it++) {
 				const int g = 4 * c + it;
-				uint32_t nx[6];
+				const int g2 = (g + 2 < NW) ? g + 2 : NW - 1;
+				uint32_t nn[6];
 #pragma unroll
 				for (int q = 0; q < 6; q++)
-					nx[q] = sw[2 + 6 * (g + 1) + q];
-				const uint32_t m = mw[g];
+					nn[q] = sw[2 + 6 * g2 + q];
+				const uint32_t nnm = mw[g2];
+				tg_psoft_fetch<0, 12>(cw + 3, (m >> 12) & 0xfff, tab, tb);
+				__builtin_amdgcn_sched_barrier(0);
 				uint32_t h[4];
-				tg_svit_block<false>(sv, cw, m & 0xfff, h);
+				tg_pvit_block<false>(sv, ta, h);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * it + d] = h[d];
-				tg_svit_block<false>(sv, cw + 3, (m >> 12) & 0xfff, h);
+				__builtin_amdgcn_sched_barrier(0);
+				tg_psoft_fetch<0, 12>(nx, nm & 0xfff, tab, ta);
+				__builtin_amdgcn_sched_barrier(0);
+				tg_pvit_block<false>(sv, tb, h);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * it + 4 + d] = h[d];
+				tg_vit_normalize(sv);	/* once per 16 steps: twelve metric bits stay exact (vit_core.h) */
 #pragma unroll
-				for (int q = 0; q < 6; q++)
+				for (int q = 0; q < 6; q++) {
 					cw[q] = nx[q];
+					nx[q] = nn[q];
+				}
+				m = nm;
+				nm = nnm;
 			}
 			if (lastchunk) {
-				const uint32_t m = mw[NW - 1];
 				uint32_t h[4];
-				tg_svit_block<false>(sv, cw, m & 0xfff, h);
+				tg_psoft_fetch<0, 6>(cw + 3, (m >> 12) & 0xfff, tab, tb);
+				tg_pvit_block<false>(sv, ta, h);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * (nit - 1) + d] = h[d];
-				tg_svit_block<true>(sv, cw + 3, (m >> 12) & 0xfff, h);
+				tg_pvit_block<true>(sv, tb, h);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * (nit - 1) + 4 + d] = h[d];
 			}
 		}
-		uint32_t s = 0;
+		/* traceback from state 0, one nibble per four-step block */
+		uint32_t pos = 0;
 #pragma unroll
 		for (int b = NBLK - 1; b >= 0; b--) {
 			const int c = b >> 3, o = 4 * (b & 7);
-			const uint32_t byte = hist_byte(H[c][o], H[c][o + 1], H[c][o + 2], H[c][o + 3], s);
-			od[b >> 2] |= byte << ((b & 3) * 8);
-			s = tg_brev4(byte);
+			const uint32_t hi = tg_ptrace_hop(H[c][o + 2], H[c][o + 3], pos);
+			const uint32_t lo = tg_ptrace_hop(H[c][o], H[c][o + 1], pos);
+			od[b >> 2] |= (lo | (hi << 4)) << ((b & 3) * 8);
 		}
 	} else if (HMODE == 0) {
 #pragma unroll 1

@@ -111,8 +111,8 @@ TG_HD void tg_vit_init(tg_vit_state &v)
  *   SWMASK : bit j set -> butterfly j uses the swapped pair (w, m)
  *   QMASK  : bit j set -> butterfly j uses Q/Qt instead of P/Pt
  */
-template <unsigned SWMASK, unsigned QMASK>
-TG_HD void tg_acs(tg_vit_state &v, tg_us2 P, tg_us2 Pt, tg_us2 Q, tg_us2 Qt)
+template <unsigned SWMASK, unsigned QMASK, typename State>
+TG_HD void tg_acs(State &v, tg_us2 P, tg_us2 Pt, tg_us2 Q, tg_us2 Qt)
 {
 	tg_us2 N[8];
 #pragma unroll
@@ -301,7 +301,8 @@ TG_HD void tg_vit_block_bm(tg_vit_state &v, uint32_t tw, uint32_t h[4], Bm bm)
 }
 
 /* subtract the smallest path metric from all 16 (only between blocks: low bytes are clear) */
-TG_HD void tg_vit_normalize(tg_vit_state &v)
+template <typename State>
+TG_HD void tg_vit_normalize(State &v)
 {
 	tg_us2 m01 = tg_min(v.Z[0], v.Z[1]), m23 = tg_min(v.Z[2], v.Z[3]);
 	tg_us2 m45 = tg_min(v.Z[4], v.Z[5]), m67 = tg_min(v.Z[6], v.Z[7]);
@@ -540,6 +541,166 @@ TG_HD void tg_svit_block(tg_svit_state &v, const uint32_t w[3], uint32_t mask12,
 		h[d] = ~(((uint32_t)v.Z[4 * d] & 0xff) | (((uint32_t)v.Z[4 * d + 1] & 0xff) << 8) |
 			 (((uint32_t)v.Z[4 * d + 2] & 0xff) << 16) | (((uint32_t)v.Z[4 * d + 3] & 0xff) << 24));
 	tg_svit_clean(v);
+}
+
+/* =========================================================================================
+ * The same soft-input trellis in packed 16-bit arithmetic (round 2; what the kernels run -- tg_svit_* above stays
+ * as the 32-bit statement of the definition, and the host tests check one against the other and both against the
+ * oracle).
+ *
+ * Correlation maximised = mismatch cost minimised: a received value x costs |x| on a branch whose expected bit
+ * disagrees with its sign and 0 otherwise, i.e. cost = (sum |x| - correlation) / 2 with the same sum on every
+ * branch of a step, so every comparison -- ties included -- comes out as in tg_sacs.  Costs are non-negative, which
+ * gives the hard trellis' word again: per 16-bit half [15:4] path metric, [3:0] the last <= 4 decisions of the
+ * survivor; tg_acs unchanged (two v_pk_add_u16 + one v_pk_min_u16 per butterfly), tie bit i of the current
+ * FOUR-step block on the candidate from predecessor j + 8.
+ *
+ *  - branch metrics: T(x) = (cost against an expected 0, cost against an expected 1) << 4 in (low, high) half =
+ *    (max(-x, 0), max(x, 0)) << 4, from a 512-entry table indexed by flip << 8 | byte (flip = the scrambling
+ *    sequence's bit: the value changes sign; -(-128) = 128 is exact in the table).  Two-value step:
+ *    P = Ta + Tb (class (0,0)), Q = swap(Ta) + Tb (class (1,0)); one-value step: P = T.
+ *  - range: a state's metric exceeds the smallest one by at most the six values of the last four steps, 6 x 128 =
+ *    768; sixteen steps add at most 24 x 128 = 3072; 3840 < 4096, so subtracting the minimum once per sixteen steps
+ *    keeps twelve bits exact.  Unreachable start states: 1024 (> 768, the largest cost a real path has after the
+ *    lead-in).
+ *  - history: four decisions per state and four-step block = the block's start state bit-reversed (decision k is
+ *    input bit k - 4).  Sixteen nibbles = two dwords per block, state s at nibble rotr4(brev4(s)) of the 64 bits
+ *    (what one v_perm_b32 per register pair, one mask and one shift-or per dword produce); the traceback hops
+ *    nibble -> 64-bit shift -> nibble.
+ * ========================================================================================= */
+struct tg_pvit_state {
+	tg_us2 Z[8];
+};
+
+#define TG_PSOFT_TAB 512
+
+TG_HD uint32_t tg_psoft_entry(uint32_t idx)
+{
+	int32_t x = (int32_t)(int8_t)(idx & 0xff);
+	if (idx & 0x100)
+		x = -x;
+	const uint32_t c0 = x < 0 ? (uint32_t)-x : 0u, c1 = x > 0 ? (uint32_t)x : 0u;
+	return (c0 << 4) | (c1 << 20);
+}
+
+TG_HD void tg_pvit_init(tg_pvit_state &v)
+{
+	v.Z[0] = tg_as_us2(TG_VIT_INF << 16);	/* state 0: metric 0; the others: 1024 << 4 */
+#pragma unroll
+	for (int k = 1; k < 8; k++)
+		v.Z[k] = tg_as_us2(TG_VIT_INF | (TG_VIT_INF << 16));
+}
+
+TG_HD void tg_pstep_a(tg_pvit_state &v, uint32_t ta, uint32_t tb, uint32_t tie2)
+{
+	const tg_us2 Ta = tg_as_us2(ta), Tb = tg_as_us2(tb), tie = tg_as_us2(tie2);
+	const tg_us2 P = Ta + Tb, Q = Ta.yx + Tb;
+	tg_acs<TG_SW_A, TG_Q_A>(v, P, P + tie, Q, Q + tie);
+}
+
+TG_HD void tg_pstep_b(tg_pvit_state &v, uint32_t t, uint32_t tie2)
+{
+	const tg_us2 P = tg_as_us2(t), Pt = P + tg_as_us2(tie2);
+	tg_acs<TG_SW_B, TG_Q_B>(v, P, Pt, P, Pt);
+}
+
+/* table index of value k of a group of dwords */
+TG_HD uint32_t tg_psoft_idx(const uint32_t *w, int k, uint32_t maskbits)
+{
+	return ((w[k >> 2] >> ((k & 3) * 8)) & 0xff) | (((maskbits >> k) & 1) << 8);
+}
+
+/* the table entries of values K0 .. K0 + N - 1 of the group w[] (flips: bits K0.. of maskbits) */
+template <int K0, int N, typename Tab>
+TG_HD void tg_psoft_fetch(const uint32_t *w, uint32_t maskbits, Tab tab, uint32_t *t)
+{
+#pragma unroll
+	for (int i = 0; i < N; i++)
+		t[i] = tab(tg_psoft_idx(w, K0 + i, maskbits));
+}
+
+/* four steps on six fetched table entries */
+TG_HD void tg_pvit_quad(tg_pvit_state &v, const uint32_t t[6])
+{
+	tg_pstep_a(v, t[0], t[1], 0x00010001u);
+	tg_pstep_b(v, t[2], 0x00020002u);
+	tg_pstep_a(v, t[3], t[4], 0x00040004u);
+	tg_pstep_b(v, t[5], 0x00080008u);
+}
+
+/* the four flush steps as a min tree (tg_flush4 with the tie bits of a four-step block) */
+TG_HD void tg_pflush4(tg_pvit_state &v)
+{
+	const tg_us2 T0 = tg_as_us2(0x00010001u), T1 = tg_as_us2(0x00020002u);
+	const tg_us2 T2 = tg_as_us2(0x00040004u), T3 = tg_as_us2(0x00080008u);
+	tg_us2 M[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		M[k] = tg_min(v.Z[k], v.Z[k + 4] + T0);
+	const tg_us2 N0 = tg_min(M[0], M[2] + T1);
+	const tg_us2 N1 = tg_min(M[1], M[3] + T1);
+	const tg_us2 R = tg_min(N0, N1 + T2);
+	v.Z[0] = tg_min(R, (R + T3).yx);
+}
+
+TG_HD uint32_t tg_pack_bytes0022(uint32_t z0, uint32_t z1)
+{
+	/* (z0.b0, z1.b0, z0.b2, z1.b2) */
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_perm(z1, z0, 0x06020400u);
+#else
+	return (z0 & 0xff) | ((z1 & 0xff) << 8) | (z0 & 0xff0000) | ((z1 << 8) & 0xff000000u);
+#endif
+}
+
+/* history of a four-step block (two dwords) out, history bits cleared */
+TG_HD void tg_pvit_hist(tg_pvit_state &v, uint32_t h[2])
+{
+	uint32_t g[4];
+#pragma unroll
+	for (int d = 0; d < 4; d++)
+		g[d] = tg_pack_bytes0022(tg_as_u32(v.Z[2 * d]), tg_as_u32(v.Z[2 * d + 1])) & 0x0f0f0f0fu;
+	h[0] = g[0] | (g[1] << 4);
+	h[1] = g[2] | (g[3] << 4);
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		v.Z[k] = tg_as_us2(tg_as_u32(v.Z[k]) & 0xfff0fff0u);
+}
+
+/* one traceback hop: the nibble of the current state from a block's two history dwords; pos (bit offset of the
+ * current state's nibble; 0 = state 0) moves on to the block's start state.  Only bits 0..5 of pos count. */
+TG_HD uint32_t tg_ptrace_hop(uint32_t h0, uint32_t h1, uint32_t &pos)
+{
+	const uint64_t H = ((uint64_t)h1 << 32) | h0;
+	const uint32_t X = (uint32_t)(H >> (pos & 63));
+	pos = ((X << 4) | (X & 0xeu)) << 1;
+	return X & 15u;
+}
+
+/* lead-in: values 0..5 of the lead-in group, history dropped */
+template <typename Tab>
+TG_HD void tg_pvit_leadin(tg_pvit_state &v, const uint32_t w[2], uint32_t mask6, Tab tab)
+{
+	uint32_t t[6];
+	tg_psoft_fetch<0, 6>(w, mask6, tab, t);
+	tg_pvit_quad(v, t);
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		v.Z[k] = tg_as_us2(tg_as_u32(v.Z[k]) & 0xfff0fff0u);
+}
+
+/* eight steps = two four-step blocks on the 12 fetched table entries t[] (tg_psoft_fetch<0, 12> of the block's three
+ * dwords); h[0..1], h[2..3]: their histories.  LAST: the second one is the four flush steps (t[6..11] unused). */
+template <bool LAST>
+TG_HD void tg_pvit_block(tg_pvit_state &v, const uint32_t t[12], uint32_t h[4])
+{
+	tg_pvit_quad(v, t);
+	tg_pvit_hist(v, h);
+	if (LAST)
+		tg_pflush4(v);
+	else
+		tg_pvit_quad(v, t + 6);
+	tg_pvit_hist(v, h + 2);
 }
 
 /* byte offset, inside a block's soft area, of the 12 values of trellis block b (after the 8-byte lead-in

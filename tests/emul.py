@@ -44,8 +44,10 @@ def pack_slot(btype, slot):
     return w
 
 
-def decode_block_soft(kind, soft4, maskwords=None):
-    """kind 0/1/2; soft4 = int8 values in type-4 (stream) order.  returns (type2 bits, crc)"""
+def decode_block_soft(kind, soft4, maskwords=None, packed=False, want_max=False):
+    """kind 0/1/2; soft4 = int8 values in type-4 (stream) order.  returns (type2 bits, crc); packed: the 16-bit
+    trellis the kernels run (tg_pvit_*) instead of the 32-bit statement (tg_svit_*); want_max: also the largest
+    12-bit metric seen"""
     nblk = {0: 10, 1: 18, 2: 36}[kind]
     s4 = np.ascontiguousarray(soft4, np.int8)
     area = np.zeros(8 + 12 * nblk + 8, np.int8)
@@ -53,6 +55,13 @@ def decode_block_soft(kind, soft4, maskwords=None):
     i8p = C.POINTER(C.c_int8)
     lib().emul_soft_layout(kind, s4.ctypes.data_as(i8p), area.ctypes.data_as(i8p))
     mw = None if maskwords is None else np.ascontiguousarray(maskwords, np.uint32).ctypes.data_as(u32p)
+    if packed:
+        mx = C.c_uint(0)
+        lib().emul_decode_psoft.restype = C.c_uint
+        crc = lib().emul_decode_psoft(kind, area.ctypes.data_as(i8p), mw, out.ctypes.data_as(u8p), C.byref(mx))
+        if want_max:
+            return out, crc, mx.value
+        return out, crc
     crc = lib().emul_decode_soft(kind, area.ctypes.data_as(i8p), mw, out.ctypes.data_as(u8p))
     return out, crc
 

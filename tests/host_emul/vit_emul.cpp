@@ -160,6 +160,64 @@ extern "C" unsigned emul_decode_soft(int kind, const int8_t *area, const uint32_
 	return crc;
 }
 
+/* the packed 16-bit soft trellis (tg_pvit_*, what k_vit<., 2> runs): same area and mask words in, same outputs.
+ * *maxmetric (optional) receives the largest 12-bit metric seen before a normalisation (must stay < 4096). */
+extern "C" unsigned emul_decode_psoft(int kind, const int8_t *area, const uint32_t *maskwords, uint8_t *out_bits, unsigned *maxmetric)
+{
+	crc_init();
+	const int nblk = tg_kind_nblk(kind);
+	static uint32_t hist[36][4];
+	static uint32_t T[TG_PSOFT_TAB];
+	for (uint32_t i = 0; i < TG_PSOFT_TAB; i++)
+		T[i] = tg_psoft_entry(i);
+	auto tab = [&](uint32_t idx) { return T[idx]; };
+	const uint32_t *aw = (const uint32_t *)area;
+	unsigned mx = 0;
+	auto track = [&](const tg_pvit_state &v) {
+		for (int k = 0; k < 8; k++) {
+			if ((unsigned)(v.Z[k].x >> 4) > mx) mx = v.Z[k].x >> 4;
+			if ((unsigned)(v.Z[k].y >> 4) > mx) mx = v.Z[k].y >> 4;
+		}
+	};
+	tg_pvit_state v;
+	tg_pvit_init(v);
+	tg_pvit_leadin(v, aw, maskwords ? (maskwords[0] >> 24) & 0x3f : 0, tab);
+	track(v);
+	for (int b = 0; b < nblk; b++) {
+		const uint32_t m12 = maskwords ? (maskwords[b >> 1] >> (12 * (b & 1))) & 0xfff : 0;
+		uint32_t t[12];
+		tg_psoft_fetch<0, 12>(aw + 2 + 3 * b, m12, tab, t);
+		if (b == nblk - 1) {
+			tg_pvit_block<true>(v, t, hist[b]);
+		} else {
+			tg_pvit_block<false>(v, t, hist[b]);
+			track(v);
+		}
+		if ((b & 1) && b != nblk - 1)
+			tg_vit_normalize(v);	/* the kernel's schedule: after every second block */
+	}
+	if (maxmetric)
+		*maxmetric = mx;
+	uint8_t bytes[37] = { 0 };
+	uint32_t pos = 0;
+	for (int b = nblk - 1; b >= 0; b--) {
+		const uint32_t hi = tg_ptrace_hop(hist[b][2], hist[b][3], pos);
+		const uint32_t lo = tg_ptrace_hop(hist[b][0], hist[b][1], pos);
+		bytes[b] = (uint8_t)(lo | (hi << 4));
+	}
+	for (int i = 0; i < 8 * nblk; i++)
+		out_bits[i] = (bytes[i >> 3] >> (i & 7)) & 1;
+	uint32_t crc = 0xffff;
+	for (int i = 0; i < nblk - 1; i++)
+		crc = ((crc << 8) & 0xffff) ^ crc_msb[crc >> 8] ^ crc_lsb[bytes[i]];
+	uint32_t nib = bytes[nblk - 1] & 15;
+	for (int i = 0; i < 4; i++) {
+		crc ^= ((nib >> i) & 1) << 15;
+		crc = (crc & 0x8000) ? (((crc << 1) ^ 0x1021) & 0xffff) : ((crc << 1) & 0xffff);
+	}
+	return crc;
+}
+
 /* the generic trellis (k_conv) for one block: same step programs, step function, normalisation schedule and
  * block-wise traceback as the kernel.  returns 0, or -1 for a shape the product rejects */
 template <int CODE, bool G3>

@@ -147,6 +147,42 @@ def test_soft_kernel_core_on_host_bit_exact(sigma):
             got, crc = emul.decode_block_soft(kind, soft)
             w1, wcrc, ok, w2 = O.decode_block_soft(t, soft, 0)
             assert (got[:n2] == w2).all() and crc == wcrc
+            gotp, crcp = emul.decode_block_soft(kind, soft, packed=True)
+            assert (gotp[:n2] == w2).all() and crcp == wcrc
+
+
+def test_packed_soft_trellis_extremes_and_flips():
+    """the packed 16-bit soft trellis the kernels run (tg_pvit_*): equal to the 32-bit statement under random sign
+    flips (the scrambling mask words), exact on full-scale inputs (+-127, -128 everywhere, long constant runs, all
+    zero), and its 12-bit metric never reaches 4096 under the kernel's normalisation schedule"""
+    rng = np.random.default_rng(77)
+    worst = 0
+    for kind, t in ((0, O.T_SB1), (1, O.T_NDB), (2, O.T_SCH_F)):
+        K, n2, n1, a = O.BLK[t]
+        nw = {0: 5, 1: 9, 2: 18}[kind]
+        cases = [np.full(K, -128, np.int8), np.full(K, 127, np.int8), np.zeros(K, np.int8),
+                 np.where(rng.random(K) < 0.5, -128, 127).astype(np.int8),
+                 np.where(np.arange(K) % 3 == 0, -128, 0).astype(np.int8)]
+        for i in range(30):
+            v = rng.integers(-128, 128, K).astype(np.int8)
+            if i % 3 == 0:
+                v = np.where(rng.random(K) < 0.5, -128, v).astype(np.int8)
+            if i % 5 == 0:      # a valid code word at full scale with a few strong errors
+                t5 = O.encode_block(t, rng.integers(0, 2, n1).astype(np.uint8), 0)
+                v = np.where(t5[:K] == 1, -128, 127).astype(np.int8)
+                e = rng.random(K) < 0.08
+                v[e] = -v[e].clip(-127, 127)
+            cases.append(v)
+        for soft in cases:
+            w1, wcrc, ok, w2 = O.decode_block_soft(t, soft, 0)
+            gotp, crcp, mx = emul.decode_block_soft(kind, soft, packed=True, want_max=True)
+            assert (gotp[:n2] == w2).all() and crcp == wcrc
+            worst = max(worst, mx)
+            mw = rng.integers(0, 1 << 30, nw).astype(np.uint32)
+            a32 = emul.decode_block_soft(kind, soft, mw)
+            a16 = emul.decode_block_soft(kind, soft, mw, packed=True)
+            assert (a32[0] == a16[0]).all() and a32[1] == a16[1]
+    assert 700 < worst < 4096
 
 
 def test_soft_definition_consistent_with_hard_slicer():
