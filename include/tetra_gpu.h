@@ -169,6 +169,15 @@ int tgpu_plan_execute(struct tgpu_plan *plan, const uint8_t *d_stream, uint8_t *
 int tgpu_plan_execute_soft(struct tgpu_plan *plan, const int8_t *d_soft_stream, uint8_t *d_rec, void *hip_stream);
 
 /*
+ * The same decode straight from the float phase stream that float_to_bits.c (float_to_bits.c:33-72) would slice:
+ * d_phi = nfloats float32 phase values (units of pi/4) on the device, symbol k = stream positions 2 k and 2 k + 1 (the
+ * slot offsets of the loaded batch count those positions; every slot must lie inside 2 nfloats positions).  Equal, record
+ * for record, to tgpu_float_to_bits(d_phi, nfloats, bits, soft) followed by tgpu_plan_execute_soft(soft): the soft
+ * values are formed inside the gather kernel and neither the bit stream nor the soft stream is written to memory.
+ */
+int tgpu_plan_execute_float(struct tgpu_plan *plan, const float *d_phi, uint64_t nfloats, uint8_t *d_rec, void *hip_stream);
+
+/*
  * float_to_bits.c on the device: n float32 phase values (units of pi/4) -> 2 n bits, 1 per byte, with
  * the slicer of float_to_bits.c:33-72 (bit-exact, NaN included).  d_soft (optional, 2 n int8):
  * soft0 = sat127(rint(64 phi)), soft1 = sat127(rint(64 (2 - |phi|))).
@@ -220,6 +229,9 @@ int tgpu_prof_create(uint32_t max_steps, struct tgpu_prof **out);
 void tgpu_prof_destroy(struct tgpu_prof *prof);
 int tgpu_plan_execute_prof(struct tgpu_plan *plan, const uint8_t *d_stream, uint8_t *d_rec, void *hip_stream,
 			   struct tgpu_prof *prof, uint32_t step);
+/* the same for tgpu_plan_execute_float() (stage 0 = the fused slicer + soft gather kernel) */
+int tgpu_plan_execute_float_prof(struct tgpu_plan *plan, const float *d_phi, uint64_t nfloats, uint8_t *d_rec, void *hip_stream,
+				 struct tgpu_prof *prof, uint32_t step);
 int tgpu_prof_read(struct tgpu_prof *prof, uint32_t nsteps, float *ms);
 const char *tgpu_stage_name(int stage);
 

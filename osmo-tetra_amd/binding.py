@@ -132,6 +132,7 @@ def lib():
     L.tgpu_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_plan_final_codes.argtypes = [C.c_void_p, C.c_void_p, u32p]
     L.tgpu_plan_execute_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tgpu_plan_execute_float.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.tgpu_float_to_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_float_to_bits_afc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_float, C.c_float,
                                          C.POINTER(C.c_float), C.c_void_p]
@@ -141,6 +142,7 @@ def lib():
     L.tgpu_prof_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_prof_destroy.argtypes = [C.c_void_p]
     L.tgpu_plan_execute_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.tgpu_plan_execute_float_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.tgpu_prof_read.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.tgpu_stage_name.restype = C.c_char_p
     L.tgpu_stage_name.argtypes = [C.c_int]
@@ -279,6 +281,15 @@ class Plan:
     def execute_soft(self, d_soft_ptr, d_rec_ptr, hip_stream=0):
         _chk(lib().tgpu_plan_execute_soft(self._h, C.c_void_p(d_soft_ptr), C.c_void_p(d_rec_ptr),
                                           C.c_void_p(hip_stream)), "tgpu_plan_execute_soft")
+
+    def execute_float(self, d_phi_ptr, nfloats, d_rec_ptr, hip_stream=0):
+        """decode straight from the float phase stream (slicer + soft gather fused; see tetra_gpu.h)"""
+        _chk(lib().tgpu_plan_execute_float(self._h, C.c_void_p(d_phi_ptr), int(nfloats), C.c_void_p(d_rec_ptr),
+                                           C.c_void_p(hip_stream)), "tgpu_plan_execute_float")
+
+    def execute_float_prof(self, d_phi_ptr, nfloats, d_rec_ptr, hip_stream, prof, step):
+        _chk(lib().tgpu_plan_execute_float_prof(self._h, C.c_void_p(d_phi_ptr), int(nfloats), C.c_void_p(d_rec_ptr),
+                                                C.c_void_p(hip_stream), prof._h, step), "tgpu_plan_execute_float_prof")
 
     def execute_prof(self, d_stream_ptr, d_rec_ptr, hip_stream, prof, step):
         _chk(lib().tgpu_plan_execute_prof(self._h, C.c_void_p(d_stream_ptr), C.c_void_p(d_rec_ptr),

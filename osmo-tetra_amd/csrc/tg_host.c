@@ -505,7 +505,9 @@ static uint32_t tgpi_burst_max(void)
 	return e ? (uint32_t)atoi(e) : TGPU_BURST_MAX_DEFAULT;
 }
 
-static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream, hipEvent_t *ev, int soft)
+/* soft: 0 = bits (1 per byte), 1 = int8 soft values, 2 = float phases (nfloats of them) */
+static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream, hipEvent_t *ev, int soft,
+		    uint64_t nfloats)
 {
 	int rc;
 #define MARK(i) do { if (ev) { hipError_t e_ = hipEventRecord(ev[i], (hipStream_t)stream); if (e_ != hipSuccess) return (int)e_; } } while (0)
@@ -539,8 +541,13 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 				if (e_ != hipSuccess)
 					return (int)e_;
 			}
-			if ((rc = tgk_front_soft((const int8_t *)d_stream, p->d_slot_off, p->nslots, p->d_softarea, p->d_packed,
-						 d_rec, stream)))
+			if (soft == 2)
+				rc = tgk_front_soft_f32((const float *)d_stream, nfloats, p->d_slot_off, p->nslots, p->d_softarea,
+							p->d_packed, d_rec, stream);
+			else
+				rc = tgk_front_soft((const int8_t *)d_stream, p->d_slot_off, p->nslots, p->d_softarea, p->d_packed,
+						    d_rec, stream);
+			if (rc)
 				return rc;
 		} else if (!p->packed_ready &&	/* stream mode: k_front_stream has already packed every grid slot */
 			   (rc = tgk_front(d_stream, p->d_slot_off, p->nslots, p->d_packed, d_rec, stream)))
@@ -784,12 +791,19 @@ int tgpu_plan_execute(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_r
 {
 	if (p && p->loaded && p->block_mode)
 		return d_stream && d_rec ? plan_run_blocks(p, d_stream, d_rec, stream) : TGPU_EINVAL;
-	return plan_run(p, d_stream, d_rec, stream, NULL, 0);
+	return plan_run(p, d_stream, d_rec, stream, NULL, 0, 0);
 }
 
 int tgpu_plan_execute_soft(struct tgpu_plan *p, const int8_t *d_soft_stream, uint8_t *d_rec, void *stream)
 {
-	return plan_run(p, (const uint8_t *)d_soft_stream, d_rec, stream, NULL, 1);
+	return plan_run(p, (const uint8_t *)d_soft_stream, d_rec, stream, NULL, 1, 0);
+}
+
+int tgpu_plan_execute_float(struct tgpu_plan *p, const float *d_phi, uint64_t nfloats, uint8_t *d_rec, void *stream)
+{
+	if (!nfloats)
+		return TGPU_EINVAL;
+	return plan_run(p, (const uint8_t *)d_phi, d_rec, stream, NULL, 2, nfloats);
 }
 
 int tgpu_float_to_bits(struct tgpu_engine *eng, const float *d_in, uint64_t n, uint8_t *d_bits, int8_t *d_soft, void *stream)
@@ -824,7 +838,15 @@ int tgpu_plan_execute_prof(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t
 {
 	if (!prof || step >= prof->max_steps)
 		return TGPU_EINVAL;
-	return plan_run(p, d_stream, d_rec, stream, prof->ev + (size_t)step * (TGPU_NSTAGES + 1), 0);
+	return plan_run(p, d_stream, d_rec, stream, prof->ev + (size_t)step * (TGPU_NSTAGES + 1), 0, 0);
+}
+
+int tgpu_plan_execute_float_prof(struct tgpu_plan *p, const float *d_phi, uint64_t nfloats, uint8_t *d_rec, void *stream,
+				 struct tgpu_prof *prof, uint32_t step)
+{
+	if (!prof || step >= prof->max_steps || !nfloats)
+		return TGPU_EINVAL;
+	return plan_run(p, (const uint8_t *)d_phi, d_rec, stream, prof->ev + (size_t)step * (TGPU_NSTAGES + 1), 2, nfloats);
 }
 
 int tgpu_prof_read(struct tgpu_prof *prof, uint32_t nsteps, float *ms)

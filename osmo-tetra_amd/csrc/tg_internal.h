@@ -48,6 +48,8 @@ int tgk_bbk_blocks(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_p
 		   const uint32_t *d_maskidx, uint8_t *d_rec, int flags, void *stream);
 int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc, uint32_t nslots,
 		   uint32_t *d_area, uint32_t *d_packed, uint8_t *d_rec, void *stream);
+int tgk_front_soft_f32(const float *d_phi, unsigned long long nfloats, const uint64_t *d_slot_desc, uint32_t nslots,
+		       uint32_t *d_area, uint32_t *d_packed, uint8_t *d_rec, void *stream);
 int tgk_float_to_bits(const float *d_in, unsigned long long n, uint8_t *d_bits, int8_t *d_soft, void *stream);
 int tgk_float_to_bits_afc(const float *d_in, unsigned long long n, uint8_t *d_bits, float filter_val,
 			  float filter_goal, float *d_state, void *stream);

@@ -1110,30 +1110,39 @@ struct tg_soft_tables {
 };
 __device__ tg_soft_tables g_soft_tab;
 
+/* F32: the input is the float phase stream itself (one float = the two stream positions 2 k, 2 k + 1; a slot offset
+ * is a position in that 2-values-per-symbol stream, odd offsets included): the wave loads the slot's 256 symbols,
+ * applies soft_sym() and parks the 512 soft values where the int8 variant parks the bytes it fetched -- float_to_bits
+ * and the gather in one pass, neither the bit stream nor the soft stream goes through memory. */
+template <bool F32>
 __global__ __launch_bounds__(256)
-void k_front_soft(const int8_t *__restrict__ soft, const uint64_t *__restrict__ slot_desc, uint32_t nslots,
+void k_front_soft(const void *__restrict__ in, unsigned long long nin, const uint64_t *__restrict__ slot_desc, uint32_t nslots,
 		  uint32_t *__restrict__ area, uint32_t *__restrict__ packed, uint8_t *__restrict__ rec)
 {
-	__shared__ uint32_t s_slot[4][128];
+	constexpr uint32_t ROW = F32 ? 136 : 128;	/* dwords per wave; F32: bytes 512..543 stay zero ("no source") */
+	constexpr uint32_t NOSRC = F32 ? 520u : 510u;
+	__shared__ uint32_t s_slot[4][ROW];
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t wave = blockIdx.x * 4 + wib;
 	const uint32_t nwaves = gridDim.x * 4;
 	uint32_t *mine = s_slot[wib];
 	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];
+	if (F32 && lane < 8)
+		mine[128 + lane] = 0;
 
 	/* this lane assembles area bytes 4 lane .. 4 lane + 3 and 256 + 4 lane ..: their LDS source addresses per burst
-	 * type stay in registers (window byte 510 is zero: "no source") */
+	 * type stay in registers (int8 variant: window byte 510 is zero = "no source") */
 	uint32_t adr[3][8];
 #pragma unroll
 	for (int x = 0; x < 3; x++)
 #pragma unroll
 		for (int q = 0; q < 8; q++) {
 			const uint32_t o = g_soft_tab.src[x][256 * (q >> 2) + 4 * lane + (q & 3)];
-			adr[x][q] = wib * 512 + (o == 0xffff ? 510u : o);
+			adr[x][q] = wib * (4 * ROW) + (o == 0xffff ? NOSRC : o);
 		}
 
-	/* groups of four neighbouring slots per wave (as k_front), the next slot's two dwords requested before this
+	/* groups of four neighbouring slots per wave (as k_front), the next slot's data requested before this
 	 * one is gathered; past the end of the sequence the last slot is requested again, so that every step issues
 	 * the same memory operations and the waits stay exact */
 	const uint32_t ngroups = (nslots + 3) >> 2;
@@ -1144,48 +1153,82 @@ void k_front_soft(const int8_t *__restrict__ soft, const uint64_t *__restrict__ 
 	if (wave + (mygroups - 1) * nwaves == ngroups - 1)
 		T -= 4 * ngroups - nslots;
 #define SLOT_OF(t) (4u * (wave + ((t) >> 2) * nwaves) + ((t) & 3u))
-	uint64_t dcur = slot_desc[SLOT_OF(0u)];
-	uint32_t n0, n1;
-	front_fetch((const uint8_t *)soft + TG_DESC_OFF(dcur), lane, n0, n1);
-	uint64_t dnext = slot_desc[SLOT_OF(T > 1 ? 1u : 0u)];
-	for (uint32_t t = 0; t < T; t++) {
-		const uint32_t slot = SLOT_OF(t);
-		const uint32_t type = TG_DESC_TYPE(dcur);
-		mine[lane] = n0;
-		mine[64 + lane] = (lane == 63) ? (n1 >> 16) : n1;	/* lane 63 fetched bytes 506..509 */
-		dcur = dnext;
-		front_fetch((const uint8_t *)soft + TG_DESC_OFF(dcur), lane, n0, n1);
-		dnext = slot_desc[SLOT_OF(t + 2 < T ? t + 2 : T - 1)];
-		uint32_t w0 = 0, w1 = 0;
-		if (type == TG_BURST_NORM_1 || type == TG_BURST_NORM_2 || type == TG_BURST_SYNC) {
-			uint32_t by[8];
-			if (type == TG_BURST_NORM_1) {
+	/* two slots' data in flight per wave: the loop body is written out for the two register sets */
+	uint64_t d[2];
+	uint32_t n0[2] = { 0, 0 }, n1[2] = { 0, 0 };
+	float fv[2][4] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } };
+	auto fetch = [&](uint64_t dd, int h) {
+		if (F32) {
+			/* wave-uniform base + 32-bit lane offsets; symbol 255 of the window belongs to the next slot (it is
+			 * read for odd offsets only) and may lie past the end of the input: clamp, any value will do */
+			const unsigned long long f0 = TG_DESC_OFF(dd) >> 1;
+			const float *base = (const float *)in + f0;
+			const unsigned long long room = nin - 1 - f0;
+			const uint32_t lim = room < 255 ? (uint32_t)room : 255u;
 #pragma unroll
-				for (int q = 0; q < 8; q++)
-					by[q] = lds0[adr[0][q]];
-			} else if (type == TG_BURST_NORM_2) {
-#pragma unroll
-				for (int q = 0; q < 8; q++)
-					by[q] = lds0[adr[1][q]];
-			} else {
-#pragma unroll
-				for (int q = 0; q < 8; q++)
-					by[q] = lds0[adr[2][q]];
+			for (int j = 0; j < 4; j++) {
+				const uint32_t k = 64 * j + lane;
+				fv[h][j] = base[k < lim ? k : lim];
 			}
-			w0 = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);
-			w1 = by[4] | (by[5] << 8) | (by[6] << 16) | (by[7] << 24);
-		} else if (lane == 0) {
-			rec[(size_t)slot * TG_REC_BYTES + TG_REC_TYPE] = TG_BURST_NONE;
+		} else {
+			front_fetch((const uint8_t *)in + TG_DESC_OFF(dd), lane, n0[h], n1[h]);
 		}
-		/* no store sits under a branch (exact s_waitcnt, see k_front): an ignored burst type writes zeros to its
-		 * area, which nothing reads, and the meta word goes through a one-dword buffer range (lane 0 only) */
-		uint32_t *dst = area + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4);
-		dst[lane] = w0;
-		dst[64 + lane] = w1;
-		const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
-		const __amdgpu_buffer_rsrc_t mw = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)slot * TG_PACKED_WORDS + TG_PW_META,
-										      0, 4, 0x00027000);
-		__builtin_amdgcn_raw_buffer_store_b32(type | (toff << 16), mw, lane * 4, 0, 0);
+	};
+	d[0] = slot_desc[SLOT_OF(0u)];
+	d[1] = slot_desc[SLOT_OF(T > 1 ? 1u : 0u)];
+	fetch(d[0], 0);
+	fetch(d[1], 1);
+	uint64_t dn = slot_desc[SLOT_OF(T > 2 ? 2u : T - 1)];
+	for (uint32_t t0 = 0; t0 < T; t0 += 2) {
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const uint32_t t = t0 + h;
+			if (t >= T)
+				break;
+			const uint32_t slot = SLOT_OF(t);
+			const uint32_t type = TG_DESC_TYPE(d[h]);
+			uint32_t odd = 0;
+			if (F32) {
+				odd = (uint32_t)TG_DESC_OFF(d[h]) & 1u;
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					((tg_u16_alias *)mine)[64 * j + lane] = (uint16_t)soft_sym(fv[h][j]);
+			} else {
+				mine[lane] = n0[h];
+				mine[64 + lane] = (lane == 63) ? (n1[h] >> 16) : n1[h];	/* lane 63 fetched bytes 506..509 */
+			}
+			d[h] = dn;
+			fetch(d[h], h);
+			dn = slot_desc[SLOT_OF(t + 3 < T ? t + 3 : T - 1)];
+			uint32_t w0 = 0, w1 = 0;
+			if (type == TG_BURST_NORM_1 || type == TG_BURST_NORM_2 || type == TG_BURST_SYNC) {
+				uint32_t by[8];
+				const int x = (type == TG_BURST_NORM_1) ? 0 : (type == TG_BURST_NORM_2) ? 1 : 2;
+				/* (an odd offset is the LDS instruction's immediate, not an address add) */
+#define SOFT_GATHER(X, ODD)									\
+				_Pragma("unroll") for (int q = 0; q < 8; q++)			\
+					by[q] = lds0[adr[X][q] + ODD];
+				if (odd) {
+					if (x == 0) { SOFT_GATHER(0, 1) } else if (x == 1) { SOFT_GATHER(1, 1) } else { SOFT_GATHER(2, 1) }
+				} else {
+					if (x == 0) { SOFT_GATHER(0, 0) } else if (x == 1) { SOFT_GATHER(1, 0) } else { SOFT_GATHER(2, 0) }
+				}
+#undef SOFT_GATHER
+				w0 = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);
+				w1 = by[4] | (by[5] << 8) | (by[6] << 16) | (by[7] << 24);
+			} else if (lane == 0) {
+				rec[(size_t)slot * TG_REC_BYTES + TG_REC_TYPE] = TG_BURST_NONE;
+			}
+			/* no store sits under a branch (exact s_waitcnt, see k_front): an ignored burst type writes zeros to its
+			 * area, which nothing reads, and the meta word goes through a one-dword buffer range (lane 0 only) */
+			uint32_t *dst = area + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4);
+			dst[lane] = w0;
+			dst[64 + lane] = w1;
+			const uint32_t toff = (type == TG_BURST_SYNC) ? TG_SYNC_TRAIN_OFF : TG_NORM_TRAIN_OFF;
+			const __amdgpu_buffer_rsrc_t mw = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)slot * TG_PACKED_WORDS + TG_PW_META,
+											      0, 4, 0x00027000);
+			__builtin_amdgcn_raw_buffer_store_b32(type | (toff << 16), mw, lane * 4, 0, 0);
+		}
 	}
 #undef SLOT_OF
 }
@@ -2664,8 +2707,8 @@ extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64
 	return launch_stream_front(d_stream, prm, d_packed, d_cls, d_ysum, d_defer, s, ev_mid);
 }
 
-extern "C" int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc, uint32_t nslots,
-			      uint32_t *d_area, uint32_t *d_packed, uint8_t *d_rec, void *stream)
+static int launch_front_soft(bool f32, const void *d_in, unsigned long long nin, const uint64_t *d_slot_desc, uint32_t nslots,
+			     uint32_t *d_area, uint32_t *d_packed, uint8_t *d_rec, void *stream)
 {
 	if (!nslots)
 		return 0;
@@ -2675,9 +2718,26 @@ extern "C" int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc,
 		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
 	if (blocks > cap)
 		blocks = cap;
-	hipLaunchKernelGGL(k_front_soft, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_soft, d_slot_desc, nslots,
-			   d_area, d_packed, d_rec);
+	if (f32)
+		hipLaunchKernelGGL(k_front_soft<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_in, nin, d_slot_desc,
+				   nslots, d_area, d_packed, d_rec);
+	else
+		hipLaunchKernelGGL(k_front_soft<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_in, nin, d_slot_desc,
+				   nslots, d_area, d_packed, d_rec);
 	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_front_soft(const int8_t *d_soft, const uint64_t *d_slot_desc, uint32_t nslots,
+			      uint32_t *d_area, uint32_t *d_packed, uint8_t *d_rec, void *stream)
+{
+	return launch_front_soft(false, d_soft, 0, d_slot_desc, nslots, d_area, d_packed, d_rec, stream);
+}
+
+/* float phases in (nfloats symbols; slot offsets count stream positions, two per symbol) */
+extern "C" int tgk_front_soft_f32(const float *d_phi, unsigned long long nfloats, const uint64_t *d_slot_desc, uint32_t nslots,
+				  uint32_t *d_area, uint32_t *d_packed, uint8_t *d_rec, void *stream)
+{
+	return launch_front_soft(true, d_phi, nfloats, d_slot_desc, nslots, d_area, d_packed, d_rec, stream);
 }
 
 extern "C" int tgk_float_to_bits(const float *d_in, unsigned long long n, uint8_t *d_bits, int8_t *d_soft, void *stream)

@@ -1643,7 +1643,52 @@ def test_config5_full_size_soft_decode_against_the_oracle(T, eng):
     assert (p["crc"][:, 0] == wcrc[:, 0]).all() and (p["crc"][n2 | sb, 1] == wcrc[n2 | sb, 1]).all()
     nblk = int(2 * (n2 | sb).sum() + n1.sum())
     assert int(p["crc_ok"][:, 0].sum() + p["crc_ok"][n2 | sb, 1].sum()) == ok and 0.3 * nblk < ok < nblk
+    # the fused path (slicer inside the gather kernel, no bit / soft stream in memory): the same records
+    d_rec2 = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan.execute_float(d_phi.data_ptr(), len(phi), d_rec2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(d_rec, d_rec2)
     plan.close()
+
+
+def test_float_input_odd_offsets_and_stream_end(T, eng):
+    """tgpu_plan_execute_float: slots at odd stream positions (a burst that starts on the second value of a symbol),
+    ignored burst types in between, NaN / infinite / huge phases, and a last slot that ends exactly with the input
+    (the 256th symbol of its window does not exist) -- records == float_to_bits + execute_soft on the same stream"""
+    import torch
+    rng = np.random.default_rng(91)
+    hs = torch.cuda.current_stream().cuda_stream
+    for trial in range(6):
+        n = int(rng.integers(1, 70))
+        types = rng.choice(np.array([0, 1, 3, 2, 4], np.uint8), n, p=[0.3, 0.3, 0.2, 0.1, 0.1]).astype(np.uint8)
+        code = int(rng.integers(0, 1 << 32))
+        slots = T.synth_slots(np.where((types == 2) | (types > 3), 0, types).astype(np.uint8), seed=100 + trial, scramb_init=code)
+        gaps = rng.integers(0, 40, n)                      # arbitrary (odd and even) gaps in front of every slot
+        if trial == 0:
+            gaps[:] = 0
+        offs, parts, o = [], [], 0
+        for i in range(n):
+            parts.append(rng.integers(0, 2, gaps[i]).astype(np.uint8)); o += int(gaps[i])
+            offs.append(o); parts.append(slots[i]); o += 510
+        bits = np.concatenate(parts)
+        if len(bits) & 1:
+            bits = np.concatenate([bits, np.zeros(1, np.uint8)])
+        phi = (O.bits_to_phase(bits) + rng.normal(0, 0.5, len(bits) // 2)).astype(np.float32)
+        k = rng.integers(0, len(phi), 12)
+        phi[k[:4]] = np.nan; phi[k[4:8]] = np.inf; phi[k[8:10]] = -np.inf; phi[k[10:]] = 3e38
+        d_phi = torch.from_numpy(phi).cuda()
+        d_bits = torch.zeros(2 * len(phi) + 64, dtype=torch.uint8, device="cuda")
+        d_soft = torch.zeros(2 * len(phi) + 64, dtype=torch.int8, device="cuda")
+        eng.float_to_bits(d_phi.data_ptr(), len(phi), d_bits.data_ptr(), d_soft.data_ptr())
+        plan = T.Plan(eng, n, 1)
+        plan.load(np.array(offs, np.uint64), types, None, np.array([code], np.uint32))
+        a = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        b = torch.full((n * T.REC_BYTES,), 0, dtype=torch.uint8, device="cuda")
+        plan.execute_soft(d_soft.data_ptr(), a.data_ptr(), hs)
+        plan.execute_float(d_phi.data_ptr(), len(phi), b.data_ptr(), hs)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), trial
+        plan.close()
 
 
 def test_config4_channels_in_one_grid_batch(T, eng):

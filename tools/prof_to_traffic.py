@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from the rocprofv3 summaries of tools/prof_run.sh:
-   python tools/prof_to_traffic.py gpurun_out/prof_<mix tag> gpurun_out/prof_<config2 tag>
+   python tools/prof_to_traffic.py gpurun_out/prof_<mix tag> [gpurun_out/prof_<config2 tag> [gpurun_out/prof_<config5 tag>]]
 bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the x2 is the gfx950 FETCH_SIZE correction of
 MI355X_MICROARCH.md); VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)."""
 import json
@@ -9,7 +9,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {"k_vit<0, 1>": "k_vit<SB1>", "k_vit<1, 1>": "k_vit<216>", "k_vit<2, 1>": "k_vit<432>"}
+NAMES = {"k_vit<0, 1>": "k_vit<SB1>", "k_vit<1, 1>": "k_vit<216>", "k_vit<2, 1>": "k_vit<432>",
+         "k_vit<0, 2>": "k_vit_soft<SB1>", "k_vit<1, 2>": "k_vit_soft<216>", "k_vit<2, 2>": "k_vit_soft<432>",
+         "k_front_soft<true>": "k_front_soft<float>", "k_front_soft<false>": "k_front_soft<int8>"}
 
 
 def read(path):
@@ -49,6 +51,13 @@ def main():
                 tj.setdefault("valu_busy", {})[k] = c2_b[k]
         tj["_provenance"] = ("round 2: the same recipe on `python bench.py --workload config2 --steps 12 --warmup 6 --no-cpu-baseline` "
                              "(profiles/r02_config2_rocprofv3.md); bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+    if len(sys.argv) > 3:
+        c5_t, c5_b = derive(read(sys.argv[3]))
+        keep = ("k_front_soft", "k_vit_soft", "k_float_to_bits")
+        tj["config5"] = {k: c5_t[k] for k in c5_t if k.startswith(keep)}
+        tj["config5_valu_busy"] = {k: c5_b[k] for k in c5_b if k.startswith(keep)}
+        tj["_config5_provenance"] = ("round 2: the same recipe on `python bench.py --workload config5 --steps 12 --warmup 6 "
+                                     "--no-cpu-baseline` (profiles/r02_config5_rocprofv3.md)")
     json.dump(tj, open(path, "w"), indent=1)
     print(json.dumps({k: tj[k] for k in ("mix", "mix_valu_busy")}, indent=1))
 
