@@ -1254,6 +1254,8 @@ __device__ __forceinline__ uint32_t field_msb(uint32_t lo, uint32_t hi, int sh, 
 
 typedef uint32_t tg_v32 __attribute__((ext_vector_type(32)));
 
+#define TG_STAGE_PITCH 20	/* dwords per lane in the record staging area: 16 + 4 (dwordx4 rows of neighbouring lanes in different banks) */
+
 /* byte 's' (0..15) of the 16 history bytes held in four dwords: two v_perm_b32 + one select */
 __device__ __forceinline__ uint32_t hist_byte(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t s)
 {
@@ -1273,7 +1275,8 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 					    uint32_t slot, uint32_t which, uint32_t idx, uint32_t midx,
 					    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 					    uint8_t *__restrict__ rec, uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code,
-					    uint8_t *__restrict__ wire, const uint32_t *__restrict__ softarea, int kflags)
+					    uint8_t *__restrict__ wire, const uint32_t *__restrict__ softarea, int kflags,
+					    uint32_t *stage = nullptr)
 {
 	constexpr int NBLK = vit_cfg<KIND>::NBLK;
 	constexpr int TYPE1 = vit_cfg<KIND>::TYPE1;
@@ -1294,6 +1297,79 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 		}
 	}
 	const uint32_t crc_ok = (crc == 0x1d0f);
+
+	if (KIND == TG_KIND_432 && stage && !block_mode) {
+		/* SCH/F: the lane owns the whole 320-byte record.  Written 16 bytes at a time per lane, every store
+		 * instruction touches 64 cache lines and every line is filled from memory before it is complete
+		 * (FETCH_SIZE 3x the input).  Instead the record goes out in five 64-byte pieces through LDS: each lane parks
+		 * its four dwordx4 of the piece, then lane l stores quarter (l & 3) of the pieces of records (l >> 2) + 16 i --
+		 * four lanes = one complete 64-byte segment, sixteen records per store instruction.  Lanes past the end
+		 * of the list hold a copy of the last item and store the same bytes again. */
+		const uint32_t lane = threadIdx.x & 63;
+		uint32_t *st_slot = stage + 64 * TG_STAGE_PITCH;	/* the 64 slot numbers */
+		st_slot[lane] = slot;
+		const uint32_t meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
+		uint32_t bbraw;
+		if (HMODE == 2) {
+			const uint32_t *sb = softarea + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + TG_SOFT_BBK / 4;
+			bbraw = 0;
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				bbraw |= ((((sb[q] >> 7) & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
+		} else
+			bbraw = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_BBK];
+		uint32_t bb = bbraw ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
+		uint32_t nerr = 0;
+		if (kflags & TGK_F_RM)
+			bb = rm3014_correct(bb, nerr);
+		const uint32_t code = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
+		auto bits16 = [&](int q) {	/* type-1 bits 16 q .. 16 q + 15, one per byte */
+			const uint32_t hw = (od[q >> 1] >> ((q & 1) * 16)) & 0xffff;
+			uint4 o;
+			o.x = spread4(hw);
+			o.y = spread4(hw >> 4);
+			o.z = spread4(hw >> 8);
+			o.w = (q * 16 + 12 < TYPE1) ? spread4(hw >> 12) : 0u;
+			return o;
+		};
+		uint4 *mine = (uint4 *)(stage + lane * TG_STAGE_PITCH);
+#pragma unroll
+		for (int c = 0; c < 5; c++) {
+			if (c == 0) {
+				/* bytes 0..15: type, flags, crc_ok[2], crc[2], code, slot; 16..31: SYNC fields (none), BBK errors */
+				mine[0] = make_uint4((meta & 0xffffu) | (crc_ok << 16), crc, code, slot);
+				mine[1] = make_uint4(0u, 0u, 0u, nerr);
+				mine[2] = make_uint4(spread4(bb), spread4(bb >> 4), spread4(bb >> 8), spread4(bb >> 12) & 0x0000ffffu);
+				mine[3] = bits16(0);
+			} else {
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					mine[i] = bits16(4 * c - 3 + i);
+			}
+			__builtin_amdgcn_s_waitcnt(0xc07f);	/* lgkmcnt(0): single wave, LDS visible */
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const uint32_t rr = (lane >> 2) + 16 * i;
+				const uint4 v = *(const uint4 *)(stage + rr * TG_STAGE_PITCH + 4 * (lane & 3));
+				*(uint4 *)(rec + (size_t)st_slot[rr] * TG_REC_BYTES + 64 * c + 16 * (lane & 3)) = v;
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+		if (!valid)
+			return;
+		if (wire) {
+			uint32_t *wr = (uint32_t *)(wire + (size_t)slot * TG_WIRE_BYTES);
+			uint32_t *wb = wr + TG_WIRE_W_BITS1;
+			constexpr int NWD = (TYPE1 + 31) / 32;
+#pragma unroll
+			for (int q = 0; q < NWD - 1; q++)
+				wb[q] = od[q];
+			wb[NWD - 1] = (od[NWD - 1] & ((1u << (TYPE1 & 31)) - 1)) | (crc << TG_WIRE_SCHF_CRC_SHIFT);
+			wr[0] = (meta & 0xff) | (((meta >> 8) & 0xff) << 8) | ((bb & 0x3fff) << 16);
+		}
+		return;
+	}
 
 	if (!valid)
 		return;
@@ -1534,6 +1610,8 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 
 	__shared__ uint4 hist[(HMODE == 0) ? NBLK * 64 : 1];
 	__shared__ uint16_t s_crc[512];
+	/* record staging of the SCH/F kernel (vit_finish): 64 lanes x four dwordx4 at a pitch of 20 dwords + 64 slot numbers */
+	__shared__ __attribute__((aligned(16))) uint32_t s_stage[(KIND == TG_KIND_432 && HMODE != 0) ? 64 * TG_STAGE_PITCH + 64 : 4];
 
 	const uint32_t lane = threadIdx.x;
 	for (int i = lane; i < 256; i += 64) {
@@ -1764,7 +1842,8 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	}
 
 	__syncthreads();	/* s_crc visible (single wave, but keep the compiler honest) */
-	vit_finish<KIND, HMODE>(od, s_crc, valid, slot, which, idx, midx, packed, masks, rec, sb_ok, sb_code, wire, softarea, kflags);
+	vit_finish<KIND, HMODE>(od, s_crc, valid, slot, which, idx, midx, packed, masks, rec, sb_ok, sb_code, wire, softarea, kflags,
+				(KIND == TG_KIND_432 && HMODE != 0 && !(kflags & TGK_F_DIRECT)) ? s_stage : nullptr);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2772,6 +2851,13 @@ extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const
 	hipStream_t s = (hipStream_t)stream;
 #define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire, d_soft, flags, d_nitems)
 	const int hm = d_soft ? 2 : tgk_hist_mode;
+	static int direct = -1;
+	if (direct < 0) {
+		const char *e = getenv("TGPU_REC_DIRECT");
+		direct = (e && atoi(e)) ? 1 : 0;
+	}
+	if (direct)
+		flags |= TGK_F_DIRECT;
 	switch (kind) {
 	case TG_KIND_SB1:
 		if (hm == 2) VIT_LAUNCH(TG_KIND_SB1, 2); else if (hm) VIT_LAUNCH(TG_KIND_SB1, 1); else VIT_LAUNCH(TG_KIND_SB1, 0);
