@@ -351,9 +351,39 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     el, delivered = reduce(el, delivered)
     decode_only = {"value": delivered / el, "ms_per_step": el / args.steps * 1e3, "bursts_delivered": delivered}
     gathered = None
+    gather_error = None
     if gather:
-        el_g, del_g, state = run_phase(args.steps, warm, True)
-        el_g, del_g = reduce(el_g, del_g)
+        # The decode-only number is complete at this point.  The exchange phase runs under a watchdog: a wedged
+        # collective must not cost the run its line -- rank 0 then reports the decode-only rate with the failure
+        # stated, and every rank leaves.
+        armed = [True]
+
+        def bail():
+            if not armed[0]:
+                return
+            if rank == 0:
+                print(json.dumps({"metric": "decoded bursts/s", "value": decode_only["value"], "unit": "bursts/s", "n_gpus": world,
+                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": decode_only["ms_per_step"],
+                                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16",
+                                  "data": "synthetic",
+                                  "config": {"workload": "SB+NDB mix through the burst-sync front end, %d channels per GPU "
+                                                         "(decode only: the per-step RCCL gather to rank 0 did not finish "
+                                                         "within %d s and was abandoned)" % (C, args.gather_timeout)},
+                                  "decode_only": decode_only,
+                                  "gathered": {"error": "timeout after %d s" % args.gather_timeout}}), flush=True)
+            os._exit(0)
+
+        tmr = threading.Timer(args.gather_timeout, bail)
+        tmr.daemon = True
+        tmr.start()
+        try:
+            el_g, del_g, state = run_phase(args.steps, warm, True)
+            el_g, del_g = reduce(el_g, del_g)
+        except Exception as ex:      # pragma: no cover
+            gather_error = repr(ex)
+        armed[0] = False
+        tmr.cancel()
+    if gather and gather_error is None:
         ngrid_r = sum((len(st) - 100) // 510 for st in streams)
         per_rank_mb = cap * T.WIRE_BYTES / 1e6
         gathered = {"value": del_g / el_g, "ms_per_step": el_g / args.steps * 1e3, "bursts_delivered": del_g,
@@ -457,6 +487,9 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     if gathered:
         out["decode_only"] = decode_only
         out["gathered"] = gathered
+    elif gather_error:
+        out["decode_only"] = decode_only
+        out["gathered"] = {"error": gather_error}
     return out
 
 
@@ -794,6 +827,9 @@ def main():
                     help="mix (default, = config3: the metric's workload): SB+NDB recordings through the GPU burst-sync front end, "
                          "1%% damaged training sequences; config2: aligned NDB slots, no front end; config5: float phases -> "
                          "soft-decision decode; conv: the generic trellis kernel")
+    ap.add_argument("--gather-timeout", type=int, default=150,
+                    help="N > 1: seconds the exchange phase (per-step RCCL gather to rank 0) may take before the run reports "
+                         "the decode-only number and leaves")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = control-flow check on a box with fewer GPUs than ranks")
     args = ap.parse_args()
