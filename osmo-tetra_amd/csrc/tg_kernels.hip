@@ -786,6 +786,17 @@ struct tg_group_data {
 #ifndef TG_STREAM_WPE
 #define TG_STREAM_WPE 4
 #endif
+/* acc & (t0 == p0) & (t1 == p1), sel = 2 p0 + p1 (a constant once the caller's loop is unrolled): one v_bitop3_b32 */
+__device__ __forceinline__ uint32_t tsq_and2(uint32_t acc, uint32_t t0, uint32_t t1, int sel)
+{
+	switch (sel) {
+	case 0: return __builtin_amdgcn_bitop3_b32(acc, t0, t1, 0x10);
+	case 1: return __builtin_amdgcn_bitop3_b32(acc, t0, t1, 0x20);
+	case 2: return __builtin_amdgcn_bitop3_b32(acc, t0, t1, 0x40);
+	default: return __builtin_amdgcn_bitop3_b32(acc, t0, t1, 0x80);
+	}
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TG_STREAM_WPE, TG_STREAM_WPE)))
 void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
@@ -901,18 +912,25 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		win[lane] = W0;
 
 		/* match masks of the three sequences at the column's 32 positions */
-		uint32_t gy = 0xffffffffu, hy = 0, gnn = 0xffffffffu, hn = 0, gp = 0xffffffffu, hp = 0;
+		/* one accumulator per sequence, two positions per step: acc & (t_j == p_j) & (t_j+1 == p_j+1) is one
+		 * three-input logic instruction (v_bitop3_b32) whatever the two pattern bits are */
+		uint32_t my = vys, mn = 0xffffffffu, mp = 0xffffffffu;
 #pragma unroll
-		for (int j = 0; j < 38; j++) {
-			const uint32_t t = (j == 0) ? W0 : (j < 32) ? __builtin_amdgcn_alignbit(W1, W0, j)
-					 : (j == 32) ? W1 : __builtin_amdgcn_alignbit(W2, W1, j - 32);
-			if ((PY >> j) & 1) gy &= t; else hy |= t;
+		for (int j = 0; j < 38; j += 2) {
+			const uint32_t t0 = (j == 0) ? W0 : (j < 32) ? __builtin_amdgcn_alignbit(W1, W0, j)
+					  : (j == 32) ? W1 : __builtin_amdgcn_alignbit(W2, W1, j - 32);
+			const int k = j + 1;
+			const uint32_t t1 = (k < 32) ? __builtin_amdgcn_alignbit(W1, W0, k)
+					  : (k == 32) ? W1 : __builtin_amdgcn_alignbit(W2, W1, k - 32);
+			/* truth table index = acc << 2 | t0 << 1 | t1: the one entry with acc = 1, t0 = p_j, t1 = p_k */
+#define TSQ_STEP(acc, P) acc = tsq_and2(acc, t0, t1, 2 * (int)(((P) >> j) & 1) + (int)(((P) >> k) & 1))
+			TSQ_STEP(my, PY);
 			if (j < 22) {
-				if ((PN >> j) & 1) gnn &= t; else hn |= t;
-				if ((PP >> j) & 1) gp &= t; else hp |= t;
+				TSQ_STEP(mn, PN);
+				TSQ_STEP(mp, PP);
 			}
+#undef TSQ_STEP
 		}
-		const uint32_t my = gy & ~hy & vys, mn = gnn & ~hn, mp = gp & ~hp;
 		const uint32_t any = my | mn | mp;
 		const unsigned long long A = __ballot((any & vmain) != 0);
 		const unsigned long long E = __ballot((any & vearly) != 0);
