@@ -52,8 +52,8 @@ def run_plan(T, eng, slots, types, chan=None, codes=None, stride=510, offsets=No
     return rec, T.parse_records(rec), codes_out
 
 
-def check_against_oracle(T, rec, types, slots, code):
-    ok, want, wcrc = O.bench_decode_slots(slots, types, code, want_out=True, want_crc=True)
+def check_against_oracle(T, rec, types, slots, code, use_acc=0):
+    ok, want, wcrc = O.bench_decode_slots(slots, types, code, use_acc=use_acc, want_out=True, want_crc=True)
     p = T.parse_records(rec)
     n1 = types == O.TRAIN_NORM_1
     n2 = types == O.TRAIN_NORM_2
@@ -1749,6 +1749,63 @@ def test_config4_channels_in_one_grid_batch(T, eng):
             ndeliv += len(idx)
         p1.close()
     assert ndeliv > 3000
+    plan.close()
+
+
+def test_metric_workload_full_size_against_the_oracle(T, eng):
+    """The default bench line's step at its own size: 8 recorded channels x 125 000 slots (own cell each, 1 % damaged
+    training sequences, 1 % payload bit errors) as ONE batch through the multi-channel synchroniser (64-byte feeds) and
+    plan.  Per channel: the synchroniser's events and the number of delivered bursts == the oracle receiver's on that
+    channel's bytes; EVERY delivered burst's type, type-1 bits, BBK, CRC words and flags == the oracle's decode of the
+    same 510 bytes; the channel's final scrambling code"""
+    import ctypes as C
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    cells = [(262, 42, 1), (901, 77, 9), (234, 14, 33), (1, 2, 3), (262, 42, 2), (505, 1, 60), (208, 10, 5), (222, 99, 7)]
+    per = 125_000
+    streams, codes, offs, o = [], [], [], 0
+    for c, cell in enumerate(cells):
+        st, code = _mix_stream(T, per, 3100 + c, cell, ber=0.01)
+        streams.append(st)
+        codes.append(code)
+        offs.append(o)
+        o += (len(st) + T.STREAM_SLACK + 15) & ~15
+    buf = np.zeros(o + 4096, np.uint8)
+    for st, f in zip(streams, offs):
+        buf[f:f + len(st)] = st
+    d = torch.from_numpy(buf).cuda()
+    ntot = sum((len(st) // 510 + 32) for st in streams)
+    plan = T.Plan(eng, ntot, len(cells))
+    ms = T.MultiSync(eng, plan, streams, d.data_ptr(), offs, 64, hs)
+    outs = ms.finish(burst_events=False, nthreads=8)
+    d_rec = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+    torch.cuda.synchronize()
+    rec = d_rec.cpu().numpy().reshape(-1, T.REC_BYTES)
+    fin = plan.final_codes()
+    total = 0
+    for c, (st, out) in enumerate(zip(streams, outs)):
+        want_ev = []
+        rx = O.Rx()
+        ecb = O.EVENT_CB(lambda ev, bitnum, arg, priv: want_ev.append((ev, bitnum, arg)) if ev != 2 else None)
+        O.lib().orc_rx_init(C.byref(rx), O.UPPER_CB(), ecb, None)
+        rx.use_acc = 1
+        O.lib().orc_rx_feed(C.byref(rx), O._p(st), len(st), 64)
+        assert out["events"] == want_ev and len(want_ev) > 1500, c
+        # every slot the locked receiver looked at is either delivered or reported (events 3, 4, 5)
+        dropped = sum(1 for e in want_ev if e[0] in (3, 4, 5))
+        assert out["noffgrid"] == 0 and out["nslots"] == rx.burst_seq - dropped, c
+        idx = T.grid_indices(out)
+        assert len(idx) == out["nslots"] and 0.93 * per < len(idx) < per
+        r = rec[out["grid_base"] + idx]
+        slots = st[out["anchor"]:out["anchor"] + 510 * (int(idx[-1]) + 1)].reshape(-1, 510)[idx]
+        ty = T.parse_records(r)["type"].astype(np.uint8)
+        ok, p = check_against_oracle(T, r, ty, slots, codes[c], use_acc=1)
+        nblk = int(2 * (ty != 0).sum() + (ty == 0).sum())
+        assert 0.2 * nblk < ok <= nblk
+        assert (p["code"][ty != 3] == codes[c]).all() and int(fin[c]) == codes[c]
+        total += len(idx)
+    assert total > 930_000
     plan.close()
 
 
