@@ -205,7 +205,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     cap = sum(len(st) // 510 + 32 for st in streams)
     W = args.sync_threads if args.sync_threads > 0 else max(1, min(8, host_threads_default() // max(1, world)))
     W = max(1, min(W, args.steps))
-    gather = world > 1
+    gather = world > 1 or args.force_gather
     nccl = args.backend == "nccl"
 
     # per-thread resources, kept over both phases
@@ -218,10 +218,13 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             r["wire"] = [torch.full((cap * T.WIRE_BYTES,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(2)]
             r["sent"] = [None, None]         # CUDA event: the gather that last read this wire buffer is done
         res_t.append(r)
+    ccomm = None
     if gather:
         comm = torch.cuda.Stream()
-        sink = [[torch.empty(cap * T.WIRE_BYTES, dtype=torch.uint8, device="cuda" if nccl else "cpu") for _ in range(world)]
-                for _ in range(2)] if rank == 0 else [None, None]
+        # rank 0: two sinks (even / odd steps), rank-major like tgpu_comm_gather fills them
+        sink_flat = [torch.empty(world * cap * T.WIRE_BYTES, dtype=torch.uint8, device="cuda" if nccl else "cpu")
+                     for _ in range(2)] if rank == 0 else [None, None]
+        sink = [list(f.view(world, -1).unbind(0)) for f in sink_flat] if rank == 0 else [None, None]
 
     def run_phase(nsteps, nwarm, with_gather):
         """nwarm + nsteps steps per rank, dealt round-robin to the W threads; returns (seconds, delivered bursts, state)"""
@@ -285,23 +288,36 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                     e.set()
                 start.abort()
 
+        warm_gathered = threading.Event()
+
         def gatherer():
             """every step's decoded blocks (wire records) to rank 0, in step order, on a stream of its own: the
-            collective of step s waits for that step's decode only, and runs under the decodes that follow"""
+            exchange of step s waits for that step's decode only, and runs under the decodes that follow.  nccl: the
+            library's own gather (tgpu_comm_gather: grouped RCCL send / receive, csrc/tg_comm.c); the warm-up steps'
+            exchanges are complete before the main thread's barrier opens the timed region, so no two threads are ever
+            inside the communication library at once"""
             try:
                 torch.cuda.set_device(local)
                 for s_id in range(total):
+                    if s_id == nwarm:
+                        if nccl:
+                            comm.synchronize()
+                        warm_gathered.set()
                     ready[s_id].wait()
                     if errors:
                         return
                     w, i, ev = info[s_id]
                     wire = res_t[w]["wire"][i]
                     if nccl:
-                        with torch.cuda.stream(comm):
-                            comm.wait_event(ev)
-                            dist.gather(wire, gather_list=sink[s_id & 1] if rank == 0 else None, dst=0)
-                            sent = torch.cuda.Event()
-                            sent.record(comm)
+                        comm.wait_event(ev)
+                        if ccomm is not None:
+                            ccomm.gather(wire.data_ptr(), wire.numel(), sink_flat[s_id & 1].data_ptr() if rank == 0 else 0,
+                                         0, comm.cuda_stream)
+                        else:
+                            with torch.cuda.stream(comm):
+                                dist.gather(wire, gather_list=sink[s_id & 1] if rank == 0 else None, dst=0)
+                        sent = torch.cuda.Event()
+                        sent.record(comm)
                         res_t[w]["sent"][i] = sent
                     else:   # control-flow check on a box with fewer GPUs than ranks: staged through the host
                         ev.synchronize()
@@ -310,6 +326,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                     comm.synchronize()
             except Exception as ex:          # pragma: no cover
                 errors.append(ex)
+            finally:
+                warm_gathered.set()
 
         threads = [threading.Thread(target=worker, args=(w,)) for w in range(W)]
         gth = threading.Thread(target=gatherer) if with_gather else None
@@ -318,6 +336,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         if gth:
             gth.start()
         start.wait()
+        if gth:
+            warm_gathered.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -376,7 +396,20 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         tmr = threading.Timer(args.gather_timeout, bail)
         tmr.daemon = True
         tmr.start()
+        gather_impl = "torch.distributed.gather (gloo, staged through the host)"
         try:
+            if nccl and not args.torch_gather:
+                try:     # the library's communicator: rank 0 draws the id, the process group carries its 128 bytes
+                    uid = torch.from_numpy(T.comm_unique_id() if rank == 0 else np.zeros(T.COMM_ID_BYTES, np.uint8)).cuda()
+                    dist.broadcast(uid, 0)
+                    torch.cuda.synchronize()
+                    ccomm = T.Comm(eng, uid.cpu().numpy(), rank, world)
+                    gather_impl = "tgpu_comm_gather (C ABI, grouped RCCL send / receive)"
+                except Exception as ex:      # pragma: no cover
+                    ccomm = None
+                    gather_impl = "torch.distributed.gather (nccl); tgpu_comm_create failed: %r" % (ex,)
+            elif nccl:
+                gather_impl = "torch.distributed.gather (nccl)"
             el_g, del_g, state = run_phase(args.steps, warm, True)
             el_g, del_g = reduce(el_g, del_g)
         except Exception as ex:      # pragma: no cover
@@ -387,6 +420,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         ngrid_r = sum((len(st) - 100) // 510 for st in streams)
         per_rank_mb = cap * T.WIRE_BYTES / 1e6
         gathered = {"value": del_g / el_g, "ms_per_step": el_g / args.steps * 1e3, "bursts_delivered": del_g,
+                    "exchange": gather_impl,
                     "bytes_per_rank_and_step": cap * T.WIRE_BYTES,
                     "link_arithmetic": "every peer sends %.1f MB per step (%d grid slots x %d B wire record, undelivered slots "
                                        "included) to rank 0 over its own xGMI link: %.1f GB/s per link at the gathered step time, "
@@ -827,6 +861,10 @@ def main():
                     help="mix (default, = config3: the metric's workload): SB+NDB recordings through the GPU burst-sync front end, "
                          "1%% damaged training sequences; config2: aligned NDB slots, no front end; config5: float phases -> "
                          "soft-decision decode; conv: the generic trellis kernel")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the exchange phase with a single rank too (exercises the RCCL path on a 1-GPU box)")
+    ap.add_argument("--torch-gather", action="store_true",
+                    help="N > 1: exchange through torch.distributed.gather instead of the library's tgpu_comm_gather")
     ap.add_argument("--gather-timeout", type=int, default=150,
                     help="N > 1: seconds the exchange phase (per-step RCCL gather to rank 0) may take before the run reports "
                          "the decode-only number and leaves")
@@ -849,8 +887,11 @@ def main():
     if args.backend == "gloo":
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -871,10 +912,17 @@ def main():
             if not args.no_secondary:
                 c2 = bench_config2(args, T, torch, dist, rank, world, local, 40, 10, with_cpu=False)
                 out["config2"] = {k: c2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline")}
-    if rank == 0:
-        print(json.dumps(out))
+    # RCCL prints a version banner through C stdio when its first communicator comes up; on a pipe that text would be
+    # flushed at exit, i.e. after the result line.  Push it out on every rank now, then let rank 0 print last.
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1 or args.force_gather:
         dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
 
 
 if __name__ == "__main__":

@@ -118,6 +118,8 @@ struct tetra_rx_state {
 #define TGPU_ENODEV    -3	/* no usable GPU: there is no CPU fallback */
 #define TGPU_ECAPACITY -4	/* more slots/channels than the plan was created for */
 #define TGPU_ESTATE    -5	/* call order violated (e.g. execute before load) */
+#define TGPU_ENOSYS    -6	/* an optional component is not available in this process (no RCCL library to load) */
+#define TGPU_ECOMM     -7	/* the communication library reported an error */
 
 const char *tgpu_strerror(int err);
 
@@ -206,6 +208,23 @@ int tgpu_plan_final_codes(struct tgpu_plan *plan, const uint8_t *d_rec, uint32_t
 int tgpu_plan_set_wire(struct tgpu_plan *plan, uint8_t *d_wire /* NULL: off */);
 int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_code, uint8_t *rec);
 int tgpu_wire_pack(const uint8_t *rec, uint8_t *wire);
+
+/*
+ * The gather itself, in C (north star: "RCCL only for the final decoded-block gather over xGMI"; the
+ * reference has no counterpart -- it runs one process per channel).  One process per GPU.  Rank 0 (or any one rank)
+ * draws an id with tgpu_comm_unique_id() and hands its TGPU_COMM_ID_BYTES bytes to the other ranks by whatever means
+ * the job has (a file, MPI, the launcher's store); every rank then calls tgpu_comm_create() with its rank.
+ * tgpu_comm_gather(): every rank's nbytes at d_send (device) arrive at the root's d_recv + rank * nbytes; grouped
+ * RCCL send / receive on hip_stream, asynchronous, peer -> root directly (one xGMI link per peer).  d_recv is read
+ * on the root only.  RCCL is loaded on first use (an RCCL the process already holds is reused); TGPU_ENOSYS if there
+ * is none.
+ */
+#define TGPU_COMM_ID_BYTES 128
+struct tgpu_comm;
+int tgpu_comm_unique_id(uint8_t id[TGPU_COMM_ID_BYTES]);
+int tgpu_comm_create(struct tgpu_engine *eng, const uint8_t id[TGPU_COMM_ID_BYTES], int rank, int world, struct tgpu_comm **out);
+int tgpu_comm_gather(struct tgpu_comm *comm, const void *d_send, size_t nbytes, void *d_recv, int root, void *hip_stream);
+void tgpu_comm_destroy(struct tgpu_comm *comm);
 
 /* diagnostic: copy the front kernel's packed slots (20 dwords per slot, csrc/tg_layout.h) of the
  * last executed batch to the host; synchronises the device */

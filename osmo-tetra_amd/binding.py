@@ -142,6 +142,11 @@ def lib():
     L.tgpu_prof_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_prof_destroy.argtypes = [C.c_void_p]
     L.tgpu_plan_execute_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.tgpu_comm_unique_id.argtypes = [u8p]
+    L.tgpu_comm_create.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.tgpu_comm_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+    L.tgpu_comm_destroy.argtypes = [C.c_void_p]
+    L.tgpu_comm_destroy.restype = None
     L.tgpu_plan_execute_float_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.tgpu_prof_read.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.tgpu_stage_name.restype = C.c_char_p
@@ -316,6 +321,35 @@ class Plan:
 
 
 NSTAGES = 6
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """tgpu_comm_unique_id: 128 bytes one rank draws and hands to the others"""
+    b = np.zeros(COMM_ID_BYTES, np.uint8)
+    _chk(lib().tgpu_comm_unique_id(b.ctypes.data_as(u8p)), "tgpu_comm_unique_id")
+    return b
+
+
+class Comm:
+    """the C-ABI gather of wire records to the collecting rank over RCCL (tgpu_comm_*)"""
+
+    def __init__(self, eng, uid, rank, world):
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        uid = _np_u8(uid)
+        _chk(lib().tgpu_comm_create(eng._h, uid.ctypes.data_as(u8p), rank, world, C.byref(self._h)), "tgpu_comm_create")
+
+    def gather(self, d_send_ptr, nbytes, d_recv_ptr, root=0, hip_stream=0):
+        _chk(lib().tgpu_comm_gather(self._h, C.c_void_p(d_send_ptr), nbytes, C.c_void_p(d_recv_ptr or 0), root,
+                                    C.c_void_p(hip_stream)), "tgpu_comm_gather")
+
+    def close(self):
+        if self._h:
+            lib().tgpu_comm_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class Prof:

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libtetra_gpu.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 HIP_SRCS = ["tg_kernels.hip"]
-C_SRCS = ["tg_host.c", "tg_sync.c", "tg_stream.c", "tg_synth.c", "tg_rm.c", "tg_conv.c", "tg_gsmtap.c", "tg_reorder.c"]
+C_SRCS = ["tg_host.c", "tg_sync.c", "tg_stream.c", "tg_synth.c", "tg_rm.c", "tg_conv.c", "tg_gsmtap.c", "tg_reorder.c", "tg_comm.c"]
 HEADERS = ["tg_layout.h", "vit_core.h", "tg_internal.h", "tg_conv.h", os.path.join(ROOT, "include", "tetra_gpu.h")]
 
 
@@ -52,7 +52,7 @@ def build(force=False, verbose=False):
         run(["gcc", "-O3", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"] + inc +
             ["-c", os.path.join(CSRC, s), "-o", o])
         objs.append(o)
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lpthread"])
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lpthread", "-ldl"])
     return LIB
 
 

@@ -95,6 +95,8 @@ const char *tgpu_strerror(int err)
 	case TGPU_ENODEV: return "no usable GPU (this library has no CPU fallback)";
 	case TGPU_ECAPACITY: return "batch exceeds plan capacity";
 	case TGPU_ESTATE: return "call order violated";
+	case TGPU_ENOSYS: return "component not available in this process (no RCCL library to load)";
+	case TGPU_ECOMM: return "communication library error";
 	default: break;
 	}
 	if (err > 0)

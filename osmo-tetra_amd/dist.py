@@ -4,7 +4,9 @@
 The path shards by channel: channels are independent, the reference itself runs
 one process per channel.  No collective takes part in decoding; the only exchange is the final
 gather of decoded blocks to the collecting rank, in the 40-byte wire form (tg_layout.h), each
-peer -> root transfer riding its own xGMI link.
+peer -> root transfer riding its own xGMI link.  The product's gather is the C-ABI entry
+tgpu_comm_gather() (csrc/tg_comm.c, binding.Comm); gather_wire() below is the torch.distributed form
+the CPU tests (gloo) and bench.py --torch-gather use.
 """
 import torch
 import torch.distributed as dist

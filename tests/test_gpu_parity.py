@@ -1752,6 +1752,51 @@ def test_config4_channels_in_one_grid_batch(T, eng):
     plan.close()
 
 
+def test_comm_gather_single_rank(T, eng):
+    """tgpu_comm_*: the C-ABI gather over RCCL with the one rank a 1-GPU box has -- id, communicator, the grouped
+    send / receive to the root (here: to itself) on a side stream, twice with different sizes, wire records of a
+    decoded batch arriving byte for byte; bad arguments are refused"""
+    import torch
+    uid = T.comm_unique_id()
+    assert uid.shape == (T.COMM_ID_BYTES,) and uid.any()
+    comm = T.Comm(eng, uid, 0, 1)
+    n = 3000
+    types = np.tile(np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8), n // 8 + 1)[:n]
+    slots = T.synth_slots(types, seed=5, scramb_init=O.scramb_get_init(262, 42, 1))
+    d_stream = torch.from_numpy(slots.reshape(-1)).cuda()
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    d_wire = torch.full((n * T.WIRE_BYTES,), 0xff, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(np.arange(n, dtype=np.uint64) * 510, types, None, np.array([3], np.uint32))
+    plan.set_wire(d_wire.data_ptr())
+    side = torch.cuda.Stream()
+    plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    done = torch.cuda.Event()
+    done.record()
+    sink = torch.zeros(n * T.WIRE_BYTES, dtype=torch.uint8, device="cuda")
+    side.wait_event(done)
+    comm.gather(d_wire.data_ptr(), n * T.WIRE_BYTES, sink.data_ptr(), 0, side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(sink, d_wire)
+    rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+    w = sink.cpu().numpy().reshape(n, T.WIRE_BYTES)
+    for i in (0, 1, 2, 7, n - 1):
+        assert (w[i] == T.wire_pack(rec[i])).all()
+    small = torch.arange(100, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(100, dtype=torch.uint8, device="cuda")
+    comm.gather(small.data_ptr(), 100, out.data_ptr(), 0, side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(small, out)
+    with pytest.raises(T.TgpuError):
+        comm.gather(small.data_ptr(), 100, out.data_ptr(), 1, side.cuda_stream)      # no such root
+    with pytest.raises(T.TgpuError):
+        comm.gather(small.data_ptr(), 100, 0, 0, side.cuda_stream)                   # the root needs a sink
+    with pytest.raises(T.TgpuError):
+        T.Comm(eng, uid, 1, 1)
+    comm.close()
+    plan.close()
+
+
 def test_metric_workload_full_size_against_the_oracle(T, eng):
     """The default bench line's step at its own size: 8 recorded channels x 125 000 slots (own cell each, 1 % damaged
     training sequences, 1 % payload bit errors) as ONE batch through the multi-channel synchroniser (64-byte feeds) and
