@@ -1908,6 +1908,8 @@ __device__ __forceinline__ uint32_t tgb_out_g12(uint32_t p, uint32_t u)
 	return o >> 2;						/* bit 1 = g1, bit 0 = g2 */
 }
 
+#define TGB_MAX_STEPS (4 + 8 * 36)	/* the SCH/F trellis: 292 steps */
+
 template <bool SB1_PASS>
 __global__ __launch_bounds__(256)
 void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_desc, const uint32_t *__restrict__ slot_chan,
@@ -1984,60 +1986,96 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	}
 	__syncthreads();
 
-	const uint32_t lane = tid & 63;
+	/*
+	 * The trellis: in-place butterflies across a 16-lane row, partner exchange with DPP row operations.
+	 * Predecessors j and j + 8 (they differ in the oldest state bit) produce 2 j and 2 j + 1 (which differ in the
+	 * newest): if the two lanes of such a pair swap words and each keeps the better candidate of its successor, no
+	 * word ever has to travel further -- the lane <-> state map rotates by one bit per step instead (state of lane L
+	 * before step k = rotl4(L, k mod 4); the pair's lanes differ in physical bit 3 - k mod 4) and is the identity
+	 * again every four steps, in particular wherever history bytes are extracted.  The partner's word arrives with
+	 * one DPP move (row_ror:8, quad permutes for bits 1 and 0) or two (row_shl:4 / row_shr:4 under bank masks for
+	 * bit 2).  What a lane adds to its own and to its partner's word at step k -- branch metric of its successor from
+	 * either predecessor, the tie / decision bit on the candidate from j + 8 -- does not depend on the metrics: all 256
+	 * threads prepare these increments for the whole block up front (one 32-bit word per step and lane in LDS), and the
+	 * serial loop is read, exchange, two adds, one min per step.
+	 */
+	__shared__ uint32_t s_inc[2][TGB_MAX_STEPS][16];
+	{
+		const uint32_t L = tid & 15, kq = tid >> 4;		/* lane of the row; step index modulo 16 */
+		const uint32_t c = kq & 3;				/* = k mod 4 for every step this thread prepares */
+		const uint32_t sig = ((L << c) | (L >> (4 - c))) & 15;	/* the lane's state before such a step */
+		const uint32_t pv = (L >> (3 - c)) & 1;		/* 0: it holds predecessor j and becomes 2 j; 1: j + 8 -> 2 j + 1 */
+		const uint32_t e0 = tgb_out_g12(sig & 7, pv);		/* expected (g1, g2) from predecessor j; from j + 8: the complement */
+		const bool odd = kq & 1;				/* one received bit (g1) instead of two */
+#pragma unroll
+		for (int b = 0; b < 2; b++) {
+			if (kind[b] < 0)
+				continue;
+			const uint32_t nst = 4 + 8 * tgb_nblk(kind[b]);
+			const uint8_t *rr = s_r[b];
+			for (uint32_t k = kq; k < nst; k += 16) {
+				const uint32_t tie = 1u << (k < 4 ? k : (k - 4) & 7);
+				uint32_t d0 = 0, d1 = 0;
+				if (k + 4 < nst) {				/* (the last four steps are the flush: nothing received) */
+					const uint32_t p3 = 3 * (k >> 1);
+					if (odd) {
+						d0 = rr[p3 + 2] ^ (e0 >> 1);
+						d1 = 1 - d0;
+					} else {
+						const uint32_t x0 = ((rr[p3] << 1) | rr[p3 + 1]) ^ e0;
+						d0 = (x0 & 1) + (x0 >> 1);
+						d1 = 2 - d0;
+					}
+				}
+				const uint32_t ca = d0 << 8, cb = (d1 << 8) + tie;	/* candidate from j; from j + 8 */
+				s_inc[b][k][L] = pv ? (cb | (ca << 16)) : (ca | (cb << 16));	/* own word | partner's word << 16 */
+			}
+		}
+	}
+	__syncthreads();
+
 	if (tid < 64) {		/* wave 0: row 0 = first block, row 1 = second */
+		const uint32_t lane = tid;
 		const uint32_t row = lane >> 4, st = lane & 15;
 		const int mykind = row < 2 ? kind[row] : -1;
 		const uint32_t nblk = mykind >= 0 ? tgb_nblk(mykind) : 0;
 		const uint32_t nblk_max = max(kind[0] >= 0 ? tgb_nblk(kind[0]) : 0u, kind[1] >= 0 ? tgb_nblk(kind[1]) : 0u);
-		const uint8_t *rr = s_r[row & 1];
-		const uint32_t p0 = st >> 1, u = st & 1;
-		const int ia = (int)(4 * ((lane & 48) + p0)), ib = (int)(4 * ((lane & 48) + p0 + 8));
-		const uint32_t e0 = tgb_out_g12(p0, u);		/* expected (g1, g2) coming from predecessor p0; from p0 + 8: the complement */
+		const uint32_t *inc = &s_inc[row & 1][0][st];
 		uint32_t W = (st == 0) ? 0u : (1000u << 8);
-		auto step2 = [&](uint32_t r1, uint32_t r2, uint32_t tie) {	/* two received bits (g1, g2) */
-			const uint32_t x0 = ((r1 << 1) | r2) ^ e0;
-			const uint32_t d0 = (x0 & 1) + (x0 >> 1), d1 = 2 - d0;
-			const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute(ia, (int)W), wb = (uint32_t)__builtin_amdgcn_ds_bpermute(ib, (int)W);
-			const uint32_t x = wa + (d0 << 8), y = wb + (d1 << 8) + tie;
-			W = x < y ? x : y;
-		};
-		auto step1 = [&](uint32_t r1, uint32_t tie) {			/* one received bit (g1) */
-			const uint32_t d0 = r1 ^ (e0 >> 1), d1 = 1 - d0;
-			const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute(ia, (int)W), wb = (uint32_t)__builtin_amdgcn_ds_bpermute(ib, (int)W);
-			const uint32_t x = wa + (d0 << 8), y = wb + (d1 << 8) + tie;
-			W = x < y ? x : y;
-		};
-		auto step0 = [&](uint32_t tie) {					/* flush step: nothing received */
-			const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute(ia, (int)W), wb = (uint32_t)__builtin_amdgcn_ds_bpermute(ib, (int)W);
-			const uint32_t y = wb + tie;
-			W = wa < y ? wa : y;
-		};
-		/* four lead-in steps (type-3 bits 0..5), then blocks of eight steps on twelve bits (vit_core.h) */
-		step2(rr[0], rr[1], 1);
-		step1(rr[2], 2);
-		step2(rr[3], rr[4], 4);
-		step1(rr[5], 8);
-		W &= ~0xffu;
+#define TGB_ACS(C, w)												\
+		{												\
+			uint32_t P;										\
+			if ((C) == 0)										\
+				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W, 0x128, 0xf, 0xf, false);	/* row_ror:8 */	\
+			else if ((C) == 1) {									\
+				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W, 0x104, 0xf, 0x5, false);	/* row_shl:4, banks 0, 2 */	\
+				P = (uint32_t)__builtin_amdgcn_update_dpp((int)P, (int)W, 0x114, 0xf, 0xa, false);	/* row_shr:4, banks 1, 3 */	\
+			} else if ((C) == 2)									\
+				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W, 0x4e, 0xf, 0xf, false);	/* quad_perm:[2,3,0,1] */	\
+			else											\
+				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W, 0xb1, 0xf, 0xf, false);	/* quad_perm:[1,0,3,2] */	\
+			const uint32_t x = W + ((w) & 0xffffu), y = P + ((w) >> 16);				\
+			W = x < y ? x : y;									\
+		}
+		{	/* four lead-in steps (type-3 bits 0..5) */
+			const uint32_t w0 = inc[0], w1 = inc[16], w2 = inc[32], w3 = inc[48];
+			TGB_ACS(0, w0) TGB_ACS(1, w1) TGB_ACS(2, w2) TGB_ACS(3, w3)
+			W &= ~0xffu;
+		}
+		/* blocks of eight steps on twelve bits (vit_core.h); a row with fewer blocks than the other runs along */
 		for (uint32_t b = 0; b < nblk_max; b++) {
-			const uint8_t *q = rr + 6 + 12 * (b < nblk ? b : 0);
-			const bool last = (b + 1 == nblk);
-			step2(q[0], q[1], 1);
-			step1(q[2], 2);
-			step2(q[3], q[4], 4);
-			step1(q[5], 8);
-			if (last) {
-				step0(16); step0(32); step0(64); step0(128);
-			} else {
-				step2(q[6], q[7], 16);
-				step1(q[8], 32);
-				step2(q[9], q[10], 64);
-				step1(q[11], 128);
-			}
+			const uint32_t *q = inc + 16 * (4 + 8 * (b < nblk ? b : 0));
+			uint32_t w[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+				w[k] = q[16 * k];
+			TGB_ACS(0, w[0]) TGB_ACS(1, w[1]) TGB_ACS(2, w[2]) TGB_ACS(3, w[3])
+			TGB_ACS(0, w[4]) TGB_ACS(1, w[5]) TGB_ACS(2, w[6]) TGB_ACS(3, w[7])
 			if (b < nblk)
 				s_hist[row & 1][b][st] = (uint8_t)W;
 			W &= ~0xffu;
 		}
+#undef TGB_ACS
 		/* block-wise traceback from state 0 (row leaders) */
 		if (st == 0 && mykind >= 0) {
 			uint32_t sidx = 0;
