@@ -42,7 +42,7 @@ int tgpi_engine_bind(const struct tgpu_engine *eng)
 }
 #define BIND(eng) do { int b_ = tgpi_engine_bind(eng); if (b_) return b_; } while (0)
 
-#define TGPU_BURST_MAX_DEFAULT 2048u	/* batches up to this many slots go through k_burst (measured crossover) */
+#define TGPU_BURST_MAX_DEFAULT 1024u	/* batches up to this many slots go through k_burst (measured crossover) */
 #define TGPU_SMALL_PLAN 256u	/* plans up to this many slots keep their descriptors in mapped host memory */
 #define TGPU_NKINDS 4	/* trellis kinds TG_KIND_SB1 / _216 / _432 / _168; index 4 = BBK in block-mode lists */
 
@@ -54,6 +54,8 @@ struct tgpu_plan {
 	int static_masks;	/* batch has no SYNC slot: mask entries are known at load time */
 	int static_pending;	/* ... and the copy of the indices + the mask kernel still have to run (first execute) */
 	int up_mapped;		/* small plans: the upload arena is pinned host memory the kernels read in place */
+	int last_burst;		/* the last execute took the workgroup-per-burst path (records carry a completion mark) */
+	int marks;		/* the owner keeps d_rec in mapped host memory and polls the marks (tgpi_plan_set_marks) */
 	/* device */
 	uint8_t *d_up, *h_up;	/* upload arena (device / pinned host mirror): one copy per load */
 	size_t up_bytes;
@@ -522,12 +524,14 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	 * TGPU_BURST_MAX = largest batch that takes this path (0 = never) */
 	if (!soft && !ev && !p->packed_ready && !p->rm_decode && !p->d_wire && !p->fastpath && p->nslots &&
 	    p->nslots <= tgpi_burst_max()) {
-		if ((rc = tgk_burst(d_stream, p->d_slot_off, p->d_slot_chan, p->d_chan_code, p->nslots, p->nsb != 0, p->d_sb_ok,
-				    p->d_sb_code, d_rec, p->d_maskidx, p->d_masks, stream)))
+		if ((rc = tgk_burst(d_stream, p->d_slot_off, p->d_slot_chan, p->d_chan_code, p->nslots, p->nchan, p->nsb != 0, p->d_sb_ok,
+				    p->d_sb_code, d_rec, p->d_maskidx, p->d_masks, p->marks, stream)))
 			return rc;
 		p->static_pending = 0;
+		p->last_burst = 1;
 		return TGPU_OK;
 	}
+	p->last_burst = 0;
 	if (p->static_pending && p->nslots) {
 		HCHK(hipMemcpyAsync(p->d_maskidx, p->d_idx_stage, (size_t)p->nslots * 4,
 				    hipMemcpyDefault, (hipStream_t)stream));
@@ -799,6 +803,17 @@ int tgpu_plan_execute(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_r
 int tgpu_plan_execute_soft(struct tgpu_plan *p, const int8_t *d_soft_stream, uint8_t *d_rec, void *stream)
 {
 	return plan_run(p, (const uint8_t *)d_soft_stream, d_rec, stream, NULL, 1, 0);
+}
+
+int tgpi_plan_last_burst(const struct tgpu_plan *p)
+{
+	return p && p->last_burst && p->marks;
+}
+
+void tgpi_plan_set_marks(struct tgpu_plan *p, int on)
+{
+	if (p)
+		p->marks = on;
 }
 
 int tgpu_plan_execute_float(struct tgpu_plan *p, const float *d_phi, uint64_t nfloats, uint8_t *d_rec, void *stream)

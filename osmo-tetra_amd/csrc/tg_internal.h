@@ -40,8 +40,9 @@ int tgk_clean(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t
 /* small batches: one workgroup per burst, the trellis states across lanes; two launches per batch (SB1 pass first
  * when the batch holds a SYNC slot).  d_sb_ok / d_sb_code are indexed by SLOT here. */
 int tgk_burst(const uint8_t *d_stream, const uint64_t *d_slot_desc, const uint32_t *d_slot_chan,
-	      const uint32_t *d_chan_code, uint32_t nslots, int have_sync, uint32_t *d_sb_ok, uint32_t *d_sb_code,
-	      uint8_t *d_rec, uint32_t *d_maskidx, uint32_t *d_masks, void *stream);
+	      const uint32_t *d_chan_code, uint32_t nslots, uint32_t nchan, int have_sync, uint32_t *d_sb_ok,
+	      uint32_t *d_sb_code, uint8_t *d_rec, uint32_t *d_maskidx, uint32_t *d_masks,
+	      int marks /* records in mapped host memory: completion marks behind a system-wide fence */, void *stream);
 /* block mode: descriptor = byte offset | table index (TG_KIND_* or 4 = BBK) << 56 | tp_sap type << 48 */
 int tgk_front_blocks(const uint8_t *d_bits, const uint64_t *d_desc, uint32_t nblocks, uint32_t *d_packed, void *stream);
 int tgk_bbk_blocks(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,
@@ -87,6 +88,8 @@ int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity);
 /* make the engine's device the calling thread's current HIP device (every allocating / launching entry point does) */
 struct tgpu_engine;
 int tgpi_engine_bind(const struct tgpu_engine *eng);
+int tgpi_plan_last_burst(const struct tgpu_plan *p);
+void tgpi_plan_set_marks(struct tgpu_plan *p, int on);	/* the caller polls completion marks in mapped records (tg_sync.c) */	/* the last execute wrote completion marks (k_burst) */
 
 /* plan internals used by the stream synchroniser (tg_stream.c) */
 struct tgpu_plan;

@@ -39,6 +39,10 @@ struct tg_const_tables {
 	uint32_t sb1_mask[5];				/* SB1 is always scrambled with init 3 */
 	uint16_t crc_lsb[256];
 	uint16_t crc_msb[256];
+	/* CRC-16 as a linear map (k_burst): crc(bits) = crc_aff[kind] ^ XOR over the set bits i of crc_lin[kind][i], bits
+	 * in the order they are fed (8 per decoded byte, LSB first; 8 (NBLK - 1) + 4 of them), kind = SB1 / 216 / 432 */
+	uint16_t crc_lin[3][288];
+	uint16_t crc_aff[4];
 };
 
 __constant__ tg_const_tables c_tab;
@@ -1910,20 +1914,46 @@ __device__ __forceinline__ uint32_t tgb_out_g12(uint32_t p, uint32_t u)
 
 #define TGB_MAX_STEPS (4 + 8 * 36)	/* the SCH/F trellis: 292 steps */
 
+#ifdef TGB_TIMING	/* experiment build: phase time stamps of workgroup 0 (tools/flush_lat.c prints them) */
+__device__ unsigned long long g_tgb_stamp[16];
+#define TGB_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tgb_stamp[k] = wall_clock64(); } while (0)
+extern "C" int tgk_burst_stamps(unsigned long long *out)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tgb_stamp), sizeof(g_tgb_stamp));
+}
+#else
+#define TGB_STAMP(k) do { } while (0)
+#endif
+
 template <bool SB1_PASS>
 __global__ __launch_bounds__(256)
 void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_desc, const uint32_t *__restrict__ slot_chan,
-	     const uint32_t *__restrict__ chan_code, uint32_t nslots, uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code,
-	     uint8_t *__restrict__ rec, uint32_t *__restrict__ maskidx, uint32_t *__restrict__ masks)
+	     const uint32_t *__restrict__ chan_code, uint32_t nslots, uint32_t nchan, uint32_t *__restrict__ sb_ok,
+	     uint32_t *__restrict__ sb_code, uint8_t *__restrict__ rec, uint32_t *__restrict__ maskidx, uint32_t *__restrict__ masks,
+	     int marks)
 {
 	__shared__ uint32_t s_slot32[128];
+	/* the descriptors and channels of this slot and the 255 before it, the channels' carry-in codes: small batches keep
+	 * them in mapped host memory, where every dependent read is a PCIe round trip -- fetch them in one */
+	__shared__ uint64_t s_desc[256];
+	__shared__ uint32_t s_chan[256], s_ccode[64];
 	__shared__ uint8_t s_r[2][432 + 16];		/* received type-3 bits per block, descrambled */
-	__shared__ uint8_t s_hist[2][36][16];
+	__shared__ uint8_t s_hist[2][37][16];		/* [.][36]: spare row for a block that only runs along */
 	__shared__ uint8_t s_od[2][40];			/* decoded bytes (8 bits per trellis block) */
 	__shared__ uint32_t s_code, s_nonbin;
 	uint8_t *s_slot = (uint8_t *)s_slot32;
 	const uint32_t i = blockIdx.x, tid = threadIdx.x;
-	const uint64_t d = slot_desc[i];
+	const uint32_t back = i < 255u ? i : 255u;
+	TGB_STAMP(0);
+	if (tid <= back) {
+		s_desc[tid] = slot_desc[i - tid];
+		s_chan[tid] = slot_chan[i - tid];
+	}
+	if (tid < 64 && tid < nchan)
+		s_ccode[tid] = chan_code[tid];
+	__syncthreads();
+	const uint64_t d = s_desc[0];
+	TGB_STAMP(1);
 	const uint32_t type = TG_DESC_TYPE(d);
 	const uint8_t *base = stream + TG_DESC_OFF(d);
 	uint8_t *r = rec + (size_t)i * TG_REC_BYTES;
@@ -1948,18 +1978,30 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	}
 	/* the code in force for this slot: look backwards through the SYNC slots of the batch (pass 1 left their results) */
 	if (tid == 0) {
-		const uint32_t ch = slot_chan[i];
-		uint32_t code = chan_code[ch];
-		if (!SB1_PASS)
-			for (int j = (int)i; j >= 0 && slot_chan[j] == ch; j--)
-				if (TG_DESC_TYPE(slot_desc[j]) == TG_BURST_SYNC && sb_ok[j]) {
-					code = sb_code[j];
-					break;
+		const uint32_t ch = s_chan[0];
+		uint32_t code = ch < 64 ? s_ccode[ch] : chan_code[ch];
+		if (!SB1_PASS) {
+			bool open = true;		/* still inside the channel's run and no good SYNC slot seen */
+			for (uint32_t t = 0; t <= back && open; t++) {
+				if (s_chan[t] != ch)
+					open = false;
+				else if (TG_DESC_TYPE(s_desc[t]) == TG_BURST_SYNC && sb_ok[i - t]) {
+					code = sb_code[i - t];
+					open = false;
 				}
+			}
+			if (open)			/* (a run longer than the window: the rest from memory) */
+				for (int j = (int)i - 256; j >= 0 && slot_chan[j] == ch; j--)
+					if (TG_DESC_TYPE(slot_desc[j]) == TG_BURST_SYNC && sb_ok[j]) {
+						code = sb_code[j];
+						break;
+					}
+		}
 		s_code = code;
 	}
 	__syncthreads();
 	const uint32_t code = s_code;
+	TGB_STAMP(2);
 
 	/* blocks of this burst: kind and where its type-4 bits sit in the slot (phy/tetra_burst.c:31-47) */
 	int kind[2] = { -1, -1 };
@@ -2000,6 +2042,7 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	 * serial loop is read, exchange, two adds, one min per step.
 	 */
 	__shared__ uint32_t s_inc[2][TGB_MAX_STEPS][16];
+	TGB_STAMP(3);
 	{
 		const uint32_t L = tid & 15, kq = tid >> 4;		/* lane of the row; step index modulo 16 */
 		const uint32_t c = kq & 3;				/* = k mod 4 for every step this thread prepares */
@@ -2013,22 +2056,37 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 				continue;
 			const uint32_t nst = 4 + 8 * tgb_nblk(kind[b]);
 			const uint8_t *rr = s_r[b];
-			for (uint32_t k = kq; k < nst; k += 16) {
+			constexpr int NIT = (TGB_MAX_STEPS + 15) / 16;
+			uint32_t ra[NIT], rb[NIT];		/* all the received bits first: one LDS latency, not one per step */
+#pragma unroll
+			for (int it = 0; it < NIT; it++) {
+				const uint32_t k = kq + 16 * it;
+				const uint32_t p3 = (k + 4 < nst) ? 3 * (k >> 1) : 0;	/* (the last four steps are the flush: nothing received) */
+				ra[it] = rr[odd ? p3 + 2 : p3];
+				rb[it] = rr[p3 + 1];
+			}
+#pragma unroll
+			for (int it = 0; it < NIT; it++) {
+				const uint32_t k = kq + 16 * it;
+				if (k >= nst)
+					break;
 				const uint32_t tie = 1u << (k < 4 ? k : (k - 4) & 7);
 				uint32_t d0 = 0, d1 = 0;
-				if (k + 4 < nst) {				/* (the last four steps are the flush: nothing received) */
-					const uint32_t p3 = 3 * (k >> 1);
+				if (k + 4 < nst) {
 					if (odd) {
-						d0 = rr[p3 + 2] ^ (e0 >> 1);
+						d0 = ra[it] ^ (e0 >> 1);
 						d1 = 1 - d0;
 					} else {
-						const uint32_t x0 = ((rr[p3] << 1) | rr[p3 + 1]) ^ e0;
+						const uint32_t x0 = ((ra[it] << 1) | rb[it]) ^ e0;
 						d0 = (x0 & 1) + (x0 >> 1);
 						d1 = 2 - d0;
 					}
 				}
-				const uint32_t ca = d0 << 8, cb = (d1 << 8) + tie;	/* candidate from j; from j + 8 */
-				s_inc[b][k][L] = pv ? (cb | (ca << 16)) : (ca | (cb << 16));	/* own word | partner's word << 16 */
+				/* low half: what the lane adds to its own word for its own successor; high half: what it adds
+				 * to its own word for the PARTNER's successor (the other input bit: expected bits complemented, so
+				 * the distances swap).  A word from predecessor j + 8 carries the tie / decision bit. */
+				const uint32_t ca = d0 << 8, cb = d1 << 8;
+				s_inc[b][k][L] = pv ? ((cb + tie) | ((ca + tie) << 16)) : (ca | (cb << 16));
 			}
 		}
 	}
@@ -2036,6 +2094,7 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 
 	if (tid < 64) {		/* wave 0: row 0 = first block, row 1 = second */
 		const uint32_t lane = tid;
+		TGB_STAMP(4);
 		const uint32_t row = lane >> 4, st = lane & 15;
 		const int mykind = row < 2 ? kind[row] : -1;
 		const uint32_t nblk = mykind >= 0 ? tgb_nblk(mykind) : 0;
@@ -2044,38 +2103,58 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 		uint32_t W = (st == 0) ? 0u : (1000u << 8);
 #define TGB_ACS(C, w)												\
 		{												\
-			uint32_t P;										\
+			/* own candidate; the candidate for the partner, which the partner picks up with a DPP move */	\
+			uint32_t x, g, P;									\
+			asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"	\
+			    : "=v"(x) : "v"(W), "v"(w));							\
+			asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"	\
+			    : "=v"(g) : "v"(W), "v"(w));							\
 			if ((C) == 0)										\
-				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W, 0x128, 0xf, 0xf, false);	/* row_ror:8 */	\
+				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x128, 0xf, 0xf, false);	/* row_ror:8 */	\
 			else if ((C) == 1) {									\
-				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W, 0x104, 0xf, 0x5, false);	/* row_shl:4, banks 0, 2 */	\
-				P = (uint32_t)__builtin_amdgcn_update_dpp((int)P, (int)W, 0x114, 0xf, 0xa, false);	/* row_shr:4, banks 1, 3 */	\
+				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x104, 0xf, 0x5, false);	/* row_shl:4, banks 0, 2 */	\
+				P = (uint32_t)__builtin_amdgcn_update_dpp((int)P, (int)g, 0x114, 0xf, 0xa, false);	/* row_shr:4, banks 1, 3 */	\
 			} else if ((C) == 2)									\
-				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W, 0x4e, 0xf, 0xf, false);	/* quad_perm:[2,3,0,1] */	\
+				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x4e, 0xf, 0xf, false);	/* quad_perm:[2,3,0,1] */	\
 			else											\
-				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W, 0xb1, 0xf, 0xf, false);	/* quad_perm:[1,0,3,2] */	\
-			const uint32_t x = W + ((w) & 0xffffu), y = P + ((w) >> 16);				\
-			W = x < y ? x : y;									\
+				P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0xb1, 0xf, 0xf, false);	/* quad_perm:[1,0,3,2] */	\
+			W = x < P ? x : P;									\
 		}
 		{	/* four lead-in steps (type-3 bits 0..5) */
 			const uint32_t w0 = inc[0], w1 = inc[16], w2 = inc[32], w3 = inc[48];
 			TGB_ACS(0, w0) TGB_ACS(1, w1) TGB_ACS(2, w2) TGB_ACS(3, w3)
 			W &= ~0xffu;
 		}
-		/* blocks of eight steps on twelve bits (vit_core.h); a row with fewer blocks than the other runs along */
-		for (uint32_t b = 0; b < nblk_max; b++) {
-			const uint32_t *q = inc + 16 * (4 + 8 * (b < nblk ? b : 0));
-			uint32_t w[8];
-#pragma unroll
-			for (int k = 0; k < 8; k++)
-				w[k] = q[16 * k];
-			TGB_ACS(0, w[0]) TGB_ACS(1, w[1]) TGB_ACS(2, w[2]) TGB_ACS(3, w[3])
-			TGB_ACS(0, w[4]) TGB_ACS(1, w[5]) TGB_ACS(2, w[6]) TGB_ACS(3, w[7])
-			if (b < nblk)
-				s_hist[row & 1][b][st] = (uint8_t)W;
-			W &= ~0xffu;
+		/* blocks of eight steps on twelve bits (vit_core.h), two per iteration with alternating register sets so that
+		 * a block's increments are read from LDS while the block before it runs; a row with fewer blocks than the
+		 * other runs along, its history bytes going to the spare row of s_hist */
+		uint32_t wa[8], wb[8];
+#define TGB_FETCH(dst, blk)											\
+		{												\
+			const uint32_t *q = inc + 16 * (4 + 8 * ((blk) < nblk ? (blk) : 0));			\
+			_Pragma("unroll") for (int k = 0; k < 8; k++)						\
+				dst[k] = q[16 * k];								\
 		}
+#define TGB_BLOCK(wv, blk)											\
+		{												\
+			TGB_ACS(0, wv[0]) TGB_ACS(1, wv[1]) TGB_ACS(2, wv[2]) TGB_ACS(3, wv[3])			\
+			TGB_ACS(0, wv[4]) TGB_ACS(1, wv[5]) TGB_ACS(2, wv[6]) TGB_ACS(3, wv[7])			\
+			s_hist[row & 1][(blk) < nblk ? (blk) : 36][st] = (uint8_t)W;				\
+			W &= ~0xffu;										\
+		}
+		TGB_FETCH(wa, 0u)
+		for (uint32_t b = 0; b < nblk_max; b += 2) {
+			TGB_FETCH(wb, b + 1)
+			TGB_BLOCK(wa, b)
+			if (b + 1 >= nblk_max)
+				break;
+			TGB_FETCH(wa, b + 2)
+			TGB_BLOCK(wb, b + 1)
+		}
+#undef TGB_FETCH
+#undef TGB_BLOCK
 #undef TGB_ACS
+		TGB_STAMP(5);
 		/* block-wise traceback from state 0 (row leaders) */
 		if (st == 0 && mykind >= 0) {
 			uint32_t sidx = 0;
@@ -2088,22 +2167,41 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	}
 	__syncthreads();
 
+	TGB_STAMP(6);
 	/* CRC-16 per block (thread 0 / 1), then the record */
 	__shared__ uint32_t s_crcv[2], s_okv[2];
-	if (tid < 2 && kind[tid] >= 0) {
-		const uint32_t nblk = tgb_nblk(kind[tid]);
-		uint32_t crc = 0xffff;
-		for (uint32_t k = 0; k + 1 < nblk; k++)
-			crc = ((crc << 8) & 0xffff) ^ c_tab.crc_msb[crc >> 8] ^ c_tab.crc_lsb[s_od[tid][k]];
-		const uint32_t nib = s_od[tid][nblk - 1] & 15;
-		for (int k = 0; k < 4; k++) {
-			crc ^= ((nib >> k) & 1) << 15;
-			crc = (crc & 0x8000) ? (((crc << 1) ^ 0x1021) & 0xffff) : ((crc << 1) & 0xffff);
+	/* the CRC is linear in the decoded bits: every thread takes the bits i = tid and tid + 256 of both blocks, XORs
+	 * their table vectors, the waves fold theirs (one memory latency + a reduction instead of 36 dependent look-ups) */
+	__shared__ uint32_t s_cpart[4];
+	{
+		uint32_t v = 0;			/* block 0 in the low half, block 1 in the high half */
+#pragma unroll
+		for (int b = 0; b < 2; b++) {
+			if (kind[b] < 0)
+				continue;
+			const uint32_t nbits = 8 * (tgb_nblk(kind[b]) - 1) + 4;
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const uint32_t ib = tid + 256 * h;
+				if (ib < nbits && ((s_od[b][ib >> 3] >> (ib & 7)) & 1))
+					v ^= (uint32_t)c_tab.crc_lin[kind[b]][ib] << (16 * b);
+			}
 		}
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1)
+			v ^= (uint32_t)__shfl_xor((int)v, m, 64);
+		if ((tid & 63) == 0)
+			s_cpart[tid >> 6] = v;
+	}
+	__syncthreads();
+	if (tid < 2 && kind[tid] >= 0) {
+		const uint32_t all = s_cpart[0] ^ s_cpart[1] ^ s_cpart[2] ^ s_cpart[3];
+		const uint32_t crc = ((all >> (16 * tid)) & 0xffff) ^ c_tab.crc_aff[kind[tid]];
 		s_crcv[tid] = crc;
 		s_okv[tid] = (crc == 0x1d0f);
 	}
 	__syncthreads();
+	TGB_STAMP(7);
 	if (SB1_PASS) {
 		if (tid == 0) {
 			const uint8_t *od = s_od[0];
@@ -2137,7 +2235,6 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 			r[TG_REC_BBK + tid] = bit;
 	}
 	if (tid == 0) {
-		r[TG_REC_TYPE] = (uint8_t)type;
 		r[TG_REC_FLAGS] = s_nonbin ? TG_FLAG_NONBINARY : 0;
 		r[TG_REC_CRC_OK] = (uint8_t)s_okv[0];
 		r[TG_REC_CRC_OK + 1] = kind[1] >= 0 ? (uint8_t)s_okv[1] : 0;
@@ -2161,20 +2258,29 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 			*(uint32_t *)(r + TG_REC_SBCODE) = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3u;
 		}
 	}
+	/* the burst type is the record's completion mark: written last, after every thread's stores are visible system
+	 * wide.  A host that holds the records in mapped memory (the channel API's small batches) presets the byte to
+	 * TG_REC_PENDING and polls it instead of paying for a stream synchronise */
+	if (marks)		/* (wave-uniform; on records in device memory the system-wide fence would only cost cache write-backs) */
+		__threadfence_system();
+	__syncthreads();
+	if (tid == 0)
+		*(volatile uint8_t *)(r + TG_REC_TYPE) = (uint8_t)type;
+	TGB_STAMP(8);
 }
 
 extern "C" int tgk_burst(const uint8_t *d_stream, const uint64_t *d_slot_desc, const uint32_t *d_slot_chan,
-			 const uint32_t *d_chan_code, uint32_t nslots, int have_sync, uint32_t *d_sb_ok, uint32_t *d_sb_code,
-			 uint8_t *d_rec, uint32_t *d_maskidx, uint32_t *d_masks, void *stream)
+			 const uint32_t *d_chan_code, uint32_t nslots, uint32_t nchan, int have_sync, uint32_t *d_sb_ok,
+			 uint32_t *d_sb_code, uint8_t *d_rec, uint32_t *d_maskidx, uint32_t *d_masks, int marks, void *stream)
 {
 	if (!nslots)
 		return 0;
 	hipStream_t s = (hipStream_t)stream;
 	if (have_sync)
 		hipLaunchKernelGGL((k_burst<true>), dim3(nslots), dim3(256), 0, s, d_stream, d_slot_desc, d_slot_chan, d_chan_code, nslots,
-				   d_sb_ok, d_sb_code, d_rec, d_maskidx, d_masks);
+				   nchan, d_sb_ok, d_sb_code, d_rec, d_maskidx, d_masks, 0);
 	hipLaunchKernelGGL((k_burst<false>), dim3(nslots), dim3(256), 0, s, d_stream, d_slot_desc, d_slot_chan, d_chan_code, nslots,
-			   d_sb_ok, d_sb_code, d_rec, d_maskidx, d_masks);
+			   nchan, d_sb_ok, d_sb_code, d_rec, d_maskidx, d_masks, marks);
 	return (int)hipGetLastError();
 }
 
@@ -2613,6 +2719,26 @@ static void build_tables(tg_const_tables *t)
 				if (j >= 0 && seq[j])
 					t->sb1_mask[d] |= 1u << p;
 			}
+	}
+	{
+		static const int nblk_of[3] = { 10, 18, 36 };	/* TG_KIND_SB1, _216, _432 */
+		for (int kind = 0; kind < 3; kind++) {
+			const int nbits = 8 * (nblk_of[kind] - 1) + 4;
+			uint16_t c = 0xffff;
+			for (int i = 0; i < nbits; i++)
+				c = tg_crc16_step_bits(c, 0, 1);
+			t->crc_aff[kind] = c;
+			for (int i = 0; i < 288; i++) {
+				uint16_t v = 0;
+				if (i < nbits) {
+					v = tg_crc16_step_bits(0, 1, 1);
+					for (int k = i + 1; k < nbits; k++)
+						v = tg_crc16_step_bits(v, 0, 1);
+				}
+				t->crc_lin[kind][i] = v;
+			}
+		}
+		t->crc_aff[3] = 0;
 	}
 	tg_crc16_make_table(t->crc_lsb);
 	for (int x = 0; x < 256; x++) {

@@ -112,6 +112,7 @@
  */
 #define TG_REC_BYTES      320
 #define TG_REC_TYPE       0
+#define TG_REC_PENDING    0xee	/* never a burst type: a host polling mapped records for completion presets this (k_burst writes the type last) */
 #define TG_REC_FLAGS      1
 #define TG_REC_CRC_OK     2
 #define TG_REC_CRC        4
