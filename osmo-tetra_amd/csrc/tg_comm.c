@@ -12,6 +12,7 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,7 +57,19 @@ static struct {
 	__typeof__(&ncclRecv) recv;
 } rc;
 
+static pthread_mutex_t rc_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int rccl_load_locked(void);
+
 static int rccl_load(void)
+{
+	pthread_mutex_lock(&rc_lock);
+	const int r = rccl_load_locked();
+	pthread_mutex_unlock(&rc_lock);
+	return r;
+}
+
+static int rccl_load_locked(void)
 {
 	if (rc.lib)
 		return TGPU_OK;
