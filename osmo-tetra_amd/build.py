@@ -50,6 +50,8 @@ def build(force=False, verbose=False):
     for s in C_SRCS:
         o = os.path.join(OBJ, s + ".o")
         run(["gcc", "-O3", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"] + inc +
+            os.environ.get("TGPU_CC_FLAGS", "").split() +       # experiment builds of the host code
+
             ["-c", os.path.join(CSRC, s), "-o", o])
         objs.append(o)
     run([hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lpthread", "-ldl"])

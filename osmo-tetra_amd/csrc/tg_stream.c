@@ -26,6 +26,9 @@
 #include <stdlib.h>
 #include <time.h>
 #include <string.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <pthread.h>
 
@@ -122,6 +125,28 @@ static int deliver_slot(struct walk *w, uint64_t off, int type, uint32_t seq, ui
 	} else
 		w->out->noffgrid++;
 	return 0;
+}
+
+/* bit j set: classification word c[j] (flags EARLY21 / NONBINARY included) is none of the three "delivered" words */
+static inline uint32_t not_plain32(const uint32_t *c, uint32_t A, uint32_t B, uint32_t C)
+{
+#if defined(__SSE2__)
+	const __m128i m = _mm_set1_epi32(0x03ffffff), a = _mm_set1_epi32((int)A), b = _mm_set1_epi32((int)B), cc = _mm_set1_epi32((int)C);
+	uint32_t r = 0;
+	for (int q = 0; q < 8; q++) {
+		const __m128i v = _mm_and_si128(_mm_loadu_si128((const __m128i *)(c + 4 * q)), m);
+		const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi32(v, a), _mm_cmpeq_epi32(v, b)), _mm_cmpeq_epi32(v, cc));
+		r |= (uint32_t)(_mm_movemask_ps(_mm_castsi128_ps(ok)) ^ 0xf) << (4 * q);
+	}
+	return r;
+#else
+	uint32_t r = 0;
+	for (int j = 0; j < 32; j++) {
+		const uint32_t v = c[j] & 0x03ffffffu;
+		r |= ((uint32_t)(v != A) & (uint32_t)(v != B) & (uint32_t)(v != C)) << j;
+	}
+	return r;
+#endif
 }
 
 static const uint8_t tsq_y38[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
@@ -321,7 +346,15 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 	int state = RX_S_UNLOCKED;
 	uint64_t nfs = 0;
 
+#ifdef TG_WALK_TIMING
+	static unsigned long long c_unl, c_blk, c_gen, n_walk;
+	unsigned long long tq = __builtin_ia32_rdtsc();
+#define TQ(acc) do { const unsigned long long t_ = __builtin_ia32_rdtsc(); acc += t_ - tq; tq = t_; } while (0)
+#else
+#define TQ(acc) do { } while (0)
+#endif
 	while (k < w.ncalls) {
+		TQ(c_gen);
 		if (state == RX_S_UNLOCKED) {
 			/* calls k+1, k+2, ...: buffer = [b, F(k)), b = max(bs, F(k) - 4096).  The reference
 			 * re-scans the whole buffer on every call; the outcome only depends on where SYNC
@@ -389,6 +422,7 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 			nfs = found_p + 296;
 			k = found_k;
 			state = RX_S_KNOW_FSTART;
+			TQ(c_unl);
 			continue;
 		}
 		if (state == RX_S_KNOW_FSTART) {
@@ -424,29 +458,53 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 					       C = TETRA_TRAIN_NORM_2 | TG_NORM_TRAIN_OFF << 8;
 				for (;;) {
 				const uint64_t gi_before = gi;
-				while (w.grid_bits && !(gi & 31) && gi + 32 <= ncls && bs + 32ull * TG_SLOT_BITS <= len &&
-				       ((bs + TG_SLOT_BITS + chunk - 1) >> w.cshift) > k) {
-					uint32_t bad = 0;
-					for (int j = 0; j < 32; j++) {
-						const uint32_t v = cls[gi + j] & 0x03ffffffu;
-						bad |= (uint32_t)(v != A) & (uint32_t)(v != B) & (uint32_t)(v != C);
+				/* bitmap mode: up to the end of the current bitmap word at a time (a whole word in the steady state,
+				 * the rest of one after a re-lock) while nothing is backlogged (k < the call that completes the first
+				 * slot: every slot is then consumed by "its" call, k ends at the last one's).  The leading run of
+				 * slots whose classification words say "delivered" goes in closed form: its bits, the ordinals,
+				 * the call that consumes the last of them; the first other slot is left to the general path. */
+				while (w.grid_bits && gi < ncls && ((bs + TG_SLOT_BITS + chunk - 1) >> w.cshift) > k) {
+					uint32_t m = 32 - (uint32_t)(gi & 31);
+					if (m > ncls - gi)
+						m = (uint32_t)(ncls - gi);
+					const uint64_t room = (len - bs) / TG_SLOT_BITS;
+					if (m > room)
+						m = (uint32_t)room;
+					uint32_t bad;
+					if (ysum)	/* the re-lock search reads the SYNC summaries every hundred slots or so: keep them streaming */
+						__builtin_prefetch(ysum + gi + 512);
+					if (gi + 32 <= ncls) {
+						bad = not_plain32(cls + gi, A, B, C);
+						if (m < 32)
+							bad &= (1u << m) - 1u;
+					} else {
+						bad = 0;
+						for (uint32_t j = 0; j < m; j++) {
+							const uint32_t v = cls[gi + j] & 0x03ffffffu;
+							bad |= ((uint32_t)(v != A) & (uint32_t)(v != B) & (uint32_t)(v != C)) << j;
+						}
 					}
-					const uint64_t klast = (bs + 32ull * TG_SLOT_BITS + chunk - 1) >> w.cshift;
-					if (bad || klast > w.ncalls)
+					uint32_t g = bad ? (uint32_t)__builtin_ctz(bad) : m;
+					while (g && ((bs + (uint64_t)g * TG_SLOT_BITS + chunk - 1) >> w.cshift) > w.ncalls)
+						g--;		/* (the stream's last calls) */
+					if (!g)
 						break;
-					w.grid_bits[gi >> 5] = 0xffffffffu;
-					out->nslots += 32;
-					k = klast;
-					seq += 32;
+					w.grid_bits[gi >> 5] |= (g == 32 ? 0xffffffffu : ((1u << g) - 1u)) << (gi & 31);
+					out->nslots += g;
+					k = (bs + (uint64_t)g * TG_SLOT_BITS + chunk - 1) >> w.cshift;
+					seq += g;
 					tn_adds = 0;
-					bs += 32ull * TG_SLOT_BITS;
-					nfs += 32ull * TG_SLOT_BITS;
-					gi += 32;
+					bs += (uint64_t)g * TG_SLOT_BITS;
+					nfs += (uint64_t)g * TG_SLOT_BITS;
+					gi += g;
+					if (g < m)
+						break;		/* the next slot is not a plain delivery */
 				}
+				/* one slot at a time: a backlog (the bursts already buffered when lock was found are consumed one per
+				 * call), and the slot-table form */
 				while (gi < ncls && bs + TG_SLOT_BITS <= len) {
 					const uint32_t v = cls[gi] & 0x03ffffffu;	/* type, offset, TG_CLS_EARLY21, TG_CLS_NONBINARY */
-					if (v != (TETRA_TRAIN_SYNC | TG_SYNC_TRAIN_OFF << 8) && v != (TETRA_TRAIN_NORM_1 | TG_NORM_TRAIN_OFF << 8) &&
-					    v != (TETRA_TRAIN_NORM_2 | TG_NORM_TRAIN_OFF << 8))
+					if (v != A && v != B && v != C)
 						break;
 					const uint64_t kc = (bs + TG_SLOT_BITS + chunk - 1) >> w.cshift;
 					const uint64_t kj = kc > k ? kc : k + 1;
@@ -464,13 +522,14 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 					bs += TG_SLOT_BITS;
 					nfs += TG_SLOT_BITS;
 					gi++;
-					if (w.grid_bits && !(gi & 31))
-						break;	/* aligned again: back to the 32-slot steps */
+					if (w.grid_bits && ((bs + TG_SLOT_BITS + chunk - 1) >> w.cshift) > k)
+						break;	/* the backlog is gone: back to the closed form */
 				}
 				if (gi == gi_before || !w.grid_bits)
 					break;
 				}
 				grid_for = bs;
+				TQ(c_blk);
 				if (bs != bs0)
 					continue;
 			}
@@ -567,6 +626,12 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 			gi++;
 		}
 	}
+#ifdef TG_WALK_TIMING
+	TQ(c_gen);
+	if (++n_walk % 512 == 0)
+		fprintf(stderr, "walk cycles per call: unlocked %.0f  block path %.0f  general %.0f (events %zu)\n", (double)c_unl / n_walk,
+			(double)c_blk / n_walk, (double)c_gen / n_walk, (size_t)out->nevents);
+#endif
 	out->final_state = state;
 	out->tail_tn_adds = tn_adds;
 	out->burst_seq = seq;
@@ -940,6 +1005,10 @@ int tgpu_sync_multi_finish(struct tgpu_sync_multi *st, uint32_t flags, unsigned 
 	struct multi_job job = { st, cls, ysum, flags, out, 0, 0 };
 	if (nthreads > st->nchan)
 		nthreads = st->nchan;
+#ifdef TG_WALK_TIMING
+	struct timespec ta, tb;
+	clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ta);
+#endif
 	if (nthreads <= 1)
 		multi_worker(&job);
 	else {
@@ -954,6 +1023,15 @@ int tgpu_sync_multi_finish(struct tgpu_sync_multi *st, uint32_t flags, unsigned 
 		for (unsigned int i = 0; i < started; i++)
 			pthread_join(th[i], NULL);
 	}
+#ifdef TG_WALK_TIMING
+	{
+		static double acc; static unsigned cnt;
+		clock_gettime(CLOCK_THREAD_CPUTIME_ID, &tb);
+		acc += (tb.tv_sec - ta.tv_sec) * 1e3 + (tb.tv_nsec - ta.tv_nsec) * 1e-6;
+		if (++cnt % 64 == 0)
+			fprintf(stderr, "walks: %.3f ms cpu per finish (mean over %u)\n", acc / cnt, cnt);
+	}
+#endif
 	if (job.rc)
 		return job.rc;
 	if (!st->ngrid)
