@@ -326,7 +326,7 @@ int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packe
 	if (ngrid > p->max_slots)
 		return TGPU_ECAPACITY;
 	if (!p->d_grid) {
-		hipError_t e = hipMalloc((void **)&p->d_grid, (size_t)p->max_slots * 6 + 16);
+		hipError_t e = hipMalloc((void **)&p->d_grid, TG_GRID_BYTES(p->max_slots));
 		if (e != hipSuccess)
 			return (int)e;
 	}
@@ -335,7 +335,7 @@ int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packe
 		if (e != hipSuccess)
 			return (int)e;
 	}
-	if (!p->h_grid && hipHostMalloc((void **)&p->h_grid, (size_t)p->max_slots * 6 + 16, hipHostMallocDefault) != hipSuccess) {
+	if (!p->h_grid && hipHostMalloc((void **)&p->h_grid, TG_GRID_BYTES(p->max_slots), hipHostMallocDefault) != hipSuccess) {
 		p->h_grid = NULL;
 		return TGPU_ENOMEM;
 	}
@@ -346,6 +346,14 @@ int tgpi_plan_grid_begin(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_packe
 	*h_cls = p->h_grid;
 	*h_ysum = (uint16_t *)(p->h_grid + ngrid);
 	return TGPU_OK;
+}
+
+/* the "plain delivery" bitmap of the grid (k_cls_plain): behind the words and summaries on both sides, so that one
+ * copy of TG_GRID_COPY_BYTES(ngrid) brings all three to the host */
+void tgpi_plan_grid_plain(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_plain, uint32_t **h_plain)
+{
+	*d_plain = p->d_grid + TG_GRID_PLAIN_WORD(ngrid);
+	*h_plain = p->h_grid + TG_GRID_PLAIN_WORD(ngrid);
 }
 
 uint32_t *tgpi_plan_defer_scratch(struct tgpu_plan *p)

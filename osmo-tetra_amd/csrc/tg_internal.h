@@ -88,6 +88,13 @@ int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity);
 /* make the engine's device the calling thread's current HIP device (every allocating / launching entry point does) */
 struct tgpu_engine;
 int tgpi_engine_bind(const struct tgpu_engine *eng);
+/* stream-mode grid buffer of a plan: ngrid classification words, ngrid 16-bit SYNC summaries, then (dword aligned) one
+ * bit per slot "plain delivery" */
+#define TG_GRID_PLAIN_WORD(n) (((size_t)(n) * 6 + 3) / 4)
+#define TG_GRID_COPY_BYTES(n) ((TG_GRID_PLAIN_WORD(n) + ((size_t)(n) + 31) / 32) * 4)
+#define TG_GRID_BYTES(n)      (TG_GRID_COPY_BYTES(n) + 16)
+void tgpi_plan_grid_plain(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_plain, uint32_t **h_plain);
+int tgk_cls_plain(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, void *stream);
 int tgpi_plan_last_burst(const struct tgpu_plan *p);
 void tgpi_plan_set_marks(struct tgpu_plan *p, int on);	/* the caller polls completion marks in mapped records (tg_sync.c) */	/* the last execute wrote completion marks (k_burst) */
 

@@ -2269,6 +2269,31 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	TGB_STAMP(8);
 }
 
+/* one bit per grid slot: the classification word alone says "delivered" (a training sequence of the right type at its
+ * nominal offset, no EARLY21 / NONBINARY flag) -- what the host walk's steady state tests, 32 slots to a word */
+__global__ __launch_bounds__(256)
+void k_cls_plain(const uint32_t *__restrict__ cls, uint32_t n, uint32_t *__restrict__ plain)
+{
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t v = i < n ? cls[i] & 0x03ffffffu : 0xffu;
+	const bool ok = v == (TG_BURST_SYNC | TG_SYNC_TRAIN_OFF << 8) || v == (TG_BURST_NORM_1 | TG_NORM_TRAIN_OFF << 8) ||
+			v == (TG_BURST_NORM_2 | TG_NORM_TRAIN_OFF << 8);
+	const unsigned long long b = __ballot(ok);
+	const uint32_t lane = threadIdx.x & 63, w = i >> 5;
+	if (lane == 0 && 32 * w < n)
+		plain[w] = (uint32_t)b;
+	if (lane == 32 && 32 * w < n)
+		plain[w] = (uint32_t)(b >> 32);
+}
+
+extern "C" int tgk_cls_plain(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, void *stream)
+{
+	if (!n)
+		return 0;
+	hipLaunchKernelGGL(k_cls_plain, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_cls, n, d_plain);
+	return (int)hipGetLastError();
+}
+
 extern "C" int tgk_burst(const uint8_t *d_stream, const uint64_t *d_slot_desc, const uint32_t *d_slot_chan,
 			 const uint32_t *d_chan_code, uint32_t nslots, uint32_t nchan, int have_sync, uint32_t *d_sb_ok,
 			 uint32_t *d_sb_code, uint8_t *d_rec, uint32_t *d_maskidx, uint32_t *d_masks, int marks, void *stream)

@@ -308,8 +308,18 @@ static int walk_per_call(struct walk *w, uint32_t flags, uint64_t anchor)
 	return TGPU_OK;
 }
 
+static int sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor, const uint32_t *cls,
+		     const uint16_t *ysum, const uint32_t *plain, uint32_t ncls, uint32_t flags, struct tgpu_sync_result *out);
+
 int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor,
 		   const uint32_t *cls, const uint16_t *ysum, uint32_t ncls, uint32_t flags, struct tgpu_sync_result *out)
+{
+	return sync_walk(h_stream, len, chunk, anchor, cls, ysum, NULL, ncls, flags, out);
+}
+
+/* plain (optional): k_cls_plain's bitmap of the same grid -- bit i = word i is one of the three "delivered" words */
+static int sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor, const uint32_t *cls,
+		     const uint16_t *ysum, const uint32_t *plain, uint32_t ncls, uint32_t flags, struct tgpu_sync_result *out)
 {
 	/* chunk <= 510: a call never feeds more than a burst consumes, so the 4096-byte buffer can only
 	 * overflow (and drop data) while UNLOCKED -- which is modelled.  tetra-rx.c uses 64. */
@@ -340,7 +350,7 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 	uint64_t bs = 0;	/* bitbuf_start_bitnum */
 	uint64_t k = 0;		/* index of the last call that has run */
 	uint64_t kceil = 0, fceil = 0, fceil_for = UINT64_MAX;
-	uint64_t gi = 0, grid_for = UINT64_MAX;
+	uint64_t gi = 0, grid_for = UINT64_MAX, gfit = UINT64_MAX;
 	int ongrid = 0;
 	uint32_t seq = 0, tn_adds = 0;
 	int state = RX_S_UNLOCKED;
@@ -456,6 +466,11 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 				 * classification words say "delivered": one word of the bitmap, closed-form ordinals */
 				const uint32_t A = TETRA_TRAIN_SYNC | TG_SYNC_TRAIN_OFF << 8, B = TETRA_TRAIN_NORM_1 | TG_NORM_TRAIN_OFF << 8,
 					       C = TETRA_TRAIN_NORM_2 | TG_NORM_TRAIN_OFF << 8;
+				if (gfit == UINT64_MAX) {	/* once per walk: the grid slots that fit into the stream */
+					gfit = len >= anchor ? (len - anchor) / TG_SLOT_BITS : 0;
+					if (gfit > ncls)
+						gfit = ncls;
+				}
 				for (;;) {
 				const uint64_t gi_before = gi;
 				/* bitmap mode: up to the end of the current bitmap word at a time (a whole word in the steady state,
@@ -465,15 +480,20 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 				 * the call that consumes the last of them; the first other slot is left to the general path. */
 				while (w.grid_bits && gi < ncls && ((bs + TG_SLOT_BITS + chunk - 1) >> w.cshift) > k) {
 					uint32_t m = 32 - (uint32_t)(gi & 31);
-					if (m > ncls - gi)
-						m = (uint32_t)(ncls - gi);
-					const uint64_t room = (len - bs) / TG_SLOT_BITS;
-					if (m > room)
-						m = (uint32_t)room;
+					if (gi >= gfit)
+						break;
+					if (m > gfit - gi)
+						m = (uint32_t)(gfit - gi);	/* grid slots that lie inside the stream (and have a word) */
 					uint32_t bad;
 					if (ysum)	/* the re-lock search reads the SYNC summaries every hundred slots or so: keep them streaming */
 						__builtin_prefetch(ysum + gi + 512);
-					if (gi + 32 <= ncls) {
+					if (plain)	/* (and with the bitmap the words themselves are only read at the exceptions) */
+						__builtin_prefetch(cls + gi + 256);
+					if (plain) {
+						bad = ~plain[gi >> 5] >> (gi & 31);
+						if (m < 32)
+							bad &= (1u << m) - 1u;
+					} else if (gi + 32 <= ncls) {
 						bad = not_plain32(cls + gi, A, B, C);
 						if (m < 32)
 							bad &= (1u << m) - 1u;
@@ -782,8 +802,13 @@ int tgpu_sync_stream_grid_begin(struct tgpu_engine *eng, struct tgpu_plan *plan,
 	if ((rc = tgpi_plan_grid_begin(plan, ncls, &d_packed, &d_cls, &d_ysum, &cls, &ysum)))
 		return rc;
 	rc = tgk_front_stream(d_stream, anchor, len, ncls, chunk, d_packed, d_cls, d_ysum, tgpi_plan_defer_scratch(plan), stream, NULL);
-	if (!rc)	/* words and summaries are adjacent on both sides: one copy into the plan's pinned mirror */
-		rc = (int)hipMemcpyAsync(cls, d_cls, (size_t)ncls * 6, hipMemcpyDeviceToHost, (hipStream_t)stream);
+	if (!rc) {
+		uint32_t *d_plain, *h_plain;
+		tgpi_plan_grid_plain(plan, ncls, &d_plain, &h_plain);
+		rc = tgk_cls_plain(d_cls, ncls, d_plain, stream);
+	}
+	if (!rc)	/* words, summaries and the bitmap are adjacent on both sides: one copy into the plan's pinned mirror */
+		rc = (int)hipMemcpyAsync(cls, d_cls, TG_GRID_COPY_BYTES(ncls), hipMemcpyDeviceToHost, (hipStream_t)stream);
 	out->ngrid = ncls;
 	return rc;
 }
@@ -811,8 +836,11 @@ int tgpu_sync_stream_grid_finish(struct tgpu_engine *eng, struct tgpu_plan *plan
 	const double t0 = now_ms();
 	rc = (int)hipStreamSynchronize((hipStream_t)stream);
 	const double t1 = now_ms();
-	if (!rc)
-		rc = tgpu_sync_walk(h_stream, len, chunk, anchor, cls, ysum, ncls, flags | TGPU_SYNC_GRID, out);
+	if (!rc) {
+		uint32_t *d_plain, *h_plain;
+		tgpi_plan_grid_plain(plan, ncls, &d_plain, &h_plain);
+		rc = sync_walk(h_stream, len, chunk, anchor, cls, ysum, h_plain, ncls, flags | TGPU_SYNC_GRID, out);
+	}
 	out->anchor = anchor;
 	const double t2 = now_ms();
 	if (!rc && !out->noffgrid)
@@ -943,8 +971,13 @@ int tgpu_sync_multi_begin(struct tgpu_engine *eng, struct tgpu_plan *plan, uint3
 		if (!rc)
 			rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
 						    tgpi_plan_defer_scratch(plan), stream, NULL);
+		if (!rc) {
+			uint32_t *d_plain, *h_plain;
+			tgpi_plan_grid_plain(plan, st->ngrid, &d_plain, &h_plain);
+			rc = tgk_cls_plain(d_cls, st->ngrid, d_plain, stream);
+		}
 		if (!rc)
-			rc = (int)hipMemcpyAsync(cls, d_cls, (size_t)st->ngrid * 6, hipMemcpyDeviceToHost, (hipStream_t)stream);
+			rc = (int)hipMemcpyAsync(cls, d_cls, TG_GRID_COPY_BYTES(st->ngrid), hipMemcpyDeviceToHost, (hipStream_t)stream);
 	}
 	if (rc) {
 		tgpu_sync_multi_free(st);
@@ -958,6 +991,7 @@ struct multi_job {
 	struct tgpu_sync_multi *st;
 	const uint32_t *cls;
 	const uint16_t *ysum;
+	const uint32_t *plain;
 	uint32_t flags;
 	struct tgpu_sync_result *out;
 	volatile uint32_t next;
@@ -975,8 +1009,8 @@ static void *multi_worker(void *arg)
 		const struct tg_chan_ent *e = &j->st->ent[c];
 		int rc;
 		if (e->ncls)
-			rc = tgpu_sync_walk(ch->h_stream, ch->len, j->st->chunk, e->anchor, j->cls + e->gbase, j->ysum + e->gbase,
-					    e->ncls, j->flags | TGPU_SYNC_GRID, &j->out[c]);
+			rc = sync_walk(ch->h_stream, ch->len, j->st->chunk, e->anchor, j->cls + e->gbase, j->ysum + e->gbase,
+				       j->plain + e->gbase / 32, e->ncls, j->flags | TGPU_SYNC_GRID, &j->out[c]);	/* (grids start at multiples of 32) */
 		else {	/* never locks: nothing of it is in the grid */
 			rc = tgpu_sync_walk(ch->h_stream, ch->len, j->st->chunk, e->anchor, NULL, NULL, 0, j->flags & ~TGPU_SYNC_GRID,
 					    &j->out[c]);
@@ -1002,7 +1036,10 @@ int tgpu_sync_multi_finish(struct tgpu_sync_multi *st, uint32_t flags, unsigned 
 	uint16_t *d_ysum, *ysum = NULL;
 	if (st->ngrid && (rc = tgpi_plan_grid_begin(st->plan, st->ngrid, &d_packed, &d_cls, &d_ysum, &cls, &ysum)))
 		return rc;
-	struct multi_job job = { st, cls, ysum, flags, out, 0, 0 };
+	uint32_t *d_plain_, *h_plain = NULL;
+	if (st->ngrid)
+		tgpi_plan_grid_plain(st->plan, st->ngrid, &d_plain_, &h_plain);
+	struct multi_job job = { st, cls, ysum, h_plain, flags, out, 0, 0 };
 	if (nthreads > st->nchan)
 		nthreads = st->nchan;
 #ifdef TG_WALK_TIMING
