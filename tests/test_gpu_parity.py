@@ -1014,6 +1014,55 @@ def test_rm3014_decode_flag(T, eng):
     bplan.close()
 
 
+def test_walk_bitmap_steady_state_equals_the_general_path(T, eng):
+    """the walk's closed-form steady state on k_cls_plain's bitmap (no per-burst events) against its own general path
+    (per-burst events on, every slot on its own) on 40 damaged streams of 200..4000 slots: lock-loss / re-lock events,
+    delivered grid slots, counters and final state; chunk sizes 32 / 64 / 128; the oracle receiver on the shorter ones"""
+    import torch
+    from test_stream_sync_cpu import SEQ_Y, SEQ_N
+    rng = np.random.default_rng(20260928)
+    hs = torch.cuda.current_stream().cuda_stream
+    nloss = 0
+    for trial in range(40):
+        n = int(rng.integers(200, 4000))
+        s, _ = _mix_stream(T, n, 5000 + trial, ber=0.0)
+        s = s.copy()
+        for _ in range(int(rng.integers(0, 12))):              # extra damage on top of the 1 % damaged training sequences
+            kind = int(rng.integers(0, 6))
+            p = int(rng.integers(0, len(s) - 300))
+            if kind == 0:
+                s[p] ^= 1
+            elif kind == 1:
+                s = np.concatenate([s[:p], rng.integers(0, 2, int(rng.integers(1, 40))).astype(np.uint8), s[p:]])
+            elif kind == 2:
+                s = np.concatenate([s[:p], s[p + int(rng.integers(1, 40)):]])
+            elif kind == 3:
+                s[p:p + 38] = SEQ_Y
+            elif kind == 4:
+                s[p:p + 22] = SEQ_N
+            else:
+                s[p:p + int(rng.integers(1, 2000))] = 0
+        s = np.ascontiguousarray(s)
+        chunk = int(rng.choice([32, 64, 64, 128]))
+        d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+        pa, pb = T.Plan(eng, len(s) // 510 + 8, 1), T.Plan(eng, len(s) // 510 + 8, 1)
+        a = T.sync_stream_grid(eng, pa, s, d.data_ptr(), chunk, hs, burst_events=False)
+        b = T.sync_stream_grid(eng, pb, s, d.data_ptr(), chunk, hs, burst_events=True)
+        evb = [e for e in b["events"] if e[0] != 2]
+        assert a["events"] == evb, trial
+        for k in ("nslots", "ngrid", "noffgrid", "anchor", "final_state", "burst_seq", "tail_tn_adds"):
+            assert a[k] == b[k], (trial, k)
+        if a["ngrid"] and not a["noffgrid"]:
+            assert (np.asarray(a["grid_bits"]) == np.asarray(b["grid_bits"])).all(), trial
+        if n < 1200:
+            _, wev = O.run_rx(s, chunk=chunk)
+            assert b["events"] == wev, trial
+        nloss += sum(1 for e in evb if e[0] in (3, 5))
+        pa.close()
+        pb.close()
+    assert nloss > 300
+
+
 def test_fuzz_damaged_streams_end_to_end(T, eng):
     """random streams with random damage (bit flips, inserted / deleted bytes, spurious training sequences, zeroed
     stretches, payload noise): channel API (records, events, TDMA time, codes) and the stream-mode plan paths
