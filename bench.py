@@ -5,21 +5,25 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Default workload (config.workload) = BASELINE.json's metric: the SB+NDB mix through the burst-sync front end
-(config 3's composition): per GPU a 1,000,000-slot recorded channel, frames of 8 slots
-[SB, N1, N2, N1, N2, N1, N2, N1], cell scrambling code learnt from SB1, 1 % of the slots with a damaged training
-sequence (dropped burst, loss of lock, re-lock), 1 bit per byte, resident in HBM.  One step = one pass of the whole
-path over that recording: GPU training-sequence search + demux/de-interleave of every grid slot, the reference's
-synchroniser walk (host, tetra_burst_sync_in() semantics at 64-byte feeds), device-built lists, SB1 -> code fill ->
-masks -> both trellis kernels; records stay in HBM.  value counts DELIVERED bursts (what tetra_burst_rx_cb() would
-have been handed), not grid slots.  Recordings are independent units (the reference runs one process per channel):
-W host threads each walk their own recordings, software-pipelined against the GPU.
+(configs[2]'s composition in configs[3]'s layout): per GPU 8 recorded channels of 125,000 slots each (own cell each),
+frames of 8 slots [SB, N1, N2, N1, N2, N1, N2, N1], cell scrambling code learnt from SB1, 1 % of the slots with a
+damaged training sequence (dropped burst, loss of lock, re-lock), 1 bit per byte, resident in HBM.  One step = one
+pass of the whole path over all of a GPU's channels as ONE batch: GPU training-sequence search + demux/de-interleave
+of every grid slot, the reference's synchroniser walk per channel (host, tetra_burst_sync_in() semantics at 64-byte
+feeds), device-built lists, SB1 -> code fill -> masks -> both trellis kernels; records stay in HBM.  value counts
+DELIVERED bursts (what tetra_burst_rx_cb() would have been handed), not grid slots.  W host threads per GPU each
+pipeline their own steps against the GPU.
 
 The JSON line also carries
   roofline     : the dominant kernel's algorithmic bytes / its HIP-event duration vs HBM peak (+ PMC traffic)
   cpu_baseline : the oracle's receiver (CPU restatement of tetra-rx's path) on the same stream, 64-byte feeds,
-                 one thread, with the Viterbi the reference really runs (libosmocore's accelerated form) and the
-                 generic one beside it
+                 one thread, with the Viterbi the reference really runs (libosmocore's accelerated form), the
+                 generic one beside it, and the same receiver on every usable host core at once (all_cores)
+  breakdown_ms : host CPU per step (process_time), the per-kernel HIP-event durations
   config2      : BASELINE configs[1] (1 M aligned NDB bursts, no sync front end) as a secondary measurement
+  N > 1        : decode_only and gathered (every step's 40-byte wire records to rank 0 through the library's
+                 tgpu_comm_gather, RCCL, overlapped; under a watchdog); value = the gathered rate
+--workload config5 | conv | config2: the other BASELINE configs / the generic trellis (own roofline, cpu_baseline).
 """
 import argparse
 import json
