@@ -230,7 +230,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     eng = T.Engine(local)
     d_base = torch.from_numpy(buf).cuda()
     cap = sum(len(st) // 510 + 32 for st in streams)
-    W = args.sync_threads if args.sync_threads > 0 else max(1, min(8, host_threads_default() // max(1, world)))
+    cores_per_rank = max(1, host_threads_default() // max(1, world))
+    W = args.sync_threads if args.sync_threads > 0 else max(1, min(8, cores_per_rank))
+    if args.sync_threads <= 0 and args.blocking_sync < 0 and cores_per_rank <= 3:
+        # few cores per GPU: host waits sleep instead of spinning (hipDeviceScheduleBlockingSync, set in main) and
+        # twice as many threads as cores keep the GPU fed while walks run (tools/sweep_cores2.sh: 2 cores, 0.66 -> 0.62 ms)
+        W = 2 * cores_per_rank
     W = max(1, min(W, args.steps))
     gather = world > 1 or args.force_gather
     nccl = args.backend == "nccl"
@@ -894,8 +899,9 @@ def main():
                     help="mix (default, = config3: the metric's workload): SB+NDB recordings through the GPU burst-sync front end, "
                          "1%% damaged training sequences; config2: aligned NDB slots, no front end; config5: float phases -> "
                          "soft-decision decode; conv: the generic trellis kernel")
-    ap.add_argument("--blocking-sync", type=int, default=0,
-                    help="1: hipDeviceScheduleBlockingSync (host waits sleep instead of spinning)")
+    ap.add_argument("--blocking-sync", type=int, default=-1,
+                    help="1: hipDeviceScheduleBlockingSync (host waits sleep instead of spinning); 0: spin; "
+                         "-1 (default): blocking only when a rank has three cores or fewer")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the exchange phase with a single rank too (exercises the RCCL path on a 1-GPU box)")
     ap.add_argument("--torch-gather", action="store_true",
@@ -922,7 +928,8 @@ def main():
     if args.backend == "gloo":
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
-    if args.blocking_sync:
+    starved = max(1, host_threads_default() // max(1, world)) <= 3
+    if args.blocking_sync > 0 or (args.blocking_sync < 0 and starved and args.sync_threads <= 0):
         import ctypes
         rc_ = ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(4)     # hipDeviceScheduleBlockingSync
         if rc_:
