@@ -632,6 +632,12 @@ int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_
 int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor,
 		   const uint32_t *cls, const uint16_t *ysum, uint32_t ncls, uint32_t flags,
 		   struct tgpu_sync_result *out);
+/* the same walk with the stream-mode kernels' third output (k_cls_plain, what the grid / multi-channel calls use
+ * internally): plain = one bit per grid slot, bit i set iff (cls[i] & 0x03ffffff) is a training sequence of type
+ * SYNC / NORM_1 / NORM_2 at its nominal offset (214 / 244 / 244) with no flag -- the steady state then reads 32 slots
+ * per word of it.  plain == NULL: tgpu_sync_walk(). */
+int tgpu_sync_walk_plain(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor, const uint32_t *cls,
+			 const uint16_t *ysum, const uint32_t *plain, uint32_t ncls, uint32_t flags, struct tgpu_sync_result *out);
 
 /* ------------------------------------------------------------------------- */
 /* 3. synthetic downlink generator (TX side of the same chain; host, multi-threaded) */

@@ -739,9 +739,17 @@ class GridSync:
         return out
 
 
-def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None, grid=False, per_call=False):
-    """host half of the stream synchroniser (tgpu_sync_walk); cls=None: every slot settled on the bytes,
-    ysum=None: re-lock searches scan the bytes"""
+def cls_plain_bits(cls):
+    """numpy statement of k_cls_plain: one bit per classification word, set iff the word alone says 'delivered' """
+    v = np.asarray(cls, np.uint32) & 0x03FFFFFF
+    ok = (v == (3 | 214 << 8)) | (v == (0 | 244 << 8)) | (v == (1 | 244 << 8))
+    pad = np.zeros((-len(ok)) % 32, bool)
+    return np.packbits(np.concatenate([ok, pad]).reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).reshape(-1)
+
+
+def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None, grid=False, per_call=False, plain=None):
+    """host half of the stream synchroniser (tgpu_sync_walk / tgpu_sync_walk_plain); cls=None: every slot settled on
+    the bytes, ysum=None: re-lock searches scan the bytes, plain: k_cls_plain's bitmap (True: computed here)"""
     stream = _np_u8(stream)
     res = SyncResult()
     if cls is not None:
@@ -749,11 +757,20 @@ def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None
     if ysum is not None:
         ysum = np.ascontiguousarray(ysum, np.uint16)
         assert cls is not None and len(ysum) == len(cls)
+    if plain is True:
+        plain = cls_plain_bits(cls)
+    flags = (0 if burst_events else 1) | (2 if grid else 0) | (4 if per_call else 0)
+    if plain is not None:
+        plain = np.ascontiguousarray(plain, np.uint32)
+        assert cls is not None and len(plain) * 32 >= len(cls)
+        _chk(lib().tgpu_sync_walk_plain(stream.ctypes.data_as(u8p), len(stream), chunk, anchor, cls.ctypes.data_as(u32p),
+                                        ysum.ctypes.data_as(u16p) if ysum is not None else None, plain.ctypes.data_as(u32p),
+                                        len(cls), flags, C.byref(res)), "tgpu_sync_walk_plain")
+        return _sync_result_to_py(res)
     _chk(lib().tgpu_sync_walk(stream.ctypes.data_as(u8p), len(stream), chunk, anchor,
                               cls.ctypes.data_as(u32p) if cls is not None else None,
                               ysum.ctypes.data_as(u16p) if ysum is not None else None,
-                              len(cls) if cls is not None else 0, (0 if burst_events else 1) | (2 if grid else 0) | (4 if per_call else 0),
-                              C.byref(res)), "tgpu_sync_walk")
+                              len(cls) if cls is not None else 0, flags, C.byref(res)), "tgpu_sync_walk")
     return _sync_result_to_py(res)
 
 

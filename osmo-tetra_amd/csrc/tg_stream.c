@@ -317,6 +317,12 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 	return sync_walk(h_stream, len, chunk, anchor, cls, ysum, NULL, ncls, flags, out);
 }
 
+int tgpu_sync_walk_plain(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor, const uint32_t *cls,
+			 const uint16_t *ysum, const uint32_t *plain, uint32_t ncls, uint32_t flags, struct tgpu_sync_result *out)
+{
+	return sync_walk(h_stream, len, chunk, anchor, cls, ysum, plain, ncls, flags, out);
+}
+
 /* plain (optional): k_cls_plain's bitmap of the same grid -- bit i = word i is one of the three "delivered" words */
 static int sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor, const uint32_t *cls,
 		     const uint16_t *ysum, const uint32_t *plain, uint32_t ncls, uint32_t flags, struct tgpu_sync_result *out)

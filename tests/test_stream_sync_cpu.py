@@ -126,8 +126,13 @@ def check(stream, chunk=64, with_cls=True):
         assert res5["events"] == quiet and res5["slots"] == res["slots"]
         res6 = T.sync_walk(stream, chunk=chunk, anchor=anchor, cls=cls, ysum=emul_ysum(stream, anchor), burst_events=False, grid=True)
         assert res6["events"] == quiet and T.grid_indices(res6).tolist() == on and res6["noffgrid"] == res4["noffgrid"]
+        # ... and with k_cls_plain's bitmap (numpy statement) its steady state reads 32 slots per word of that
+        res7 = T.sync_walk(stream, chunk=chunk, anchor=anchor, cls=cls, ysum=emul_ysum(stream, anchor), burst_events=False, grid=True,
+                           plain=True)
+        assert res7["events"] == quiet and T.grid_indices(res7).tolist() == on and res7["noffgrid"] == res4["noffgrid"]
+        assert res7["nslots"] == res6["nslots"]
         for k in ("final_state", "tail_tn_adds", "burst_seq"):
-            assert res5[k] == res[k] and res6[k] == res[k] and res4[k] == res[k]
+            assert res5[k] == res[k] and res6[k] == res[k] and res4[k] == res[k] and res7[k] == res[k]
     return res
 
 
