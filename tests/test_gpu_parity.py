@@ -1801,6 +1801,57 @@ def test_config4_channels_in_one_grid_batch(T, eng):
     plan.close()
 
 
+def test_burst_kernel_long_runs_and_many_channels(T, eng, monkeypatch):
+    """k_burst's look-back for the scrambling code beyond its 256-slot LDS window (one SYNC slot, then 899 NORM slots
+    of the same channel: the code must still come from slot 0), a failed SB1 far back that must be skipped, and 70
+    channels with carry-in codes (channels >= 64 take the code from memory): records and final codes == the batch
+    kernels'"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    cell = (901, 77, 9)
+    code = O.scramb_get_init(*cell)
+    cases = []
+    # (a) one good SYNC slot, a long run behind it; carry-in code is something else
+    n = 900
+    ty = np.where(np.arange(n) % 2 == 0, O.TRAIN_NORM_1, O.TRAIN_NORM_2).astype(np.uint8)
+    ty[0] = O.TRAIN_SYNC
+    sl = T.synth_slots(ty, seed=77, scramb_init=code, mcc=cell[0], mnc=cell[1], cc=cell[2], ber=0.01)
+    cases.append((ty, sl, np.zeros(n, np.uint32), np.array([0x12345], np.uint32)))
+    # (b) the same with a second SYNC slot at 300 whose SB1 is destroyed: slots behind it keep slot 0's code
+    sl2 = sl.copy()
+    ty2 = ty.copy()
+    ty2[300] = O.TRAIN_SYNC
+    sl2[300] = T.synth_slots(np.array([O.TRAIN_SYNC], np.uint8), seed=5, scramb_init=code, mcc=1, mnc=2, cc=3)[0]
+    sl2[300, 94:214] ^= (np.random.default_rng(3).random(120) < 0.5).astype(np.uint8)
+    cases.append((ty2, sl2, np.zeros(n, np.uint32), np.array([0x12345], np.uint32)))
+    # (c) 70 channels, two slots each, no SYNC slot: every channel decodes with its own carry-in code
+    nch = 70
+    carry = (np.arange(nch, dtype=np.uint32) * 2654435761 + 3).astype(np.uint32)
+    ty3 = np.tile(np.array([O.TRAIN_NORM_1, O.TRAIN_NORM_2], np.uint8), nch)
+    ch3 = np.repeat(np.arange(nch, dtype=np.uint32), 2)
+    sl3 = np.concatenate([T.synth_slots(ty3[2 * c:2 * c + 2], seed=900 + c, scramb_init=int(carry[c])) for c in range(nch)])
+    cases.append((ty3, sl3, ch3, carry))
+    for ty_, sl_, ch_, carry_ in cases:
+        n_ = len(ty_)
+        d = torch.from_numpy(sl_.reshape(-1)).cuda()
+        out = {}
+        for mode, mx in (("burst", "100000"), ("batch", "0")):
+            monkeypatch.setenv("TGPU_BURST_MAX", mx)
+            d_rec = torch.zeros(n_ * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+            plan = T.Plan(eng, n_, len(carry_))
+            plan.load(np.arange(n_, dtype=np.uint64) * 510, ty_, ch_, carry_)
+            plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+            torch.cuda.synchronize()
+            out[mode] = (d_rec.cpu().numpy().reshape(n_, T.REC_BYTES), plan.final_codes().tolist())
+            plan.close()
+        assert (out["burst"][0] == out["batch"][0]).all() and out["burst"][1] == out["batch"][1]
+        p = T.parse_records(out["burst"][0])
+        if len(carry_) == 1:
+            assert (p["code"][1:] == code).all() and p["crc_ok"][1:, 0].mean() > 0.5
+        else:
+            assert (p["code"] == carry_[ch_]).all() and p["crc_ok"][:, 0].all()
+
+
 def test_comm_gather_single_rank(T, eng):
     """tgpu_comm_*: the C-ABI gather over RCCL with the one rank a 1-GPU box has -- id, communicator, the grouped
     send / receive to the root (here: to itself) on a side stream, twice with different sizes, wire records of a
