@@ -206,6 +206,11 @@ int tgpu_plan_final_codes(struct tgpu_plan *plan, const uint8_t *d_rec, uint32_t
  */
 #define TGPU_WIRE_BYTES 40
 int tgpu_plan_set_wire(struct tgpu_plan *plan, uint8_t *d_wire /* NULL: off */);
+/* on: with a wire buffer attached the trellis kernels write ONLY the wire records -- the 320-byte records (one byte per
+ * type-1 bit, the reference's format) are eight times the volume and are what a step's HBM writes consist of; a
+ * consumer that takes the packed form (the gather to a collecting rank; a host that unpacks with tgpu_wire_unpack())
+ * does not need them.  d_rec is still passed to execute: slots of an ignored burst type get their 0xff type byte. */
+int tgpu_plan_set_wire_only(struct tgpu_plan *plan, int on);
 int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_code, uint8_t *rec);
 int tgpu_wire_pack(const uint8_t *rec, uint8_t *wire);
 

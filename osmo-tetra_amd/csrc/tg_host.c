@@ -56,6 +56,7 @@ struct tgpu_plan {
 	int up_mapped;		/* small plans: the upload arena is pinned host memory the kernels read in place */
 	int last_burst;		/* the last execute took the workgroup-per-burst path (records carry a completion mark) */
 	int marks;		/* the owner keeps d_rec in mapped host memory and polls the marks (tgpi_plan_set_marks) */
+	int wire_only;		/* tgpu_plan_set_wire_only: the trellis kernels write the wire records only */
 	/* device */
 	uint8_t *d_up, *h_up;	/* upload arena (device / pinned host mirror): one copy per load */
 	size_t up_bytes;
@@ -570,7 +571,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	MARK(1);
 	if (p->nslots && !p->static_masks) {
 		if ((rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, p->nsb, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, p->rm_decode ? TGK_F_RM : 0, NULL, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, (p->rm_decode ? TGK_F_RM : 0) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0), NULL, stream)))
 			return rc;
 	}
 	MARK(2);
@@ -596,7 +597,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 		if (e_ != hipSuccess)
 			return (int)e_;
 	}
-	const int kf = p->rm_decode ? TGK_F_RM : 0;
+	const int kf = (p->rm_decode ? TGK_F_RM : 0) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0);
 	const int fast = p->fastpath && !soft;
 	const uint32_t *items216 = p->d_list_216, *items432 = p->d_list_432, *cnt216 = NULL, *cnt432 = NULL;
 	void *s432 = fork ? (void *)p->side : stream;
@@ -798,7 +799,7 @@ static int plan_run_blocks(struct tgpu_plan *p, const uint8_t *d_bits, uint8_t *
 				  p->d_sb_code, NULL, NULL, TGK_F_BLOCK, NULL, stream)))
 			return rc;
 	return tgk_bbk_blocks(p->d_list_bbk, p->nbbk, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-			      p->rm_decode ? TGK_F_RM : 0, stream);
+			      (p->rm_decode ? TGK_F_RM : 0) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0), stream);
 }
 
 int tgpu_plan_execute(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream)
@@ -884,6 +885,14 @@ int tgpu_prof_read(struct tgpu_prof *prof, uint32_t nsteps, float *ms)
 		for (int k = 0; k < TGPU_NSTAGES; k++)
 			HCHK(hipEventElapsedTime(&ms[(size_t)s * TGPU_NSTAGES + k], ev[k], ev[k + 1]));
 	}
+	return TGPU_OK;
+}
+
+int tgpu_plan_set_wire_only(struct tgpu_plan *p, int on)
+{
+	if (!p)
+		return TGPU_EINVAL;
+	p->wire_only = on ? 1 : 0;
 	return TGPU_OK;
 }
 

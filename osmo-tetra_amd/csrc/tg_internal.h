@@ -83,6 +83,7 @@ const uint16_t *tgi_rm_parity(void);
 int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity);
 #define TGK_F_BLOCK 1	/* tgk_vit flags: items are blocks on their own */
 #define TGK_F_RM    2	/* correct the BBK with the RM(30,14) decoder before its first 14 bits are kept */
+#define TGK_F_WIREONLY 8	/* only the 40-byte wire records are written (tgpu_plan_set_wire_only): no 320-byte records */
 #define TGK_F_DIRECT 4	/* SCH/F records written 16 bytes per lane instead of through the LDS transpose (A/B: TGPU_REC_DIRECT=1) */
 
 /* make the engine's device the calling thread's current HIP device (every allocating / launching entry point does) */

@@ -1320,7 +1320,8 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 	}
 	const uint32_t crc_ok = (crc == 0x1d0f);
 
-	if (KIND == TG_KIND_432 && stage && !block_mode) {
+	const bool wire_only = kflags & TGK_F_WIREONLY;
+	if (KIND == TG_KIND_432 && stage && !block_mode && !wire_only) {
 		/* SCH/F: the lane owns the whole 320-byte record.  Written 16 bytes at a time per lane, every store
 		 * instruction touches 64 cache lines and every line is filled from memory before it is complete
 		 * (FETCH_SIZE 3x the input).  Instead the record goes out in five 64-byte pieces through LDS: each lane parks
@@ -1398,7 +1399,7 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 
 	/* ---- outputs ---- */
 	uint8_t *r = rec + (size_t)slot * TG_REC_BYTES;
-	{
+	if (!wire_only) {
 		uint4 *dst = (uint4 *)(r + (which ? TG_REC_BITS2 : TG_REC_BITS1));
 		constexpr int NST = (TYPE1 + 15) / 16;
 #pragma unroll
@@ -1415,8 +1416,10 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 			dst[q] = o;
 		}
 	}
-	r[TG_REC_CRC_OK + which] = (uint8_t)crc_ok;
-	*(uint16_t *)(r + TG_REC_CRC + 2 * which) = (uint16_t)crc;
+	if (!wire_only) {
+		r[TG_REC_CRC_OK + which] = (uint8_t)crc_ok;
+		*(uint16_t *)(r + TG_REC_CRC + 2 * which) = (uint16_t)crc;
+	}
 
 	/* optional bit-packed copy for transport (wave-uniform branch): tg_layout.h "Wire record".  The lanes of a slot
 	 * write disjoint bytes: each block its payload words and its half (SCH/F: its field) of w[9], the primary lane
@@ -1448,17 +1451,21 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 		const uint32_t fn = FIELD_MSB(od, 12, 5), mn = FIELD_MSB(od, 17, 6);
 		const uint32_t mcc = FIELD_MSB(od, 31, 10), mnc = FIELD_MSB(od, 41, 14);
 		const uint32_t code = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3u;
-		*(uint32_t *)(r + TG_REC_SBF0) = cc | (tn << 8) | (fn << 16) | (mn << 24);
-		*(uint32_t *)(r + TG_REC_SBF1) = mcc | (mnc << 16);
-		*(uint32_t *)(r + TG_REC_SBCODE) = code;
+		if (!wire_only) {
+			*(uint32_t *)(r + TG_REC_SBF0) = cc | (tn << 8) | (fn << 16) | (mn << 24);
+			*(uint32_t *)(r + TG_REC_SBF1) = mcc | (mnc << 16);
+			*(uint32_t *)(r + TG_REC_SBCODE) = code;
+		}
 		sb_ok[idx] = crc_ok;
 		sb_code[idx] = code;
-		if (block_mode) {	/* a block on its own: this lane also writes the header */
+		if (block_mode && !wire_only) {	/* a block on its own: this lane also writes the header */
 			r[TG_REC_TYPE] = (uint8_t)packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
 			*(uint32_t *)(r + TG_REC_CODE) = 3u;
 			*(uint32_t *)(r + TG_REC_SLOT) = slot;
 		}
 	} else if (block_mode) {
+		if (wire_only)
+			return;
 		/* block mode (tgpu_plan_load_blocks): one block per record, no burst around it */
 		const uint32_t meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
 		r[TG_REC_TYPE] = (uint8_t)meta;
@@ -1486,17 +1493,19 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 			uint32_t nerr = 0;
 			if (kflags & TGK_F_RM)		/* non-default: minimum-distance decoding of the (30,14) word first */
 				bb = rm3014_correct(bb, nerr);
-			r[TG_REC_BBK_NERR] = (uint8_t)nerr;
-			uint4 o;
-			o.x = spread4(bb);
-			o.y = spread4(bb >> 4);
-			o.z = spread4(bb >> 8);
-			o.w = spread4(bb >> 12) & 0x0000ffffu;	/* 14 type-1 bits (tetra_lower_mac.c:268-274) */
-			*(uint4 *)(r + TG_REC_BBK) = o;
-			r[TG_REC_TYPE] = (uint8_t)btype;
-			r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
-			*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
-			*(uint32_t *)(r + TG_REC_SLOT) = slot;
+			if (!wire_only) {
+				r[TG_REC_BBK_NERR] = (uint8_t)nerr;
+				uint4 o;
+				o.x = spread4(bb);
+				o.y = spread4(bb >> 4);
+				o.z = spread4(bb >> 8);
+				o.w = spread4(bb >> 12) & 0x0000ffffu;	/* 14 type-1 bits (tetra_lower_mac.c:268-274) */
+				*(uint4 *)(r + TG_REC_BBK) = o;
+				r[TG_REC_TYPE] = (uint8_t)btype;
+				r[TG_REC_FLAGS] = (uint8_t)(meta >> 8);
+				*(uint32_t *)(r + TG_REC_CODE) = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
+				*(uint32_t *)(r + TG_REC_SLOT) = slot;
+			}
 			if (wr)
 				wr[0] = btype | (((meta >> 8) & 0xff) << 8) | ((bb & 0x3fff) << 16);
 		}

@@ -1852,6 +1852,53 @@ def test_burst_kernel_long_runs_and_many_channels(T, eng, monkeypatch):
             assert (p["code"] == carry_[ch_]).all() and p["crc_ok"][:, 0].all()
 
 
+def test_wire_only_mode(T, eng, monkeypatch):
+    """tgpu_plan_set_wire_only: the wire records are the ones of a normal run byte for byte (all burst types, noise, code
+    learnt from SB1 mid-batch, the RM option), the 320-byte records are left alone (but for the type byte of ignored
+    slots), the scrambling codes in force afterwards are the same"""
+    import torch
+    monkeypatch.setenv("TGPU_BURST_MAX", "0")
+    hs = torch.cuda.current_stream().cuda_stream
+    n = 5000
+    rng = np.random.default_rng(12)
+    types = np.tile(np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8), n // 8 + 1)[:n]
+    types[rng.integers(0, n, 20)] = 2                      # ignored type
+    cell = (262, 42, 1)
+    code = O.scramb_get_init(*cell)
+    slots = T.synth_slots(np.where(types == 2, 0, types).astype(np.uint8), seed=9, scramb_init=code, mcc=cell[0], mnc=cell[1], cc=cell[2], ber=0.03)
+    d = torch.from_numpy(slots.reshape(-1)).cuda()
+    for rm in (False, True):
+        res = {}
+        for mode in ("full", "wire_only"):
+            plan = T.Plan(eng, n, 1)
+            plan.set_rm_decode(rm)
+            plan.load(np.arange(n, dtype=np.uint64) * 510, types, None, np.array([3], np.uint32))
+            d_rec = torch.full((n * T.REC_BYTES,), 0xAB, dtype=torch.uint8, device="cuda")
+            d_wire = torch.full((n * T.WIRE_BYTES,), 0xFF, dtype=torch.uint8, device="cuda")
+            plan.set_wire(d_wire.data_ptr())
+            plan.set_wire_only(mode == "wire_only")
+            plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+            torch.cuda.synchronize()
+            res[mode] = (d_rec.cpu().numpy().reshape(n, T.REC_BYTES), d_wire.cpu().numpy().reshape(n, T.WIRE_BYTES),
+                         plan.final_codes().tolist())
+            plan.close()
+        assert (res["full"][1] == res["wire_only"][1]).all() and res["full"][2] == res["wire_only"][2] == [code]
+        untouched = res["wire_only"][0].copy()
+        assert (untouched[types != 2] == 0xAB).all()
+        assert (untouched[types == 2][:, 1:] == 0xAB).all() and (untouched[types == 2][:, 0] == 0xFF).all()
+        # and the wire records unpack to the full run's records
+        for i in (0, 1, 2, 3, 9, n - 1):
+            back = T.wire_unpack(res["wire_only"][1][[i]], [i], [code])[0]
+            full = res["full"][0][i]
+            pa, pb = T.parse_records(back[None]), T.parse_records(full[None])
+            n1, n2 = {0: (268, 0), 1: (124, 124), 3: (60, 124)}[int(types[i])]      # (the full run's buffer was prefilled)
+            assert (pa["bits1"][0][:n1] == pb["bits1"][0][:n1]).all() and (pa["bits2"][0][:n2] == pb["bits2"][0][:n2]).all()
+            for k in ("type", "bbk"):
+                assert (np.asarray(pa[k]) == np.asarray(pb[k])).all(), (i, k)
+            nb = 2 if n2 else 1
+            assert (pa["crc"][0][:nb] == pb["crc"][0][:nb]).all() and (pa["crc_ok"][0][:nb] == pb["crc_ok"][0][:nb]).all()
+
+
 def test_comm_gather_single_rank(T, eng):
     """tgpu_comm_*: the C-ABI gather over RCCL with the one rank a 1-GPU box has -- id, communicator, the grouped
     send / receive to the root (here: to itself) on a side stream, twice with different sizes, wire records of a
