@@ -461,7 +461,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                     "bytes_per_rank_and_step": cap * T.WIRE_BYTES,
                     "link_arithmetic": "every peer sends %.1f MB per step (%d grid slots x %d B wire record, undelivered slots "
                                        "included) to rank 0 over its own xGMI link: %.1f GB/s per link at the gathered step time, "
-                                       "%.1f GB/s at the decode-only step time (one link direction ~ 64 GB/s by spec, 7 links into "
+                                       "%.1f GB/s at the decode-only step time (one xGMI link ~ 153 GB/s over both directions, i.e. ~ 77 GB/s towards rank 0; 7 links into "
                                        "rank 0); rank 0 takes in %.1f GB/s in total"
                                        % (per_rank_mb, cap, T.WIRE_BYTES, per_rank_mb / (el_g / args.steps * 1e3),
                                           per_rank_mb / (el / args.steps * 1e3), (world - 1) * per_rank_mb / (el_g / args.steps * 1e3))}
