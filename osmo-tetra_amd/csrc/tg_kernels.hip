@@ -1885,22 +1885,24 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
  * 16-state add-compare-select as a butterfly ACROSS LANES.  It exists for small batches (the drop-in channel API
  * with a handful of bursts per flush), where the lane-per-trellis kernels leave 63 of 64 lanes idle and a flush is a
  * chain of eight launches: here a flush is two (k_burst<true> for the SB1 blocks of the SYNC slots, then k_burst<false>
- * for everything), and a 432-bit block takes 296 x ~100 cycles instead of 296 x 28 dependent instructions.
+ * for everything).
  *
- *   - the slot's 510 bytes -> LDS; every thread de-interleaves, de-punctures (2/3: the order of the bits is the
- *     type-3 order) and descrambles its share of a block: r[i] = byte[(a (i + 1)) mod K] != 0, XOR bit (same position)
- *     of the scrambling sequence in its linear form (parity(code & lfsr_lin[pos]), lower_mac/tetra_scramb.c:34-50);
+ *   - descriptors and channels of the slot and the 255 before it + the channels' carry-in codes -> LDS in one parallel
+ *     load (small batches keep them in mapped host memory: every dependent read would be a PCIe round trip), then the
+ *     slot's 510 bytes -> LDS; every thread de-interleaves, de-punctures (2/3: the order of the bits is the type-3
+ *     order) and descrambles its share of a block: r[i] = byte[(a (i + 1)) mod K] != 0, XOR bit (same position) of
+ *     the scrambling sequence in its linear form (parity(code & lfsr_lin[pos]), lower_mac/tetra_scramb.c:34-50);
  *   - the scrambling code of the slot = the SYNC PDU of the latest SYNC slot at or before it (same channel) whose SB1
  *     passed its CRC, else the channel's carry-in (lower_mac/tetra_lower_mac.c:179-186, 291-300): pass 1 leaves
  *     (crc_ok, code) per SYNC slot, pass 2's workgroups look backwards through them -- no forward-fill launches;
- *   - trellis: lane s of a 16-lane row holds state s as metric << 8 | survivor byte (the lane-per-trellis word, one
- *     state per lane).  Per step: the words of the two predecessors s >> 1 and (s >> 1) + 8 come over the LDS
- *     crossbar (ds_bpermute_b32), the one from the predecessor whose oldest bit is 1 gets the step's tie / decision
- *     bit added, v_min_u32 selects: same tie rule and register-exchange history as vit_core.h, so the 8-step
- *     blocks, the 16 history bytes per block (here: one ds_write_b8 per lane) and the block-wise traceback are the
- *     same too.  Row 0 of wave 0 decodes the slot's first block, row 1 the second, side by side;
- *   - CRC-16 (table form), type-1 bits at one byte per bit, BBK, header: the record of the lane-per-trellis path,
- *     byte for byte (tests/test_gpu_parity.py::test_burst_kernel_equals_batch_kernels).
+ *   - trellis: a lane of a 16-lane row holds one state as metric << 8 | survivor byte (the lane-per-trellis word, one
+ *     state per lane): same tie rule and register-exchange history as vit_core.h, so the 8-step blocks, the 16
+ *     history bytes per block (one ds_write_b8 per lane) and the block-wise traceback are the same too.  The
+ *     butterflies run in place with DPP partner exchanges and increments prepared by all threads (comment at s_inc
+ *     below).  Row 0 of wave 0 decodes the slot's first block, row 1 the second, side by side;
+ *   - CRC-16 as the linear map it is (c_tab.crc_lin), type-1 bits at one byte per bit, BBK, header: the record of the
+ *     lane-per-trellis path, byte for byte (tests/test_gpu_parity.py::test_burst_kernel_equals_batch_kernels); the
+ *     burst type is written last -- behind a system-wide fence when the owner polls it (marks).
  */
 /* block parameters per kind on the device (tg_layout.h's host inlines: lower_mac/tetra_lower_mac.c:55-102) */
 __device__ __forceinline__ uint32_t tgb_K(int kind)    { return kind == TG_KIND_SB1 ? 120u : kind == TG_KIND_216 ? 216u : 432u; }
