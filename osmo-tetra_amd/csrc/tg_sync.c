@@ -460,7 +460,9 @@ static int wait_records(struct tgpu_channel *ch, uint32_t n)
 				if ((t.tv_sec - t0.tv_sec) * 1000000000L + (t.tv_nsec - t0.tv_nsec) > 2000000L)
 					return 0;
 			}
+#if defined(__x86_64__) || defined(__i386__)
 			__builtin_ia32_pause();
+#endif
 		}
 	}
 	__atomic_thread_fence(__ATOMIC_ACQUIRE);
