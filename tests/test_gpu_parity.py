@@ -1700,6 +1700,44 @@ def test_config5_full_size_soft_decode_against_the_oracle(T, eng):
     plan.close()
 
 
+def test_float_input_two_channels_codes_learnt_mid_batch(T, eng):
+    """tgpu_plan_execute_float on a two-channel batch whose scrambling codes are only learnt from SB1 inside the batch
+    (carry-in code 3 / a wrong one): records == float_to_bits + execute_soft, blocks behind a good SYNC slot pass
+    their CRC with the learnt code, final codes per channel"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    cells = [(262, 42, 1), (901, 77, 9)]
+    n = 4000
+    pat = np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8)
+    types = np.tile(pat, n // 8 + 1)[:n]
+    chan = (np.arange(n) >= n // 2).astype(np.uint32)
+    parts = []
+    for c, cell in enumerate(cells):
+        m = int((chan == c).sum())
+        parts.append(T.synth_slots(types[chan == c], seed=70 + c, scramb_init=O.scramb_get_init(*cell), mcc=cell[0], mnc=cell[1], cc=cell[2]))
+    slots = np.concatenate(parts)
+    rng = np.random.default_rng(8)
+    phi = (O.bits_to_phase(slots.reshape(-1)) + rng.normal(0, 0.45, slots.size // 2)).astype(np.float32)
+    d_phi = torch.from_numpy(phi).cuda()
+    d_bits = torch.zeros(2 * len(phi) + 64, dtype=torch.uint8, device="cuda")
+    d_soft = torch.zeros(2 * len(phi) + 64, dtype=torch.int8, device="cuda")
+    eng.float_to_bits(d_phi.data_ptr(), len(phi), d_bits.data_ptr(), d_soft.data_ptr())
+    plan = T.Plan(eng, n, 2)
+    plan.load(np.arange(n, dtype=np.uint64) * 510, types, chan, np.array([3, 0x1234567], np.uint32))
+    a = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan.execute_soft(d_soft.data_ptr(), a.data_ptr(), hs)
+    plan.execute_float(d_phi.data_ptr(), len(phi), b.data_ptr(), hs)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    p = T.parse_records(b.cpu().numpy().reshape(n, T.REC_BYTES))
+    want = np.array([O.scramb_get_init(*cells[int(c)]) for c in chan], np.uint32)
+    assert (p["code"][types != 3] == want[types != 3]).all()          # slot 0 of each channel is a SYNC slot
+    assert p["crc_ok"][types == 0, 0].mean() > 0.9
+    assert plan.final_codes().tolist() == [O.scramb_get_init(*cells[0]), O.scramb_get_init(*cells[1])]
+    plan.close()
+
+
 def test_float_input_odd_offsets_and_stream_end(T, eng):
     """tgpu_plan_execute_float: slots at odd stream positions (a burst that starts on the second value of a symbol),
     ignored burst types in between, NaN / infinite / huge phases, and a last slot that ends exactly with the input
