@@ -149,6 +149,9 @@ void tgpu_plan_destroy(struct tgpu_plan *plan);
  * NON-DECREASING in i (slots of one channel are contiguous and in stream order).
  * chan_code[c]: scrambling code in effect for channel c before its first slot
  * (tcd->scramb_init, lower_mac/tetra_lower_mac.c:104-113; 0 for a fresh channel).
+ * A plan must be idle when it is loaded: plans of up to 256 slots keep the batch description in mapped host memory
+ * that the kernels of an execute still in flight read in place (no copy at load time), so loading batch n + 1 while
+ * batch n runs needs a second plan (which is also how larger batches are pipelined).
  */
 int tgpu_plan_load(struct tgpu_plan *plan, uint32_t nslots, const uint64_t *slot_off,
 		   const uint8_t *slot_type, const uint32_t *slot_chan,
@@ -291,6 +294,7 @@ int tgpu_record_sync_info(const uint8_t *rec, struct tgpu_sync_info *out);
 
 /* TMV-SAP UNITDATA indication: what the reference hands to upper_mac_prim_recv()
  * inside struct tetra_tmvsap_prim + msgb (tetra_prim.h:25-47). */
+#define TGPU_BURST_UNKNOWN 0xff	/* tgpu_unitdata.burst_type: not known (never a value of enum tetra_train_seq) */
 struct tgpu_unitdata {
 	enum tp_sap_data_type type;
 	int blk_num;
@@ -300,7 +304,9 @@ struct tgpu_unitdata {
 	uint32_t scrambling_code;
 	struct tetra_tdma_time tdma_time;
 	uint32_t burst_seq;		/* ordinal of the LOCKED burst */
-	enum tetra_train_seq burst_type;
+	enum tetra_train_seq burst_type;	/* of the burst the block came in; on the tp_sap_udata_ind() seam, where blocks
+					 * arrive on their own, TGPU_BURST_UNKNOWN for a block no burst type is implied by
+					 * (BBK, SCH/HU) unless tetra_burst_rx_cb() of this library handed it over */
 	uint16_t type1_len;
 	const uint8_t *type1;		/* msg->l1h: borrowed for the call */
 	int traffic;			/* != 0: block is a traffic-channel block (cur_burst.is_traffic value);

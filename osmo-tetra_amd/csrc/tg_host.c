@@ -87,6 +87,7 @@ struct tgpu_plan {
 	uint32_t *h_last_slot_of_chan;
 	struct tg_chan_ent *d_chan_tab, *h_chan_tab;	/* multi-channel stream mode: channel table (64 entries) */
 	uint32_t *d_defer;	/* stream mode: slots the packed-bit front end hands to its exact pass (count + list) */
+	uint64_t max_off;	/* slot mode: largest slot offset of the load (bounds check of tgpu_plan_execute_float) */
 };
 
 const char *tgpu_strerror(int err)
@@ -152,7 +153,10 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	/* descriptors 8n, chan 4n, sbord 4n, lists <= 8n in total, static mask indices 4n, codes, padding */
 	p->up_bytes = 28 * n + 4 * (size_t)max_chan + 8 * UP_ALIGN;
 	/* small plans (the drop-in channel API at small batch sizes: a flush is a round trip, and every copy in it costs
-	 * more than the bytes): descriptors and lists stay in pinned host memory and the kernels read them in place */
+	 * more than the bytes): descriptors and lists stay in pinned host memory and the kernels read them in place.
+	 * Consequence for callers: a small plan must be idle (its last execute complete) before the next tgpu_plan_load*()
+	 * rewrites that memory -- larger plans copy at load time and may be reloaded while an execute is in flight only
+	 * in so far as the copy is ordered behind it by the caller (include/tetra_gpu.h, tgpu_plan_load) */
 	p->up_mapped = max_slots <= TGPU_SMALL_PLAN && !getenv("TGPU_NO_ZERO_COPY");
 	if (hipHostMalloc((void **)&p->h_up, p->up_bytes, p->up_mapped ? hipHostMallocMapped : hipHostMallocDefault) != hipSuccess) {
 		p->h_up = NULL;
@@ -235,10 +239,13 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 		return TGPU_ECAPACITY;
 	/* pass 1: validate and count, so that the upload arena can be laid out exactly */
 	uint32_t nsb = 0, n216 = 0, n432 = 0, prev = 0;
+	uint64_t max_off = 0;
 	for (uint32_t i = 0; i < nslots; i++) {
 		if (SLOT_CHAN(i) >= nchan || SLOT_CHAN(i) < prev || (SLOT_OFF(i) >> 56))
 			return TGPU_EINVAL;
 		prev = SLOT_CHAN(i);
+		if (SLOT_OFF(i) > max_off)
+			max_off = SLOT_OFF(i);
 		const uint8_t t = SLOT_TYPE(i);
 		nsb += t == TETRA_TRAIN_SYNC;
 		n216 += (t == TETRA_TRAIN_SYNC) + 2 * (t == TETRA_TRAIN_NORM_2);
@@ -302,6 +309,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 	 * issued on the caller's stream in front of the first execute (static_pending) */
 	p->static_masks = is_static;
 	p->static_pending = is_static;
+	p->max_off = max_off;
 	p->d_idx_stage = d_idx_stage;
 	p->packed_ready = 0;
 	p->block_mode = 0;
@@ -529,6 +537,10 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	BIND(p->eng);
 	if (!p->loaded || (soft && p->packed_ready) || p->block_mode)
 		return TGPU_ESTATE;
+	/* float input: slot offsets count stream positions, two per symbol; a slot that starts past the input would make
+	 * the kernel's clamp arithmetic wrap */
+	if (soft == 2 && p->nslots && p->max_off + TG_SLOT_BITS > 2 * nfloats)
+		return TGPU_EINVAL;
 	/* small batches: one workgroup per burst, trellis states across lanes, two launches (k_burst).
 	 * TGPU_BURST_MAX = largest batch that takes this path (0 = never) */
 	if (!soft && !ev && !p->packed_ready && !p->rm_decode && !p->d_wire && !p->fastpath && p->nslots &&
@@ -536,7 +548,9 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 		if ((rc = tgk_burst(d_stream, p->d_slot_off, p->d_slot_chan, p->d_chan_code, p->nslots, p->nchan, p->nsb != 0, p->d_sb_ok,
 				    p->d_sb_code, d_rec, p->d_maskidx, p->d_masks, p->marks, stream)))
 			return rc;
-		p->static_pending = 0;
+		/* k_burst uses d_maskidx / d_masks as its own scratch (entry i = the code in force at slot i): a later execute
+		 * of the same load on the batch kernels' path has to rebuild the static mask table and indices first */
+		p->static_pending = p->static_masks;
 		p->last_burst = 1;
 		return TGPU_OK;
 	}

@@ -1970,15 +1970,13 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	uint8_t *r = rec + (size_t)i * TG_REC_BYTES;
 	if (SB1_PASS && type != TG_BURST_SYNC)
 		return;
-	if (type != TG_BURST_SYNC && type != TG_BURST_NORM_1 && type != TG_BURST_NORM_2) {
-		if (tid == 0)
-			r[TG_REC_TYPE] = TG_BURST_NONE;
-		return;
-	}
+	/* a burst type this path does not decode: no record, but the slot still has a code in force (the batch kernels'
+	 * forward fill gives every slot one, and tgpu_plan_final_codes() reads the channel's last slot whatever its type) */
+	const bool ignored = type != TG_BURST_SYNC && type != TG_BURST_NORM_1 && type != TG_BURST_NORM_2;
 	if (tid == 0)
 		s_nonbin = 0;
 	__syncthreads();
-	{	/* the slot -> LDS (byte loads: any alignment), non-binary test */
+	if (!ignored) {	/* the slot -> LDS (byte loads: any alignment), non-binary test */
 		const uint32_t b0 = base[2 * tid < 510 ? 2 * tid : 509], b1 = base[2 * tid + 1 < 510 ? 2 * tid + 1 : 509];
 		if (2 * tid < 510)
 			s_slot[2 * tid] = (uint8_t)b0;
@@ -2009,7 +2007,14 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 					}
 		}
 		s_code = code;
+		if (ignored) {
+			r[TG_REC_TYPE] = TG_BURST_NONE;
+			maskidx[i] = i;
+			masks[(size_t)i * TG_MASK_WORDS + TG_MW_CODE] = code;
+		}
 	}
+	if (ignored)		/* (workgroup-uniform; SB1_PASS never gets here with one) */
+		return;
 	__syncthreads();
 	const uint32_t code = s_code;
 	TGB_STAMP(2);

@@ -171,6 +171,7 @@ struct tgpu_channel {
 	uint64_t *bq_off;
 	uint8_t *bq_type;
 	uint32_t *bq_code;
+	uint8_t bq_burst, bq_burst_known;	/* burst type of the blocks tetra_burst_rx_cb() is handing over right now */
 };
 
 #define BQ_STRIDE 432u
@@ -179,6 +180,8 @@ struct bq_item {
 	uint8_t type;			/* enum tp_sap_data_type */
 	uint8_t blk_num;
 	uint16_t len;
+	uint8_t burst_type;		/* enum tetra_train_seq of the burst the block came in (see bq_burst_type) */
+	uint32_t burst_seq;
 	struct tetra_tdma_time time;	/* t_phy_state.time when the block was handed over (tetra_lower_mac.c:167) */
 };
 
@@ -633,14 +636,41 @@ int tgpu_channel_burst_rx(struct tgpu_channel *ch, const uint8_t *burst, unsigne
  */
 struct tetra_phy_state t_phy_state __attribute__((weak));
 
+static void bq_free(struct tgpu_channel *ch)
+{
+	free(ch->bq);
+	free(ch->bq_off);
+	free(ch->bq_type);
+	free(ch->bq_code);
+	if (ch->bq_bits) (void)hipHostFree(ch->bq_bits);
+	if (ch->bq_rec) (void)hipHostFree(ch->bq_rec);
+	if (ch->d_bq_bits) (void)hipFree(ch->d_bq_bits);
+	if (ch->d_bq_rec) (void)hipFree(ch->d_bq_rec);
+	if (ch->bplan) tgpu_plan_destroy(ch->bplan);
+	ch->bq = NULL;
+	ch->bq_off = NULL;
+	ch->bq_type = NULL;
+	ch->bq_code = NULL;
+	ch->bq_bits = ch->bq_rec = ch->d_bq_bits = ch->d_bq_rec = NULL;
+	ch->bplan = NULL;
+	ch->bq_cap = 0;
+}
+
+/* all or nothing: bq_cap is set last and is what the callers test, a partial allocation is taken back so that the
+ * next call starts from scratch */
 static int bq_alloc(struct tgpu_channel *ch)
 {
-	if (ch->bq)
+	if (ch->bq_cap)
 		return TGPU_OK;
-	const size_t n = (size_t)ch->batch_slots * 3 + 3;
-	int rc = tgpu_plan_create(ch->eng, (uint32_t)n, 4, &ch->bplan);
+	int rc = tgpi_engine_bind(ch->eng);
 	if (rc)
 		return rc;
+	const size_t n = (size_t)ch->batch_slots * 3 + 3;
+	rc = tgpu_plan_create(ch->eng, (uint32_t)n, 4, &ch->bplan);
+	if (rc) {
+		ch->bplan = NULL;
+		return rc;
+	}
 	hipError_t e = hipSuccess;
 	ch->bq = calloc(n, sizeof(*ch->bq));
 	ch->bq_off = calloc(n, sizeof(uint64_t));
@@ -650,8 +680,10 @@ static int bq_alloc(struct tgpu_channel *ch)
 	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->bq_rec, n * TGPU_REC_BYTES, 0);
 	if (e == hipSuccess) e = hipMalloc((void **)&ch->d_bq_bits, n * BQ_STRIDE);
 	if (e == hipSuccess) e = hipMalloc((void **)&ch->d_bq_rec, n * TGPU_REC_BYTES);
-	if (e != hipSuccess || !ch->bq || !ch->bq_off || !ch->bq_type || !ch->bq_code)
+	if (e != hipSuccess || !ch->bq || !ch->bq_off || !ch->bq_type || !ch->bq_code) {
+		bq_free(ch);
 		return e != hipSuccess ? (int)e : TGPU_ENOMEM;
+	}
 	for (size_t i = 0; i < n; i++)
 		ch->bq_off[i] = i * BQ_STRIDE;
 	ch->bq_cap = (uint32_t)n;
@@ -664,6 +696,13 @@ static int flush_blocks(struct tgpu_channel *ch)
 	if (!n)
 		return TGPU_OK;
 	hipError_t e = hipSuccess;
+	{
+		const int brc = tgpi_engine_bind(ch->eng);	/* the calling thread may have another device current */
+		if (brc) {
+			ch->bq_n = 0;
+			return channel_fail(ch, brc, n);
+		}
+	}
 	for (uint32_t i = 0; i < n; i++) {
 		ch->bq_type[i] = ch->bq[i].type;
 		ch->bq_code[i] = ch->scramb_init;	/* the code in force: an SB1 only ever ends a batch */
@@ -685,7 +724,7 @@ static int flush_blocks(struct tgpu_channel *ch)
 		const struct bq_item *it = &ch->bq[i];
 		const uint8_t *rec = ch->bq_rec + (size_t)i * TGPU_REC_BYTES;
 		struct tgpu_block b;
-		struct pending pd = { ch->burst_seq, 0, TETRA_TRAIN_SYNC };
+		struct pending pd = { it->burst_seq, 0, it->burst_type };
 		memset(&b, 0, sizeof(b));
 		b.type = (enum tp_sap_data_type)it->type;
 		b.blk_num = it->blk_num;
@@ -700,6 +739,22 @@ static int flush_blocks(struct tgpu_channel *ch)
 			t_phy_state.time = tm;		/* tetra_lower_mac.c:302 (deliver_block wrote it on a good CRC) */
 	}
 	return TGPU_OK;
+}
+
+/* burst type of a block handed over on its own: tetra_burst_rx_cb() below knows it and leaves it in ch->bq_burst for the
+ * blocks it hands over; for a bare tp_sap_udata_ind() call it follows from the block type where that is unambiguous
+ * (phy/tetra_burst.c:350-372: SB1 / SB2 only come in SYNC bursts, SCH/F in NORM_1, NDB halves in NORM_2), and is
+ * TGPU_BURST_UNKNOWN (0xff) for a BBK or SCH/HU block, which any burst type (or none of the downlink ones) carries */
+static uint8_t bq_burst_type(const struct tgpu_channel *ch, enum tp_sap_data_type type)
+{
+	if (ch->bq_burst_known)
+		return ch->bq_burst;
+	switch (type) {
+	case TPSAP_T_SB1: case TPSAP_T_SB2: return TETRA_TRAIN_SYNC;
+	case TPSAP_T_SCH_F: return TETRA_TRAIN_NORM_1;
+	case TPSAP_T_NDB: return TETRA_TRAIN_NORM_2;
+	default: return TGPU_BURST_UNKNOWN;
+	}
 }
 
 void tp_sap_udata_ind(enum tp_sap_data_type type, int blk_num, const uint8_t *bits, unsigned int len, void *priv)
@@ -722,6 +777,8 @@ void tp_sap_udata_ind(enum tp_sap_data_type type, int blk_num, const uint8_t *bi
 	it->blk_num = (uint8_t)blk_num;
 	it->len = (uint16_t)len;
 	it->time = t_phy_state.time;
+	it->burst_type = bq_burst_type(ch, type);
+	it->burst_seq = ch->burst_seq;
 	memcpy(ch->bq_bits + (size_t)ch->bq_n * BQ_STRIDE, bits, len);
 	ch->bq_n++;
 	if (type == TPSAP_T_SB1 || ch->bq_n >= ch->bq_cap)
@@ -732,16 +789,21 @@ void tp_sap_udata_ind(enum tp_sap_data_type type, int blk_num, const uint8_t *bi
 void tetra_burst_rx_cb(const uint8_t *burst, unsigned int len, enum tetra_train_seq type, void *priv)
 {
 	uint8_t bbk[30], both[432];
-	if (!burst || len < TG_SLOT_BITS)
+	struct tgpu_channel *ch = priv;
+	if (!burst || len < TG_SLOT_BITS || !ch)
 		return;
+	if (type != TETRA_TRAIN_SYNC && type != TETRA_TRAIN_NORM_1 && type != TETRA_TRAIN_NORM_2)
+		return;		/* uplink training sequences: ignored */
+	ch->burst_seq++;	/* ordinal of the burst, reported with its blocks (tgpu_unitdata.burst_seq) */
+	ch->bq_burst = (uint8_t)type;
+	ch->bq_burst_known = 1;
 	if (type == TETRA_TRAIN_SYNC) {
 		tp_sap_udata_ind(TPSAP_T_SB1, BLK_1, burst + TG_SB_BLK1_OFF, 120, priv);
 		tp_sap_udata_ind(TPSAP_T_BBK, 0, burst + TG_SB_BBK_OFF, 30, priv);
 		tp_sap_udata_ind(TPSAP_T_SB2, BLK_2, burst + TG_SB_BLK2_OFF, 216, priv);
+		ch->bq_burst_known = 0;
 		return;
 	}
-	if (type != TETRA_TRAIN_NORM_1 && type != TETRA_TRAIN_NORM_2)
-		return;		/* uplink training sequences: ignored */
 	memcpy(bbk, burst + TG_NDB_BBK1_OFF, 14);
 	memcpy(bbk + 14, burst + TG_NDB_BBK2_OFF, 16);
 	tp_sap_udata_ind(TPSAP_T_BBK, 0, bbk, 30, priv);
@@ -753,6 +815,7 @@ void tetra_burst_rx_cb(const uint8_t *burst, unsigned int len, enum tetra_train_
 		memcpy(both + 216, burst + TG_NDB_BLK2_OFF, 216);
 		tp_sap_udata_ind(TPSAP_T_SCH_F, 0, both, 432, priv);
 	}
+	ch->bq_burst_known = 0;
 }
 
 /* ------------------------------------------------------------------------- */
