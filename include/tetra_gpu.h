@@ -650,6 +650,17 @@ int tgpu_sync_walk(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64
 int tgpu_sync_walk_plain(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor, const uint32_t *cls,
 			 const uint16_t *ysum, const uint32_t *plain, uint32_t ncls, uint32_t flags, struct tgpu_sync_result *out);
 
+/*
+ * The walk in the form the device runs it (k_walk: one lane per grid slot that is no plain delivery, reachability by
+ * pointer doubling -- csrc/tg_walk_core.h), executed phase by phase on the host.  Test aid: same outputs as
+ * tgpu_sync_walk_plain(..., TGPU_SYNC_GRID | TGPU_SYNC_NO_BURST_EVENTS) whenever *status comes back 0; *status = 1
+ * where the device form hands the channel to the host walk (*why: the TGW_WHY_* reason).  chunk: a power of two
+ * inside the closed form's range; anchor: the stream's first lock (as tgpu_sync_stream() reports it).
+ */
+int tgpu_sync_walk_emul(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor, const uint32_t *cls,
+			const uint16_t *ysum, const uint32_t *plain, uint32_t ncls, struct tgpu_sync_result *out, int *status,
+			int *why);
+
 /* ------------------------------------------------------------------------- */
 /* 3. synthetic downlink generator (TX side of the same chain; host, multi-threaded) */
 /* ------------------------------------------------------------------------- */

@@ -169,6 +169,8 @@ def lib():
     L.tgpu_channel_scramb_init.argtypes = [C.c_void_p, u32p]
     L.tgpu_sync_walk.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u16p, C.c_uint32, C.c_uint32, C.POINTER(SyncResult)]
     L.tgpu_sync_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, u16p, C.c_void_p]
+    L.tgpu_sync_walk_emul.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u16p, u32p, C.c_uint32, C.POINTER(SyncResult),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.tgpu_sync_stream.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
     L.tgpu_sync_stream_grid.argtypes = [C.c_void_p, C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
@@ -776,6 +778,21 @@ def sync_walk(stream, chunk=64, anchor=0, cls=None, burst_events=True, ysum=None
                               ysum.ctypes.data_as(u16p) if ysum is not None else None,
                               len(cls) if cls is not None else 0, flags, C.byref(res)), "tgpu_sync_walk")
     return _sync_result_to_py(res)
+
+
+def sync_walk_emul(stream, chunk, anchor, cls, ysum, plain=None):
+    """tgpu_sync_walk_emul: the device form of the walk (k_walk's phases over csrc/tg_walk_core.h) run on the host;
+    returns (outcome, status, why) -- status 1: the device form would hand this channel to the host walk"""
+    stream = _np_u8(stream)
+    cls = np.ascontiguousarray(cls, np.uint32)
+    ysum = np.ascontiguousarray(ysum, np.uint16)
+    plain = np.ascontiguousarray(cls_plain_bits(cls) if plain is None else plain, np.uint32)
+    res = SyncResult()
+    st, why = C.c_int(0), C.c_int(0)
+    _chk(lib().tgpu_sync_walk_emul(stream.ctypes.data_as(u8p), len(stream), chunk, anchor, cls.ctypes.data_as(u32p),
+                                   ysum.ctypes.data_as(u16p), plain.ctypes.data_as(u32p), len(cls), C.byref(res),
+                                   C.byref(st), C.byref(why)), "tgpu_sync_walk_emul")
+    return _sync_result_to_py(res), st.value, why.value
 
 
 def sync_classify(engine, d_stream_ptr, length, chunk, anchor, nslots, hip_stream=0, with_ysum=False):

@@ -88,6 +88,11 @@ struct tgpu_plan {
 	struct tg_chan_ent *d_chan_tab, *h_chan_tab;	/* multi-channel stream mode: channel table (64 entries) */
 	uint32_t *d_defer;	/* stream mode: slots the packed-bit front end hands to its exact pass (count + list) */
 	uint64_t max_off;	/* slot mode: largest slot offset of the load (bounds check of tgpu_plan_execute_float) */
+	/* stream mode with the walk on the device (tgpu_sync_multi_launch): item counts stay on the device */
+	const uint32_t *d_counts;	/* [nsb, n216, n432] behind the list builder's block sums; NULL: the host knows them */
+	uint8_t *d_walk, *h_walk;	/* roots, summaries, events of k_walk (device / pinned mirror), max_chan channels */
+	void *d_walk_recs;		/* max_chan * (TGW_NCAP + 1) node records */
+	uint32_t *d_bits_dev;		/* the delivered bitmap k_walk left in the upload arena */
 };
 
 const char *tgpu_strerror(int err)
@@ -208,7 +213,7 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	void *d[] = { p->up_mapped ? NULL : p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
-		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab, p->d_defer };
+		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab, p->d_defer, p->d_walk, p->d_walk_recs };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
 			(void)hipFree(d[i]);
@@ -218,6 +223,8 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 		(void)hipHostFree(p->h_grid);
 	if (p->h_chan_tab)
 		(void)hipHostFree(p->h_chan_tab);
+	if (p->h_walk)
+		(void)hipHostFree(p->h_walk);
 	free(p->h_last_slot_of_chan);
 	free(p);
 }
@@ -309,6 +316,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 	 * issued on the caller's stream in front of the first execute (static_pending) */
 	p->static_masks = is_static;
 	p->static_pending = is_static;
+	p->d_counts = NULL;
 	p->max_off = max_off;
 	p->d_idx_stage = d_idx_stage;
 	p->packed_ready = 0;
@@ -443,6 +451,7 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 	p->static_pending = 0;
 	p->packed_ready = 1;
 	p->block_mode = 0;
+	p->d_counts = NULL;
 	p->nslots = ngrid;
 	p->nchan = nchan;
 	p->nsb = tot[0];
@@ -450,6 +459,123 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 	p->n432 = tot[2];
 	p->loaded = 1;
 	return TGPU_OK;
+}
+
+/*
+ * The same with the delivered bitmap made on the device (k_walk): nothing comes back to the host before the decode.
+ * The lists are sized for the worst case (every grid slot of one kind) and the item counts stay behind the list
+ * builder's block sums; the trellis kernels and k_masks read them there (d_counts).
+ * *d_bits_out = where k_walk is to leave the bitmap (ngrid bits, channel grids at multiples of 32).
+ */
+int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const uint32_t *codes, uint32_t **d_bits_out,
+			      void *stream)
+{
+	if (!p || !ngrid || !p->d_grid || !nchan || !codes || !d_bits_out)
+		return TGPU_EINVAL;
+	BIND(p->eng);
+	if (ngrid > p->max_slots || nchan > p->max_chan)
+		return TGPU_ECAPACITY;
+	const size_t nwords = ((size_t)ngrid + 31) / 32, nblk = ((size_t)ngrid + 1023) / 1024;
+	size_t o = 0;
+#define UP_AT(ptr, type, count) do { ptr = (type *)(p->d_up + o); \
+		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
+	uint32_t *d_bits, *d_blk;
+	UP_AT(p->d_chan_code, uint32_t, nchan);
+	const size_t upload = o;
+	UP_AT(d_bits, uint32_t, nwords);
+	UP_AT(p->d_slot_chan, uint32_t, ngrid);
+	UP_AT(p->d_slot_sbord, int32_t, ngrid);
+	UP_AT(p->d_list_sb, uint32_t, ngrid);
+	UP_AT(p->d_list_216, uint32_t, 2 * (size_t)ngrid);
+	UP_AT(p->d_list_432, uint32_t, ngrid);
+	UP_AT(d_blk, uint32_t, 3 * (nblk + 1));
+#undef UP_AT
+	p->d_slot_off = NULL;
+	if (o > p->up_bytes)
+		return TGPU_ECAPACITY;
+	memcpy(p->h_up, codes, (size_t)nchan * 4);
+	if (!p->up_mapped)
+		HCHK(hipMemcpyAsync(p->d_up, p->h_up, upload, hipMemcpyHostToDevice, (hipStream_t)stream));
+	p->d_bits_dev = d_bits;
+	p->d_counts = d_blk + 3 * nblk;
+	*d_bits_out = d_bits;
+	p->loaded = 0;
+	p->nslots = ngrid;
+	p->nchan = nchan;
+	return TGPU_OK;
+}
+
+/* second half: the lists from the bitmap k_walk has left (same stream, no host wait) */
+int tgpi_plan_grid_lists_dev(struct tgpu_plan *p, const struct tg_chan_ent *ents, void *stream)
+{
+	if (!p || !p->d_counts || !p->d_bits_dev || (ents && !p->d_chan_tab))
+		return TGPU_EINVAL;
+	BIND(p->eng);
+	const uint32_t ngrid = p->nslots;
+	const size_t nblk = ((size_t)ngrid + 1023) / 1024;
+	int rc = tgk_grid_lists(p->d_grid, p->d_bits_dev, ngrid, (uint32_t *)p->d_counts - 3 * nblk, p->d_slot_chan, p->d_slot_sbord,
+				p->d_list_sb, p->d_list_216, p->d_list_432, ents ? p->d_chan_tab : NULL, ents ? p->nchan : 1, stream);
+	if (rc)
+		return rc;
+	for (uint32_t c = 0; c < p->nchan; c++)
+		p->h_last_slot_of_chan[c] = 0xffffffffu;	/* tgpi_plan_set_last_slot() once the bitmap is on the host */
+	p->static_masks = 0;
+	p->static_pending = 0;
+	p->packed_ready = 1;
+	p->block_mode = 0;
+	p->nsb = ngrid;		/* upper bounds: the launches are sized for them, the kernels read d_counts */
+	p->n216 = 2 * ngrid;
+	p->n432 = ngrid;
+	p->loaded = 1;
+	return TGPU_OK;
+}
+
+void tgpi_plan_set_last_slot(struct tgpu_plan *p, uint32_t chan, uint32_t slot)
+{
+	if (p && chan < p->max_chan)
+		p->h_last_slot_of_chan[chan] = slot;
+}
+
+/* buffers of the device walk: per channel a root, a summary and TGW_EVCAP events (device + pinned mirror), node records */
+int tgpi_plan_walk_buffers(struct tgpu_plan *p, struct tg_walk_root **d_roots, struct tg_walk_root **h_roots,
+			   struct tg_walk_sum **d_sums, struct tg_walk_sum **h_sums, void **d_events, void **h_events,
+			   void **d_recs)
+{
+	if (!p)
+		return TGPU_EINVAL;
+	BIND(p->eng);
+	const size_t nc = p->max_chan < 64 ? p->max_chan : 64;
+	const size_t o_sum = nc * sizeof(struct tg_walk_root), o_ev = o_sum + nc * sizeof(struct tg_walk_sum);
+	const size_t bytes = o_ev + nc * (size_t)TGW_EVCAP * sizeof(tgpu_sync_event_rec_dev);
+	if (!p->d_walk) {
+		HCHK(hipMalloc((void **)&p->d_walk, bytes));
+		if (hipHostMalloc((void **)&p->h_walk, bytes, hipHostMallocDefault) != hipSuccess) {
+			p->h_walk = NULL;
+			(void)hipFree(p->d_walk);
+			p->d_walk = NULL;
+			return TGPU_ENOMEM;
+		}
+	}
+	if (!p->d_walk_recs) {
+		hipError_t e = hipMalloc(&p->d_walk_recs, nc * (size_t)(TGW_NCAP + 1) * TGW_REC_BYTES);
+		if (e != hipSuccess) {
+			p->d_walk_recs = NULL;
+			return (int)e;
+		}
+	}
+	*d_roots = (struct tg_walk_root *)p->d_walk;
+	*h_roots = (struct tg_walk_root *)p->h_walk;
+	*d_sums = (struct tg_walk_sum *)(p->d_walk + o_sum);
+	*h_sums = (struct tg_walk_sum *)(p->h_walk + o_sum);
+	*d_events = p->d_walk + o_ev;
+	*h_events = p->h_walk + o_ev;
+	*d_recs = p->d_walk_recs;
+	return TGPU_OK;
+}
+
+uint32_t *tgpi_plan_bits_dev(struct tgpu_plan *p)
+{
+	return p ? p->d_bits_dev : NULL;
 }
 
 int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_off, const uint8_t *slot_type,
@@ -585,7 +711,8 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	MARK(1);
 	if (p->nslots && !p->static_masks) {
 		if ((rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, p->nsb, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, (p->rm_decode ? TGK_F_RM : 0) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0), NULL, stream)))
+				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, (p->rm_decode ? TGK_F_RM : 0) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0),
+				  p->d_counts, stream)))
 			return rc;
 	}
 	MARK(2);
@@ -596,7 +723,8 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	}
 	MARK(3);
 	if (p->nslots && !p->static_masks) {
-		if ((rc = tgk_masks(p->d_chan_code, p->nchan, p->d_sb_ok, p->d_sb_code, p->nsb, p->d_list_sb, p->d_slot_chan, p->d_masks, stream)))
+		if ((rc = tgk_masks_dev(p->d_chan_code, p->nchan, p->d_sb_ok, p->d_sb_code, p->nsb, p->d_counts, p->d_list_sb, p->d_slot_chan,
+					p->d_masks, stream)))
 			return rc;
 	}
 	MARK(4);
@@ -612,8 +740,9 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 			return (int)e_;
 	}
 	const int kf = (p->rm_decode ? TGK_F_RM : 0) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0);
-	const int fast = p->fastpath && !soft;
-	const uint32_t *items216 = p->d_list_216, *items432 = p->d_list_432, *cnt216 = NULL, *cnt432 = NULL;
+	const int fast = p->fastpath && !soft && !p->d_counts;	/* (the clean-block pre-pass wants host-side counts) */
+	const uint32_t *items216 = p->d_list_216, *items432 = p->d_list_432;
+	const uint32_t *cnt216 = p->d_counts ? p->d_counts + 1 : NULL, *cnt432 = p->d_counts ? p->d_counts + 2 : NULL;
 	void *s432 = fork ? (void *)p->side : stream;
 	if (fast && p->nslots) {
 		/* blocks that are code words are finished by k_clean; the trellis kernels get the rest, counted on the device */
@@ -791,6 +920,7 @@ int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t 
 	p->nchan = nu;
 	p->static_masks = 1;
 	p->static_pending = 0;
+	p->d_counts = NULL;
 	p->packed_ready = 0;
 	p->block_mode = 1;
 	p->loaded = 1;

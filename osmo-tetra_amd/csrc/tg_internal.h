@@ -65,6 +65,10 @@ int tgk_fill(const uint32_t *d_slot_chan, const int32_t *d_slot_sbord, const uin
 int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
 	      const uint32_t *d_sb_code, uint32_t nsb, const uint32_t *d_list_sb, const uint32_t *d_slot_chan,
 	      uint32_t *d_masks, void *stream);
+/* d_nsb != NULL: the number of SYNC slots is read from the device, nsb is its upper bound */
+int tgk_masks_dev(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
+		  const uint32_t *d_sb_code, uint32_t nsb, const uint32_t *d_nsb, const uint32_t *d_list_sb,
+		  const uint32_t *d_slot_chan, uint32_t *d_masks, void *stream);
 
 /* out[b][j] = in[b][src[j]] for src[j] >= 0 (tg_reorder.c) */
 int tgk_reorder(const uint8_t *d_in, unsigned long long nblocks, uint32_t nbits, const int32_t *d_src, uint8_t *d_out,
@@ -75,6 +79,22 @@ int tgk_reorder(const uint8_t *d_in, unsigned long long nblocks, uint32_t nbits,
 int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uint32_t n, uint32_t *d_blk,
 		   uint32_t *d_slot_chan, int32_t *d_slot_sbord, uint32_t *d_list_sb, uint32_t *d_list_216,
 		   uint32_t *d_list_432, const struct tg_chan_ent *d_chan /* NULL: one channel */, uint32_t nchan, void *stream);
+
+/* the synchroniser's walk on the device (k_walk, tg_walk_core.h): one workgroup per channel of the table */
+#define TGW_NCAP 8192u	/* nodes (grid slots that are no plain delivery) per channel */
+#define TGW_WCAP 8192u	/* bitmap words per channel: 262 144 grid slots */
+struct tg_walk_root {	/* the stream's first lock (tg_stream.c:find_anchor): buffer start and index of the call that found it */
+	uint64_t found_bs, found_k;
+};
+struct tg_walk_sum {
+	uint32_t nslots, nevents, final_state, tail_tn_adds, burst_seq, status /* TGW_OK / TGW_FALLBACK */, why, nnodes;
+};
+typedef struct { int32_t ev; uint32_t bitnum, arg; } tgpu_sync_event_rec_dev;	/* = struct tgpu_sync_event_rec */
+#define TGW_EVCAP 16384u	/* events per channel the device walk can report */
+#define TGW_REC_BYTES 152u	/* sizeof(struct tgw_rec), checked where it is allocated */
+int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
+	     uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
+	     struct tg_walk_sum *d_sums, void *d_events, uint32_t evcap, void *d_recs, void *stream);
 
 /* optional RM(30,14) decoder (tg_rm.c): coset-leader table (65536 words, built on first use) and the generator's
  * parity rows; tgk_rm_enable() uploads both for the kernels (flag TGK_F_RM of tgk_vit / tgk_bbk_blocks) */
@@ -109,6 +129,16 @@ int tgpi_plan_chan_table(struct tgpu_plan *p, const struct tg_chan_ent *ents, ui
 /* ents == NULL, nchan == 1: one channel owns the grid; else the table given to tgpi_plan_chan_table() */
 int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t nchan, const uint32_t *codes,
 			const struct tg_chan_ent *ents, void *stream);
+
+/* stream mode with the walk on the device (tg_stream.c: tgpu_sync_multi_launch) */
+int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const uint32_t *codes, uint32_t **d_bits_out,
+			      void *stream);
+int tgpi_plan_grid_lists_dev(struct tgpu_plan *p, const struct tg_chan_ent *ents, void *stream);
+void tgpi_plan_set_last_slot(struct tgpu_plan *p, uint32_t chan, uint32_t slot);
+int tgpi_plan_walk_buffers(struct tgpu_plan *p, struct tg_walk_root **d_roots, struct tg_walk_root **h_roots,
+			   struct tg_walk_sum **d_sums, struct tg_walk_sum **h_sums, void **d_events, void **h_events,
+			   void **d_recs);
+uint32_t *tgpi_plan_bits_dev(struct tgpu_plan *p);
 
 #ifdef __cplusplus
 }

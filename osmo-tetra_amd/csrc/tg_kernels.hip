@@ -435,6 +435,7 @@ struct tg_stream_params {
 	uint32_t chunk;		/* bytes per tetra_burst_sync_in() call being emulated */
 	int32_t cshift;		/* log2(chunk) when it is a power of two, else -1 */
 	uint32_t y32, y6, n22, p22;
+	uint32_t q22, x22;	/* first 22 bits of the other two sequences the reference's look-ahead filter passes */
 	/* several recorded channels in one grid (BASELINE config 4: a GPU's share of the channels in one batch): channel
 	 * c owns grid slots gbase .. gbase + ncls - 1 (gbase a multiple of 32, the slots up to the next channel's gbase
 	 * are padding and never decoded); its stream lies at byte d_off of the buffer, anchor / len are relative to it */
@@ -508,13 +509,14 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 		anyb = (((d0 & m0) | (d1 & m1) | (d2 & m2)) & 0xfefefefeu) ? 2u : 0u;
 	}
 
-	uint32_t rc = TG_BURST_NONE, offs = 0, flags = 0, early = 0;
+	uint32_t rc = TG_BURST_NONE, offs = 0, flags = 0;
 	uint32_t ys = TG_YS_NONE;	/* where SYNC sequences start inside this slot, window or not */
-	bool found = false;
+	bool found = false, inview = false;	/* inview: a sequence that ends inside the view, inside the window or not */
 #pragma unroll
 	for (int r = 0; r < 10; r++) {
 		const bool full = (r < 4 || !found) && 64u * r < wv;
-		if (full || r < 8) {
+		const bool look = r >= 7 && !found && 64u * r < vis;	/* nothing so far: anything in the rest of the view? */
+		if (full || r < 8 || look) {
 			const uint32_t c = 64 * r + lane;
 			const uint32_t b0 = (uint32_t)B[r], b1 = (uint32_t)(B[r] >> 32);
 			const uint32_t b2 = (uint32_t)B[r + 1], b3 = (uint32_t)(B[r + 1] >> 32);
@@ -539,6 +541,9 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 						ys |= TG_YS_MULTI;
 				}
 			}
+			if (look)	/* (rounds 0..6: whatever starts there ends inside every window) */
+				inview = inview || __ballot((y38 && c + 38 <= vis) ||
+							    (((win & 0x3fffff) == prm.n22 || (win & 0x3fffff) == prm.p22) && c + 22 <= vis)) != 0;
 			if (full) {
 				/* the window holds at least 510 bytes: rounds 0..6 (c + 38 <= 485) need no bound */
 				const bool in38 = (r < 7) || (c + 38 <= w), in22 = (r < 7) || (c + 22 <= w);
@@ -546,9 +551,26 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 				const bool isn = ((win & 0x3fffff) == prm.n22) && in22;
 				const bool isp = ((win & 0x3fffff) == prm.p22) && in22;
 				const bool any = isy || isn || isp;
-				if (r == 0)
-					early = __ballot(any && c < 21) != 0;
-				const unsigned long long m = __ballot(any && c >= 21);
+				unsigned long long m = __ballot(any && c >= 21);
+				if (r == 0) {
+					/* positions below 21: the reference gates every position with a 22-bit look-ahead window that
+					 * is primed with in[0..19] and then fed in[cur + 21], i.e. until cur = 21 it holds the stream
+					 * with in[20] missing (phy/tetra_burst.c:289-297).  A sequence that starts there counts iff that
+					 * skewed window equals the first 22 bits of ANY of the five training sequences: e_0..e_21 =
+					 * in[c-1..19], in[21..c+21] (c = 0: a zero, in[0..19], in[21]) */
+					const unsigned long long S = B[0];
+					const uint32_t cc = lane < 21 ? lane : 20;
+					uint32_t X;
+					if (cc == 0)
+						X = (((uint32_t)S & 0xfffffu) << 1) | ((uint32_t)(S >> 21) & 1u) << 21;
+					else
+						X = ((uint32_t)(S >> (cc - 1)) & ((1u << (21 - cc)) - 1u)) |
+						    (((uint32_t)(S >> 21) & ((1u << (cc + 1)) - 1u)) << (21 - cc));
+					const bool gate = X == (prm.y32 & 0x3fffffu) || X == prm.n22 || X == prm.p22 || X == prm.q22 || X == prm.x22;
+					const unsigned long long me = __ballot(any && c < 21 && gate);
+					if (me)
+						m = me;		/* the first accepted one wins over anything from 21 on */
+				}
 				if (!found && m) {
 					const uint32_t l0 = __builtin_ctzll(m);
 					offs = 64 * r + l0;
@@ -559,12 +581,12 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 			}
 		}
 	}
-	if (early)
-		flags |= TG_CLS_EARLY21;
 	if (__ballot(anyb > 1))
 		flags |= TG_CLS_NONBINARY;
 	if (!found && w > TG_STREAM_VIEW)
 		flags |= TG_CLS_CLIPPED;
+	if (!found && !inview)
+		flags |= TG_CLS_NOVIEW;
 
 	/* what tetra_burst_sync_in() would hand to tetra_burst_rx_cb() (phy/tetra_burst_sync.c:121-141) */
 	uint32_t dtype = TG_BURST_NONE;
@@ -962,13 +984,15 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			ys |= TG_YS_MULTI;
 		if (!yb)
 			ys = TG_YS_NONE;
-		const bool dfr = defer_all || a == 0;
+		/* a sequence below offset 21 is accepted or not by the reference's skewed look-ahead window: the exact pass
+		 * evaluates that rule (rare: a payload coincidence, about ten slots in a million) */
+		const bool dfr = defer_all || a == 0 || early;
 		uint32_t dtype = TG_BURST_NONE;
 		if (rc == TG_BURST_SYNC ? offs == TG_SYNC_TRAIN_OFF : offs == TG_NORM_TRAIN_OFF)
 			dtype = rc;
 		if (dfr)
 			dtype = TG_BURST_NONE;
-		const uint32_t clsword = dfr ? TG_CLS_DEFER : (rc | (offs << 8) | (early ? (uint32_t)TG_CLS_EARLY21 << 24 : 0u));
+		const uint32_t clsword = dfr ? TG_CLS_DEFER : (rc | (offs << 8));
 		const uint32_t meta = dfr ? 0u : (dtype | (offs << 16));
 
 		const uint32_t first = 4u * g;
@@ -2616,8 +2640,10 @@ void k_fill_apply(const uint32_t *slot_chan, const int32_t *slot_sbord, const ui
 /* ------------------------------------------------------------------------- */
 __global__ __launch_bounds__(256)
 void k_masks(const uint32_t *chan_code, uint32_t nchan, const uint32_t *sb_ok, const uint32_t *sb_code,
-	     uint32_t nsb, const uint32_t *list_sb, const uint32_t *slot_chan, uint32_t *masks)
+	     uint32_t nsb, const uint32_t *nsb_dev, const uint32_t *list_sb, const uint32_t *slot_chan, uint32_t *masks)
 {
+	if (nsb_dev)		/* the number of SYNC slots was counted on the device (nsb = its upper bound) */
+		nsb = *nsb_dev;
 	/* a wavefront keeps the linear-form masks of its 18 x 64 output bits in registers, looks at 64 entries at a
 	 * time and builds the ones a slot can point at: entry 0, the channel carry-ins, and the SYNC slots that decoded
 	 * (CRC) to a code other than their predecessor's (sb_redundant) -- per built entry 18 x (and, popcount, ballot)
@@ -2918,6 +2944,8 @@ extern "C" int tgk_bbk_blocks(const uint32_t *d_items, uint32_t nitems, const ui
 static const uint8_t tsq_n[22] = { 1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0 };
 static const uint8_t tsq_p[22] = { 0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0 };
 static const uint8_t tsq_y[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
+static const uint8_t tsq_q[22] = { 1,0,1,1,0,1,1,1,0,0,0,0,0,1,1,0,1,0,1,1,0,1 };
+static const uint8_t tsq_x[30] = { 1,0,0,1,1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0,0,0,1,1 };
 
 static uint32_t host_pattern_bits(const uint8_t *seq, int from, int n)
 {
@@ -2977,6 +3005,8 @@ static void stream_patterns(tg_stream_params &prm, uint32_t chunk)
 	prm.y6 = host_pattern_bits(tsq_y, 32, 6);
 	prm.n22 = host_pattern_bits(tsq_n, 0, 22);
 	prm.p22 = host_pattern_bits(tsq_p, 0, 22);
+	prm.q22 = host_pattern_bits(tsq_q, 0, 22);
+	prm.x22 = host_pattern_bits(tsq_x, 0, 22);
 }
 
 /* ev_mid (optional hipEvent_t): recorded between the packed-bit kernel and its fix-up pass (per-kernel timing) */
@@ -3303,15 +3333,361 @@ extern "C" int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uin
 	return (int)hipGetLastError();
 }
 
-extern "C" int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
-			 const uint32_t *d_sb_code, uint32_t nsb, const uint32_t *d_list_sb, const uint32_t *d_slot_chan,
-			 uint32_t *d_masks, void *stream)
+extern "C" int tgk_masks_dev(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
+			     const uint32_t *d_sb_code, uint32_t nsb, const uint32_t *d_nsb, const uint32_t *d_list_sb,
+			     const uint32_t *d_slot_chan, uint32_t *d_masks, void *stream)
 {
 	const uint32_t nent = 1 + nchan + nsb;
 	uint32_t blocks = ((nent + 63) / 64 + 3) / 4;	/* a wave per 64 entries */
 	if (blocks > 2048)
 		blocks = 2048;
 	hipLaunchKernelGGL(k_masks, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_chan_code, nchan, d_sb_ok, d_sb_code, nsb,
-			   d_list_sb, d_slot_chan, d_masks);
+			   d_nsb, d_list_sb, d_slot_chan, d_masks);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_sb_ok,
+			 const uint32_t *d_sb_code, uint32_t nsb, const uint32_t *d_list_sb, const uint32_t *d_slot_chan,
+			 uint32_t *d_masks, void *stream)
+{
+	return tgk_masks_dev(d_chan_code, nchan, d_sb_ok, d_sb_code, nsb, NULL, d_list_sb, d_slot_chan, d_masks, stream);
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_walk: the burst synchroniser's walk over a classified grid, on the device */
+/* ------------------------------------------------------------------------- */
+/*
+ * tetra_burst_sync_in() (phy/tetra_burst_sync.c:54-154) per channel, from the classification words, the SYNC
+ * summaries and k_cls_plain's bitmap, without the host: what tg_stream.c:sync_walk() computes in grid mode
+ * (delivered bitmap, events, counts, final state), in the node form of tg_walk_core.h.
+ *
+ * One workgroup of 1024 threads per channel; bitmap, node list and arrival pointers live in LDS:
+ *   A  the channel's plain bitmap -> LDS; nodes = its zero bits; per-word prefix counts (block scan)
+ *   B  node list (slot of the i-th node)
+ *   C  every node through tgw_run(), one lane each (a dozen dependent reads of cls / ysum per node: latency bound,
+ *      hidden by the thousand lanes); the stream's head (the first lock, found on the host) likewise; arrival slot
+ *      -> index of the first node at or after it
+ *   D  which nodes does the walk visit?  reachability from the head's arrival along the arrival pointers: pointer
+ *      doubling, marks {succ^n(head) : n < 2^r} after r rounds
+ *   E  delivered bitmap = plain bitmap - spans of the visited nodes [slot, arrival) + their own deliveries
+ *   F  bitmap -> global, number of delivered bursts, last delivered slot
+ *   G  events of the visited nodes in slot order (block scan of the counts), bursts handled but not delivered,
+ *      those after the last delivery (tail_tn_adds), final state
+ * A channel with more than TGW_NCAP nodes or TGW_WCAP bitmap words, or whose walk meets something only the bytes can
+ * settle (tg_walk_core.h), reports TGW_FALLBACK: the host walk takes over.
+ */
+#include "tg_walk_core.h"
+static_assert(sizeof(tgw_rec) <= TGW_REC_BYTES, "TGW_REC_BYTES");
+
+#define TGW_THREADS 1024
+#define TGW_LDS_BYTES (TGW_WCAP * 4 + TGW_NCAP * 4 + TGW_WCAP * 2 + 2 * (TGW_NCAP + 8) * 2 + 2 * (TGW_NCAP + 8))
+
+__device__ __forceinline__ uint32_t tgw_block_excl_scan(uint32_t v, uint32_t *sm /* 17 words */, uint32_t &total)
+{
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	uint32_t inc = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = __shfl_up(inc, d);
+		if (lane >= (uint32_t)d)
+			inc += o;
+	}
+	__syncthreads();	/* sm may still be read from the previous scan */
+	if (lane == 63)
+		sm[w] = inc;
+	__syncthreads();
+	uint32_t pre = 0, tot = 0;
+	for (uint32_t q = 0; q < TGW_THREADS / 64; q++) {
+		const uint32_t x = sm[q];
+		if (q < w)
+			pre += x;
+		tot += x;
+	}
+	total = tot;
+	return pre + inc - v;
+}
+
+__global__ __launch_bounds__(TGW_THREADS)
+void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan, const tg_walk_root *__restrict__ roots,
+	    uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
+	    const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, tg_walk_sum *__restrict__ sums,
+	    tgpu_sync_event_rec_dev *__restrict__ g_events, uint32_t evcap, tgw_rec *__restrict__ g_recs)
+{
+	extern __shared__ uint32_t s_dyn[];
+	uint32_t *bm = s_dyn;
+	uint32_t *nslot = bm + TGW_WCAP;
+	uint16_t *wpre = (uint16_t *)(nslot + TGW_NCAP);
+	uint16_t *Ja = wpre + TGW_WCAP, *Jb = Ja + TGW_NCAP + 8;
+	uint8_t *mark = (uint8_t *)(Jb + TGW_NCAP + 8);
+	uint8_t *evc = mark + TGW_NCAP + 8;
+	__shared__ uint32_t sm[20];
+	__shared__ uint32_t s_head, s_fb, s_why, s_nd, s_tail, s_last, s_lastdel, s_ns;
+
+	const uint32_t c = blockIdx.x, tid = threadIdx.x;
+	const tg_chan_ent ce = chan[c];
+	const tg_walk_root rt = roots[c];
+	tg_walk_sum *sum = sums + c;
+	tgw_rec *recs = g_recs + (size_t)c * (TGW_NCAP + 1);
+	tgpu_sync_event_rec_dev *events = g_events + (size_t)c * evcap;
+	const uint32_t ncls = ce.ncls, W = (ncls + 31) >> 5, w0 = ce.gbase >> 5;
+
+	if (tid == 0) {
+		s_head = 0xffffffffu;
+		s_fb = 0;
+		s_why = 0;
+		s_nd = s_tail = 0;
+		s_last = 0;		/* 1 + index of the last visited node (0: only the head run) */
+		s_lastdel = 0;
+		s_ns = 0;
+	}
+	__syncthreads();
+	if (!ncls || W > TGW_WCAP) {	/* nothing classified (the host settles such a channel) or too long for one workgroup */
+		if (tid == 0) {
+			sum->nslots = sum->nevents = sum->tail_tn_adds = sum->burst_seq = 0;
+			sum->final_state = TGW_S_UNLOCKED;
+			sum->status = ncls ? TGW_FALLBACK : TGW_OK;
+			sum->why = ncls ? TGW_WHY_SIZE : 0;
+			sum->nnodes = 0;
+		}
+		return;
+	}
+	tgw_chan wc;
+	wc.cls = g_cls + ce.gbase;
+	wc.ysum = g_ysum + ce.gbase;
+	wc.s = d_base + ce.d_off;
+	wc.len = ce.len;
+	wc.anchor = ce.anchor;
+	wc.ncalls = (ce.len + chunk - 1) >> cshift;
+	wc.ncls = ncls;
+	wc.chunk = chunk;
+	wc.cshift = cshift;
+
+	/* A: bitmap -> LDS (bits at and past ncls read "plain" so that they are no nodes; they are cleared again in F) */
+	constexpr uint32_t WPT = TGW_WCAP / TGW_THREADS;	/* consecutive words per thread */
+	uint32_t cnt = 0;
+#pragma unroll
+	for (uint32_t q = 0; q < WPT; q++) {
+		const uint32_t w = WPT * tid + q;
+		if (w < W) {
+			uint32_t v = g_plain[w0 + w];
+			if (w == W - 1 && (ncls & 31))
+				v |= ~0u << (ncls & 31);
+			bm[w] = v;
+			cnt += __popc(~v);
+		}
+	}
+	uint32_t N;
+	uint32_t base = tgw_block_excl_scan(cnt, sm, N);
+	if (N > TGW_NCAP) {
+		if (tid == 0) {
+			sum->nslots = sum->nevents = sum->tail_tn_adds = sum->burst_seq = 0;
+			sum->final_state = TGW_S_UNLOCKED;
+			sum->status = TGW_FALLBACK;
+			sum->why = TGW_WHY_NODES;
+			sum->nnodes = N;
+		}
+		return;
+	}
+	/* B: prefix counts per word, node list */
+#pragma unroll
+	for (uint32_t q = 0; q < WPT; q++) {
+		const uint32_t w = WPT * tid + q;
+		if (w < W) {
+			wpre[w] = (uint16_t)base;
+			uint32_t z = ~bm[w];
+			while (z) {
+				const uint32_t b = __builtin_ctz(z);
+				z &= z - 1;
+				nslot[base++] = 32 * w + b;
+			}
+		}
+	}
+	__syncthreads();
+	auto rank = [&](uint32_t t) -> uint32_t {	/* index of the first node at or after grid slot t */
+		if (t >= ncls)
+			return N;
+		const uint32_t w = t >> 5;
+		return (uint32_t)wpre[w] + __popc(~bm[w] & ((1u << (t & 31)) - 1u));
+	};
+	/* C: every node, and the stream's head */
+	for (uint32_t i = tid; i < N; i += TGW_THREADS) {
+		const uint64_t bs = wc.anchor + (uint64_t)nslot[i] * TG_SLOT_BITS;
+		const uint64_t kc = (bs + TG_SLOT_BITS + chunk - 1) >> cshift;
+		tgw_rec r;
+		tgw_run(&wc, TGW_S_LOCKED, bs, bs + TG_SLOT_BITS, kc - 1, &r);
+		recs[i] = r;
+		Ja[i] = (uint16_t)(r.status == TGW_OK ? rank(r.next) : N);
+	}
+	if (tid == TGW_THREADS - 1) {
+		tgw_rec r;
+		tgw_run(&wc, TGW_S_KNOW_FSTART, rt.found_bs, wc.anchor, rt.found_k, &r);
+		recs[TGW_NCAP] = r;
+		if (r.status != TGW_OK) {
+			s_fb = 1;
+			s_why = r.why;
+		} else
+			s_head = rank(r.next);
+	}
+	if (tid == 0)
+		Ja[N] = Jb[N] = (uint16_t)N;
+	for (uint32_t i = tid; i <= N; i += TGW_THREADS)
+		mark[i] = 0;
+	__syncthreads();
+	/* D: reachability from the head along the arrival pointers */
+	{
+		const uint32_t head = s_head;
+		if (tid == 0 && head < N)
+			mark[head] = 1;
+		__syncthreads();
+		uint16_t *J = Ja, *Jn = Jb;
+		for (uint32_t span = 1; span <= N; span <<= 1) {
+			for (uint32_t v = tid; v < N; v += TGW_THREADS)
+				if (mark[v] && J[v] < N)
+					mark[J[v]] = 1;
+			for (uint32_t v = tid; v < N; v += TGW_THREADS) {
+				const uint32_t j = J[v];
+				Jn[v] = j < N ? J[j] : (uint16_t)N;
+			}
+			__syncthreads();
+			uint16_t *t = J;
+			J = Jn;
+			Jn = t;
+		}
+	}
+	/* E: spans of the visited nodes (and of the head run) leave the bitmap, their own deliveries enter it */
+	auto clear_span = [&](uint32_t from, uint32_t to) {	/* grid slots [from, to) */
+		if (to > ncls)
+			to = ncls;
+		while (from < to) {
+			const uint32_t w = from >> 5, b = from & 31;
+			const uint32_t n = (32 - b < to - from) ? 32 - b : to - from;
+			const uint32_t m = (n == 32 ? 0xffffffffu : ((1u << n) - 1u)) << b;
+			atomicAnd(&bm[w], ~m);
+			from += n;
+		}
+	};
+	for (uint32_t i = tid; i < N; i += TGW_THREADS)
+		if (mark[i]) {
+			const tgw_rec *r = recs + i;
+			if (r->status != TGW_OK) {
+				s_fb = 1;
+				s_why = r->why;
+			}
+			clear_span(nslot[i], r->next);
+			atomicMax(&s_last, i + 1);
+		}
+	if (tid == TGW_THREADS - 1 && !s_fb)
+		clear_span(0, recs[TGW_NCAP].next);
+	__syncthreads();
+	if (s_fb) {
+		if (tid == 0) {
+			sum->nslots = sum->nevents = sum->tail_tn_adds = sum->burst_seq = 0;
+			sum->final_state = TGW_S_UNLOCKED;
+			sum->status = TGW_FALLBACK;
+			sum->why = s_why;
+			sum->nnodes = N;
+		}
+		return;
+	}
+	for (uint32_t i = tid; i < N + 1; i += TGW_THREADS) {
+		const bool root = (i == N);
+		if (root || mark[i]) {
+			const tgw_rec *r = recs + (root ? TGW_NCAP : i);
+			for (uint32_t d = 0; d < r->ndel; d++)
+				atomicOr(&bm[r->del[d] >> 5], 1u << (r->del[d] & 31));
+		}
+	}
+	__syncthreads();
+	/* F: bitmap out, delivered bursts, last delivered slot */
+	{
+		uint32_t ns = 0, lastd = 0xffffffffu;
+#pragma unroll
+		for (uint32_t q = 0; q < WPT; q++) {
+			const uint32_t w = WPT * tid + q;
+			if (w < W) {
+				uint32_t v = bm[w];
+				if (w == W - 1 && (ncls & 31))
+					v &= (1u << (ncls & 31)) - 1u;
+				g_bits[w0 + w] = v;
+				ns += __popc(v);
+				if (v)
+					lastd = 32 * w + 31 - __builtin_clz(v);
+			}
+		}
+		if (ns)
+			atomicAdd(&s_ns, ns);
+		if (lastd != 0xffffffffu)
+			atomicMax(&s_lastdel, lastd + 1);	/* 1 + last delivered slot, 0 = none */
+	}
+	__syncthreads();
+	/* G: events in slot order */
+	constexpr uint32_t NPT = TGW_NCAP / TGW_THREADS;
+	const tgw_rec *root = recs + TGW_NCAP;
+	uint32_t ecnt = 0;
+#pragma unroll
+	for (uint32_t q = 0; q < NPT; q++) {
+		const uint32_t i = NPT * tid + q;
+		if (i < N && mark[i])
+			ecnt += recs[i].nev;
+	}
+	uint32_t etot;
+	uint32_t eoff = tgw_block_excl_scan(ecnt, sm, etot) + root->nev;
+	etot += root->nev;
+	const uint32_t lastdel = s_lastdel;
+	uint32_t nd = 0, tail = 0;
+	auto emit = [&](const tgw_rec *r, uint32_t at) {
+		for (uint32_t e = 0; e < r->nev; e++) {
+			if (at + e < evcap) {
+				events[at + e].ev = (int32_t)r->ev[e][0];
+				events[at + e].bitnum = r->ev[e][1];
+				events[at + e].arg = r->ev[e][2];
+			}
+			if (r->evslot[e] != TGW_NOSLOT) {
+				nd++;
+				if (r->evslot[e] + 1 > lastdel)
+					tail++;
+			}
+		}
+	};
+	if (tid == TGW_THREADS - 1)
+		emit(root, 0);
+#pragma unroll
+	for (uint32_t q = 0; q < NPT; q++) {
+		const uint32_t i = NPT * tid + q;
+		if (i < N && mark[i]) {
+			emit(recs + i, eoff);
+			eoff += recs[i].nev;
+		}
+	}
+	if (nd)
+		atomicAdd(&s_nd, nd);
+	if (tail)
+		atomicAdd(&s_tail, tail);
+	__syncthreads();
+	if (tid == 0) {
+		const tgw_rec *lastrec = s_last ? recs + (s_last - 1) : root;
+		sum->nslots = s_ns;
+		sum->nevents = etot;
+		sum->final_state = lastrec->next == TGW_END ? lastrec->end_state : TGW_S_LOCKED;
+		sum->tail_tn_adds = s_tail;
+		sum->burst_seq = s_ns + s_nd;
+		sum->status = etot > evcap ? TGW_FALLBACK : TGW_OK;
+		sum->why = etot > evcap ? TGW_WHY_EVENTS : 0;
+		sum->nnodes = N;
+	}
+}
+
+extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
+			uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
+			struct tg_walk_sum *d_sums, void *d_events, uint32_t evcap, void *d_recs, void *stream)
+{
+	if (!nchan)
+		return 0;
+	if (!chunk || (chunk & (chunk - 1)))
+		return -1;
+	HIPCHK(hipFuncSetAttribute((const void *)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
+	hipLaunchKernelGGL(k_walk, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, (hipStream_t)stream, d_base, d_chan, d_roots, chunk,
+			   (uint32_t)__builtin_ctz(chunk), d_cls, d_ysum, d_plain, d_bits, d_sums,
+			   (tgpu_sync_event_rec_dev *)d_events, evcap, (tgw_rec *)d_recs);
 	return (int)hipGetLastError();
 }

@@ -63,13 +63,18 @@
  *   bits 0..7   first training sequence found in the search window (enum tetra_train_seq) or 0xff
  *   bits 8..23  its offset
  *   bits 24..31 TG_CLS_* flags
- * Semantics = tetra_find_train_seq(slot, w, NORM_1|NORM_2|SYNC) of the reference restricted to
- * positions >= 21; a hit below 21 (where the reference's look-ahead filter is skewed) only raises
- * TG_CLS_EARLY21 and is settled on the host with the exact routine.
+ * Semantics = tetra_find_train_seq(slot, w, NORM_1|NORM_2|SYNC) of the reference for the steady-state window w,
+ * including its rule for positions below 21, where the look-ahead filter is skewed (phy/tetra_burst.c:289-297: a
+ * sequence there counts iff the filter -- the stream with in[20] missing -- equals the head of one of the five
+ * training sequences); round 3: the kernels evaluate that rule themselves.  TG_CLS_EARLY21 is what a producer that does
+ * not (the round-1/2 kernels, a simplified model) sets instead: "a full match exists below 21, ask the exact routine".
  */
-#define TG_CLS_EARLY21    0x01	/* a full match exists at an offset < 21 */
+#define TG_CLS_EARLY21    0x01	/* a full match exists at an offset < 21 and was NOT evaluated */
 #define TG_CLS_NONBINARY  0x02
 #define TG_CLS_CLIPPED    0x04	/* window longer than the kernel's 640-byte view and nothing found in view */
+#define TG_CLS_NOVIEW     0x08	/* nothing found, and nothing in the rest of the 640-byte view (bounded by the stream's end)
+				 * either: "nothing" is then also the answer for any longer window up to the view -- what the
+				 * synchroniser searches while it works off a backlog (tg_walk_core.h) */
 /* SYNC-sequence summary of a grid slot (uint16): where the 38-bit y sequence starts inside the slot's own
  * 510 positions, regardless of any search window -- what an UNLOCKED synchroniser scans for */
 #define TG_YS_NONE        0xffffu	/* no y sequence starts in this slot */

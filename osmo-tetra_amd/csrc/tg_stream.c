@@ -35,6 +35,7 @@
 #include "tetra_gpu.h"
 #include "tg_layout.h"
 #include "tg_internal.h"
+#include "tg_walk_core.h"
 
 #define MASK_LOCKED ((1u << TETRA_TRAIN_NORM_1) | (1u << TETRA_TRAIN_NORM_2) | (1u << TETRA_TRAIN_SYNC))
 
@@ -675,7 +676,18 @@ void tgpu_sync_result_free(struct tgpu_sync_result *r)
 }
 
 /* first lock of a stream, host only: where the slot grid starts (0 if the stream never locks) */
+static int find_anchor_root(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t *anchor, int *locks,
+			    struct tg_walk_root *root);
+
 static int find_anchor(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t *anchor, int *locks)
+{
+	return find_anchor_root(h_stream, len, chunk, anchor, locks, NULL);
+}
+
+/* root (optional): buffer start and index of the call that finds the first SYNC sequence -- where the device walk
+ * (k_walk) takes over */
+static int find_anchor_root(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t *anchor, int *locks,
+			    struct tg_walk_root *root)
 {
 	/* run the walk without classification until the first LOCKED burst: cheap, it stops early */
 	struct walk w = { h_stream, len, chunk, (len + chunk - 1) / chunk, NULL, 0, 0, NULL, 0, 0, NULL, NULL, 0,
@@ -691,6 +703,10 @@ static int find_anchor(const uint8_t *h_stream, uint64_t len, uint32_t chunk, ui
 		if (exact_find(&w, b, (uint32_t)(f - b), 1u << TETRA_TRAIN_SYNC, &offs) >= 0) {
 			*anchor = b + offs + 296;
 			*locks = 1;
+			if (root) {
+				root->found_bs = b;
+				root->found_k = kk;
+			}
 			return TGPU_OK;
 		}
 	}
@@ -1162,4 +1178,191 @@ int tgpu_sync_stream_grid(struct tgpu_engine *eng, struct tgpu_plan *plan, const
 	if (rc)
 		return rc;
 	return tgpu_sync_stream_grid_finish(eng, plan, h_stream, len, chunk, flags, scramb_init, out, stream);
+}
+
+/* ------------------------------------------------------------------------- */
+/* the walk in the form the device runs it (k_walk), on the host              */
+/* ------------------------------------------------------------------------- */
+/*
+ * tgpu_sync_walk_emul(): k_walk's phases one after the other on the CPU, over the same tg_walk_core.h -- nodes from
+ * the plain bitmap, every node through tgw_run(), reachability by pointer doubling, bitmap / events / counts from
+ * the visited nodes.  Same outputs as tgpu_sync_walk_plain(..., TGPU_SYNC_GRID | TGPU_SYNC_NO_BURST_EVENTS) whenever
+ * *status comes back 0; *status = 1 (TGW_FALLBACK, *why = TGW_WHY_*) where the device form hands the channel to the
+ * host walk.  This is what the CPU tests fuzz against sync_walk() and the oracle; it is not a product path.
+ */
+int tgpu_sync_walk_emul(const uint8_t *h_stream, uint64_t len, uint32_t chunk, uint64_t anchor, const uint32_t *cls,
+			const uint16_t *ysum, const uint32_t *plain, uint32_t ncls, struct tgpu_sync_result *out, int *status,
+			int *why)
+{
+	if (!h_stream || !out || !cls || !ysum || !plain || !ncls || !status || !why || !chunk || (chunk & (chunk - 1)) ||
+	    chunk < TGPU_SYNC_CHUNK_MIN || chunk > TGPU_SYNC_CHUNK_MAX)
+		return TGPU_EINVAL;
+	memset(out, 0, sizeof(*out));
+	*status = TGW_OK;
+	*why = 0;
+	uint64_t a2 = 0;
+	int locks = 0;
+	struct tg_walk_root root = { 0, 0 };
+	int rc = find_anchor_root(h_stream, len, chunk, &a2, &locks, &root);
+	if (rc)
+		return rc;
+	if (!locks || a2 != anchor)
+		return TGPU_EINVAL;
+	const uint32_t W = (ncls + 31) / 32;
+	if (W > TGW_WCAP) {
+		*status = TGW_FALLBACK;
+		*why = TGW_WHY_SIZE;
+		return TGPU_OK;
+	}
+	struct tgw_chan wc = { cls, ysum, h_stream, len, anchor, (len + chunk - 1) / chunk, ncls, chunk, (uint32_t)__builtin_ctz(chunk) };
+	uint32_t *bm = malloc((size_t)W * 4), *wpre = malloc((size_t)W * 4);
+	uint32_t *nslot = malloc((size_t)TGW_NCAP * 4);
+	uint16_t *Ja = malloc((TGW_NCAP + 8) * 2), *Jb = malloc((TGW_NCAP + 8) * 2);
+	uint8_t *mark = calloc(TGW_NCAP + 8, 1);
+	struct tgw_rec *recs = malloc(((size_t)TGW_NCAP + 1) * sizeof(*recs));
+	rc = TGPU_ENOMEM;
+	if (!bm || !wpre || !nslot || !Ja || !Jb || !mark || !recs)
+		goto done;
+	rc = TGPU_OK;
+	/* A, B */
+	uint32_t N = 0;
+	for (uint32_t w = 0; w < W; w++) {
+		uint32_t v = plain[w];
+		if (w == W - 1 && (ncls & 31))
+			v |= ~0u << (ncls & 31);
+		bm[w] = v;
+		wpre[w] = N;
+		for (uint32_t z = ~v; z; z &= z - 1) {
+			if (N < TGW_NCAP)
+				nslot[N] = 32 * w + (uint32_t)__builtin_ctz(z);
+			N++;
+		}
+	}
+	if (N > TGW_NCAP) {
+		*status = TGW_FALLBACK;
+		*why = TGW_WHY_NODES;
+		goto done;
+	}
+#define RANK(t) ((t) >= ncls ? N : wpre[(t) >> 5] + (uint32_t)__builtin_popcount(~bm[(t) >> 5] & ((1u << ((t) & 31)) - 1u)))
+	/* C */
+	for (uint32_t i = 0; i < N; i++) {
+		const uint64_t bs = anchor + (uint64_t)nslot[i] * TG_SLOT_BITS;
+		const uint64_t kc = (bs + TG_SLOT_BITS + chunk - 1) >> wc.cshift;
+		tgw_run(&wc, TGW_S_LOCKED, bs, bs + TG_SLOT_BITS, kc - 1, &recs[i]);
+		Ja[i] = (uint16_t)(recs[i].status == TGW_OK ? RANK(recs[i].next) : N);
+	}
+	struct tgw_rec *rr = &recs[TGW_NCAP];
+	tgw_run(&wc, TGW_S_KNOW_FSTART, root.found_bs, anchor, root.found_k, rr);
+	if (rr->status != TGW_OK) {
+		*status = TGW_FALLBACK;
+		*why = rr->why;
+		goto done;
+	}
+	const uint32_t head = RANK(rr->next);
+#undef RANK
+	Ja[N] = Jb[N] = (uint16_t)N;
+	/* D */
+	if (head < N)
+		mark[head] = 1;
+	{
+		uint16_t *J = Ja, *Jn = Jb;
+		for (uint32_t span = 1; span <= N; span <<= 1) {
+			for (uint32_t v = 0; v < N; v++)
+				if (mark[v] && J[v] < N)
+					mark[J[v]] = 1;
+			for (uint32_t v = 0; v < N; v++)
+				Jn[v] = J[v] < N ? J[J[v]] : (uint16_t)N;
+			uint16_t *t = J;
+			J = Jn;
+			Jn = t;
+		}
+	}
+	/* E */
+	uint32_t lastnode = 0;
+	for (uint32_t i = 0; i <= N; i++) {
+		const int isroot = (i == N);
+		if (!isroot && !mark[i])
+			continue;
+		const struct tgw_rec *r = isroot ? rr : &recs[i];
+		if (r->status != TGW_OK) {
+			*status = TGW_FALLBACK;
+			*why = r->why;
+			goto done;
+		}
+		uint32_t from = isroot ? 0 : nslot[i], to = r->next > ncls ? ncls : r->next;
+		for (; from < to; from++)
+			bm[from >> 5] &= ~(1u << (from & 31));
+		if (!isroot)
+			lastnode = i + 1;
+	}
+	for (uint32_t i = 0; i <= N; i++) {
+		const int isroot = (i == N);
+		if (!isroot && !mark[i])
+			continue;
+		const struct tgw_rec *r = isroot ? rr : &recs[i];
+		for (uint32_t d = 0; d < r->ndel; d++)
+			bm[r->del[d] >> 5] |= 1u << (r->del[d] & 31);
+	}
+	/* F */
+	uint32_t ns = 0, lastdel = 0;
+	if (ncls & 31)
+		bm[W - 1] &= (1u << (ncls & 31)) - 1u;
+	for (uint32_t w = 0; w < W; w++) {
+		ns += (uint32_t)__builtin_popcount(bm[w]);
+		if (bm[w])
+			lastdel = 32 * w + 32 - (uint32_t)__builtin_clz(bm[w]);
+	}
+	/* G */
+	uint32_t etot = rr->nev;
+	for (uint32_t i = 0; i < N; i++)
+		if (mark[i])
+			etot += recs[i].nev;
+	if (etot > TGW_EVCAP) {
+		*status = TGW_FALLBACK;
+		*why = TGW_WHY_EVENTS;
+		goto done;
+	}
+	out->events = malloc((size_t)(etot ? etot : 1) * sizeof(*out->events));
+	if (!out->events) {
+		rc = TGPU_ENOMEM;
+		goto done;
+	}
+	uint32_t nd = 0, tail = 0, e = 0;
+	for (uint32_t i = 0; i <= N; i++) {
+		const uint32_t j = i ? i - 1 : N;	/* the head run first, then the nodes in slot order */
+		if (j != N && !mark[j])
+			continue;
+		const struct tgw_rec *r = j == N ? rr : &recs[j];
+		for (uint32_t q = 0; q < r->nev; q++, e++) {
+			out->events[e].ev = (int32_t)r->ev[q][0];
+			out->events[e].bitnum = r->ev[q][1];
+			out->events[e].arg = r->ev[q][2];
+			if (r->evslot[q] != TGW_NOSLOT) {
+				nd++;
+				if (r->evslot[q] + 1 > lastdel)
+					tail++;
+			}
+		}
+	}
+	out->nevents = etot;
+	out->nslots = ns;
+	out->ngrid = ncls;
+	out->anchor = anchor;
+	out->burst_seq = ns + nd;
+	out->tail_tn_adds = tail;
+	{
+		const struct tgw_rec *lr = lastnode ? &recs[lastnode - 1] : rr;
+		out->final_state = lr->next == TGW_END ? lr->end_state : RX_S_LOCKED;
+	}
+	out->grid_bits = bm;
+	bm = NULL;
+done:
+	free(bm);
+	free(wpre);
+	free(nslot);
+	free(Ja);
+	free(Jb);
+	free(mark);
+	free(recs);
+	return rc;
 }

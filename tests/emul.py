@@ -72,3 +72,28 @@ def conv_decode(pu, mother, type3, type2_len):
     out = np.zeros(type2_len, np.uint8)
     rc = lib().emul_conv_decode(pu, mother, len(t3), type2_len, t3.ctypes.data_as(u8p), out.ctypes.data_as(u8p))
     return None if rc else out
+
+
+# ---- classification words / SYNC summaries of a 0 / 1 stream (tests/host_emul/cls_emul.c) ----
+CLS_SRC = os.path.join(HERE, "host_emul", "cls_emul.c")
+CLS_LIB = os.path.join(HERE, "host_emul", "libcls_emul.so")
+_cls_lib = None
+
+
+def cls_ysum(stream, anchor, chunk, view=640):
+    """(cls, ysum) as tests/test_stream_sync_cpu.py's emul_cls / emul_ysum give them, in C: streams of bench size"""
+    global _cls_lib
+    if _cls_lib is None:
+        if not os.path.exists(CLS_LIB) or os.path.getmtime(CLS_SRC) > os.path.getmtime(CLS_LIB):
+            subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", CLS_SRC, "-o", CLS_LIB])
+        _cls_lib = C.CDLL(CLS_LIB)
+        _cls_lib.emul_cls_ysum.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p, C.POINTER(C.c_uint16)]
+        _cls_lib.emul_cls_ysum.restype = None
+    s = np.ascontiguousarray(stream, np.uint8)
+    L = len(s)
+    n = (L - anchor) // 510 if L >= anchor + 510 else 0
+    cls = np.zeros(max(n, 1), np.uint32)
+    ys = np.zeros(max(n, 1), np.uint16)
+    _cls_lib.emul_cls_ysum(s.ctypes.data_as(u8p), L, anchor, chunk, view, cls.ctypes.data_as(u32p),
+                           ys.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return cls[:n], ys[:n]

@@ -12,6 +12,18 @@ import osmo_tetra_amd as T
 
 SEQ_N = np.array([1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0], np.uint8)
 SEQ_Y = np.array([1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1], np.uint8)
+SEQ_P = np.array([0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0], np.uint8)
+SEQ_Q = np.array([1,0,1,1,0,1,1,1,0,0,0,0,0,1,1,0,1,0,1,1,0,1], np.uint8)
+SEQ_X = np.array([1,0,0,1,1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0,0,0,1,1], np.uint8)
+HEADS = [x[:22].tolist() for x in (SEQ_Y, SEQ_N, SEQ_P, SEQ_Q, SEQ_X)]
+
+
+def skewed_gate(buf, c):
+    """phy/tetra_burst.c:289-297 for a position c < 21: the look-ahead window is primed with in[0..19] and then fed
+    in[cur + 21], so it holds the stream with in[20] missing; a sequence at c only counts if that window equals the
+    first 22 bits of one of the five training sequences"""
+    e = ([0] + buf[0:20].tolist() + [int(buf[21])]) if c == 0 else (buf[c - 1:20].tolist() + buf[21:c + 22].tolist())
+    return e in HEADS
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -47,23 +59,30 @@ def emul_cls(stream, anchor, chunk, view=640):
         wv = min(w, view)
         buf = pad[bs:bs + 700].copy()
         buf[wv:] = 0
-        rc, off, early = 0xFF, 0, 0
+        rc, off = 0xFF, 0
         for c in range(0, wv):
             t = None
             if c + 38 <= w and (buf[c:c + 38] == SEQ_Y).all():
                 t = 3
             elif c + 22 <= w and (buf[c:c + 22] == SEQ_N).all():
                 t = 0
-            elif c + 22 <= w and (buf[c:c + 22] == np.array([0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0])).all():
+            elif c + 22 <= w and (buf[c:c + 22] == SEQ_P).all():
                 t = 1
             if t is None:
                 continue
-            if c < 21:
-                early = 1
+            if c < 21 and not skewed_gate(buf, c):
                 continue
             rc, off = t, c
             break
-        flags = early | (4 if (rc == 0xFF and w > view) else 0)
+        flags = 4 if (rc == 0xFF and w > view) else 0
+        if rc == 0xFF:      # TG_CLS_NOVIEW: nothing in the rest of the view (up to the stream's end) either
+            vis = min(L - bs, view)
+            full = pad[bs:bs + 700]
+            anyv = any(((c + 38 <= vis and (full[c:c + 38] == SEQ_Y).all()) or
+                        (c + 22 <= vis and ((full[c:c + 22] == SEQ_N).all() or (full[c:c + 22] == SEQ_P).all())))
+                       for c in range(21, vis))
+            if not anyv:
+                flags |= 8
         out[i] = rc | (off << 8) | (flags << 24)
     return out
 
@@ -287,3 +306,104 @@ def test_per_call_form_equals_closed_form_and_oracle():
             assert a["slots"] == b["slots"] and a["events"] == b["events"]
         for chunk in (5, 20, 297, 400):
             check(s, chunk=chunk, with_cls=False)
+
+
+# ---- the walk in the form the device runs it (csrc/tg_walk_core.h, k_walk's phases on the host) ----
+def _dev_form(s, chunk):
+    import emul
+    ref0 = T.sync_walk(s, chunk=chunk, burst_events=False)
+    ev0 = [e for e in ref0["events"] if e[0] == 1]
+    if not ev0:
+        return None
+    anchor = ev0[0][1] + ev0[0][2] + 296
+    if anchor + 510 > len(s):
+        return None
+    cls, ys = emul.cls_ysum(s, anchor, chunk)
+    ref = T.sync_walk(s, chunk=chunk, anchor=anchor, cls=cls, ysum=ys, burst_events=False, grid=True, plain=True)
+    got, st, why = T.sync_walk_emul(s, chunk, anchor, cls, ys)
+    if st:
+        return "fallback", why
+    assert ref["noffgrid"] == 0
+    assert got["events"] == ref["events"]
+    for k in ("nslots", "ngrid", "final_state", "burst_seq", "tail_tn_adds"):
+        assert got[k] == ref[k], k
+    assert (np.asarray(got["grid_bits"]) == np.asarray(ref["grid_bits"])).all()
+    # ... and the host walk itself equals the oracle's receiver on the bytes (events, number of bursts handed over)
+    recs, oev = O.run_rx(s, chunk=chunk)
+    assert [e for e in oev if e[0] != 2] == ref["events"]
+    return "ok", len(ref["events"])
+
+
+def test_cls_statement_in_c_equals_numpy_statement():
+    """tests/host_emul/cls_emul.c (what the large CPU cases use) == emul_cls / emul_ysum above, early sequences and
+    the TG_CLS_NOVIEW flag included; and both give tetra_find_train_seq()'s answer slot by slot"""
+    import emul
+    rng = np.random.default_rng(3)
+    for t in range(12):
+        s, _ = synth.frame_stream(seed=t + 1, nframes=int(rng.integers(2, 8)), lead_in=int(rng.integers(0, 300)), pad=int(rng.integers(600, 900)))
+        s = s.copy()
+        anchor = int(rng.integers(0, 700))
+        n = (len(s) - anchor) // 510
+        for _ in range(6):
+            seq = (SEQ_Y, SEQ_N, SEQ_P)[int(rng.integers(0, 3))]
+            o = anchor + 510 * int(rng.integers(0, n)) + int(rng.integers(0, 30))
+            s[o:o + len(seq)] = seq
+        for _ in range(3):
+            s[int(rng.integers(0, len(s)))] ^= 1
+        for chunk in (32, 64, 256):
+            c, d = emul.cls_ysum(s, anchor, chunk)
+            assert (emul_cls(s, anchor, chunk) == c).all() and (emul_ysum(s, anchor) == d).all()
+        c, _ = emul.cls_ysum(s, anchor, 64)
+        pad = np.concatenate([s, np.zeros(64, np.uint8)])
+        for i in range(n):
+            bs = anchor + 510 * i
+            w = min(-(-(bs + 510) // 64) * 64, len(s)) - bs
+            rc, off = T.find_train_seq(pad[bs:bs + w + 40], w, (1 << 0) | (1 << 1) | (1 << 3))
+            cw = int(c[i])
+            assert (cw & 0xFF, (cw >> 8) & 0xFFFF if cw & 0xFF != 0xFF else 0) == ((rc, off) if rc >= 0 else (0xFF, 0))
+
+
+def test_device_form_of_the_walk_equals_the_host_walk():
+    """tgpu_sync_walk_emul (one lane per non-plain grid slot through tgw_run, reachability by pointer doubling: what
+    k_walk does) == the host walk == the oracle on damaged streams that stay on their grid: damaged training
+    sequences (incl. two and three in a row, right after a SYNC burst, at the stream's end), spurious sequences
+    anywhere, zeroed stretches; where it reports 'fallback' the reason is one of the documented ones"""
+    rng = np.random.default_rng(2468)
+    nok = nfb = 0
+    for trial in range(60):
+        stream, slots = synth.frame_stream(seed=100 + trial, nframes=int(rng.integers(3, 30)), lead_in=int(rng.integers(0, 400)),
+                                           pad=int(rng.integers(600, 900)))
+        s = stream.copy()
+        tr = [i for i in range(0, len(s) - 60) if (s[i:i + 22] == SEQ_N).all() or (s[i:i + 22] == SEQ_P).all() or (s[i:i + 38] == SEQ_Y).all()]
+        for i in tr:
+            if rng.random() < 0.12:
+                s[i + int(rng.integers(0, 22))] ^= 1
+        if trial % 3 == 0 and len(tr) > 6:        # runs of damaged slots, the last slots of the stream
+            j = int(rng.integers(0, len(tr) - 3))
+            for i in tr[j:j + 3] + tr[-2:]:
+                s[i + 3] ^= 1
+        for _ in range(int(rng.integers(0, 6))):
+            kind, p = int(rng.integers(0, 3)), int(rng.integers(0, len(s) - 60))
+            if kind == 0:
+                s[p:p + 38] = SEQ_Y
+            elif kind == 1:
+                s[p:p + 22] = SEQ_N
+            else:
+                s[p:p + int(rng.integers(1, 2500))] = 0
+        r = _dev_form(np.ascontiguousarray(s), int(rng.choice([32, 64, 64, 128])))
+        if r is None:
+            continue
+        if r[0] == "ok":
+            nok += 1
+        else:
+            nfb += 1
+            assert r[1] in (2, 3, 4), r       # TGW_WHY_WINDOW / _EARLY / _OFFGRID: the bytes have to decide
+    assert nok >= 30, (nok, nfb)
+
+
+def test_device_form_on_a_recording_of_bench_size():
+    """one bench channel (125 000 slots, 1 % damaged training sequences, 64-byte feeds): no fallback, same outcome"""
+    import bench
+    st, _, _ = bench.make_mix_stream(T, 125000, 5, mnc=47, cc=6)
+    r = _dev_form(np.ascontiguousarray(st), 64)
+    assert r[0] == "ok" and r[1] > 1500
