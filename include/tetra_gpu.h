@@ -491,6 +491,28 @@ int tgpu_sync_multi_finish(struct tgpu_sync_multi *st, uint32_t flags, unsigned 
 			   void *hip_stream);
 uint32_t tgpu_sync_multi_ngrid(const struct tgpu_sync_multi *st);
 void tgpu_sync_multi_free(struct tgpu_sync_multi *st);
+/*
+ * The same batch with the synchroniser walks on the DEVICE (round 3; k_walk, csrc/tg_walk_core.h): one call enqueues
+ * everything on hip_stream -- classification, plain bitmap, the walk of every channel (delivered bitmap, events, counts),
+ * the lists from that bitmap, the decode into d_rec (tgpu_plan_execute is part of it), and the copies of the outcomes
+ * into pinned memory -- and returns without waiting; the host's share of a step is the first lock of every channel
+ * (a few kB of each stream) and the launches.  chunk: a power of two inside the closed form's range (tetra-rx.c feeds 64).
+ *   tgpu_sync_multi_collect() waits for the batch and fills out[nchan] like tgpu_sync_multi_finish() does (events without
+ *   TGPU_EV_BURST; release each with tgpu_sync_result_free()).  Where the device walk cannot settle a channel -- only the
+ *   bytes can decide (a byte other than 0 / 1 near an exception, a sequence in the first 21 bytes of a search buffer, a
+ *   re-lock off the grid, a window beyond the kernel's view: feeds of 128 / 256 bytes), more than 8192 exceptions or
+ *   262 144 grid slots in one channel -- the batch is redone through the host walks and decoded again before the call
+ *   returns: same results (tgpu_sync_dev_fellback() tells).
+ * Plan capacity as above; the plan must stay untouched between launch and collect; several batches are kept in flight
+ * with several plans.
+ */
+struct tgpu_sync_dev;
+int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+			   const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *hip_stream);
+int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *out);
+uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd);
+int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd);
+void tgpu_sync_dev_free(struct tgpu_sync_dev *sd);
 /* measurement aid, as tgpu_sync_front_prof() for a multi-channel batch */
 int tgpu_sync_front_prof_multi(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
 			       const uint8_t *d_base, uint32_t chunk, uint32_t nrep, float us[2], void *hip_stream);

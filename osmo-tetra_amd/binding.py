@@ -169,6 +169,14 @@ def lib():
     L.tgpu_channel_scramb_init.argtypes = [C.c_void_p, u32p]
     L.tgpu_sync_walk.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u16p, C.c_uint32, C.c_uint32, C.POINTER(SyncResult)]
     L.tgpu_sync_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, u16p, C.c_void_p]
+    L.tgpu_sync_multi_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(MultiChan), C.c_void_p, C.c_uint32, C.c_void_p,
+                                         C.POINTER(C.c_void_p), C.c_void_p]
+    L.tgpu_sync_multi_collect.argtypes = [C.c_void_p, C.POINTER(SyncResult)]
+    L.tgpu_sync_dev_ngrid.argtypes = [C.c_void_p]
+    L.tgpu_sync_dev_ngrid.restype = C.c_uint32
+    L.tgpu_sync_dev_fellback.argtypes = [C.c_void_p]
+    L.tgpu_sync_dev_free.argtypes = [C.c_void_p]
+    L.tgpu_sync_dev_free.restype = None
     L.tgpu_sync_walk_emul.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u16p, u32p, C.c_uint32, C.POINTER(SyncResult),
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.tgpu_sync_stream.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SyncResult), C.c_void_p]
@@ -699,6 +707,65 @@ class MultiSync:
     def __del__(self):
         if getattr(self, "_h", None):
             lib().tgpu_sync_multi_free(self._h)
+
+
+class MultiSyncDev:
+    """tgpu_sync_multi_launch / _collect: the same batch with the synchroniser walks on the device (k_walk) and the
+    decode into d_rec enqueued behind them -- the constructor returns without waiting, collect() waits and returns one
+    outcome per channel (events, delivered bitmap, counts); .fellback tells whether the host walks had to decide"""
+
+    def __init__(self, engine, plan, streams, d_base_ptr, d_offs, d_rec_ptr, chunk=64, hip_stream=0, codes=None, chans=None):
+        self.engine, self.plan, self.hip_stream = engine, plan, hip_stream
+        if chans is not None:       # (a prepared channel table: the bench builds it once)
+            self.streams, self._ch = chans
+        else:
+            self.streams, self._ch = multi_chan_table(streams, d_offs, codes)
+        n = len(self.streams)
+        self._h = C.c_void_p()
+        _chk(lib().tgpu_sync_multi_launch(engine._h, plan._h, n, self._ch, C.c_void_p(d_base_ptr), chunk, C.c_void_p(d_rec_ptr),
+                                          C.byref(self._h), C.c_void_p(hip_stream)), "tgpu_sync_multi_launch")
+        self.ngrid = lib().tgpu_sync_dev_ngrid(self._h)
+        self.fellback = False
+
+    def collect(self, raw=False):
+        n = len(self.streams)
+        res = (SyncResult * n)()
+        try:
+            _chk(lib().tgpu_sync_multi_collect(self._h, res), "tgpu_sync_multi_collect")
+            self.fellback = bool(lib().tgpu_sync_dev_fellback(self._h))
+        finally:
+            lib().tgpu_sync_dev_free(self._h)
+            self._h = C.c_void_p()
+        if self.ngrid:
+            self.plan.nslots, self.plan.nchan = self.ngrid, n
+        if raw:         # counts only (the bench's timed loop): no numpy views, the C arrays are released here
+            out = [dict(nslots=res[c].nslots, nevents=res[c].nevents, noffgrid=res[c].noffgrid, ngrid=res[c].ngrid,
+                        final_state=res[c].final_state, burst_seq=res[c].burst_seq) for c in range(n)]
+            for c in range(n):
+                lib().tgpu_sync_result_free(C.byref(res[c]))
+            return out
+        out = []
+        for c in range(n):
+            r = SyncResult()
+            C.memmove(C.byref(r), C.byref(res[c]), C.sizeof(SyncResult))
+            out.append(_sync_result_to_py(r))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().tgpu_sync_dev_free(self._h)
+
+
+def multi_chan_table(streams, d_offs, codes=None):
+    """(host arrays kept alive, struct tgpu_multi_chan[n]) for MultiSync / MultiSyncDev"""
+    xs = [_np_u8(x) for x in streams]
+    ch = (MultiChan * len(xs))()
+    for c, x in enumerate(xs):
+        ch[c].h_stream = x.ctypes.data_as(u8p)
+        ch[c].d_off = int(d_offs[c])
+        ch[c].len = len(x)
+        ch[c].scramb_init = int(codes[c]) if codes is not None else 0
+    return xs, ch
 
 
 def sync_front_prof_multi(engine, plan, streams, d_base_ptr, d_offs, chunk=64, nrep=10, hip_stream=0):

@@ -93,6 +93,7 @@ struct tgpu_plan {
 	uint8_t *d_walk, *h_walk;	/* roots, summaries, events of k_walk (device / pinned mirror), max_chan channels */
 	void *d_walk_recs;		/* max_chan * (TGW_NCAP + 1) node records */
 	uint32_t *d_bits_dev;		/* the delivered bitmap k_walk left in the upload arena */
+	uint32_t *h_bits;		/* pinned: where it is copied for the host */
 };
 
 const char *tgpu_strerror(int err)
@@ -225,6 +226,8 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 		(void)hipHostFree(p->h_chan_tab);
 	if (p->h_walk)
 		(void)hipHostFree(p->h_walk);
+	if (p->h_bits)
+		(void)hipHostFree(p->h_bits);
 	free(p->h_last_slot_of_chan);
 	free(p);
 }
@@ -576,6 +579,27 @@ int tgpi_plan_walk_buffers(struct tgpu_plan *p, struct tg_walk_root **d_roots, s
 uint32_t *tgpi_plan_bits_dev(struct tgpu_plan *p)
 {
 	return p ? p->d_bits_dev : NULL;
+}
+
+/* pinned words for the bitmap coming back (max_slots bits), allocated on first use */
+int tgpi_plan_bits_mirror(struct tgpu_plan *p, uint32_t **h_bits)
+{
+	if (!p || !h_bits)
+		return TGPU_EINVAL;
+	if (!p->h_bits && hipHostMalloc((void **)&p->h_bits, ((size_t)p->max_slots + 31) / 32 * 4 + 16, hipHostMallocDefault) != hipSuccess) {
+		p->h_bits = NULL;
+		return TGPU_ENOMEM;
+	}
+	*h_bits = p->h_bits;
+	return TGPU_OK;
+}
+
+uint8_t *tgpi_plan_walk_events_dev(struct tgpu_plan *p)
+{
+	if (!p || !p->d_walk)
+		return NULL;
+	const size_t nc = p->max_chan < 64 ? p->max_chan : 64;
+	return p->d_walk + nc * sizeof(struct tg_walk_root) + nc * sizeof(struct tg_walk_sum);
 }
 
 int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_off, const uint8_t *slot_type,

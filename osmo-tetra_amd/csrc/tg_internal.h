@@ -91,6 +91,7 @@ struct tg_walk_sum {
 };
 typedef struct { int32_t ev; uint32_t bitnum, arg; } tgpu_sync_event_rec_dev;	/* = struct tgpu_sync_event_rec */
 #define TGW_EVCAP 16384u	/* events per channel the device walk can report */
+#define TGW_EVEAGER 4096u	/* of those, copied to the host with the batch; the rest on demand */
 #define TGW_REC_BYTES 152u	/* sizeof(struct tgw_rec), checked where it is allocated */
 int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 	     uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
@@ -139,6 +140,8 @@ int tgpi_plan_walk_buffers(struct tgpu_plan *p, struct tg_walk_root **d_roots, s
 			   struct tg_walk_sum **d_sums, struct tg_walk_sum **h_sums, void **d_events, void **h_events,
 			   void **d_recs);
 uint32_t *tgpi_plan_bits_dev(struct tgpu_plan *p);
+int tgpi_plan_bits_mirror(struct tgpu_plan *p, uint32_t **h_bits);	/* pinned host words for the delivered bitmap */
+uint8_t *tgpi_plan_walk_events_dev(struct tgpu_plan *p);
 
 #ifdef __cplusplus
 }

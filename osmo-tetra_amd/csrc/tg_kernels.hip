@@ -3419,7 +3419,6 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	uint16_t *wpre = (uint16_t *)(nslot + TGW_NCAP);
 	uint16_t *Ja = wpre + TGW_WCAP, *Jb = Ja + TGW_NCAP + 8;
 	uint8_t *mark = (uint8_t *)(Jb + TGW_NCAP + 8);
-	uint8_t *evc = mark + TGW_NCAP + 8;
 	__shared__ uint32_t sm[20];
 	__shared__ uint32_t s_head, s_fb, s_why, s_nd, s_tail, s_last, s_lastdel, s_ns;
 

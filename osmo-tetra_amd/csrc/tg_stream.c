@@ -1366,3 +1366,250 @@ done:
 	free(recs);
 	return rc;
 }
+
+/* ------------------------------------------------------------------------- */
+/* multi-channel batches with the walk on the device                          */
+/* ------------------------------------------------------------------------- */
+/*
+ * tgpu_sync_multi_launch(): everything a batch needs is enqueued on the caller's stream and the call returns -- first
+ * lock of every channel (host, a few kB of each stream), channel table + roots up, k_front_stream (+ fix), k_cls_plain,
+ * k_walk (the synchroniser per channel: delivered bitmap, events, counts), the list builder on that bitmap, SB1 -> code
+ * fill -> masks -> trellis kernels with the item counts read on the device, summaries + events + bitmap back into pinned
+ * memory.  No host wait in between: a step costs the host its launches.
+ * tgpu_sync_multi_collect(): waits for the batch and hands out the per-channel outcomes.  Where the device walk could
+ * not settle a channel (tg_walk_core.h: only the bytes can decide, more than TGW_NCAP exceptions, ...) the batch is
+ * redone through the host walks (tgpu_sync_multi_finish) and decoded again before the call returns -- same results,
+ * one batch later in time.
+ */
+struct tgpu_sync_dev {
+	struct tgpu_sync_multi *st;
+	const uint8_t *d_base;
+	uint8_t *d_rec;
+	hipStream_t stream;
+	hipEvent_t done;
+	struct tg_walk_root *h_roots;
+	struct tg_walk_sum *h_sums;
+	tgpu_sync_event_rec_dev *h_events;
+	uint32_t *h_bits;	/* pinned mirror of the delivered bitmap */
+	uint32_t nwords;
+	int fellback;
+};
+
+void tgpu_sync_dev_free(struct tgpu_sync_dev *sd)
+{
+	if (!sd)
+		return;
+	if (sd->done)
+		(void)hipEventDestroy(sd->done);
+	tgpu_sync_multi_free(sd->st);
+	free(sd);
+}
+
+int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+			   const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *stream)
+{
+	if (!eng || !plan || !nchan || nchan > 64 || !ch || !d_base || !d_rec || !out)
+		return TGPU_EINVAL;
+	if (!chunk || (chunk & (chunk - 1)) || chunk < TGPU_SYNC_CHUNK_MIN || chunk > TGPU_SYNC_CHUNK_MAX)
+		return TGPU_EINVAL;	/* (other feed sizes: tgpu_sync_multi_begin / _finish) */
+	*out = NULL;
+	int rc = tgpi_engine_bind(eng);
+	if (rc)
+		return rc;
+	struct tgpu_sync_dev *sd = calloc(1, sizeof(*sd));
+	struct tgpu_sync_multi *st = calloc(1, sizeof(*st));
+	if (!sd || !st) {
+		free(sd);
+		free(st);
+		return TGPU_ENOMEM;
+	}
+	sd->st = st;
+	sd->d_base = d_base;
+	sd->d_rec = d_rec;
+	sd->stream = (hipStream_t)stream;
+	st->eng = eng;
+	st->plan = plan;
+	st->nchan = nchan;
+	st->chunk = chunk;
+	st->ch = malloc((size_t)nchan * sizeof(*ch));
+	st->ent = calloc(nchan, sizeof(*st->ent));
+	st->locks = calloc(nchan, sizeof(int));
+	rc = (st->ch && st->ent && st->locks) ? TGPU_OK : TGPU_ENOMEM;
+	if (!rc)
+		rc = (int)hipEventCreateWithFlags(&sd->done, hipEventDisableTiming);
+	struct tg_walk_root *d_roots = NULL;
+	struct tg_walk_sum *d_sums = NULL;
+	void *d_events = NULL, *h_events = NULL, *d_recs = NULL;
+	if (!rc)
+		rc = tgpi_plan_walk_buffers(plan, &d_roots, &sd->h_roots, &d_sums, &sd->h_sums, &d_events, &h_events, &d_recs);
+	sd->h_events = h_events;
+	if (!rc)
+		memcpy(st->ch, ch, (size_t)nchan * sizeof(*ch));
+	uint64_t total = 0;
+	uint32_t codes[64];
+	for (uint32_t c = 0; c < nchan && !rc; c++) {
+		uint64_t anchor = 0;
+		if (!ch[c].h_stream) {
+			rc = TGPU_EINVAL;
+			break;
+		}
+		sd->h_roots[c].found_bs = sd->h_roots[c].found_k = 0;
+		rc = find_anchor_root(ch[c].h_stream, ch[c].len, chunk, &anchor, &st->locks[c], &sd->h_roots[c]);
+		uint64_t n = 0;
+		if (!rc && st->locks[c] && anchor + TG_SLOT_BITS <= ch[c].len)
+			n = (ch[c].len - anchor) / TG_SLOT_BITS;
+		else
+			st->locks[c] = 0;
+		st->ent[c].d_off = ch[c].d_off;
+		st->ent[c].anchor = anchor;
+		st->ent[c].len = ch[c].len;
+		st->ent[c].gbase = (uint32_t)total;
+		st->ent[c].ncls = (uint32_t)n;
+		codes[c] = ch[c].scramb_init;
+		total += (n + 31) & ~(uint64_t)31;
+		if (total > 0xfffffff0u)
+			rc = TGPU_ECAPACITY;
+	}
+	st->ngrid = (uint32_t)total;
+	if (!rc && st->ngrid) {
+		uint32_t *d_packed, *d_cls, *cls, *d_plain, *h_plain, *d_bits = NULL;
+		uint16_t *d_ysum, *ysum;
+		struct tg_chan_ent *d_tab;
+		rc = tgpi_plan_grid_begin(plan, st->ngrid, &d_packed, &d_cls, &d_ysum, &cls, &ysum);
+		if (!rc)
+			rc = tgpi_plan_chan_table(plan, st->ent, nchan, &d_tab, stream);
+		if (!rc)
+			rc = (int)hipMemcpyAsync(d_roots, sd->h_roots, (size_t)nchan * sizeof(*d_roots), hipMemcpyHostToDevice, sd->stream);
+		if (!rc)
+			rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
+						    tgpi_plan_defer_scratch(plan), stream, NULL);
+		if (!rc) {
+			tgpi_plan_grid_plain(plan, st->ngrid, &d_plain, &h_plain);
+			rc = tgk_cls_plain(d_cls, st->ngrid, d_plain, stream);
+		}
+		if (!rc)
+			rc = tgpi_plan_grid_layout_dev(plan, st->ngrid, nchan, codes, &d_bits, stream);
+		if (!rc)
+			rc = tgk_walk(d_base, d_tab, d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, d_sums, d_events, TGW_EVCAP,
+				      d_recs, stream);
+		if (!rc)
+			rc = tgpi_plan_grid_lists_dev(plan, st->ent, stream);
+		if (!rc)
+			rc = tgpu_plan_execute(plan, d_base, d_rec, stream);
+		/* what the host wants to know: summaries, the first events of every channel, the bitmap */
+		if (!rc)
+			rc = (int)hipMemcpyAsync(sd->h_sums, d_sums, (size_t)nchan * sizeof(*d_sums), hipMemcpyDeviceToHost, sd->stream);
+		for (uint32_t c = 0; c < nchan && !rc; c++)
+			rc = (int)hipMemcpyAsync(sd->h_events + (size_t)c * TGW_EVCAP, (tgpu_sync_event_rec_dev *)d_events + (size_t)c * TGW_EVCAP,
+						 (size_t)TGW_EVEAGER * sizeof(tgpu_sync_event_rec_dev), hipMemcpyDeviceToHost, sd->stream);
+		if (!rc) {
+			sd->nwords = (st->ngrid + 31) / 32;
+			rc = tgpi_plan_bits_mirror(plan, &sd->h_bits);
+			if (!rc)
+				rc = (int)hipMemcpyAsync(sd->h_bits, d_bits, (size_t)sd->nwords * 4, hipMemcpyDeviceToHost, sd->stream);
+		}
+	}
+	if (!rc)
+		rc = (int)hipEventRecord(sd->done, sd->stream);
+	if (rc) {
+		tgpu_sync_dev_free(sd);
+		return rc;
+	}
+	*out = sd;
+	return TGPU_OK;
+}
+
+uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd)
+{
+	return sd ? sd->st->ngrid : 0;
+}
+
+int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd)
+{
+	return sd ? sd->fellback : 0;
+}
+
+int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *out)
+{
+	if (!sd || !out)
+		return TGPU_EINVAL;
+	struct tgpu_sync_multi *st = sd->st;
+	memset(out, 0, (size_t)st->nchan * sizeof(*out));
+	int rc = tgpi_engine_bind(st->eng);
+	if (rc)
+		return rc;
+	rc = (int)hipEventSynchronize(sd->done);
+	if (rc)
+		return rc;
+	int fb = 0;
+	for (uint32_t c = 0; c < st->nchan; c++)
+		if (st->ent[c].ncls && sd->h_sums[c].status != TGW_OK)
+			fb = 1;
+	if (getenv("TGPU_WALK_DEBUG"))
+		for (uint32_t c = 0; c < st->nchan; c++)
+			fprintf(stderr, "k_walk channel %u: %u grid slots, %u nodes, status %u (why %u), %u delivered, %u events\n", c,
+				st->ent[c].ncls, sd->h_sums[c].nnodes, sd->h_sums[c].status, sd->h_sums[c].why, sd->h_sums[c].nslots,
+				sd->h_sums[c].nevents);
+	if (fb || getenv("TGPU_WALK_HOST")) {
+		/* the host walks decide: classification words, summaries and plain bitmap over, walks, bitmap up, lists, decode */
+		sd->fellback = 1;
+		if (st->ngrid) {
+			uint32_t *d_packed, *d_cls, *cls;
+			uint16_t *d_ysum, *ysum;
+			rc = tgpi_plan_grid_begin(st->plan, st->ngrid, &d_packed, &d_cls, &d_ysum, &cls, &ysum);
+			if (!rc)
+				rc = (int)hipMemcpyAsync(cls, d_cls, TG_GRID_COPY_BYTES(st->ngrid), hipMemcpyDeviceToHost, sd->stream);
+			if (rc)
+				return rc;
+		}
+		rc = tgpu_sync_multi_finish(st, TGPU_SYNC_NO_BURST_EVENTS, 4, out, sd->stream);
+		if (!rc && st->ngrid)
+			rc = tgpu_plan_execute(st->plan, sd->d_base, sd->d_rec, sd->stream);
+		if (!rc)
+			rc = (int)hipStreamSynchronize(sd->stream);
+		return rc;
+	}
+	for (uint32_t c = 0; c < st->nchan && !rc; c++) {
+		const struct tg_chan_ent *e = &st->ent[c];
+		struct tgpu_sync_result *o = &out[c];
+		if (!e->ncls) {	/* never locks (or nothing behind the lock): nothing of it is in the grid; the bytes settle it */
+			rc = tgpu_sync_walk(st->ch[c].h_stream, st->ch[c].len, st->chunk, e->anchor, NULL, NULL, 0, TGPU_SYNC_NO_BURST_EVENTS, o);
+			o->noffgrid = o->nslots;
+			o->anchor = e->anchor;
+			o->grid_base = e->gbase;
+			continue;
+		}
+		const struct tg_walk_sum *s = &sd->h_sums[c];
+		o->nslots = s->nslots;
+		o->nevents = s->nevents;
+		o->final_state = (int)s->final_state;
+		o->tail_tn_adds = s->tail_tn_adds;
+		o->burst_seq = s->burst_seq;
+		o->anchor = e->anchor;
+		o->ngrid = e->ncls;
+		o->grid_base = e->gbase;
+		const size_t nw = ((size_t)e->ncls + 31) / 32;
+		o->grid_bits = malloc(nw * 4);
+		o->events = malloc((size_t)(s->nevents ? s->nevents : 1) * sizeof(*o->events));
+		if (!o->grid_bits || !o->events) {
+			rc = TGPU_ENOMEM;
+			break;
+		}
+		memcpy(o->grid_bits, sd->h_bits + e->gbase / 32, nw * 4);
+		const uint32_t eager = s->nevents < TGW_EVEAGER ? s->nevents : TGW_EVEAGER;
+		memcpy(o->events, sd->h_events + (size_t)c * TGW_EVCAP, (size_t)eager * sizeof(*o->events));
+		if (s->nevents > eager) {	/* a channel with many exceptions: the rest of its events in a second copy */
+			uint8_t *d_ev = tgpi_plan_walk_events_dev(st->plan);
+			rc = (int)hipMemcpy(o->events + eager, d_ev + ((size_t)c * TGW_EVCAP + eager) * sizeof(*o->events),
+					    (size_t)(s->nevents - eager) * sizeof(*o->events), hipMemcpyDeviceToHost);
+		}
+		uint32_t last = 0xffffffffu;
+		for (size_t wd = nw; wd-- > 0;)
+			if (o->grid_bits[wd]) {
+				last = e->gbase + (uint32_t)(wd * 32 + 31 - (uint32_t)__builtin_clz(o->grid_bits[wd]));
+				break;
+			}
+		tgpi_plan_set_last_slot(st->plan, c, last);
+	}
+	return rc;
+}

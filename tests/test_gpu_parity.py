@@ -570,7 +570,8 @@ def test_stream_front_packed_bits_equals_per_position(T, eng, seed, lead_in, chu
     assert (a[0] == b[0]).all(), np.flatnonzero(a[0] != b[0])[:10]
     assert (a[1] == b[1]).all(), np.flatnonzero(a[1] != b[1])[:10]
     assert (a[0] & 0xff != 0xff).sum() > n // 2                 # most slots carry a burst ...
-    assert ((a[0] >> 24) & 1).sum() > 0 and ((a[0] >> 25) & 1).sum() > 0   # ... and the hard cases are in there
+    assert ((a[0] >> 24) & 1).sum() == 0            # (round 3: sequences below offset 21 are evaluated, not flagged)
+    assert ((a[0] >> 25) & 1).sum() > 0             # ... and the hard cases are in there
     assert (a[2] is None) == (b[2] is None) and (a[2] is None) == bool(seed & 1)
     if a[2] is not None:
         assert (a[2] == b[2]).all(), np.flatnonzero((a[2] != b[2]).any(axis=1))[:10]
@@ -1839,6 +1840,123 @@ def test_config4_channels_in_one_grid_batch(T, eng):
     plan.close()
 
 
+def _multi_batch(T, streams):
+    import torch
+    offs, o = [], 0
+    for st in streams:
+        offs.append(o)
+        o += (len(st) + T.STREAM_SLACK + 15) & ~15
+    buf = np.zeros(o + 4096, np.uint8)
+    for st, f in zip(streams, offs):
+        buf[f:f + len(st)] = st
+    return torch.from_numpy(buf).cuda(), offs, sum((len(st) // 510 + 32) for st in streams)
+
+
+def _same_batch_outcome(T, a, b, rec_a, rec_b, what):
+    for c, (x, y) in enumerate(zip(a, b)):
+        assert x["events"] == y["events"], (what, c)
+        for k in ("nslots", "ngrid", "noffgrid", "anchor", "final_state", "burst_seq", "tail_tn_adds", "grid_base"):
+            assert x[k] == y[k], (what, c, k, x[k], y[k])
+        if x["ngrid"] and not x["noffgrid"]:
+            assert (np.asarray(x["grid_bits"]) == np.asarray(y["grid_bits"])).all(), (what, c)
+            idx = x["grid_base"] + T.grid_indices(x)
+            assert (rec_a[idx] == rec_b[idx]).all(), (what, c)
+
+
+@pytest.mark.parametrize("chunk", [64, 32])
+def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, monkeypatch):
+    """tgpu_sync_multi_launch / _collect (the synchroniser walks on the device: k_walk) against tgpu_sync_multi_begin /
+    _finish (host walks) on the same multi-channel batch: eight channels of different cells, lengths, lead-ins and damage
+    -- damaged training sequences in runs, right behind SYNC bursts (the one-call backlog) and in the last slots, spurious
+    sequences below offset 21 (the reference's skewed look-ahead rule, now evaluated by the kernels), a channel with next
+    to nothing in it, one that ends inside a burst.  Per channel: events, counts, final state, delivered bitmap, every
+    delivered record byte, final codes.  No fallback on these; then once more with the fallback forced (same results)"""
+    import torch
+    from test_stream_sync_cpu import SEQ_N, SEQ_P
+    hs = torch.cuda.current_stream().cuda_stream
+    cells = [(262, 42, 1), (901, 77, 9), (234, 14, 33), (1, 2, 3), (262, 42, 2), (505, 1, 60), (208, 10, 5), (222, 99, 7)]
+    rng = np.random.default_rng(4040 + chunk)
+    streams = []
+    for c, cell in enumerate(cells):
+        nsl = int(rng.integers(200, 3000)) if c != 3 else 2
+        st, _ = _mix_stream(T, nsl, 1900 + c, cell, ber=0.02)
+        st = st.copy()
+        lead = 100 + 510            # (_mix_stream: 100 lead-in bits, then the lock-only SYNC burst)
+        tr = [lead + 510 * i + (214 if i % 8 == 0 else 244) for i in range(nsl)]
+        for q, i in enumerate(tr):
+            if rng.random() < 0.03:
+                st[i + int(rng.integers(0, 22))] ^= 1
+        if nsl > 100:
+            for j in (17, 18, 19, 41, 43, nsl - 2, nsl - 1, 64, 72, 73):      # runs, slots next to SYNC bursts (multiples of 8), the end
+                st[tr[j] + 2] ^= 1
+            for j in (30, 55, 77):                                                # sequences below offset 21 of a slot
+                seq = (SEQ_N, SEQ_P)[j % 2]           # (a spurious SYNC sequence pulls the walk off the grid: next test)
+                o = lead + 510 * j + int(rng.integers(0, 21))
+                st[o:o + len(seq)] = seq
+        if c == 5:
+            st = st[:len(st) - 700 - 200]
+        streams.append(np.ascontiguousarray(st))
+    d, offs, ntot = _multi_batch(T, streams)
+    pa, pb = T.Plan(eng, ntot, len(cells)), T.Plan(eng, ntot, len(cells))
+    ms = T.MultiSync(eng, pa, streams, d.data_ptr(), offs, chunk, hs)
+    ref = ms.finish(burst_events=False, nthreads=3)
+    ra = torch.zeros(max(ms.ngrid, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    pa.execute(d.data_ptr(), ra.data_ptr(), hs)
+    torch.cuda.synchronize()
+    rec_a = ra.cpu().numpy().reshape(-1, T.REC_BYTES)
+    assert all(x["noffgrid"] == 0 for x in ref) and sum(len(x["events"]) for x in ref) > 300
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("TGPU_WALK_HOST", "1")
+        rb = torch.zeros(max(ms.ngrid, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), chunk, hs)
+        got = msd.collect()
+        assert msd.fellback == forced and msd.ngrid == ms.ngrid
+        _same_batch_outcome(T, ref, got, rec_a, rb.cpu().numpy().reshape(-1, T.REC_BYTES), "forced" if forced else "device")
+        assert pb.final_codes().tolist() == pa.final_codes().tolist()
+    pa.close()
+    pb.close()
+
+
+def test_device_walk_hands_over_what_only_the_bytes_settle(T, eng):
+    """streams whose walk the device form cannot settle -- a byte other than 0 / 1 next to a damaged slot, an inserted
+    byte (the synchroniser re-locks beside the grid), a SYNC sequence in the first 21 bytes of a search buffer -- come
+    back through the host walks: .fellback is set, the outcome is the host path's (and, off the grid, noffgrid says
+    so as before)"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    cell = (262, 42, 1)
+    base, _ = _mix_stream(T, 600, 77, cell, ber=0.0)
+    lead = 100 + 510
+    cases = []
+    a = base.copy()
+    a[lead + 510 * 20 + 244 + 3] ^= 1
+    a[lead + 510 * 20 + 100] = 7
+    cases.append(a)
+    b = np.concatenate([base[:lead + 510 * 33 + 17], [1], base[lead + 510 * 33 + 17:]]).astype(np.uint8)
+    cases.append(b)
+    from test_stream_sync_cpu import SEQ_Y
+    c3 = base.copy()              # a spurious SYNC sequence behind a lost lock: a lock beside the grid, nothing delivered there
+    c3[lead + 510 * 72 + 214 + 2] ^= 1
+    c3[lead + 510 * 77 + 6:][:38] = SEQ_Y
+    cases.append(c3)
+    for st in cases:
+        d, offs, ntot = _multi_batch(T, [st, base])
+        pa, pb = T.Plan(eng, ntot, 2), T.Plan(eng, ntot, 2)
+        ms = T.MultiSync(eng, pa, [st, base], d.data_ptr(), offs, 64, hs)
+        ref = ms.finish(burst_events=False, nthreads=2)
+        ra = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        pa.execute(d.data_ptr(), ra.data_ptr(), hs)
+        rb = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        msd = T.MultiSyncDev(eng, pb, [st, base], d.data_ptr(), offs, rb.data_ptr(), 64, hs)
+        got = msd.collect()
+        torch.cuda.synchronize()
+        assert msd.fellback
+        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES), "handed over")
+        pa.close()
+        pb.close()
+
+
 def test_burst_kernel_long_runs_and_many_channels(T, eng, monkeypatch):
     """k_burst's look-back for the scrambling code beyond its 256-slot LDS window (one SYNC slot, then 899 NORM slots
     of the same channel: the code must still come from slot 0), a failed SB1 far back that must be skipped, and 70
@@ -2036,6 +2154,23 @@ def test_metric_workload_full_size_against_the_oracle(T, eng):
         assert (p["code"][ty != 3] == codes[c]).all() and int(fin[c]) == codes[c]
         total += len(idx)
     assert total > 930_000
+    # the same batch with the walks on the device (k_walk; what bench.py times): no fallback, every channel's events,
+    # counts and delivered bitmap equal the host walks' (just checked against the oracle), every record byte equal
+    plan2 = T.Plan(eng, ntot, len(cells))
+    d_rec2 = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    msd = T.MultiSyncDev(eng, plan2, streams, d.data_ptr(), offs, d_rec2.data_ptr(), 64, hs)
+    outs2 = msd.collect()
+    assert not msd.fellback and msd.ngrid == ms.ngrid
+    rec2 = d_rec2.cpu().numpy().reshape(-1, T.REC_BYTES)
+    for c, (a, b) in enumerate(zip(outs, outs2)):
+        assert a["events"] == b["events"], c
+        for k in ("nslots", "ngrid", "noffgrid", "anchor", "final_state", "burst_seq", "tail_tn_adds", "grid_base"):
+            assert a[k] == b[k], (c, k)
+        assert (np.asarray(a["grid_bits"]) == np.asarray(b["grid_bits"])).all()
+        idx = a["grid_base"] + T.grid_indices(a)
+        assert (rec[idx] == rec2[idx]).all(), c
+    assert plan2.final_codes().tolist() == fin.tolist()
+    plan2.close()
     plan.close()
 
 
@@ -2110,3 +2245,65 @@ def test_burst_kernel_equals_batch_kernels(T, eng, n, monkeypatch):
         for cval in sorted(set(exp[keep].tolist())):
             m = keep & (exp == cval)
             check_against_oracle(T, a[0][m], ty[m], (sl_in[m] != 0).astype(np.uint8), int(cval))
+
+
+def test_burst_path_then_batch_path_on_one_load(T, eng, monkeypatch):
+    """one load, several executes on different paths: a static batch (no SYNC slot) goes through k_burst,
+    which uses the mask index / mask table as its own scratch, and is then executed again on the lane-per-trellis
+    kernels (per-stage profiling, a wire buffer, the RM option, TGPU_BURST_MAX lowered): the static mask table must be
+    rebuilt -- every execute gives the first one's records.  And a channel whose LAST slot is of an ignored burst type
+    still reports its code after a k_burst execute (the batch kernels' forward fill gives every slot one)"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    n = 300
+    rng = np.random.default_rng(31)
+    ty = rng.choice([O.TRAIN_NORM_1, O.TRAIN_NORM_2], n).astype(np.uint8)
+    chan = (np.arange(n) >= 120).astype(np.uint32)
+    carry = np.array([O.scramb_get_init(262, 42, 1), O.scramb_get_init(901, 77, 9)], np.uint32)
+    sl = np.concatenate([T.synth_slots(ty[:120], seed=1, scramb_init=int(carry[0]), ber=0.02),
+                         T.synth_slots(ty[120:], seed=2, scramb_init=int(carry[1]), ber=0.02)])
+    d = torch.from_numpy(sl.reshape(-1)).cuda()
+    plan = T.Plan(eng, n, 2)
+    plan.load(np.arange(n, dtype=np.uint64) * 510, ty, chan, carry)
+    recs = []
+    prof = T.Prof(1)
+    d_wire = torch.full((n * T.WIRE_BYTES,), 0xFF, dtype=torch.uint8, device="cuda")
+    for step in range(5):
+        d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        if step == 1:
+            plan.execute_prof(d.data_ptr(), d_rec.data_ptr(), hs, prof, 0)       # never the burst path
+        elif step == 3:
+            plan.set_wire(d_wire.data_ptr())                                        # neither
+            plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+            plan.set_wire(0)
+        else:
+            plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)                        # k_burst (n <= 1024)
+        torch.cuda.synchronize()
+        recs.append(d_rec.cpu().numpy())
+        assert plan.final_codes().tolist() == carry.tolist(), step
+    for step in range(1, 5):
+        assert (recs[step] == recs[0]).all(), step
+    p = T.parse_records(recs[0].reshape(n, T.REC_BYTES))
+    assert (p["code"] == carry[chan]).all() and p["crc_ok"][:, 0].mean() > 0.5
+    plan.close()
+    # an ignored burst type in a channel's last slot, SYNC slots in the batch: the code in force comes from them
+    ty2 = np.array([3, 0, 1, 0, 2, 3, 1, 2], np.uint8)
+    chan2 = np.array([0, 0, 0, 0, 0, 1, 1, 1], np.uint32)
+    cells = [(262, 42, 1), (901, 77, 9)]
+    sl2 = np.concatenate([T.synth_slots(np.where(ty2[:5] == 2, 0, ty2[:5]).astype(np.uint8), seed=3, scramb_init=O.scramb_get_init(*cells[0]),
+                                        mcc=262, mnc=42, cc=1),
+                          T.synth_slots(np.where(ty2[5:] == 2, 0, ty2[5:]).astype(np.uint8), seed=4, scramb_init=O.scramb_get_init(*cells[1]),
+                                        mcc=901, mnc=77, cc=9)])
+    d2 = torch.from_numpy(sl2.reshape(-1)).cuda()
+    res = {}
+    for mode, mx in (("burst", "100000"), ("batch", "0")):
+        monkeypatch.setenv("TGPU_BURST_MAX", mx)
+        pl = T.Plan(eng, 8, 2)
+        pl.load(np.arange(8, dtype=np.uint64) * 510, ty2, chan2, np.array([5, 9], np.uint32))
+        r = torch.zeros(8 * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        pl.execute(d2.data_ptr(), r.data_ptr(), hs)
+        torch.cuda.synchronize()
+        res[mode] = (r.cpu().numpy(), pl.final_codes().tolist())
+        pl.close()
+    assert res["burst"][1] == res["batch"][1] == [O.scramb_get_init(*cells[0]), O.scramb_get_init(*cells[1])]
+    assert (res["burst"][0] == res["batch"][0]).all()
