@@ -8,21 +8,28 @@ Default workload (config.workload) = BASELINE.json's metric: the SB+NDB mix thro
 (configs[2]'s composition in configs[3]'s layout): per GPU 8 recorded channels of 125,000 slots each (own cell each),
 frames of 8 slots [SB, N1, N2, N1, N2, N1, N2, N1], cell scrambling code learnt from SB1, 1 % of the slots with a
 damaged training sequence (dropped burst, loss of lock, re-lock), 1 bit per byte, resident in HBM.  One step = one
-pass of the whole path over all of a GPU's channels as ONE batch: GPU training-sequence search + demux/de-interleave
-of every grid slot, the reference's synchroniser walk per channel (host, tetra_burst_sync_in() semantics at 64-byte
-feeds), device-built lists, SB1 -> code fill -> masks -> both trellis kernels; records stay in HBM.  value counts
-DELIVERED bursts (what tetra_burst_rx_cb() would have been handed), not grid slots.  W host threads per GPU each
-pipeline their own steps against the GPU.
+pass of the whole path over all of a GPU's channels as ONE batch, enqueued by ONE call (tgpu_sync_multi_launch): GPU
+training-sequence search + demux/de-interleave of every grid slot, the reference's synchroniser walk of every channel
+ON THE GPU (k_walk, tetra_burst_sync_in() semantics at 64-byte feeds), device-built lists, SB1 -> code fill -> masks ->
+both trellis kernels; records stay in HBM.  value counts DELIVERED bursts (what tetra_burst_rx_cb() would have been
+handed), not grid slots.  One host thread per GPU keeps `--depth` steps in flight.
+
+Timing (round 3): ONE continuous run of warm-up + windows x K steps + tail; a window = completion of step w ->
+completion of step w + K (HIP events behind every step's last operation), i.e. exactly K classifications, K walks and K
+decodes complete inside it; ms_per_step = the median window, the list is in the line (timing.windows_ms_per_step),
+next to the contract's own form (K steps between two synchronisations, ramp-up and drain included).
 
 The JSON line also carries
   roofline     : the dominant kernel's algorithmic bytes / its HIP-event duration vs HBM peak (+ PMC traffic)
-  cpu_baseline : the oracle's receiver (CPU restatement of tetra-rx's path) on the same stream, 64-byte feeds,
+  cpu_baseline : the oracle's receiver (CPU restatement of tetra-rx's path) on channel 0's stream, 64-byte feeds,
                  one thread, with the Viterbi the reference really runs (libosmocore's accelerated form), the
                  generic one beside it, and the same receiver on every usable host core at once (all_cores)
+  end_to_end   : host buffer -> H2D -> the same step -> D2H of wire records -> a callback per delivered record
   breakdown_ms : host CPU per step (process_time), the per-kernel HIP-event durations
   config2      : BASELINE configs[1] (1 M aligned NDB bursts, no sync front end) as a secondary measurement
-  N > 1        : decode_only and gathered (every step's 40-byte wire records to rank 0 through the library's
-                 tgpu_comm_gather, RCCL, overlapped; under a watchdog); value = the gathered rate
+  N > 1        : single_gpu_reference (rank 0 alone, same job), decode_only and gathered (every step's 40-byte wire
+                 records to rank 0 through the library's tgpu_comm_gather, RCCL, on the step's stream; under a
+                 watchdog), per_gpu_efficiency of both; value = the gathered rate
 --workload config5 | conv | config2: the other BASELINE configs / the generic trellis (own roofline, cpu_baseline).
 """
 import argparse
@@ -168,7 +175,7 @@ def cpu_baseline_stream(stream, budget_s=7.0):
     except Exception as ex:      # pragma: no cover
         allc = {"error": repr(ex)}
     return {"value": res[1][0], "unit": "bursts/s", "cores": 1, "kind": "port", "all_cores": allc,
-            "sample": f"{res[1][1]} bursts delivered from the first {res[1][1] * 510 // 1000} kB of the same stream in "
+            "sample": f"{res[1][1]} bursts delivered from the first {res[1][1] * 510 // 1000} kB of channel 0's stream (the bytes the GPU run had) in "
                       f"{res[1][2]:.1f} s: oracle/tetra_oracle.c receiver ({build}; synchroniser + demux + descramble + "
                       f"de-interleave + de-puncture + Viterbi + CRC, no callbacks / printing), 64-byte feeds, one thread, "
                       f"libosmocore's accelerated Viterbi restated (what osmo_conv_decode() dispatches N=4, K=5 to)",
@@ -207,11 +214,18 @@ def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1):  # noqa: D401
     return stream, types, code
 
 
+def _median(xs):
+    xs = sorted(xs)
+    m = len(xs) // 2
+    return xs[m] if len(xs) & 1 else 0.5 * (xs[m - 1] + xs[m])
+
+
 def bench_mix(args, T, torch, dist, rank, world, local):
     """the metric's workload (BASELINE configs[2] composition, laid out as configs[3]'s per-GPU share): every GPU has
-    C recorded channels of its own, all of them in one batch per step"""
-    import queue
-    import threading
+    C recorded channels of its own, all of them in one batch per step.  One host thread per rank; a step is ONE call
+    (tgpu_sync_multi_launch: classification, the synchroniser walks on the device, lists, decode -- nothing waited for
+    on the host), `depth` steps are in flight on as many streams / plans."""
+    import collections
     n, C = args.bursts, max(1, args.channels)
     per = n // C
     streams, codes = [], []
@@ -230,189 +244,118 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     eng = T.Engine(local)
     d_base = torch.from_numpy(buf).cuda()
     cap = sum(len(st) // 510 + 32 for st in streams)
-    cores_per_rank = max(1, host_threads_default() // max(1, world))
-    W = args.sync_threads if args.sync_threads > 0 else max(1, min(8, cores_per_rank))
-    if args.sync_threads <= 0 and args.blocking_sync < 0 and cores_per_rank <= 3:
-        # few cores per GPU: host waits sleep instead of spinning (hipDeviceScheduleBlockingSync, set in main) and
-        # twice as many threads as cores keep the GPU fed while walks run (tools/sweep_cores2.sh: 2 cores, 0.66 -> 0.62 ms)
-        W = 2 * cores_per_rank
-    W = max(1, min(W, args.steps))
+    D = max(2, args.depth)
+    K, R, W = args.steps, max(1, args.windows), max(args.warmup, D)
+    chans = T.multi_chan_table(streams, offs)         # carry-in codes 0: every cell's code is learnt from SB1 inside the batch
+    plans = [T.Plan(eng, cap, C) for _ in range(D)]
+    recs = [torch.empty(cap * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D)]
+    strm = [torch.cuda.Stream() for _ in range(D)]
     gather = world > 1 or args.force_gather
     nccl = args.backend == "nccl"
+    state = {"fellback": 0, "ngrid": 0, "ccomm": None, "impl": None}
+    wires = sink = None
 
-    # per-thread resources, kept over both phases
-    res_t = []
-    for w in range(W):
-        r = {"rec": [torch.empty(cap * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(2)],
-             "plan": [T.Plan(eng, cap, C) for _ in range(2)],
-             "dec": [torch.cuda.Stream() for _ in range(2)], "cst": [torch.cuda.Stream() for _ in range(2)]}
-        if gather:
-            r["wire"] = [torch.full((cap * T.WIRE_BYTES,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(2)]
-            r["sent"] = [None, None]         # CUDA event: the gather that last read this wire buffer is done
-        res_t.append(r)
-    ccomm = None
-    if gather:
-        comm = torch.cuda.Stream()
-        # rank 0: two sinks (even / odd steps), rank-major like tgpu_comm_gather fills them
-        sink_flat = [torch.empty(world * cap * T.WIRE_BYTES, dtype=torch.uint8, device="cuda" if nccl else "cpu")
-                     for _ in range(2)] if rank == 0 else [None, None]
-        sink = [list(f.view(world, -1).unbind(0)) for f in sink_flat] if rank == 0 else [None, None]
+    def finish(ms):
+        outs = ms.collect(raw=True)
+        assert all(x["noffgrid"] == 0 for x in outs)
+        state["fellback"] += int(ms.fellback)
+        state["ngrid"] = ms.ngrid
+        return sum(x["nslots"] for x in outs)
 
-    cpu = [0.0]
+    def exchange(j):
+        """this step's decoded blocks (40-byte wire records of the batch's grid slots) to rank 0, on the step's own stream:
+        it waits for this decode only and runs beside the other streams' kernels"""
+        nbytes = cap * T.WIRE_BYTES      # the same on every rank (recordings of equal length): grid slots + 32 slack slots per channel
+        w = wires[j][:nbytes]
+        if nccl and state["ccomm"] is not None:
+            state["ccomm"].gather(w.data_ptr(), nbytes, sink[j].data_ptr() if rank == 0 else 0, 0, strm[j].cuda_stream)
+        elif nccl:
+            with torch.cuda.stream(strm[j]):
+                dist.gather(w, gather_list=list(sink[j].view(world, -1)[:, :nbytes].unbind(0)) if rank == 0 else None, dst=0)
+        else:       # control-flow check on a box with fewer GPUs than ranks: staged through the host
+            strm[j].synchronize()
+            dist.gather(w.cpu(), gather_list=list(sink[j].view(world, -1)[:, :nbytes].unbind(0)) if rank == 0 else None, dst=0)
 
-    def run_phase(nsteps, nwarm, with_gather):
-        """nwarm + nsteps steps per rank, dealt round-robin to the W threads; returns (seconds, delivered bursts, state)"""
-        total = nwarm + nsteps
-        start = threading.Barrier(W + 1)
-        ready = [threading.Event() for _ in range(total)]     # step s has been launched (its CUDA event recorded)
-        info = [None] * total
-        state, errors = {}, []
+    def run(total, with_gather):
+        """`total` steps back to back, at most D in flight; returns (delivered bursts per step, completion events)"""
+        evs, fl, delivered = [], collections.deque(), []
+        for k in range(total):
+            j = k % D
+            if len(fl) == D:
+                delivered.append(finish(fl.popleft()))
+            plans[j].set_wire(wires[j].data_ptr() if with_gather else 0)
+            fl.append(T.MultiSyncDev(eng, plans[j], None, d_base.data_ptr(), None, recs[j].data_ptr(), 64,
+                                     strm[j].cuda_stream, chans=chans))
+            if with_gather:
+                exchange(j)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(strm[j])
+            evs.append(ev)
+        while fl:
+            delivered.append(finish(fl.popleft()))
+        return delivered, evs
 
-        def worker(w):
-            try:
-                torch.cuda.set_device(local)
-                r = res_t[w]
-                mine = list(range(w, total, W))
-                done = [None, None]
-                ms = [None, None]
-                t_sync, delivered, outs, last = 0.0, 0, None, 0
-                if mine:
-                    ms[0] = T.MultiSync(eng, r["plan"][0], streams, d_base.data_ptr(), offs, 64, r["cst"][0].cuda_stream, codes=None)
-                for k, s_id in enumerate(mine):
-                    if s_id >= nwarm and (k == 0 or mine[k - 1] < nwarm):
-                        for e in done:
-                            if e is not None:
-                                e.synchronize()
-                        start.wait()             # the timed region starts when every thread has warmed up
-                        start.wait()
-                        t_sync, delivered = 0.0, 0
-                    i, j = k & 1, (k & 1) ^ 1
-                    if k + 1 < len(mine):
-                        if done[j] is not None:
-                            done[j].synchronize()    # the decode that last used that plan / record buffer
-                        ms[j] = T.MultiSync(eng, r["plan"][j], streams, d_base.data_ptr(), offs, 64, r["cst"][j].cuda_stream)
-                    a = time.perf_counter()
-                    outs = ms[i].finish(burst_events=False, nthreads=args.walk_threads)
-                    assert all(x["noffgrid"] == 0 for x in outs)
-                    t_sync += time.perf_counter() - a
-                    delivered += sum(x["nslots"] for x in outs)
-                    if with_gather:
-                        if r["sent"][i] is not None:
-                            r["dec"][i].wait_event(r["sent"][i])
-                        r["plan"][i].set_wire(r["wire"][i].data_ptr())
-                    else:
-                        r["plan"][i].set_wire(0)
-                    r["plan"][i].execute(d_base.data_ptr(), r["rec"][i].data_ptr(), r["dec"][i].cuda_stream)
-                    done[i] = torch.cuda.Event()
-                    done[i].record(r["dec"][i])
-                    if with_gather:
-                        info[s_id] = (w, i, done[i])
-                        ready[s_id].set()
-                    last = i
-                if not any(s >= nwarm for s in mine):      # a thread without a timed step still meets the barrier
-                    start.wait()
-                    start.wait()
-                for e in done:
-                    if e is not None:
-                        e.synchronize()
-                state[w] = (outs, last, t_sync, delivered, len([s for s in mine if s >= nwarm]))
-            except Exception as ex:          # pragma: no cover
-                errors.append(ex)
-                for e in ready:
-                    e.set()
-                start.abort()
-
-        warm_gathered = threading.Event()
-
-        def gatherer():
-            """every step's decoded blocks (wire records) to rank 0, in step order, on a stream of its own: the
-            exchange of step s waits for that step's decode only, and runs under the decodes that follow.  nccl: the
-            library's own gather (tgpu_comm_gather: grouped RCCL send / receive, csrc/tg_comm.c); the warm-up steps'
-            exchanges are complete before the main thread's barrier opens the timed region, so no two threads are ever
-            inside the communication library at once"""
-            try:
-                torch.cuda.set_device(local)
-                for s_id in range(total):
-                    if s_id == nwarm:
-                        if nccl:
-                            comm.synchronize()
-                        warm_gathered.set()
-                    ready[s_id].wait()
-                    if errors:
-                        return
-                    w, i, ev = info[s_id]
-                    wire = res_t[w]["wire"][i]
-                    if nccl:
-                        comm.wait_event(ev)
-                        if ccomm is not None:
-                            ccomm.gather(wire.data_ptr(), wire.numel(), sink_flat[s_id & 1].data_ptr() if rank == 0 else 0,
-                                         0, comm.cuda_stream)
-                        else:
-                            with torch.cuda.stream(comm):
-                                dist.gather(wire, gather_list=sink[s_id & 1] if rank == 0 else None, dst=0)
-                        sent = torch.cuda.Event()
-                        sent.record(comm)
-                        res_t[w]["sent"][i] = sent
-                    else:   # control-flow check on a box with fewer GPUs than ranks: staged through the host
-                        ev.synchronize()
-                        dist.gather(wire.cpu(), gather_list=sink[s_id & 1] if rank == 0 else None, dst=0)
-                if nccl:
-                    comm.synchronize()
-            except Exception as ex:          # pragma: no cover
-                errors.append(ex)
-            finally:
-                warm_gathered.set()
-
-        threads = [threading.Thread(target=worker, args=(w,)) for w in range(W)]
-        gth = threading.Thread(target=gatherer) if with_gather else None
-        for th in threads:
-            th.start()
-        if gth:
-            gth.start()
-        start.wait()
-        if gth:
-            warm_gathered.wait()
+    def sync_all():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        c0 = time.process_time()
-        start.wait()
-        for th in threads:
-            th.join()
-        cpu[0] = time.process_time() - c0      # CPU seconds of all threads of this rank over the timed region
-        if gth:
-            gth.join()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+
+    def measure(with_gather, alone=False):
+        """one continuous run of W + R K + D steps (the pipeline stays full before, through and after the timed steps);
+        window r = completion of step W - 1 + r K  ->  completion of step W - 1 + (r + 1) K: exactly K classifications,
+        K walks, K decodes (and K exchanges) complete inside it.  Plus the contract's form: K steps between two
+        synchronisations (ramp-up and drain included)."""
+        run(max(D, K if not alone else D), with_gather)    # allocations, first-use paths, clocks
+        if not alone:
+            sync_all()
+        else:
             torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if errors:
-            raise errors[0]
-        return el, sum(v[3] for v in state.values()), state
+        c0, t0 = time.process_time(), time.perf_counter()
+        delivered, evs = run(W + R * K + D, with_gather)
+        torch.cuda.synchronize()
+        cpu_s, wall_s = time.process_time() - c0, time.perf_counter() - t0
+        tk = [evs[W - 1].elapsed_time(e) for e in evs[W - 1:]]
+        for i in range(1, len(tk)):               # (steps run on D streams: completion times are made monotone)
+            tk[i] = max(tk[i], tk[i - 1])
+        win = [(tk[(r + 1) * K] - tk[r * K]) / K for r in range(R)]
+        per_step = delivered[W]
+        assert all(x == per_step for x in delivered), "the same recording gave different numbers of bursts"
+        if not alone:
+            sync_all()
+        t1 = time.perf_counter()
+        run(K, with_gather)
+        if not alone:
+            sync_all()
+        else:
+            torch.cuda.synchronize()
+        bracket = (time.perf_counter() - t1) / K * 1e3
+        if world > 1 and not alone:
+            dev = "cuda" if nccl else "cpu"
+            t = torch.tensor(win + [bracket], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            win, bracket = t[:-1].tolist(), float(t[-1].item())
+            d = torch.tensor([float(per_step)], dtype=torch.float64, device=dev)
+            dist.all_reduce(d, op=dist.ReduceOp.SUM)
+            tot = int(d.item())
+        else:
+            tot = per_step
+        med = _median(win)
+        return {"value": tot / (med * 1e-3), "ms_per_step": med, "windows_ms_per_step": [round(x, 5) for x in win],
+                "window_spread": (max(win) - min(win)) / med, "all_windows_ms_per_step": (tk[R * K] - tk[0]) / (R * K),
+                "sync_bracketed_ms_per_step": bracket, "bursts_delivered_per_step": tot,
+                "host_cpu_ms_per_step": cpu_s / (W + R * K + D) * 1e3, "host_wall_ms_per_step": wall_s / (W + R * K + D) * 1e3}
 
-    def reduce(el, delivered):
-        if world > 1:
-            t = torch.tensor([el, float(delivered)], dtype=torch.float64, device="cuda" if nccl else "cpu")
-            tmax = t.clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            return float(tmax[0].item()), int(t[1].item())
-        return el, delivered
-
-    warm = max(2 * W, args.warmup)
-    el, delivered, state = run_phase(args.steps, warm, False)
-    cpu_ms_step = cpu[0] / args.steps * 1e3
-    el, delivered = reduce(el, delivered)
-    decode_only = {"value": delivered / el, "ms_per_step": el / args.steps * 1e3, "bursts_delivered": delivered}
-    gathered = None
-    gather_error = None
+    single = None
+    if world > 1:
+        # what ONE of these GPUs does on its own, measured in this very job (rank 0 alone, the others wait): the
+        # reference the per-GPU efficiencies below are quoted against
+        if rank == 0:
+            single = measure(False, alone=True)
+        sync_all()
+    decode_only = measure(False)
+    gathered = gather_error = None
     if gather:
-        # The decode-only number is complete at this point.  The exchange phase runs under a watchdog: a wedged
-        # collective must not cost the run its line -- rank 0 then reports the decode-only rate with the failure
-        # stated, and every rank leaves.
         armed = [True]
 
         def bail():
@@ -420,63 +363,66 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                 return
             if rank == 0:
                 print(json.dumps({"metric": "decoded bursts/s", "value": decode_only["value"], "unit": "bursts/s", "n_gpus": world,
-                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": decode_only["ms_per_step"],
+                                  "steps": K, "warmup": args.warmup, "ms_per_step": decode_only["ms_per_step"],
                                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16",
                                   "data": "synthetic",
                                   "config": {"workload": "SB+NDB mix through the burst-sync front end, %d channels per GPU "
-                                                         "(decode only: the per-step RCCL gather to rank 0 did not finish "
+                                                         "(decode only: the per-step gather to rank 0 did not finish "
                                                          "within %d s and was abandoned)" % (C, args.gather_timeout)},
-                                  "decode_only": decode_only,
+                                  "decode_only": decode_only, "single_gpu_reference": single,
                                   "gathered": {"error": "timeout after %d s" % args.gather_timeout}}), flush=True)
             os._exit(0)
 
         tmr = threading.Timer(args.gather_timeout, bail)
         tmr.daemon = True
         tmr.start()
-        gather_impl = "torch.distributed.gather (gloo, staged through the host)"
         try:
+            wires = [torch.full((cap * T.WIRE_BYTES,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(D)]
+            sink = [torch.empty(world * cap * T.WIRE_BYTES, dtype=torch.uint8, device="cuda" if nccl else "cpu")
+                    for _ in range(D)] if rank == 0 else [None] * D
+            state["impl"] = "torch.distributed.gather (gloo, staged through the host)"
             if nccl and not args.torch_gather:
                 try:     # the library's communicator: rank 0 draws the id, the process group carries its 128 bytes
                     uid = torch.from_numpy(T.comm_unique_id() if rank == 0 else np.zeros(T.COMM_ID_BYTES, np.uint8)).cuda()
                     dist.broadcast(uid, 0)
                     torch.cuda.synchronize()
-                    ccomm = T.Comm(eng, uid.cpu().numpy(), rank, world)
-                    gather_impl = "tgpu_comm_gather (C ABI, grouped RCCL send / receive)"
+                    state["ccomm"] = T.Comm(eng, uid.cpu().numpy(), rank, world)
+                    state["impl"] = "tgpu_comm_gather (C ABI, grouped RCCL send / receive)"
                 except Exception as ex:      # pragma: no cover
-                    ccomm = None
-                    gather_impl = "torch.distributed.gather (nccl); tgpu_comm_create failed: %r" % (ex,)
+                    state["ccomm"] = None
+                    state["impl"] = "torch.distributed.gather (nccl); tgpu_comm_create failed: %r" % (ex,)
             elif nccl:
-                gather_impl = "torch.distributed.gather (nccl)"
-            el_g, del_g, state = run_phase(args.steps, warm, True)
-            el_g, del_g = reduce(el_g, del_g)
+                state["impl"] = "torch.distributed.gather (nccl)"
+            gathered = measure(True)
         except Exception as ex:      # pragma: no cover
             gather_error = repr(ex)
         armed[0] = False
         tmr.cancel()
-    if gather and gather_error is None:
-        ngrid_r = sum((len(st) - 100) // 510 for st in streams)
-        per_rank_mb = cap * T.WIRE_BYTES / 1e6
-        gathered = {"value": del_g / el_g, "ms_per_step": el_g / args.steps * 1e3, "bursts_delivered": del_g,
-                    "exchange": gather_impl,
-                    "bytes_per_rank_and_step": cap * T.WIRE_BYTES,
-                    "link_arithmetic": "every peer sends %.1f MB per step (%d grid slots x %d B wire record, undelivered slots "
-                                       "included) to rank 0 over its own xGMI link: %.1f GB/s per link at the gathered step time, "
-                                       "%.1f GB/s at the decode-only step time (one xGMI link ~ 153 GB/s over both directions, i.e. ~ 77 GB/s towards rank 0; 7 links into "
-                                       "rank 0); rank 0 takes in %.1f GB/s in total"
-                                       % (per_rank_mb, cap, T.WIRE_BYTES, per_rank_mb / (el_g / args.steps * 1e3),
-                                          per_rank_mb / (el / args.steps * 1e3), (world - 1) * per_rank_mb / (el_g / args.steps * 1e3))}
+    if gathered:
+        sent = cap * T.WIRE_BYTES
+        gathered["exchange"] = state["impl"]
+        gathered["bytes_per_rank_and_step"] = sent
+        gathered["link_arithmetic"] = ("every peer sends %.1f MB per step (%d slots x %d B wire record) to rank 0 over its own xGMI "
+                                       "link: %.1f GB/s per link at the gathered step time (one xGMI link ~ 77 GB/s towards rank 0), "
+                                       "rank 0 takes in %.1f GB/s in total"
+                                       % (sent / 1e6, cap, T.WIRE_BYTES, sent / 1e6 / gathered["ms_per_step"],
+                                          (world - 1) * sent / 1e6 / gathered["ms_per_step"]))
     if rank != 0:
         return None
-    outs, last, _, _, _ = state[0]
-    r0 = res_t[0]
-    t_sync = sum(v[2] / max(1, v[4]) for v in state.values()) / W
     hs = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
 
-    # correctness guard on the timed output: a sample of the delivered bursts of every channel against the oracle
-    # (checker only) -- type-1 bits, BBK and CRC words of up to 512 delivered grid slots per channel
+    # one more step, collected in full: the outcome of the timed path for the checks below
+    plans[0].set_wire(wires[0].data_ptr() if gathered else 0)
+    ms = T.MultiSyncDev(eng, plans[0], None, d_base.data_ptr(), None, recs[0].data_ptr(), 64, strm[0].cuda_stream, chans=chans)
+    outs = ms.collect()
+    torch.cuda.synchronize()
+    assert not ms.fellback and state["fellback"] == 0, "the device walk handed a batch to the host walks"
     check = None
-    rec_all = r0["rec"][last].view(-1, T.REC_BYTES)
+    rec_all = recs[0].view(-1, T.REC_BYTES)
     if not args.no_cpu_baseline:
+        # correctness guard on the timed output: delivered bursts of every channel against the oracle (checker only) --
+        # type-1 bits, BBK, CRC words and codes of up to 512 delivered grid slots per channel
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oraclelib as O
         nchk = 0
@@ -495,18 +441,24 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                 (n1 | n2 | sb).all() and (p["code"][~sb] == codes[c]).all()
             assert good, "decoded records of channel %d differ from the oracle" % c
             nchk += len(first)
-        check = "type-1 bits, BBK, CRC words and scrambling codes of %d delivered bursts (all %d channels) equal the oracle's" % (nchk, C)
+            if gathered:        # ... and what arrived on the collecting rank is this rank's share, byte for byte
+                w0 = sink[0].view(world, -1)[0].view(-1, T.WIRE_BYTES)
+                idx = torch.from_numpy(out["grid_base"] + first)
+                assert torch.equal(w0[idx.to(w0.device)].cpu(), wires[0].view(-1, T.WIRE_BYTES)[idx.cuda()].cpu())
+                back = T.wire_unpack(w0[idx.to(w0.device)].cpu().numpy(), (out["grid_base"] + first).tolist(), [codes[c]] * len(first))
+                pw = T.parse_records(back)
+                assert (pw["bbk"] == p["bbk"]).all() and (pw["crc"][:, 0] == p["crc"][:, 0]).all()
+        check = "type-1 bits, BBK, CRC words and scrambling codes of %d delivered bursts (all %d channels) equal the oracle's%s" % (
+            nchk, C, "; the same bursts' wire records on the collecting rank equal the sender's" if gathered else "")
 
-    # per-kernel durations (HIP events on the launch stream, after the timed region): the front end on channel 0's
-    # share is not representative -- time the batch's own launches
-    us_front, us_fix = T.sync_front_prof_multi(eng, r0["plan"][last ^ 1], streams, d_base.data_ptr(), offs, 64, 10, hs)
+    # per-kernel durations: the same step with HIP events between all of its stages, on the launch stream
     prof = T.Prof(8)
+    dev = []
     for q in range(8):
-        r0["plan"][last].execute_prof(d_base.data_ptr(), r0["rec"][last].data_ptr(), hs, prof, q)
-    torch.cuda.synchronize()
-    st_ms = prof.read(8)[2:].mean(axis=0)      # ms per stage (k_front is skipped in stream mode: stage 0 is empty)
+        dev.append(T.sync_multi_launch_prof(eng, plans[1], chans, d_base.data_ptr(), recs[1].data_ptr(), prof, q, 64, hs))
+    st_ms = prof.read(8)[2:].mean(axis=0)
     names = T.Prof.stage_names()
-    kern_ms = {"k_front_stream": us_front * 1e-3, "k_front_stream_fix": us_fix * 1e-3}
+    kern_ms = {k: float(np.mean([x[k] for x in dev[2:]])) for k in dev[0]}
     for i in range(1, len(names)):
         kern_ms[names[i]] = float(st_ms[i])
     dom = max(kern_ms, key=kern_ms.get)
@@ -514,11 +466,11 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     nd = sum(x["nslots"] for x in outs)
     n_sb, n_n1, n_n2 = nd // 8, nd // 2, nd - nd // 8 - nd // 2     # delivered bursts by type (the damage is uniform)
     # 510 B in per slot the front end looks at; type-1 bits at 1 B/bit + 16 B per block out
-    alg = {"k_front_stream": ngrid * 510, "k_front_stream_fix": 0,
-           "k_vit<SB1>": n_sb * (60 + 16), "k_fill": 0, "k_masks": 0,
+    alg = {"k_front_stream": ngrid * 510,
+           "k_vit<SB1>": n_sb * (60 + 16),
            "k_vit<216>": n_n2 * (14 + 124 + 124 + 3 * 16) + n_sb * (14 + 124 + 2 * 16),
            "k_vit<432>": n_n1 * (14 + 268 + 2 * 16)}
-    achieved = alg[dom] / (kern_ms[dom] * 1e-3) / 1e9
+    achieved = alg.get(dom, 0) / (kern_ms[dom] * 1e-3) / 1e9
     traffic = valu_busy = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -526,26 +478,89 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         valu_busy = tj.get("mix_valu_busy", {}).get(dom)
     except Exception:
         pass
+
+    # the second number SURVEY 8(d) asks for: end to end -- pinned host buffer -> H2D -> the same step -> D2H of the
+    # wire records -> every delivered record handed to a (no-op) callback; 2 steps in flight
+    e2e = None
+    if world == 1 and not args.no_e2e:
+        try:
+            h_in = torch.from_numpy(buf).pin_memory()
+            d_in = [torch.empty_like(d_base) for _ in range(2)]
+            wr = [torch.full((cap * T.WIRE_BYTES,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            h_w = [torch.empty(cap * T.WIRE_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            ne = max(4, args.e2e_steps)
+            fl, handed = collections.deque(), 0
+
+            def e2e_finish(item):
+                msd, j = item
+                outs_ = msd.collect(raw=True)
+                strm[j].synchronize()
+                return T.wire_foreach_noop(h_w[j].numpy()[:msd.ngrid * T.WIRE_BYTES], None, msd.ngrid), sum(x["nslots"] for x in outs_)
+
+            for phase, steps in (("warm", 2), ("timed", ne)):
+                if phase == "timed":
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    handed = 0
+                for k in range(steps):
+                    j = k & 1
+                    if len(fl) == 2:
+                        a, b = e2e_finish(fl.popleft())
+                        assert a == b, (a, b)
+                        handed += a
+                    with torch.cuda.stream(strm[j]):
+                        d_in[j].copy_(h_in, non_blocking=True)
+                    plans[j].set_wire(wr[j].data_ptr())
+                    msd = T.MultiSyncDev(eng, plans[j], None, d_in[j].data_ptr(), None, recs[j].data_ptr(), 64, strm[j].cuda_stream,
+                                         chans=chans)
+                    with torch.cuda.stream(strm[j]):
+                        h_w[j].copy_(wr[j], non_blocking=True)
+                    fl.append((msd, j))
+                while fl:
+                    a, b = e2e_finish(fl.popleft())
+                    assert a == b, (a, b)
+                    handed += a
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            e2e = {"value": handed / el, "unit": "bursts/s", "steps": ne, "ms_per_step": el / ne * 1e3,
+                   "h2d_bytes_per_step": int(buf.nbytes), "d2h_bytes_per_step": int(cap * T.WIRE_BYTES),
+                   "pcie_bound_bursts_per_s": 63e9 / 510.0,
+                   "note": "pinned host buffer (1 bit per byte, %.0f MB) -> H2D -> classification / walks / decode -> D2H of the "
+                           "40-byte wire records -> every delivered record handed to a no-op C callback (tgpu_wire_foreach); "
+                           "2 steps in flight; bound by the 510 B per burst over PCIe (63 GB/s -> 1.2e8 bursts/s), not by the "
+                           "kernels" % (buf.nbytes / 1e6)}
+            for p_ in plans:
+                p_.set_wire(0)
+        except Exception as ex:      # pragma: no cover
+            e2e = {"error": repr(ex)}
+
     head = gathered if gathered else decode_only
-    value = head["value"]
-    out = {"metric": "decoded bursts/s", "value": value, "unit": "bursts/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+    out = {"metric": "decoded bursts/s", "value": head["value"], "unit": "bursts/s", "n_gpus": world,
+           "steps": K, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
            "config": {"workload": "SB+NDB mix through the burst-sync front end (BASELINE configs[2] composition in configs[3]'s layout): "
                                   "per GPU %d recorded channels of %d slots each (own cell each), frames [SB,N1,N2,N1,N2,N1,N2,N1], cell "
                                   "code from SB1, 1%% damaged training sequences, resident in HBM; step = one pass over all of a GPU's "
-                                  "channels as ONE batch (GPU sequence search + demux of every grid slot, host synchroniser walks at "
-                                  "64-byte feeds, device lists, SB1 / fill / masks / trellis); value = delivered bursts/s%s; %d host "
-                                  "threads per GPU, each pipelining its own steps" %
-                                  (C, per, ", every step's decoded blocks gathered to rank 0 (40-B wire records, RCCL, overlapped)" if gathered else "", W),
+                                  "channels as ONE batch (GPU sequence search + demux of every grid slot, the synchroniser walks of "
+                                  "all channels on the GPU at 64-byte feeds, device lists, SB1 / fill / masks / trellis); value = "
+                                  "delivered bursts/s%s; one host thread per GPU, %d steps in flight" %
+                                  (C, per, ", every step's decoded blocks gathered to rank 0 (40-B wire records, RCCL)" if gathered else "", D),
                       "channels_per_gpu": C, "slots_per_channel": per, "grid_slots_per_step": int(ngrid),
-                      "delivered_per_step": int(nd), "host_threads_per_gpu": W,
-                      "parallelism": "channels sharded over GPUs (8 per GPU), no collective in decoding" +
-                                     ("; one RCCL gather of wire records per step to rank 0, on its own stream" if gathered else ""),
+                      "delivered_per_step": int(nd), "host_threads_per_gpu": 1, "steps_in_flight": D,
+                      "parallelism": "channels sharded over GPUs (%d per GPU), no collective in decoding" % C +
+                                     ("; one gather of wire records per step to rank 0, on the step's stream" if gathered else ""),
                       "check": check},
-           "breakdown_ms": {"host cpu per step, all threads of rank 0 (process_time over the decode-only region)": cpu_ms_step,
-                            "sync finish per step and thread (wait for the classification, host walks, device list build)": t_sync * 1e3,
-                            "gpu kernels per step (serialised, HIP events)": kern_ms},
+           "timing": {"method": "one continuous run of warm-up + %d x %d steps + tail with %d steps in flight; ms_per_step = median over "
+                                "the %d windows of (completion of step w + K) - (completion of step w) / K from HIP events recorded "
+                                "behind each step's last operation: exactly K classifications, K walks, K decodes complete inside "
+                                "a window; max over ranks per window" % (R, K, D, R),
+                      "windows_ms_per_step": head["windows_ms_per_step"], "window_spread": head["window_spread"],
+                      "all_windows_ms_per_step": head["all_windows_ms_per_step"],
+                      "sync_bracketed_ms_per_step (K steps between two synchronisations, ramp-up and drain included)": head["sync_bracketed_ms_per_step"],
+                      "front_end_launches_per_window": K},
+           "breakdown_ms": {"host cpu per step (process_time over the continuous run: the launching thread + the HIP runtime's own)": head["host_cpu_ms_per_step"],
+                            "host wall per step of the continuous run": head["host_wall_ms_per_step"],
+                            "gpu kernels per step (serialised, HIP events on the launch stream)": kern_ms},
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
                         "kernel_ms": kern_ms[dom],
@@ -556,12 +571,16 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                                 "region; traffic = PMC bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes) and "
                                 "valu_busy_frac from profiles/traffic.json of the same command; every kernel of this path is bound by "
                                 "vector-instruction issue, not by HBM (DESIGN.md section 4)"}}
-    if gathered:
+    if e2e:
+        out["end_to_end"] = e2e
+    if gathered or gather_error:
         out["decode_only"] = decode_only
-        out["gathered"] = gathered
-    elif gather_error:
-        out["decode_only"] = decode_only
-        out["gathered"] = {"error": gather_error}
+        out["gathered"] = gathered if gathered else {"error": gather_error}
+    if single:
+        out["single_gpu_reference"] = single
+        out["per_gpu_efficiency"] = {"decode_only": decode_only["value"] / world / single["value"],
+                                     "gathered": (gathered["value"] / world / single["value"]) if gathered else None,
+                                     "note": "per-GPU rate / the rate of rank 0 running alone in this same job (single_gpu_reference)"}
     return out
 
 
@@ -885,29 +904,27 @@ def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=18)
+    ap.add_argument("--steps", type=int, default=20, help="K: steps per timed window")
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--windows", type=int, default=6, help="mix: K-step windows inside the one continuous run (median reported)")
+    ap.add_argument("--depth", type=int, default=3, help="mix: steps in flight per GPU (plans / streams)")
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts (slots) per GPU per step")
     ap.add_argument("--ber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 object of the default run")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (host buffer -> H2D -> step -> D2H -> callback)")
+    ap.add_argument("--e2e-steps", type=int, default=8)
     ap.add_argument("--channels", type=int, default=8, help="mix: recorded channels per GPU (BASELINE config 4: 8), all in one batch")
-    ap.add_argument("--walk-threads", type=int, default=1, help="mix: host threads inside one step's synchroniser walks")
-    ap.add_argument("--sync-threads", type=int, default=0,
-                    help="mix: host threads per GPU, each synchronising (walking) its own recordings (0 = min(8, usable cores / ranks))")
     ap.add_argument("--workload", default="mix", choices=["mix", "config3", "config2", "config5", "conv"],
                     help="mix (default, = config3: the metric's workload): SB+NDB recordings through the GPU burst-sync front end, "
                          "1%% damaged training sequences; config2: aligned NDB slots, no front end; config5: float phases -> "
                          "soft-decision decode; conv: the generic trellis kernel")
-    ap.add_argument("--blocking-sync", type=int, default=-1,
-                    help="1: hipDeviceScheduleBlockingSync (host waits sleep instead of spinning); 0: spin; "
-                         "-1 (default): blocking only when a rank has three cores or fewer")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the exchange phase with a single rank too (exercises the RCCL path on a 1-GPU box)")
     ap.add_argument("--torch-gather", action="store_true",
                     help="N > 1: exchange through torch.distributed.gather instead of the library's tgpu_comm_gather")
     ap.add_argument("--gather-timeout", type=int, default=150,
-                    help="N > 1: seconds the exchange phase (per-step RCCL gather to rank 0) may take before the run reports "
+                    help="N > 1: seconds the exchange phase (per-step gather to rank 0) may take before the run reports "
                          "the decode-only number and leaves")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = control-flow check on a box with fewer GPUs than ranks")
@@ -928,12 +945,17 @@ def main():
     if args.backend == "gloo":
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
-    starved = max(1, host_threads_default() // max(1, world)) <= 3
-    if args.blocking_sync > 0 or (args.blocking_sync < 0 and starved and args.sync_threads <= 0):
-        import ctypes
-        rc_ = ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(4)     # hipDeviceScheduleBlockingSync
-        if rc_:
-            print("hipSetDeviceFlags ->", rc_, file=sys.stderr)
+    pinned = None
+    if world > 1 and hasattr(os, "sched_setaffinity"):
+        # every rank keeps to its own share of the cores (one host thread per rank does the launching)
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            share = max(1, len(cores) // world)
+            mine = cores[local * share:(local + 1) * share] or cores
+            os.sched_setaffinity(0, mine)
+            pinned = len(mine)
+        except OSError:
+            pass
     if world > 1 or args.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
@@ -952,9 +974,12 @@ def main():
         out = bench_config2(args, T, torch, dist, rank, world, local, args.steps, args.warmup)
     else:
         out = bench_mix(args, T, torch, dist, rank, world, local)
+        if rank == 0:
+            out["config"]["host_cores_per_rank"] = pinned if pinned else host_threads_default()
         if rank == 0 and world == 1:
             if not args.no_cpu_baseline:
-                stream, _, _ = make_mix_stream(T, min(args.bursts, 400_000), rank, mnc=42 + rank)
+                # channel 0 of rank 0 as the timed run had it (the generator is deterministic)
+                stream, _, _ = make_mix_stream(T, args.bursts // max(1, args.channels), 0, mnc=42, cc=1)
                 out["cpu_baseline"] = cpu_baseline_stream(stream)
             if not args.no_secondary:
                 c2 = bench_config2(args, T, torch, dist, rank, world, local, 40, 10, with_cpu=False)

@@ -513,6 +513,21 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd);
 int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd);
 void tgpu_sync_dev_free(struct tgpu_sync_dev *sd);
+/* measurement aid: one such batch, synchronously, with HIP events between all of its stages on hip_stream: dev_ms[] =
+ * the stages in front of the decode (names: tgpu_sync_dev_stage_name), the decode's stages in prof / step as
+ * tgpu_plan_execute_prof() leaves them (read with tgpu_prof_read; stage 0, k_front, is empty in stream mode) */
+#define TGPU_NDEVSTAGES 5
+int tgpu_sync_multi_launch_prof(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+				const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, void *hip_stream, struct tgpu_prof *prof,
+				uint32_t step, float dev_ms[TGPU_NDEVSTAGES]);
+const char *tgpu_sync_dev_stage_name(int stage);
+/* the consumer's end of a gathered batch: every delivered burst's 40-byte wire record (csrc/tg_layout.h) handed to a
+ * callback, in grid order.  grid_bits = the delivered bitmap of the ngrid slots (NULL: every record that carries a burst
+ * type); cb == NULL only counts.  Returns the number of records handed over.  tgpu_wire_noop_cb(): a callback that reads
+ * the record's header and does nothing else (priv -> a uint64_t), for measurements. */
+typedef void (*tgpu_wire_cb)(const uint8_t *wire_rec, uint32_t grid_slot, void *priv);
+uint64_t tgpu_wire_foreach(const uint8_t *wire, const uint32_t *grid_bits, uint32_t ngrid, tgpu_wire_cb cb, void *priv);
+tgpu_wire_cb tgpu_wire_noop_cb(void);
 /* measurement aid, as tgpu_sync_front_prof() for a multi-channel batch */
 int tgpu_sync_front_prof_multi(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
 			       const uint8_t *d_base, uint32_t chunk, uint32_t nrep, float us[2], void *hip_stream);

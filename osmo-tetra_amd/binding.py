@@ -172,6 +172,8 @@ def lib():
     L.tgpu_sync_multi_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(MultiChan), C.c_void_p, C.c_uint32, C.c_void_p,
                                          C.POINTER(C.c_void_p), C.c_void_p]
     L.tgpu_sync_multi_collect.argtypes = [C.c_void_p, C.POINTER(SyncResult)]
+    L.tgpu_sync_multi_launch_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(MultiChan), C.c_void_p, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.tgpu_sync_dev_ngrid.argtypes = [C.c_void_p]
     L.tgpu_sync_dev_ngrid.restype = C.c_uint32
     L.tgpu_sync_dev_fellback.argtypes = [C.c_void_p]
@@ -754,6 +756,32 @@ class MultiSyncDev:
     def __del__(self):
         if getattr(self, "_h", None):
             lib().tgpu_sync_dev_free(self._h)
+
+
+DEV_STAGES = 5
+
+
+def sync_multi_launch_prof(engine, plan, chans, d_base_ptr, d_rec_ptr, prof, step, chunk=64, hip_stream=0):
+    """tgpu_sync_multi_launch_prof: one device-walk batch, synchronously, HIP events between all stages.  Returns
+    {stage name: ms} for the stages in front of the decode; the decode's own stages are in prof[step]"""
+    xs, ch = chans
+    ms = (C.c_float * DEV_STAGES)()
+    _chk(lib().tgpu_sync_multi_launch_prof(engine._h, plan._h, len(xs), ch, C.c_void_p(d_base_ptr), chunk, C.c_void_p(d_rec_ptr),
+                                           C.c_void_p(hip_stream), prof._h, step, ms), "tgpu_sync_multi_launch_prof")
+    lib().tgpu_sync_dev_stage_name.restype = C.c_char_p
+    return {lib().tgpu_sync_dev_stage_name(i).decode(): float(ms[i]) for i in range(DEV_STAGES)}
+
+
+def wire_foreach_noop(wire, grid_bits, ngrid):
+    """tgpu_wire_foreach with the library's no-op callback: number of delivered records handed over (host arrays)"""
+    w = _np_u8(wire)
+    acc = C.c_uint64(0)
+    lib().tgpu_wire_noop_cb.restype = C.c_void_p
+    lib().tgpu_wire_foreach.restype = C.c_uint64
+    lib().tgpu_wire_foreach.argtypes = [u8p, u32p, C.c_uint32, C.c_void_p, C.c_void_p]
+    bits = None if grid_bits is None else np.ascontiguousarray(grid_bits, np.uint32)
+    return int(lib().tgpu_wire_foreach(w.ctypes.data_as(u8p), bits.ctypes.data_as(u32p) if bits is not None else None, ngrid,
+                                       lib().tgpu_wire_noop_cb(), C.cast(C.byref(acc), C.c_void_p)))
 
 
 def multi_chan_table(streams, d_offs, codes=None):

@@ -1405,8 +1405,57 @@ void tgpu_sync_dev_free(struct tgpu_sync_dev *sd)
 	free(sd);
 }
 
+/* evs (optional): TGPU_NDEVSTAGES + 1 events recorded around the stages in front of the decode; prof / step: per-stage events
+ * of the decode itself (tgpu_plan_execute_prof) */
+static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+			const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *stream,
+			hipEvent_t *evs, struct tgpu_prof *prof, uint32_t step);
+
 int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
 			   const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *stream)
+{
+	return multi_launch(eng, plan, nchan, ch, d_base, chunk, d_rec, out, stream, NULL, NULL, 0);
+}
+
+const char *tgpu_sync_dev_stage_name(int stage)
+{
+	static const char *const names[TGPU_NDEVSTAGES] = { "k_front_stream", "k_front_stream_fix", "k_cls_plain", "k_walk", "k_grid_lists" };
+	return (stage >= 0 && stage < TGPU_NDEVSTAGES) ? names[stage] : "?";
+}
+
+/* measurement aid: one batch, synchronously, with HIP events between all of its stages on hip_stream: dev_ms[] = the
+ * TGPU_NDEVSTAGES stages in front of the decode (tgpu_sync_dev_stage_name), the decode's own stages in prof / step as
+ * tgpu_plan_execute_prof() leaves them (stage 0, k_front, is empty in stream mode) */
+int tgpu_sync_multi_launch_prof(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+				const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, void *stream, struct tgpu_prof *prof,
+				uint32_t step, float dev_ms[TGPU_NDEVSTAGES])
+{
+	if (!prof || !dev_ms)
+		return TGPU_EINVAL;
+	int rc = tgpi_engine_bind(eng);
+	if (rc)
+		return rc;
+	hipEvent_t evs[TGPU_NDEVSTAGES + 1];
+	memset(evs, 0, sizeof(evs));
+	for (int i = 0; i <= TGPU_NDEVSTAGES && !rc; i++)
+		rc = (int)hipEventCreate(&evs[i]);
+	struct tgpu_sync_dev *sd = NULL;
+	if (!rc)
+		rc = multi_launch(eng, plan, nchan, ch, d_base, chunk, d_rec, &sd, stream, evs, prof, step);
+	if (!rc)
+		rc = (int)hipStreamSynchronize((hipStream_t)stream);
+	for (int i = 0; i < TGPU_NDEVSTAGES && !rc; i++)
+		rc = (int)hipEventElapsedTime(&dev_ms[i], evs[i], evs[i + 1]);
+	for (int i = 0; i <= TGPU_NDEVSTAGES; i++)
+		if (evs[i])
+			(void)hipEventDestroy(evs[i]);
+	tgpu_sync_dev_free(sd);
+	return rc;
+}
+
+static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+			const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *stream,
+			hipEvent_t *evs, struct tgpu_prof *prof, uint32_t step)
 {
 	if (!eng || !plan || !nchan || nchan > 64 || !ch || !d_base || !d_rec || !out)
 		return TGPU_EINVAL;
@@ -1480,22 +1529,29 @@ int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint
 			rc = tgpi_plan_chan_table(plan, st->ent, nchan, &d_tab, stream);
 		if (!rc)
 			rc = (int)hipMemcpyAsync(d_roots, sd->h_roots, (size_t)nchan * sizeof(*d_roots), hipMemcpyHostToDevice, sd->stream);
+#define EVMARK(i) do { if (evs && !rc) rc = (int)hipEventRecord(evs[i], sd->stream); } while (0)
+		if (!rc)
+			rc = tgpi_plan_grid_layout_dev(plan, st->ngrid, nchan, codes, &d_bits, stream);
+		EVMARK(0);
 		if (!rc)
 			rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
-						    tgpi_plan_defer_scratch(plan), stream, NULL);
+						    tgpi_plan_defer_scratch(plan), stream, evs ? evs[1] : NULL);
+		EVMARK(2);
 		if (!rc) {
 			tgpi_plan_grid_plain(plan, st->ngrid, &d_plain, &h_plain);
 			rc = tgk_cls_plain(d_cls, st->ngrid, d_plain, stream);
 		}
-		if (!rc)
-			rc = tgpi_plan_grid_layout_dev(plan, st->ngrid, nchan, codes, &d_bits, stream);
+		EVMARK(3);
 		if (!rc)
 			rc = tgk_walk(d_base, d_tab, d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, d_sums, d_events, TGW_EVCAP,
 				      d_recs, stream);
+		EVMARK(4);
 		if (!rc)
 			rc = tgpi_plan_grid_lists_dev(plan, st->ent, stream);
+		EVMARK(5);
+#undef EVMARK
 		if (!rc)
-			rc = tgpu_plan_execute(plan, d_base, d_rec, stream);
+			rc = prof ? tgpu_plan_execute_prof(plan, d_base, d_rec, stream, prof, step) : tgpu_plan_execute(plan, d_base, d_rec, stream);
 		/* what the host wants to know: summaries, the first events of every channel, the bitmap */
 		if (!rc)
 			rc = (int)hipMemcpyAsync(sd->h_sums, d_sums, (size_t)nchan * sizeof(*d_sums), hipMemcpyDeviceToHost, sd->stream);
@@ -1538,7 +1594,17 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 	int rc = tgpi_engine_bind(st->eng);
 	if (rc)
 		return rc;
-	rc = (int)hipEventSynchronize(sd->done);
+	/* wait for the batch: the stream's completion event is polled with short sleeps in between -- a spinning
+	 * hipEventSynchronize() costs a whole core per GPU for as long as the GPU works (TGPU_SPIN_WAIT=1 does that) */
+	if (getenv("TGPU_SPIN_WAIT"))
+		rc = (int)hipEventSynchronize(sd->done);
+	else {
+		hipError_t q;
+		const struct timespec nap = { 0, 20000 };
+		while ((q = hipEventQuery(sd->done)) == hipErrorNotReady)
+			nanosleep(&nap, NULL);
+		rc = (int)q;
+	}
 	if (rc)
 		return rc;
 	int fb = 0;
@@ -1612,4 +1678,46 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 		tgpi_plan_set_last_slot(st->plan, c, last);
 	}
 	return rc;
+}
+
+
+/* Hand every delivered burst's wire record of a gathered batch to a callback (host): wire = the 40-byte records of ngrid
+ * grid slots, grid_bits = the delivered bitmap of the same slots (NULL: every slot whose record carries a burst type).
+ * cb == NULL counts only.  Returns the number of records handed over.  What the end-to-end measurement of bench.py ends
+ * in: the consumer's side of "records delivered to a callback" without unpacking (tgpu_wire_unpack does that per record). */
+uint64_t tgpu_wire_foreach(const uint8_t *wire, const uint32_t *grid_bits, uint32_t ngrid, tgpu_wire_cb cb, void *priv)
+{
+	uint64_t n = 0;
+	if (!wire)
+		return 0;
+	if (grid_bits) {
+		for (uint32_t w = 0; w < (ngrid + 31) / 32; w++)
+			for (uint32_t z = grid_bits[w]; z; z &= z - 1) {
+				const uint32_t g = 32 * w + (uint32_t)__builtin_ctz(z);
+				if (g >= ngrid)
+					break;
+				if (cb)
+					cb(wire + (size_t)g * TG_WIRE_BYTES, g, priv);
+				n++;
+			}
+		return n;
+	}
+	for (uint32_t g = 0; g < ngrid; g++)
+		if (wire[(size_t)g * TG_WIRE_BYTES] != 0xff) {
+			if (cb)
+				cb(wire + (size_t)g * TG_WIRE_BYTES, g, priv);
+			n++;
+		}
+	return n;
+}
+
+static void wire_noop(const uint8_t *rec, uint32_t slot, void *priv)
+{
+	(void)slot;
+	*(volatile uint64_t *)priv += rec[0];	/* touches the record: the consumer at least reads the header */
+}
+
+tgpu_wire_cb tgpu_wire_noop_cb(void)
+{
+	return wire_noop;
 }
