@@ -803,6 +803,47 @@ __device__ __forceinline__ uint32_t front_gather_bits(const uint8_t *lds0, const
 	return myword;
 }
 
+/*
+ * The gather of round 3: a lane owns one BYTE of the packed slot (60 of its 80 bytes carry bits: three per code word,
+ * the lead-in bits of the two blocks, four BBK bytes) and collects its eight bits in eight rounds of one LDS byte read
+ * and ONE vector instruction.  What makes one instruction enough: the slot's bit window lies in LDS eight times,
+ * version s shifted down by s bits, so that window bit p is bit 0 of byte p >> 3 of version p & 7 -- the wanted bit
+ * arrives at a fixed position, and v_alignbit_b32 (acc:byte >> 1) shifts it into the accumulator's top while the
+ * accumulator moves down: after eight rounds the top byte holds the lane's output byte, round r at bit r.  No masks,
+ * no compares, no ballots, no v_writelane: 8 + 1 instructions per slot instead of 41, plus 7 alignbits and 7 LDS
+ * stores per GROUP for the shifted copies.  Layout: slot k at k * TG_VER_SLOT dwords (= 16 mod 32: the copies' stores
+ * are conflict-free), version s at s * TG_VER_STRIDE dwords inside it (the byte reads' conflicts were counted over the
+ * three gather tables for every stride: 57 LDS cycles for the 48 half-wave reads at 24, 69 at 64); dword 16 of version 0
+ * stays zero: where "no source" points.
+ */
+#define TG_VER_STRIDE 24	/* dwords between the versions of a slot's window */
+#define TG_VER_SLOT   208	/* dwords per slot: 8 versions + pad */
+/* (one asm block per burst type and slot of the group: the slot's offset is the reads' immediate, the eight reads are
+ * in flight together and each shift waits for its own byte only; written as asm because hipcc otherwise merges the
+ * three burst types' gathers into one tail behind eight register moves / adds per slot.  X only makes the blocks differ.) */
+template <int KOFF, int X>
+__device__ __forceinline__ uint32_t front_gather_bytes(const uint32_t (&a)[8])
+{
+	uint32_t acc, t0, t1, t2, t3, t4, t5, t6, t7;
+	asm volatile("; gather %18\n\t"
+		     "ds_read_u8 %1, %9 offset:%17\n\tds_read_u8 %2, %10 offset:%17\n\tds_read_u8 %3, %11 offset:%17\n\t"
+		     "ds_read_u8 %4, %12 offset:%17\n\tds_read_u8 %5, %13 offset:%17\n\tds_read_u8 %6, %14 offset:%17\n\t"
+		     "ds_read_u8 %7, %15 offset:%17\n\tds_read_u8 %8, %16 offset:%17\n\t"
+		     "s_waitcnt lgkmcnt(7)\n\tv_lshlrev_b32 %0, 31, %1\n\t"
+		     "s_waitcnt lgkmcnt(6)\n\tv_alignbit_b32 %0, %2, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(5)\n\tv_alignbit_b32 %0, %3, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(4)\n\tv_alignbit_b32 %0, %4, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(3)\n\tv_alignbit_b32 %0, %5, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(2)\n\tv_alignbit_b32 %0, %6, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(1)\n\tv_alignbit_b32 %0, %7, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(0)\n\tv_alignbit_b32 %0, %8, %0, 1\n\t"
+		     "v_lshrrev_b32 %0, 24, %0"
+		     : "=&v"(acc), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+		     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "n"(KOFF), "n"(X)
+		     : "memory");
+	return acc;
+}
+
 struct tg_group_data {
 	uint4 a, b, c;	/* bytes 16 l .., 1024 + 16 l .., 2048 + 16 min(l, 7) .. of the group's aligned range */
 	uint32_t a0;	/* the group starts a0 bytes into that range */
@@ -811,6 +852,9 @@ struct tg_group_data {
 
 #ifndef TG_STREAM_WPE
 #define TG_STREAM_WPE 4
+#endif
+#ifndef TG_STREAM_GATHER
+#define TG_STREAM_GATHER 2	/* 1: ballots + v_writelane (round 2), 2: byte owners on shifted window copies (front_gather_bytes) */
 #endif
 /* acc & (t0 == p0) & (t1 == p1), sel = 2 p0 + p1 (a constant once the caller's loop is unrolled): one v_bitop3_b32 */
 __device__ __forceinline__ uint32_t tsq_and2(uint32_t acc, uint32_t t0, uint32_t t1, int sel)
@@ -830,8 +874,12 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 {
 	constexpr uint64_t PY = tsq_bits(TSQ_Y), PN = tsq_bits(TSQ_N), PP = tsq_bits(TSQ_P);
 	__shared__ uint32_t s_bits[4][72];	/* per wave: the group's bit string (68 dwords used) */
+#if TG_STREAM_GATHER == 1
 	__shared__ uint32_t s_win[4][64];	/* per wave: four slot-aligned 512-bit windows */
-	__shared__ uint32_t s_out[4][128];	/* per wave: four packed slots on their way out, then their cls / ysum words */
+#else
+	__shared__ uint32_t s_win[4][4 * TG_VER_SLOT];	/* per wave: four slots x eight shifted copies of the 512-bit window */
+#endif
+	__shared__ uint32_t s_out[4][160];	/* per wave: four packed slots on their way out, then their cls / ysum words (+ the idle lanes' dump) */
 
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -844,6 +892,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	uint32_t *mo = s_out[wib];
 	const uint8_t *lds0 = (const uint8_t *)&s_win[0][0];
 
+#if TG_STREAM_GATHER == 1
 	/* gather tables: byte of the window and bit inside it, per round and burst type */
 	uint32_t g_adr[3][10], g_msk[3][3];
 #pragma unroll
@@ -858,6 +907,29 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			g_msk[x][r >> 2] |= (none ? 0u : (1u << (o & 7))) << (8 * (r & 3));
 		}
 	}
+#else
+	/* the lane's byte of the packed slot: lanes 0..53 byte l % 3 of code word l / 3, 54 / 55 the lead-in bits of the two
+	 * blocks (byte 3 of words 0 and 9), 56..59 the BBK word, 60..63 none; per burst type and round the LDS byte that
+	 * carries the wanted bit at its bit 0 */
+	const uint32_t ow = lane < 54 ? lane / 3 : lane == 54 ? 0u : lane == 55 ? (uint32_t)TG_PW_BLK2 : (uint32_t)TG_PW_BBK;
+	const uint32_t ob = lane < 54 ? lane % 3 : lane < 56 ? 3u : lane - 56;
+	const uint32_t obyte = lane < 60 ? 4 * ow + ob : 4 * 88 + (lane - 60);	/* (the idle lanes write behind the staged slots: < 640 with the last slot's offset) */
+	uint32_t g_adr[3][8];
+	/* (the asm block takes LDS addresses as the hardware sees them: the array's offset inside the workgroup's LDS) */
+	const uint32_t ver0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)&s_win[0][0];
+#pragma unroll
+	for (int x = 0; x < 3; x++)
+#pragma unroll
+		for (int r = 0; r < 8; r++) {
+			const uint32_t o = lane < 60 ? c_tab.front_src[x][ow][8 * ob + r] : 0xffffu;
+			g_adr[x][r] = ver0 + wib * (4 * TG_VER_SLOT * 4) + (o == 0xffff ? 64u : (o & 7) * (TG_VER_STRIDE * 4) + (o >> 3));
+			asm volatile("" : "+v"(g_adr[x][r]));	/* the whole address in the register: the slot's offset is the immediate */
+		}
+	if (lane < 4)
+		win[lane * TG_VER_SLOT + 16] = 0;	/* "no source" reads this */
+	for (int i = lane; i < 128; i += 64)
+		mo[i] = 0;				/* bytes of the staged slots that nobody owns stay zero */
+#endif
 	/* which positions of the lane's column count: main search 21..472, "early" 0..20, SYNC summary 0..509 */
 	const uint32_t vmain = (col == 0) ? 0xffe00000u : (col == 14) ? 0x01ffffffu : (col == 15) ? 0u : 0xffffffffu;
 	const uint32_t vearly = (col == 0) ? 0x001fffffu : 0u;
@@ -935,7 +1007,17 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			W1 = __builtin_amdgcn_alignbit(D2, D1, p);
 			W2 = __builtin_amdgcn_alignbit(D3, D2, p);
 		}
+#if TG_STREAM_GATHER == 1
 		win[lane] = W0;
+#else
+		{
+			uint32_t *v = win + (lane >> 4) * TG_VER_SLOT + col;
+			v[0] = W0;
+#pragma unroll
+			for (int sft = 1; sft < 8; sft++)
+				v[sft * TG_VER_STRIDE] = __builtin_amdgcn_alignbit(W1, W0, sft);
+		}
+#endif
 
 		/* match masks of the three sequences at the column's 32 positions */
 		/* one accumulator per sequence, two positions per step: acc & (t_j == p_j) & (t_j+1 == p_j+1) is one
@@ -997,6 +1079,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 
 		const uint32_t first = 4u * g;
 		const uint32_t cnt = (prm.nslots - first < 4u) ? prm.nslots - first : 4u;
+#if TG_STREAM_GATHER == 1
 #define STREAM_SLOT_K(K)												\
 		{													\
 			const uint32_t dt = __builtin_amdgcn_readlane(dtype, (K));					\
@@ -1010,6 +1093,20 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			if (lane < TG_PACKED_WORDS)									\
 				mo[(K) * TG_PACKED_WORDS + lane] = myword;						\
 		}
+#else
+#define STREAM_SLOT_K(K)												\
+		{													\
+			const uint32_t dt = __builtin_amdgcn_readlane(dtype, (K));					\
+			uint32_t mybyte = 0;										\
+			if (dt == TG_BURST_NORM_1)									\
+				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 0>(g_adr[0]);			\
+			else if (dt == TG_BURST_NORM_2)									\
+				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 1>(g_adr[1]);			\
+			else if (dt == TG_BURST_SYNC)									\
+				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 2>(g_adr[2]);			\
+			((uint8_t *)mo)[(K) * TG_PACKED_WORDS * 4 + obyte] = (uint8_t)mybyte;				\
+		}
+#endif
 		STREAM_SLOT_K(0)
 		STREAM_SLOT_K(1)
 		STREAM_SLOT_K(2)
