@@ -637,6 +637,20 @@ void tetra_acelp_codec_to_acelp(const uint8_t *in, uint8_t *out);
 int tgpu_gsmtap_makemsg(const struct tetra_tdma_time *tm, enum tetra_log_chan lchan, uint8_t ts, uint8_t ss,
 			int8_t signal_dbm, uint8_t snr, const uint8_t *bitdata, unsigned int bitlen,
 			uint8_t *out, size_t out_size);
+/*
+ * The same for a whole decoded batch on the device (k_gsmtap): d_rec = nslots 320-byte records as the plan left them,
+ * d_times[i] = the PHY clock when burst i comes in (struct tetra_tdma_time, device memory; the host's replay has it: the
+ * clock after tetra_tdma_time_add_tn() of the burst's time steps -- a SYNC burst with a good SB1 sets tn / fn / mn
+ * itself), d_traffic (optional): byte per slot, bit 0 = the burst is a traffic burst (cur_burst.is_traffic: its SCH/F or
+ * second block is dumped, not indicated), bit 1 = its second block was stolen (and is indicated after all).  Message k
+ * (burst order: SB1 BBK SB2 / BBK BLK1 BLK2 / BBK SCH-F) of slot i at d_msgs + (3 i + k) * TGPU_GSMTAP_STRIDE, its length
+ * in d_lens[3 i + k]; 0 = no message (CRC failed, no such block, slot not decoded).  ss = signal = snr = 0 and ts = tn - 1
+ * as in the reference's call (tetra_upper_mac.c:483-486); the first indication of every block (further PDUs of one block
+ * are the callback's: tgpu_gsmtap_makemsg() with the offset).
+ */
+#define TGPU_GSMTAP_STRIDE 52
+int tgpu_gsmtap_batch(struct tgpu_engine *eng, const uint8_t *d_rec, const struct tetra_tdma_time *d_times, const uint8_t *d_traffic,
+		      uint32_t nslots, uint8_t *d_msgs, uint8_t *d_lens, void *hip_stream);
 
 /*
  * The reference's traffic-channel dump block (lower_mac/tetra_lower_mac.c:213-231, the input format of the

@@ -526,6 +526,19 @@ def rm3014_decode(rx30):
     return int(d.value), int(n.value)
 
 
+GSMTAP_STRIDE = 52
+
+
+def gsmtap_batch(engine, d_rec_ptr, d_times_ptr, nslots, d_msgs_ptr, d_lens_ptr, d_traffic_ptr=0, hip_stream=0):
+    """tgpu_gsmtap_batch: GSMTAP messages of every CRC-OK block of a decoded batch, on the device (3 per slot)"""
+    lib().tgpu_gsmtap_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    _chk(lib().tgpu_gsmtap_batch(engine._h, C.c_void_p(d_rec_ptr), C.c_void_p(d_times_ptr), C.c_void_p(d_traffic_ptr), nslots,
+                                 C.c_void_p(d_msgs_ptr), C.c_void_p(d_lens_ptr), C.c_void_p(hip_stream)), "tgpu_gsmtap_batch")
+
+
+TDMA_TIME_DTYPE = np.dtype([("hn", np.uint16), ("_p", np.uint16), ("sn", np.uint32), ("tn", np.uint32), ("fn", np.uint32), ("mn", np.uint32)])
+
+
 def traffic_block(type4):
     """tgpu_traffic_block: the reference's 690-word traffic dump block from descrambled type-4 bits"""
     t = _np_u8(type4)

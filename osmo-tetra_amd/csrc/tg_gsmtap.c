@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "tetra_gpu.h"
+#include "tg_internal.h"
 
 #define GSMTAP_VERSION        0x02
 #define GSMTAP_TYPE_TETRA_I1  0x05
@@ -43,4 +44,17 @@ int tgpu_gsmtap_makemsg(const struct tetra_tdma_time *tm, enum tetra_log_chan lc
 		if (bitdata[i])
 			out[16 + (i >> 3)] |= (uint8_t)(0x80u >> (i & 7));
 	return (int)(16u + packed_len);
+}
+
+/* the batch form: one launch for all CRC-OK blocks of a decoded batch (k_gsmtap, tg_kernels.hip) */
+int tgpu_gsmtap_batch(struct tgpu_engine *eng, const uint8_t *d_rec, const struct tetra_tdma_time *d_times, const uint8_t *d_traffic,
+		      uint32_t nslots, uint8_t *d_msgs, uint8_t *d_lens, void *hip_stream)
+{
+	if (!eng || (nslots && (!d_rec || !d_times || !d_msgs || !d_lens)))
+		return TGPU_EINVAL;
+	_Static_assert(sizeof(struct tetra_tdma_time) == sizeof(tg_tdma_time_dev), "time layout");
+	int rc = tgpi_engine_bind(eng);
+	if (rc)
+		return rc;
+	return tgk_gsmtap(d_rec, d_times, d_traffic, nslots, d_msgs, d_lens, hip_stream);
 }

@@ -97,6 +97,11 @@ int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const stru
 	     uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
 	     struct tg_walk_sum *d_sums, void *d_events, uint32_t evcap, void *d_recs, void *stream);
 
+/* GSMTAP messages of a decoded batch (k_gsmtap); tg_tdma_time_dev = struct tetra_tdma_time */
+typedef struct { uint16_t hn; uint32_t sn, tn, fn, mn; } tg_tdma_time_dev;
+int tgk_gsmtap(const uint8_t *d_rec, const void *d_times, const uint8_t *d_traffic, uint32_t nslots, uint8_t *d_msgs,
+	       uint8_t *d_lens, void *stream);
+
 /* optional RM(30,14) decoder (tg_rm.c): coset-leader table (65536 words, built on first use) and the generator's
  * parity rows; tgk_rm_enable() uploads both for the kernels (flag TGK_F_RM of tgk_vit / tgk_bbk_blocks) */
 const uint32_t *tgi_rm_leader_table(void);

@@ -885,12 +885,16 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t wave = blockIdx.x * 4 + wib;
 	const uint32_t nwaves = gridDim.x * 4;
+#if TG_STREAM_GATHER == 1
 	const uint32_t half = lane >> 5, bit = lane & 31;
+#endif
 	const uint32_t col = lane & 15;			/* 32-position column of the lane's slot */
 	uint32_t *bits = s_bits[wib];
 	uint32_t *win = s_win[wib];
 	uint32_t *mo = s_out[wib];
+#if TG_STREAM_GATHER == 1
 	const uint8_t *lds0 = (const uint8_t *)&s_win[0][0];
+#endif
 
 #if TG_STREAM_GATHER == 1
 	/* gather tables: byte of the window and bit inside it, per round and burst type */
@@ -3785,5 +3789,109 @@ extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 	hipLaunchKernelGGL(k_walk, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, (hipStream_t)stream, d_base, d_chan, d_roots, chunk,
 			   (uint32_t)__builtin_ctz(chunk), d_cls, d_ysum, d_plain, d_bits, d_sums,
 			   (tgpu_sync_event_rec_dev *)d_events, evcap, (tgw_rec *)d_recs);
+	return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_gsmtap: GSMTAP messages of a decoded batch          */
+/* ------------------------------------------------------------------------- */
+/*
+ * What the reference's upper MAC sends for every CRC-OK block it is indicated (tetra_upper_mac.c:483-488 ->
+ * tetra_gsmtap.c:31-63): 16-byte GSMTAP v2 header (type TETRA_I1, timeslot tn - 1, frame number ((hn 60) + mn) 18 + fn in
+ * network order, channel sub-type) + the block's type-1 bits packed MSB first.  One thread per (slot, block of the
+ * burst in the reference's order: SB1 BBK SB2 / BBK BLK1 BLK2 / BBK SCH-F); message k of slot i at msgs + (3 i + k) *
+ * TG_GSMTAP_STRIDE, its length in lens[3 i + k] (0: none -- the block failed its CRC, the burst has no such block, the
+ * slot was not decoded, or the caller marks the burst as traffic and the block is one the reference dumps instead).
+ * times[i] = the PHY clock when the burst comes in (after the time steps of tetra_burst_sync_in()); a SYNC burst whose
+ * SB1 passes its CRC sets tn / fn / mn from its PDU for all three of its blocks (tetra_lower_mac.c:291-302, 332).
+ * Logical channels as tetra_lower_mac.c:170-173, 303, 315-319: SB1 BSCH, BBK AACH, SCH-F SCH_F, SB2 BNCH in the BNCH
+ * frame, else (SB2, NDB) unknown (sub-type 0).  The first indication of a block only: further PDUs of the same block
+ * (tetra_lower_mac.c:330-352) depend on the upper MAC's return value -- the host's tgpu_gsmtap_makemsg() with an offset.
+ */
+#define TG_GSMTAP_STRIDE 52
+__global__ __launch_bounds__(256)
+void k_gsmtap(const uint8_t *__restrict__ rec, const tg_tdma_time_dev *__restrict__ times, const uint8_t *__restrict__ traffic,
+	      uint32_t nslots, uint8_t *__restrict__ msgs, uint8_t *__restrict__ lens)
+{
+	const uint32_t id = blockIdx.x * 256 + threadIdx.x;
+	if (id >= 3 * nslots)
+		return;
+	const uint32_t i = id / 3, k = id % 3;
+	const uint8_t *r = rec + (size_t)i * TG_REC_BYTES;
+	uint8_t *m = msgs + (size_t)id * TG_GSMTAP_STRIDE;
+	const uint32_t type = r[TG_REC_TYPE];
+	/* block k of the burst: 0 SB1 / 1 BBK / 2 first block / 3 second block, 4 none */
+	uint32_t what = 4;
+	if (type == TG_BURST_SYNC)
+		what = k == 0 ? 0u : k == 1 ? 1u : 3u;
+	else if (type == TG_BURST_NORM_2)
+		what = k == 0 ? 1u : k == 1 ? 2u : 3u;
+	else if (type == TG_BURST_NORM_1)
+		what = k == 0 ? 1u : k == 1 ? 2u : 4u;
+	const uint8_t *bits = r + TG_REC_BBK;
+	uint32_t nbits = 14, ok = 1, sub = 2 /* GSMTAP_TETRA_AACH */;
+	tg_tdma_time_dev tm = times[i];
+	if (type == TG_BURST_SYNC && r[TG_REC_CRC_OK]) {
+		const uint32_t f0 = *(const uint32_t *)(r + TG_REC_SBF0);
+		tm.tn = (f0 >> 8) & 0xff;
+		tm.fn = (f0 >> 16) & 0xff;
+		tm.mn = f0 >> 24;
+	}
+	const bool is_traffic = traffic && traffic[i];
+	if (what == 0) {
+		bits = r + TG_REC_BITS1;
+		nbits = 60;
+		ok = r[TG_REC_CRC_OK];
+		sub = 1;	/* BSCH */
+	} else if (what == 2) {
+		bits = r + TG_REC_BITS1;
+		nbits = type == TG_BURST_NORM_1 ? 268 : 124;
+		ok = r[TG_REC_CRC_OK];
+		sub = type == TG_BURST_NORM_1 ? 5u : 0u;	/* SCH_F; an NDB half has no channel yet (tetra_lower_mac.c:312) */
+		if (is_traffic && type == TG_BURST_NORM_1)
+			what = 4;			/* dumped, not indicated (tetra_lower_mac.c:198) */
+	} else if (what == 3) {
+		bits = r + TG_REC_BITS2;
+		nbits = 124;
+		ok = r[TG_REC_CRC_OK + 1];
+		sub = (type == TG_BURST_SYNC && tm.fn == 18 && tm.tn == 4 - ((tm.mn + 3) % 4)) ? 6u : 0u;	/* BNCH (:122-127, 170) */
+		if (is_traffic && (traffic[i] & 2) == 0)
+			what = 4;			/* second block of a traffic slot that was not stolen */
+	}
+	if (what == 4 || !ok) {
+		lens[id] = 0;
+		return;
+	}
+	const uint32_t fn = ((tm.hn * 60u) + tm.mn) * 18u + tm.fn;
+	const uint32_t nbytes = (nbits + 7) >> 3;
+	m[0] = 2;	/* GSMTAP_VERSION */
+	m[1] = 4;	/* header length in words */
+	m[2] = 5;	/* GSMTAP_TYPE_TETRA_I1 */
+	m[3] = (uint8_t)(tm.tn - 1);
+	m[4] = m[5] = 0;
+	m[6] = m[7] = 0;
+	m[8] = (uint8_t)(fn >> 24);
+	m[9] = (uint8_t)(fn >> 16);
+	m[10] = (uint8_t)(fn >> 8);
+	m[11] = (uint8_t)fn;
+	m[12] = (uint8_t)sub;
+	m[13] = m[14] = m[15] = 0;
+	for (uint32_t b = 0; b < nbytes; b++) {
+		uint32_t v = 0;
+		for (uint32_t q = 0; q < 8; q++)
+			if (8 * b + q < nbits && bits[8 * b + q])
+				v |= 0x80u >> q;
+		m[16 + b] = (uint8_t)v;
+	}
+	lens[id] = (uint8_t)(16 + nbytes);
+}
+
+extern "C" int tgk_gsmtap(const uint8_t *d_rec, const void *d_times, const uint8_t *d_traffic, uint32_t nslots, uint8_t *d_msgs,
+			  uint8_t *d_lens, void *stream)
+{
+	if (!nslots)
+		return 0;
+	hipLaunchKernelGGL(k_gsmtap, dim3((3 * nslots + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_rec,
+			   (const tg_tdma_time_dev *)d_times, d_traffic, nslots, d_msgs, d_lens);
 	return (int)hipGetLastError();
 }

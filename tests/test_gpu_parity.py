@@ -2307,3 +2307,84 @@ def test_burst_path_then_batch_path_on_one_load(T, eng, monkeypatch):
         pl.close()
     assert res["burst"][1] == res["batch"][1] == [O.scramb_get_init(*cells[0]), O.scramb_get_init(*cells[1])]
     assert (res["burst"][0] == res["batch"][0]).all()
+
+
+def test_gsmtap_messages_of_a_batch_on_device(T, eng):
+    """tgpu_gsmtap_batch (k_gsmtap): the GSMTAP message of every CRC-OK block of a decoded batch -- all three burst types,
+    payload noise (failed CRCs give no message), SYNC bursts that move the clock, the BNCH frame, traffic bursts with and
+    without a stolen second block -- against the oracle's restatement of tetra_gsmtap_makemsg() (tetra_gsmtap.c:31-63)
+    driven by the reference's call (tetra_upper_mac.c:483-486: ts = tn - 1, ss = signal = snr = 0, the block's type-1
+    bits) with the clock and logical channel of tetra_lower_mac.c:167-173, 291-319; and against the product's own host
+    function"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    n = 900
+    rng = np.random.default_rng(77)
+    cell = (262, 42, 1)
+    code = O.scramb_get_init(*cell)
+    types = np.tile(np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8), n // 8 + 1)[:n]
+    types[(np.arange(n) // 4) % 18 == 17] = 3       # (the generator's SYNC PDU of slot i carries fn = (i / 4) % 18 + 1: frame 18 -> BNCH)
+    slots = T.synth_slots(types, seed=5000, scramb_init=code, mcc=cell[0], mnc=cell[1], cc=cell[2], ber=0.04)
+    # the PHY clock burst by burst: one time step per burst (tetra_tdma.c:27-58), a good SB1 sets tn / fn / mn
+    tm = [0, 0, 1, 1, 1]              # hn, sn, tn, fn, mn
+    times = np.zeros(n, T.TDMA_TIME_DTYPE)
+    clock = []
+    for i in range(n):
+        tm[2] += 1
+        if tm[2] > 4:
+            tm[3] += tm[2] // 4
+            tm[2] %= 4
+        if tm[3] > 18:
+            tm[4] += tm[3] // 18
+            tm[3] %= 18
+        if tm[4] > 60:
+            tm[4] %= 60
+        times[i] = (tm[0], 0, tm[1], tm[2], tm[3], tm[4])
+        clock.append(tuple(tm))
+        if types[i] == 3 and O.decode_block(O.T_SB1, slots[i][94:214], 3)[2]:
+            tm[2], tm[3], tm[4] = i % 4 + 1, (i // 4) % 18 + 1, (i // 72) % 60 + 1
+    traffic = np.zeros(n, np.uint8)
+    traffic[rng.integers(0, n, 60)] = 1
+    traffic[rng.integers(0, n, 30)] = 3
+    d = torch.from_numpy(slots.reshape(-1)).cuda()
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 1)
+    plan.load(np.arange(n, dtype=np.uint64) * 510, types, None, np.array([code], np.uint32))
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+    d_times = torch.from_numpy(times.view(np.uint8)).cuda()
+    d_traffic = torch.from_numpy(traffic).cuda()
+    d_msgs = torch.full((3 * n * T.GSMTAP_STRIDE,), 0xEE, dtype=torch.uint8, device="cuda")
+    d_lens = torch.full((3 * n,), 0xEE, dtype=torch.uint8, device="cuda")
+    T.gsmtap_batch(eng, d_rec.data_ptr(), d_times.data_ptr(), n, d_msgs.data_ptr(), d_lens.data_ptr(), d_traffic.data_ptr(), hs)
+    torch.cuda.synchronize()
+    msgs = d_msgs.cpu().numpy().reshape(n, 3, T.GSMTAP_STRIDE)
+    lens = d_lens.cpu().numpy().reshape(n, 3)
+    rec = d_rec.cpu().numpy().reshape(n, T.REC_BYTES)
+    LC = {"SCH_F": 1, "AACH": 8, "BSCH": 10, "BNCH": 11}
+    nmsg = nbnch = 0
+    for i in range(n):
+        blocks = T.record_blocks(rec[i])
+        t = list(clock[i])
+        sb1_ok = types[i] == 3 and blocks[0]["crc_ok"]
+        if sb1_ok:
+            f0 = int(T.parse_records(rec[i][None])["sbf0"][0])
+            t[2], t[3], t[4] = (f0 >> 8) & 0xFF, (f0 >> 16) & 0xFF, f0 >> 24
+            assert (t[2], t[3], t[4]) == (i % 4 + 1, (i // 4) % 18 + 1, (i // 72) % 60 + 1)
+        for k, b in enumerate(blocks):
+            is_bnch = t[3] == 18 and t[2] == 4 - ((t[4] + 3) % 4)
+            lchan = {T.T_SB1: LC["BSCH"], T.T_BBK: LC["AACH"], T.T_SCH_F: LC["SCH_F"]}.get(b["type"], LC["BNCH"] if (b["type"] == T.T_SB2 and is_bnch) else 0)
+            dumped = traffic[i] & 1 and (b["type"] == T.T_SCH_F or (b["blk_num"] == 2 and not (traffic[i] & 2)))
+            if not b["crc_ok"] or dumped:
+                assert lens[i, k] == 0, (i, k)
+                continue
+            t1 = np.frombuffer(b["type1"], np.uint8)
+            want = np.frombuffer(bytes(O.gsmtap_makemsg((t[0], t[1], t[2], t[3], t[4]), lchan, t[2] - 1, t1)), np.uint8)
+            assert lens[i, k] == len(want) and (msgs[i, k, :len(want)] == want).all(), (i, k)
+            own = np.frombuffer(bytes(T.gsmtap_makemsg((t[0], t[1], t[2], t[3], t[4]), lchan, t[2] - 1, t1)), np.uint8)
+            assert (own == want).all()
+            nmsg += 1
+            nbnch += lchan == LC["BNCH"]
+        for k in range(len(blocks), 3):
+            assert lens[i, k] == 0
+    assert nmsg > 1200 and nbnch >= 3, (nmsg, nbnch)
+    plan.close()
