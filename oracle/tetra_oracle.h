@@ -258,9 +258,14 @@ void orc_tp_sap_udata_ind(struct orc_rx *rx, int type, int blk_num, const uint8_
  * optional decoder).  rx30 bit 29 = first received bit.  Returns the 14 data bits (bit 13 = first). */
 uint16_t orc_rm3014_decode_ml(uint32_t rx30, unsigned *nerr);
 
-/* traffic dump block (tetra_lower_mac.c:213-231): 690 int16 from the descrambled type-4 bits of a traffic block */
+/* GSMTAP message of a decoded block (tetra_gsmtap.c:31-63 restated).  PARITY UNPINNED for the header: libosmocore's
+ * gsmtap.h is absent here, so GSMTAP_VERSION (2), GSMTAP_TYPE_TETRA_I1 (5), the GSMTAP_TETRA_* sub-types (BSCH 1, AACH 2,
+ * SCH_HU 3, SCH_HD 4, SCH_F 5, BNCH 6, STCH 7, TCH_F 8) and the 16-byte struct gsmtap_hdr layout are RECALLED from its
+ * published header, not read from a file in this image; the bit packing (osmo_ubit2pbit: MSB first) and the frame-number
+ * arithmetic (tetra_tdma.c:96-99) follow files that are here. */
 int orc_gsmtap_makemsg(const struct orc_tdma_time *tm, int lchan, uint8_t ts, uint8_t ss, int8_t signal_dbm,
 		       uint8_t snr, const uint8_t *bits, unsigned bitlen, uint8_t *out);
+/* traffic dump block (tetra_lower_mac.c:213-231): 690 int16 from the descrambled type-4 bits of a traffic block */
 void orc_traffic_block(const uint8_t *type4, unsigned len, int16_t *block690);
 /* ACELP bit re-ordering (lower_mac/tch_reordering.c:94-140) with caller-supplied class position tables */
 void orc_acelp_type2_to_codec(const uint8_t *in, uint8_t *out, const uint8_t *const cls[3], const unsigned ncls[3]);
