@@ -1,0 +1,42 @@
+"""bench.py itself on the GPU box: the multi-rank path nobody can rehearse on RCCL with one GPU is run with two ranks
+over gloo sharing that GPU (same code: single-GPU reference, decode-only phase, gathered phase with every step's wire
+records collected on rank 0, the oracle check of rank 0's records AND of what arrived in its sink), and with one rank
+through the library's RCCL gather (--force-gather)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _line(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu():
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29533", "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "2",
+               "--windows", "2", "--bursts", "64000"])
+    assert d["n_gpus"] == 2 and d["metric"] == "decoded bursts/s" and d["scaling"] == "weak" and d["steps"] == 4
+    for k in ("decode_only", "gathered", "single_gpu_reference", "per_gpu_efficiency", "roofline", "timing"):
+        assert k in d, k
+    assert "error" not in d["gathered"] and d["value"] == d["gathered"]["value"] > 0
+    assert d["gathered"]["bursts_delivered_per_step"] == d["decode_only"]["bursts_delivered_per_step"] > 2 * 0.9 * 64000 * 0.9
+    assert "equal the oracle's" in d["config"]["check"] and "collecting rank" in d["config"]["check"]
+    assert 0 < d["per_gpu_efficiency"]["decode_only"] < 1.5
+    assert len(d["timing"]["windows_ms_per_step"]) == 2
+
+
+def test_bench_single_rank_with_the_rccl_gather():
+    d = _line([sys.executable, "bench.py", "--force-gather", "--steps", "4", "--warmup", "2", "--windows", "2", "--bursts", "64000",
+               "--no-secondary", "--no-e2e"])
+    assert d["n_gpus"] == 1 and "tgpu_comm_gather" in d["gathered"]["exchange"]
+    assert "collecting rank" in d["config"]["check"] and d["cpu_baseline"]["value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
