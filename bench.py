@@ -907,7 +907,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20, help="K: steps per timed window")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--windows", type=int, default=6, help="mix: K-step windows inside the one continuous run (median reported)")
-    ap.add_argument("--depth", type=int, default=3, help="mix: steps in flight per GPU (plans / streams)")
+    ap.add_argument("--depth", type=int, default=4, help="mix: steps in flight per GPU (plans / streams)")
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts (slots) per GPU per step")
     ap.add_argument("--ber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
