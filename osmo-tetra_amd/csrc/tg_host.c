@@ -90,10 +90,9 @@ struct tgpu_plan {
 	uint64_t max_off;	/* slot mode: largest slot offset of the load (bounds check of tgpu_plan_execute_float) */
 	/* stream mode with the walk on the device (tgpu_sync_multi_launch): item counts stay on the device */
 	const uint32_t *d_counts;	/* [nsb, n216, n432] behind the list builder's block sums; NULL: the host knows them */
-	uint8_t *d_walk, *h_walk;	/* roots, summaries, events of k_walk (device / pinned mirror), max_chan channels */
+	uint8_t *d_walk, *h_walk;	/* k_walk's blocks (tg_walk_io): up, down, device-only events (device / pinned mirror) */
 	void *d_walk_recs;		/* max_chan * (TGW_NCAP + 1) node records */
 	uint32_t *d_bits_dev;		/* the delivered bitmap k_walk left in the upload arena */
-	uint32_t *h_bits;		/* pinned: where it is copied for the host */
 };
 
 const char *tgpu_strerror(int err)
@@ -226,8 +225,6 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 		(void)hipHostFree(p->h_chan_tab);
 	if (p->h_walk)
 		(void)hipHostFree(p->h_walk);
-	if (p->h_bits)
-		(void)hipHostFree(p->h_bits);
 	free(p->h_last_slot_of_chan);
 	free(p);
 }
@@ -468,12 +465,12 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
  * The same with the delivered bitmap made on the device (k_walk): nothing comes back to the host before the decode.
  * The lists are sized for the worst case (every grid slot of one kind) and the item counts stay behind the list
  * builder's block sums; the trellis kernels and k_masks read them there (d_counts).
+ * d_codes: the channels' carry-in codes, already on the device (tg_walk_io's upload block);
  * *d_bits_out = where k_walk is to leave the bitmap (ngrid bits, channel grids at multiples of 32).
  */
-int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const uint32_t *codes, uint32_t **d_bits_out,
-			      void *stream)
+int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, uint32_t *d_codes, uint32_t **d_bits_out)
 {
-	if (!p || !ngrid || !p->d_grid || !nchan || !codes || !d_bits_out)
+	if (!p || !ngrid || !p->d_grid || !nchan || !d_codes || !d_bits_out)
 		return TGPU_EINVAL;
 	BIND(p->eng);
 	if (ngrid > p->max_slots || nchan > p->max_chan)
@@ -483,8 +480,6 @@ int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t ncha
 #define UP_AT(ptr, type, count) do { ptr = (type *)(p->d_up + o); \
 		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
 	uint32_t *d_bits, *d_blk;
-	UP_AT(p->d_chan_code, uint32_t, nchan);
-	const size_t upload = o;
 	UP_AT(d_bits, uint32_t, nwords);
 	UP_AT(p->d_slot_chan, uint32_t, ngrid);
 	UP_AT(p->d_slot_sbord, int32_t, ngrid);
@@ -496,9 +491,7 @@ int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t ncha
 	p->d_slot_off = NULL;
 	if (o > p->up_bytes)
 		return TGPU_ECAPACITY;
-	memcpy(p->h_up, codes, (size_t)nchan * 4);
-	if (!p->up_mapped)
-		HCHK(hipMemcpyAsync(p->d_up, p->h_up, upload, hipMemcpyHostToDevice, (hipStream_t)stream));
+	p->d_chan_code = d_codes;
 	p->d_bits_dev = d_bits;
 	p->d_counts = d_blk + 3 * nblk;
 	*d_bits_out = d_bits;
@@ -508,16 +501,16 @@ int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t ncha
 	return TGPU_OK;
 }
 
-/* second half: the lists from the bitmap k_walk has left (same stream, no host wait) */
-int tgpi_plan_grid_lists_dev(struct tgpu_plan *p, const struct tg_chan_ent *ents, void *stream)
+/* second half: the lists from the bitmap k_walk has left (same stream, no host wait); d_tab: the channel table on the device */
+int tgpi_plan_grid_lists_dev(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, void *stream)
 {
-	if (!p || !p->d_counts || !p->d_bits_dev || (ents && !p->d_chan_tab))
+	if (!p || !p->d_counts || !p->d_bits_dev || !d_tab)
 		return TGPU_EINVAL;
 	BIND(p->eng);
 	const uint32_t ngrid = p->nslots;
 	const size_t nblk = ((size_t)ngrid + 1023) / 1024;
 	int rc = tgk_grid_lists(p->d_grid, p->d_bits_dev, ngrid, (uint32_t *)p->d_counts - 3 * nblk, p->d_slot_chan, p->d_slot_sbord,
-				p->d_list_sb, p->d_list_216, p->d_list_432, ents ? p->d_chan_tab : NULL, ents ? p->nchan : 1, stream);
+				p->d_list_sb, p->d_list_216, p->d_list_432, d_tab, p->nchan, stream);
 	if (rc)
 		return rc;
 	for (uint32_t c = 0; c < p->nchan; c++)
@@ -539,20 +532,22 @@ void tgpi_plan_set_last_slot(struct tgpu_plan *p, uint32_t chan, uint32_t slot)
 		p->h_last_slot_of_chan[chan] = slot;
 }
 
-/* buffers of the device walk: per channel a root, a summary and TGW_EVCAP events (device + pinned mirror), node records */
-int tgpi_plan_walk_buffers(struct tgpu_plan *p, struct tg_walk_root **d_roots, struct tg_walk_root **h_roots,
-			   struct tg_walk_sum **d_sums, struct tg_walk_sum **h_sums, void **d_events, void **h_events,
-			   void **d_recs)
+/* blocks of a device-walk batch (tg_walk_io): allocated once per plan for max_chan channels and max_slots grid slots, the
+ * down block laid out for this batch's nchan / ngrid so that ONE copy brings summaries, eager events and bitmap */
+int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struct tg_walk_io *io)
 {
-	if (!p)
+	if (!p || !io || !nchan || nchan > 64 || nchan > p->max_chan || ngrid > p->max_slots)
 		return TGPU_EINVAL;
 	BIND(p->eng);
 	const size_t nc = p->max_chan < 64 ? p->max_chan : 64;
-	const size_t o_sum = nc * sizeof(struct tg_walk_root), o_ev = o_sum + nc * sizeof(struct tg_walk_sum);
-	const size_t bytes = o_ev + nc * (size_t)TGW_EVCAP * sizeof(tgpu_sync_event_rec_dev);
+	const size_t up = 64 * (sizeof(struct tg_chan_ent) + sizeof(struct tg_walk_root) + 4);
+	const size_t down_max = 64 * sizeof(struct tg_walk_sum) + nc * (size_t)TGW_EVEAGER * sizeof(tgpu_sync_event_rec_dev) +
+				(((size_t)p->max_slots + 31) / 32 + 4) * 4;
+	const size_t big = nc * (size_t)TGW_EVCAP * sizeof(tgpu_sync_event_rec_dev);
+	const size_t o_down = (up + 255) & ~(size_t)255, o_big = (o_down + down_max + 255) & ~(size_t)255;
 	if (!p->d_walk) {
-		HCHK(hipMalloc((void **)&p->d_walk, bytes));
-		if (hipHostMalloc((void **)&p->h_walk, bytes, hipHostMallocDefault) != hipSuccess) {
+		HCHK(hipMalloc((void **)&p->d_walk, o_big + big));
+		if (hipHostMalloc((void **)&p->h_walk, o_big, hipHostMallocDefault) != hipSuccess) {
 			p->h_walk = NULL;
 			(void)hipFree(p->d_walk);
 			p->d_walk = NULL;
@@ -566,40 +561,33 @@ int tgpi_plan_walk_buffers(struct tgpu_plan *p, struct tg_walk_root **d_roots, s
 			return (int)e;
 		}
 	}
-	*d_roots = (struct tg_walk_root *)p->d_walk;
-	*h_roots = (struct tg_walk_root *)p->h_walk;
-	*d_sums = (struct tg_walk_sum *)(p->d_walk + o_sum);
-	*h_sums = (struct tg_walk_sum *)(p->h_walk + o_sum);
-	*d_events = p->d_walk + o_ev;
-	*h_events = p->h_walk + o_ev;
-	*d_recs = p->d_walk_recs;
+	memset(io, 0, sizeof(*io));
+	io->d_up0 = p->d_walk;
+	io->h_up0 = p->h_walk;
+	io->up_bytes = up;
+	io->d_tab = (struct tg_chan_ent *)io->d_up0;
+	io->h_tab = (struct tg_chan_ent *)io->h_up0;
+	io->d_roots = (struct tg_walk_root *)(io->d_tab + 64);
+	io->h_roots = (struct tg_walk_root *)(io->h_tab + 64);
+	io->d_codes = (uint32_t *)(io->d_roots + 64);
+	io->h_codes = (uint32_t *)(io->h_roots + 64);
+	io->d_down0 = p->d_walk + o_down;
+	io->h_down0 = p->h_walk + o_down;
+	io->d_sums = (struct tg_walk_sum *)io->d_down0;
+	io->h_sums = (struct tg_walk_sum *)io->h_down0;
+	io->d_eager = (tgpu_sync_event_rec_dev *)(io->d_sums + 64);
+	io->h_eager = (tgpu_sync_event_rec_dev *)(io->h_sums + 64);
+	io->d_bits2 = (uint32_t *)(io->d_eager + (size_t)nchan * TGW_EVEAGER);
+	io->h_bits2 = (uint32_t *)(io->h_eager + (size_t)nchan * TGW_EVEAGER);
+	io->down_bytes = (size_t)((uint8_t *)(io->d_bits2 + ((size_t)ngrid + 31) / 32) - io->d_down0);
+	io->d_evbig = (tgpu_sync_event_rec_dev *)(p->d_walk + o_big);
+	io->d_recs = p->d_walk_recs;
 	return TGPU_OK;
 }
 
 uint32_t *tgpi_plan_bits_dev(struct tgpu_plan *p)
 {
 	return p ? p->d_bits_dev : NULL;
-}
-
-/* pinned words for the bitmap coming back (max_slots bits), allocated on first use */
-int tgpi_plan_bits_mirror(struct tgpu_plan *p, uint32_t **h_bits)
-{
-	if (!p || !h_bits)
-		return TGPU_EINVAL;
-	if (!p->h_bits && hipHostMalloc((void **)&p->h_bits, ((size_t)p->max_slots + 31) / 32 * 4 + 16, hipHostMallocDefault) != hipSuccess) {
-		p->h_bits = NULL;
-		return TGPU_ENOMEM;
-	}
-	*h_bits = p->h_bits;
-	return TGPU_OK;
-}
-
-uint8_t *tgpi_plan_walk_events_dev(struct tgpu_plan *p)
-{
-	if (!p || !p->d_walk)
-		return NULL;
-	const size_t nc = p->max_chan < 64 ? p->max_chan : 64;
-	return p->d_walk + nc * sizeof(struct tg_walk_root) + nc * sizeof(struct tg_walk_sum);
 }
 
 int tgpu_plan_load(struct tgpu_plan *p, uint32_t nslots, const uint64_t *slot_off, const uint8_t *slot_type,

@@ -93,9 +93,29 @@ typedef struct { int32_t ev; uint32_t bitnum, arg; } tgpu_sync_event_rec_dev;	/*
 #define TGW_EVCAP 16384u	/* events per channel the device walk can report */
 #define TGW_EVEAGER 4096u	/* of those, copied to the host with the batch; the rest on demand */
 #define TGW_REC_BYTES 152u	/* sizeof(struct tgw_rec), checked where it is allocated */
+/* d_bits: the delivered bitmap for the list builder; d_bits2: a second copy in the block that goes to the host;
+ * events 0 .. TGW_EVEAGER - 1 of channel c at d_eager + c * TGW_EVEAGER (same block), the others at d_evbig + c * TGW_EVCAP */
 int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 	     uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
-	     struct tg_walk_sum *d_sums, void *d_events, uint32_t evcap, void *d_recs, void *stream);
+	     uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *stream);
+/* buffers of a device-walk batch: ONE block up (channel table, roots, carry-in codes), ONE block down (summaries, the
+ * first TGW_EVEAGER events of every channel, the delivered bitmap), device-only scratch (further events, node records) */
+struct tg_walk_io {
+	uint8_t *d_up0, *h_up0;
+	size_t up_bytes;
+	struct tg_chan_ent *d_tab, *h_tab;
+	struct tg_walk_root *d_roots, *h_roots;
+	uint32_t *d_codes, *h_codes;
+	uint8_t *d_down0, *h_down0;
+	size_t down_bytes;
+	struct tg_walk_sum *d_sums, *h_sums;
+	tgpu_sync_event_rec_dev *d_eager, *h_eager;
+	uint32_t *d_bits2, *h_bits2;
+	tgpu_sync_event_rec_dev *d_evbig;
+	void *d_recs;
+};
+struct tgpu_plan;
+int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struct tg_walk_io *io);
 
 /* GSMTAP messages of a decoded batch (k_gsmtap); tg_tdma_time_dev = struct tetra_tdma_time */
 typedef struct { uint16_t hn; uint32_t sn, tn, fn, mn; } tg_tdma_time_dev;
@@ -137,16 +157,10 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 			const struct tg_chan_ent *ents, void *stream);
 
 /* stream mode with the walk on the device (tg_stream.c: tgpu_sync_multi_launch) */
-int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const uint32_t *codes, uint32_t **d_bits_out,
-			      void *stream);
-int tgpi_plan_grid_lists_dev(struct tgpu_plan *p, const struct tg_chan_ent *ents, void *stream);
+int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, uint32_t *d_codes, uint32_t **d_bits_out);
+int tgpi_plan_grid_lists_dev(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, void *stream);
 void tgpi_plan_set_last_slot(struct tgpu_plan *p, uint32_t chan, uint32_t slot);
-int tgpi_plan_walk_buffers(struct tgpu_plan *p, struct tg_walk_root **d_roots, struct tg_walk_root **h_roots,
-			   struct tg_walk_sum **d_sums, struct tg_walk_sum **h_sums, void **d_events, void **h_events,
-			   void **d_recs);
 uint32_t *tgpi_plan_bits_dev(struct tgpu_plan *p);
-int tgpi_plan_bits_mirror(struct tgpu_plan *p, uint32_t **h_bits);	/* pinned host words for the delivered bitmap */
-uint8_t *tgpi_plan_walk_events_dev(struct tgpu_plan *p);
 
 #ifdef __cplusplus
 }

@@ -3522,12 +3522,25 @@ __device__ __forceinline__ uint32_t tgw_block_excl_scan(uint32_t v, uint32_t *sm
 	return pre + inc - v;
 }
 
+#ifdef TGW_TIMING
+__device__ unsigned long long g_tgw_stamp[64][12];
+#define TGW_STAMP(i) do { if (threadIdx.x == 0) g_tgw_stamp[blockIdx.x][i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int tgk_walk_stamps(unsigned long long *out)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tgw_stamp), sizeof(g_tgw_stamp));
+}
+#else
+#define TGW_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(TGW_THREADS)
 void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan, const tg_walk_root *__restrict__ roots,
 	    uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
-	    const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, tg_walk_sum *__restrict__ sums,
-	    tgpu_sync_event_rec_dev *__restrict__ g_events, uint32_t evcap, tgw_rec *__restrict__ g_recs)
+	    const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, uint32_t *__restrict__ g_bits2,
+	    tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager,
+	    tgpu_sync_event_rec_dev *__restrict__ g_evbig, tgw_rec *__restrict__ g_recs)
 {
+	constexpr uint32_t evcap = TGW_EVCAP;
 	extern __shared__ uint32_t s_dyn[];
 	uint32_t *bm = s_dyn;
 	uint32_t *nslot = bm + TGW_WCAP;
@@ -3542,7 +3555,8 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	const tg_walk_root rt = roots[c];
 	tg_walk_sum *sum = sums + c;
 	tgw_rec *recs = g_recs + (size_t)c * (TGW_NCAP + 1);
-	tgpu_sync_event_rec_dev *events = g_events + (size_t)c * evcap;
+	/* event e of the channel: the first TGW_EVEAGER in the block that is copied to the host with the batch, the rest behind */
+	tgpu_sync_event_rec_dev *ev_eager = g_eager + (size_t)c * TGW_EVEAGER, *ev_big = g_evbig + (size_t)c * evcap;
 	const uint32_t ncls = ce.ncls, W = (ncls + 31) >> 5, w0 = ce.gbase >> 5;
 
 	if (tid == 0) {
@@ -3576,6 +3590,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	wc.chunk = chunk;
 	wc.cshift = cshift;
 
+	TGW_STAMP(0);
 	/* A: bitmap -> LDS (bits at and past ncls read "plain" so that they are no nodes; they are cleared again in F) */
 	constexpr uint32_t WPT = TGW_WCAP / TGW_THREADS;	/* consecutive words per thread */
 	uint32_t cnt = 0;
@@ -3623,6 +3638,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 		const uint32_t w = t >> 5;
 		return (uint32_t)wpre[w] + __popc(~bm[w] & ((1u << (t & 31)) - 1u));
 	};
+	TGW_STAMP(1);
 	/* C: every node, and the stream's head */
 	for (uint32_t i = tid; i < N; i += TGW_THREADS) {
 		const uint64_t bs = wc.anchor + (uint64_t)nslot[i] * TG_SLOT_BITS;
@@ -3647,6 +3663,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	for (uint32_t i = tid; i <= N; i += TGW_THREADS)
 		mark[i] = 0;
 	__syncthreads();
+	TGW_STAMP(2);
 	/* D: reachability from the head along the arrival pointers */
 	{
 		const uint32_t head = s_head;
@@ -3668,6 +3685,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 			Jn = t;
 		}
 	}
+	TGW_STAMP(3);
 	/* E: spans of the visited nodes (and of the head run) leave the bitmap, their own deliveries enter it */
 	auto clear_span = [&](uint32_t from, uint32_t to) {	/* grid slots [from, to) */
 		if (to > ncls)
@@ -3712,6 +3730,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 		}
 	}
 	__syncthreads();
+	TGW_STAMP(4);
 	/* F: bitmap out, delivered bursts, last delivered slot */
 	{
 		uint32_t ns = 0, lastd = 0xffffffffu;
@@ -3723,6 +3742,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 				if (w == W - 1 && (ncls & 31))
 					v &= (1u << (ncls & 31)) - 1u;
 				g_bits[w0 + w] = v;
+				g_bits2[w0 + w] = v;
 				ns += __popc(v);
 				if (v)
 					lastd = 32 * w + 31 - __builtin_clz(v);
@@ -3734,6 +3754,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 			atomicMax(&s_lastdel, lastd + 1);	/* 1 + last delivered slot, 0 = none */
 	}
 	__syncthreads();
+	TGW_STAMP(5);
 	/* G: events in slot order */
 	constexpr uint32_t NPT = TGW_NCAP / TGW_THREADS;
 	const tgw_rec *root = recs + TGW_NCAP;
@@ -3752,9 +3773,10 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	auto emit = [&](const tgw_rec *r, uint32_t at) {
 		for (uint32_t e = 0; e < r->nev; e++) {
 			if (at + e < evcap) {
-				events[at + e].ev = (int32_t)r->ev[e][0];
-				events[at + e].bitnum = r->ev[e][1];
-				events[at + e].arg = r->ev[e][2];
+				tgpu_sync_event_rec_dev *o = at + e < TGW_EVEAGER ? ev_eager + at + e : ev_big + at + e;
+				o->ev = (int32_t)r->ev[e][0];
+				o->bitnum = r->ev[e][1];
+				o->arg = r->ev[e][2];
 			}
 			if (r->evslot[e] != TGW_NOSLOT) {
 				nd++;
@@ -3789,11 +3811,12 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 		sum->why = etot > evcap ? TGW_WHY_EVENTS : 0;
 		sum->nnodes = N;
 	}
+	TGW_STAMP(6);
 }
 
 extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 			uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
-			struct tg_walk_sum *d_sums, void *d_events, uint32_t evcap, void *d_recs, void *stream)
+			uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *stream)
 {
 	if (!nchan)
 		return 0;
@@ -3801,8 +3824,8 @@ extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 		return -1;
 	HIPCHK(hipFuncSetAttribute((const void *)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
 	hipLaunchKernelGGL(k_walk, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, (hipStream_t)stream, d_base, d_chan, d_roots, chunk,
-			   (uint32_t)__builtin_ctz(chunk), d_cls, d_ysum, d_plain, d_bits, d_sums,
-			   (tgpu_sync_event_rec_dev *)d_events, evcap, (tgw_rec *)d_recs);
+			   (uint32_t)__builtin_ctz(chunk), d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums,
+			   (tgpu_sync_event_rec_dev *)d_eager, (tgpu_sync_event_rec_dev *)d_evbig, (tgw_rec *)d_recs);
 	return (int)hipGetLastError();
 }
 

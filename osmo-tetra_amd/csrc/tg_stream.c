@@ -1387,11 +1387,7 @@ struct tgpu_sync_dev {
 	uint8_t *d_rec;
 	hipStream_t stream;
 	hipEvent_t done;
-	struct tg_walk_root *h_roots;
-	struct tg_walk_sum *h_sums;
-	tgpu_sync_event_rec_dev *h_events;
-	uint32_t *h_bits;	/* pinned mirror of the delivered bitmap */
-	uint32_t nwords;
+	struct tg_walk_io io;	/* the batch's blocks: one copy up, one copy down */
 	int fellback;
 };
 
@@ -1486,15 +1482,10 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 	rc = (st->ch && st->ent && st->locks) ? TGPU_OK : TGPU_ENOMEM;
 	if (!rc)
 		rc = (int)hipEventCreateWithFlags(&sd->done, hipEventDisableTiming);
-	struct tg_walk_root *d_roots = NULL;
-	struct tg_walk_sum *d_sums = NULL;
-	void *d_events = NULL, *h_events = NULL, *d_recs = NULL;
-	if (!rc)
-		rc = tgpi_plan_walk_buffers(plan, &d_roots, &sd->h_roots, &d_sums, &sd->h_sums, &d_events, &h_events, &d_recs);
-	sd->h_events = h_events;
 	if (!rc)
 		memcpy(st->ch, ch, (size_t)nchan * sizeof(*ch));
 	uint64_t total = 0;
+	struct tg_walk_root roots[64];
 	uint32_t codes[64];
 	for (uint32_t c = 0; c < nchan && !rc; c++) {
 		uint64_t anchor = 0;
@@ -1502,8 +1493,8 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			rc = TGPU_EINVAL;
 			break;
 		}
-		sd->h_roots[c].found_bs = sd->h_roots[c].found_k = 0;
-		rc = find_anchor_root(ch[c].h_stream, ch[c].len, chunk, &anchor, &st->locks[c], &sd->h_roots[c]);
+		roots[c].found_bs = roots[c].found_k = 0;
+		rc = find_anchor_root(ch[c].h_stream, ch[c].len, chunk, &anchor, &st->locks[c], &roots[c]);
 		uint64_t n = 0;
 		if (!rc && st->locks[c] && anchor + TG_SLOT_BITS <= ch[c].len)
 			n = (ch[c].len - anchor) / TG_SLOT_BITS;
@@ -1523,18 +1514,22 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 	if (!rc && st->ngrid) {
 		uint32_t *d_packed, *d_cls, *cls, *d_plain, *h_plain, *d_bits = NULL;
 		uint16_t *d_ysum, *ysum;
-		struct tg_chan_ent *d_tab;
+		struct tg_walk_io *io = &sd->io;
 		rc = tgpi_plan_grid_begin(plan, st->ngrid, &d_packed, &d_cls, &d_ysum, &cls, &ysum);
 		if (!rc)
-			rc = tgpi_plan_chan_table(plan, st->ent, nchan, &d_tab, stream);
-		if (!rc)
-			rc = (int)hipMemcpyAsync(d_roots, sd->h_roots, (size_t)nchan * sizeof(*d_roots), hipMemcpyHostToDevice, sd->stream);
+			rc = tgpi_plan_walk_io(plan, nchan, st->ngrid, io);
+		if (!rc) {	/* channel table, roots and carry-in codes: one block, one copy */
+			memcpy(io->h_tab, st->ent, (size_t)nchan * sizeof(*st->ent));
+			memcpy(io->h_roots, roots, (size_t)nchan * sizeof(*roots));
+			memcpy(io->h_codes, codes, (size_t)nchan * 4);
+			rc = (int)hipMemcpyAsync(io->d_up0, io->h_up0, io->up_bytes, hipMemcpyHostToDevice, sd->stream);
+		}
 #define EVMARK(i) do { if (evs && !rc) rc = (int)hipEventRecord(evs[i], sd->stream); } while (0)
 		if (!rc)
-			rc = tgpi_plan_grid_layout_dev(plan, st->ngrid, nchan, codes, &d_bits, stream);
+			rc = tgpi_plan_grid_layout_dev(plan, st->ngrid, nchan, io->d_codes, &d_bits);
 		EVMARK(0);
 		if (!rc)
-			rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
+			rc = tgk_front_stream_multi(d_base, io->d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
 						    tgpi_plan_defer_scratch(plan), stream, evs ? evs[1] : NULL);
 		EVMARK(2);
 		if (!rc) {
@@ -1543,27 +1538,18 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 		}
 		EVMARK(3);
 		if (!rc)
-			rc = tgk_walk(d_base, d_tab, d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, d_sums, d_events, TGW_EVCAP,
-				      d_recs, stream);
+			rc = tgk_walk(d_base, io->d_tab, io->d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, io->d_bits2, io->d_sums,
+				      io->d_eager, io->d_evbig, io->d_recs, stream);
 		EVMARK(4);
 		if (!rc)
-			rc = tgpi_plan_grid_lists_dev(plan, st->ent, stream);
+			rc = tgpi_plan_grid_lists_dev(plan, io->d_tab, stream);
 		EVMARK(5);
 #undef EVMARK
 		if (!rc)
 			rc = prof ? tgpu_plan_execute_prof(plan, d_base, d_rec, stream, prof, step) : tgpu_plan_execute(plan, d_base, d_rec, stream);
-		/* what the host wants to know: summaries, the first events of every channel, the bitmap */
+		/* what the host wants to know -- summaries, the first events of every channel, the bitmap -- in one copy */
 		if (!rc)
-			rc = (int)hipMemcpyAsync(sd->h_sums, d_sums, (size_t)nchan * sizeof(*d_sums), hipMemcpyDeviceToHost, sd->stream);
-		for (uint32_t c = 0; c < nchan && !rc; c++)
-			rc = (int)hipMemcpyAsync(sd->h_events + (size_t)c * TGW_EVCAP, (tgpu_sync_event_rec_dev *)d_events + (size_t)c * TGW_EVCAP,
-						 (size_t)TGW_EVEAGER * sizeof(tgpu_sync_event_rec_dev), hipMemcpyDeviceToHost, sd->stream);
-		if (!rc) {
-			sd->nwords = (st->ngrid + 31) / 32;
-			rc = tgpi_plan_bits_mirror(plan, &sd->h_bits);
-			if (!rc)
-				rc = (int)hipMemcpyAsync(sd->h_bits, d_bits, (size_t)sd->nwords * 4, hipMemcpyDeviceToHost, sd->stream);
-		}
+			rc = (int)hipMemcpyAsync(io->h_down0, io->d_down0, io->down_bytes, hipMemcpyDeviceToHost, sd->stream);
 	}
 	if (!rc)
 		rc = (int)hipEventRecord(sd->done, sd->stream);
@@ -1609,20 +1595,23 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 		return rc;
 	int fb = 0;
 	for (uint32_t c = 0; c < st->nchan; c++)
-		if (st->ent[c].ncls && sd->h_sums[c].status != TGW_OK)
+		if (st->ent[c].ncls && sd->io.h_sums[c].status != TGW_OK)
 			fb = 1;
 	if (getenv("TGPU_WALK_DEBUG"))
 		for (uint32_t c = 0; c < st->nchan; c++)
 			fprintf(stderr, "k_walk channel %u: %u grid slots, %u nodes, status %u (why %u), %u delivered, %u events\n", c,
-				st->ent[c].ncls, sd->h_sums[c].nnodes, sd->h_sums[c].status, sd->h_sums[c].why, sd->h_sums[c].nslots,
-				sd->h_sums[c].nevents);
+				st->ent[c].ncls, sd->io.h_sums[c].nnodes, sd->io.h_sums[c].status, sd->io.h_sums[c].why, sd->io.h_sums[c].nslots,
+				sd->io.h_sums[c].nevents);
 	if (fb || getenv("TGPU_WALK_HOST")) {
 		/* the host walks decide: classification words, summaries and plain bitmap over, walks, bitmap up, lists, decode */
 		sd->fellback = 1;
 		if (st->ngrid) {
 			uint32_t *d_packed, *d_cls, *cls;
 			uint16_t *d_ysum, *ysum;
+			struct tg_chan_ent *d_tab;
 			rc = tgpi_plan_grid_begin(st->plan, st->ngrid, &d_packed, &d_cls, &d_ysum, &cls, &ysum);
+			if (!rc)
+				rc = tgpi_plan_chan_table(st->plan, st->ent, st->nchan, &d_tab, sd->stream);	/* (the host path's own copy of the table) */
 			if (!rc)
 				rc = (int)hipMemcpyAsync(cls, d_cls, TG_GRID_COPY_BYTES(st->ngrid), hipMemcpyDeviceToHost, sd->stream);
 			if (rc)
@@ -1645,7 +1634,7 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 			o->grid_base = e->gbase;
 			continue;
 		}
-		const struct tg_walk_sum *s = &sd->h_sums[c];
+		const struct tg_walk_sum *s = &sd->io.h_sums[c];
 		o->nslots = s->nslots;
 		o->nevents = s->nevents;
 		o->final_state = (int)s->final_state;
@@ -1661,14 +1650,12 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 			rc = TGPU_ENOMEM;
 			break;
 		}
-		memcpy(o->grid_bits, sd->h_bits + e->gbase / 32, nw * 4);
+		memcpy(o->grid_bits, sd->io.h_bits2 + e->gbase / 32, nw * 4);
 		const uint32_t eager = s->nevents < TGW_EVEAGER ? s->nevents : TGW_EVEAGER;
-		memcpy(o->events, sd->h_events + (size_t)c * TGW_EVCAP, (size_t)eager * sizeof(*o->events));
-		if (s->nevents > eager) {	/* a channel with many exceptions: the rest of its events in a second copy */
-			uint8_t *d_ev = tgpi_plan_walk_events_dev(st->plan);
-			rc = (int)hipMemcpy(o->events + eager, d_ev + ((size_t)c * TGW_EVCAP + eager) * sizeof(*o->events),
+		memcpy(o->events, sd->io.h_eager + (size_t)c * TGW_EVEAGER, (size_t)eager * sizeof(*o->events));
+		if (s->nevents > eager)		/* a channel with many exceptions: the rest of its events in a second copy */
+			rc = (int)hipMemcpy(o->events + eager, sd->io.d_evbig + (size_t)c * TGW_EVCAP + eager,
 					    (size_t)(s->nevents - eager) * sizeof(*o->events), hipMemcpyDeviceToHost);
-		}
 		uint32_t last = 0xffffffffu;
 		for (size_t wd = nw; wd-- > 0;)
 			if (o->grid_bits[wd]) {
