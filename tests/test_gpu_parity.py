@@ -403,6 +403,23 @@ def test_config2_full_size_roundtrip(T, eng):
     sl = slice(500_000, 500_400)
     rec_sl = np.ascontiguousarray(d_rec.view(n, T.REC_BYTES)[sl].cpu().numpy())
     check_against_oracle(T, rec_sl, types[sl], slots[sl], 0)
+    # second pass, the sub-run that exercises the tie rule: the same million bursts with 2 % bit
+    # errors in the coded fields.  Blocks that pass their CRC must equal the payload; a 20 000-slot slice of it (40 000
+    # trellises with noise) is compared with the oracle on every bit, crc word and flag
+    del p
+    noisy = T.synth_slots(types, seed=1, scramb_init=0, ber=0.02)
+    d_stream.copy_(torch.from_numpy(noisy.reshape(-1)))
+    plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    p = T.parse_records(d_rec.cpu().numpy().reshape(n, T.REC_BYTES))
+    ok1, ok2 = p["crc_ok"][:, 0] == 1, p["crc_ok"][:, 1] == 1
+    assert 0.2 < ok1[n1].mean() < 0.999 and 0.5 < ok1[n2].mean() < 0.9999      # noise bites, most blocks survive
+    assert (p["bits1"][n1 & ok1] == t1[n1 & ok1, 14:282]).all()
+    assert (p["bits1"][n2 & ok1][:, :124] == t1[n2 & ok1, 14:138]).all()
+    assert (p["bits2"][n2 & ok2] == t1[n2 & ok2, 138:262]).all()
+    sl = slice(300_000, 320_000)
+    rec_sl = np.ascontiguousarray(d_rec.view(n, T.REC_BYTES)[sl].cpu().numpy())
+    check_against_oracle(T, rec_sl, types[sl], noisy[sl], 0)
     plan.close()
 
 
