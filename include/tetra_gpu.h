@@ -516,7 +516,7 @@ void tgpu_sync_dev_free(struct tgpu_sync_dev *sd);
 /* measurement aid: one such batch, synchronously, with HIP events between all of its stages on hip_stream: dev_ms[] =
  * the stages in front of the decode (names: tgpu_sync_dev_stage_name), the decode's stages in prof / step as
  * tgpu_plan_execute_prof() leaves them (read with tgpu_prof_read; stage 0, k_front, is empty in stream mode) */
-#define TGPU_NDEVSTAGES 5
+#define TGPU_NDEVSTAGES 8
 int tgpu_sync_multi_launch_prof(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
 				const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, void *hip_stream, struct tgpu_prof *prof,
 				uint32_t step, float dev_ms[TGPU_NDEVSTAGES]);

@@ -771,7 +771,7 @@ class MultiSyncDev:
             lib().tgpu_sync_dev_free(self._h)
 
 
-DEV_STAGES = 5
+DEV_STAGES = 8
 
 
 def sync_multi_launch_prof(engine, plan, chans, d_base_ptr, d_rec_ptr, prof, step, chunk=64, hip_stream=0):

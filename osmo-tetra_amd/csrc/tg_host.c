@@ -90,6 +90,12 @@ struct tgpu_plan {
 	uint64_t max_off;	/* slot mode: largest slot offset of the load (bounds check of tgpu_plan_execute_float) */
 	/* stream mode with the walk on the device (tgpu_sync_multi_launch): item counts stay on the device */
 	const uint32_t *d_counts;	/* [nsb, n216, n432] behind the list builder's block sums; NULL: the host knows them */
+	uint32_t *d_lb_tbl, *d_lb_ok, *d_lb_prevw;	/* device-walk batches: code table, okbits, look-back words (in d_up) */
+	uint8_t *d_lb_wchan;
+	uint8_t *d_rec_dev;		/* ... the batch's records (the SB1 launch runs before tgpu_plan_execute gets them) */
+	int dev_mid;			/* ... SB1 / code fill / masks were done by the device-walk stages */
+	int have_final;			/* ... and the codes after the batch are in h_final_code */
+	uint32_t h_final_code[64];
 	uint8_t *d_walk, *h_walk;	/* k_walk's blocks (tg_walk_io): up, down, device-only events (device / pinned mirror) */
 	void *d_walk_recs;		/* max_chan * (TGW_NCAP + 1) node records */
 	uint32_t *d_bits_dev;		/* the delivered bitmap k_walk left in the upload arena */
@@ -156,7 +162,7 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	p->max_chan = max_chan;
 	const size_t n = max_slots;
 	/* descriptors 8n, chan 4n, sbord 4n, lists <= 8n in total, static mask indices 4n, codes, padding */
-	p->up_bytes = 28 * n + 4 * (size_t)max_chan + 8 * UP_ALIGN;
+	p->up_bytes = 28 * n + 4 * (size_t)max_chan + 16 * UP_ALIGN + 4 * (TGK_LB_TBL + 1);	/* (+ the code table of device-walk batches) */
 	/* small plans (the drop-in channel API at small batch sizes: a flush is a round trip, and every copy in it costs
 	 * more than the bytes): descriptors and lists stay in pinned host memory and the kernels read them in place.
 	 * Consequence for callers: a small plan must be idle (its last execute complete) before the next tgpu_plan_load*()
@@ -317,6 +323,8 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 	p->static_masks = is_static;
 	p->static_pending = is_static;
 	p->d_counts = NULL;
+	p->dev_mid = 0;
+	p->have_final = 0;
 	p->max_off = max_off;
 	p->d_idx_stage = d_idx_stage;
 	p->packed_ready = 0;
@@ -452,6 +460,8 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 	p->packed_ready = 1;
 	p->block_mode = 0;
 	p->d_counts = NULL;
+	p->dev_mid = 0;
+	p->have_final = 0;
 	p->nslots = ngrid;
 	p->nchan = nchan;
 	p->nsb = tot[0];
@@ -462,68 +472,137 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 }
 
 /*
- * The same with the delivered bitmap made on the device (k_walk): nothing comes back to the host before the decode.
- * The lists are sized for the worst case (every grid slot of one kind) and the item counts stay behind the list
- * builder's block sums; the trellis kernels and k_masks read them there (d_counts).
- * d_codes: the channels' carry-in codes, already on the device (tg_walk_io's upload block);
- * *d_bits_out = where k_walk is to leave the bitmap (ngrid bits, channel grids at multiples of 32).
+ * Device-walk batches (tg_stream.c: tgpu_sync_multi_launch): nothing comes back to the host before the decode, and what
+ * lies between the front end and the trellis kernels is five small launches (tg_kernels.hip, k_lists2):
+ *   stage 1 (before k_walk)  one memset (counters, code table, okbits), k_cls_plain2; then beside the walk, on the plan's
+ *                            side stream: k_vit<SB1> over the SYNC-classified slots, k_masks2
+ *   stage 2 (after k_walk)   k_lb_scan, k_lists2 (mask entry per delivered slot, item lists), the two trellis kernels with
+ *                            their item counts read on the device
+ * d_codes / d_tab: the channels' carry-in codes and the channel table, already on the device (tg_walk_io's upload block);
+ * d_plain: where k_cls_plain2 leaves the plain bitmap; d_final: 65 words for the codes after the batch + the overflow flag
+ * of the code table (in the block that goes to the host); *d_bits_out: where k_walk is to leave the delivered bitmap.
+ * serial != 0: everything on the caller's stream in program order (per-stage profiling).
  */
-int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, uint32_t *d_codes, uint32_t **d_bits_out)
+int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const struct tg_chan_ent *d_tab, uint32_t *d_codes,
+			 uint32_t *d_plain, uint32_t **d_bits_out, void *stream, int serial, void **evs)
 {
-	if (!p || !ngrid || !p->d_grid || !nchan || !d_codes || !d_bits_out)
+	if (!p || !ngrid || !p->d_grid || !nchan || !d_codes || !d_tab || !d_bits_out)
 		return TGPU_EINVAL;
 	BIND(p->eng);
 	if (ngrid > p->max_slots || nchan > p->max_chan)
 		return TGPU_ECAPACITY;
-	const size_t nwords = ((size_t)ngrid + 31) / 32, nblk = ((size_t)ngrid + 1023) / 1024;
+	const size_t nwords = ((size_t)ngrid + 31) / 32;
 	size_t o = 0;
 #define UP_AT(ptr, type, count) do { ptr = (type *)(p->d_up + o); \
 		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
-	uint32_t *d_bits, *d_blk;
+	uint32_t *d_cnt, *d_tbl, *d_ok, *d_bits, *d_prevw;
+	uint8_t *d_wchan;
+	UP_AT(d_cnt, uint32_t, 4);
+	UP_AT(d_tbl, uint32_t, TGK_LB_TBL + 1);
+	UP_AT(d_ok, uint32_t, nwords);
+	const size_t zero_bytes = o;		/* counters, code table (+ overflow flag), okbits: cleared per batch in one go */
 	UP_AT(d_bits, uint32_t, nwords);
-	UP_AT(p->d_slot_chan, uint32_t, ngrid);
-	UP_AT(p->d_slot_sbord, int32_t, ngrid);
+	UP_AT(d_prevw, uint32_t, nwords);
+	UP_AT(d_wchan, uint8_t, nwords);
+	UP_AT(p->d_slot_sbord, int32_t, ngrid);		/* here: the mask entry a SYNC slot's good SB1 took (k_vit<SB1>) */
 	UP_AT(p->d_list_sb, uint32_t, ngrid);
 	UP_AT(p->d_list_216, uint32_t, 2 * (size_t)ngrid);
 	UP_AT(p->d_list_432, uint32_t, ngrid);
-	UP_AT(d_blk, uint32_t, 3 * (nblk + 1));
 #undef UP_AT
 	p->d_slot_off = NULL;
+	p->d_slot_chan = NULL;
 	if (o > p->up_bytes)
 		return TGPU_ECAPACITY;
 	p->d_chan_code = d_codes;
 	p->d_bits_dev = d_bits;
-	p->d_counts = d_blk + 3 * nblk;
+	p->d_counts = d_cnt;
+	p->d_lb_tbl = d_tbl;
+	p->d_lb_ok = d_ok;
+	p->d_lb_prevw = d_prevw;
+	p->d_lb_wchan = d_wchan;
 	*d_bits_out = d_bits;
 	p->loaded = 0;
 	p->nslots = ngrid;
 	p->nchan = nchan;
+	hipStream_t s = (hipStream_t)stream;
+	HCHK(hipMemsetAsync(p->d_up, 0, zero_bytes, s));
+	int rc = tgk_cls_plain2(p->d_grid, ngrid, d_plain, p->d_list_sb, d_cnt, d_wchan, d_tab, nchan, stream);
+	if (rc)
+		return rc;
+	if (evs)
+		HCHK(hipEventRecord((hipEvent_t)evs[0], s));
+	hipStream_t s2 = serial ? s : p->side;
+	if (!serial) {
+		HCHK(hipEventRecord(p->ev_fork, s));
+		HCHK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+	}
+	const int kf = TGK_F_LOOKBACK | (int)(nchan << 8) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0);
+	rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, ngrid, p->d_packed, d_tbl, NULL, p->d_rec_dev, d_ok, (uint32_t *)p->d_slot_sbord, p->d_wire,
+		     NULL, kf, d_cnt, (void *)s2);
+	if (rc)
+		return rc;
+	if (evs)
+		HCHK(hipEventRecord((hipEvent_t)evs[1], s2));
+	rc = tgk_masks2(d_codes, nchan, d_tbl, p->d_masks, (void *)s2);
+	if (rc)
+		return rc;
+	if (evs)
+		HCHK(hipEventRecord((hipEvent_t)evs[2], s2));
+	if (!serial)
+		HCHK(hipEventRecord(p->ev_join, p->side));
 	return TGPU_OK;
 }
 
-/* second half: the lists from the bitmap k_walk has left (same stream, no host wait); d_tab: the channel table on the device */
-int tgpi_plan_grid_lists_dev(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, void *stream)
+int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, uint32_t *d_final, void *stream, int serial, void **evs)
 {
-	if (!p || !p->d_counts || !p->d_bits_dev || !d_tab)
+	if (!p || !p->d_counts || !p->d_bits_dev || !d_tab || !d_final)
 		return TGPU_EINVAL;
 	BIND(p->eng);
 	const uint32_t ngrid = p->nslots;
-	const size_t nblk = ((size_t)ngrid + 1023) / 1024;
-	int rc = tgk_grid_lists(p->d_grid, p->d_bits_dev, ngrid, (uint32_t *)p->d_counts - 3 * nblk, p->d_slot_chan, p->d_slot_sbord,
-				p->d_list_sb, p->d_list_216, p->d_list_432, d_tab, p->nchan, stream);
+	hipStream_t s = (hipStream_t)stream;
+	if (!serial)
+		HCHK(hipStreamWaitEvent(s, p->ev_join, 0));
+	int rc = tgk_lb_scan(p->d_lb_ok, p->d_bits_dev, p->d_lb_wchan, (ngrid + 31) / 32, p->d_lb_prevw, d_tab, p->nchan, p->d_chan_code,
+			     (const uint32_t *)p->d_slot_sbord, p->d_masks, p->d_lb_tbl, d_final, stream);
 	if (rc)
 		return rc;
+	if (evs)
+		HCHK(hipEventRecord((hipEvent_t)evs[0], s));
+	rc = tgk_lists2(p->d_grid, p->d_bits_dev, ngrid, p->d_lb_ok, p->d_lb_prevw, p->d_lb_wchan, (const uint32_t *)p->d_slot_sbord,
+			p->d_maskidx, p->d_list_216, p->d_list_432, (uint32_t *)p->d_counts, stream);
+	if (rc)
+		return rc;
+	if (evs)
+		HCHK(hipEventRecord((hipEvent_t)evs[1], s));
 	for (uint32_t c = 0; c < p->nchan; c++)
-		p->h_last_slot_of_chan[c] = 0xffffffffu;	/* tgpi_plan_set_last_slot() once the bitmap is on the host */
+		p->h_last_slot_of_chan[c] = 0xffffffffu;
 	p->static_masks = 0;
 	p->static_pending = 0;
 	p->packed_ready = 1;
 	p->block_mode = 0;
-	p->nsb = ngrid;		/* upper bounds: the launches are sized for them, the kernels read d_counts */
+	p->dev_mid = 1;		/* plan_run: SB1 / fill / masks are done, the trellis kernels read their counts on the device */
+	p->have_final = 0;
+	p->nsb = ngrid;		/* upper bounds: the launches are sized for them */
 	p->n216 = 2 * ngrid;
 	p->n432 = ngrid;
 	p->loaded = 1;
 	return TGPU_OK;
+}
+
+/* the SB1 launch of stage 1 writes into the batch's records: tell the plan where they are before stage 1 */
+void tgpi_plan_set_rec(struct tgpu_plan *p, uint8_t *d_rec)
+{
+	if (p)
+		p->d_rec_dev = d_rec;
+}
+
+/* codes in force after a device-walk batch (k_lb_scan left them in the block that came to the host) */
+void tgpi_plan_set_final_codes(struct tgpu_plan *p, const uint32_t *codes, uint32_t nchan)
+{
+	if (!p || nchan > p->max_chan)
+		return;
+	memcpy(p->h_final_code, codes, (size_t)nchan * 4);
+	p->have_final = 1;
 }
 
 void tgpi_plan_set_last_slot(struct tgpu_plan *p, uint32_t chan, uint32_t slot)
@@ -541,7 +620,7 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 	BIND(p->eng);
 	const size_t nc = p->max_chan < 64 ? p->max_chan : 64;
 	const size_t up = 64 * (sizeof(struct tg_chan_ent) + sizeof(struct tg_walk_root) + 4);
-	const size_t down_max = 64 * sizeof(struct tg_walk_sum) + nc * (size_t)TGW_EVEAGER * sizeof(tgpu_sync_event_rec_dev) +
+	const size_t down_max = 64 * sizeof(struct tg_walk_sum) + 68 * 4 + nc * (size_t)TGW_EVEAGER * sizeof(tgpu_sync_event_rec_dev) +
 				(((size_t)p->max_slots + 31) / 32 + 4) * 4;
 	const size_t big = nc * (size_t)TGW_EVCAP * sizeof(tgpu_sync_event_rec_dev);
 	const size_t o_down = (up + 255) & ~(size_t)255, o_big = (o_down + down_max + 255) & ~(size_t)255;
@@ -575,8 +654,10 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 	io->h_down0 = p->h_walk + o_down;
 	io->d_sums = (struct tg_walk_sum *)io->d_down0;
 	io->h_sums = (struct tg_walk_sum *)io->h_down0;
-	io->d_eager = (tgpu_sync_event_rec_dev *)(io->d_sums + 64);
-	io->h_eager = (tgpu_sync_event_rec_dev *)(io->h_sums + 64);
+	io->d_final = (uint32_t *)(io->d_sums + 64);
+	io->h_final = (uint32_t *)(io->h_sums + 64);
+	io->d_eager = (tgpu_sync_event_rec_dev *)(io->d_final + 68);
+	io->h_eager = (tgpu_sync_event_rec_dev *)(io->h_final + 68);
 	io->d_bits2 = (uint32_t *)(io->d_eager + (size_t)nchan * TGW_EVEAGER);
 	io->h_bits2 = (uint32_t *)(io->h_eager + (size_t)nchan * TGW_EVEAGER);
 	io->down_bytes = (size_t)((uint8_t *)(io->d_bits2 + ((size_t)ngrid + 31) / 32) - io->d_down0);
@@ -721,20 +802,20 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 			return rc;
 	}
 	MARK(1);
-	if (p->nslots && !p->static_masks) {
+	if (p->nslots && !p->static_masks && !p->dev_mid) {
 		if ((rc = tgk_vit(TG_KIND_SB1, p->d_list_sb, p->nsb, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
 				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, (p->rm_decode ? TGK_F_RM : 0) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0),
 				  p->d_counts, stream)))
 			return rc;
 	}
 	MARK(2);
-	if (p->nslots && !p->static_masks) {
+	if (p->nslots && !p->static_masks && !p->dev_mid) {
 		if ((rc = tgk_fill(p->d_slot_chan, p->d_slot_sbord, p->d_sb_ok, p->d_sb_code, p->d_list_sb, p->nchan, p->nslots, p->d_block_tmp,
 				   p->d_maskidx, stream)))
 			return rc;
 	}
 	MARK(3);
-	if (p->nslots && !p->static_masks) {
+	if (p->nslots && !p->static_masks && !p->dev_mid) {
 		if ((rc = tgk_masks_dev(p->d_chan_code, p->nchan, p->d_sb_ok, p->d_sb_code, p->nsb, p->d_counts, p->d_list_sb, p->d_slot_chan,
 					p->d_masks, stream)))
 			return rc;
@@ -933,6 +1014,8 @@ int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t 
 	p->static_masks = 1;
 	p->static_pending = 0;
 	p->d_counts = NULL;
+	p->dev_mid = 0;
+	p->have_final = 0;
 	p->packed_ready = 0;
 	p->block_mode = 1;
 	p->loaded = 1;
@@ -1174,6 +1257,12 @@ int tgpu_plan_final_codes(struct tgpu_plan *p, const uint8_t *d_rec, uint32_t *c
 		return TGPU_EINVAL;
 	BIND(p->eng);
 	(void)d_rec;
+	if (p->dev_mid) {	/* a device-walk batch: k_lb_scan computed them, tgpu_sync_multi_collect() brought them over */
+		if (!p->have_final)
+			return TGPU_ESTATE;
+		memcpy(chan_code_out, p->h_final_code, (size_t)p->nchan * 4);
+		return TGPU_OK;
+	}
 	/* code in effect after the batch = mask entry of the channel's last slot */
 	HCHK(hipDeviceSynchronize());
 	for (uint32_t c = 0; c < p->nchan; c++) {

@@ -111,6 +111,7 @@ struct tg_walk_io {
 	struct tg_walk_sum *d_sums, *h_sums;
 	tgpu_sync_event_rec_dev *d_eager, *h_eager;
 	uint32_t *d_bits2, *h_bits2;
+	uint32_t *d_final, *h_final;	/* 64 codes after the batch + the code table's overflow flag */
 	tgpu_sync_event_rec_dev *d_evbig;
 	void *d_recs;
 };
@@ -130,6 +131,9 @@ int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity);
 #define TGK_F_BLOCK 1	/* tgk_vit flags: items are blocks on their own */
 #define TGK_F_RM    2	/* correct the BBK with the RM(30,14) decoder before its first 14 bits are kept */
 #define TGK_F_WIREONLY 8	/* only the 40-byte wire records are written (tgpu_plan_set_wire_only): no 320-byte records */
+#define TGK_F_LOOKBACK 16	/* SB1 launch of a device-walk batch: d_sb_ok = okbits (bit per grid slot), d_sb_code = mask entry per slot, d_masks =
+				 * the code table (TGK_LB_TBL + 1 words), flags >> 8 = number of channels (tg_kernels.hip, k_lists2) */
+#define TGK_LB_TBL 4096u
 #define TGK_F_DIRECT 4	/* SCH/F records written 16 bytes per lane instead of through the LDS transpose (A/B: TGPU_REC_DIRECT=1) */
 
 /* make the engine's device the calling thread's current HIP device (every allocating / launching entry point does) */
@@ -156,9 +160,23 @@ int tgpi_plan_chan_table(struct tgpu_plan *p, const struct tg_chan_ent *ents, ui
 int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t nchan, const uint32_t *codes,
 			const struct tg_chan_ent *ents, void *stream);
 
+/* device-walk batches: everything between the front end and the trellis kernels (tg_kernels.hip, k_lists2) */
+int tgk_cls_plain2(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, uint32_t *d_list_sb, uint32_t *d_cnt_sb,
+		   uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, void *stream);
+int tgk_masks2(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_tbl, uint32_t *d_masks, void *stream);
+int tgk_lb_scan(const uint32_t *d_okbits, const uint32_t *d_dbits, const uint8_t *d_word_chan, uint32_t nwords,
+		uint32_t *d_prevw, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_chan_code,
+		const uint32_t *d_slot_entry, const uint32_t *d_masks, const uint32_t *d_tbl, uint32_t *d_final_code, void *stream);
+int tgk_lists2(const uint32_t *d_cls, const uint32_t *d_dbits, uint32_t n, const uint32_t *d_okbits, const uint32_t *d_prevw,
+	       const uint8_t *d_word_chan, const uint32_t *d_slot_entry, uint32_t *d_maskidx, uint32_t *d_list_216,
+	       uint32_t *d_list_432, uint32_t *d_cnt, void *stream);
 /* stream mode with the walk on the device (tg_stream.c: tgpu_sync_multi_launch) */
-int tgpi_plan_grid_layout_dev(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, uint32_t *d_codes, uint32_t **d_bits_out);
-int tgpi_plan_grid_lists_dev(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, void *stream);
+/* evs (optional, serial mode): HIP events recorded behind stage 1's three launches / stage 2's two */
+int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const struct tg_chan_ent *d_tab, uint32_t *d_codes,
+			 uint32_t *d_plain, uint32_t **d_bits_out, void *stream, int serial, void **evs);
+int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, uint32_t *d_final, void *stream, int serial, void **evs);
+void tgpi_plan_set_rec(struct tgpu_plan *p, uint8_t *d_rec);
+void tgpi_plan_set_final_codes(struct tgpu_plan *p, const uint32_t *codes, uint32_t nchan);
 void tgpi_plan_set_last_slot(struct tgpu_plan *p, uint32_t chan, uint32_t slot);
 uint32_t *tgpi_plan_bits_dev(struct tgpu_plan *p);
 

@@ -1397,6 +1397,7 @@ void k_front_soft(const void *__restrict__ in, unsigned long long nin, const uin
 /* ------------------------------------------------------------------------- */
 /* k_vit<KIND>                                                               */
 /* ------------------------------------------------------------------------- */
+#define TG_LB_TBL 4096u		/* hash table slots for the scrambling codes of a device-walk batch (k_lists2) */
 template <int KIND> struct vit_cfg;
 template <> struct vit_cfg<TG_KIND_SB1> { enum { NBLK = 10, TYPE1 = 60, MW = 0 }; };
 template <> struct vit_cfg<TG_KIND_216> { enum { NBLK = 18, TYPE1 = 124, MW = TG_MW_216 }; };
@@ -1595,8 +1596,48 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 			*(uint32_t *)(r + TG_REC_SBF1) = mcc | (mnc << 16);
 			*(uint32_t *)(r + TG_REC_SBCODE) = code;
 		}
-		sb_ok[idx] = crc_ok;
-		sb_code[idx] = code;
+		if (kflags & TGK_F_LOOKBACK) {
+			/* device-walk batches (see k_lists2): sb_ok = one bit per grid slot "SB1 passed its CRC", sb_code = the slot's
+			 * mask-table entry, masks = the batch's code table (open addressing, 0 = free: a code ends in binary 11) */
+			/* one table access per DISTINCT code of the wave (a recording has one cell: every lane brings the same code, and
+			 * a hundred thousand compare-and-swaps on one word would serialise): the first lane of each group looks its
+			 * code up -- a plain read first, the atomic only while the slot reads free -- and hands the slot to the others */
+			uint32_t *tbl = const_cast<uint32_t *>(masks);
+			const bool live = valid && crc_ok;
+			uint32_t myh = 0;
+			unsigned long long todo = __ballot(live);
+			while (todo) {
+				const uint32_t l0 = (uint32_t)__builtin_ctzll(todo);
+				const uint32_t c0 = __builtin_amdgcn_readlane(code, l0);
+				uint32_t h = (c0 * 2654435761u) >> 20, probe = 0;
+				if ((threadIdx.x & 63) == l0) {
+					for (; probe < TG_LB_TBL; probe++) {
+						uint32_t old = __hip_atomic_load(&tbl[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (old == 0u)
+							old = atomicCAS(&tbl[h], 0u, c0);
+						if (old == 0u || old == c0)
+							break;
+						h = (h + 1) & (TG_LB_TBL - 1);
+					}
+					if (probe == TG_LB_TBL) {	/* more codes than the table holds: the batch is handed to the host path */
+						atomicOr(&tbl[TG_LB_TBL], 1u);
+						h = 0;
+					}
+				}
+				h = __builtin_amdgcn_readlane(h, l0);
+				const bool mine = live && code == c0;
+				if (mine)
+					myh = h;
+				todo &= ~__ballot(mine);
+			}
+			if (live) {
+				sb_code[slot] = 1u + ((uint32_t)kflags >> 8) + myh;
+				atomicOr(&sb_ok[slot >> 5], 1u << (slot & 31));
+			}
+		} else {
+			sb_ok[idx] = crc_ok;
+			sb_code[idx] = code;
+		}
 		if (block_mode && !wire_only) {	/* a block on its own: this lane also writes the header */
 			r[TG_REC_TYPE] = (uint8_t)packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
 			*(uint32_t *)(r + TG_REC_CODE) = 3u;
@@ -3930,5 +3971,311 @@ extern "C" int tgk_gsmtap(const uint8_t *d_rec, const void *d_times, const uint8
 		return 0;
 	hipLaunchKernelGGL(k_gsmtap, dim3((3 * nslots + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_rec,
 			   (const tg_tdma_time_dev *)d_times, d_traffic, nslots, d_msgs, d_lens);
+	return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
+/* device-walk batches: everything between the front end and the trellis kernels in five small launches */
+/* ------------------------------------------------------------------------- */
+/*
+ * The host-walk path builds ordered lists (count / scan / emit), decodes SB1 over the ordered SYNC list, forward-fills
+ * the code over all slots (reduce / scan / apply) and builds mask entries per SYNC ordinal: ten launches, ~85 us of small
+ * kernels per 1 M slots.  With the walk on the device none of that order is needed:
+ *   k_cls_plain2  plain bitmap (as k_cls_plain) + the list of SYNC-classified slots (wave-aggregated append, any order)
+ *                 + the channel of every 32-slot word                                    -- before the walk
+ *   k_vit<SB1>    over that list, beside the walk (side stream): a block that passes its CRC sets its slot's bit in
+ *                 'okbits' and takes a mask-table entry for its code from a small hash table (codes in play are few:
+ *                 one per cell), remembered per slot                                     (tg_lb, vit_finish)
+ *   k_masks2      the scrambling masks of the entries in use (carry-ins + hash table)
+ *   k_lb_scan     per 32-slot word: the latest word at or before it (same channel) that holds a delivered SYNC slot
+ *                 with a good SB1 -- one workgroup, running maximum; also every channel's code after the batch
+ *   k_lists2      per delivered slot: the mask entry of the latest such SYNC slot at or before it (this slot included:
+ *                 an SB1 sets the code for the BBK and SB2 of its own burst, tetra_lower_mac.c:179-186, 291-300), else
+ *                 the channel's carry-in; and the slot's items appended to the 216 / 432 lists (wave-aggregated, any
+ *                 order -- records are addressed by slot)
+ * An undelivered SYNC slot may be decoded (its SB1 costs 84 trellis steps) but never counts: the look-back ANDs okbits
+ * with the delivered bitmap.
+ */
+#define TG_MID_CHUNKS 4		/* 1024-slot chunks per workgroup of k_cls_plain2 / k_lists2: one atomic per 4096 slots and list */
+__global__ __launch_bounds__(1024)
+void k_cls_plain2(const uint32_t *__restrict__ cls, uint32_t n, uint32_t *__restrict__ plain, uint32_t *__restrict__ list_sb,
+		  uint32_t *__restrict__ cnt_sb, uint8_t *__restrict__ word_chan, const tg_chan_ent *__restrict__ chan, uint32_t nchan)
+{
+	/* (a single word takes ~90 atomics per microsecond: one per wave would be 15 000 of them) */
+	__shared__ uint32_t s_cnt[TG_MID_CHUNKS][16], s_base;
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned long long sbm[TG_MID_CHUNKS];
+	bool sb[TG_MID_CHUNKS];
+#pragma unroll
+	for (int j = 0; j < TG_MID_CHUNKS; j++) {
+		const uint32_t i = (blockIdx.x * TG_MID_CHUNKS + j) * 1024 + threadIdx.x;
+		const uint32_t w = i >> 5;
+		const uint32_t v = i < n ? cls[i] & 0x03ffffffu : 0xffu;
+		sb[j] = v == (TG_BURST_SYNC | TG_SYNC_TRAIN_OFF << 8);
+		const bool ok = sb[j] || v == (TG_BURST_NORM_1 | TG_NORM_TRAIN_OFF << 8) || v == (TG_BURST_NORM_2 | TG_NORM_TRAIN_OFF << 8);
+		const unsigned long long b = __ballot(ok);
+		sbm[j] = __ballot(sb[j]);
+		if (lane == 0 && 32 * w < n)
+			plain[w] = (uint32_t)b;
+		if (lane == 32 && 32 * w < n)
+			plain[w] = (uint32_t)(b >> 32);
+		/* the wave's 64 slots lie in one or two channels (grids start at multiples of 32) */
+		if ((lane == 0 || lane == 32) && 32 * w < n) {
+			uint32_t c = 0;
+			for (uint32_t q = 1; q < nchan; q++)
+				c += chan[q].gbase <= i;
+			word_chan[w] = (uint8_t)c;
+		}
+		if (lane == 0)
+			s_cnt[j][wv] = (uint32_t)__builtin_popcountll(sbm[j]);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0;
+		for (int q = 0; q < TG_MID_CHUNKS * 16; q++)
+			tot += s_cnt[0][q];
+		s_base = tot ? atomicAdd(cnt_sb, tot) : 0u;
+	}
+	__syncthreads();
+	uint32_t pos = s_base;
+#pragma unroll
+	for (int j = 0; j < TG_MID_CHUNKS; j++) {
+		uint32_t mine = pos;
+		for (uint32_t q = 0; q < 16; q++) {
+			if (q < wv)
+				mine += s_cnt[j][q];
+			pos += s_cnt[j][q];
+		}
+		if (sb[j])
+			list_sb[mine + __builtin_popcountll(sbm[j] & ((1ull << lane) - 1))] = (blockIdx.x * TG_MID_CHUNKS + j) * 1024 + threadIdx.x;
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_masks2(const uint32_t *__restrict__ chan_code, uint32_t nchan, const uint32_t *__restrict__ tbl, uint32_t *__restrict__ masks)
+{
+	/* as k_masks: a wavefront keeps the linear-form masks of its 18 x 64 output bits in registers and builds, of 64 entries
+	 * at a time, the ones in use: entry 0, the channel carry-ins, the occupied slots of the code table */
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t half = lane >> 5, bit = lane & 31;
+	const uint32_t nent = 1 + nchan + TG_LB_TBL;
+	uint32_t lin[TG_MW_ROUNDS];
+#pragma unroll
+	for (int r = 0; r < TG_MW_ROUNDS; r++) {
+		const uint16_t pos = c_tab.mask_pos[2 * r + half][bit];
+		lin[r] = (pos != 0xffff) ? c_tab.lfsr_lin[pos] : 0u;
+	}
+	for (uint32_t e0 = wave * 64; e0 < nent; e0 += nwaves * 64) {
+		const uint32_t e = e0 + lane;
+		uint32_t mycode = 0;
+		bool need = e < nent;
+		if (e >= 1 && e <= nchan)
+			mycode = chan_code[e - 1];
+		else if (e > nchan && e < nent) {
+			mycode = tbl[e - 1 - nchan];
+			need = mycode != 0;
+		}
+		unsigned long long todo = __ballot(need);
+		while (todo) {
+			const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+			todo &= todo - 1;
+			const uint32_t code = __builtin_amdgcn_readlane(mycode, l);
+			uint32_t myword = 0;
+#pragma unroll
+			for (int r = 0; r < TG_MW_ROUNDS; r++) {
+				const unsigned long long bal = __ballot(__popc(code & lin[r]) & 1);
+				myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
+				myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
+			}
+			if (lane == TG_MW_CODE)
+				myword = code;
+			if (lane < TG_MASK_WORDS)
+				masks[(size_t)(e0 + l) * TG_MASK_WORDS + lane] = myword;
+		}
+	}
+}
+
+/* latest delivered SYNC slot with a good SB1 at or before grid slot g in g's channel, or 0xffffffff */
+__device__ __forceinline__ uint32_t tg_lb_find(uint32_t g, const uint32_t *__restrict__ okbits, const uint32_t *__restrict__ dbits,
+					       const uint32_t *__restrict__ prevw, const uint8_t *__restrict__ word_chan)
+{
+	const uint32_t w = g >> 5;
+	uint32_t m = okbits[w] & dbits[w] & (0xffffffffu >> (31 - (g & 31)));
+	uint32_t ww = w;
+	if (!m) {
+		if (!w)
+			return 0xffffffffu;
+		const uint32_t p = prevw[w - 1];	/* 1 + the latest word <= w - 1 that has one, in that word's channel; 0: none */
+		if (!p || word_chan[p - 1] != word_chan[w])
+			return 0xffffffffu;
+		ww = p - 1;
+		m = okbits[ww] & dbits[ww];
+	}
+	return 32 * ww + 31 - __builtin_clz(m);
+}
+
+#define LBS_THREADS 1024
+__global__ __launch_bounds__(LBS_THREADS)
+void k_lb_scan(const uint32_t *__restrict__ okbits, const uint32_t *__restrict__ dbits, const uint8_t *__restrict__ word_chan,
+	       uint32_t nwords, uint32_t *__restrict__ prevw, const tg_chan_ent *__restrict__ chan, uint32_t nchan,
+	       const uint32_t *__restrict__ chan_code, const uint32_t *__restrict__ slot_entry, const uint32_t *__restrict__ masks,
+	       const uint32_t *__restrict__ tbl, uint32_t *__restrict__ final_code)
+{
+	/* one workgroup per channel (a channel's words never look into another's): running maximum of (word + 1 if the word has
+	 * a delivered good SYNC slot, else 0) over the channel's words, 1024 consecutive words per pass (coalesced loads, the
+	 * next pass's in flight during the scan) */
+	__shared__ uint32_t sm[LBS_THREADS / 64];
+	const uint32_t c = blockIdx.x;
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const uint32_t w0 = chan[c].gbase >> 5, wn = (chan[c].ncls + 31) >> 5;
+	(void)nwords;
+	uint32_t carry = 0;
+	uint32_t w = threadIdx.x;
+	uint32_t has = w < wn ? (okbits[w0 + w] & dbits[w0 + w]) : 0u;
+	for (uint32_t base = 0; base < wn; base += LBS_THREADS) {
+		const uint32_t wnext = base + LBS_THREADS + threadIdx.x;
+		const uint32_t hnext = wnext < wn ? (okbits[w0 + wnext] & dbits[w0 + wnext]) : 0u;
+		uint32_t inc = has ? w0 + w + 1 : 0u;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(inc, d);
+			if (lane >= (uint32_t)d && o > inc)
+				inc = o;
+		}
+		__syncthreads();
+		if (lane == 63)
+			sm[wv] = inc;
+		__syncthreads();
+		uint32_t pre = carry, tot = carry;
+		for (uint32_t q = 0; q < LBS_THREADS / 64; q++) {
+			if (q < wv)
+				pre = sm[q] > pre ? sm[q] : pre;
+			tot = sm[q] > tot ? sm[q] : tot;
+		}
+		if (w < wn)
+			prevw[w0 + w] = inc > pre ? inc : pre;
+		carry = tot;
+		w = wnext;
+		has = hnext;
+	}
+	(void)word_chan;
+	/* the code in force after the batch: the channel's latest delivered good SYNC slot, else its carry-in */
+	if (threadIdx.x == 0) {
+		uint32_t code = chan_code[c];
+		if (carry) {
+			const uint32_t ww = carry - 1;
+			const uint32_t m = okbits[ww] & dbits[ww];
+			code = masks[(size_t)slot_entry[32 * ww + 31 - __builtin_clz(m)] * TG_MASK_WORDS + TG_MW_CODE];
+		}
+		final_code[c] = code;
+		if (c == 0)
+			final_code[64] = tbl[TG_LB_TBL];	/* != 0: the batch had more codes than the table holds */
+	}
+}
+
+__global__ __launch_bounds__(1024)
+void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbits, uint32_t n, const uint32_t *__restrict__ okbits,
+	      const uint32_t *__restrict__ prevw, const uint8_t *__restrict__ word_chan, const uint32_t *__restrict__ slot_entry,
+	      uint32_t *__restrict__ maskidx, uint32_t *__restrict__ list_216, uint32_t *__restrict__ list_432,
+	      uint32_t *__restrict__ cnt /* [1]: 216 items, [2]: 432 items */)
+{
+	__shared__ uint32_t s_c216[TG_MID_CHUNKS][16], s_c432[TG_MID_CHUNKS][16], s_b216, s_b432;
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const unsigned long long below = (1ull << lane) - 1;
+	uint32_t t[TG_MID_CHUNKS], in216[TG_MID_CHUNKS], in432[TG_MID_CHUNKS];
+#pragma unroll
+	for (int j = 0; j < TG_MID_CHUNKS; j++) {
+		const uint32_t g = (blockIdx.x * TG_MID_CHUNKS + j) * 1024 + threadIdx.x;
+		t[j] = TG_BURST_NONE;
+		if (g < n && ((dbits[g >> 5] >> (g & 31)) & 1))
+			t[j] = cls[g] & 0xff;
+		if (t[j] != TG_BURST_NONE) {
+			const uint32_t gs = tg_lb_find(g, okbits, dbits, prevw, word_chan);
+			maskidx[g] = gs != 0xffffffffu ? slot_entry[gs] : 1u + word_chan[g >> 5];
+		}
+		const unsigned long long msb = __ballot(t[j] == TG_BURST_SYNC), mn2 = __ballot(t[j] == TG_BURST_NORM_2);
+		const unsigned long long mn1 = __ballot(t[j] == TG_BURST_NORM_1);
+		in216[j] = __builtin_popcountll(msb & below) + 2 * __builtin_popcountll(mn2 & below);
+		in432[j] = __builtin_popcountll(mn1 & below);
+		if (lane == 0) {
+			s_c216[j][wv] = __builtin_popcountll(msb) + 2 * __builtin_popcountll(mn2);
+			s_c432[j][wv] = __builtin_popcountll(mn1);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 2) {		/* one atomic per workgroup and list */
+		uint32_t tot = 0;
+		for (int q = 0; q < TG_MID_CHUNKS * 16; q++)
+			tot += threadIdx.x ? s_c432[0][q] : s_c216[0][q];
+		const uint32_t base = tot ? atomicAdd(cnt + 1 + threadIdx.x, tot) : 0u;
+		if (threadIdx.x)
+			s_b432 = base;
+		else
+			s_b216 = base;
+	}
+	__syncthreads();
+	uint32_t r216 = s_b216, r432 = s_b432;
+#pragma unroll
+	for (int j = 0; j < TG_MID_CHUNKS; j++) {
+		const uint32_t g = (blockIdx.x * TG_MID_CHUNKS + j) * 1024 + threadIdx.x;
+		uint32_t p216 = r216, p432 = r432;
+		for (uint32_t q = 0; q < 16; q++) {
+			if (q < wv) {
+				p216 += s_c216[j][q];
+				p432 += s_c432[j][q];
+			}
+			r216 += s_c216[j][q];
+			r432 += s_c432[j][q];
+		}
+		p216 += in216[j];
+		p432 += in432[j];
+		if (t[j] == TG_BURST_SYNC)
+			list_216[p216] = (g << 1) | 1;		/* SB2 */
+		else if (t[j] == TG_BURST_NORM_2) {
+			list_216[p216] = g << 1;
+			list_216[p216 + 1] = (g << 1) | 1;
+		} else if (t[j] == TG_BURST_NORM_1)
+			list_432[p432] = g;
+	}
+}
+
+extern "C" int tgk_cls_plain2(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, uint32_t *d_list_sb, uint32_t *d_cnt_sb,
+			      uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, void *stream)
+{
+	if (!n)
+		return 0;
+	hipLaunchKernelGGL(k_cls_plain2, dim3((n + 1024 * TG_MID_CHUNKS - 1) / (1024 * TG_MID_CHUNKS)), dim3(1024), 0, (hipStream_t)stream, d_cls, n, d_plain, d_list_sb, d_cnt_sb,
+			   d_word_chan, d_chan, nchan);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_masks2(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_tbl, uint32_t *d_masks, void *stream)
+{
+	const uint32_t nent = 1 + nchan + TG_LB_TBL;
+	hipLaunchKernelGGL(k_masks2, dim3(((nent + 63) / 64 + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_chan_code, nchan, d_tbl, d_masks);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_lb_scan(const uint32_t *d_okbits, const uint32_t *d_dbits, const uint8_t *d_word_chan, uint32_t nwords,
+			   uint32_t *d_prevw, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_chan_code,
+			   const uint32_t *d_slot_entry, const uint32_t *d_masks, const uint32_t *d_tbl, uint32_t *d_final_code, void *stream)
+{
+	if (!nwords)
+		return 0;
+	hipLaunchKernelGGL(k_lb_scan, dim3(nchan), dim3(LBS_THREADS), 0, (hipStream_t)stream, d_okbits, d_dbits, d_word_chan, nwords, d_prevw,
+			   d_chan, nchan, d_chan_code, d_slot_entry, d_masks, d_tbl, d_final_code);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_lists2(const uint32_t *d_cls, const uint32_t *d_dbits, uint32_t n, const uint32_t *d_okbits, const uint32_t *d_prevw,
+			  const uint8_t *d_word_chan, const uint32_t *d_slot_entry, uint32_t *d_maskidx, uint32_t *d_list_216,
+			  uint32_t *d_list_432, uint32_t *d_cnt, void *stream)
+{
+	if (!n)
+		return 0;
+	hipLaunchKernelGGL(k_lists2, dim3((n + 1024 * TG_MID_CHUNKS - 1) / (1024 * TG_MID_CHUNKS)), dim3(1024), 0, (hipStream_t)stream, d_cls, d_dbits, n, d_okbits, d_prevw,
+			   d_word_chan, d_slot_entry, d_maskidx, d_list_216, d_list_432, d_cnt);
 	return (int)hipGetLastError();
 }

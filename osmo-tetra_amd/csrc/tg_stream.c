@@ -1415,7 +1415,8 @@ int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint
 
 const char *tgpu_sync_dev_stage_name(int stage)
 {
-	static const char *const names[TGPU_NDEVSTAGES] = { "k_front_stream", "k_front_stream_fix", "k_cls_plain", "k_walk", "k_grid_lists" };
+	static const char *const names[TGPU_NDEVSTAGES] = { "k_front_stream", "k_front_stream_fix", "k_cls_plain2", "k_vit<SB1>", "k_masks2",
+							    "k_walk", "k_lb_scan", "k_lists2" };
 	return (stage >= 0 && stage < TGPU_NDEVSTAGES) ? names[stage] : "?";
 }
 
@@ -1525,25 +1526,24 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			rc = (int)hipMemcpyAsync(io->d_up0, io->h_up0, io->up_bytes, hipMemcpyHostToDevice, sd->stream);
 		}
 #define EVMARK(i) do { if (evs && !rc) rc = (int)hipEventRecord(evs[i], sd->stream); } while (0)
-		if (!rc)
-			rc = tgpi_plan_grid_layout_dev(plan, st->ngrid, nchan, io->d_codes, &d_bits);
 		EVMARK(0);
 		if (!rc)
 			rc = tgk_front_stream_multi(d_base, io->d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
 						    tgpi_plan_defer_scratch(plan), stream, evs ? evs[1] : NULL);
 		EVMARK(2);
 		if (!rc) {
+			/* plain bitmap + SYNC list; SB1 and the masks beside the walk (side stream), or in line when stages are timed */
 			tgpi_plan_grid_plain(plan, st->ngrid, &d_plain, &h_plain);
-			rc = tgk_cls_plain(d_cls, st->ngrid, d_plain, stream);
+			tgpi_plan_set_rec(plan, d_rec);
+			rc = tgpi_plan_dev_stage1(plan, st->ngrid, nchan, io->d_tab, io->d_codes, d_plain, &d_bits, stream, evs != NULL,
+						  evs ? (void **)(evs + 3) : NULL);
 		}
-		EVMARK(3);
 		if (!rc)
 			rc = tgk_walk(d_base, io->d_tab, io->d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, io->d_bits2, io->d_sums,
 				      io->d_eager, io->d_evbig, io->d_recs, stream);
-		EVMARK(4);
+		EVMARK(6);
 		if (!rc)
-			rc = tgpi_plan_grid_lists_dev(plan, io->d_tab, stream);
-		EVMARK(5);
+			rc = tgpi_plan_dev_stage2(plan, io->d_tab, io->d_final, stream, evs != NULL, evs ? (void **)(evs + 7) : NULL);
 #undef EVMARK
 		if (!rc)
 			rc = prof ? tgpu_plan_execute_prof(plan, d_base, d_rec, stream, prof, step) : tgpu_plan_execute(plan, d_base, d_rec, stream);
@@ -1597,6 +1597,8 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 	for (uint32_t c = 0; c < st->nchan; c++)
 		if (st->ent[c].ncls && sd->io.h_sums[c].status != TGW_OK)
 			fb = 1;
+	if (st->ngrid && sd->io.h_final[64])
+		fb = 1;		/* more scrambling codes in the batch than the device path's table holds */
 	if (getenv("TGPU_WALK_DEBUG"))
 		for (uint32_t c = 0; c < st->nchan; c++)
 			fprintf(stderr, "k_walk channel %u: %u grid slots, %u nodes, status %u (why %u), %u delivered, %u events\n", c,
@@ -1664,6 +1666,8 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 			}
 		tgpi_plan_set_last_slot(st->plan, c, last);
 	}
+	if (!rc && st->ngrid)
+		tgpi_plan_set_final_codes(st->plan, sd->io.h_final, st->nchan);
 	return rc;
 }
 
