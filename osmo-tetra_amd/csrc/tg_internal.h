@@ -25,6 +25,7 @@ struct tg_chan_ent {
 	uint64_t d_off, anchor, len;
 	uint32_t gbase, ncls;
 };
+void tgk_front_stream_ev_start(void *ev);	/* timing: record 'ev' right in front of this thread's next k_front_stream launch */
 int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots,
 			   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer,
 			   void *stream, void *ev_mid);

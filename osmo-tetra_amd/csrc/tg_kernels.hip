@@ -3114,6 +3114,14 @@ static uint32_t host_pattern_bits(const uint8_t *seq, int from, int n)
 static void stream_patterns(tg_stream_params &prm, uint32_t chunk);
 
 /* both passes of the packed-bit front end; d_defer: scratch of TG_DEFER_WORDS(nslots) dwords (count + list) */
+/* per-kernel timing: an event to be recorded right in front of the next k_front_stream launch of this thread (behind the
+ * clearing of the deferred-slot counter, which is a launch of its own) */
+static __thread void *tl_front_ev_start;
+extern "C" void tgk_front_stream_ev_start(void *ev)
+{
+	tl_front_ev_start = ev;
+}
+
 static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &prm, uint32_t *d_packed, uint32_t *d_cls,
 			       uint16_t *d_ysum, uint32_t *d_defer, hipStream_t s, void *ev_mid)
 {
@@ -3125,6 +3133,10 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 	if (blocks > cap)
 		blocks = cap;
 	HIPCHK(hipMemsetAsync(d_defer, 0, 4, s));
+	if (tl_front_ev_start) {
+		HIPCHK(hipEventRecord((hipEvent_t)tl_front_ev_start, s));
+		tl_front_ev_start = nullptr;
+	}
 	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
 	if (ev_mid)
 		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));

@@ -1526,7 +1526,8 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			rc = (int)hipMemcpyAsync(io->d_up0, io->h_up0, io->up_bytes, hipMemcpyHostToDevice, sd->stream);
 		}
 #define EVMARK(i) do { if (evs && !rc) rc = (int)hipEventRecord(evs[i], sd->stream); } while (0)
-		EVMARK(0);
+		if (evs)
+			tgk_front_stream_ev_start(evs[0]);
 		if (!rc)
 			rc = tgk_front_stream_multi(d_base, io->d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
 						    tgpi_plan_defer_scratch(plan), stream, evs ? evs[1] : NULL);
