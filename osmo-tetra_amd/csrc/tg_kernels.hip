@@ -851,7 +851,8 @@ struct tg_group_data {
 };
 
 #ifndef TG_STREAM_WPE
-#define TG_STREAM_WPE 4
+#define TG_STREAM_WPE 6	/* waves per SIMD (80 VGPRs: 6 fit).  With the grid at two rounds of resident workgroups (launch_stream_front):
+			 * 4 -> 161-168 us per 1 M slots, 5 -> 156-161, 6 -> 155-159, 8 (64 VGPRs) -> 195-200 (tools/front_grid.sh) */
 #endif
 #ifndef TG_STREAM_GATHER
 #define TG_STREAM_GATHER 2	/* 1: ballots + v_writelane (round 2), 2: byte owners on shifted window copies (front_gather_bytes) */
@@ -867,6 +868,27 @@ __device__ __forceinline__ uint32_t tsq_and2(uint32_t acc, uint32_t t0, uint32_t
 	}
 }
 
+#ifndef TGS_ABLATE
+#define TGS_ABLATE 0	/* measurement builds only (tools/front_ablate.sh): 1 no stores, 2 every group from one address, 4 no
+			 * gathers, 8 no search, 16 no shifted copies -- the kernel's results are wrong with any of them */
+#endif
+#ifdef TGS_TIMING
+/* measurement build: reference-clock ticks (s_memtime, 100 MHz) a wave spends between the marks of a group, summed over
+ * all waves; tools/front_phases.py */
+__device__ unsigned long long g_tgs_acc[8];
+extern "C" int tgk_front_stream_stamps(unsigned long long *out, int reset)
+{
+	static const unsigned long long z[8] = { 0 };
+	int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tgs_acc), sizeof(g_tgs_acc));
+	if (!rc && reset)
+		rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tgs_acc), z, sizeof(z));
+	return rc;
+}
+#define TGS_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+			 tgs_acc[i] += t_ - tgs_last; tgs_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TGS_MARK(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TG_STREAM_WPE, TG_STREAM_WPE)))
 void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
@@ -881,6 +903,9 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 #endif
 	__shared__ uint32_t s_out[4][160];	/* per wave: four packed slots on their way out, then their cls / ysum words (+ the idle lanes' dump) */
 
+#ifdef TGS_TIMING
+	unsigned long long tgs_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tgs_last = __builtin_amdgcn_s_memtime();
+#endif
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t wave = blockIdx.x * 4 + wib;
@@ -993,7 +1018,11 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			gb = prm.anchor + (uint64_t)g * TG_GROUP_BYTES;
 			d.fast = gb + TG_GROUP_BYTES + TG_STREAM_VIEW <= prm.len;
 		}
+#if TGS_ABLATE & 2
+		const uint8_t *p = stream + first + 2040u * (wave & 1023u);
+#else
 		const uint8_t *p = stream + (d.fast ? gb : first);
+#endif
 		d.a0 = (uint32_t)((uintptr_t)p & 15);
 		const uint8_t *base16 = p - d.a0;
 		d.a = *(const uint4 *)(base16 + 16 * lane);
@@ -1002,11 +1031,13 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	};
 
 	auto work = [&](uint32_t g, const tg_group_data &cur) {
+		TGS_MARK(0);	/* since the last mark: the next group's fetch issued */
 		/* bytes other than 0 / 1 anywhere in the group: not for this kernel */
 		const uint32_t orall = cur.a.x | cur.a.y | cur.a.z | cur.a.w | cur.b.x | cur.b.y | cur.b.z | cur.b.w |
 				       cur.c.x | cur.c.y | cur.c.z | cur.c.w;
 		const bool defer_all = !cur.fast || __ballot((orall & 0xfefefefeu) != 0) != 0;
 
+		TGS_MARK(1);	/* the group's bytes are here */
 		/* bytes -> bits -> LDS */
 		{
 			tg_u16_alias *b16 = (tg_u16_alias *)bits;
@@ -1025,6 +1056,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			W1 = __builtin_amdgcn_alignbit(D2, D1, p);
 			W2 = __builtin_amdgcn_alignbit(D3, D2, p);
 		}
+		TGS_MARK(2);	/* bits through LDS, the lane's column */
 #if TG_STREAM_GATHER == 1
 		win[lane] = W0;
 #else
@@ -1032,7 +1064,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			uint32_t *v = win + (lane >> 4) * TG_VER_SLOT + col;
 			v[0] = W0;
 #pragma unroll
-			for (int sft = 1; sft < 8; sft++)
+			for (int sft = 1; sft < ((TGS_ABLATE & 16) ? 1 : 8); sft++)
 				v[sft * TG_VER_STRIDE] = __builtin_amdgcn_alignbit(W1, W0, sft);
 		}
 #endif
@@ -1042,7 +1074,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		 * three-input logic instruction (v_bitop3_b32) whatever the two pattern bits are */
 		uint32_t my = vys, mn = 0xffffffffu, mp = 0xffffffffu;
 #pragma unroll
-		for (int j = 0; j < 38; j += 2) {
+		for (int j = 0; j < ((TGS_ABLATE & 8) ? 2 : 38); j += 2) {
 			const uint32_t t0 = (j == 0) ? W0 : (j < 32) ? __builtin_amdgcn_alignbit(W1, W0, j)
 					  : (j == 32) ? W1 : __builtin_amdgcn_alignbit(W2, W1, j - 32);
 			const int k = j + 1;
@@ -1062,6 +1094,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		const unsigned long long E = __ballot((any & vearly) != 0);
 		const unsigned long long Y = __ballot(my != 0);
 
+		TGS_MARK(3);	/* shifted copies stored, match masks, ballots */
 		/* per slot: first column with a hit -> its match words (LDS crossbar) -> first position, which sequence;
 		 * lanes 0..3 do this for slots 0..3 of the group (the others compute along) */
 		const uint32_t sl = lane & 3;
@@ -1116,7 +1149,9 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		{													\
 			const uint32_t dt = __builtin_amdgcn_readlane(dtype, (K));					\
 			uint32_t mybyte = 0;										\
-			if (dt == TG_BURST_NORM_1)									\
+			if (TGS_ABLATE & 4)											\
+				mybyte = dt;											\
+			else if (dt == TG_BURST_NORM_1)									\
 				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 0>(g_adr[0]);			\
 			else if (dt == TG_BURST_NORM_2)									\
 				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 1>(g_adr[1]);			\
@@ -1125,11 +1160,13 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			((uint8_t *)mo)[(K) * TG_PACKED_WORDS * 4 + obyte] = (uint8_t)mybyte;				\
 		}
 #endif
+		TGS_MARK(4);	/* classification of the four slots */
 		STREAM_SLOT_K(0)
 		STREAM_SLOT_K(1)
 		STREAM_SLOT_K(2)
 		STREAM_SLOT_K(3)
 #undef STREAM_SLOT_K
+		TGS_MARK(5);	/* the four gathers */
 		if (lane < 4) {
 			mo[lane * TG_PACKED_WORDS + TG_PW_META] = meta;
 			mo[80 + lane] = clsword;
@@ -1146,12 +1183,14 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 					defer[TG_DEFER_LIST + pos + __builtin_popcount(dm & ((1u << lane) - 1))] = first + lane;
 			}
 		}
-		front_flush(mo, lane, first, cnt, packed);
-		if (lane < cnt) {
+		if (!(TGS_ABLATE & 1) || prm.nslots == 0xffffffffu)
+			front_flush(mo, lane, first, cnt, packed);
+		if (lane < cnt && (!(TGS_ABLATE & 1) || prm.nslots == 0xffffffffu)) {
 			cls[first + lane] = mo[80 + lane];
 			if (ysum)
 				ysum[first + lane] = (uint16_t)mo[84 + lane];
 		}
+		TGS_MARK(6);	/* staged stores */
 	};
 
 	/* two register sets with fixed roles: the next group is requested before this one is worked on, no copies */
@@ -1171,6 +1210,11 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			break;
 		g = gA;
 	}
+#ifdef TGS_TIMING
+	if (lane == 0)
+		for (int i = 0; i < 8; i++)
+			atomicAdd(&g_tgs_acc[i], tgs_acc[i]);
+#endif
 }
 
 /* ------------------------------------------------------------------------- */
@@ -3127,7 +3171,7 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 {
 	const uint32_t nslots = prm.nslots;
 	uint32_t blocks = ((nslots + 3) / 4 + 3) / 4;	/* a wave per group of four slots */
-	uint32_t cap = 256 * 8;
+	uint32_t cap = 256 * 2 * TG_STREAM_WPE;	/* two rounds of what the 256 CUs hold: one round (persistent waves) is 3-4 % slower, four rounds 5 % */
 	if (const char *e = getenv("TGPU_FRONT_BLOCKS"))
 		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
 	if (blocks > cap)

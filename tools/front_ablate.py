@@ -1,0 +1,22 @@
+"""k_front_stream alone on the bench's batch of 8 channels: mean microseconds over nrep launches (HIP events around the
+kernel).  Used with measurement builds of the library (tools/front_ablate.sh)."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+import osmo_tetra_amd as T
+import bench
+Cn, per = 8, 125000
+streams = [bench.make_mix_stream(T, per, c, mnc=42 + c, cc=1 + c)[0] for c in range(Cn)]
+offs, o = [], 0
+for st in streams:
+    offs.append(o); o += (len(st) + T.STREAM_SLACK + 15) & ~15
+buf = np.zeros(o + 4096, np.uint8)
+for st, f in zip(streams, offs):
+    buf[f:f + len(st)] = st
+eng = T.Engine(0)
+d_base = torch.from_numpy(buf).cuda()
+cap = sum(len(st) // 510 + 32 for st in streams)
+plan = T.Plan(eng, cap, Cn)
+hs = torch.cuda.current_stream().cuda_stream
+r = [T.sync_front_prof_multi(eng, plan, streams, d_base.data_ptr(), offs, 64, 20, hs) for _ in range(3)]
+print(sys.argv[1] if len(sys.argv) > 1 else "", " ".join("front %.1f us fix %.1f us" % (a, b) for a, b in r))
