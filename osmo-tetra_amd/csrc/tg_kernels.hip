@@ -870,7 +870,9 @@ __device__ __forceinline__ uint32_t tsq_and2(uint32_t acc, uint32_t t0, uint32_t
 
 #ifndef TGS_ABLATE
 #define TGS_ABLATE 0	/* measurement builds only (tools/front_ablate.sh): 1 no stores, 2 every group from one address, 4 no
-			 * gathers, 8 no search, 16 no shifted copies -- the kernel's results are wrong with any of them */
+			 * gathers, 8 no search and no classification, 16 no shifted copies, 32 no classification, 64 no atomic for the deferred slots,
+			 * 128 classification kept but the gather always NORM_1's, 256 no classification but the gather's type varies -- the kernel's
+			 * results are wrong with any of them */
 #endif
 #ifdef TGS_TIMING
 /* measurement build: reference-clock ticks (s_memtime, 100 MHz) a wave spends between the marks of a group, summed over
@@ -1095,6 +1097,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		const unsigned long long Y = __ballot(my != 0);
 
 		TGS_MARK(3);	/* shifted copies stored, match masks, ballots */
+#if !(TGS_ABLATE & (8 | 32 | 256))
 		/* per slot: first column with a hit -> its match words (LDS crossbar) -> first position, which sequence;
 		 * lanes 0..3 do this for slots 0..3 of the group (the others compute along) */
 		const uint32_t sl = lane & 3;
@@ -1125,8 +1128,18 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			dtype = rc;
 		if (dfr)
 			dtype = TG_BURST_NONE;
+#endif
+#if TGS_ABLATE & (8 | 32 | 256)
+		/* (measurement builds: every slot "a NORM_1 burst at its place", whatever the search said) */
+		const bool dfr = false;
+		const uint32_t dtype = TG_BURST_NORM_1;
+		const uint32_t clsword = TG_BURST_NORM_1 | (TG_NORM_TRAIN_OFF << 8);
+		const uint32_t meta = (dtype | (TG_NORM_TRAIN_OFF << 16)) ^ ((TGS_ABLATE & (32 | 256)) ? (any & 1u) : 0u);
+		uint32_t ys = TG_YS_NONE;
+#else
 		const uint32_t clsword = dfr ? TG_CLS_DEFER : (rc | (offs << 8));
 		const uint32_t meta = dfr ? 0u : (dtype | (offs << 16));
+#endif
 
 		const uint32_t first = 4u * g;
 		const uint32_t cnt = (prm.nslots - first < 4u) ? prm.nslots - first : 4u;
@@ -1147,7 +1160,9 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 #else
 #define STREAM_SLOT_K(K)												\
 		{													\
-			const uint32_t dt = __builtin_amdgcn_readlane(dtype, (K));					\
+			const uint32_t dt = (TGS_ABLATE & 128) ? (uint32_t)TG_BURST_NORM_1 :					\
+					    (TGS_ABLATE & 256) ? (((g + (K)) & 1) ? (uint32_t)TG_BURST_NORM_1 : (uint32_t)TG_BURST_NORM_2) : \
+					    (uint32_t)__builtin_amdgcn_readlane(dtype, (K));				\
 			uint32_t mybyte = 0;										\
 			if (TGS_ABLATE & 4)											\
 				mybyte = dt;											\
@@ -1176,7 +1191,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			const uint32_t dm = (uint32_t)__ballot(lane < cnt && dfr) & 15u;
 			if (dm) {
 				uint32_t pos = 0;
-				if (lane == 0)
+				if (lane == 0 && !(TGS_ABLATE & 64))
 					pos = atomicAdd(defer, (uint32_t)__builtin_popcount(dm));
 				pos = __builtin_amdgcn_readfirstlane(pos);
 				if (lane < 4 && ((dm >> lane) & 1))
