@@ -33,6 +33,7 @@ The JSON line also carries
 --workload config5 | conv | config2: the other BASELINE configs / the generic trellis (own roofline, cpu_baseline).
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -245,11 +246,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     d_base = torch.from_numpy(buf).cuda()
     cap = sum(len(st) // 510 + 32 for st in streams)
     D = max(2, args.depth)
-    K, R, W = args.steps, max(1, args.windows), max(args.warmup, D)
+    K, R, W = args.steps, max(1, args.windows), max(args.warmup, 6 * D)     # (the first ~20 steps of a run are 4 % slower: clocks, queues filling)
     chans = T.multi_chan_table(streams, offs)         # carry-in codes 0: every cell's code is learnt from SB1 inside the batch
-    plans = [T.Plan(eng, cap, C) for _ in range(D)]
-    recs = [torch.empty(cap * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D)]
-    strm = [torch.cuda.Stream() for _ in range(D)]
+    D2 = 8 if (world == 1 and not args.no_secondary and D < 8) else D       # the deeper pipeline measured beside the headline
+    plans = [T.Plan(eng, cap, C) for _ in range(D2)]
+    recs = [torch.empty(cap * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D2)]
+    strm = [torch.cuda.Stream() for _ in range(D2)]
     gather = world > 1 or args.force_gather
     nccl = args.backend == "nccl"
     state = {"fellback": 0, "ngrid": 0, "ccomm": None, "impl": None}
@@ -276,7 +278,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             strm[j].synchronize()
             dist.gather(w.cpu(), gather_list=list(sink[j].view(world, -1)[:, :nbytes].unbind(0)) if rank == 0 else None, dst=0)
 
-    def run(total, with_gather):
+    def run(total, with_gather, D=D):
         """`total` steps back to back, at most D in flight; returns (delivered bursts per step, completion events)"""
         evs, fl, delivered = [], collections.deque(), []
         for k in range(total):
@@ -301,18 +303,23 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             dist.barrier()
             torch.cuda.synchronize()
 
-    def measure(with_gather, alone=False):
+    def measure(with_gather, alone=False, D=D, W=W):
         """one continuous run of W + R K + D steps (the pipeline stays full before, through and after the timed steps);
         window r = completion of step W - 1 + r K  ->  completion of step W - 1 + (r + 1) K: exactly K classifications,
         K walks, K decodes (and K exchanges) complete inside it.  Plus the contract's form: K steps between two
         synchronisations (ramp-up and drain included)."""
-        run(max(D, K if not alone else D), with_gather)    # allocations, first-use paths, clocks
+        run(max(D, K if not alone else D), with_gather, D)    # allocations, first-use paths, clocks
         if not alone:
             sync_all()
         else:
             torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()          # (a collection of the interpreter's in the middle of the run is a multi-millisecond hole in one window)
         c0, t0 = time.process_time(), time.perf_counter()
-        delivered, evs = run(W + R * K + D, with_gather)
+        try:
+            delivered, evs = run(W + R * K + D, with_gather, D)
+        finally:
+            gc.enable()
         torch.cuda.synchronize()
         cpu_s, wall_s = time.process_time() - c0, time.perf_counter() - t0
         tk = [evs[W - 1].elapsed_time(e) for e in evs[W - 1:]]
@@ -324,7 +331,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         if not alone:
             sync_all()
         t1 = time.perf_counter()
-        run(K, with_gather)
+        run(K, with_gather, D)
         if not alone:
             sync_all()
         else:
@@ -354,6 +361,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             single = measure(False, alone=True)
         sync_all()
     decode_only = measure(False)
+    deeper = measure(False, D=D2, W=max(W, 5 * D2)) if D2 > D else None
     gathered = gather_error = None
     if gather:
         armed = [True]
@@ -552,10 +560,10 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                       "parallelism": "channels sharded over GPUs (%d per GPU), no collective in decoding" % C +
                                      ("; one gather of wire records per step to rank 0, on the step's stream" if gathered else ""),
                       "check": check},
-           "timing": {"method": "one continuous run of warm-up + %d x %d steps + tail with %d steps in flight; ms_per_step = median over "
+           "timing": {"method": "one continuous run of %d warm-up steps + %d x %d steps + tail with %d steps in flight; ms_per_step = median over "
                                 "the %d windows of (completion of step w + K) - (completion of step w) / K from HIP events recorded "
                                 "behind each step's last operation: exactly K classifications, K walks, K decodes complete inside "
-                                "a window; max over ranks per window" % (R, K, D, R),
+                                "a window; max over ranks per window" % (W, R, K, D, R),
                       "windows_ms_per_step": head["windows_ms_per_step"], "window_spread": head["window_spread"],
                       "all_windows_ms_per_step": head["all_windows_ms_per_step"],
                       "sync_bracketed_ms_per_step (K steps between two synchronisations, ramp-up and drain included)": head["sync_bracketed_ms_per_step"],
@@ -573,6 +581,11 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                                 "region; traffic = PMC bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes) and "
                                 "valu_busy_frac from profiles/traffic.json of the same command; every kernel of this path is bound by "
                                 "vector-instruction issue, not by HBM (DESIGN.md section 4)"}}
+    if deeper:
+        out["deeper_pipeline"] = {k_: deeper[k_] for k_ in ("value", "ms_per_step", "windows_ms_per_step", "window_spread", "all_windows_ms_per_step")}
+        out["deeper_pipeline"].update({"steps_in_flight": D2, "note": "the same measurement with %d batches in flight on %d streams (the runtime's 4 hardware queues then hold "
+                                        "two batches each and none runs dry while the host collects and relaunches): a higher rate, but batches "
+                                        "complete in clumps and the 20-step windows alias with them (spread), so the headline stays at %d in flight" % (D2, D2, D)})
     if e2e:
         out["end_to_end"] = e2e
     if gathered or gather_error:
