@@ -326,6 +326,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         for i in range(1, len(tk)):               # (steps run on D streams: completion times are made monotone)
             tk[i] = max(tk[i], tk[i - 1])
         win = [(tk[(r + 1) * K] - tk[r * K]) / K for r in range(R)]
+        if os.environ.get("BENCH_STEP_TIMES"):
+            print("step completion deltas (ms), depth %d:" % D, [round(tk[i + 1] - tk[i], 3) for i in range(min(48, len(tk) - 1))], file=sys.stderr)
         per_step = delivered[W]
         assert all(x == per_step for x in delivered), "the same recording gave different numbers of bursts"
         if not alone:
@@ -960,17 +962,30 @@ def main():
     if args.backend == "gloo":
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
-    pinned = None
-    if world > 1 and hasattr(os, "sched_setaffinity"):
-        # every rank keeps to its own share of the cores (one host thread per rank does the launching)
+    pinned = numa = None
+    if hasattr(os, "sched_setaffinity"):
+        # the rank's threads -- and with them its pinned buffers (first touch) -- go to the CPUs of the NUMA node its GPU
+        # hangs off (on a two-socket box the far socket costs a third of the host-to-device rate and slows every doorbell);
+        # ranks whose GPUs share a node split that node's CPUs among them (one host thread per rank does the launching)
         try:
-            cores = sorted(os.sched_getaffinity(0))
-            share = max(1, len(cores) // world)
-            mine = cores[local * share:(local + 1) * share] or cores
-            os.sched_setaffinity(0, mine)
-            pinned = len(mine)
-        except OSError:
-            pass
+            allowed = set(os.sched_getaffinity(0))
+            locs = [T.device_host_locality(i % torch.cuda.device_count()) for i in range(world)]
+            _, node, cpus = locs[local if args.backend != "gloo" else 0]
+            mine = sorted(allowed & set(cpus)) or sorted(allowed)
+            if world > 1:
+                peers = [i for i in range(world) if locs[i if args.backend != "gloo" else 0][1] == node] if cpus else list(range(world))
+                share = max(1, len(mine) // len(peers))
+                k = peers.index(int(os.environ.get("LOCAL_RANK", "0")))
+                mine = mine[k * share:(k + 1) * share] or mine
+                pinned = len(mine)
+            for tid in os.listdir("/proc/self/task"):       # the runtime's helper threads exist already
+                try:
+                    os.sched_setaffinity(int(tid), mine)
+                except OSError:
+                    pass
+            numa = {"gpu_numa_node": node, "cpus": len(mine)}
+        except Exception as ex:      # pragma: no cover  (no sysfs, an exotic container: the run goes on unpinned)
+            numa = {"error": repr(ex)}
     if world > 1 or args.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
@@ -991,6 +1006,7 @@ def main():
         out = bench_mix(args, T, torch, dist, rank, world, local)
         if rank == 0:
             out["config"]["host_cores_per_rank"] = pinned if pinned else host_threads_default()
+            out["config"]["host_placement"] = numa
         if rank == 0 and world == 1:
             if not args.no_cpu_baseline:
                 # channel 0 of rank 0 as the timed run had it (the generator is deterministic)

@@ -129,6 +129,12 @@ const char *tgpu_strerror(int err);
 struct tgpu_engine;
 int tgpu_engine_create(struct tgpu_engine **out, int device);
 void tgpu_engine_destroy(struct tgpu_engine *eng);
+/* where the GPU sits in the host: its PCI address ("0000:bb:dd.f"), the NUMA node it hangs off (-1 = unknown) and that
+ * node's CPUs as the kernel prints them ("64-127,192-255"; "" = unknown), from hipDeviceGetPCIBusId() and
+ * /sys/bus/pci/devices/<address>/{numa_node,local_cpulist}.  A process that feeds the GPU from host buffers wants its
+ * threads -- and with them its pinned buffers -- on these CPUs: on a two-socket box the far socket costs a third of the
+ * host-to-device rate.  The library never changes anybody's affinity itself.  bdf >= 16 bytes, cpulist: n bytes. */
+int tgpu_device_host_locality(int device, char bdf[16], int *numa_node, char *cpulist, size_t n);
 
 /* ------------------------------------------------------------------------- */
 /* 1. plan API                                                                */

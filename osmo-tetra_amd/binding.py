@@ -108,6 +108,7 @@ def lib():
     L.tgpu_strerror.restype = C.c_char_p
     L.tgpu_strerror.argtypes = [C.c_int]
     L.tgpu_engine_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.tgpu_device_host_locality.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
     L.tgpu_engine_destroy.argtypes = [C.c_void_p]
     L.tgpu_plan_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.tgpu_plan_destroy.argtypes = [C.c_void_p]
@@ -807,6 +808,20 @@ def multi_chan_table(streams, d_offs, codes=None):
         ch[c].len = len(x)
         ch[c].scramb_init = int(codes[c]) if codes is not None else 0
     return xs, ch
+
+
+def device_host_locality(device=0):
+    """tgpu_device_host_locality: (PCI address, NUMA node or -1, sorted list of that node's CPUs or [])"""
+    bdf, cl, node = C.create_string_buffer(16), C.create_string_buffer(512), C.c_int(-1)
+    _chk(lib().tgpu_device_host_locality(device, bdf, C.byref(node), cl, 512), "tgpu_device_host_locality")
+    cpus = []
+    for part in cl.value.decode().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return bdf.value.decode(), int(node.value), sorted(set(cpus))
 
 
 def sync_front_prof_multi(engine, plan, streams, d_base_ptr, d_offs, chunk=64, nrep=10, hip_stream=0):

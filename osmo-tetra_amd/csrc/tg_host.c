@@ -15,6 +15,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -143,6 +144,48 @@ int tgpu_engine_create(struct tgpu_engine **out, int device)
 void tgpu_engine_destroy(struct tgpu_engine *eng)
 {
 	free(eng);
+}
+
+int tgpu_device_host_locality(int device, char bdf[16], int *numa_node, char *cpulist, size_t n)
+{
+	char id[32] = "", path[96];
+	int cnt = 0;
+	if (!bdf)
+		return TGPU_EINVAL;
+	if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt)
+		return TGPU_ENODEV;
+	hipError_t e = hipDeviceGetPCIBusId(id, (int)sizeof(id), device);
+	if (e != hipSuccess)
+		return (int)e;
+	for (char *q = id; *q; q++)
+		if (*q >= 'A' && *q <= 'F')
+			*q = (char)(*q - 'A' + 'a');	/* sysfs spells the address in lower case */
+	snprintf(bdf, 16, "%s", id);
+	if (numa_node) {
+		*numa_node = -1;
+		snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", id);
+		FILE *f = fopen(path, "r");
+		if (f) {
+			if (fscanf(f, "%d", numa_node) != 1)
+				*numa_node = -1;
+			fclose(f);
+		}
+	}
+	if (cpulist && n) {
+		cpulist[0] = 0;
+		snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", id);
+		FILE *f = fopen(path, "r");
+		if (f) {
+			if (fgets(cpulist, (int)n, f)) {
+				size_t l = strlen(cpulist);
+				while (l && (cpulist[l - 1] == '\n' || cpulist[l - 1] == ' '))
+					cpulist[--l] = 0;
+			} else
+				cpulist[0] = 0;
+			fclose(f);
+		}
+	}
+	return TGPU_OK;
 }
 
 #define UP_ALIGN 256u

@@ -2405,3 +2405,15 @@ def test_gsmtap_messages_of_a_batch_on_device(T, eng):
             assert lens[i, k] == 0
     assert nmsg > 1200 and nbnch >= 3, (nmsg, nbnch)
     plan.close()
+
+
+@pytest.mark.gpu
+def test_device_host_locality(T):
+    """tgpu_device_host_locality(): the GPU's PCI address as sysfs spells it, a NUMA node (or -1) and that node's CPUs"""
+    import os
+    import re
+    bdf, node, cpus = T.device_host_locality(0)
+    assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-9a-f]", bdf), bdf
+    assert node >= -1 and all(c >= 0 for c in cpus) and cpus == sorted(set(cpus))
+    if os.path.exists("/sys/bus/pci/devices/%s/numa_node" % bdf):
+        assert node == int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
