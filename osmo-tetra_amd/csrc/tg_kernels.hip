@@ -1861,7 +1861,7 @@ void k_clean(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t
  *          packed bits, 32-bit correlation metrics (tg_svit_*), history in VGPRs as in mode 1.
  */
 template <int KIND, int HMODE>
-__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (HMODE == 2) ? (KIND == TG_KIND_432 ? 2 : 4) : (KIND == TG_KIND_432 ? 3 : 4))
+__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (HMODE == 2) ? (KIND == TG_KIND_SB1 ? 4 : 2) : (KIND == TG_KIND_432 ? 3 : 4))
 void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
@@ -1956,10 +1956,32 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		__syncthreads();
 		auto tab = [&](uint32_t idx) { return s_bm[idx]; };
 		const uint32_t *sw = softarea + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + (which ? TG_SOFT_AREA2 / 4 : 0);
+		/* the half-slot blocks: the wave's 64 soft areas (224 B each) come in ONCE, as 14 direct-to-LDS loads of 1 KB in
+		 * which 14 neighbouring lanes cover one area (whole lines, each fetched one time), and the trellis reads its
+		 * values from LDS.  Walking the areas 24 bytes per 16 steps per lane touched every line five times over ~20 us
+		 * with a working set of the L2's size: 738 MB of traffic for 400 MB.  14 KB per wave: two waves per SIMD (what
+		 * the SCH/F kernel runs with as well; the trellis has the instruction-level parallelism for it). */
+		constexpr bool STAGED = (KIND == TG_KIND_216);
+		constexpr int AREA_DW = (TG_SOFT_LEADIN_BYTES + TG_SOFT_BLOCK_BYTES * NBLK) / 4;	/* 56 */
+		__shared__ __attribute__((aligned(16))) uint32_t s_soft[STAGED ? 64 * AREA_DW : 4];
+		if (STAGED) {
+			static_assert(!STAGED || AREA_DW % 4 == 0, "whole 16-byte pieces");
+			constexpr int PIECES = AREA_DW / 4;	/* 14 */
+			const uint32_t myoff = (uint32_t)(sw - softarea);
+#pragma unroll
+			for (int k = 0; k < PIECES; k++) {
+				const uint32_t i = lane + 64u * k, r = i / PIECES, pc = i - PIECES * r;
+				const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * r), (int)myoff);
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(softarea + (size_t)off + 4 * pc),
+								 (__attribute__((address_space(3))) void *)(s_soft + 256 * k), 16, 0, 0);
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		auto rd = [&](int i) { return STAGED ? s_soft[lane * AREA_DW + i] : sw[i]; };
 		tg_pvit_state sv;
 		tg_pvit_init(sv);
 		{
-			const uint32_t lw[2] = { sw[0], sw[1] };
+			const uint32_t lw[2] = { rd(0), rd(1) };
 			tg_pvit_leadin(sv, lw, (mw[0] >> 24) & 0x3f, tab);
 		}
 		/* software pipeline: the values (and mask word) of iteration g + 2 are loaded from global memory during
@@ -1968,8 +1990,8 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		uint32_t cw[6], nx[6], m = mw[0], nm = mw[NW > 1 ? 1 : 0];
 #pragma unroll
 		for (int q = 0; q < 6; q++) {
-			cw[q] = sw[2 + q];
-			nx[q] = sw[2 + (NW > 1 ? 6 : 0) + q];
+			cw[q] = rd(2 + q);
+			nx[q] = rd(2 + (NW > 1 ? 6 : 0) + q);
 		}
 		uint32_t ta[12], tb[12];
 		tg_psoft_fetch<0, 12>(cw, m & 0xfff, tab, ta);
@@ -1987,7 +2009,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 				uint32_t nn[6];
 #pragma unroll
 				for (int q = 0; q < 6; q++)
-					nn[q] = sw[2 + 6 * g2 + q];
+					nn[q] = rd(2 + 6 * g2 + q);
 				const uint32_t nnm = mw[g2];
 				tg_psoft_fetch<0, 12>(cw + 3, (m >> 12) & 0xfff, tab, tb);
 				__builtin_amdgcn_sched_barrier(0);
