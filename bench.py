@@ -278,20 +278,21 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             strm[j].synchronize()
             dist.gather(w.cpu(), gather_list=list(sink[j].view(world, -1)[:, :nbytes].unbind(0)) if rank == 0 else None, dst=0)
 
-    def run(total, with_gather, D=D):
+    def run(total, with_gather, D=D, S=None):
         """`total` steps back to back, at most D in flight; returns (delivered bursts per step, completion events)"""
         evs, fl, delivered = [], collections.deque(), []
+        S = S or D           # (S < D: plan j runs on stream j % S -- a stream then holds its next batch before the host has collected the last)
         for k in range(total):
             j = k % D
             if len(fl) == D:
                 delivered.append(finish(fl.popleft()))
             plans[j].set_wire(wires[j].data_ptr() if with_gather else 0)
             fl.append(T.MultiSyncDev(eng, plans[j], None, d_base.data_ptr(), None, recs[j].data_ptr(), 64,
-                                     strm[j].cuda_stream, chans=chans))
+                                     strm[j % S].cuda_stream, chans=chans))
             if with_gather:
                 exchange(j)
             ev = torch.cuda.Event(enable_timing=True)
-            ev.record(strm[j])
+            ev.record(strm[j % S])
             evs.append(ev)
         while fl:
             delivered.append(finish(fl.popleft()))
@@ -303,12 +304,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             dist.barrier()
             torch.cuda.synchronize()
 
-    def measure(with_gather, alone=False, D=D, W=W):
+    def measure(with_gather, alone=False, D=D, W=W, S=None):
         """one continuous run of W + R K + D steps (the pipeline stays full before, through and after the timed steps);
         window r = completion of step W - 1 + r K  ->  completion of step W - 1 + (r + 1) K: exactly K classifications,
         K walks, K decodes (and K exchanges) complete inside it.  Plus the contract's form: K steps between two
         synchronisations (ramp-up and drain included)."""
-        run(max(D, K if not alone else D), with_gather, D)    # allocations, first-use paths, clocks
+        run(max(D, K if not alone else D), with_gather, D, S)    # allocations, first-use paths, clocks
         if not alone:
             sync_all()
         else:
@@ -317,7 +318,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         gc.disable()          # (a collection of the interpreter's in the middle of the run is a multi-millisecond hole in one window)
         c0, t0 = time.process_time(), time.perf_counter()
         try:
-            delivered, evs = run(W + R * K + D, with_gather, D)
+            delivered, evs = run(W + R * K + D, with_gather, D, S)
         finally:
             gc.enable()
         torch.cuda.synchronize()
@@ -333,7 +334,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         if not alone:
             sync_all()
         t1 = time.perf_counter()
-        run(K, with_gather, D)
+        run(K, with_gather, D, S)
         if not alone:
             sync_all()
         else:
@@ -363,6 +364,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             single = measure(False, alone=True)
         sync_all()
     decode_only = measure(False)
+    # (8 plans on 4 streams -- S=4 -- give the same rate and the same 8-step completion pattern as 8 streams: the pattern is the
+    # GPU's interleaving of four concurrent batches, and 20-step windows cut it at two different phases)
     deeper = measure(False, D=D2, W=max(W, 5 * D2)) if D2 > D else None
     gathered = gather_error = None
     if gather:
