@@ -854,6 +854,9 @@ struct tg_group_data {
 #define TG_STREAM_WPE 6	/* waves per SIMD (80 VGPRs: 6 fit).  With the grid at two rounds of resident workgroups (launch_stream_front):
 			 * 4 -> 161-168 us per 1 M slots, 5 -> 156-161, 6 -> 155-159, 8 (64 VGPRs) -> 195-200 (tools/front_grid.sh) */
 #endif
+#ifndef TG_STREAM_CLS
+#define TG_STREAM_CLS 2	/* per-slot outcome of the search: 1 = ballots + LDS crossbar, lanes 0..3 (round 2), 2 = reductions inside the slot's 16-lane row */
+#endif
 #ifndef TG_STREAM_GATHER
 #define TG_STREAM_GATHER 2	/* 1: ballots + v_writelane (round 2), 2: byte owners on shifted window copies (front_gather_bytes) */
 #endif
@@ -1092,12 +1095,59 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 #undef TSQ_STEP
 		}
 		const uint32_t any = my | mn | mp;
+#if TG_STREAM_CLS == 1
 		const unsigned long long A = __ballot((any & vmain) != 0);
 		const unsigned long long E = __ballot((any & vearly) != 0);
 		const unsigned long long Y = __ballot(my != 0);
+#endif
 
 		TGS_MARK(3);	/* shifted copies stored, match masks, ballots */
-#if !(TGS_ABLATE & (8 | 32 | 256))
+#if !(TGS_ABLATE & (8 | 32 | 256)) && TG_STREAM_CLS == 2
+		/* per slot (= 16-lane row): the first hit and the SYNC summary by reductions inside the row -- every lane makes a
+		 * key of its own first hit ((position << 2 | type) in the high half, first y position in the low half: one
+		 * v_pk_min_u16 reduces both) and a count word (hit below 21 in the high half, number of y hits in the low), four
+		 * rotate-and-combine steps (DPP row_ror 8 4 2 1) leave the row's result in all of its lanes.  Vector
+		 * instructions only: the form with ballots, per-lane shifts of them and the LDS crossbar cost 24 us per 1 M
+		 * slots in round trips between the vector unit, scalar registers and LDS (TGS_ABLATE), this one */
+		typedef unsigned short cls_us2 __attribute__((ext_vector_type(2)));
+		const uint32_t hm = any & vmain;
+		const uint32_t hb = (uint32_t)__builtin_ctz(hm | 0x80000000u);
+		const uint32_t ht = ((my >> hb) & 1) ? (uint32_t)TG_BURST_SYNC : ((mn >> hb) & 1) ? (uint32_t)TG_BURST_NORM_1 : (uint32_t)TG_BURST_NORM_2;
+		const uint32_t hkey = hm ? (((32u * col + hb) << 2) | ht) : 0xffffu;
+		const uint32_t ykey = my ? (32u * col + (uint32_t)__builtin_ctz(my | 0x80000000u)) : 0xffffu;
+		uint32_t rmin = (hkey << 16) | ykey;
+		uint32_t rsum = (((any & vearly) != 0) ? 0x10000u : 0u) + (uint32_t)__builtin_popcount(my);	/* (<= 510 y hits: the halves do not meet) */
+#define ROW_STEP(CTRL)													\
+		{													\
+			const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)rmin, (int)rmin, (CTRL), 0xf, 0xf, false);	\
+			const uint32_t u_ = (uint32_t)__builtin_amdgcn_update_dpp((int)rsum, (int)rsum, (CTRL), 0xf, 0xf, false);	\
+			const cls_us2 m_ = __builtin_elementwise_min(__builtin_bit_cast(cls_us2, rmin), __builtin_bit_cast(cls_us2, t_));	\
+			rmin = __builtin_bit_cast(uint32_t, m_);							\
+			rsum += u_;											\
+		}
+		ROW_STEP(0x128)	/* row_ror:8 */
+		ROW_STEP(0x124)
+		ROW_STEP(0x122)
+		ROW_STEP(0x121)
+#undef ROW_STEP
+		const uint32_t k16 = rmin >> 16, yfirst = rmin & 0xffffu, ycnt = rsum & 0xffffu;
+		const uint32_t offs = k16 >> 2, rc = k16 & 3u;
+		uint32_t ys = ycnt ? (yfirst | (ycnt > 1 ? (uint32_t)TG_YS_MULTI : 0u)) : (uint32_t)TG_YS_NONE;
+		/* a sequence below offset 21 is accepted or not by the reference's skewed look-ahead window: the exact pass
+		 * evaluates that rule (rare: a payload coincidence, about ten slots in a million) */
+		const bool dfr = defer_all || k16 == 0xffffu || (rsum >> 16) != 0;
+		uint32_t dtype = TG_BURST_NONE;
+		if (rc == TG_BURST_SYNC ? offs == TG_SYNC_TRAIN_OFF : offs == TG_NORM_TRAIN_OFF)
+			dtype = rc;
+		if (dfr)
+			dtype = TG_BURST_NONE;
+#define CLS_OWNER      ((lane & 15u) == 0u)	/* the lane that writes the slot's words */
+#define CLS_SLOT       (lane >> 4)
+#define CLS_LANE_OF(K) (16 * (K))
+#elif !(TGS_ABLATE & (8 | 32 | 256))
+#define CLS_OWNER      (lane < 4u)
+#define CLS_SLOT       lane
+#define CLS_LANE_OF(K) (K)
 		/* per slot: first column with a hit -> its match words (LDS crossbar) -> first position, which sequence;
 		 * lanes 0..3 do this for slots 0..3 of the group (the others compute along) */
 		const uint32_t sl = lane & 3;
@@ -1130,6 +1180,9 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			dtype = TG_BURST_NONE;
 #endif
 #if TGS_ABLATE & (8 | 32 | 256)
+#define CLS_OWNER      (lane < 4u)
+#define CLS_SLOT       lane
+#define CLS_LANE_OF(K) (K)
 		/* (measurement builds: every slot "a NORM_1 burst at its place", whatever the search said) */
 		const bool dfr = false;
 		const uint32_t dtype = TG_BURST_NORM_1;
@@ -1146,7 +1199,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 #if TG_STREAM_GATHER == 1
 #define STREAM_SLOT_K(K)												\
 		{													\
-			const uint32_t dt = __builtin_amdgcn_readlane(dtype, (K));					\
+			const uint32_t dt = __builtin_amdgcn_readlane(dtype, CLS_LANE_OF(K));				\
 			uint32_t myword = 0;										\
 			if (dt == TG_BURST_NORM_1)									\
 				myword = front_gather_bits<64 * (K)>(lds0, g_adr[0], g_msk[0]);				\
@@ -1162,7 +1215,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		{													\
 			const uint32_t dt = (TGS_ABLATE & 128) ? (uint32_t)TG_BURST_NORM_1 :					\
 					    (TGS_ABLATE & 256) ? (((g + (K)) & 1) ? (uint32_t)TG_BURST_NORM_1 : (uint32_t)TG_BURST_NORM_2) : \
-					    (uint32_t)__builtin_amdgcn_readlane(dtype, (K));				\
+					    (uint32_t)__builtin_amdgcn_readlane(dtype, CLS_LANE_OF(K));		\
 			uint32_t mybyte = 0;										\
 			if (TGS_ABLATE & 4)											\
 				mybyte = dt;											\
@@ -1182,22 +1235,26 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		STREAM_SLOT_K(3)
 #undef STREAM_SLOT_K
 		TGS_MARK(5);	/* the four gathers */
-		if (lane < 4) {
-			mo[lane * TG_PACKED_WORDS + TG_PW_META] = meta;
-			mo[80 + lane] = clsword;
-			mo[84 + lane] = ys;
+		if (CLS_OWNER) {
+			mo[CLS_SLOT * TG_PACKED_WORDS + TG_PW_META] = meta;
+			mo[80 + CLS_SLOT] = clsword;
+			mo[84 + CLS_SLOT] = ys;
 		}
 		{	/* slots this pass could not settle: onto the list of k_front_stream_fix (one atomic per group that has any) */
-			const uint32_t dm = (uint32_t)__ballot(lane < cnt && dfr) & 15u;
+			const bool mine = CLS_OWNER && CLS_SLOT < cnt && dfr;
+			const unsigned long long dm = __ballot(mine);
 			if (dm) {
 				uint32_t pos = 0;
 				if (lane == 0 && !(TGS_ABLATE & 64))
-					pos = atomicAdd(defer, (uint32_t)__builtin_popcount(dm));
+					pos = atomicAdd(defer, (uint32_t)__builtin_popcountll(dm));
 				pos = __builtin_amdgcn_readfirstlane(pos);
-				if (lane < 4 && ((dm >> lane) & 1))
-					defer[TG_DEFER_LIST + pos + __builtin_popcount(dm & ((1u << lane) - 1))] = first + lane;
+				if (mine)
+					defer[TG_DEFER_LIST + pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] = first + CLS_SLOT;
 			}
 		}
+#undef CLS_OWNER
+#undef CLS_SLOT
+#undef CLS_LANE_OF
 		if (!(TGS_ABLATE & 1) || prm.nslots == 0xffffffffu)
 			front_flush(mo, lane, first, cnt, packed);
 		if (lane < cnt && (!(TGS_ABLATE & 1) || prm.nslots == 0xffffffffu)) {
