@@ -49,15 +49,16 @@ def main():
                 tj[k] = c2_t[k]
             if k in c2_b:
                 tj.setdefault("valu_busy", {})[k] = c2_b[k]
-        tj["_provenance"] = ("round 2: the same recipe on `python bench.py --workload config2 --steps 12 --warmup 6 --no-cpu-baseline` "
-                             "(profiles/r02_config2_rocprofv3.md); bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+        tj["_provenance"] = ("round 3: the same recipe on `python bench.py --workload config2 ...` (tools/prof_run.sh %s config2 1; "
+                             "profiles/r03_config2_rocprofv3.md); bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
+                             % os.path.basename(sys.argv[2]).replace("prof_", ""))
     if len(sys.argv) > 3:
         c5_t, c5_b = derive(read(sys.argv[3]))
         keep = ("k_front_soft", "k_vit_soft", "k_float_to_bits")
         tj["config5"] = {k: c5_t[k] for k in c5_t if k.startswith(keep)}
         tj["config5_valu_busy"] = {k: c5_b[k] for k in c5_b if k.startswith(keep)}
-        tj["_config5_provenance"] = ("round 2: the same recipe on `python bench.py --workload config5 --steps 12 --warmup 6 "
-                                     "--no-cpu-baseline` (profiles/r02_config5_rocprofv3.md)")
+        tj["_config5_provenance"] = ("round 3: the same recipe on `python bench.py --workload config5 ...` (tools/prof_run.sh %s config5 1; "
+                                     "profiles/r03_config5_rocprofv3.md)" % os.path.basename(sys.argv[3]).replace("prof_", ""))
     json.dump(tj, open(path, "w"), indent=1)
     print(json.dumps({k: tj[k] for k in ("mix", "mix_valu_busy")}, indent=1))
 
