@@ -603,6 +603,26 @@ int tgpu_conv_create(struct tgpu_engine *eng, int punct, int mother_rate, uint32
 int tgpu_conv_execute(struct tgpu_conv *cv, const void *d_type3, uint64_t nblocks, void *d_type2, void *hip_stream);
 void tgpu_conv_destroy(struct tgpu_conv *cv);
 
+/*
+ * The lower MAC's intermediate bit strings of a batch of blocks of one type, one byte per bit, as the reference's DEBUGP
+ * lines show them (lower_mac/tetra_lower_mac.c:175 type5, :188 type4, :246 type3, :251 type3dp, :254 type2) -- the steps
+ * the product kernels fold into a mask, a gather order and a trellis on code words, here one after the other on the
+ * device (csrc/tg_stages.c): for looking inside a block, and as a second formulation the tests hold the fused path
+ * against.  type: TPSAP_T_SB1 / _SB2 / _NDB / _SCH_HU / _SCH_F (K = 120 / 216 / 216 / 168 / 432 received bits, the 2/3
+ * puncturer on the rate-1/4 code) or TPSAP_T_BBK (30 bits: descrambled, the first 14 kept, :268-274).
+ *   d_type5 : nblocks x K received bytes (0 = bit 0, anything else = bit 1), d_codes: a scrambling code per block (SB1
+ *             ignores it: the fixed code 3, tetra_scramb.h:14)
+ *   d_type4, d_type3: nblocks x K;  d_type3dp: nblocks x mother_len (0xff = punctured away);  d_type2: nblocks x
+ *   type2_len decoded bits;  d_crc (optional): crc16_ccitt_bits() over the first type1_len + 16 of them, 0x1d0f = good.
+ *   BBK: d_type3 / d_type3dp / d_crc are not written.  Lengths: tgpu_stages_lengths().  Launches only.
+ */
+struct tgpu_stages;
+int tgpu_stages_create(struct tgpu_engine *eng, enum tp_sap_data_type type, struct tgpu_stages **out);
+int tgpu_stages_lengths(const struct tgpu_stages *st, uint32_t *type345_len, uint32_t *mother_len, uint32_t *type2_len, uint32_t *type1_len);
+int tgpu_stages_execute(struct tgpu_stages *st, const uint8_t *d_type5, const uint32_t *d_codes, uint64_t nblocks, uint8_t *d_type4,
+			uint8_t *d_type3, uint8_t *d_type3dp, uint8_t *d_type2, uint16_t *d_crc, void *hip_stream);
+void tgpu_stages_destroy(struct tgpu_stages *st);
+
 /* the reference's puncturing entry points on host buffers, same names, arguments and -EINVAL behaviour
  * (lower_mac/tetra_conv_enc.c:201-248; 'pu' is enum tetra_rcpc_puncturer) */
 int get_punctured_rate(int pu, uint8_t *in, int len, uint8_t *out);

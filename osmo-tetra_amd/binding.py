@@ -108,6 +108,11 @@ def lib():
     L.tgpu_strerror.restype = C.c_char_p
     L.tgpu_strerror.argtypes = [C.c_int]
     L.tgpu_engine_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.tgpu_stages_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.tgpu_stages_lengths.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
+    L.tgpu_stages_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
+    L.tgpu_stages_destroy.argtypes = [C.c_void_p]
+    L.tgpu_stages_destroy.restype = None
     L.tgpu_device_host_locality.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
     L.tgpu_engine_destroy.argtypes = [C.c_void_p]
     L.tgpu_plan_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -808,6 +813,33 @@ def multi_chan_table(streams, d_offs, codes=None):
         ch[c].len = len(x)
         ch[c].scramb_init = int(codes[c]) if codes is not None else 0
     return xs, ch
+
+
+class Stages:
+    """tgpu_stages_*: the lower MAC's steps one by one for a batch of blocks of one tp_sap_data_type (device pointers)"""
+
+    def __init__(self, engine, blk_type):
+        self._h = C.c_void_p()
+        _chk(lib().tgpu_stages_create(engine._h, int(blk_type), C.byref(self._h)), "tgpu_stages_create")
+        v = [C.c_uint32() for _ in range(4)]
+        _chk(lib().tgpu_stages_lengths(self._h, *[C.byref(x) for x in v]), "tgpu_stages_lengths")
+        self.K, self.mother_len, self.type2_len, self.type1_len = [int(x.value) for x in v]
+
+    def execute(self, d_type5, d_codes, nblocks, d_type4, d_type3, d_type3dp, d_type2, d_crc=0, hip_stream=0):
+        _chk(lib().tgpu_stages_execute(self._h, C.c_void_p(d_type5), C.c_void_p(d_codes), nblocks, C.c_void_p(d_type4),
+                                       C.c_void_p(d_type3), C.c_void_p(d_type3dp), C.c_void_p(d_type2), C.c_void_p(d_crc),
+                                       C.c_void_p(hip_stream)), "tgpu_stages_execute")
+
+    def close(self):
+        if self._h:
+            lib().tgpu_stages_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_host_locality(device=0):

@@ -123,6 +123,10 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 typedef struct { uint16_t hn; uint32_t sn, tn, fn, mn; } tg_tdma_time_dev;
 int tgk_gsmtap(const uint8_t *d_rec, const void *d_times, const uint8_t *d_traffic, uint32_t nslots, uint8_t *d_msgs,
 	       uint8_t *d_lens, void *stream);
+int tgk_stages(const uint8_t *d_type5, const uint32_t *d_codes, uint32_t fixed_code, unsigned long long nblocks, uint32_t K,
+	       uint32_t a, uint32_t mother_len, uint8_t *d_type4, uint8_t *d_type3, uint8_t *d_type3dp, void *stream);
+int tgk_stages_crc(const uint8_t *d_type2, unsigned long long nblocks, uint32_t type2_len, uint32_t n, uint16_t *d_crc,
+		   void *stream);
 
 /* optional RM(30,14) decoder (tg_rm.c): coset-leader table (65536 words, built on first use) and the generator's
  * parity rows; tgk_rm_enable() uploads both for the kernels (flag TGK_F_RM of tgk_vit / tgk_bbk_blocks) */

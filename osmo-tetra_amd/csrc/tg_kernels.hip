@@ -11,6 +11,11 @@
  *   k_masks          : scrambling sequence -> masks in code-word layout   (row X)
  *   k_grid_*         : stream mode: per-slot arrays and item lists from classification words + bitmap
  *   k_conv<CODE,NCH> : generic trellis: any RCPC puncturer on either mother code
+ *   k_burst<SB1_PASS>: small batches: one workgroup per burst, butterflies across a 16-lane DPP row
+ *   k_walk           : the burst synchroniser's walk of every channel on the device (tg_walk_core.h; row S)
+ *   k_cls_plain2, k_masks2, k_lb_scan, k_lists2 : device-walk batches: plain bitmap, SYNC list, code look-back, item lists
+ *   k_reorder, k_gsmtap : ACELP re-ordering with the caller's tables, GSMTAP messages of a batch
+ *   k_stages(_crc)   : the chain's intermediate bit strings step by step (the reference's DEBUGP lines; tg_stages.c)
  *
  * No MFMA anywhere: there is no dense contraction on this path.  The trellis kernels are VALU-issue bound
  * packed-u16 integer work (one lane per trellis); the front kernels are byte gathers, part HBM, part issue bound
@@ -4121,6 +4126,84 @@ extern "C" int tgk_gsmtap(const uint8_t *d_rec, const void *d_times, const uint8
 		return 0;
 	hipLaunchKernelGGL(k_gsmtap, dim3((3 * nslots + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_rec,
 			   (const tg_tdma_time_dev *)d_times, d_traffic, nslots, d_msgs, d_lens);
+	return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_stages: the lower MAC's steps one by one (the reference's DEBUGP lines)   */
+/* ------------------------------------------------------------------------- */
+/*
+ * What the product kernels fold into one gather table and a trellis, as the separate steps of
+ * lower_mac/tetra_lower_mac.c:175-254 -- for looking inside a block, and as a second formulation the tests hold the fused
+ * kernels against.  One workgroup per block, a thread per bit, one byte per bit:
+ *   type4[i]   = type5[i] ^ seq(code)[i]                 (tetra_scramb_bits, :178-186; seq in its linear form)
+ *   type3[i]   = type4[(a (i + 1)) mod K]                (block_deinterleave, :245)
+ *   type3dp    = 0xff everywhere, then type3[j] at position 8 (j / 3) + {0, 1, 4}[j mod 3]
+ *                                                        (tetra_rcpc_depunct with the 2/3 puncturer, :249-250)
+ * type2 is the generic trellis' (tgpu_conv_execute on type3), the CRC k_stages_crc's.  a == 0 (BBK): type4 only.
+ */
+__global__ __launch_bounds__(256)
+void k_stages(const uint8_t *__restrict__ type5, const uint32_t *__restrict__ codes, uint32_t fixed_code, uint32_t K, uint32_t a,
+	      uint32_t mother_len, uint8_t *__restrict__ type4, uint8_t *__restrict__ type3, uint8_t *__restrict__ type3dp)
+{
+	__shared__ uint8_t s4[432];
+	const size_t blk = blockIdx.x;
+	const uint32_t code = codes ? codes[blk] : fixed_code;
+	for (uint32_t i = threadIdx.x; i < K; i += 256) {
+		const uint8_t b = (uint8_t)((type5[blk * K + i] != 0) ^ (__popc(code & c_tab.lfsr_lin[i]) & 1));
+		s4[i] = b;
+		type4[blk * K + i] = b;
+	}
+	if (!a)
+		return;
+	for (uint32_t i = threadIdx.x; i < mother_len; i += 256)
+		type3dp[blk * mother_len + i] = 0xff;
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < K; i += 256) {
+		const uint8_t b = s4[(a * (i + 1)) % K];
+		type3[blk * K + i] = b;
+		const uint32_t r = i % 3;
+		type3dp[blk * mother_len + 8 * (i / 3) + (r == 2 ? 4 : r)] = b;
+	}
+}
+
+/* CRC-16 of a block's first n bits, bit by bit (x^16 + x^12 + x^5 + 1, register preset to ones, no final complement:
+ * crc16_ccitt_bits() of lower_mac/crc_simple.c; a good block leaves 0x1d0f, crc_simple.h), a thread per block */
+__global__ __launch_bounds__(256)
+void k_stages_crc(const uint8_t *__restrict__ type2, unsigned long long nblocks, uint32_t type2_len, uint32_t n, uint16_t *__restrict__ crc)
+{
+	const unsigned long long blk = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+	if (blk >= nblocks)
+		return;
+	uint32_t reg = 0xffff;
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t fb = ((reg >> 15) ^ type2[blk * type2_len + i]) & 1u;
+		reg = (reg << 1) & 0xffff;
+		if (fb)
+			reg ^= 0x1021;
+	}
+	crc[blk] = (uint16_t)reg;
+}
+
+extern "C" int tgk_stages(const uint8_t *d_type5, const uint32_t *d_codes, uint32_t fixed_code, unsigned long long nblocks, uint32_t K,
+			  uint32_t a, uint32_t mother_len, uint8_t *d_type4, uint8_t *d_type3, uint8_t *d_type3dp, void *stream)
+{
+	if (!nblocks)
+		return 0;
+	if (K > 432 || nblocks > 0x7fffffffull)
+		return -1;	/* TGPU_EINVAL */
+	hipLaunchKernelGGL(k_stages, dim3((uint32_t)nblocks), dim3(256), 0, (hipStream_t)stream, d_type5, d_codes, fixed_code, K, a,
+			   mother_len, d_type4, d_type3, d_type3dp);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_stages_crc(const uint8_t *d_type2, unsigned long long nblocks, uint32_t type2_len, uint32_t n, uint16_t *d_crc,
+			      void *stream)
+{
+	if (!nblocks)
+		return 0;
+	hipLaunchKernelGGL(k_stages_crc, dim3((uint32_t)((nblocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_type2, nblocks,
+			   type2_len, n, d_crc);
 	return (int)hipGetLastError();
 }
 

@@ -2417,3 +2417,69 @@ def test_device_host_locality(T):
     assert node >= -1 and all(c >= 0 for c in cpus) and cpus == sorted(set(cpus))
     if os.path.exists("/sys/bus/pci/devices/%s/numa_node" % bdf):
         assert node == int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ber", [0.0, 0.05])
+def test_stages_step_by_step_and_against_the_fused_path(T, eng, ber):
+    """tgpu_stages_*: the lower MAC one step at a time on the device (what the reference prints with DEBUGP,
+    tetra_lower_mac.c:175-254) == the oracle's step functions (scrambler, de-interleaver, de-puncturer, Viterbi, CRC), for
+    every block type; and the fused kernels' type-1 bits / CRC words of the same blocks == the staged chain's"""
+    import torch
+    rng = np.random.default_rng(int(ber * 100) + 77)
+    hs = torch.cuda.current_stream().cuda_stream
+    codes_pool = np.array([0, 3, 0x41802A07, 0x12345677, 0xFFFFFFFF], np.uint32)
+    for t in (O.T_SB1, O.T_SB2, O.T_NDB, O.T_SCH_HU, O.T_SCH_F, O.T_BBK):
+        K, n2, n1, a = O.BLK[t]
+        n = 300
+        codes = codes_pool[rng.integers(0, len(codes_pool), n)]
+        t5 = np.zeros((n, K), np.uint8)
+        for i in range(n):
+            enc = 3 if t == O.T_SB1 else int(codes[i])
+            t5[i] = O.encode_bbk(rng.integers(0, 2, 14).astype(np.uint8), enc) if t == O.T_BBK else \
+                O.encode_block(t, rng.integers(0, 2, n1).astype(np.uint8), enc)
+        t5 ^= (rng.random(t5.shape) < ber).astype(np.uint8)
+        st = T.Stages(eng, t)
+        assert (st.K, st.type2_len, st.type1_len) == (K, n2 if t != O.T_BBK else 14, n1)
+        d5 = torch.from_numpy(t5 * 255).cuda()        # (a received byte other than 0 is a 1)
+        dc = torch.from_numpy(codes.view(np.int32)).cuda()
+        d4 = torch.full((n, K), 7, dtype=torch.uint8, device="cuda")
+        d3 = torch.full((n, K), 7, dtype=torch.uint8, device="cuda")
+        ddp = torch.full((n, max(st.mother_len, 1)), 7, dtype=torch.uint8, device="cuda")
+        d2 = torch.full((n, st.type2_len), 7, dtype=torch.uint8, device="cuda")
+        dcrc = torch.zeros(n, dtype=torch.int16, device="cuda")
+        st.execute(d5.data_ptr(), dc.data_ptr(), n, d4.data_ptr(), d3.data_ptr(), ddp.data_ptr(), d2.data_ptr(), dcrc.data_ptr(), hs)
+        torch.cuda.synchronize()
+        g4, g3, gdp, g2 = d4.cpu().numpy(), d3.cpu().numpy(), ddp.cpu().numpy(), d2.cpu().numpy()
+        gcrc = dcrc.cpu().numpy().view(np.uint16)
+        for i in range(n):
+            code = 3 if t == O.T_SB1 else int(codes[i])
+            w4 = O.scramb(code, t5[i])
+            assert (g4[i] == w4).all(), (t, i, "type4")
+            if t == O.T_BBK:
+                assert (g2[i] == w4[:14]).all() and (g3[i] == 7).all()
+                continue
+            w3 = O.deinterleave(K, a, w4)
+            assert (g3[i] == w3).all(), (t, i, "type3")
+            wdp = O.depuncture(0, w3, 4 * n2)
+            assert (gdp[i] == wdp).all(), (t, i, "type3dp")
+            w2 = O.viterbi_hard(wdp, n2)
+            assert (g2[i] == w2).all(), (t, i, "type2")
+            assert gcrc[i] == O.crc16(w2[:n1 + 16]), (t, i, "crc")
+        # the fused kernels on the same blocks
+        plan = T.Plan(eng, n, 8)
+        flat = torch.from_numpy(t5.reshape(-1)).cuda()
+        d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        plan.load_blocks(np.arange(n, dtype=np.uint64) * K, np.full(n, t, np.uint8), codes)
+        plan.execute(flat.data_ptr(), d_rec.data_ptr(), hs)
+        torch.cuda.synchronize()
+        p = T.parse_records(d_rec.cpu().numpy().reshape(n, T.REC_BYTES))
+        if t == O.T_BBK:
+            assert (p["bbk"] == g2[:, :14]).all()
+        else:
+            assert (p["bits1"][:, :n1] == g2[:, :n1]).all() and (p["crc"][:, 0] == gcrc).all()
+            assert (p["crc_ok"][:, 0] == (gcrc == 0x1d0f)).all()
+        plan.close()
+        st.close()
+    with pytest.raises(T.TgpuError):
+        T.Stages(eng, 9)
