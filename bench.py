@@ -316,13 +316,13 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             torch.cuda.synchronize()
         gc.collect()
         gc.disable()          # (a collection of the interpreter's in the middle of the run is a multi-millisecond hole in one window)
-        c0, t0 = time.process_time(), time.perf_counter()
+        c0, t0, h0 = time.process_time(), time.perf_counter(), time.thread_time()
         try:
             delivered, evs = run(W + R * K + D, with_gather, D, S)
         finally:
             gc.enable()
         torch.cuda.synchronize()
-        cpu_s, wall_s = time.process_time() - c0, time.perf_counter() - t0
+        cpu_s, wall_s, thr_s = time.process_time() - c0, time.perf_counter() - t0, time.thread_time() - h0
         tk = [evs[W - 1].elapsed_time(e) for e in evs[W - 1:]]
         for i in range(1, len(tk)):               # (steps run on D streams: completion times are made monotone)
             tk[i] = max(tk[i], tk[i - 1])
@@ -354,7 +354,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         return {"value": tot / (med * 1e-3), "ms_per_step": med, "windows_ms_per_step": [round(x, 5) for x in win],
                 "window_spread": (max(win) - min(win)) / med, "all_windows_ms_per_step": (tk[R * K] - tk[0]) / (R * K),
                 "sync_bracketed_ms_per_step": bracket, "bursts_delivered_per_step": tot,
-                "host_cpu_ms_per_step": cpu_s / (W + R * K + D) * 1e3, "host_wall_ms_per_step": wall_s / (W + R * K + D) * 1e3}
+                "host_cpu_ms_per_step": cpu_s / (W + R * K + D) * 1e3, "host_wall_ms_per_step": wall_s / (W + R * K + D) * 1e3,
+                "launch_thread_cpu_ms_per_step": thr_s / (W + R * K + D) * 1e3}
 
     single = None
     if world > 1:
@@ -574,6 +575,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                       "sync_bracketed_ms_per_step (K steps between two synchronisations, ramp-up and drain included)": head["sync_bracketed_ms_per_step"],
                       "front_end_launches_per_window": K},
            "breakdown_ms": {"host cpu per step (process_time over the continuous run: the launching thread + the HIP runtime's own)": head["host_cpu_ms_per_step"],
+                            "host cpu per step, the launching thread alone (thread_time: launch call, collect, the polled wait, the interpreter); "
+                            "the rest is a thread of the HIP runtime that spins while kernel completions arrive back to back": head["launch_thread_cpu_ms_per_step"],
                             "host wall per step of the continuous run": head["host_wall_ms_per_step"],
                             "gpu kernels per step (serialised, HIP events on the launch stream)": kern_ms},
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
