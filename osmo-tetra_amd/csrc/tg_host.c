@@ -99,6 +99,8 @@ struct tgpu_plan {
 	uint32_t h_final_code[64];
 	uint8_t *d_walk, *h_walk;	/* k_walk's blocks (tg_walk_io): up, down, device-only events (device / pinned mirror) */
 	void *d_walk_recs;		/* max_chan * (TGW_NCAP + 1) node records */
+	uint8_t *d_walk_big;		/* scratch slots of k_walk_big (channels beyond TGW_WCAP bitmap words), on first need */
+	uint32_t walk_big_slots;
 	uint32_t *d_bits_dev;		/* the delivered bitmap k_walk left in the upload arena */
 };
 
@@ -262,7 +264,8 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	void *d[] = { p->up_mapped ? NULL : p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
-		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab, p->d_defer, p->d_walk, p->d_walk_recs };
+		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab, p->d_defer, p->d_walk, p->d_walk_recs,
+		      p->d_walk_big };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
 			(void)hipFree(d[i]);
@@ -706,6 +709,34 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 	io->down_bytes = (size_t)((uint8_t *)(io->d_bits2 + ((size_t)ngrid + 31) / 32) - io->d_down0);
 	io->d_evbig = (tgpu_sync_event_rec_dev *)(p->d_walk + o_big);
 	io->d_recs = p->d_walk_recs;
+	return TGPU_OK;
+}
+
+int tgpi_plan_walk_big(struct tgpu_plan *p, uint32_t nbig, struct tg_walk_io *io)
+{
+	if (!p || !io || !nbig || nbig > TGW_BIG_MAX)
+		return TGPU_EINVAL;
+	BIND(p->eng);
+	/* caps from the plan's capacity: one such channel can be as long as the plan (the others are then short) */
+	io->big.wcap = (p->max_slots + 31) / 32 + 1;
+	io->big.ncap = tg_walk_big_ncap(p->max_slots);
+	io->big.evcap = 4 * io->big.ncap;
+	struct tg_walk_big_layout L;
+	tg_walk_big_offsets(io->big.wcap, io->big.ncap, io->big.evcap, &L);
+	if (p->walk_big_slots < nbig) {
+		if (p->d_walk_big) {	/* (the plan is idle between collect and the next launch: nothing uses the old area) */
+			(void)hipFree(p->d_walk_big);
+			p->d_walk_big = NULL;
+			p->walk_big_slots = 0;
+		}
+		hipError_t e = hipMalloc((void **)&p->d_walk_big, (size_t)nbig * L.slot_bytes);
+		if (e != hipSuccess) {
+			p->d_walk_big = NULL;
+			return (int)e;
+		}
+		p->walk_big_slots = nbig;
+	}
+	io->d_big = p->d_walk_big;
 	return TGPU_OK;
 }
 

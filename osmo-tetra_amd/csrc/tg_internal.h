@@ -99,6 +99,39 @@ typedef struct { int32_t ev; uint32_t bitnum, arg; } tgpu_sync_event_rec_dev;	/*
 int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 	     uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
 	     uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *stream);
+/* channels beyond TGW_WCAP words (recordings of more than 262 144 slots): k_walk_big, one workgroup each, with its working
+ * arrays in global memory -- a scratch slot per such channel, laid out by tg_walk_big_offsets() for the caps the plan was
+ * made with (wcap: bitmap words, ncap: nodes, evcap: events of the channel behind the TGW_EVEAGER first ones) */
+#define TGW_BIG_MAX 8u
+struct tg_walk_big {
+	uint32_t n, wcap, ncap, evcap;
+	uint32_t chan[TGW_BIG_MAX];
+};
+struct tg_walk_big_layout {
+	size_t o_bm, o_nslot, o_wpre, o_ja, o_jb, o_mark, o_recs, o_ev, slot_bytes;
+};
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline void tg_walk_big_offsets(uint32_t wcap, uint32_t ncap, uint32_t evcap, struct tg_walk_big_layout *L)
+{
+	size_t o = 0;
+#define TGW_AT(field, bytes) do { L->field = o; o = (o + (size_t)(bytes) + 255) & ~(size_t)255; } while (0)
+	TGW_AT(o_bm, (size_t)wcap * 4);
+	TGW_AT(o_nslot, (size_t)ncap * 4);
+	TGW_AT(o_wpre, (size_t)wcap * 4);
+	TGW_AT(o_ja, ((size_t)ncap + 8) * 4);
+	TGW_AT(o_jb, ((size_t)ncap + 8) * 4);
+	TGW_AT(o_mark, (size_t)ncap + 8);
+	TGW_AT(o_recs, ((size_t)ncap + 1) * TGW_REC_BYTES);
+	TGW_AT(o_ev, (size_t)evcap * 12);
+#undef TGW_AT
+	L->slot_bytes = o;
+}
+static inline uint32_t tg_walk_big_ncap(uint32_t slots) { return slots / 8 < 16384u ? 16384u : slots / 8; }
+int tgk_walk_big(const struct tg_walk_big *big, void *d_scratch, const uint8_t *d_base, const struct tg_chan_ent *d_chan,
+		 const struct tg_walk_root *d_roots, uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum,
+		 const uint32_t *d_plain, uint32_t *d_bits, uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *stream);
 /* buffers of a device-walk batch: ONE block up (channel table, roots, carry-in codes), ONE block down (summaries, the
  * first TGW_EVEAGER events of every channel, the delivered bitmap), device-only scratch (further events, node records) */
 struct tg_walk_io {
@@ -115,9 +148,13 @@ struct tg_walk_io {
 	uint32_t *d_final, *h_final;	/* 64 codes after the batch + the code table's overflow flag */
 	tgpu_sync_event_rec_dev *d_evbig;
 	void *d_recs;
+	struct tg_walk_big big;		/* the batch's channels beyond TGW_WCAP words (n = 0: none) and the scratch caps */
+	uint8_t *d_big;			/* big.n scratch slots (tg_walk_big_offsets) */
 };
 struct tgpu_plan;
 int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struct tg_walk_io *io);
+/* scratch for k_walk_big: nbig slots at the plan's caps (allocated on the first batch that needs it); fills io->big's caps and io->d_big */
+int tgpi_plan_walk_big(struct tgpu_plan *p, uint32_t nbig, struct tg_walk_io *io);
 
 /* GSMTAP messages of a decoded batch (k_gsmtap); tg_tdma_time_dev = struct tetra_tdma_time */
 typedef struct { uint16_t hn; uint32_t sn, tn, fn, mn; } tg_tdma_time_dev;

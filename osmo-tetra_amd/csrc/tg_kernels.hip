@@ -3729,30 +3729,30 @@ extern "C" int tgk_walk_stamps(unsigned long long *out)
 #define TGW_STAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(TGW_THREADS)
-void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan, const tg_walk_root *__restrict__ roots,
-	    uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
-	    const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, uint32_t *__restrict__ g_bits2,
-	    tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager,
-	    tgpu_sync_event_rec_dev *__restrict__ g_evbig, tgw_rec *__restrict__ g_recs)
+/*
+ * The body, for both homes of its working arrays: BIG = false, LDS (a channel of up to TGW_WCAP bitmap words and TGW_NCAP
+ * nodes: 16-bit node indices, loop counts known at compile time); BIG = true, global memory (k_walk_big: a channel
+ * beyond that -- a recording of more than 262 144 slots -- with the caps the plan's scratch area was made for; the same
+ * steps at L2 latency, a millisecond or two for a million slots, on one compute unit beside the other batches' kernels).
+ */
+template <bool BIG, typename idx_t>
+__device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *nslot, idx_t *wpre, idx_t *Ja, idx_t *Jb, uint8_t *mark,
+					  tgw_rec *recs, tgpu_sync_event_rec_dev *ev_big, const uint32_t wcap, const uint32_t ncap,
+					  const uint32_t evcap, const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan,
+					  const tg_walk_root *__restrict__ roots, uint32_t chunk, uint32_t cshift,
+					  const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
+					  const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, uint32_t *__restrict__ g_bits2,
+					  tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager)
 {
-	constexpr uint32_t evcap = TGW_EVCAP;
-	extern __shared__ uint32_t s_dyn[];
-	uint32_t *bm = s_dyn;
-	uint32_t *nslot = bm + TGW_WCAP;
-	uint16_t *wpre = (uint16_t *)(nslot + TGW_NCAP);
-	uint16_t *Ja = wpre + TGW_WCAP, *Jb = Ja + TGW_NCAP + 8;
-	uint8_t *mark = (uint8_t *)(Jb + TGW_NCAP + 8);
 	__shared__ uint32_t sm[20];
 	__shared__ uint32_t s_head, s_fb, s_why, s_nd, s_tail, s_last, s_lastdel, s_ns;
 
-	const uint32_t c = blockIdx.x, tid = threadIdx.x;
+	const uint32_t tid = threadIdx.x;
 	const tg_chan_ent ce = chan[c];
 	const tg_walk_root rt = roots[c];
 	tg_walk_sum *sum = sums + c;
-	tgw_rec *recs = g_recs + (size_t)c * (TGW_NCAP + 1);
 	/* event e of the channel: the first TGW_EVEAGER in the block that is copied to the host with the batch, the rest behind */
-	tgpu_sync_event_rec_dev *ev_eager = g_eager + (size_t)c * TGW_EVEAGER, *ev_big = g_evbig + (size_t)c * evcap;
+	tgpu_sync_event_rec_dev *ev_eager = g_eager + (size_t)c * TGW_EVEAGER;
 	const uint32_t ncls = ce.ncls, W = (ncls + 31) >> 5, w0 = ce.gbase >> 5;
 
 	if (tid == 0) {
@@ -3765,7 +3765,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 		s_ns = 0;
 	}
 	__syncthreads();
-	if (!ncls || W > TGW_WCAP) {	/* nothing classified (the host settles such a channel) or too long for one workgroup */
+	if (!ncls || W > wcap) {	/* nothing classified (the host settles such a channel) or too long for this form's arrays */
 		if (tid == 0) {
 			sum->nslots = sum->nevents = sum->tail_tn_adds = sum->burst_seq = 0;
 			sum->final_state = TGW_S_UNLOCKED;
@@ -3788,7 +3788,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 
 	TGW_STAMP(0);
 	/* A: bitmap -> LDS (bits at and past ncls read "plain" so that they are no nodes; they are cleared again in F) */
-	constexpr uint32_t WPT = TGW_WCAP / TGW_THREADS;	/* consecutive words per thread */
+	const uint32_t WPT = BIG ? (W + TGW_THREADS - 1) / TGW_THREADS : TGW_WCAP / TGW_THREADS;	/* consecutive words per thread */
 	uint32_t cnt = 0;
 #pragma unroll
 	for (uint32_t q = 0; q < WPT; q++) {
@@ -3803,7 +3803,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	}
 	uint32_t N;
 	uint32_t base = tgw_block_excl_scan(cnt, sm, N);
-	if (N > TGW_NCAP) {
+	if (N > ncap) {
 		if (tid == 0) {
 			sum->nslots = sum->nevents = sum->tail_tn_adds = sum->burst_seq = 0;
 			sum->final_state = TGW_S_UNLOCKED;
@@ -3818,7 +3818,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	for (uint32_t q = 0; q < WPT; q++) {
 		const uint32_t w = WPT * tid + q;
 		if (w < W) {
-			wpre[w] = (uint16_t)base;
+			wpre[w] = (idx_t)base;
 			uint32_t z = ~bm[w];
 			while (z) {
 				const uint32_t b = __builtin_ctz(z);
@@ -3842,12 +3842,12 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 		tgw_rec r;
 		tgw_run(&wc, TGW_S_LOCKED, bs, bs + TG_SLOT_BITS, kc - 1, &r);
 		recs[i] = r;
-		Ja[i] = (uint16_t)(r.status == TGW_OK ? rank(r.next) : N);
+		Ja[i] = (idx_t)(r.status == TGW_OK ? rank(r.next) : N);
 	}
 	if (tid == TGW_THREADS - 1) {
 		tgw_rec r;
 		tgw_run(&wc, TGW_S_KNOW_FSTART, rt.found_bs, wc.anchor, rt.found_k, &r);
-		recs[TGW_NCAP] = r;
+		recs[ncap] = r;
 		if (r.status != TGW_OK) {
 			s_fb = 1;
 			s_why = r.why;
@@ -3855,7 +3855,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 			s_head = rank(r.next);
 	}
 	if (tid == 0)
-		Ja[N] = Jb[N] = (uint16_t)N;
+		Ja[N] = Jb[N] = (idx_t)N;
 	for (uint32_t i = tid; i <= N; i += TGW_THREADS)
 		mark[i] = 0;
 	__syncthreads();
@@ -3866,17 +3866,17 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 		if (tid == 0 && head < N)
 			mark[head] = 1;
 		__syncthreads();
-		uint16_t *J = Ja, *Jn = Jb;
+		idx_t *J = Ja, *Jn = Jb;
 		for (uint32_t span = 1; span <= N; span <<= 1) {
 			for (uint32_t v = tid; v < N; v += TGW_THREADS)
 				if (mark[v] && J[v] < N)
 					mark[J[v]] = 1;
 			for (uint32_t v = tid; v < N; v += TGW_THREADS) {
 				const uint32_t j = J[v];
-				Jn[v] = j < N ? J[j] : (uint16_t)N;
+				Jn[v] = j < N ? J[j] : (idx_t)N;
 			}
 			__syncthreads();
-			uint16_t *t = J;
+			idx_t *t = J;
 			J = Jn;
 			Jn = t;
 		}
@@ -3905,7 +3905,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 			atomicMax(&s_last, i + 1);
 		}
 	if (tid == TGW_THREADS - 1 && !s_fb)
-		clear_span(0, recs[TGW_NCAP].next);
+		clear_span(0, recs[ncap].next);
 	__syncthreads();
 	if (s_fb) {
 		if (tid == 0) {
@@ -3920,7 +3920,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	for (uint32_t i = tid; i < N + 1; i += TGW_THREADS) {
 		const bool root = (i == N);
 		if (root || mark[i]) {
-			const tgw_rec *r = recs + (root ? TGW_NCAP : i);
+			const tgw_rec *r = recs + (root ? ncap : i);
 			for (uint32_t d = 0; d < r->ndel; d++)
 				atomicOr(&bm[r->del[d] >> 5], 1u << (r->del[d] & 31));
 		}
@@ -3952,8 +3952,8 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	__syncthreads();
 	TGW_STAMP(5);
 	/* G: events in slot order */
-	constexpr uint32_t NPT = TGW_NCAP / TGW_THREADS;
-	const tgw_rec *root = recs + TGW_NCAP;
+	const uint32_t NPT = BIG ? (N + TGW_THREADS - 1) / TGW_THREADS : TGW_NCAP / TGW_THREADS;
+	const tgw_rec *root = recs + ncap;
 	uint32_t ecnt = 0;
 #pragma unroll
 	for (uint32_t q = 0; q < NPT; q++) {
@@ -4010,6 +4010,42 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	TGW_STAMP(6);
 }
 
+__global__ __launch_bounds__(TGW_THREADS)
+void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan, const tg_walk_root *__restrict__ roots,
+	    uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
+	    const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, uint32_t *__restrict__ g_bits2,
+	    tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager,
+	    tgpu_sync_event_rec_dev *__restrict__ g_evbig, tgw_rec *__restrict__ g_recs)
+{
+	extern __shared__ uint32_t s_dyn[];
+	uint32_t *bm = s_dyn;
+	uint32_t *nslot = bm + TGW_WCAP;
+	uint16_t *wpre = (uint16_t *)(nslot + TGW_NCAP);
+	uint16_t *Ja = wpre + TGW_WCAP, *Jb = Ja + TGW_NCAP + 8;
+	uint8_t *mark = (uint8_t *)(Jb + TGW_NCAP + 8);
+	const uint32_t c = blockIdx.x;
+	walk_body<false, uint16_t>(c, bm, nslot, wpre, Ja, Jb, mark, g_recs + (size_t)c * (TGW_NCAP + 1), g_evbig + (size_t)c * TGW_EVCAP,
+				   TGW_WCAP, TGW_NCAP, TGW_EVCAP, d_base, chan, roots, chunk, cshift, g_cls, g_ysum, g_plain, g_bits, g_bits2,
+				   sums, g_eager);
+}
+
+/* the channels of the batch that are too long for the form above (their indices in `big`), one workgroup each, working
+ * arrays in the plan's scratch area (tg_walk_big_layout): runs behind k_walk, which has reported them as TGW_WHY_SIZE */
+__global__ __launch_bounds__(TGW_THREADS)
+void k_walk_big(tg_walk_big big, uint8_t *__restrict__ scratch, const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan,
+		const tg_walk_root *__restrict__ roots, uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls,
+		const uint16_t *__restrict__ g_ysum, const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits,
+		uint32_t *__restrict__ g_bits2, tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager)
+{
+	tg_walk_big_layout L;
+	tg_walk_big_offsets(big.wcap, big.ncap, big.evcap, &L);
+	uint8_t *base = scratch + (size_t)blockIdx.x * L.slot_bytes;
+	walk_body<true, uint32_t>(big.chan[blockIdx.x], (uint32_t *)(base + L.o_bm), (uint32_t *)(base + L.o_nslot), (uint32_t *)(base + L.o_wpre),
+				  (uint32_t *)(base + L.o_ja), (uint32_t *)(base + L.o_jb), base + L.o_mark, (tgw_rec *)(base + L.o_recs),
+				  (tgpu_sync_event_rec_dev *)(base + L.o_ev), big.wcap, big.ncap, big.evcap, d_base, chan, roots, chunk, cshift,
+				  g_cls, g_ysum, g_plain, g_bits, g_bits2, sums, g_eager);
+}
+
 extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 			uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
 			uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *stream)
@@ -4022,6 +4058,20 @@ extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 	hipLaunchKernelGGL(k_walk, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, (hipStream_t)stream, d_base, d_chan, d_roots, chunk,
 			   (uint32_t)__builtin_ctz(chunk), d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums,
 			   (tgpu_sync_event_rec_dev *)d_eager, (tgpu_sync_event_rec_dev *)d_evbig, (tgw_rec *)d_recs);
+	return (int)hipGetLastError();
+}
+
+extern "C" int tgk_walk_big(const struct tg_walk_big *big, void *d_scratch, const uint8_t *d_base, const struct tg_chan_ent *d_chan,
+			    const struct tg_walk_root *d_roots, uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum,
+			    const uint32_t *d_plain, uint32_t *d_bits, uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *stream)
+{
+	if (!big || !big->n)
+		return 0;
+	if (big->n > TGW_BIG_MAX || !d_scratch || !chunk || (chunk & (chunk - 1)))
+		return -1;
+	hipLaunchKernelGGL(k_walk_big, dim3(big->n), dim3(TGW_THREADS), 0, (hipStream_t)stream, *big, (uint8_t *)d_scratch, d_base, d_chan,
+			   d_roots, chunk, (uint32_t)__builtin_ctz(chunk), d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums,
+			   (tgpu_sync_event_rec_dev *)d_eager);
 	return (int)hipGetLastError();
 }
 

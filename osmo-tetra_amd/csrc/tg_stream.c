@@ -1210,17 +1210,16 @@ int tgpu_sync_walk_emul(const uint8_t *h_stream, uint64_t len, uint32_t chunk, u
 	if (!locks || a2 != anchor)
 		return TGPU_EINVAL;
 	const uint32_t W = (ncls + 31) / 32;
-	if (W > TGW_WCAP) {
-		*status = TGW_FALLBACK;
-		*why = TGW_WHY_SIZE;
-		return TGPU_OK;
-	}
+	/* (a channel beyond TGW_WCAP words runs the same steps with the caps of k_walk_big's scratch area -- there made for
+	 * the plan's capacity, here for the channel's own length) */
+	const int big = W > TGW_WCAP;
+	const uint32_t ncap = big ? tg_walk_big_ncap(ncls) : TGW_NCAP, evcap = big ? 4 * ncap : TGW_EVCAP;
 	struct tgw_chan wc = { cls, ysum, h_stream, len, anchor, (len + chunk - 1) / chunk, ncls, chunk, (uint32_t)__builtin_ctz(chunk) };
 	uint32_t *bm = malloc((size_t)W * 4), *wpre = malloc((size_t)W * 4);
-	uint32_t *nslot = malloc((size_t)TGW_NCAP * 4);
-	uint16_t *Ja = malloc((TGW_NCAP + 8) * 2), *Jb = malloc((TGW_NCAP + 8) * 2);
-	uint8_t *mark = calloc(TGW_NCAP + 8, 1);
-	struct tgw_rec *recs = malloc(((size_t)TGW_NCAP + 1) * sizeof(*recs));
+	uint32_t *nslot = malloc((size_t)ncap * 4);
+	uint32_t *Ja = malloc(((size_t)ncap + 8) * 4), *Jb = malloc(((size_t)ncap + 8) * 4);
+	uint8_t *mark = calloc((size_t)ncap + 8, 1);
+	struct tgw_rec *recs = malloc(((size_t)ncap + 1) * sizeof(*recs));
 	rc = TGPU_ENOMEM;
 	if (!bm || !wpre || !nslot || !Ja || !Jb || !mark || !recs)
 		goto done;
@@ -1234,12 +1233,12 @@ int tgpu_sync_walk_emul(const uint8_t *h_stream, uint64_t len, uint32_t chunk, u
 		bm[w] = v;
 		wpre[w] = N;
 		for (uint32_t z = ~v; z; z &= z - 1) {
-			if (N < TGW_NCAP)
+			if (N < ncap)
 				nslot[N] = 32 * w + (uint32_t)__builtin_ctz(z);
 			N++;
 		}
 	}
-	if (N > TGW_NCAP) {
+	if (N > ncap) {
 		*status = TGW_FALLBACK;
 		*why = TGW_WHY_NODES;
 		goto done;
@@ -1250,9 +1249,9 @@ int tgpu_sync_walk_emul(const uint8_t *h_stream, uint64_t len, uint32_t chunk, u
 		const uint64_t bs = anchor + (uint64_t)nslot[i] * TG_SLOT_BITS;
 		const uint64_t kc = (bs + TG_SLOT_BITS + chunk - 1) >> wc.cshift;
 		tgw_run(&wc, TGW_S_LOCKED, bs, bs + TG_SLOT_BITS, kc - 1, &recs[i]);
-		Ja[i] = (uint16_t)(recs[i].status == TGW_OK ? RANK(recs[i].next) : N);
+		Ja[i] = recs[i].status == TGW_OK ? RANK(recs[i].next) : N;
 	}
-	struct tgw_rec *rr = &recs[TGW_NCAP];
+	struct tgw_rec *rr = &recs[ncap];
 	tgw_run(&wc, TGW_S_KNOW_FSTART, root.found_bs, anchor, root.found_k, rr);
 	if (rr->status != TGW_OK) {
 		*status = TGW_FALLBACK;
@@ -1261,19 +1260,19 @@ int tgpu_sync_walk_emul(const uint8_t *h_stream, uint64_t len, uint32_t chunk, u
 	}
 	const uint32_t head = RANK(rr->next);
 #undef RANK
-	Ja[N] = Jb[N] = (uint16_t)N;
+	Ja[N] = Jb[N] = N;
 	/* D */
 	if (head < N)
 		mark[head] = 1;
 	{
-		uint16_t *J = Ja, *Jn = Jb;
+		uint32_t *J = Ja, *Jn = Jb;
 		for (uint32_t span = 1; span <= N; span <<= 1) {
 			for (uint32_t v = 0; v < N; v++)
 				if (mark[v] && J[v] < N)
 					mark[J[v]] = 1;
 			for (uint32_t v = 0; v < N; v++)
-				Jn[v] = J[v] < N ? J[J[v]] : (uint16_t)N;
-			uint16_t *t = J;
+				Jn[v] = J[v] < N ? J[J[v]] : N;
+			uint32_t *t = J;
 			J = Jn;
 			Jn = t;
 		}
@@ -1318,7 +1317,7 @@ int tgpu_sync_walk_emul(const uint8_t *h_stream, uint64_t len, uint32_t chunk, u
 	for (uint32_t i = 0; i < N; i++)
 		if (mark[i])
 			etot += recs[i].nev;
-	if (etot > TGW_EVCAP) {
+	if (etot > evcap) {
 		*status = TGW_FALLBACK;
 		*why = TGW_WHY_EVENTS;
 		goto done;
@@ -1543,6 +1542,20 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 		if (!rc)
 			rc = tgk_walk(d_base, io->d_tab, io->d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, io->d_bits2, io->d_sums,
 				      io->d_eager, io->d_evbig, io->d_recs, stream);
+		if (!rc) {	/* channels of more than 262 144 slots: the same walk with its arrays in global memory, behind the first */
+			struct tg_walk_big big = { 0 };
+			for (uint32_t c = 0; c < nchan && big.n < TGW_BIG_MAX; c++)
+				if (((uint64_t)st->ent[c].ncls + 31) / 32 > TGW_WCAP)
+					big.chan[big.n++] = c;
+			if (big.n) {
+				rc = tgpi_plan_walk_big(plan, big.n, io);
+				io->big.n = big.n;
+				memcpy(io->big.chan, big.chan, sizeof(big.chan));
+				if (!rc)
+					rc = tgk_walk_big(&io->big, io->d_big, d_base, io->d_tab, io->d_roots, chunk, d_cls, d_ysum, d_plain,
+							  d_bits, io->d_bits2, io->d_sums, io->d_eager, stream);
+			}
+		}
 		EVMARK(6);
 		if (!rc)
 			rc = tgpi_plan_dev_stage2(plan, io->d_tab, io->d_final, stream, evs != NULL, evs ? (void **)(evs + 7) : NULL);
@@ -1664,9 +1677,21 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 		memcpy(o->grid_bits, sd->io.h_bits2 + e->gbase / 32, nw * 4);
 		const uint32_t eager = s->nevents < TGW_EVEAGER ? s->nevents : TGW_EVEAGER;
 		memcpy(o->events, sd->io.h_eager + (size_t)c * TGW_EVEAGER, (size_t)eager * sizeof(*o->events));
-		if (s->nevents > eager)		/* a channel with many exceptions: the rest of its events in a second copy */
-			rc = (int)hipMemcpy(o->events + eager, sd->io.d_evbig + (size_t)c * TGW_EVCAP + eager,
-					    (size_t)(s->nevents - eager) * sizeof(*o->events), hipMemcpyDeviceToHost);
+		if (s->nevents > eager) {	/* a channel with many exceptions: the rest of its events in a second copy */
+			const tgpu_sync_event_rec_dev *src = sd->io.d_evbig + (size_t)c * TGW_EVCAP;
+			for (uint32_t k = 0; k < sd->io.big.n; k++)
+				if (sd->io.big.chan[k] == c) {		/* (a long channel's are in its scratch slot) */
+					struct tg_walk_big_layout L;
+					tg_walk_big_offsets(sd->io.big.wcap, sd->io.big.ncap, sd->io.big.evcap, &L);
+					src = (const tgpu_sync_event_rec_dev *)(sd->io.d_big + (size_t)k * L.slot_bytes + L.o_ev);
+				}
+			/* (on the batch's own stream, which is idle by now: a plain hipMemcpy() goes through the null stream and
+			 * waits for every other batch in flight) */
+			rc = (int)hipMemcpyAsync(o->events + eager, src + eager, (size_t)(s->nevents - eager) * sizeof(*o->events),
+						 hipMemcpyDeviceToHost, sd->stream);
+			if (!rc)
+				rc = (int)hipStreamSynchronize(sd->stream);
+		}
 		uint32_t last = 0xffffffffu;
 		for (size_t wd = nw; wd-- > 0;)
 			if (o->grid_bits[wd]) {

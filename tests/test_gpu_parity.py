@@ -2483,3 +2483,34 @@ def test_stages_step_by_step_and_against_the_fused_path(T, eng, ber):
         st.close()
     with pytest.raises(T.TgpuError):
         T.Stages(eng, 9)
+
+
+@pytest.mark.gpu
+def test_device_walk_of_a_channel_beyond_one_workgroups_arrays(T, eng):
+    """a recording of 300 000 slots (more than the 262 144 whose bitmap and node list k_walk keeps in LDS) next to a
+    short one in the same batch: k_walk_big walks it with its arrays in the plan's scratch area -- no hand-over to the
+    host walks, and events (5 600 of them: more than the block that comes down with the batch holds), counts, final state, delivered bitmap, every
+    delivered record and the final codes equal the host-walk batch's"""
+    import torch
+    import bench
+    hs = torch.cuda.current_stream().cuda_stream
+    st0, _, _ = bench.make_mix_stream(T, 300000, 2, mnc=61, cc=4)
+    st1, _, _ = bench.make_mix_stream(T, 5000, 3, mnc=62, cc=5)
+    streams = [np.ascontiguousarray(st0), np.ascontiguousarray(st1)]
+    d, offs, ntot = _multi_batch(T, streams)
+    pa, pb = T.Plan(eng, ntot, 2), T.Plan(eng, ntot, 2)
+    ms = T.MultiSync(eng, pa, streams, d.data_ptr(), offs, 64, hs)
+    ref = ms.finish(burst_events=False, nthreads=2)
+    ra = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    pa.execute(d.data_ptr(), ra.data_ptr(), hs)
+    torch.cuda.synchronize()
+    assert ref[0]["ngrid"] > 262144 and len(ref[0]["events"]) > 4096     # (more events than the block that comes down with the batch)
+    for rep in range(2):            # (twice: the scratch area is allocated by the first batch that needs it)
+        rb = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), 64, hs)
+        got = msd.collect()
+        assert not msd.fellback and msd.ngrid == ms.ngrid
+        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES), "long channel")
+        assert pb.final_codes().tolist() == pa.final_codes().tolist()
+    pa.close()
+    pb.close()

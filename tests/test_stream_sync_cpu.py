@@ -407,3 +407,12 @@ def test_device_form_on_a_recording_of_bench_size():
     st, _, _ = bench.make_mix_stream(T, 125000, 5, mnc=47, cc=6)
     r = _dev_form(np.ascontiguousarray(st), 64)
     assert r[0] == "ok" and r[1] > 1500
+
+
+def test_device_form_on_a_recording_beyond_one_workgroups_arrays():
+    """a channel of 266 000 slots (more than the 262 144 the LDS form holds): the same steps with the caps of k_walk_big's
+    scratch area -- no hand-over to the host walk, same outcome as the host walk"""
+    import bench
+    st, _, _ = bench.make_mix_stream(T, 266000, 3, mnc=44, cc=9)
+    r = _dev_form(np.ascontiguousarray(st), 64)
+    assert r[0] == "ok" and r[1] > 3000
