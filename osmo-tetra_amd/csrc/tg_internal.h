@@ -82,8 +82,12 @@ int tgk_grid_lists(const uint32_t *d_cls, const uint32_t *d_bits, uint32_t n, ui
 		   uint32_t *d_list_432, const struct tg_chan_ent *d_chan /* NULL: one channel */, uint32_t nchan, void *stream);
 
 /* the synchroniser's walk on the device (k_walk, tg_walk_core.h): one workgroup per channel of the table */
+#ifndef TGW_NCAP
 #define TGW_NCAP 8192u	/* nodes (grid slots that are no plain delivery) per channel */
+#endif
+#ifndef TGW_WCAP
 #define TGW_WCAP 8192u	/* bitmap words per channel: 262 144 grid slots */
+#endif
 struct tg_walk_root {	/* the stream's first lock (tg_stream.c:find_anchor): buffer start and index of the call that found it */
 	uint64_t found_bs, found_k;
 };

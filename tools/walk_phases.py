@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 import bench
-Cn, per = 8, 125000
+Cn = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+per = 1000000 // Cn
 streams = [bench.make_mix_stream(T, per, c, mnc=42 + c, cc=1 + c)[0] for c in range(Cn)]
 offs, o = [], 0
 for st in streams:
