@@ -99,6 +99,7 @@ struct tgpu_plan {
 	uint32_t h_final_code[64];
 	uint8_t *d_walk, *h_walk;	/* k_walk's blocks (tg_walk_io): up, down, device-only events (device / pinned mirror) */
 	void *d_walk_recs;		/* max_chan * (TGW_NCAP + 1) node records */
+	void *d_walk_tmp;		/* hand-over area of the split walk */
 	uint8_t *d_walk_big;		/* scratch slots of k_walk_big (channels beyond TGW_WCAP bitmap words), on first need */
 	uint32_t walk_big_slots;
 	uint32_t *d_bits_dev;		/* the delivered bitmap k_walk left in the upload arena */
@@ -265,7 +266,7 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
 	void *d[] = { p->up_mapped ? NULL : p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
 		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab, p->d_defer, p->d_walk, p->d_walk_recs,
-		      p->d_walk_big };
+		      p->d_walk_big, p->d_walk_tmp };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
 		if (d[i])
 			(void)hipFree(d[i]);
@@ -686,7 +687,15 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 			return (int)e;
 		}
 	}
+	if (!p->d_walk_tmp) {
+		hipError_t e = hipMalloc(&p->d_walk_tmp, TGW_TMP_BYTES);
+		if (e != hipSuccess) {
+			p->d_walk_tmp = NULL;
+			return (int)e;
+		}
+	}
 	memset(io, 0, sizeof(*io));
+	io->d_tmp = p->d_walk_tmp;
 	io->d_up0 = p->d_walk;
 	io->h_up0 = p->h_walk;
 	io->up_bytes = up;

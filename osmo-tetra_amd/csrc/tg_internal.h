@@ -102,7 +102,9 @@ typedef struct { int32_t ev; uint32_t bitnum, arg; } tgpu_sync_event_rec_dev;	/*
  * events 0 .. TGW_EVEAGER - 1 of channel c at d_eager + c * TGW_EVEAGER (same block), the others at d_evbig + c * TGW_EVCAP */
 int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 	     uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
-	     uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *stream);
+	     uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp, void *stream);
+/* d_tmp != NULL: the split form (node pass as a grid-wide launch between two per-channel ones); TGW_TMP_BYTES of device memory */
+#define TGW_TMP_BYTES (1024u + 64u * (TGW_NCAP + TGW_WCAP + TGW_NCAP + 8u) * 4u)
 /* channels beyond TGW_WCAP words (recordings of more than 262 144 slots): k_walk_big, one workgroup each, with its working
  * arrays in global memory -- a scratch slot per such channel, laid out by tg_walk_big_offsets() for the caps the plan was
  * made with (wcap: bitmap words, ncap: nodes, evcap: events of the channel behind the TGW_EVEAGER first ones) */
@@ -135,7 +137,8 @@ static inline void tg_walk_big_offsets(uint32_t wcap, uint32_t ncap, uint32_t ev
 static inline uint32_t tg_walk_big_ncap(uint32_t slots) { return slots / 8 < 16384u ? 16384u : slots / 8; }
 int tgk_walk_big(const struct tg_walk_big *big, void *d_scratch, const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 		 const struct tg_walk_root *d_roots, uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum,
-		 const uint32_t *d_plain, uint32_t *d_bits, uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *stream);
+		 const uint32_t *d_plain, uint32_t *d_bits, uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_tmp,
+		 void *stream);
 /* buffers of a device-walk batch: ONE block up (channel table, roots, carry-in codes), ONE block down (summaries, the
  * first TGW_EVEAGER events of every channel, the delivered bitmap), device-only scratch (further events, node records) */
 struct tg_walk_io {
@@ -152,6 +155,7 @@ struct tg_walk_io {
 	uint32_t *d_final, *h_final;	/* 64 codes after the batch + the code table's overflow flag */
 	tgpu_sync_event_rec_dev *d_evbig;
 	void *d_recs;
+	void *d_tmp;			/* hand-over area of the split walk (TGW_TMP_BYTES) */
 	struct tg_walk_big big;		/* the batch's channels beyond TGW_WCAP words (n = 0: none) and the scratch caps */
 	uint8_t *d_big;			/* big.n scratch slots (tg_walk_big_offsets) */
 };

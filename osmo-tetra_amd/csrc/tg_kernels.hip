@@ -3735,8 +3735,18 @@ extern "C" int tgk_walk_stamps(unsigned long long *out)
  * beyond that -- a recording of more than 262 144 slots -- with the caps the plan's scratch area was made for; the same
  * steps at L2 latency, a millisecond or two for a million slots, on one compute unit beside the other batches' kernels).
  */
-template <bool BIG, typename idx_t>
+/* MODE 0: all of it in one launch.  MODE 1 + k_walk_nodes + MODE 2: the node pass (C) -- a dozen dependent reads per node, the
+ * longest stretch of the walk -- as a launch of its own over the whole chip: MODE 1 runs A and B and leaves node list, word
+ * prefixes and the node count in global memory (tg_walk_tmp), k_walk_nodes takes every node of every channel through tgw_run()
+ * (256 nodes per workgroup), MODE 2 runs A and B again (the LDS form; the other keeps its arrays), picks the arrival pointers
+ * up and goes on with D .. G. */
+struct tg_walk_tmp {
+	uint32_t *nslot, *wpre, *J;	/* this channel's node list, per-word prefix counts, arrival pointers */
+	uint32_t *meta;			/* this channel's {node count or ~0: nothing to do, head, fallback flag, reason} */
+};
+template <bool BIG, typename idx_t, int MODE>
 __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *nslot, idx_t *wpre, idx_t *Ja, idx_t *Jb, uint8_t *mark,
+					  const tg_walk_tmp tmp,
 					  tgw_rec *recs, tgpu_sync_event_rec_dev *ev_big, const uint32_t wcap, const uint32_t ncap,
 					  const uint32_t evcap, const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan,
 					  const tg_walk_root *__restrict__ roots, uint32_t chunk, uint32_t cshift,
@@ -3765,6 +3775,8 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 		s_ns = 0;
 	}
 	__syncthreads();
+	if (MODE == 1 && tid == 0)
+		tmp.meta[0] = 0xffffffffu;	/* until A and B are through: nothing for k_walk_nodes / MODE 2 to do */
 	if (!ncls || W > wcap) {	/* nothing classified (the host settles such a channel) or too long for this form's arrays */
 		if (tid == 0) {
 			sum->nslots = sum->nevents = sum->tail_tn_adds = sum->burst_seq = 0;
@@ -3790,6 +3802,12 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	/* A: bitmap -> LDS (bits at and past ncls read "plain" so that they are no nodes; they are cleared again in F) */
 	const uint32_t WPT = BIG ? (W + TGW_THREADS - 1) / TGW_THREADS : TGW_WCAP / TGW_THREADS;	/* consecutive words per thread */
 	uint32_t cnt = 0;
+	uint32_t N, base = 0;
+	if (BIG && MODE == 2) {		/* (bitmap, node list and prefixes are where MODE 1 left them) */
+		N = tmp.meta[0];
+		if (N == 0xffffffffu)
+			return;
+	} else {
 #pragma unroll
 	for (uint32_t q = 0; q < WPT; q++) {
 		const uint32_t w = WPT * tid + q;
@@ -3801,8 +3819,8 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 			cnt += __popc(~v);
 		}
 	}
-	uint32_t N;
-	uint32_t base = tgw_block_excl_scan(cnt, sm, N);
+	base = tgw_block_excl_scan(cnt, sm, N);
+	}
 	if (N > ncap) {
 		if (tid == 0) {
 			sum->nslots = sum->nevents = sum->tail_tn_adds = sum->burst_seq = 0;
@@ -3814,6 +3832,7 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 		return;
 	}
 	/* B: prefix counts per word, node list */
+	if (!(BIG && MODE == 2)) {
 #pragma unroll
 	for (uint32_t q = 0; q < WPT; q++) {
 		const uint32_t w = WPT * tid + q;
@@ -3827,7 +3846,19 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 			}
 		}
 	}
+	}
 	__syncthreads();
+	if (MODE == 1) {	/* hand the lists to k_walk_nodes */
+		if (!BIG) {
+			for (uint32_t i = tid; i < N; i += TGW_THREADS)
+				tmp.nslot[i] = nslot[i];
+			for (uint32_t w = tid; w < W; w += TGW_THREADS)
+				tmp.wpre[w] = wpre[w];
+		}
+		if (tid == 0)
+			tmp.meta[0] = N;
+		return;
+	}
 	auto rank = [&](uint32_t t) -> uint32_t {	/* index of the first node at or after grid slot t */
 		if (t >= ncls)
 			return N;
@@ -3836,6 +3867,16 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	};
 	TGW_STAMP(1);
 	/* C: every node, and the stream's head */
+	if (MODE == 2) {	/* (done by k_walk_nodes) */
+		if (!BIG)
+			for (uint32_t i = tid; i < N; i += TGW_THREADS)
+				Ja[i] = (idx_t)tmp.J[i];
+		if (tid == 0) {
+			s_head = tmp.meta[1];
+			s_fb = tmp.meta[2];
+			s_why = tmp.meta[3];
+		}
+	} else {
 	for (uint32_t i = tid; i < N; i += TGW_THREADS) {
 		const uint64_t bs = wc.anchor + (uint64_t)nslot[i] * TG_SLOT_BITS;
 		const uint64_t kc = (bs + TG_SLOT_BITS + chunk - 1) >> cshift;
@@ -3853,6 +3894,7 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 			s_why = r.why;
 		} else
 			s_head = rank(r.next);
+	}
 	}
 	if (tid == 0)
 		Ja[N] = Jb[N] = (idx_t)N;
@@ -4010,12 +4052,37 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	TGW_STAMP(6);
 }
 
+/* layout of the split form's hand-over area (the LDS form): per channel four words of meta data, then node list, word prefixes
+ * and arrival pointers as 32-bit words */
+#define TGW_TMP_META_BYTES 1024u	/* 64 channels x {N, head, fallback, reason} */
+#define TGW_TMP_CHAN_WORDS (TGW_NCAP + TGW_WCAP + TGW_NCAP + 8u)
+__device__ __forceinline__ tg_walk_tmp walk_tmp_small(uint8_t *d_tmp, uint32_t c)
+{
+	tg_walk_tmp t;
+	uint32_t *w = (uint32_t *)(d_tmp + TGW_TMP_META_BYTES) + (size_t)c * TGW_TMP_CHAN_WORDS;
+	t.nslot = w;
+	t.wpre = w + TGW_NCAP;
+	t.J = w + TGW_NCAP + TGW_WCAP;
+	t.meta = (uint32_t *)d_tmp + 4 * c;
+	return t;
+}
+__device__ __forceinline__ tg_walk_tmp walk_tmp_big(uint8_t *slot, const tg_walk_big_layout &L, uint8_t *d_tmp, uint32_t c)
+{
+	tg_walk_tmp t;
+	t.nslot = (uint32_t *)(slot + L.o_nslot);
+	t.wpre = (uint32_t *)(slot + L.o_wpre);
+	t.J = (uint32_t *)(slot + L.o_ja);
+	t.meta = (uint32_t *)d_tmp + 4 * c;
+	return t;
+}
+
+template <int MODE>
 __global__ __launch_bounds__(TGW_THREADS)
 void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan, const tg_walk_root *__restrict__ roots,
 	    uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
 	    const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, uint32_t *__restrict__ g_bits2,
 	    tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager,
-	    tgpu_sync_event_rec_dev *__restrict__ g_evbig, tgw_rec *__restrict__ g_recs)
+	    tgpu_sync_event_rec_dev *__restrict__ g_evbig, tgw_rec *__restrict__ g_recs, uint8_t *__restrict__ d_tmp)
 {
 	extern __shared__ uint32_t s_dyn[];
 	uint32_t *bm = s_dyn;
@@ -4024,54 +4091,156 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	uint16_t *Ja = wpre + TGW_WCAP, *Jb = Ja + TGW_NCAP + 8;
 	uint8_t *mark = (uint8_t *)(Jb + TGW_NCAP + 8);
 	const uint32_t c = blockIdx.x;
-	walk_body<false, uint16_t>(c, bm, nslot, wpre, Ja, Jb, mark, g_recs + (size_t)c * (TGW_NCAP + 1), g_evbig + (size_t)c * TGW_EVCAP,
-				   TGW_WCAP, TGW_NCAP, TGW_EVCAP, d_base, chan, roots, chunk, cshift, g_cls, g_ysum, g_plain, g_bits, g_bits2,
-				   sums, g_eager);
+	tg_walk_tmp tmp = { nullptr, nullptr, nullptr, nullptr };
+	if (MODE)
+		tmp = walk_tmp_small(d_tmp, c);
+	walk_body<false, uint16_t, MODE>(c, bm, nslot, wpre, Ja, Jb, mark, tmp, g_recs + (size_t)c * (TGW_NCAP + 1),
+					 g_evbig + (size_t)c * TGW_EVCAP, TGW_WCAP, TGW_NCAP, TGW_EVCAP, d_base, chan, roots, chunk, cshift, g_cls,
+					 g_ysum, g_plain, g_bits, g_bits2, sums, g_eager);
 }
 
 /* the channels of the batch that are too long for the form above (their indices in `big`), one workgroup each, working
  * arrays in the plan's scratch area (tg_walk_big_layout): runs behind k_walk, which has reported them as TGW_WHY_SIZE */
+template <int MODE>
 __global__ __launch_bounds__(TGW_THREADS)
 void k_walk_big(tg_walk_big big, uint8_t *__restrict__ scratch, const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan,
 		const tg_walk_root *__restrict__ roots, uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls,
 		const uint16_t *__restrict__ g_ysum, const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits,
-		uint32_t *__restrict__ g_bits2, tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager)
+		uint32_t *__restrict__ g_bits2, tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager,
+		uint8_t *__restrict__ d_tmp)
 {
 	tg_walk_big_layout L;
 	tg_walk_big_offsets(big.wcap, big.ncap, big.evcap, &L);
 	uint8_t *base = scratch + (size_t)blockIdx.x * L.slot_bytes;
-	walk_body<true, uint32_t>(big.chan[blockIdx.x], (uint32_t *)(base + L.o_bm), (uint32_t *)(base + L.o_nslot), (uint32_t *)(base + L.o_wpre),
-				  (uint32_t *)(base + L.o_ja), (uint32_t *)(base + L.o_jb), base + L.o_mark, (tgw_rec *)(base + L.o_recs),
-				  (tgpu_sync_event_rec_dev *)(base + L.o_ev), big.wcap, big.ncap, big.evcap, d_base, chan, roots, chunk, cshift,
-				  g_cls, g_ysum, g_plain, g_bits, g_bits2, sums, g_eager);
+	const uint32_t c = big.chan[blockIdx.x];
+	tg_walk_tmp tmp = { nullptr, nullptr, nullptr, nullptr };
+	if (MODE)
+		tmp = walk_tmp_big(base, L, d_tmp, c);
+	walk_body<true, uint32_t, MODE>(c, (uint32_t *)(base + L.o_bm), (uint32_t *)(base + L.o_nslot), (uint32_t *)(base + L.o_wpre),
+					(uint32_t *)(base + L.o_ja), (uint32_t *)(base + L.o_jb), base + L.o_mark, tmp, (tgw_rec *)(base + L.o_recs),
+					(tgpu_sync_event_rec_dev *)(base + L.o_ev), big.wcap, big.ncap, big.evcap, d_base, chan, roots, chunk,
+					cshift, g_cls, g_ysum, g_plain, g_bits, g_bits2, sums, g_eager);
+}
+
+/* phase C of the walk over the whole chip: workgroup (x, y) takes nodes 256 x .. of channel y (BIG: of the y-th long channel)
+ * through tgw_run(); its first thread also runs the stream's head */
+template <bool BIG>
+__global__ __launch_bounds__(256)
+void k_walk_nodes(tg_walk_big big, uint8_t *__restrict__ scratch, uint8_t *__restrict__ d_tmp, tgw_rec *__restrict__ g_recs,
+		  const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan, const tg_walk_root *__restrict__ roots,
+		  uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
+		  const uint32_t *__restrict__ g_plain)
+{
+	const uint32_t c = BIG ? big.chan[blockIdx.y] : blockIdx.y;
+	tg_walk_tmp tmp;
+	tgw_rec *recs;
+	uint32_t ncap;
+	if (BIG) {
+		tg_walk_big_layout L;
+		tg_walk_big_offsets(big.wcap, big.ncap, big.evcap, &L);
+		uint8_t *slot = scratch + (size_t)blockIdx.y * L.slot_bytes;
+		tmp = walk_tmp_big(slot, L, d_tmp, c);
+		recs = (tgw_rec *)(slot + L.o_recs);
+		ncap = big.ncap;
+	} else {
+		tmp = walk_tmp_small(d_tmp, c);
+		recs = g_recs + (size_t)c * (TGW_NCAP + 1);
+		ncap = TGW_NCAP;
+	}
+	const uint32_t N = tmp.meta[0];
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (N == 0xffffffffu || (i >= N && i != 0))
+		return;
+	const tg_chan_ent ce = chan[c];
+	const uint32_t ncls = ce.ncls, W = (ncls + 31) >> 5, w0 = ce.gbase >> 5;
+	tgw_chan wc;
+	wc.cls = g_cls + ce.gbase;
+	wc.ysum = g_ysum + ce.gbase;
+	wc.s = d_base + ce.d_off;
+	wc.len = ce.len;
+	wc.anchor = ce.anchor;
+	wc.ncalls = (ce.len + chunk - 1) >> cshift;
+	wc.ncls = ncls;
+	wc.chunk = chunk;
+	wc.cshift = cshift;
+	auto rank = [&](uint32_t t) -> uint32_t {	/* index of the first node at or after grid slot t */
+		if (t >= ncls)
+			return N;
+		const uint32_t w = t >> 5;
+		uint32_t v = g_plain[w0 + w];
+		if (w == W - 1 && (ncls & 31))
+			v |= ~0u << (ncls & 31);
+		return tmp.wpre[w] + __popc(~v & ((1u << (t & 31)) - 1u));
+	};
+	if (i < N) {
+		const uint64_t bs = wc.anchor + (uint64_t)tmp.nslot[i] * TG_SLOT_BITS;
+		const uint64_t kc = (bs + TG_SLOT_BITS + chunk - 1) >> cshift;
+		tgw_rec r;
+		tgw_run(&wc, TGW_S_LOCKED, bs, bs + TG_SLOT_BITS, kc - 1, &r);
+		recs[i] = r;
+		tmp.J[i] = r.status == TGW_OK ? rank(r.next) : N;
+	}
+	if (i == 0) {
+		const tg_walk_root rt = roots[c];
+		tgw_rec r;
+		tgw_run(&wc, TGW_S_KNOW_FSTART, rt.found_bs, wc.anchor, rt.found_k, &r);
+		recs[ncap] = r;
+		tmp.meta[1] = r.status == TGW_OK ? rank(r.next) : 0xffffffffu;
+		tmp.meta[2] = r.status != TGW_OK;
+		tmp.meta[3] = r.status != TGW_OK ? r.why : 0u;
+	}
 }
 
 extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 			uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
-			uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *stream)
+			uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp, void *stream)
 {
 	if (!nchan)
 		return 0;
-	if (!chunk || (chunk & (chunk - 1)))
+	if (!chunk || (chunk & (chunk - 1)) || nchan > 64)
 		return -1;
-	HIPCHK(hipFuncSetAttribute((const void *)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
-	hipLaunchKernelGGL(k_walk, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, (hipStream_t)stream, d_base, d_chan, d_roots, chunk,
-			   (uint32_t)__builtin_ctz(chunk), d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums,
-			   (tgpu_sync_event_rec_dev *)d_eager, (tgpu_sync_event_rec_dev *)d_evbig, (tgw_rec *)d_recs);
+	const uint32_t cshift = (uint32_t)__builtin_ctz(chunk);
+	hipStream_t s = (hipStream_t)stream;
+#define WALK_ARGS d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums, \
+		  (tgpu_sync_event_rec_dev *)d_eager, (tgpu_sync_event_rec_dev *)d_evbig, (tgw_rec *)d_recs, (uint8_t *)d_tmp
+	if (!d_tmp) {
+		HIPCHK(hipFuncSetAttribute((const void *)k_walk<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
+		hipLaunchKernelGGL(k_walk<0>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);
+		return (int)hipGetLastError();
+	}
+	HIPCHK(hipFuncSetAttribute((const void *)k_walk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
+	HIPCHK(hipFuncSetAttribute((const void *)k_walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
+	hipLaunchKernelGGL(k_walk<1>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);
+	tg_walk_big none = {};
+	hipLaunchKernelGGL(k_walk_nodes<false>, dim3(TGW_NCAP / 256, nchan), dim3(256), 0, s, none, (uint8_t *)nullptr, (uint8_t *)d_tmp,
+			   (tgw_rec *)d_recs, d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain);
+	hipLaunchKernelGGL(k_walk<2>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);
+#undef WALK_ARGS
 	return (int)hipGetLastError();
 }
 
 extern "C" int tgk_walk_big(const struct tg_walk_big *big, void *d_scratch, const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 			    const struct tg_walk_root *d_roots, uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum,
-			    const uint32_t *d_plain, uint32_t *d_bits, uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *stream)
+			    const uint32_t *d_plain, uint32_t *d_bits, uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_tmp,
+			    void *stream)
 {
 	if (!big || !big->n)
 		return 0;
 	if (big->n > TGW_BIG_MAX || !d_scratch || !chunk || (chunk & (chunk - 1)))
 		return -1;
-	hipLaunchKernelGGL(k_walk_big, dim3(big->n), dim3(TGW_THREADS), 0, (hipStream_t)stream, *big, (uint8_t *)d_scratch, d_base, d_chan,
-			   d_roots, chunk, (uint32_t)__builtin_ctz(chunk), d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums,
-			   (tgpu_sync_event_rec_dev *)d_eager);
+	const uint32_t cshift = (uint32_t)__builtin_ctz(chunk);
+	hipStream_t s = (hipStream_t)stream;
+#define WALK_ARGS *big, (uint8_t *)d_scratch, d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums, \
+		  (tgpu_sync_event_rec_dev *)d_eager, (uint8_t *)d_tmp
+	if (!d_tmp) {
+		hipLaunchKernelGGL(k_walk_big<0>, dim3(big->n), dim3(TGW_THREADS), 0, s, WALK_ARGS);
+		return (int)hipGetLastError();
+	}
+	hipLaunchKernelGGL(k_walk_big<1>, dim3(big->n), dim3(TGW_THREADS), 0, s, WALK_ARGS);
+	hipLaunchKernelGGL(k_walk_nodes<true>, dim3((big->ncap + 255) / 256, big->n), dim3(256), 0, s, *big, (uint8_t *)d_scratch,
+			   (uint8_t *)d_tmp, (tgw_rec *)nullptr, d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain);
+	hipLaunchKernelGGL(k_walk_big<2>, dim3(big->n), dim3(TGW_THREADS), 0, s, WALK_ARGS);
+#undef WALK_ARGS
 	return (int)hipGetLastError();
 }
 

@@ -1541,7 +1541,7 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 		}
 		if (!rc)
 			rc = tgk_walk(d_base, io->d_tab, io->d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, io->d_bits2, io->d_sums,
-				      io->d_eager, io->d_evbig, io->d_recs, stream);
+				      io->d_eager, io->d_evbig, io->d_recs, getenv("TGPU_WALK_MONO") ? NULL : io->d_tmp, stream);
 		if (!rc) {	/* channels of more than 262 144 slots: the same walk with its arrays in global memory, behind the first */
 			struct tg_walk_big big = { 0 };
 			for (uint32_t c = 0; c < nchan && big.n < TGW_BIG_MAX; c++)
@@ -1553,7 +1553,7 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 				memcpy(io->big.chan, big.chan, sizeof(big.chan));
 				if (!rc)
 					rc = tgk_walk_big(&io->big, io->d_big, d_base, io->d_tab, io->d_roots, chunk, d_cls, d_ysum, d_plain,
-							  d_bits, io->d_bits2, io->d_sums, io->d_eager, stream);
+							  d_bits, io->d_bits2, io->d_sums, io->d_eager, getenv("TGPU_WALK_MONO") ? NULL : io->d_tmp, stream);
 			}
 		}
 		EVMARK(6);
