@@ -304,7 +304,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             dist.barrier()
             torch.cuda.synchronize()
 
-    def measure(with_gather, alone=False, D=D, W=W, S=None):
+    def measure(with_gather, alone=False, D=D, W=W, S=None, K=K, R=R):
         """one continuous run of W + R K + D steps (the pipeline stays full before, through and after the timed steps);
         window r = completion of step W - 1 + r K  ->  completion of step W - 1 + (r + 1) K: exactly K classifications,
         K walks, K decodes (and K exchanges) complete inside it.  Plus the contract's form: K steps between two
@@ -367,7 +367,9 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     decode_only = measure(False)
     # (8 plans on 4 streams -- S=4 -- give the same rate and the same 8-step completion pattern as 8 streams: the pattern is the
     # GPU's interleaving of four concurrent batches, and 20-step windows cut it at two different phases)
-    deeper = measure(False, D=D2, W=max(W, 5 * D2)) if D2 > D else None
+    # its windows are 5 x D2 steps long: batches then complete in a repeating D2-step pattern, and windows of the contract's 20
+    # steps would cut that pattern at two different phases (they alternate 0.405 / 0.45 ms)
+    deeper = measure(False, D=D2, W=max(W, 5 * D2), K=5 * D2, R=4) if D2 > D else None
     gathered = gather_error = None
     if gather:
         armed = [True]
@@ -596,7 +598,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         out["deeper_pipeline"] = {k_: deeper[k_] for k_ in ("value", "ms_per_step", "windows_ms_per_step", "window_spread", "all_windows_ms_per_step")}
         out["deeper_pipeline"].update({"steps_in_flight": D2, "note": "the same measurement with %d batches in flight on %d streams (the runtime's 4 hardware queues then hold "
                                         "two batches each and none runs dry while the host collects and relaunches): a higher rate, but batches "
-                                        "complete in clumps and the 20-step windows alias with them (spread), so the headline stays at %d in flight" % (D2, D2, D)})
+                                        "complete in a repeating %d-step pattern which windows of the contract's 20 steps cut at two different phases, so the "
+                                        "headline stays at %d in flight; this object's windows are %d steps long" % (D2, D2, D2, D, 5 * D2)})
     if e2e:
         out["end_to_end"] = e2e
     if gathered or gather_error:
