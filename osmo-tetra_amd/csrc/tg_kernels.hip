@@ -4208,8 +4208,14 @@ extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 		hipLaunchKernelGGL(k_walk<0>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);
 		return (int)hipGetLastError();
 	}
-	HIPCHK(hipFuncSetAttribute((const void *)k_walk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
-	HIPCHK(hipFuncSetAttribute((const void *)k_walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
+	static __thread int attr_set_dev = -1;	/* (the attribute is per device and process: once per thread and device is enough) */
+	int dev = 0;
+	HIPCHK(hipGetDevice(&dev));
+	if (attr_set_dev != dev) {
+		HIPCHK(hipFuncSetAttribute((const void *)k_walk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
+		HIPCHK(hipFuncSetAttribute((const void *)k_walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
+		attr_set_dev = dev;
+	}
 	hipLaunchKernelGGL(k_walk<1>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);
 	tg_walk_big none = {};
 	hipLaunchKernelGGL(k_walk_nodes<false>, dim3(TGW_NCAP / 256, nchan), dim3(256), 0, s, none, (uint8_t *)nullptr, (uint8_t *)d_tmp,
