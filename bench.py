@@ -258,7 +258,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     wires = sink = None
 
     def finish(ms):
-        outs = ms.collect(raw=True)
+        outs = ms.collect_end(raw=True)     # (collect_begin() has run: the batch's successor is launched in between)
         assert all(x["noffgrid"] == 0 for x in outs)
         state["fellback"] += int(ms.fellback)
         state["ngrid"] = ms.ngrid
@@ -284,8 +284,10 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         S = S or D           # (S < D: plan j runs on stream j % S -- a stream then holds its next batch before the host has collected the last)
         for k in range(total):
             j = k % D
-            if len(fl) == D:
-                delivered.append(finish(fl.popleft()))
+            old = None
+            if len(fl) == D:            # wait for the oldest batch and take its outcome out of the plan's buffers ...
+                old = fl.popleft()
+                old.collect_begin()
             plans[j].set_wire(wires[j].data_ptr() if with_gather else 0)
             fl.append(T.MultiSyncDev(eng, plans[j], None, d_base.data_ptr(), None, recs[j].data_ptr(), 64,
                                      strm[j % S].cuda_stream, chans=chans))
@@ -294,8 +296,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(strm[j % S])
             evs.append(ev)
+            if old is not None:         # ... its successor is on the stream: now look at what it delivered
+                delivered.append(finish(old))
         while fl:
-            delivered.append(finish(fl.popleft()))
+            old = fl.popleft()
+            old.collect_begin()
+            delivered.append(finish(old))
         return delivered, evs
 
     def sync_all():

@@ -748,17 +748,27 @@ class MultiSyncDev:
         self.ngrid = lib().tgpu_sync_dev_ngrid(self._h)
         self.fellback = False
 
-    def collect(self, raw=False):
+    def collect_begin(self):
+        """the C half of collect(): wait for the batch, take its outcome out of the plan's buffers -- after this the plan is
+        free for the next launch, before collect_end() turns the outcome into Python objects"""
         n = len(self.streams)
-        res = (SyncResult * n)()
+        self._res = (SyncResult * n)()
         try:
-            _chk(lib().tgpu_sync_multi_collect(self._h, res), "tgpu_sync_multi_collect")
+            _chk(lib().tgpu_sync_multi_collect(self._h, self._res), "tgpu_sync_multi_collect")
             self.fellback = bool(lib().tgpu_sync_dev_fellback(self._h))
         finally:
             lib().tgpu_sync_dev_free(self._h)
             self._h = C.c_void_p()
         if self.ngrid:
             self.plan.nslots, self.plan.nchan = self.ngrid, n
+
+    def collect(self, raw=False):
+        self.collect_begin()
+        return self.collect_end(raw)
+
+    def collect_end(self, raw=False):
+        n = len(self.streams)
+        res, self._res = self._res, None
         if raw:         # counts only (the bench's timed loop): no numpy views, the C arrays are released here
             out = [dict(nslots=res[c].nslots, nevents=res[c].nevents, noffgrid=res[c].noffgrid, ngrid=res[c].ngrid,
                         final_state=res[c].final_state, burst_seq=res[c].burst_seq) for c in range(n)]
