@@ -196,7 +196,7 @@ def host_threads_default():
     return n
 
 
-def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1):  # noqa: D401
+def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1, damaged=0.01):  # noqa: D401
     """config 3's stream: 100 random lead-in bits, a lock-only SB, n slots in frames of 8, 1 % damaged training
     sequences, 700 pad bytes"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -206,7 +206,7 @@ def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1):  # noqa: D401
     code = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3
     slots = T.synth_slots(np.concatenate([[3], types]).astype(np.uint8), seed=11 + seed, scramb_init=code,
                           mcc=mcc, mnc=mnc, cc=cc)
-    bad = np.flatnonzero(rng.random(n) < 0.01) + 1
+    bad = np.flatnonzero(rng.random(n) < damaged) + 1
     y = slots[0, 214:252].tolist()
     for i in bad:
         off = 214 if slots[i, 214:252].tolist() == y else 244

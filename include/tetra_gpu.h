@@ -506,11 +506,12 @@ void tgpu_sync_multi_free(struct tgpu_sync_multi *st);
  *   tgpu_sync_multi_collect() waits for the batch and fills out[nchan] like tgpu_sync_multi_finish() does (events without
  *   TGPU_EV_BURST; release each with tgpu_sync_result_free()).  Where the device walk cannot settle a channel -- only the
  *   bytes can decide (a byte other than 0 / 1 near an exception, a sequence in the first 21 bytes of a search buffer, a
- *   re-lock off the grid, a window beyond the kernel's view: feeds of 128 / 256 bytes), or a channel of up to 262 144
- *   grid slots has more than 8192 exceptions -- the batch is redone through the host walks and decoded again before the
- *   call returns: same results (tgpu_sync_dev_fellback() tells).  A channel of more than 262 144 slots (an hour of one
- *   carrier) is walked on the device as well, with its working arrays in a scratch area of the plan instead of LDS
- *   (k_walk_big: up to 8 such channels per batch, exceptions up to an eighth of the plan's slots).
+ *   re-lock off the grid, a window beyond the kernel's view: feeds of 128 / 256 bytes) -- the batch is redone through the
+ *   host walks and decoded again before the call returns: same results (tgpu_sync_dev_fellback() tells).  A channel of
+ *   more than 262 144 slots (an hour of one carrier) is walked on the device as well, with its working arrays in a scratch
+ *   area of the plan instead of LDS (k_walk_big: up to 8 such channels per batch, exceptions up to an eighth of the plan's
+ *   slots); so is a shorter one with more exceptions than the LDS form holds (8192: a noisy recording) -- from the second
+ *   batch on: the first one that overflows goes through the host walks and leaves the density it saw with the plan.
  * Plan capacity as above; the plan must stay untouched between launch and collect; several batches are kept in flight
  * with several plans.
  */

@@ -102,6 +102,7 @@ struct tgpu_plan {
 	void *d_walk_tmp;		/* hand-over area of the split walk */
 	uint8_t *d_walk_big;		/* scratch slots of k_walk_big (channels beyond TGW_WCAP bitmap words), on first need */
 	uint32_t walk_big_slots;
+	uint32_t walk_big_nodes;	/* nodes a channel of the LDS form had when it overflowed (0: never): sizes the long form's threshold */
 	uint32_t *d_bits_dev;		/* the delivered bitmap k_walk left in the upload arena */
 };
 
@@ -719,6 +720,28 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 	io->d_evbig = (tgpu_sync_event_rec_dev *)(p->d_walk + o_big);
 	io->d_recs = p->d_walk_recs;
 	return TGPU_OK;
+}
+
+/* A channel short enough for the LDS form of the walk can still have more exceptions than that form holds (TGW_NCAP: a noisy
+ * recording).  The batch it happens in goes through the host walks; the plan remembers the exception density it saw, and from
+ * then on channels that would overflow at that density take the long form (k_walk_big) from the start.
+ * tgpi_plan_walk_threshold(): channels of more than this many slots take the long form. */
+void tgpi_plan_walk_overflow(struct tgpu_plan *p, uint32_t nslots, uint32_t nnodes)
+{
+	if (!p || !nslots || !nnodes)
+		return;
+	/* slots at which this density reaches three quarters of TGW_NCAP */
+	uint64_t t = (uint64_t)nslots * (TGW_NCAP * 3 / 4) / nnodes;
+	if (t < 4096)
+		t = 4096;
+	if (!p->walk_big_nodes || t < p->walk_big_nodes)
+		p->walk_big_nodes = (uint32_t)t;
+}
+
+uint32_t tgpi_plan_walk_threshold(const struct tgpu_plan *p)
+{
+	const uint32_t cap = TGW_WCAP * 32u;
+	return p && p->walk_big_nodes && p->walk_big_nodes < cap ? p->walk_big_nodes : cap;
 }
 
 int tgpi_plan_walk_big(struct tgpu_plan *p, uint32_t nbig, struct tg_walk_io *io)

@@ -102,7 +102,8 @@ typedef struct { int32_t ev; uint32_t bitnum, arg; } tgpu_sync_event_rec_dev;	/*
  * events 0 .. TGW_EVEAGER - 1 of channel c at d_eager + c * TGW_EVEAGER (same block), the others at d_evbig + c * TGW_EVCAP */
 int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 	     uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
-	     uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp, void *stream);
+	     uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp,
+	     unsigned long long skip_mask /* channels left to tgk_walk_big */, void *stream);
 /* d_tmp != NULL: the split form (node pass as a grid-wide launch between two per-channel ones); TGW_TMP_BYTES of device memory */
 #define TGW_TMP_BYTES (1024u + 64u * (TGW_NCAP + TGW_WCAP + TGW_NCAP + 8u) * 4u)
 /* channels beyond TGW_WCAP words (recordings of more than 262 144 slots): k_walk_big, one workgroup each, with its working
@@ -163,6 +164,8 @@ struct tgpu_plan;
 int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struct tg_walk_io *io);
 /* scratch for k_walk_big: nbig slots at the plan's caps (allocated on the first batch that needs it); fills io->big's caps and io->d_big */
 int tgpi_plan_walk_big(struct tgpu_plan *p, uint32_t nbig, struct tg_walk_io *io);
+void tgpi_plan_walk_overflow(struct tgpu_plan *p, uint32_t nslots, uint32_t nnodes);
+uint32_t tgpi_plan_walk_threshold(const struct tgpu_plan *p);
 
 /* GSMTAP messages of a decoded batch (k_gsmtap); tg_tdma_time_dev = struct tetra_tdma_time */
 typedef struct { uint16_t hn; uint32_t sn, tn, fn, mn; } tg_tdma_time_dev;

@@ -3746,7 +3746,7 @@ struct tg_walk_tmp {
 };
 template <bool BIG, typename idx_t, int MODE>
 __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *nslot, idx_t *wpre, idx_t *Ja, idx_t *Jb, uint8_t *mark,
-					  const tg_walk_tmp tmp,
+					  const tg_walk_tmp tmp, const bool skip,
 					  tgw_rec *recs, tgpu_sync_event_rec_dev *ev_big, const uint32_t wcap, const uint32_t ncap,
 					  const uint32_t evcap, const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan,
 					  const tg_walk_root *__restrict__ roots, uint32_t chunk, uint32_t cshift,
@@ -3777,12 +3777,12 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	__syncthreads();
 	if (MODE == 1 && tid == 0)
 		tmp.meta[0] = 0xffffffffu;	/* until A and B are through: nothing for k_walk_nodes / MODE 2 to do */
-	if (!ncls || W > wcap) {	/* nothing classified (the host settles such a channel) or too long for this form's arrays */
+	if (!ncls || W > wcap || skip) {	/* nothing classified (the host settles such a channel), too long for this form's arrays, or left to the long form */
 		if (tid == 0) {
 			sum->nslots = sum->nevents = sum->tail_tn_adds = sum->burst_seq = 0;
 			sum->final_state = TGW_S_UNLOCKED;
 			sum->status = ncls ? TGW_FALLBACK : TGW_OK;
-			sum->why = ncls ? TGW_WHY_SIZE : 0;
+			sum->why = ncls ? TGW_WHY_SIZE : 0;	/* (k_walk_big overwrites this where it runs) */
 			sum->nnodes = 0;
 		}
 		return;
@@ -4082,7 +4082,8 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	    uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
 	    const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, uint32_t *__restrict__ g_bits2,
 	    tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager,
-	    tgpu_sync_event_rec_dev *__restrict__ g_evbig, tgw_rec *__restrict__ g_recs, uint8_t *__restrict__ d_tmp)
+	    tgpu_sync_event_rec_dev *__restrict__ g_evbig, tgw_rec *__restrict__ g_recs, uint8_t *__restrict__ d_tmp,
+	    unsigned long long skip_mask)
 {
 	extern __shared__ uint32_t s_dyn[];
 	uint32_t *bm = s_dyn;
@@ -4094,7 +4095,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	tg_walk_tmp tmp = { nullptr, nullptr, nullptr, nullptr };
 	if (MODE)
 		tmp = walk_tmp_small(d_tmp, c);
-	walk_body<false, uint16_t, MODE>(c, bm, nslot, wpre, Ja, Jb, mark, tmp, g_recs + (size_t)c * (TGW_NCAP + 1),
+	walk_body<false, uint16_t, MODE>(c, bm, nslot, wpre, Ja, Jb, mark, tmp, ((skip_mask >> c) & 1) != 0, g_recs + (size_t)c * (TGW_NCAP + 1),
 					 g_evbig + (size_t)c * TGW_EVCAP, TGW_WCAP, TGW_NCAP, TGW_EVCAP, d_base, chan, roots, chunk, cshift, g_cls,
 					 g_ysum, g_plain, g_bits, g_bits2, sums, g_eager);
 }
@@ -4117,7 +4118,7 @@ void k_walk_big(tg_walk_big big, uint8_t *__restrict__ scratch, const uint8_t *_
 	if (MODE)
 		tmp = walk_tmp_big(base, L, d_tmp, c);
 	walk_body<true, uint32_t, MODE>(c, (uint32_t *)(base + L.o_bm), (uint32_t *)(base + L.o_nslot), (uint32_t *)(base + L.o_wpre),
-					(uint32_t *)(base + L.o_ja), (uint32_t *)(base + L.o_jb), base + L.o_mark, tmp, (tgw_rec *)(base + L.o_recs),
+					(uint32_t *)(base + L.o_ja), (uint32_t *)(base + L.o_jb), base + L.o_mark, tmp, false, (tgw_rec *)(base + L.o_recs),
 					(tgpu_sync_event_rec_dev *)(base + L.o_ev), big.wcap, big.ncap, big.evcap, d_base, chan, roots, chunk,
 					cshift, g_cls, g_ysum, g_plain, g_bits, g_bits2, sums, g_eager);
 }
@@ -4193,7 +4194,8 @@ void k_walk_nodes(tg_walk_big big, uint8_t *__restrict__ scratch, uint8_t *__res
 
 extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 			uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
-			uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp, void *stream)
+			uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp,
+			unsigned long long skip_mask, void *stream)
 {
 	if (!nchan)
 		return 0;
@@ -4202,7 +4204,7 @@ extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 	const uint32_t cshift = (uint32_t)__builtin_ctz(chunk);
 	hipStream_t s = (hipStream_t)stream;
 #define WALK_ARGS d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums, \
-		  (tgpu_sync_event_rec_dev *)d_eager, (tgpu_sync_event_rec_dev *)d_evbig, (tgw_rec *)d_recs, (uint8_t *)d_tmp
+		  (tgpu_sync_event_rec_dev *)d_eager, (tgpu_sync_event_rec_dev *)d_evbig, (tgw_rec *)d_recs, (uint8_t *)d_tmp, skip_mask
 	if (!d_tmp) {
 		HIPCHK(hipFuncSetAttribute((const void *)k_walk<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
 		hipLaunchKernelGGL(k_walk<0>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);

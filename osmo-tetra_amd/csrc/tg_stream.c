@@ -1539,14 +1539,20 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			rc = tgpi_plan_dev_stage1(plan, st->ngrid, nchan, io->d_tab, io->d_codes, d_plain, &d_bits, stream, evs != NULL,
 						  evs ? (void **)(evs + 3) : NULL);
 		}
+		/* channels of more than 262 144 slots -- or of fewer, once the plan has seen the LDS form overflow with exceptions
+		 * (tgpi_plan_walk_threshold) --: the same walk with its arrays in global memory, behind the first */
+		struct tg_walk_big big = { 0 };
+		unsigned long long skip = 0;
+		const uint32_t thr = tgpi_plan_walk_threshold(plan);
+		for (uint32_t c = 0; c < nchan && big.n < TGW_BIG_MAX; c++)
+			if (st->ent[c].ncls > thr) {
+				big.chan[big.n++] = c;
+				skip |= 1ull << c;
+			}
 		if (!rc)
 			rc = tgk_walk(d_base, io->d_tab, io->d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, io->d_bits2, io->d_sums,
-				      io->d_eager, io->d_evbig, io->d_recs, getenv("TGPU_WALK_MONO") ? NULL : io->d_tmp, stream);
-		if (!rc) {	/* channels of more than 262 144 slots: the same walk with its arrays in global memory, behind the first */
-			struct tg_walk_big big = { 0 };
-			for (uint32_t c = 0; c < nchan && big.n < TGW_BIG_MAX; c++)
-				if (((uint64_t)st->ent[c].ncls + 31) / 32 > TGW_WCAP)
-					big.chan[big.n++] = c;
+				      io->d_eager, io->d_evbig, io->d_recs, getenv("TGPU_WALK_MONO") ? NULL : io->d_tmp, skip, stream);
+		if (!rc) {
 			if (big.n) {
 				rc = tgpi_plan_walk_big(plan, big.n, io);
 				io->big.n = big.n;
@@ -1617,8 +1623,11 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 		return rc;
 	int fb = 0;
 	for (uint32_t c = 0; c < st->nchan; c++)
-		if (st->ent[c].ncls && sd->io.h_sums[c].status != TGW_OK)
+		if (st->ent[c].ncls && sd->io.h_sums[c].status != TGW_OK) {
 			fb = 1;
+			if (sd->io.h_sums[c].why == TGW_WHY_NODES)	/* more exceptions than the LDS form holds: the long form next time */
+				tgpi_plan_walk_overflow(st->plan, st->ent[c].ncls, sd->io.h_sums[c].nnodes);
+		}
 	if (st->ngrid && sd->io.h_final[64])
 		fb = 1;		/* more scrambling codes in the batch than the device path's table holds */
 	if (getenv("TGPU_WALK_DEBUG"))

@@ -2514,3 +2514,33 @@ def test_device_walk_of_a_channel_beyond_one_workgroups_arrays(T, eng):
         assert pb.final_codes().tolist() == pa.final_codes().tolist()
     pa.close()
     pb.close()
+
+
+@pytest.mark.gpu
+def test_device_walk_takes_noisy_channels_into_the_long_form(T, eng):
+    """a channel short enough for the LDS form of the walk but with more exceptions than that form holds (150 000 slots, 8 %
+    damaged training sequences: > 8192 nodes): the first batch goes through the host walks (.fellback), the plan remembers
+    the density, and the next batches walk that channel in the long form on the device -- same outcome every time"""
+    import torch
+    import bench
+    hs = torch.cuda.current_stream().cuda_stream
+    st0, _, _ = bench.make_mix_stream(T, 150000, 6, mnc=71, cc=2, damaged=0.08)
+    st1, _, _ = bench.make_mix_stream(T, 4000, 7, mnc=72, cc=3)
+    streams = [np.ascontiguousarray(st0), np.ascontiguousarray(st1)]
+    d, offs, ntot = _multi_batch(T, streams)
+    pa, pb = T.Plan(eng, ntot, 2), T.Plan(eng, ntot, 2)
+    ms = T.MultiSync(eng, pa, streams, d.data_ptr(), offs, 64, hs)
+    ref = ms.finish(burst_events=False, nthreads=2)
+    ra = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    pa.execute(d.data_ptr(), ra.data_ptr(), hs)
+    torch.cuda.synchronize()
+    fell = []
+    for rep in range(3):
+        rb = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), 64, hs)
+        got = msd.collect()
+        fell.append(bool(msd.fellback))
+        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES), "noisy channel %d" % rep)
+    assert fell == [True, False, False], fell
+    pa.close()
+    pb.close()
