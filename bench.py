@@ -152,7 +152,19 @@ def cpu_baseline_stream(stream, budget_s=7.0):
             el = time.perf_counter() - t0
             rate = rx.burst_seq / el
             n = int(min(len(stream), max(n, rate * budget_s * 510)))
-        res[acc] = (rate, int(rx.burst_seq), el)
+        # a channel's stream is a second's worth of CPU work: further passes over it (a fresh receiver each) until the leg
+        # has run for about five seconds; the rate is bursts over time of all passes
+        nb, tt, passes = int(rx.burst_seq), el, 1
+        while acc == 1 and tt < 5.0 and n == len(stream):
+            rx = O.Rx()
+            lib.orc_rx_init(C.byref(rx), O.UPPER_CB(), O.EVENT_CB(), None)
+            rx.use_acc = acc
+            t0 = time.perf_counter()
+            lib.orc_rx_feed(C.byref(rx), O._p(piece), len(piece), 64)
+            tt += time.perf_counter() - t0
+            nb += int(rx.burst_seq)
+            passes += 1
+        res[acc] = (nb / tt, nb, tt, passes)
     # the same receiver on every usable host core at once (one recorded channel per thread, like the reference's one
     # process per channel): what the box's CPUs deliver together
     ncpu = host_threads_default()
@@ -176,7 +188,7 @@ def cpu_baseline_stream(stream, budget_s=7.0):
     except Exception as ex:      # pragma: no cover
         allc = {"error": repr(ex)}
     return {"value": res[1][0], "unit": "bursts/s", "cores": 1, "kind": "port", "all_cores": allc,
-            "sample": f"{res[1][1]} bursts delivered from the first {res[1][1] * 510 // 1000} kB of channel 0's stream (the bytes the GPU run had) in "
+            "sample": f"{res[1][1]} bursts delivered in {res[1][3]} pass(es) over the first {res[1][1] // res[1][3] * 510 // 1000} kB of channel 0's stream (the bytes the GPU run had), "
                       f"{res[1][2]:.1f} s: oracle/tetra_oracle.c receiver ({build}; synchroniser + demux + descramble + "
                       f"de-interleave + de-puncture + Viterbi + CRC, no callbacks / printing), 64-byte feeds, one thread, "
                       f"libosmocore's accelerated Viterbi restated (what osmo_conv_decode() dispatches N=4, K=5 to)",
