@@ -60,6 +60,7 @@ struct tgpu_plan {
 	int wire_only;		/* tgpu_plan_set_wire_only: the trellis kernels write the wire records only */
 	/* device */
 	uint8_t *d_up, *h_up;	/* upload arena (device / pinned host mirror): one copy per load */
+	uint8_t *d_up_dev;	/* small plans (up_mapped): the arena of device-walk batches, whose kernels run atomics on it -- device memory */
 	size_t up_bytes;
 	uint64_t *d_slot_off;	/* the next seven point into d_up, laid out per load */
 	uint32_t *d_slot_chan;
@@ -232,7 +233,9 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 		DALLOC(p->d_up, p->up_bytes);
 	DALLOC(p->d_packed, n * TG_PACKED_WORDS * 4);
 	DALLOC(p->d_maskidx, n * 4);
-	DALLOC(p->d_masks, (1 + (size_t)max_chan + n) * TG_MASK_WORDS * 4);
+	/* mask entries: 0 = the fixed code 3, 1 + c = channel c's carry-in code, then one per SYNC slot of a batch (<= n) or --
+	 * device-walk batches -- one per slot of the batch's code hash table (1 + nchan + h, h < TGK_LB_TBL), whatever n is */
+	DALLOC(p->d_masks, (1 + (size_t)max_chan + (n > TGK_LB_TBL ? n : TGK_LB_TBL)) * TG_MASK_WORDS * 4);
 	DALLOC(p->d_sb_ok, n * 4);
 	DALLOC(p->d_sb_code, n * 4);
 	DALLOC(p->d_block_tmp, ((n + 1023) / 1024 + 1) * sizeof(unsigned long long));
@@ -265,7 +268,7 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->side) (void)hipStreamDestroy(p->side);
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-	void *d[] = { p->up_mapped ? NULL : p->d_up, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
+	void *d[] = { p->up_mapped ? NULL : p->d_up, p->d_up_dev, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
 		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab, p->d_defer, p->d_walk, p->d_walk_recs,
 		      p->d_walk_big, p->d_walk_tmp };
 	for (size_t i = 0; i < sizeof(d) / sizeof(d[0]); i++)
@@ -541,7 +544,15 @@ int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, co
 		return TGPU_ECAPACITY;
 	const size_t nwords = ((size_t)ngrid + 31) / 32;
 	size_t o = 0;
-#define UP_AT(ptr, type, count) do { ptr = (type *)(p->d_up + o); \
+	/* counters, code table and okbits are the targets of device atomics (k_vit<SB1> LOOKBACK, k_cls_plain2, k_lists2): never
+	 * in mapped host memory (PCIe atomics are slow where they exist at all) -- a small plan gets a device arena for these batches */
+	uint8_t *base = p->d_up;
+	if (p->up_mapped) {
+		if (!p->d_up_dev)
+			HCHK(hipMalloc((void **)&p->d_up_dev, p->up_bytes));
+		base = p->d_up_dev;
+	}
+#define UP_AT(ptr, type, count) do { ptr = (type *)(base + o); \
 		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
 	uint32_t *d_cnt, *d_tbl, *d_ok, *d_bits, *d_prevw;
 	uint8_t *d_wchan;
@@ -573,7 +584,7 @@ int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, co
 	p->nslots = ngrid;
 	p->nchan = nchan;
 	hipStream_t s = (hipStream_t)stream;
-	HCHK(hipMemsetAsync(p->d_up, 0, zero_bytes, s));
+	HCHK(hipMemsetAsync(base, 0, zero_bytes, s));
 	int rc = tgk_cls_plain2(p->d_grid, ngrid, d_plain, p->d_list_sb, d_cnt, d_wchan, d_tab, nchan, stream);
 	if (rc)
 		return rc;

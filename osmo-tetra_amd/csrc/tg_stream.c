@@ -1526,7 +1526,7 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			rc = (int)hipMemcpyAsync(io->d_up0, io->h_up0, io->up_bytes, hipMemcpyHostToDevice, sd->stream);
 		}
 #define EVMARK(i) do { if (evs && !rc) rc = (int)hipEventRecord(evs[i], sd->stream); } while (0)
-		if (evs)
+		if (evs && !rc)		/* (armed only when the launch it is for follows: the caller destroys the event) */
 			tgk_front_stream_ev_start(evs[0]);
 		if (!rc)
 			rc = tgk_front_stream_multi(d_base, io->d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
@@ -1575,6 +1575,10 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 	if (!rc)
 		rc = (int)hipEventRecord(sd->done, sd->stream);
 	if (rc) {
+		/* stage 1 may have forked work onto the plan's side stream and part of the batch may be running: nothing of it may
+		 * outlive the objects freed here, and this thread's armed start event must not reach a later launch */
+		tgk_front_stream_ev_start(NULL);
+		(void)hipDeviceSynchronize();
 		tgpu_sync_dev_free(sd);
 		return rc;
 	}
@@ -1630,7 +1634,7 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 		}
 	if (st->ngrid && sd->io.h_final[64])
 		fb = 1;		/* more scrambling codes in the batch than the device path's table holds */
-	if (getenv("TGPU_WALK_DEBUG"))
+	if (st->ngrid && getenv("TGPU_WALK_DEBUG"))
 		for (uint32_t c = 0; c < st->nchan; c++)
 			fprintf(stderr, "k_walk channel %u: %u grid slots, %u nodes, status %u (why %u), %u delivered, %u events\n", c,
 				st->ent[c].ncls, sd->io.h_sums[c].nnodes, sd->io.h_sums[c].status, sd->io.h_sums[c].why, sd->io.h_sums[c].nslots,
@@ -1680,6 +1684,8 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 		o->grid_bits = malloc(nw * 4);
 		o->events = malloc((size_t)(s->nevents ? s->nevents : 1) * sizeof(*o->events));
 		if (!o->grid_bits || !o->events) {
+			for (uint32_t k = 0; k <= c; k++)	/* nothing half-filled is handed back with an error */
+				tgpu_sync_result_free(&out[k]);
 			rc = TGPU_ENOMEM;
 			break;
 		}
