@@ -224,6 +224,46 @@ int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_
 int tgpu_wire_pack(const uint8_t *rec, uint8_t *wire);
 
 /*
+ * Compact transport form of a batch ("cwire", csrc/tg_cwire.h): what a rank hands to the gather.  The 40-byte wire records
+ * exist for every grid slot; the collecting rank's upper MAC is handed delivered bursts only (phy/tetra_burst_sync.c:113-150)
+ * and acts on CRC-good blocks (tetra_upper_mac.c:480-488).  One buffer per batch: header, channel table, delivered bitmap,
+ * block table, then the delivered bursts' records back to back in grid order -- 16 header bits (burst type, the 14 BBK bits)
+ * + the type-1 bits: 36 bytes for NORM_1, 33 for NORM_2, 25 for SYNC; a burst with a flag or a failed CRC travels as its
+ * 40-byte wire record behind an escape byte (41).  33.5 bytes per delivered burst of the SB+NDB mix instead of 40 per grid slot.
+ *   tgpu_cwire_bound()      bytes a batch of ngrid slots in nchan channels can need at most (capacity for the calls below)
+ *   tgpu_plan_set_cwire()   device-walk batches (tgpu_sync_multi_launch) of this plan leave the compact form of their wire
+ *                           records (tgpu_plan_set_wire() must be set too) in d_cwire (16-byte aligned), enqueued behind
+ *                           the decode; tgpu_sync_dev_cwire_bytes() after tgpu_sync_multi_collect() = the bytes to send
+ *                           (0: no compact form was made -- no cwire buffer, an empty grid, or the batch fell back to the
+ *                           host walks, whose decode does not redo it: use tgpu_wire_compact() with the bitmap of the outcome)
+ *   tgpu_wire_compact()     the same for any batch: d_wire = ngrid 40-byte records, d_grid_bits = its delivered bitmap
+ *                           (device), channel c = grid slots gbase[c] .. gbase[c] + ncls[c] - 1 (gbase multiples of 32,
+ *                           ascending, <= 64 channels); d_total (optional, device): two words -- the bytes the batch needs
+ *                           and its delivered bursts (0xffffffff: cap was too small, the buffer holds no records).  Launches only.
+ *   tgpu_cwire_pack()       the host form (same bytes); returns the size or a negative TGPU_E* code
+ *   tgpu_cwire_info / _chan / _foreach / _expand: the reader the collecting rank runs on a received buffer (host): checks the
+ *                           header, per-channel counts, every delivered burst handed to a callback as its 40-byte wire
+ *                           record (grid order; tgpu_wire_unpack() makes the full record of it), or the whole grid's wire
+ *                           records rebuilt (0xff for undelivered slots) + the bitmap.  _foreach returns the bursts handed
+ *                           over or a negative code when the buffer does not parse.
+ */
+struct tgpu_cwire_info {
+	uint32_t nchan, ngrid, ndelivered;
+	uint64_t total_bytes;
+};
+typedef void (*tgpu_wire_cb)(const uint8_t *wire_rec, uint32_t grid_slot, void *priv);
+uint64_t tgpu_cwire_bound(uint32_t ngrid, uint32_t nchan);
+int tgpu_plan_set_cwire(struct tgpu_plan *plan, uint8_t *d_cwire /* NULL: off */, size_t cap_bytes);
+int tgpu_wire_compact(struct tgpu_engine *eng, const uint8_t *d_wire, const uint32_t *d_grid_bits, uint32_t ngrid, uint32_t nchan,
+		      const uint32_t *gbase, const uint32_t *ncls, uint8_t *d_cwire, size_t cap_bytes, uint32_t *d_total, void *hip_stream);
+int64_t tgpu_cwire_pack(const uint8_t *wire, const uint32_t *grid_bits, uint32_t ngrid, uint32_t nchan, const uint32_t *gbase,
+			const uint32_t *ncls, uint8_t *out, size_t cap_bytes);
+int tgpu_cwire_info(const uint8_t *cwire, size_t nbytes, struct tgpu_cwire_info *out);
+int tgpu_cwire_chan(const uint8_t *cwire, size_t nbytes, uint32_t chan, uint32_t *gbase, uint32_t *ncls, uint32_t *ndelivered);
+int64_t tgpu_cwire_foreach(const uint8_t *cwire, size_t nbytes, tgpu_wire_cb cb, void *priv);
+int tgpu_cwire_expand(const uint8_t *cwire, size_t nbytes, uint8_t *wire /* ngrid x 40 */, uint32_t *grid_bits /* optional */);
+
+/*
  * The gather itself, in C (north star: "RCCL only for the final decoded-block gather over xGMI"; the
  * reference has no counterpart -- it runs one process per channel).  One process per GPU.  Rank 0 (or any one rank)
  * draws an id with tgpu_comm_unique_id() and hands its TGPU_COMM_ID_BYTES bytes to the other ranks by whatever means
@@ -238,6 +278,11 @@ struct tgpu_comm;
 int tgpu_comm_unique_id(uint8_t id[TGPU_COMM_ID_BYTES]);
 int tgpu_comm_create(struct tgpu_engine *eng, const uint8_t id[TGPU_COMM_ID_BYTES], int rank, int world, struct tgpu_comm **out);
 int tgpu_comm_gather(struct tgpu_comm *comm, const void *d_send, size_t nbytes, void *d_recv, int root, void *hip_stream);
+/* the same with a size per rank (the compact form above): rank r's nbytes[r] bytes arrive at the root's d_recv + offs[r]; every
+ * rank passes its own size in nbytes[its rank], the root needs all of nbytes[] and offs[] (the other ranks may pass NULL offs).
+ * How the sizes reach the root is the job's business, like the id (they are known after tgpu_sync_multi_collect()). */
+int tgpu_comm_gatherv(struct tgpu_comm *comm, const void *d_send, const size_t *nbytes, void *d_recv, const size_t *offs, int root,
+		      void *hip_stream);
 void tgpu_comm_destroy(struct tgpu_comm *comm);
 
 /* diagnostic: copy the front kernel's packed slots (20 dwords per slot, csrc/tg_layout.h) of the
@@ -521,6 +566,7 @@ int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint
 int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *out);
 uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd);
 int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd);
+uint64_t tgpu_sync_dev_cwire_bytes(const struct tgpu_sync_dev *sd);	/* after collect; tgpu_plan_set_cwire() */
 void tgpu_sync_dev_free(struct tgpu_sync_dev *sd);
 /* measurement aid: one such batch, synchronously, with HIP events between all of its stages on hip_stream: dev_ms[] =
  * the stages in front of the decode (names: tgpu_sync_dev_stage_name), the decode's stages in prof / step as
@@ -534,7 +580,6 @@ const char *tgpu_sync_dev_stage_name(int stage);
  * callback, in grid order.  grid_bits = the delivered bitmap of the ngrid slots (NULL: every record that carries a burst
  * type); cb == NULL only counts.  Returns the number of records handed over.  tgpu_wire_noop_cb(): a callback that reads
  * the record's header and does nothing else (priv -> a uint64_t), for measurements. */
-typedef void (*tgpu_wire_cb)(const uint8_t *wire_rec, uint32_t grid_slot, void *priv);
 uint64_t tgpu_wire_foreach(const uint8_t *wire, const uint32_t *grid_bits, uint32_t ngrid, tgpu_wire_cb cb, void *priv);
 tgpu_wire_cb tgpu_wire_noop_cb(void);
 /* measurement aid, as tgpu_sync_front_prof() for a multi-channel batch */

@@ -70,6 +70,10 @@ class SyncResult(C.Structure):
                 ("grid_base", C.c_uint32)]
 
 
+class CwireInfo(C.Structure):
+    _fields_ = [("nchan", C.c_uint32), ("ngrid", C.c_uint32), ("ndelivered", C.c_uint32), ("total_bytes", C.c_uint64)]
+
+
 class MultiChan(C.Structure):
     _fields_ = [("h_stream", u8p), ("d_off", C.c_uint64), ("len", C.c_uint64), ("scramb_init", C.c_uint32)]
 
@@ -154,6 +158,21 @@ def lib():
     L.tgpu_comm_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
     L.tgpu_comm_destroy.argtypes = [C.c_void_p]
     L.tgpu_comm_destroy.restype = None
+    L.tgpu_comm_gatherv.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]
+    L.tgpu_cwire_bound.restype = C.c_uint64
+    L.tgpu_cwire_bound.argtypes = [C.c_uint32, C.c_uint32]
+    L.tgpu_plan_set_cwire.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.tgpu_wire_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, u32p, u32p, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_void_p]
+    L.tgpu_cwire_pack.restype = C.c_int64
+    L.tgpu_cwire_pack.argtypes = [u8p, u32p, C.c_uint32, C.c_uint32, u32p, u32p, u8p, C.c_size_t]
+    L.tgpu_cwire_info.argtypes = [u8p, C.c_size_t, C.POINTER(CwireInfo)]
+    L.tgpu_cwire_chan.argtypes = [u8p, C.c_size_t, C.c_uint32, u32p, u32p, u32p]
+    L.tgpu_cwire_foreach.restype = C.c_int64
+    L.tgpu_cwire_foreach.argtypes = [u8p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.tgpu_cwire_expand.argtypes = [u8p, C.c_size_t, u8p, u32p]
+    L.tgpu_sync_dev_cwire_bytes.restype = C.c_uint64
+    L.tgpu_sync_dev_cwire_bytes.argtypes = [C.c_void_p]
     L.tgpu_plan_execute_float_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.tgpu_prof_read.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.tgpu_stage_name.restype = C.c_char_p
@@ -322,6 +341,10 @@ class Plan:
     def set_wire_only(self, on=True):
         _chk(lib().tgpu_plan_set_wire_only(self._h, int(bool(on))), "tgpu_plan_set_wire_only")
 
+    def set_cwire(self, d_cwire_ptr, cap_bytes=0):
+        """device-walk batches of this plan leave the compact transport form of their wire records (set_wire() too) here"""
+        _chk(lib().tgpu_plan_set_cwire(self._h, C.c_void_p(d_cwire_ptr), cap_bytes), "tgpu_plan_set_cwire")
+
     def set_wire(self, d_wire_ptr):
         _chk(lib().tgpu_plan_set_wire(self._h, C.c_void_p(d_wire_ptr)), "tgpu_plan_set_wire")
 
@@ -363,6 +386,13 @@ class Comm:
         self.rank, self.world = rank, world
         uid = _np_u8(uid)
         _chk(lib().tgpu_comm_create(eng._h, uid.ctypes.data_as(u8p), rank, world, C.byref(self._h)), "tgpu_comm_create")
+
+    def gatherv(self, d_send_ptr, nbytes, d_recv_ptr, offs, root=0, hip_stream=0):
+        """a size per rank: rank r's nbytes[r] bytes arrive at the root's d_recv + offs[r]"""
+        nb = (C.c_size_t * len(nbytes))(*[int(x) for x in nbytes])
+        of = (C.c_size_t * len(nbytes))(*[int(x) for x in offs]) if offs is not None else None
+        _chk(lib().tgpu_comm_gatherv(self._h, C.c_void_p(d_send_ptr), nb, C.c_void_p(d_recv_ptr), of, root, C.c_void_p(hip_stream)),
+             "tgpu_comm_gatherv")
 
     def gather(self, d_send_ptr, nbytes, d_recv_ptr, root=0, hip_stream=0):
         _chk(lib().tgpu_comm_gather(self._h, C.c_void_p(d_send_ptr), nbytes, C.c_void_p(d_recv_ptr or 0), root,
@@ -756,6 +786,7 @@ class MultiSyncDev:
         try:
             _chk(lib().tgpu_sync_multi_collect(self._h, self._res), "tgpu_sync_multi_collect")
             self.fellback = bool(lib().tgpu_sync_dev_fellback(self._h))
+            self.cwire_bytes = int(lib().tgpu_sync_dev_cwire_bytes(self._h))
         finally:
             lib().tgpu_sync_dev_free(self._h)
             self._h = C.c_void_p()
@@ -799,6 +830,62 @@ def sync_multi_launch_prof(engine, plan, chans, d_base_ptr, d_rec_ptr, prof, ste
                                            C.c_void_p(hip_stream), prof._h, step, ms), "tgpu_sync_multi_launch_prof")
     lib().tgpu_sync_dev_stage_name.restype = C.c_char_p
     return {lib().tgpu_sync_dev_stage_name(i).decode(): float(ms[i]) for i in range(DEV_STAGES)}
+
+
+def cwire_bound(ngrid, nchan):
+    return int(lib().tgpu_cwire_bound(ngrid, nchan))
+
+
+def wire_compact(engine, d_wire_ptr, d_bits_ptr, ngrid, gbase, ncls, d_cwire_ptr, cap, d_total_ptr=0, hip_stream=0):
+    """tgpu_wire_compact: 40-byte wire records + delivered bitmap (device) -> the compact transport form (device)"""
+    gb, nc = np.ascontiguousarray(gbase, np.uint32), np.ascontiguousarray(ncls, np.uint32)
+    _chk(lib().tgpu_wire_compact(engine._h, C.c_void_p(d_wire_ptr), C.c_void_p(d_bits_ptr), ngrid, len(gb), gb.ctypes.data_as(u32p),
+                                 nc.ctypes.data_as(u32p), C.c_void_p(d_cwire_ptr), cap, C.c_void_p(d_total_ptr), C.c_void_p(hip_stream)),
+         "tgpu_wire_compact")
+
+
+def cwire_pack(wire, grid_bits, ngrid, gbase, ncls):
+    """tgpu_cwire_pack (host): the compact form of ngrid 40-byte wire records under a delivered bitmap, as a uint8 array"""
+    w, b = _np_u8(wire).reshape(-1), np.ascontiguousarray(grid_bits, np.uint32)
+    gb, nc = np.ascontiguousarray(gbase, np.uint32), np.ascontiguousarray(ncls, np.uint32)
+    out = np.zeros(cwire_bound(ngrid, len(gb)), np.uint8)
+    n = lib().tgpu_cwire_pack(w.ctypes.data_as(u8p), b.ctypes.data_as(u32p), ngrid, len(gb), gb.ctypes.data_as(u32p),
+                              nc.ctypes.data_as(u32p), out.ctypes.data_as(u8p), len(out))
+    if n < 0:
+        _chk(int(n), "tgpu_cwire_pack")
+    return out[:n].copy()
+
+
+def cwire_info(cw):
+    """header + per-channel (gbase, ncls, delivered) of a compact buffer (host array)"""
+    c = _np_u8(cw)
+    inf = CwireInfo()
+    _chk(lib().tgpu_cwire_info(c.ctypes.data_as(u8p), len(c), C.byref(inf)), "tgpu_cwire_info")
+    chans = []
+    for k in range(inf.nchan):
+        g, n, d = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _chk(lib().tgpu_cwire_chan(c.ctypes.data_as(u8p), len(c), k, C.byref(g), C.byref(n), C.byref(d)), "tgpu_cwire_chan")
+        chans.append((g.value, n.value, d.value))
+    return dict(nchan=inf.nchan, ngrid=inf.ngrid, ndelivered=inf.ndelivered, total_bytes=int(inf.total_bytes), chans=chans)
+
+
+def cwire_expand(cw):
+    """(wire records of the whole grid [ngrid, 40] with 0xff rows for undelivered slots, delivered bitmap) of a compact buffer"""
+    c = _np_u8(cw)
+    inf = cwire_info(c)
+    wire = np.empty((inf["ngrid"], WIRE_BYTES), np.uint8)
+    bits = np.zeros((inf["ngrid"] + 31) // 32, np.uint32)
+    _chk(lib().tgpu_cwire_expand(c.ctypes.data_as(u8p), len(c), wire.ctypes.data_as(u8p), bits.ctypes.data_as(u32p)), "tgpu_cwire_expand")
+    return wire, bits
+
+
+def cwire_count(cw):
+    """tgpu_cwire_foreach with no callback: parses every record, returns the number of delivered bursts"""
+    c = _np_u8(cw)
+    n = lib().tgpu_cwire_foreach(c.ctypes.data_as(u8p), len(c), None, None)
+    if n < 0:
+        _chk(int(n), "tgpu_cwire_foreach")
+    return int(n)
 
 
 def wire_foreach_noop(wire, grid_bits, ngrid):

@@ -14,9 +14,9 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libtetra_gpu.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
-HIP_SRCS = ["tg_kernels.hip"]
-C_SRCS = ["tg_host.c", "tg_sync.c", "tg_stream.c", "tg_synth.c", "tg_rm.c", "tg_conv.c", "tg_gsmtap.c", "tg_reorder.c", "tg_comm.c", "tg_stages.c"]
-HEADERS = ["tg_layout.h", "vit_core.h", "tg_internal.h", "tg_conv.h", os.path.join(ROOT, "include", "tetra_gpu.h")]
+HIP_SRCS = ["tg_kernels.hip", "tg_cwire.hip"]
+C_SRCS = ["tg_host.c", "tg_sync.c", "tg_stream.c", "tg_synth.c", "tg_rm.c", "tg_conv.c", "tg_gsmtap.c", "tg_reorder.c", "tg_comm.c", "tg_stages.c", "tg_cwire.c"]
+HEADERS = ["tg_layout.h", "vit_core.h", "tg_internal.h", "tg_conv.h", "tg_cwire.h", "tg_walk_core.h", os.path.join(ROOT, "include", "tetra_gpu.h")]
 
 
 def _newer(src_list, target):
@@ -33,27 +33,34 @@ def build(force=False, verbose=False):
     if not force and not _newer(srcs + hdrs + [os.path.abspath(__file__)], LIB):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
-    objs = []
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + os.path.join(ROCM, "include")]
+    hip_flags = os.environ.get("TGPU_HIPCC_FLAGS", "").split()     # experiment builds (-DTG_...=n)
+    cc_flags = os.environ.get("TGPU_CC_FLAGS", "").split()         # experiment builds of the host code
+    # an object is kept when it is newer than its source, every header and this recipe, and was built with the same flags
+    stamp = os.path.join(OBJ, "flags.txt")
+    flags_now = " ".join(hip_flags) + "|" + " ".join(cc_flags)
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flags_now
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
 
-    for s in HIP_SRCS:
-        o = os.path.join(OBJ, s + ".o")
-        run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"] + inc +
-            os.environ.get("TGPU_HIPCC_FLAGS", "").split() +    # experiment builds (-DTG_...=n)
-            ["-c", os.path.join(CSRC, s), "-o", o])
+    jobs, objs = [], []
+    for s in HIP_SRCS + C_SRCS:
+        src, o = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
         objs.append(o)
-    for s in C_SRCS:
-        o = os.path.join(OBJ, s + ".o")
-        run(["gcc", "-O3", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"] + inc +
-            os.environ.get("TGPU_CC_FLAGS", "").split() +       # experiment builds of the host code
-
-            ["-c", os.path.join(CSRC, s), "-o", o])
-        objs.append(o)
+        if not force and same_flags and not _newer([src] + hdrs + [os.path.abspath(__file__)], o):
+            continue
+        if s in HIP_SRCS:
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"] + inc + hip_flags + ["-c", src, "-o", o])
+        else:
+            jobs.append(["gcc", "-O3", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"] + inc + cc_flags +
+                        ["-c", src, "-o", o])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    open(stamp, "w").write(flags_now)
     run([hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lpthread", "-ldl"])
     return LIB
 

@@ -154,6 +154,29 @@ int tgpu_comm_gather(struct tgpu_comm *c, const void *d_send, size_t nbytes, voi
 	return (e == ncclSuccess && e2 == ncclSuccess) ? TGPU_OK : TGPU_ECOMM;
 }
 
+int tgpu_comm_gatherv(struct tgpu_comm *c, const void *d_send, const size_t *nbytes, void *d_recv, const size_t *offs, int root,
+		      void *hip_stream)
+{
+	if (!c || !nbytes || root < 0 || root >= c->world || (c->rank == root && (!d_recv || !offs)))
+		return TGPU_EINVAL;
+	if (nbytes[c->rank] && !d_send)
+		return TGPU_EINVAL;
+	int r = tgpi_engine_bind(c->eng);
+	if (r)
+		return r;
+	hipStream_t s = (hipStream_t)hip_stream;
+	/* a rank with nothing to send takes no part in the group (its zero is known to the root as well) */
+	ncclResult_t e = rc.group_start();
+	if (e == ncclSuccess && c->rank == root)
+		for (int p = 0; p < c->world && e == ncclSuccess; p++)
+			if (nbytes[p])
+				e = rc.recv((uint8_t *)d_recv + offs[p], nbytes[p], ncclUint8, p, c->comm, s);
+	if (e == ncclSuccess && nbytes[c->rank])
+		e = rc.send(d_send, nbytes[c->rank], ncclUint8, root, c->comm, s);
+	ncclResult_t e2 = rc.group_end();
+	return (e == ncclSuccess && e2 == ncclSuccess) ? TGPU_OK : TGPU_ECOMM;
+}
+
 void tgpu_comm_destroy(struct tgpu_comm *c)
 {
 	if (!c)

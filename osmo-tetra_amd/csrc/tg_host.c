@@ -74,6 +74,8 @@ struct tgpu_plan {
 	uint32_t *d_sb_ok, *d_sb_code;
 	unsigned long long *d_block_tmp;
 	uint8_t *d_wire;	/* caller-owned, optional */
+	uint8_t *d_cwire;	/* caller-owned, optional: compact form of a device-walk batch's wire records (tgpu_plan_set_cwire) */
+	size_t cwire_cap;
 	uint32_t *d_softarea;	/* max_slots * 512 B, allocated on the first soft execute */
 	uint32_t *d_grid;	/* stream mode: classification words + SYNC summaries, max_slots * 6 B, allocated on first use */
 	uint32_t *h_grid;	/* pinned host mirror of d_grid */
@@ -1250,6 +1252,31 @@ int tgpu_plan_set_wire_only(struct tgpu_plan *p, int on)
 		return TGPU_EINVAL;
 	p->wire_only = on ? 1 : 0;
 	return TGPU_OK;
+}
+
+int tgpu_plan_set_cwire(struct tgpu_plan *p, uint8_t *d_cwire, size_t cap)
+{
+	if (!p || ((uintptr_t)d_cwire & 15) || (d_cwire && cap < 4096) || cap > 0xfffffff0u)
+		return TGPU_EINVAL;
+	p->d_cwire = d_cwire;
+	p->cwire_cap = d_cwire ? cap : 0;
+	return TGPU_OK;
+}
+
+/* device-walk batches (tg_stream.c): the compact form of the batch's wire records behind its decode, if asked for */
+int tgpi_plan_cwire(struct tgpu_plan *p, const struct tg_cw_chans *ch, uint32_t *d_total, void *stream)
+{
+	if (!p || !ch)
+		return TGPU_EINVAL;
+	if (!p->d_cwire || !p->d_wire || !p->d_bits_dev || !p->nslots)
+		return TGPU_OK;
+	BIND(p->eng);
+	return tgk_cwire(p->d_wire, p->d_bits_dev, p->nslots, ch, p->d_cwire, (uint32_t)p->cwire_cap, d_total, stream);
+}
+
+int tgpi_plan_has_cwire(const struct tgpu_plan *p)
+{
+	return p && p->d_cwire && p->d_wire;
 }
 
 int tgpu_plan_set_wire(struct tgpu_plan *p, uint8_t *d_wire)

@@ -187,6 +187,7 @@ int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity);
 #define TGK_F_LOOKBACK 16	/* SB1 launch of a device-walk batch: d_sb_ok = okbits (bit per grid slot), d_sb_code = mask entry per slot, d_masks =
 				 * the code table (TGK_LB_TBL + 1 words), flags >> 8 = number of channels (tg_kernels.hip, k_lists2) */
 #define TGK_LB_TBL 4096u
+#define TGK_F_NT 32	/* record segments leave with non-temporal stores (whole segments only: the LDS-transposed forms) */
 #define TGK_F_DIRECT 4	/* SCH/F records written 16 bytes per lane instead of through the LDS transpose (A/B: TGPU_REC_DIRECT=1) */
 
 /* make the engine's device the calling thread's current HIP device (every allocating / launching entry point does) */
@@ -223,6 +224,17 @@ int tgk_lb_scan(const uint32_t *d_okbits, const uint32_t *d_dbits, const uint8_t
 int tgk_lists2(const uint32_t *d_cls, const uint32_t *d_dbits, uint32_t n, const uint32_t *d_okbits, const uint32_t *d_prevw,
 	       const uint8_t *d_word_chan, const uint32_t *d_slot_entry, uint32_t *d_maskidx, uint32_t *d_list_216,
 	       uint32_t *d_list_432, uint32_t *d_cnt, void *stream);
+/* compact transport form of a batch (tg_cwire.h / tg_cwire.hip): the delivered slots' 40-byte wire records -> one buffer of
+ * header, channel table, bitmap, block table and 25 / 33 / 36 (41) byte records; d_total (optional): two words, the bytes the
+ * batch needs and its delivered bursts (0xffffffff: cap was too small and no record was written) */
+struct tg_cw_chans {
+	uint32_t n;
+	uint32_t gbase[64], ncls[64];
+};
+int tgk_cwire(const uint8_t *d_wire, const uint32_t *d_bits, uint32_t ngrid, const struct tg_cw_chans *ch, uint8_t *d_out,
+	      uint32_t cap, uint32_t *d_total, void *stream);
+int tgpi_plan_cwire(struct tgpu_plan *p, const struct tg_cw_chans *ch, uint32_t *d_total, void *stream);
+int tgpi_plan_has_cwire(const struct tgpu_plan *p);
 /* stream mode with the walk on the device (tg_stream.c: tgpu_sync_multi_launch) */
 /* evs (optional, serial mode): HIP events recorded behind stage 1's three launches / stage 2's two */
 int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const struct tg_chan_ent *d_tab, uint32_t *d_codes,

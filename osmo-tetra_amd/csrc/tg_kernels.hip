@@ -1536,6 +1536,7 @@ __device__ __forceinline__ uint32_t field_msb(uint32_t lo, uint32_t hi, int sh, 
 #define FIELD_MSB(od, n0, len) field_msb((od)[(n0) >> 5], (od)[((n0) >> 5) + 1], (n0) & 31, (len))
 
 typedef uint32_t tg_v32 __attribute__((ext_vector_type(32)));
+typedef uint32_t tg_u32x4 __attribute__((ext_vector_type(4)));
 
 #define TG_STAGE_PITCH 20	/* dwords per lane in the record staging area: 16 + 4 (dwordx4 rows of neighbouring lanes in different banks) */
 
@@ -1636,7 +1637,11 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 			for (int i = 0; i < 4; i++) {
 				const uint32_t rr = (lane >> 2) + 16 * i;
 				const uint4 v = *(const uint4 *)(stage + rr * TG_STAGE_PITCH + 4 * (lane & 3));
-				*(uint4 *)(rec + (size_t)st_slot[rr] * TG_REC_BYTES + 64 * c + 16 * (lane & 3)) = v;
+				uint4 *dst = (uint4 *)(rec + (size_t)st_slot[rr] * TG_REC_BYTES + 64 * c + 16 * (lane & 3));
+				if (kflags & TGK_F_NT)		/* whole segments, never read again by this GPU: past the caches */
+					__builtin_nontemporal_store(*(const tg_u32x4 *)&v, (tg_u32x4 *)dst);
+				else
+					*dst = v;
 			}
 			__builtin_amdgcn_wave_barrier();
 		}
@@ -3422,6 +3427,13 @@ extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const
 	}
 	if (direct)
 		flags |= TGK_F_DIRECT;
+	static int nt = -1;
+	if (nt < 0) {
+		const char *e = getenv("TGPU_REC_NT");
+		nt = (e && atoi(e)) ? 1 : 0;
+	}
+	if (nt)
+		flags |= TGK_F_NT;
 	switch (kind) {
 	case TG_KIND_SB1:
 		if (hm == 2) VIT_LAUNCH(TG_KIND_SB1, 2); else if (hm) VIT_LAUNCH(TG_KIND_SB1, 1); else VIT_LAUNCH(TG_KIND_SB1, 0);

@@ -1389,6 +1389,8 @@ struct tgpu_sync_dev {
 	hipEvent_t done;
 	struct tg_walk_io io;	/* the batch's blocks: one copy up, one copy down */
 	int fellback;
+	int cwire;		/* the compact transport form was enqueued behind the decode (tgpu_plan_set_cwire) */
+	uint64_t cwire_bytes;	/* ... its size, known after collect */
 };
 
 void tgpu_sync_dev_free(struct tgpu_sync_dev *sd)
@@ -1568,6 +1570,18 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 #undef EVMARK
 		if (!rc)
 			rc = prof ? tgpu_plan_execute_prof(plan, d_base, d_rec, stream, prof, step) : tgpu_plan_execute(plan, d_base, d_rec, stream);
+		/* the compact transport form of the batch's wire records (tgpu_plan_set_cwire), its size into the block below */
+		if (!rc && tgpi_plan_has_cwire(plan)) {
+			struct tg_cw_chans cw;
+			memset(&cw, 0, sizeof(cw));
+			cw.n = nchan;
+			for (uint32_t c = 0; c < nchan; c++) {
+				cw.gbase[c] = st->ent[c].gbase;
+				cw.ncls[c] = st->ent[c].ncls;
+			}
+			sd->cwire = 1;
+			rc = tgpi_plan_cwire(plan, &cw, io->d_final + 66, stream);
+		}
 		/* what the host wants to know -- summaries, the first events of every channel, the bitmap -- in one copy */
 		if (!rc)
 			rc = (int)hipMemcpyAsync(io->h_down0, io->d_down0, io->down_bytes, hipMemcpyDeviceToHost, sd->stream);
@@ -1594,6 +1608,11 @@ uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd)
 int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd)
 {
 	return sd ? sd->fellback : 0;
+}
+
+uint64_t tgpu_sync_dev_cwire_bytes(const struct tgpu_sync_dev *sd)
+{
+	return sd ? sd->cwire_bytes : 0;
 }
 
 int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *out)
@@ -1717,6 +1736,12 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 	}
 	if (!rc && st->ngrid)
 		tgpi_plan_set_final_codes(st->plan, sd->io.h_final, st->nchan);
+	if (!rc && st->ngrid && sd->cwire) {
+		if (sd->io.h_final[67] == 0xffffffffu)
+			rc = TGPU_ECAPACITY;	/* the buffer given to tgpu_plan_set_cwire() is smaller than tgpu_cwire_bound() and this batch needed more */
+		else
+			sd->cwire_bytes = sd->io.h_final[66];
+	}
 	return rc;
 }
 
