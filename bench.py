@@ -266,8 +266,13 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     strm = [torch.cuda.Stream() for _ in range(D2)]
     gather = world > 1 or args.force_gather
     nccl = args.backend == "nccl"
-    state = {"fellback": 0, "ngrid": 0, "ccomm": None, "impl": None}
+    state = {"fellback": 0, "ngrid": 0, "ccomm": None, "impl": None, "sizes": None}
     wires = sink = None
+    compact = args.wire_form == "compact"
+    cwcap = (T.cwire_bound(cap, C) + 255) & ~255       # a rank's share of the sink, and the capacity of a compact buffer
+    cws = csink = cstream = gg = None                  # compact form: two buffers per plan, the sink, the exchange's own stream, the size group
+    pend = collections.deque()                         # compact form: steps whose sizes are on their way round the ranks
+    gdone = {}                                         # compact form: buffer -> event behind the gather that last read it
 
     def finish(ms):
         outs = ms.collect_end(raw=True)     # (collect_begin() has run: the batch's successor is launched in between)
@@ -290,6 +295,41 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             strm[j].synchronize()
             dist.gather(w.cpu(), gather_list=list(sink[j].view(world, -1)[:, :nbytes].unbind(0)) if rank == 0 else None, dst=0)
 
+    def post_compact(evs):
+        """the oldest pending step: its sizes have been round the ranks (control plane: the gloo group), now the payload --
+        every rank's compact buffer to rank 0, exact sizes, grouped RCCL send / receive on the exchange's own stream"""
+        work, szs, mine, buf, slot = pend.popleft()
+        work.wait()
+        sizes = [int(x.item()) for x in szs]
+        assert sizes[rank] == mine
+        state["sizes"], state["last_slot"] = sizes, slot
+        offs = [r * cwcap for r in range(world)]
+        if nccl and state["ccomm"] is not None:
+            state["ccomm"].gatherv(buf.data_ptr(), sizes, csink[slot].data_ptr() if rank == 0 else 0, offs if rank == 0 else None, 0,
+                                   cstream.cuda_stream)
+        else:       # torch.distributed.gather wants one size: padded to the largest (nccl: --torch-gather; gloo: staged through the host)
+            m = (max(sizes) + 15) & ~15
+            with torch.cuda.stream(cstream):
+                if nccl:
+                    dist.gather(buf[:m], gather_list=list(csink[slot].view(world, -1)[:, :m].unbind(0)) if rank == 0 else None, dst=0)
+                else:
+                    cstream.synchronize()
+                    dist.gather(buf[:m].cpu(), gather_list=list(csink[slot].view(world, -1)[:, :m].unbind(0)) if rank == 0 else None, dst=0)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(cstream)
+        gdone[buf.data_ptr()] = ev
+        evs.append(ev)          # the step is complete when its blocks are on the collecting rank
+
+    def start_compact(ms, buf, k, evs):
+        """a collected step: its compact size starts its way round the ranks (asynchronous); the step before it is posted"""
+        assert ms.fellback or ms.cwire_bytes > 0
+        mine = int(ms.cwire_bytes)
+        szs = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        work = dist.all_gather(szs, torch.tensor([mine], dtype=torch.int64), group=gg, async_op=True)
+        pend.append((work, szs, mine, buf, k & 1))
+        while len(pend) > 1:
+            post_compact(evs)
+
     def run(total, with_gather, D=D, S=None):
         """`total` steps back to back, at most D in flight; returns (delivered bursts per step, completion events)"""
         evs, fl, delivered = [], collections.deque(), []
@@ -299,21 +339,36 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             old = None
             if len(fl) == D:            # wait for the oldest batch and take its outcome out of the plan's buffers ...
                 old = fl.popleft()
-                old.collect_begin()
+                old[0].collect_begin()
             plans[j].set_wire(wires[j].data_ptr() if with_gather else 0)
-            fl.append(T.MultiSyncDev(eng, plans[j], None, d_base.data_ptr(), None, recs[j].data_ptr(), 64,
-                                     strm[j % S].cuda_stream, chans=chans))
-            if with_gather:
+            buf = None
+            if with_gather and compact:
+                buf = cws[j][(k // D) & 1]
+                if buf.data_ptr() in gdone:     # the gather that last read this buffer (2 D steps ago) must be through with it
+                    gdone.pop(buf.data_ptr()).synchronize()
+                plans[j].set_cwire(buf.data_ptr(), cwcap)
+            else:
+                plans[j].set_cwire(0)
+            fl.append((T.MultiSyncDev(eng, plans[j], None, d_base.data_ptr(), None, recs[j].data_ptr(), 64,
+                                      strm[j % S].cuda_stream, chans=chans), buf, k))
+            if with_gather and not compact:
                 exchange(j)
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record(strm[j % S])
-            evs.append(ev)
+            if not (with_gather and compact):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(strm[j % S])
+                evs.append(ev)
             if old is not None:         # ... its successor is on the stream: now look at what it delivered
-                delivered.append(finish(old))
+                if with_gather and compact:
+                    start_compact(old[0], old[1], old[2], evs)
+                delivered.append(finish(old[0]))
         while fl:
             old = fl.popleft()
-            old.collect_begin()
-            delivered.append(finish(old))
+            old[0].collect_begin()
+            if with_gather and compact:
+                start_compact(old[0], old[1], old[2], evs)
+            delivered.append(finish(old[0]))
+        while pend:
+            post_compact(evs)
         return delivered, evs
 
     def sync_all():
@@ -414,6 +469,11 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             wires = [torch.full((cap * T.WIRE_BYTES,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(D)]
             sink = [torch.empty(world * cap * T.WIRE_BYTES, dtype=torch.uint8, device="cuda" if nccl else "cpu")
                     for _ in range(D)] if rank == 0 else [None] * D
+            if compact:
+                cws = [[torch.zeros(cwcap, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(D)]
+                csink = [torch.zeros(world * cwcap, dtype=torch.uint8, device="cuda" if nccl else "cpu") for _ in range(2)] if rank == 0 else [None] * 2
+                cstream = torch.cuda.Stream()
+                gg = dist.new_group(backend="gloo") if nccl else None      # the sizes' way round the ranks (control plane)
             state["impl"] = "torch.distributed.gather (gloo, staged through the host)"
             if nccl and not args.torch_gather:
                 try:     # the library's communicator: rank 0 draws the id, the process group carries its 128 bytes
@@ -421,7 +481,9 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                     dist.broadcast(uid, 0)
                     torch.cuda.synchronize()
                     state["ccomm"] = T.Comm(eng, uid.cpu().numpy(), rank, world)
-                    state["impl"] = "tgpu_comm_gather (C ABI, grouped RCCL send / receive)"
+                    state["impl"] = ("tgpu_comm_gatherv (C ABI, grouped RCCL send / receive, a size per rank; the sizes go round the ranks "
+                                     "on a gloo group one step ahead of the payload)" if compact else
+                                     "tgpu_comm_gather (C ABI, grouped RCCL send / receive)")
                 except Exception as ex:      # pragma: no cover
                     state["ccomm"] = None
                     state["impl"] = "torch.distributed.gather (nccl); tgpu_comm_create failed: %r" % (ex,)
@@ -433,14 +495,22 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         armed[0] = False
         tmr.cancel()
     if gathered:
-        sent = cap * T.WIRE_BYTES
+        sent = max(state["sizes"]) if compact else cap * T.WIRE_BYTES
+        ref_ms = (single or decode_only)["ms_per_step"]
         gathered["exchange"] = state["impl"]
+        gathered["wire_form"] = ("compact (csrc/tg_cwire.h): delivered bursts only, 36 / 33 / 25 bytes per NORM_1 / NORM_2 / SYNC burst (41 with a flag or "
+                                 "a failed CRC) + the delivered bitmap; made on the device behind every step's decode (k_cw_*)" if compact else
+                                 "grid: one 40-byte wire record per grid slot")
         gathered["bytes_per_rank_and_step"] = sent
-        gathered["link_arithmetic"] = ("every peer sends %.1f MB per step (%d slots x %d B wire record) to rank 0 over its own xGMI "
-                                       "link: %.1f GB/s per link at the gathered step time (one xGMI link ~ 77 GB/s towards rank 0), "
-                                       "rank 0 takes in %.1f GB/s in total"
-                                       % (sent / 1e6, cap, T.WIRE_BYTES, sent / 1e6 / gathered["ms_per_step"],
-                                          (world - 1) * sent / 1e6 / gathered["ms_per_step"]))
+        if compact:
+            gathered["bytes_per_rank_and_step_all_ranks"] = state["sizes"]
+            gathered["bytes_per_delivered_burst"] = sent / (gathered["bursts_delivered_per_step"] / world)
+        gathered["link_arithmetic"] = ("every peer sends %.1f MB per step to rank 0 over its own xGMI link: %.1f GB/s per link at the "
+                                       "single-GPU step time (%.3f ms) = %.2f of the ~77 GB/s one direction of a link offers, %.1f GB/s "
+                                       "at the gathered step time; rank 0 takes in %.1f GB/s in total (the grid form would be %.1f MB: %.1f GB/s)"
+                                       % (sent / 1e6, sent / 1e6 / ref_ms, ref_ms, sent / 1e6 / ref_ms / 77.0, sent / 1e6 / gathered["ms_per_step"],
+                                          (world - 1) * sent / 1e6 / gathered["ms_per_step"], cap * T.WIRE_BYTES / 1e6,
+                                          cap * T.WIRE_BYTES / 1e6 / ref_ms))
     if rank != 0:
         return None
     hs = torch.cuda.current_stream().cuda_stream
@@ -448,6 +518,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
 
     # one more step, collected in full: the outcome of the timed path for the checks below
     plans[0].set_wire(wires[0].data_ptr() if gathered else 0)
+    if gathered and compact:
+        plans[0].set_cwire(cws[0][0].data_ptr(), cwcap)
     ms = T.MultiSyncDev(eng, plans[0], None, d_base.data_ptr(), None, recs[0].data_ptr(), 64, strm[0].cuda_stream, chans=chans)
     outs = ms.collect()
     torch.cuda.synchronize()
@@ -478,8 +550,16 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             assert good, "decoded records of channel %d differ from the oracle" % c
             nchk += len(first)
             if gathered:        # ... and what arrived on the collecting rank is this rank's share, byte for byte
-                w0 = sink[0].view(world, -1)[0].view(-1, T.WIRE_BYTES)
                 idx = torch.from_numpy(out["grid_base"] + first)
+                if compact:     # (the timed steps decoded the same recording: rank 0's share of the last gather is this step's buffer)
+                    if c == 0:
+                        got = csink[state["last_slot"]][:ms.cwire_bytes].cpu().numpy()
+                        mine_cw = cws[0][0][:ms.cwire_bytes].cpu().numpy()
+                        assert ms.cwire_bytes == state["sizes"][0] and (got == mine_cw).all()
+                        wgrid, _ = T.cwire_expand(got)
+                    w0 = torch.from_numpy(wgrid)
+                else:
+                    w0 = sink[0].view(world, -1)[0].view(-1, T.WIRE_BYTES)
                 assert torch.equal(w0[idx.to(w0.device)].cpu(), wires[0].view(-1, T.WIRE_BYTES)[idx.cuda()].cpu())
                 back = T.wire_unpack(w0[idx.to(w0.device)].cpu().numpy(), (out["grid_base"] + first).tolist(), [codes[c]] * len(first))
                 pw = T.parse_records(back)
@@ -968,6 +1048,9 @@ def main():
                          "soft-decision decode; conv: the generic trellis kernel")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the exchange phase with a single rank too (exercises the RCCL path on a 1-GPU box)")
+    ap.add_argument("--wire-form", default="compact", choices=["compact", "grid"],
+                    help="what a rank hands to the gather: the compact form (delivered bursts only, csrc/tg_cwire.h) or one 40-byte "
+                         "wire record per grid slot")
     ap.add_argument("--torch-gather", action="store_true",
                     help="N > 1: exchange through torch.distributed.gather instead of the library's tgpu_comm_gather")
     ap.add_argument("--gather-timeout", type=int, default=150,

@@ -148,6 +148,8 @@ void k_cw_scan(uint32_t *__restrict__ out, tg_cw_chans ch, uint32_t ngrid, uint3
 		out[5] = L.o_bits;
 		out[6] = L.o_blk;
 		out[7] = L.o_rec;
+		for (uint32_t i = L.o_blk / 4 + 2 * (L.nblk + 1); i < L.o_rec / 4; i++)
+			out[i] = 0;			/* (the pad in front of the records) */
 		if (total_out) {
 			total_out[0] = (uint32_t)total;	/* the bytes the batch needs, whether they fit or not */
 			total_out[1] = fits ? cc : 0xffffffffu;

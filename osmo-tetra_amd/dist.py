@@ -34,3 +34,23 @@ def gather_wire(local, dst=0, group=None, async_op=False, out=None):
         out = None
     work = dist.gather(local, gather_list=out, dst=dst, group=group, async_op=async_op)
     return out, work
+
+
+def gather_compact(local, nbytes, dst=0, group=None):
+    """Gather the ranks' compact buffers (csrc/tg_cwire.h: a different size per rank and step) to `dst`.
+
+    local: uint8 tensor holding this rank's buffer in its first nbytes bytes.  The sizes go round the ranks first
+    (all_gather of one int64: the job's control plane), then every rank sends its buffer padded to the largest --
+    torch.distributed.gather wants one size; the product's tgpu_comm_gatherv() sends exact sizes.  Returns
+    (sizes, list of tensors trimmed to their size) on `dst`, (sizes, None) elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    szs = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(szs, torch.tensor([int(nbytes)], dtype=torch.int64), group=group)
+    sizes = [int(x.item()) for x in szs]
+    m = (max(sizes) + 15) & ~15
+    send = torch.zeros(m, dtype=torch.uint8, device=local.device)
+    send[:nbytes] = local[:nbytes]
+    out = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, gather_list=out, dst=dst, group=group)
+    return sizes, ([o[:n] for o, n in zip(out, sizes)] if rank == dst else None)

@@ -20,10 +20,17 @@ def _line(cmd):
     return json.loads(p.stdout.strip().splitlines()[-1])
 
 
-def test_bench_two_ranks_over_gloo_on_one_gpu():
+@pytest.mark.parametrize("form", ["compact", "grid"])
+def test_bench_two_ranks_over_gloo_on_one_gpu(form):
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29533", "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "2",
-               "--windows", "2", "--bursts", "64000"])
+               "--master-port", "29533" if form == "compact" else "29534", "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4",
+               "--warmup", "2", "--windows", "2", "--bursts", "64000", "--wire-form", form])
+    assert d["gathered"]["wire_form"].startswith(form)
+    per_rank = d["gathered"]["bursts_delivered_per_step"] / 2
+    if form == "compact":       # delivered bursts only, ~33.5 bytes each (+ bitmap and tables), against 40 per grid slot
+        assert d["gathered"]["bytes_per_rank_and_step"] < 35.5 * per_rank and len(d["gathered"]["bytes_per_rank_and_step_all_ranks"]) == 2
+    else:
+        assert d["gathered"]["bytes_per_rank_and_step"] >= 40 * 64000
     assert d["n_gpus"] == 2 and d["metric"] == "decoded bursts/s" and d["scaling"] == "weak" and d["steps"] == 4
     for k in ("decode_only", "gathered", "single_gpu_reference", "per_gpu_efficiency", "roofline", "timing"):
         assert k in d, k
@@ -34,9 +41,11 @@ def test_bench_two_ranks_over_gloo_on_one_gpu():
     assert len(d["timing"]["windows_ms_per_step"]) == 2
 
 
-def test_bench_single_rank_with_the_rccl_gather():
+@pytest.mark.parametrize("form", ["compact", "grid"])
+def test_bench_single_rank_with_the_rccl_gather(form):
     d = _line([sys.executable, "bench.py", "--force-gather", "--steps", "4", "--warmup", "2", "--windows", "2", "--bursts", "64000",
-               "--no-secondary", "--no-e2e"])
-    assert d["n_gpus"] == 1 and "tgpu_comm_gather" in d["gathered"]["exchange"]
+               "--no-secondary", "--no-e2e", "--wire-form", form])
+    assert d["n_gpus"] == 1 and ("tgpu_comm_gatherv" if form == "compact" else "tgpu_comm_gather (") in d["gathered"]["exchange"]
+    assert d["gathered"]["wire_form"].startswith(form)
     assert "collecting rank" in d["config"]["check"] and d["cpu_baseline"]["value"] > 0
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0

@@ -76,6 +76,76 @@ def _worker(rank, world, port, nchan, nslots, q):
     dist.destroy_process_group()
 
 
+def _delivered(chan, nslots):
+    """which slots of a channel count as delivered in the compact-form test (a run of lost bursts per channel)"""
+    d = np.ones(nslots, bool)
+    d[5 + chan:9 + chan] = False
+    d[nslots - 1 - chan % 3] = False
+    return d
+
+
+def _worker_compact(rank, world, port, nchan, nslots, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = tdist.shard_channels(nchan, rank, world)
+    # the rank's batch: its channels' grids one after the other (each padded to a multiple of 32 slots), the delivered
+    # bitmap, and the compact form of both -- what k_cw_* leave on a GPU rank (tgpu_cwire_pack is their host form)
+    pad = (nslots + 31) & ~31
+    n = max(hi - lo, 1)
+    wire = np.full((n * pad, T.WIRE_BYTES), 0xFF, np.uint8)
+    bits = np.zeros(n * pad // 32, np.uint32)
+    for k, c in enumerate(range(lo, hi)):
+        wire[k * pad:k * pad + nslots] = _real_wire(c, nslots)
+        idx = k * pad + np.flatnonzero(_delivered(c, nslots))
+        np.bitwise_or.at(bits, idx >> 5, np.uint32(1) << (idx & 31).astype(np.uint32))
+    cw = T.cwire_pack(wire, bits, n * pad, [k * pad for k in range(hi - lo)] or [0], [nslots] * (hi - lo) or [0])
+    sizes, got = tdist.gather_compact(torch.from_numpy(cw), len(cw), dst=0)
+    if rank == 0:
+        q.put((sizes, [g.numpy() for g in got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_gather_of_compact_buffers_world2():
+    """the compact transport form through a world-2 gather: every rank's buffer has its own size (different channel
+    counts, different losses); the collecting rank reads the headers, gets exactly the delivered bursts back, and their
+    records are the oracle's decode"""
+    T.build_library()
+    nchan, nslots, world = 5, 40, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_compact, args=(r, world, port, nchan, nslots, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    sizes, got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(set(sizes)) == 2 and all(len(g) == n for g, n in zip(got, sizes))
+    pad = (nslots + 31) & ~31
+    nesc = 0
+    for r in range(world):
+        lo, hi = tdist.shard_channels(nchan, r, world)
+        inf = T.cwire_info(got[r])
+        assert inf["nchan"] == hi - lo and inf["total_bytes"] == sizes[r]
+        wire, bits = T.cwire_expand(got[r])
+        assert T.cwire_count(got[r]) == inf["ndelivered"] == sum(int(_delivered(c, nslots).sum()) for c in range(lo, hi))
+        for k, c in enumerate(range(lo, hi)):
+            rec, code = _channel_records(c, nslots)
+            d = _delivered(c, nslots)
+            assert inf["chans"][k] == (k * pad, nslots, int(d.sum()))
+            w = wire[k * pad:k * pad + nslots]
+            assert (w[~d] == 0xFF).all()
+            back = T.wire_unpack(w[d], slot_ids=np.flatnonzero(d), codes=np.full(int(d.sum()), code, np.uint32))
+            assert (back[:, :16] == rec[d][:, :16]).all() and (back[:, 28:] == rec[d][:, 28:]).all()
+            nesc += int((T.parse_records(back)["crc_ok"][:, 0] == 0).sum())
+        # less than the grid form, and the good bursts at their short size
+        assert sizes[r] < (hi - lo) * nslots * T.WIRE_BYTES
+    assert nesc > 0
+
+
 def test_shard_channels_partition():
     for nchan in (1, 7, 8, 64, 65):
         for world in (1, 2, 3, 8):
