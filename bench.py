@@ -12,12 +12,17 @@ pass of the whole path over all of a GPU's channels as ONE batch, enqueued by ON
 training-sequence search + demux/de-interleave of every grid slot, the reference's synchroniser walk of every channel
 ON THE GPU (k_walk, tetra_burst_sync_in() semantics at 64-byte feeds), device-built lists, SB1 -> code fill -> masks ->
 both trellis kernels; records stay in HBM.  value counts DELIVERED bursts (what tetra_burst_rx_cb() would have been
-handed), not grid slots.  One host thread per GPU keeps `--depth` steps in flight.
+handed), not grid slots.  One host thread per GPU keeps `--depth` (8) steps in flight, each on a stream of its own, all
+of a batch's kernels on that one stream (tgpu_plan_set_side_stream(plan, 0)): the HIP runtime multiplexes a process's
+streams onto four hardware queues, and a batch that is split over two streams spreads the batches unevenly over them
+(round 4; `round3_form` in the line is the old arrangement measured beside it).
 
-Timing (round 3): ONE continuous run of warm-up + windows x K steps + tail; a window = completion of step w ->
-completion of step w + K (HIP events behind every step's last operation), i.e. exactly K classifications, K walks and K
-decodes complete inside it; ms_per_step = the median window, the list is in the line (timing.windows_ms_per_step),
-next to the contract's own form (K steps between two synchronisations, ramp-up and drain included).
+Timing: ONE continuous run of warm-up + windows x K steps + tail; a HIP event behind every step's last operation.
+Batches in flight share the GPU and complete in bunches, so a window boundary is the MEAN completion time of the D most
+recent steps (D = steps in flight): window r = (boundary(w + (r + 1) K) - boundary(w + r K)) / K, exactly K classifications,
+K walks and K decodes per window whatever the phase of the bunches; ms_per_step = the median window; the windows, the
+same windows without the averaging and the contract's own form (K steps between two synchronisations, ramp-up and drain
+included) are all in the line (timing.*).
 
 The JSON line also carries
   roofline     : the dominant kernel's algorithmic bytes / its HIP-event duration vs HBM peak (+ PMC traffic)
@@ -28,8 +33,9 @@ The JSON line also carries
   breakdown_ms : host CPU per step (process_time), the per-kernel HIP-event durations
   config2      : BASELINE configs[1] (1 M aligned NDB bursts, no sync front end) as a secondary measurement
   N > 1        : single_gpu_reference (rank 0 alone, same job), decode_only and gathered (every step's 40-byte wire
-                 records to rank 0 through the library's tgpu_comm_gather, RCCL, on the step's stream; under a
-                 watchdog), per_gpu_efficiency of both; value = the gathered rate
+                 blocks to rank 0 in the compact transport form -- delivered bursts only, csrc/tg_cwire.h -- through the
+                 library's tgpu_comm_gatherv, RCCL, on a stream of its own; under a watchdog), per_gpu_efficiency of
+                 both; value = the gathered rate
 --workload config5 | conv | config2: the other BASELINE configs / the generic trellis (own roofline, cpu_baseline).
 """
 import argparse
@@ -258,10 +264,14 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     d_base = torch.from_numpy(buf).cuda()
     cap = sum(len(st) // 510 + 32 for st in streams)
     D = max(2, args.depth)
-    K, R, W = args.steps, max(1, args.windows), max(args.warmup, 6 * D)     # (the first ~20 steps of a run are 4 % slower: clocks, queues filling)
+    K, R, W = args.steps, max(1, args.windows), max(args.warmup, 6 * D) + D     # (the first ~20 steps of a run are 4 % slower: clocks, queues filling)
     chans = T.multi_chan_table(streams, offs)         # carry-in codes 0: every cell's code is learnt from SB1 inside the batch
-    D2 = 8 if (world == 1 and not args.no_secondary and D < 8) else D       # the deeper pipeline measured beside the headline
+    D2 = D
     plans = [T.Plan(eng, cap, C) for _ in range(D2)]
+    # every batch on ONE stream (= one hardware queue): with several batches in flight the plans' side streams spread the batches
+    # unevenly over the runtime's four hardware queues (tgpu_plan_set_side_stream; DESIGN.md section 5 has the A/B)
+    for p_ in plans:
+        p_.set_side_stream(args.side_stream)
     recs = [torch.empty(cap * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D2)]
     strm = [torch.cuda.Stream() for _ in range(D2)]
     gather = world > 1 or args.force_gather
@@ -377,7 +387,9 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             dist.barrier()
             torch.cuda.synchronize()
 
-    def measure(with_gather, alone=False, D=D, W=W, S=None, K=K, R=R):
+    S0 = min(D, args.streams) if args.streams else None
+
+    def measure(with_gather, alone=False, D=D, W=W, S=S0, K=K, R=R):
         """one continuous run of W + R K + D steps (the pipeline stays full before, through and after the timed steps);
         window r = completion of step W - 1 + r K  ->  completion of step W - 1 + (r + 1) K: exactly K classifications,
         K walks, K decodes (and K exchanges) complete inside it.  Plus the contract's form: K steps between two
@@ -396,10 +408,17 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             gc.enable()
         torch.cuda.synchronize()
         cpu_s, wall_s, thr_s = time.process_time() - c0, time.perf_counter() - t0, time.thread_time() - h0
-        tk = [evs[W - 1].elapsed_time(e) for e in evs[W - 1:]]
+        base = W - 1 - (D - 1)
+        tk = [evs[base].elapsed_time(e) for e in evs[base:]]
         for i in range(1, len(tk)):               # (steps run on D streams: completion times are made monotone)
             tk[i] = max(tk[i], tk[i - 1])
-        win = [(tk[(r + 1) * K] - tk[r * K]) / K for r in range(R)]
+        raw = [(tk[D - 1 + (r + 1) * K] - tk[D - 1 + r * K]) / K for r in range(R)]
+        # steps complete in bunches (the D batches in flight share the GPU and finish together): a window boundary is the MEAN
+        # completion time of the D most recent steps -- the D spans of K steps that end in a boundary start at all D phases of
+        # the pattern once, so the estimate does not depend on where in a bunch the window happens to be cut
+        sm = [sum(tk[i - D + 1:i + 1]) / D for i in range(D - 1, len(tk))]
+        win = [(sm[(r + 1) * K] - sm[r * K]) / K for r in range(R)]
+        tk = tk[D - 1:]
         if os.environ.get("BENCH_STEP_TIMES"):
             print("step completion deltas (ms), depth %d:" % D, [round(tk[i + 1] - tk[i], 3) for i in range(min(48, len(tk) - 1))], file=sys.stderr)
         per_step = delivered[W]
@@ -424,7 +443,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         else:
             tot = per_step
         med = _median(win)
+        if world > 1 and not alone:
+            t = torch.tensor(raw, dtype=torch.float64, device="cuda" if nccl else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            raw = t.tolist()
         return {"value": tot / (med * 1e-3), "ms_per_step": med, "windows_ms_per_step": [round(x, 5) for x in win],
+                "unsmoothed_windows_ms_per_step": [round(x, 5) for x in raw],
                 "window_spread": (max(win) - min(win)) / med, "all_windows_ms_per_step": (tk[R * K] - tk[0]) / (R * K),
                 "sync_bracketed_ms_per_step": bracket, "bursts_delivered_per_step": tot,
                 "host_cpu_ms_per_step": cpu_s / (W + R * K + D) * 1e3, "host_wall_ms_per_step": wall_s / (W + R * K + D) * 1e3,
@@ -438,11 +462,14 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             single = measure(False, alone=True)
         sync_all()
     decode_only = measure(False)
-    # (8 plans on 4 streams -- S=4 -- give the same rate and the same 8-step completion pattern as 8 streams: the pattern is the
-    # GPU's interleaving of four concurrent batches, and 20-step windows cut it at two different phases)
-    # its windows are 5 x D2 steps long: batches then complete in a repeating D2-step pattern, and windows of the contract's 20
-    # steps would cut that pattern at two different phases (they alternate 0.405 / 0.45 ms)
-    deeper = measure(False, D=D2, W=max(W, 5 * D2), K=5 * D2, R=4) if D2 > D else None
+    # the round-3 form beside it: four batches in flight, each plan's side stream in play
+    r3form = None
+    if world == 1 and not args.no_secondary and not args.side_stream:
+        for p_ in plans:
+            p_.set_side_stream(True)
+        r3form = measure(False, D=min(4, D))
+        for p_ in plans:
+            p_.set_side_stream(False)
     gathered = gather_error = None
     if gather:
         armed = [True]
@@ -669,11 +696,13 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                       "parallelism": "channels sharded over GPUs (%d per GPU), no collective in decoding" % C +
                                      ("; one gather of wire records per step to rank 0, on the step's stream" if gathered else ""),
                       "check": check},
-           "timing": {"method": "one continuous run of %d warm-up steps + %d x %d steps + tail with %d steps in flight; ms_per_step = median over "
-                                "the %d windows of (completion of step w + K) - (completion of step w) / K from HIP events recorded "
-                                "behind each step's last operation: exactly K classifications, K walks, K decodes complete inside "
-                                "a window; max over ranks per window" % (W, R, K, D, R),
+           "timing": {"method": "one continuous run of %d warm-up steps + %d x %d steps + tail with %d steps in flight; a HIP event behind each "
+                                "step's last operation; window boundary = mean completion time of the %d most recent steps (batches in flight "
+                                "complete in bunches: the mean makes a window independent of where in a bunch it is cut), window = (boundary "
+                                "K steps later - boundary) / K: exactly K classifications, K walks, K decodes per window; ms_per_step = median "
+                                "over the %d windows; max over ranks per window" % (W, R, K, D, D, R),
                       "windows_ms_per_step": head["windows_ms_per_step"], "window_spread": head["window_spread"],
+                      "windows_ms_per_step_without_the_averaging": head["unsmoothed_windows_ms_per_step"],
                       "all_windows_ms_per_step": head["all_windows_ms_per_step"],
                       "sync_bracketed_ms_per_step (K steps between two synchronisations, ramp-up and drain included)": head["sync_bracketed_ms_per_step"],
                       "front_end_launches_per_window": K},
@@ -692,12 +721,11 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                                 "region; traffic = PMC bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes) and "
                                 "valu_busy_frac from profiles/traffic.json of the same command; every kernel of this path is bound by "
                                 "vector-instruction issue, not by HBM (DESIGN.md section 4)"}}
-    if deeper:
-        out["deeper_pipeline"] = {k_: deeper[k_] for k_ in ("value", "ms_per_step", "windows_ms_per_step", "window_spread", "all_windows_ms_per_step")}
-        out["deeper_pipeline"].update({"steps_in_flight": D2, "note": "the same measurement with %d batches in flight on %d streams (the runtime's 4 hardware queues then hold "
-                                        "two batches each and none runs dry while the host collects and relaunches): a higher rate, but batches "
-                                        "complete in a repeating %d-step pattern which windows of the contract's 20 steps cut at two different phases, so the "
-                                        "headline stays at %d in flight; this object's windows are %d steps long" % (D2, D2, D2, D, 5 * D2)})
+    if r3form:
+        out["round3_form"] = {k_: r3form[k_] for k_ in ("value", "ms_per_step", "windows_ms_per_step", "window_spread", "all_windows_ms_per_step", "host_cpu_ms_per_step")}
+        out["round3_form"]["note"] = ("the same measurement as round 3 ran it: 4 batches in flight and the plans' side streams in play (k_vit<432> beside "
+                                      "k_vit<216>, the SB1 decode beside the walk): 12 streams on the runtime's 4 hardware queues, batches spread unevenly "
+                                      "over them; host_cpu_ms_per_step includes a runtime thread that spins on the cross-stream events")
     if e2e:
         out["end_to_end"] = e2e
     if gathered or gather_error:
@@ -1034,7 +1062,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20, help="K: steps per timed window")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--windows", type=int, default=6, help="mix: K-step windows inside the one continuous run (median reported)")
-    ap.add_argument("--depth", type=int, default=4, help="mix: steps in flight per GPU (plans / streams)")
+    ap.add_argument("--depth", type=int, default=8, help="mix: steps in flight per GPU (plans / streams)")
+    ap.add_argument("--side-stream", action="store_true", help="mix: keep the plans' side streams in play (the round-3 form)")
+    ap.add_argument("--streams", type=int, default=0, help="mix: streams the steps in flight run on (0 = one per step in flight; fewer: "
+                                                           "plan j runs on stream j %% streams)")
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts (slots) per GPU per step")
     ap.add_argument("--ber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

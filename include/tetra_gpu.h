@@ -220,6 +220,15 @@ int tgpu_plan_set_wire(struct tgpu_plan *plan, uint8_t *d_wire /* NULL: off */);
  * consumer that takes the packed form (the gather to a collecting rank; a host that unpacks with tgpu_wire_unpack())
  * does not need them.  d_rec is still passed to execute: slots of an ignored burst type get their 0xff type byte. */
 int tgpu_plan_set_wire_only(struct tgpu_plan *plan, int on);
+/*
+ * A plan owns a side stream: independent kernels of ONE batch run beside each other there (k_vit<432> beside k_vit<216>; in
+ * device-walk batches the SB1 decode beside the synchroniser walk), which shortens a single batch's latency.  A caller that
+ * keeps SEVERAL batches in flight on several streams is better off with off: each batch then lives on its caller's stream
+ * alone, i.e. on ONE hardware queue (the HIP runtime multiplexes all streams of a process onto 4 of them, and two streams
+ * that share a queue run one after the other) -- with the side streams in play the batches spread unevenly over the queues
+ * (bench.py, four batches in flight: 0.46 ms per step on, 0.42 off).  Default: on.
+ */
+int tgpu_plan_set_side_stream(struct tgpu_plan *plan, int on);
 int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_code, uint8_t *rec);
 int tgpu_wire_pack(const uint8_t *rec, uint8_t *wire);
 

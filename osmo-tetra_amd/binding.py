@@ -143,6 +143,7 @@ def lib():
     L.tgpu_plan_final_codes.argtypes = [C.c_void_p, C.c_void_p, u32p]
     L.tgpu_plan_execute_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_plan_set_wire_only.argtypes = [C.c_void_p, C.c_int]
+    L.tgpu_plan_set_side_stream.argtypes = [C.c_void_p, C.c_int]
     L.tgpu_plan_execute_float.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.tgpu_float_to_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tgpu_float_to_bits_afc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_float, C.c_float,
@@ -337,6 +338,9 @@ class Plan:
     def execute_prof(self, d_stream_ptr, d_rec_ptr, hip_stream, prof, step):
         _chk(lib().tgpu_plan_execute_prof(self._h, C.c_void_p(d_stream_ptr), C.c_void_p(d_rec_ptr),
                                           C.c_void_p(hip_stream), prof._h, step), "tgpu_plan_execute_prof")
+
+    def set_side_stream(self, on=True):
+        _chk(lib().tgpu_plan_set_side_stream(self._h, int(on)), "tgpu_plan_set_side_stream")
 
     def set_wire_only(self, on=True):
         _chk(lib().tgpu_plan_set_wire_only(self._h, int(bool(on))), "tgpu_plan_set_wire_only")

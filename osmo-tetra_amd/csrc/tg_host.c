@@ -58,6 +58,7 @@ struct tgpu_plan {
 	int last_burst;		/* the last execute took the workgroup-per-burst path (records carry a completion mark) */
 	int marks;		/* the owner keeps d_rec in mapped host memory and polls the marks (tgpi_plan_set_marks) */
 	int wire_only;		/* tgpu_plan_set_wire_only: the trellis kernels write the wire records only */
+	int no_side;		/* tgpu_plan_set_side_stream(plan, 0): everything of a batch on the caller's stream */
 	/* device */
 	uint8_t *d_up, *h_up;	/* upload arena (device / pinned host mirror): one copy per load */
 	uint8_t *d_up_dev;	/* small plans (up_mapped): the arena of device-walk batches, whose kernels run atomics on it -- device memory */
@@ -592,6 +593,7 @@ int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, co
 		return rc;
 	if (evs)
 		HCHK(hipEventRecord((hipEvent_t)evs[0], s));
+	serial = serial || p->no_side;
 	hipStream_t s2 = serial ? s : p->side;
 	if (!serial) {
 		HCHK(hipEventRecord(p->ev_fork, s));
@@ -621,6 +623,7 @@ int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, u
 	BIND(p->eng);
 	const uint32_t ngrid = p->nslots;
 	hipStream_t s = (hipStream_t)stream;
+	serial = serial || p->no_side;
 	if (!serial)
 		HCHK(hipStreamWaitEvent(s, p->ev_join, 0));
 	int rc = tgk_lb_scan(p->d_lb_ok, p->d_bits_dev, p->d_lb_wchan, (ngrid + 31) / 32, p->d_lb_prevw, d_tab, p->nchan, p->d_chan_code,
@@ -943,7 +946,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	/* the two trellis kernels do not depend on each other: unless per-stage timing was asked for,
 	 * k_vit<432> goes to a side stream (fork/join with events, still capturable) so that the tails
 	 * of the two launches overlap */
-	const int fork = (ev == NULL) && p->n216 && p->n432 && p->nslots > 4096;	/* (a small batch gains nothing from the side stream) */
+	const int fork = (ev == NULL) && !p->no_side && p->n216 && p->n432 && p->nslots > 4096;	/* (a small batch gains nothing from the side stream) */
 	if (fork) {
 		hipError_t e_ = hipEventRecord(p->ev_fork, (hipStream_t)stream);
 		if (e_ == hipSuccess)
@@ -1243,6 +1246,14 @@ int tgpu_prof_read(struct tgpu_prof *prof, uint32_t nsteps, float *ms)
 		for (int k = 0; k < TGPU_NSTAGES; k++)
 			HCHK(hipEventElapsedTime(&ms[(size_t)s * TGPU_NSTAGES + k], ev[k], ev[k + 1]));
 	}
+	return TGPU_OK;
+}
+
+int tgpu_plan_set_side_stream(struct tgpu_plan *p, int on)
+{
+	if (!p)
+		return TGPU_EINVAL;
+	p->no_side = !on;
 	return TGPU_OK;
 }
 

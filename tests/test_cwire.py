@@ -145,7 +145,7 @@ def test_device_compaction_equals_the_host_packer(T, eng):
             assert (got[:len(want)] == want).all(), (ngrid, kw, int(np.flatnonzero(got[:len(want)] != want)[0]))
             assert (got[cap:] == 0xAB).all()
             # too small a buffer: the needed size comes back, the count word says "nothing written", nothing behind cap is touched
-            if len(want) > 8192:
+            if int(tot[1]) > 200:
                 small = (len(want) - 100) & ~15
                 d_out.fill_(0xAB)
                 T.wire_compact(eng, d_w.data_ptr(), d_b.data_ptr(), ngrid, gbase, ncls, d_out.data_ptr(), small, d_tot.data_ptr(),
@@ -261,7 +261,9 @@ def test_compact_wire_of_a_decoded_batch_unpacks_to_its_records(T, eng):
             gi = T.grid_indices(o)
             st = streams[c]
             slots = st[o["anchor"]:o["anchor"] + 510 * (int(gi[-1]) + 1)].reshape(-1, 510)[gi]
-            check_against_oracle(T, r["rec"][idx], ty, slots, codes[c], use_acc=1)
+            known = pb["code"] == codes[c]          # (a noisy channel's first SB1 may fail: bursts before the first good one keep the carry-in code 0)
+            assert known.mean() > 0.9
+            check_against_oracle(T, r["rec"][idx][known], ty[known], slots[known], codes[c], use_acc=1)
         assert nbad > 50          # (escape records were in play)
 
 
