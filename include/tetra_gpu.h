@@ -129,6 +129,23 @@ const char *tgpu_strerror(int err);
 struct tgpu_engine;
 int tgpu_engine_create(struct tgpu_engine **out, int device);
 void tgpu_engine_destroy(struct tgpu_engine *eng);
+/*
+ * Process-wide switches: test aids and documented alternatives of the device path.  They are set by these calls only --
+ * nothing in the library reads the environment, so a production process's environment cannot change which kernels run.
+ * Results are the same bytes whatever the setting (the GPU suite runs its tests under each of them).
+ */
+enum tgpu_option {
+	TGPU_OPT_BURST_MAX = 1,		/* largest batch (slots) that takes the workgroup-per-burst kernel k_burst; default 1024, 0 = never */
+	TGPU_OPT_STREAM_EXACT,		/* 1: the stream front end runs its per-position form on every grid slot (default 0: on the slots the
+					 * packed-bit form cannot settle) */
+	TGPU_OPT_WALK_HOST,		/* 1: tgpu_sync_multi_collect() redoes every device-walk batch through the host walks (default 0: only
+					 * where the device walk hands a channel over) */
+	TGPU_OPT_WALK_MONO,		/* 1: the device walk as one launch per form instead of three (node pass over the whole chip) */
+	TGPU_OPT_FRONT_BLOCKS,		/* > 0: cap on the front-end kernels' workgroups (tests run their loops' tails with 1 and 2) */
+	TGPU_OPT__COUNT
+};
+int tgpu_engine_set_option(struct tgpu_engine *eng, int /* enum tgpu_option */ option, long value);
+long tgpu_engine_get_option(const struct tgpu_engine *eng, int option);
 /* where the GPU sits in the host: its PCI address ("0000:bb:dd.f"), the NUMA node it hangs off (-1 = unknown) and that
  * node's CPUs as the kernel prints them ("64-127,192-255"; "" = unknown), from hipDeviceGetPCIBusId() and
  * /sys/bus/pci/devices/<address>/{numa_node,local_cpulist}.  A process that feeds the GPU from host buffers wants its

@@ -239,6 +239,21 @@ def lib():
     return L
 
 
+OPT_BURST_MAX, OPT_STREAM_EXACT, OPT_WALK_HOST, OPT_WALK_MONO, OPT_FRONT_BLOCKS = range(1, 6)
+
+
+def set_option(opt, value):
+    """tgpu_engine_set_option: a process-wide switch of the library (enum tgpu_option); nothing reads the environment"""
+    lib().tgpu_engine_set_option.argtypes = [C.c_void_p, C.c_int, C.c_long]
+    _chk(lib().tgpu_engine_set_option(None, int(opt), int(value)), "tgpu_engine_set_option")
+
+
+def get_option(opt):
+    lib().tgpu_engine_get_option.argtypes = [C.c_void_p, C.c_int]
+    lib().tgpu_engine_get_option.restype = C.c_long
+    return int(lib().tgpu_engine_get_option(None, int(opt)))
+
+
 def _chk(rc, what):
     if rc != 0:
         raise TgpuError(f"{what}: {lib().tgpu_strerror(rc).decode()} ({rc})")

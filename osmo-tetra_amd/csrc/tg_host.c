@@ -29,6 +29,32 @@ struct tgpu_engine {
 
 int tgpu_plan_set_fastpath(struct tgpu_plan *p, int on);
 
+/* process-wide switches (tgpu_engine_set_option): test aids and documented alternatives -- set by explicit calls only,
+ * nothing in this library reads the environment */
+static long tg_options[TGPU_OPT__COUNT] = {
+	[TGPU_OPT_BURST_MAX] = 1024,	/* measured crossover of k_burst and the lane-per-trellis kernels */
+};
+
+long tgi_option(int opt)
+{
+	return opt > 0 && opt < TGPU_OPT__COUNT ? tg_options[opt] : 0;
+}
+
+int tgpu_engine_set_option(struct tgpu_engine *eng, int opt, long value)
+{
+	(void)eng;	/* (process-wide: the launch layer has no engine; the argument keeps the call next to the engine it is meant for) */
+	if (opt <= 0 || opt >= TGPU_OPT__COUNT || value < 0)
+		return TGPU_EINVAL;
+	tg_options[opt] = value;
+	return TGPU_OK;
+}
+
+long tgpu_engine_get_option(const struct tgpu_engine *eng, int opt)
+{
+	(void)eng;
+	return tgi_option(opt);
+}
+
 /* HIP's current device is per thread: every entry point that allocates, copies or launches makes the engine's
  * device current first (a host with one thread per channel, or engines on several GPUs in one process) */
 int tgpi_engine_bind(const struct tgpu_engine *eng)
@@ -43,7 +69,6 @@ int tgpi_engine_bind(const struct tgpu_engine *eng)
 }
 #define BIND(eng) do { int b_ = tgpi_engine_bind(eng); if (b_) return b_; } while (0)
 
-#define TGPU_BURST_MAX_DEFAULT 1024u	/* batches up to this many slots go through k_burst (measured crossover) */
 #define TGPU_SMALL_PLAN 256u	/* plans up to this many slots keep their descriptors in mapped host memory */
 #define TGPU_NKINDS 4	/* trellis kinds TG_KIND_SB1 / _216 / _432 / _168; index 4 = BBK in block-mode lists */
 
@@ -219,7 +244,7 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	 * Consequence for callers: a small plan must be idle (its last execute complete) before the next tgpu_plan_load*()
 	 * rewrites that memory -- larger plans copy at load time and may be reloaded while an execute is in flight only
 	 * in so far as the copy is ordered behind it by the caller (include/tetra_gpu.h, tgpu_plan_load) */
-	p->up_mapped = max_slots <= TGPU_SMALL_PLAN && !getenv("TGPU_NO_ZERO_COPY");
+	p->up_mapped = max_slots <= TGPU_SMALL_PLAN;
 	if (hipHostMalloc((void **)&p->h_up, p->up_bytes, p->up_mapped ? hipHostMallocMapped : hipHostMallocDefault) != hipSuccess) {
 		p->h_up = NULL;
 		tgpu_plan_destroy(p);
@@ -252,13 +277,6 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	    hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
 		tgpu_plan_destroy(p);
 		return TGPU_ENOMEM;
-	}
-	if (getenv("TGPU_FASTPATH") && atoi(getenv("TGPU_FASTPATH"))) {	/* test knob: fast path on for every plan */
-		int rc = tgpu_plan_set_fastpath(p, 1);
-		if (rc) {
-			tgpu_plan_destroy(p);
-			return rc;
-		}
 	}
 	*out = p;
 	return TGPU_OK;
@@ -863,8 +881,7 @@ const char *tgpu_stage_name(int stage)
 
 static uint32_t tgpi_burst_max(void)
 {
-	const char *e = getenv("TGPU_BURST_MAX");	/* read every time: tests switch it */
-	return e ? (uint32_t)atoi(e) : TGPU_BURST_MAX_DEFAULT;
+	return (uint32_t)tgi_option(TGPU_OPT_BURST_MAX);
 }
 
 /* soft: 0 = bits (1 per byte), 1 = int8 soft values, 2 = float phases (nfloats of them) */

@@ -9,6 +9,7 @@ extern "C" {
 #endif
 
 int tgk_init(void);
+long tgi_option(int opt);	/* enum tgpu_option (tgpu_engine_set_option): process-wide switches, never the environment */
 /* d_slot_desc[i] = byte offset | (uint64_t)burst type << 56 */
 int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 	      uint32_t nslots, uint32_t *d_packed, uint8_t *d_rec, void *stream);
@@ -187,8 +188,6 @@ int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity);
 #define TGK_F_LOOKBACK 16	/* SB1 launch of a device-walk batch: d_sb_ok = okbits (bit per grid slot), d_sb_code = mask entry per slot, d_masks =
 				 * the code table (TGK_LB_TBL + 1 words), flags >> 8 = number of channels (tg_kernels.hip, k_lists2) */
 #define TGK_LB_TBL 4096u
-#define TGK_F_NT 32	/* record segments leave with non-temporal stores (whole segments only: the LDS-transposed forms) */
-#define TGK_F_DIRECT 4	/* SCH/F records written 16 bytes per lane instead of through the LDS transpose (A/B: TGPU_REC_DIRECT=1) */
 
 /* make the engine's device the calling thread's current HIP device (every allocating / launching entry point does) */
 struct tgpu_engine;

@@ -26,6 +26,7 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include "tetra_gpu.h"
 #include "tg_layout.h"
 #include "vit_core.h"
 #include "tg_internal.h"
@@ -768,46 +769,6 @@ __device__ __forceinline__ uint32_t bytes16_to_bits(const uint4 &x)
 	return lo | (hi << 8);
 }
 
-/* gather of one slot from its 64-byte bit window: byte reads at the lane's addresses (+ the slot's window offset as
- * the instruction's immediate), the lane's bit isolated by its mask (four masks to a dword: SDWA picks the byte; all
- * ten ANDs are issued before the first compare, an SDWA result wants a wait state before it is read), ballots and
- * writelanes as front_gather */
-template <int KOFF>
-__device__ __forceinline__ uint32_t front_gather_bits(const uint8_t *lds0, const uint32_t (&addr)[10], const uint32_t (&msk)[3])
-{
-	uint32_t myword = 0;
-	uint32_t bytes[10], t[10];
-#pragma unroll
-	for (int r = 0; r < 10; r++)
-		bytes[r] = lds0[addr[r] + KOFF];
-#pragma unroll
-	for (int r = 0; r < 10; r++) {
-		switch (r & 3) {
-		case 0: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(t[r]) : "v"(bytes[r]), "v"(msk[r >> 2])); break;
-		case 1: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(t[r]) : "v"(bytes[r]), "v"(msk[r >> 2])); break;
-		case 2: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(t[r]) : "v"(bytes[r]), "v"(msk[r >> 2])); break;
-		default: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(t[r]) : "v"(bytes[r]), "v"(msk[r >> 2])); break;
-		}
-	}
-	unsigned long long bal[10];
-#pragma unroll
-	for (int r = 0; r < 10; r++)
-		bal[r] = __ballot(t[r] != 0);
-	asm("s_nop 4\n\t"
-	    "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
-	    "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
-	    "v_writelane_b32 %0, %9, 8\n\tv_writelane_b32 %0, %10, 9\n\tv_writelane_b32 %0, %11, 10\n\tv_writelane_b32 %0, %12, 11\n\t"
-	    "v_writelane_b32 %0, %13, 12\n\tv_writelane_b32 %0, %14, 13\n\tv_writelane_b32 %0, %15, 14\n\tv_writelane_b32 %0, %16, 15\n\t"
-	    "v_writelane_b32 %0, %17, 16\n\tv_writelane_b32 %0, %18, 17\n\tv_writelane_b32 %0, %19, 18\n\tv_writelane_b32 %0, %20, 19"
-	    : "+v"(myword)
-	    : "s"((uint32_t)bal[0]), "s"((uint32_t)(bal[0] >> 32)), "s"((uint32_t)bal[1]), "s"((uint32_t)(bal[1] >> 32)),
-	      "s"((uint32_t)bal[2]), "s"((uint32_t)(bal[2] >> 32)), "s"((uint32_t)bal[3]), "s"((uint32_t)(bal[3] >> 32)),
-	      "s"((uint32_t)bal[4]), "s"((uint32_t)(bal[4] >> 32)), "s"((uint32_t)bal[5]), "s"((uint32_t)(bal[5] >> 32)),
-	      "s"((uint32_t)bal[6]), "s"((uint32_t)(bal[6] >> 32)), "s"((uint32_t)bal[7]), "s"((uint32_t)(bal[7] >> 32)),
-	      "s"((uint32_t)bal[8]), "s"((uint32_t)(bal[8] >> 32)), "s"((uint32_t)bal[9]), "s"((uint32_t)(bal[9] >> 32)));
-	return myword;
-}
-
 /*
  * The gather of round 3: a lane owns one BYTE of the packed slot (60 of its 80 bytes carry bits: three per code word,
  * the lead-in bits of the two blocks, four BBK bytes) and collects its eight bits in eight rounds of one LDS byte read
@@ -859,12 +820,6 @@ struct tg_group_data {
 #define TG_STREAM_WPE 6	/* waves per SIMD (80 VGPRs: 6 fit).  With the grid at two rounds of resident workgroups (launch_stream_front):
 			 * 4 -> 161-168 us per 1 M slots, 5 -> 156-161, 6 -> 155-159, 8 (64 VGPRs) -> 195-200 (tools/front_grid.sh) */
 #endif
-#ifndef TG_STREAM_CLS
-#define TG_STREAM_CLS 2	/* per-slot outcome of the search: 1 = ballots + LDS crossbar, lanes 0..3 (round 2), 2 = reductions inside the slot's 16-lane row */
-#endif
-#ifndef TG_STREAM_GATHER
-#define TG_STREAM_GATHER 2	/* 1: ballots + v_writelane (round 2), 2: byte owners on shifted window copies (front_gather_bytes) */
-#endif
 /* acc & (t0 == p0) & (t1 == p1), sel = 2 p0 + p1 (a constant once the caller's loop is unrolled): one v_bitop3_b32 */
 __device__ __forceinline__ uint32_t tsq_and2(uint32_t acc, uint32_t t0, uint32_t t1, int sel)
 {
@@ -906,11 +861,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 {
 	constexpr uint64_t PY = tsq_bits(TSQ_Y), PN = tsq_bits(TSQ_N), PP = tsq_bits(TSQ_P);
 	__shared__ uint32_t s_bits[4][72];	/* per wave: the group's bit string (68 dwords used) */
-#if TG_STREAM_GATHER == 1
-	__shared__ uint32_t s_win[4][64];	/* per wave: four slot-aligned 512-bit windows */
-#else
 	__shared__ uint32_t s_win[4][4 * TG_VER_SLOT];	/* per wave: four slots x eight shifted copies of the 512-bit window */
-#endif
 	__shared__ uint32_t s_out[4][160];	/* per wave: four packed slots on their way out, then their cls / ysum words (+ the idle lanes' dump) */
 
 #ifdef TGS_TIMING
@@ -920,33 +871,11 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t wave = blockIdx.x * 4 + wib;
 	const uint32_t nwaves = gridDim.x * 4;
-#if TG_STREAM_GATHER == 1
-	const uint32_t half = lane >> 5, bit = lane & 31;
-#endif
 	const uint32_t col = lane & 15;			/* 32-position column of the lane's slot */
 	uint32_t *bits = s_bits[wib];
 	uint32_t *win = s_win[wib];
 	uint32_t *mo = s_out[wib];
-#if TG_STREAM_GATHER == 1
-	const uint8_t *lds0 = (const uint8_t *)&s_win[0][0];
-#endif
 
-#if TG_STREAM_GATHER == 1
-	/* gather tables: byte of the window and bit inside it, per round and burst type */
-	uint32_t g_adr[3][10], g_msk[3][3];
-#pragma unroll
-	for (int x = 0; x < 3; x++) {
-		g_msk[x][0] = g_msk[x][1] = g_msk[x][2] = 0;
-#pragma unroll
-		for (int r = 0; r < 10; r++) {
-			const uint32_t o = c_tab.front_src[x][2 * r + half][bit];
-			const bool none = (o == 0xffff);
-			g_adr[x][r] = wib * 256 + (none ? 0u : (o >> 3));
-			asm volatile("" : "+v"(g_adr[x][r]));	/* the whole address in the register: the slot's offset is the immediate */
-			g_msk[x][r >> 2] |= (none ? 0u : (1u << (o & 7))) << (8 * (r & 3));
-		}
-	}
-#else
 	/* the lane's byte of the packed slot: lanes 0..53 byte l % 3 of code word l / 3, 54 / 55 the lead-in bits of the two
 	 * blocks (byte 3 of words 0 and 9), 56..59 the BBK word, 60..63 none; per burst type and round the LDS byte that
 	 * carries the wanted bit at its bit 0 */
@@ -982,7 +911,6 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		win[lane * TG_VER_SLOT + 16] = 0;	/* "no source" reads this */
 	for (int i = lane; i < 128; i += 64)
 		mo[i] = 0;				/* bytes of the staged slots that nobody owns stay zero */
-#endif
 	/* which positions of the lane's column count: main search 21..472, "early" 0..20, SYNC summary 0..509 */
 	const uint32_t vmain = (col == 0) ? 0xffe00000u : (col == 14) ? 0x01ffffffu : (col == 15) ? 0u : 0xffffffffu;
 	const uint32_t vearly = (col == 0) ? 0x001fffffu : 0u;
@@ -1067,9 +995,6 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			W2 = __builtin_amdgcn_alignbit(D3, D2, p);
 		}
 		TGS_MARK(2);	/* bits through LDS, the lane's column */
-#if TG_STREAM_GATHER == 1
-		win[lane] = W0;
-#else
 		{
 			uint32_t *v = win + (lane >> 4) * TG_VER_SLOT + col;
 			v[0] = W0;
@@ -1077,7 +1002,6 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			for (int sft = 1; sft < ((TGS_ABLATE & 16) ? 1 : 8); sft++)
 				v[sft * TG_VER_STRIDE] = __builtin_amdgcn_alignbit(W1, W0, sft);
 		}
-#endif
 
 		/* match masks of the three sequences at the column's 32 positions */
 		/* one accumulator per sequence, two positions per step: acc & (t_j == p_j) & (t_j+1 == p_j+1) is one
@@ -1100,14 +1024,9 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 #undef TSQ_STEP
 		}
 		const uint32_t any = my | mn | mp;
-#if TG_STREAM_CLS == 1
-		const unsigned long long A = __ballot((any & vmain) != 0);
-		const unsigned long long E = __ballot((any & vearly) != 0);
-		const unsigned long long Y = __ballot(my != 0);
-#endif
 
 		TGS_MARK(3);	/* shifted copies stored, match masks, ballots */
-#if !(TGS_ABLATE & (8 | 32 | 256)) && TG_STREAM_CLS == 2
+#if !(TGS_ABLATE & (8 | 32 | 256))
 		/* per slot (= 16-lane row): the first hit and the SYNC summary by reductions inside the row -- every lane makes a
 		 * key of its own first hit ((position << 2 | type) in the high half, first y position in the low half: one
 		 * v_pk_min_u16 reduces both) and a count word (hit below 21 in the high half, number of y hits in the low), four
@@ -1149,40 +1068,6 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 #define CLS_OWNER      ((lane & 15u) == 0u)	/* the lane that writes the slot's words */
 #define CLS_SLOT       (lane >> 4)
 #define CLS_LANE_OF(K) (16 * (K))
-#elif !(TGS_ABLATE & (8 | 32 | 256))
-#define CLS_OWNER      (lane < 4u)
-#define CLS_SLOT       lane
-#define CLS_LANE_OF(K) (K)
-		/* per slot: first column with a hit -> its match words (LDS crossbar) -> first position, which sequence;
-		 * lanes 0..3 do this for slots 0..3 of the group (the others compute along) */
-		const uint32_t sl = lane & 3;
-		const uint32_t a = (uint32_t)(A >> (16 * sl)) & 0xffffu;
-		const uint32_t i0 = __builtin_ctz(a | 0x10000u);
-		const uint32_t src = 4 * (16 * sl + (i0 & 15));
-		const uint32_t vm = (i0 == 0) ? 0xffe00000u : (i0 == 14) ? 0x01ffffffu : 0xffffffffu;
-		const uint32_t sy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)my) & vm;
-		const uint32_t sn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)mn) & vm;
-		const uint32_t sp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)mp) & vm;
-		const uint32_t b = __builtin_ctz(sy | sn | sp | 0x80000000u);
-		const uint32_t offs = 32 * i0 + b;
-		const uint32_t rc = ((sy >> b) & 1) ? TG_BURST_SYNC : ((sn >> b) & 1) ? TG_BURST_NORM_1 : TG_BURST_NORM_2;
-		const uint32_t early = (uint32_t)(E >> (16 * sl)) & 1u;
-		const uint32_t yb = (uint32_t)(Y >> (16 * sl)) & 0xffffu;
-		const uint32_t j0 = __builtin_ctz(yb | 0x10000u);
-		const uint32_t yv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * (16 * sl + (j0 & 15))), (int)my);
-		uint32_t ys = 32 * j0 + __builtin_ctz(yv | 0x80000000u);
-		if ((yb & (yb - 1)) | (yv & (yv - 1)))
-			ys |= TG_YS_MULTI;
-		if (!yb)
-			ys = TG_YS_NONE;
-		/* a sequence below offset 21 is accepted or not by the reference's skewed look-ahead window: the exact pass
-		 * evaluates that rule (rare: a payload coincidence, about ten slots in a million) */
-		const bool dfr = defer_all || a == 0 || early;
-		uint32_t dtype = TG_BURST_NONE;
-		if (rc == TG_BURST_SYNC ? offs == TG_SYNC_TRAIN_OFF : offs == TG_NORM_TRAIN_OFF)
-			dtype = rc;
-		if (dfr)
-			dtype = TG_BURST_NONE;
 #endif
 #if TGS_ABLATE & (8 | 32 | 256)
 #define CLS_OWNER      (lane < 4u)
@@ -1201,21 +1086,6 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 
 		const uint32_t first = 4u * g;
 		const uint32_t cnt = (prm.nslots - first < 4u) ? prm.nslots - first : 4u;
-#if TG_STREAM_GATHER == 1
-#define STREAM_SLOT_K(K)												\
-		{													\
-			const uint32_t dt = __builtin_amdgcn_readlane(dtype, CLS_LANE_OF(K));				\
-			uint32_t myword = 0;										\
-			if (dt == TG_BURST_NORM_1)									\
-				myword = front_gather_bits<64 * (K)>(lds0, g_adr[0], g_msk[0]);				\
-			else if (dt == TG_BURST_NORM_2)									\
-				myword = front_gather_bits<64 * (K)>(lds0, g_adr[1], g_msk[1]);				\
-			else if (dt == TG_BURST_SYNC)									\
-				myword = front_gather_bits<64 * (K)>(lds0, g_adr[2], g_msk[2]);				\
-			if (lane < TG_PACKED_WORDS)									\
-				mo[(K) * TG_PACKED_WORDS + lane] = myword;						\
-		}
-#else
 #define STREAM_SLOT_K(K)												\
 		{													\
 			const uint32_t dt = (TGS_ABLATE & 128) ? (uint32_t)TG_BURST_NORM_1 :					\
@@ -1232,7 +1102,6 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 2>(g_adr[2]);			\
 			((uint8_t *)mo)[(K) * TG_PACKED_WORDS * 4 + obyte] = (uint8_t)mybyte;				\
 		}
-#endif
 		TGS_MARK(4);	/* classification of the four slots */
 		STREAM_SLOT_K(0)
 		STREAM_SLOT_K(1)
@@ -1536,7 +1405,6 @@ __device__ __forceinline__ uint32_t field_msb(uint32_t lo, uint32_t hi, int sh, 
 #define FIELD_MSB(od, n0, len) field_msb((od)[(n0) >> 5], (od)[((n0) >> 5) + 1], (n0) & 31, (len))
 
 typedef uint32_t tg_v32 __attribute__((ext_vector_type(32)));
-typedef uint32_t tg_u32x4 __attribute__((ext_vector_type(4)));
 
 #define TG_STAGE_PITCH 20	/* dwords per lane in the record staging area: 16 + 4 (dwordx4 rows of neighbouring lanes in different banks) */
 
@@ -1638,10 +1506,7 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 				const uint32_t rr = (lane >> 2) + 16 * i;
 				const uint4 v = *(const uint4 *)(stage + rr * TG_STAGE_PITCH + 4 * (lane & 3));
 				uint4 *dst = (uint4 *)(rec + (size_t)st_slot[rr] * TG_REC_BYTES + 64 * c + 16 * (lane & 3));
-				if (kflags & TGK_F_NT)		/* whole segments, never read again by this GPU: past the caches */
-					__builtin_nontemporal_store(*(const tg_u32x4 *)&v, (tg_u32x4 *)dst);
-				else
-					*dst = v;
+				*dst = v;
 			}
 			__builtin_amdgcn_wave_barrier();
 		}
@@ -1919,7 +1784,6 @@ void k_clean(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t
 }
 
 /*
- * HMODE 0: survivor history in LDS (16 B per lane per 8-step block).
  * HMODE 1: survivor history in VGPRs -- chunks of 32 registers (8 blocks) written through
  *          the VGPR index mode (s_set_gpr_idx_on) with a wave-uniform block index, read back
  *          with static indices by the fully unrolled traceback.  No LDS for the trellis at
@@ -1928,7 +1792,7 @@ void k_clean(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t
  *          packed bits, 32-bit correlation metrics (tg_svit_*), history in VGPRs as in mode 1.
  */
 template <int KIND, int HMODE>
-__global__ __launch_bounds__(64, (HMODE == 0) ? 1 : (HMODE == 2) ? (KIND == TG_KIND_SB1 ? 4 : 2) : (KIND == TG_KIND_432 ? 3 : 4))
+__global__ __launch_bounds__(64, (HMODE == 2) ? (KIND == TG_KIND_SB1 ? 4 : 2) : (KIND == TG_KIND_432 ? 3 : 4))
 void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
@@ -1945,10 +1809,9 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	constexpr int NOD = (NBLK + 3) / 4;		/* dwords of decoded bits */
 	constexpr int NCH = (NBLK + 7) / 8;		/* history chunks of 8 blocks */
 
-	__shared__ uint4 hist[(HMODE == 0) ? NBLK * 64 : 1];
 	__shared__ uint16_t s_crc[512];
 	/* record staging of the SCH/F kernel (vit_finish): 64 lanes x four dwordx4 at a pitch of 20 dwords + 64 slot numbers */
-	__shared__ __attribute__((aligned(16))) uint32_t s_stage[(KIND == TG_KIND_432 && HMODE != 0) ? 64 * TG_STAGE_PITCH + 64 : 4];
+	__shared__ __attribute__((aligned(16))) uint32_t s_stage[(KIND == TG_KIND_432) ? 64 * TG_STAGE_PITCH + 64 : 4];
 
 	const uint32_t lane = threadIdx.x;
 	for (int i = lane; i < 256; i += 64) {
@@ -2123,35 +1986,6 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 			const uint32_t lo = tg_ptrace_hop(H[c][o], H[c][o + 1], pos);
 			od[b >> 2] |= (lo | (hi << 4)) << ((b & 3) * 8);
 		}
-	} else if (HMODE == 0) {
-#pragma unroll 1
-		for (int it = 0; it < NW - 1; it++) {
-			const uint32_t nxt = s_cw[(it + 1) * 64 + lane];
-			uint32_t h[4];
-			tg_vit_block_bm<false>(v, cur, h, bm);
-			hist[(2 * it) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-			tg_vit_block_bm<false>(v, cur >> 12, h, bm);
-			hist[(2 * it + 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-			if (KIND == TG_KIND_432 && it == 8)
-				tg_vit_normalize(v);
-			cur = nxt;
-		}
-		{
-			uint32_t h[4];
-			tg_vit_block_bm<false>(v, cur, h, bm);
-			hist[(NBLK - 2) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-			tg_vit_block_bm<true>(v, cur >> 12, h, bm);
-			hist[(NBLK - 1) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
-		}
-		/* block-wise traceback from state 0 */
-		const uint8_t *hb = (const uint8_t *)hist + lane * 16;
-		uint32_t s = 0;
-#pragma unroll
-		for (int b = NBLK - 1; b >= 0; b--) {
-			const uint32_t byte = hb[b * 1024 + s];
-			od[b >> 2] |= byte << ((b & 3) * 8);
-			s = tg_brev4(byte);
-		}
 	} else {
 		tg_v32 H[NCH];
 #pragma unroll
@@ -2202,7 +2036,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 
 	__syncthreads();	/* s_crc visible (single wave, but keep the compiler honest) */
 	vit_finish<KIND, HMODE>(od, s_crc, valid, slot, which, idx, midx, packed, masks, rec, sb_ok, sb_code, wire, softarea, kflags,
-				(KIND == TG_KIND_432 && HMODE != 0 && !(kflags & TGK_F_DIRECT)) ? s_stage : nullptr);
+				(KIND == TG_KIND_432) ? s_stage : nullptr);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -3123,7 +2957,6 @@ static void build_tables(tg_const_tables *t)
 
 /* survivor-history placement of the trellis kernels: 1 = VGPRs (default), 0 = LDS.
  * Tuning knob for A/B runs (environment TGPU_HIST_MODE), both are bit-identical. */
-static int tgk_hist_mode = 1;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -3164,8 +2997,6 @@ extern "C" int tgk_init(void)
 	build_soft_tables(&shost);
 	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_soft_tab), &shost, sizeof(shost)));
 	build_tables(&host);
-	if (const char *e = getenv("TGPU_HIST_MODE"))
-		tgk_hist_mode = atoi(e) ? 1 : 0;
 	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &host, sizeof(host)));
 	{
 		static uint16_t lut[8192];
@@ -3182,8 +3013,8 @@ extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 		return 0;
 	uint32_t blocks = (nslots + 3) / 4;
 	uint32_t cap = 256 * 32;	/* measured on MI355X (tools/exp_front_grid.py): 2048 156 us, 4096 154 us, 8192 144 us */
-	if (const char *e = getenv("TGPU_FRONT_BLOCKS"))
-		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
+	if (tgi_option(TGPU_OPT_FRONT_BLOCKS) > 0)
+		cap = (uint32_t)tgi_option(TGPU_OPT_FRONT_BLOCKS);
 	if (blocks > cap)
 		blocks = cap;
 	hipLaunchKernelGGL(k_front, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
@@ -3276,8 +3107,8 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 	const uint32_t nslots = prm.nslots;
 	uint32_t blocks = ((nslots + 3) / 4 + 3) / 4;	/* a wave per group of four slots */
 	uint32_t cap = 256 * 2 * TG_STREAM_WPE;	/* two rounds of what the 256 CUs hold: one round (persistent waves) is 3-4 % slower, four rounds 5 % */
-	if (const char *e = getenv("TGPU_FRONT_BLOCKS"))
-		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
+	if (tgi_option(TGPU_OPT_FRONT_BLOCKS) > 0)
+		cap = (uint32_t)tgi_option(TGPU_OPT_FRONT_BLOCKS);
 	if (blocks > cap)
 		blocks = cap;
 	HIPCHK(hipMemsetAsync(d_defer, 0, 4, s));
@@ -3340,8 +3171,7 @@ extern "C" int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64
 	prm.len = len;
 	prm.nslots = nslots;
 	stream_patterns(prm, chunk);
-	const char *ev = getenv("TGPU_STREAM_V1");	/* =1: the per-position kernel on every slot (A/B runs) */
-	const int v1 = ev ? atoi(ev) : 0;
+	const int v1 = tgi_option(TGPU_OPT_STREAM_EXACT) != 0;	/* the per-position kernel on every slot (tests hold the two forms against each other) */
 	hipStream_t s = (hipStream_t)stream;
 	if (v1 || nslots < 16) {	/* (a handful of slots: the packed-bit kernel's group fetch wants 2176 readable bytes) */
 		uint32_t blocks = (nslots + 3) / 4;
@@ -3362,8 +3192,8 @@ static int launch_front_soft(bool f32, const void *d_in, unsigned long long nin,
 		return 0;
 	uint32_t blocks = (nslots + 3) / 4;
 	uint32_t cap = 256 * 8;
-	if (const char *e = getenv("TGPU_FRONT_BLOCKS"))
-		cap = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : cap;
+	if (tgi_option(TGPU_OPT_FRONT_BLOCKS) > 0)
+		cap = (uint32_t)tgi_option(TGPU_OPT_FRONT_BLOCKS);
 	if (blocks > cap)
 		blocks = cap;
 	if (f32)
@@ -3419,33 +3249,19 @@ extern "C" int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const
 	const dim3 grid((nitems + 63) / 64), block(64);
 	hipStream_t s = (hipStream_t)stream;
 #define VIT_LAUNCH(K, H) hipLaunchKernelGGL((k_vit<K, H>), grid, block, 0, s, d_items, nitems, d_packed, d_masks, d_maskidx, d_rec, d_sb_ok, d_sb_code, d_wire, d_soft, flags, d_nitems)
-	const int hm = d_soft ? 2 : tgk_hist_mode;
-	static int direct = -1;
-	if (direct < 0) {
-		const char *e = getenv("TGPU_REC_DIRECT");
-		direct = (e && atoi(e)) ? 1 : 0;
-	}
-	if (direct)
-		flags |= TGK_F_DIRECT;
-	static int nt = -1;
-	if (nt < 0) {
-		const char *e = getenv("TGPU_REC_NT");
-		nt = (e && atoi(e)) ? 1 : 0;
-	}
-	if (nt)
-		flags |= TGK_F_NT;
+	const int hm = d_soft ? 2 : 1;	/* survivor history in VGPRs (vit_core.h); 2 = the soft-input trellis */
 	switch (kind) {
 	case TG_KIND_SB1:
-		if (hm == 2) VIT_LAUNCH(TG_KIND_SB1, 2); else if (hm) VIT_LAUNCH(TG_KIND_SB1, 1); else VIT_LAUNCH(TG_KIND_SB1, 0);
+		if (hm == 2) VIT_LAUNCH(TG_KIND_SB1, 2); else VIT_LAUNCH(TG_KIND_SB1, 1);
 		break;
 	case TG_KIND_216:
-		if (hm == 2) VIT_LAUNCH(TG_KIND_216, 2); else if (hm) VIT_LAUNCH(TG_KIND_216, 1); else VIT_LAUNCH(TG_KIND_216, 0);
+		if (hm == 2) VIT_LAUNCH(TG_KIND_216, 2); else VIT_LAUNCH(TG_KIND_216, 1);
 		break;
 	case TG_KIND_432:
-		if (hm == 2) VIT_LAUNCH(TG_KIND_432, 2); else if (hm) VIT_LAUNCH(TG_KIND_432, 1); else VIT_LAUNCH(TG_KIND_432, 0);
+		if (hm == 2) VIT_LAUNCH(TG_KIND_432, 2); else VIT_LAUNCH(TG_KIND_432, 1);
 		break;
 	case TG_KIND_168:	/* hard input only */
-		if (hm == 2) return -1; else if (hm) VIT_LAUNCH(TG_KIND_168, 1); else VIT_LAUNCH(TG_KIND_168, 0);
+		if (hm == 2) return -1; else VIT_LAUNCH(TG_KIND_168, 1);
 		break;
 	default:
 		return -1;

@@ -750,12 +750,6 @@ int tgpu_sync_classify(struct tgpu_engine *eng, const uint8_t *d_stream, uint64_
 	return rc;
 }
 
-static double now_ms(void)
-{
-	struct timespec ts;
-	clock_gettime(CLOCK_MONOTONIC, &ts);
-	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-}
 
 int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uint8_t *d_stream, uint64_t len,
 		     uint32_t chunk, uint32_t flags, struct tgpu_sync_result *out, void *stream)
@@ -764,7 +758,6 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
 		return TGPU_EINVAL;
 	uint64_t anchor = 0;
 	int locks = 0;
-	const double t0 = now_ms();
 	int rc = find_anchor(h_stream, len, chunk, &anchor, &locks);
 	if (rc)
 		return rc;
@@ -786,13 +779,9 @@ int tgpu_sync_stream(struct tgpu_engine *eng, const uint8_t *h_stream, const uin
 			return rc;
 		}
 	}
-	const double t1 = now_ms();
 	rc = tgpu_sync_walk(h_stream, len, chunk, anchor, cls, ysum, ncls, flags, out);
 	out->anchor = anchor;
 	free(cls);
-	if (getenv("TGPU_SYNC_TIMING"))
-		fprintf(stderr, "tgpu_sync_stream: anchor+classify %.3f ms, walk %.3f ms (%u slots, %u events)\n",
-			t1 - t0, now_ms() - t1, out->nslots, out->nevents);
 	return rc;
 }
 
@@ -856,21 +845,15 @@ int tgpu_sync_stream_grid_finish(struct tgpu_engine *eng, struct tgpu_plan *plan
 	uint16_t *d_ysum, *ysum;
 	if ((rc = tgpi_plan_grid_begin(plan, ncls, &d_packed, &d_cls, &d_ysum, &cls, &ysum)))
 		return rc;
-	const double t0 = now_ms();
 	rc = (int)hipStreamSynchronize((hipStream_t)stream);
-	const double t1 = now_ms();
 	if (!rc) {
 		uint32_t *d_plain, *h_plain;
 		tgpi_plan_grid_plain(plan, ncls, &d_plain, &h_plain);
 		rc = sync_walk(h_stream, len, chunk, anchor, cls, ysum, h_plain, ncls, flags | TGPU_SYNC_GRID, out);
 	}
 	out->anchor = anchor;
-	const double t2 = now_ms();
 	if (!rc && !out->noffgrid)
 		rc = tgpi_plan_grid_load(plan, ncls, out->grid_bits, 1, &scramb_init, NULL, stream);
-	if (getenv("TGPU_SYNC_TIMING"))
-		fprintf(stderr, "tgpu_sync_stream_grid: wait for the classification %.3f ms, walk %.3f ms, device lists %.3f ms (%u of %u grid slots, %u events)\n",
-			t1 - t0, t2 - t1, now_ms() - t2, out->nslots, ncls, out->nevents);
 	return rc;
 }
 
@@ -1553,7 +1536,7 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			}
 		if (!rc)
 			rc = tgk_walk(d_base, io->d_tab, io->d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, io->d_bits2, io->d_sums,
-				      io->d_eager, io->d_evbig, io->d_recs, getenv("TGPU_WALK_MONO") ? NULL : io->d_tmp, skip, stream);
+				      io->d_eager, io->d_evbig, io->d_recs, tgi_option(TGPU_OPT_WALK_MONO) ? NULL : io->d_tmp, skip, stream);
 		if (!rc) {
 			if (big.n) {
 				rc = tgpi_plan_walk_big(plan, big.n, io);
@@ -1561,7 +1544,7 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 				memcpy(io->big.chan, big.chan, sizeof(big.chan));
 				if (!rc)
 					rc = tgk_walk_big(&io->big, io->d_big, d_base, io->d_tab, io->d_roots, chunk, d_cls, d_ysum, d_plain,
-							  d_bits, io->d_bits2, io->d_sums, io->d_eager, getenv("TGPU_WALK_MONO") ? NULL : io->d_tmp, stream);
+							  d_bits, io->d_bits2, io->d_sums, io->d_eager, tgi_option(TGPU_OPT_WALK_MONO) ? NULL : io->d_tmp, stream);
 			}
 		}
 		EVMARK(6);
@@ -1625,10 +1608,8 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 	if (rc)
 		return rc;
 	/* wait for the batch: the stream's completion event is polled with short sleeps in between -- a spinning
-	 * hipEventSynchronize() costs a whole core per GPU for as long as the GPU works (TGPU_SPIN_WAIT=1 does that) */
-	if (getenv("TGPU_SPIN_WAIT"))
-		rc = (int)hipEventSynchronize(sd->done);
-	else {
+	 * hipEventSynchronize() costs a whole core per GPU for as long as the GPU works */
+	{
 		/* (a thread's timer slack, 50 us by default, is added to every sleep: for the duration of the wait it is set to
 		 * 1 us, so that a nap is the 20 us asked for and the batch's successor is launched that much sooner) */
 		hipError_t q;
@@ -1653,12 +1634,7 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 		}
 	if (st->ngrid && sd->io.h_final[64])
 		fb = 1;		/* more scrambling codes in the batch than the device path's table holds */
-	if (st->ngrid && getenv("TGPU_WALK_DEBUG"))
-		for (uint32_t c = 0; c < st->nchan; c++)
-			fprintf(stderr, "k_walk channel %u: %u grid slots, %u nodes, status %u (why %u), %u delivered, %u events\n", c,
-				st->ent[c].ncls, sd->io.h_sums[c].nnodes, sd->io.h_sums[c].status, sd->io.h_sums[c].why, sd->io.h_sums[c].nslots,
-				sd->io.h_sums[c].nevents);
-	if (fb || getenv("TGPU_WALK_HOST")) {
+	if (fb || tgi_option(TGPU_OPT_WALK_HOST)) {
 		/* the host walks decide: classification words, summaries and plain bitmap over, walks, bitmap up, lists, decode */
 		sd->fellback = 1;
 		if (st->ngrid) {

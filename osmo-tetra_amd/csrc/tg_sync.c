@@ -217,7 +217,7 @@ int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unit
 	ch->h_chan = calloc(n, 4);
 	/* small batches are round trips: the bursts stay in pinned host memory, the kernels read them and write the
 	 * records in place over PCIe (no copy operations in a flush); larger ones go through device buffers */
-	ch->zero_copy = batch_slots <= 64 && !getenv("TGPU_NO_ZERO_COPY");
+	ch->zero_copy = batch_slots <= 64;
 	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_slots, n * SLOT_STRIDE + 64, ch->zero_copy ? hipHostMallocMapped : 0);
 	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_rec, n * TGPU_REC_BYTES, ch->zero_copy ? hipHostMallocMapped : 0);
 	if (ch->zero_copy) {

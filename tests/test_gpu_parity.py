@@ -29,6 +29,20 @@ def eng(T):
     e.close()
 
 
+@pytest.fixture
+def topt(T):
+    """a process-wide library switch (tgpu_engine_set_option) for the duration of one test"""
+    saved = {}
+
+    def set_(name, value):
+        o = getattr(T, "OPT_" + name)
+        saved.setdefault(o, T.get_option(o))
+        T.set_option(o, value)
+    yield set_
+    for o, v in saved.items():
+        T.set_option(o, v)
+
+
 def run_plan(T, eng, slots, types, chan=None, codes=None, stride=510, offsets=None):
     """slots: (n,510) host array -> parsed records"""
     import torch
@@ -423,10 +437,10 @@ def test_config2_full_size_roundtrip(T, eng):
     plan.close()
 
 
-def test_front_kernel_packing(T, eng, monkeypatch):
+def test_front_kernel_packing(T, eng, topt):
     """k_front's packed code words == the layout function both sides are built from (tg_layout.h),
     for all burst types, odd offsets and the last slot of a buffer (no read past byte 509)"""
-    monkeypatch.setenv("TGPU_BURST_MAX", "0")        # (small batches would bypass k_front)
+    topt("BURST_MAX", int("0"))        # (small batches would bypass k_front)
     import torch
     import emul
     rng = np.random.default_rng(12)
@@ -563,7 +577,7 @@ def _hostile_stream(T, seed, nslots, lead_in, shift=True):
 
 
 @pytest.mark.parametrize("seed,lead_in,chunk", [(1, 100, 64), (2, 7, 64), (3, 333, 100), (4, 1000, 510), (5, 41, 1)])
-def test_stream_front_packed_bits_equals_per_position(T, eng, seed, lead_in, chunk, monkeypatch):
+def test_stream_front_packed_bits_equals_per_position(T, eng, seed, lead_in, chunk, topt):
     """k_front_stream (packed bits, bit-parallel search, + k_front_stream_fix) == k_front_stream_v1 (the per-position
     form on every slot): classification words, SYNC summaries and packed slots, bit for bit, on hostile streams of
     every 16-byte alignment class"""
@@ -575,7 +589,7 @@ def test_stream_front_packed_bits_equals_per_position(T, eng, seed, lead_in, chu
     d = torch.from_numpy(np.concatenate([s, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("TGPU_STREAM_V1", mode)
+        topt("STREAM_EXACT", int(mode))
         cls, ys = T.sync_classify(eng, d.data_ptr(), len(s), chunk, anchor, n, with_ysum=True)
         plan = T.Plan(eng, n + 8, 1)
         g = T.GridSync(eng, plan, s, d.data_ptr(), chunk)
@@ -1197,11 +1211,11 @@ def test_clean_block_fastpath_is_invisible(T, eng):
 
 
 @pytest.mark.parametrize("fast", [False, True])
-def test_batch_size_sweep(T, eng, fast, monkeypatch):
+def test_batch_size_sweep(T, eng, fast, topt):
     """ragged batch sizes around the kernels' tiling (wave = 64 items, workgroups of 256 / 1024, grid-stride loops,
     pipelined front end with its tail): every size decodes like the oracle (the lane-per-trellis kernels at every
     size: the workgroup-per-burst path of small batches is switched off here, it has its own test)"""
-    monkeypatch.setenv("TGPU_BURST_MAX", "0")
+    topt("BURST_MAX", int("0"))
     rng = np.random.default_rng(5)
     nmax = 9000
     ty_all = rng.choice([O.TRAIN_NORM_1, O.TRAIN_NORM_2], nmax).astype(np.uint8)
@@ -1470,11 +1484,11 @@ def test_plan_and_conv_execute_are_graph_capturable(T, eng):
     plan.close()
 
 
-def test_front_end_pipeline_tails(T, eng, monkeypatch):
+def test_front_end_pipeline_tails(T, eng, topt):
     """k_front with very few waves (TGPU_FRONT_BLOCKS, a test knob of the launcher), so that every wave runs its
     prologue, the unconditional main loop and the checked tail over sequences of every length: groups of four
     slots, a short last group, fewer slots than waves -- every batch size from 1 to 150 and a few larger ones"""
-    monkeypatch.setenv("TGPU_BURST_MAX", "0")        # (small batches would bypass k_front)
+    topt("BURST_MAX", int("0"))        # (small batches would bypass k_front)
     import torch
     import emul
     rng = np.random.default_rng(15)
@@ -1484,7 +1498,7 @@ def test_front_end_pipeline_tails(T, eng, monkeypatch):
     hs = torch.cuda.current_stream().cuda_stream
     want = [emul.pack_slot(int(ty_all[i]), slots_all[i])[:19] for i in range(nmax)]
     for blocks in ("1", "2"):
-        monkeypatch.setenv("TGPU_FRONT_BLOCKS", blocks)
+        topt("FRONT_BLOCKS", int(blocks))
         for n in list(range(1, 151)) + [255, 256, 257, 511, 700]:
             d = torch.from_numpy(slots_all[:n].reshape(-1).copy()).cuda()
             plan = T.Plan(eng, n, 1)
@@ -1880,8 +1894,8 @@ def _same_batch_outcome(T, a, b, rec_a, rec_b, what):
             assert (rec_a[idx] == rec_b[idx]).all(), (what, c)
 
 
-@pytest.mark.parametrize("chunk", [64, 32])
-def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, monkeypatch):
+@pytest.mark.parametrize("chunk,mono", [(64, 0), (32, 0), (64, 1)])
+def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, mono, topt):
     """tgpu_sync_multi_launch / _collect (the synchroniser walks on the device: k_walk) against tgpu_sync_multi_begin /
     _finish (host walks) on the same multi-channel batch: eight channels of different cells, lengths, lead-ins and damage
     -- damaged training sequences in runs, right behind SYNC bursts (the one-call backlog) and in the last slots, spurious
@@ -1890,6 +1904,7 @@ def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, monkeypatch):
     delivered record byte, final codes.  No fallback on these; then once more with the fallback forced (same results)"""
     import torch
     from test_stream_sync_cpu import SEQ_N, SEQ_P
+    topt("WALK_MONO", mono)         # (the walk as one launch per form instead of three: same outcome)
     hs = torch.cuda.current_stream().cuda_stream
     cells = [(262, 42, 1), (901, 77, 9), (234, 14, 33), (1, 2, 3), (262, 42, 2), (505, 1, 60), (208, 10, 5), (222, 99, 7)]
     rng = np.random.default_rng(4040 + chunk)
@@ -1924,7 +1939,7 @@ def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, monkeypatch):
     assert all(x["noffgrid"] == 0 for x in ref) and sum(len(x["events"]) for x in ref) > 300
     for forced in (False, True):
         if forced:
-            monkeypatch.setenv("TGPU_WALK_HOST", "1")
+            topt("WALK_HOST", int("1"))
         rb = torch.zeros(max(ms.ngrid, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
         msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), chunk, hs)
         got = msd.collect()
@@ -1974,7 +1989,7 @@ def test_device_walk_hands_over_what_only_the_bytes_settle(T, eng):
         pb.close()
 
 
-def test_burst_kernel_long_runs_and_many_channels(T, eng, monkeypatch):
+def test_burst_kernel_long_runs_and_many_channels(T, eng, topt):
     """k_burst's look-back for the scrambling code beyond its 256-slot LDS window (one SYNC slot, then 899 NORM slots
     of the same channel: the code must still come from slot 0), a failed SB1 far back that must be skipped, and 70
     channels with carry-in codes (channels >= 64 take the code from memory): records and final codes == the batch
@@ -2009,7 +2024,7 @@ def test_burst_kernel_long_runs_and_many_channels(T, eng, monkeypatch):
         d = torch.from_numpy(sl_.reshape(-1)).cuda()
         out = {}
         for mode, mx in (("burst", "100000"), ("batch", "0")):
-            monkeypatch.setenv("TGPU_BURST_MAX", mx)
+            topt("BURST_MAX", int(mx))
             d_rec = torch.zeros(n_ * T.REC_BYTES, dtype=torch.uint8, device="cuda")
             plan = T.Plan(eng, n_, len(carry_))
             plan.load(np.arange(n_, dtype=np.uint64) * 510, ty_, ch_, carry_)
@@ -2025,12 +2040,12 @@ def test_burst_kernel_long_runs_and_many_channels(T, eng, monkeypatch):
             assert (p["code"] == carry_[ch_]).all() and p["crc_ok"][:, 0].all()
 
 
-def test_wire_only_mode(T, eng, monkeypatch):
+def test_wire_only_mode(T, eng, topt):
     """tgpu_plan_set_wire_only: the wire records are the ones of a normal run byte for byte (all burst types, noise, code
     learnt from SB1 mid-batch, the RM option), the 320-byte records are left alone (but for the type byte of ignored
     slots), the scrambling codes in force afterwards are the same"""
     import torch
-    monkeypatch.setenv("TGPU_BURST_MAX", "0")
+    topt("BURST_MAX", int("0"))
     hs = torch.cuda.current_stream().cuda_stream
     n = 5000
     rng = np.random.default_rng(12)
@@ -2192,7 +2207,7 @@ def test_metric_workload_full_size_against_the_oracle(T, eng):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 16, 33, 200, 1500])
-def test_burst_kernel_equals_batch_kernels(T, eng, n, monkeypatch):
+def test_burst_kernel_equals_batch_kernels(T, eng, n, topt):
     """k_burst (one workgroup per burst, trellis states across lanes; the path of small batches) writes the very
     records the lane-per-trellis batch kernels write -- every byte -- and both are the oracle's decode: mixed burst
     types with SYNC slots that switch the code mid-batch (a valid cell, a failed SB1, a second cell), two channels
@@ -2233,7 +2248,7 @@ def test_burst_kernel_equals_batch_kernels(T, eng, n, monkeypatch):
         d = torch.from_numpy(buf).cuda()
         out = {}
         for mode, mx in (("burst", "100000"), ("batch", "0")):
-            monkeypatch.setenv("TGPU_BURST_MAX", mx)
+            topt("BURST_MAX", int(mx))
             d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
             plan = T.Plan(eng, n, 2)
             plan.load(offs, ty, chan, carry)
@@ -2264,7 +2279,7 @@ def test_burst_kernel_equals_batch_kernels(T, eng, n, monkeypatch):
             check_against_oracle(T, a[0][m], ty[m], (sl_in[m] != 0).astype(np.uint8), int(cval))
 
 
-def test_burst_path_then_batch_path_on_one_load(T, eng, monkeypatch):
+def test_burst_path_then_batch_path_on_one_load(T, eng, topt):
     """one load, several executes on different paths: a static batch (no SYNC slot) goes through k_burst,
     which uses the mask index / mask table as its own scratch, and is then executed again on the lane-per-trellis
     kernels (per-stage profiling, a wire buffer, the RM option, TGPU_BURST_MAX lowered): the static mask table must be
@@ -2314,7 +2329,7 @@ def test_burst_path_then_batch_path_on_one_load(T, eng, monkeypatch):
     d2 = torch.from_numpy(sl2.reshape(-1)).cuda()
     res = {}
     for mode, mx in (("burst", "100000"), ("batch", "0")):
-        monkeypatch.setenv("TGPU_BURST_MAX", mx)
+        topt("BURST_MAX", int(mx))
         pl = T.Plan(eng, 8, 2)
         pl.load(np.arange(8, dtype=np.uint64) * 510, ty2, chan2, np.array([5, 9], np.uint32))
         r = torch.zeros(8 * T.REC_BYTES, dtype=torch.uint8, device="cuda")
@@ -2485,6 +2500,34 @@ def test_stages_step_by_step_and_against_the_fused_path(T, eng, ber):
         T.Stages(eng, 9)
 
 
+def _oracle_check_of_a_walked_channel(T, st, out, rec, code, nrec=20000):
+    """a channel of a device-walk batch against the ORACLE's receiver on the same bytes (not against the product's own host
+    walk): every synchroniser event, the number of delivered bursts, and the records of a slice of the delivered bursts
+    (nrec of them: from the start, the middle and the end) against the oracle's decode"""
+    import ctypes as C
+    want_ev = []
+    rx = O.Rx()
+    ecb = O.EVENT_CB(lambda ev, bitnum, arg, priv: want_ev.append((ev, bitnum, arg)) if ev != 2 else None)
+    O.lib().orc_rx_init(C.byref(rx), O.UPPER_CB(), ecb, None)
+    rx.use_acc = 1
+    O.lib().orc_rx_feed(C.byref(rx), O._p(st), len(st), 64)
+    assert out["events"] == want_ev
+    dropped = sum(1 for e in want_ev if e[0] in (3, 4, 5))
+    assert out["noffgrid"] == 0 and out["nslots"] == rx.burst_seq - dropped
+    idx = T.grid_indices(out)
+    assert len(idx) == out["nslots"]
+    third = nrec // 3
+    pick = np.unique(np.concatenate([np.arange(min(third, len(idx))), len(idx) // 2 + np.arange(min(third, len(idx) - len(idx) // 2)),
+                                     np.arange(max(0, len(idx) - third), len(idx))]))
+    gi = idx[pick]
+    r = rec[out["grid_base"] + gi]
+    slots = np.stack([st[out["anchor"] + 510 * int(g):out["anchor"] + 510 * int(g) + 510] for g in gi])
+    ty = T.parse_records(r)["type"].astype(np.uint8)
+    ok, p = check_against_oracle(T, r, ty, slots, code, use_acc=1)
+    assert (p["code"][ty != 3] == code).all()
+    return len(want_ev), len(pick)
+
+
 @pytest.mark.gpu
 def test_device_walk_of_a_channel_beyond_one_workgroups_arrays(T, eng):
     """a recording of 300 000 slots (more than the 262 144 whose bitmap and node list k_walk keeps in LDS) next to a
@@ -2494,8 +2537,8 @@ def test_device_walk_of_a_channel_beyond_one_workgroups_arrays(T, eng):
     import torch
     import bench
     hs = torch.cuda.current_stream().cuda_stream
-    st0, _, _ = bench.make_mix_stream(T, 300000, 2, mnc=61, cc=4)
-    st1, _, _ = bench.make_mix_stream(T, 5000, 3, mnc=62, cc=5)
+    st0, _, code0 = bench.make_mix_stream(T, 300000, 2, mnc=61, cc=4)
+    st1, _, code1 = bench.make_mix_stream(T, 5000, 3, mnc=62, cc=5)
     streams = [np.ascontiguousarray(st0), np.ascontiguousarray(st1)]
     d, offs, ntot = _multi_batch(T, streams)
     pa, pb = T.Plan(eng, ntot, 2), T.Plan(eng, ntot, 2)
@@ -2510,8 +2553,13 @@ def test_device_walk_of_a_channel_beyond_one_workgroups_arrays(T, eng):
         msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), 64, hs)
         got = msd.collect()
         assert not msd.fellback and msd.ngrid == ms.ngrid
-        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES), "long channel")
+        rec_b = rb.cpu().numpy().reshape(-1, T.REC_BYTES)
+        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rec_b, "long channel")
         assert pb.final_codes().tolist() == pa.final_codes().tolist()
+        if rep == 0:        # the device walk's outcome against the oracle's receiver on the same bytes, both channels
+            nev, nrec = _oracle_check_of_a_walked_channel(T, streams[0], got[0], rec_b, code0)
+            assert nev > 4096 and nrec >= 20000 - 2
+            _oracle_check_of_a_walked_channel(T, streams[1], got[1], rec_b, code1)
     pa.close()
     pb.close()
 
@@ -2524,8 +2572,8 @@ def test_device_walk_takes_noisy_channels_into_the_long_form(T, eng):
     import torch
     import bench
     hs = torch.cuda.current_stream().cuda_stream
-    st0, _, _ = bench.make_mix_stream(T, 150000, 6, mnc=71, cc=2, damaged=0.08)
-    st1, _, _ = bench.make_mix_stream(T, 4000, 7, mnc=72, cc=3)
+    st0, _, code0 = bench.make_mix_stream(T, 150000, 6, mnc=71, cc=2, damaged=0.08)
+    st1, _, code1 = bench.make_mix_stream(T, 4000, 7, mnc=72, cc=3)
     streams = [np.ascontiguousarray(st0), np.ascontiguousarray(st1)]
     d, offs, ntot = _multi_batch(T, streams)
     pa, pb = T.Plan(eng, ntot, 2), T.Plan(eng, ntot, 2)
@@ -2540,7 +2588,45 @@ def test_device_walk_takes_noisy_channels_into_the_long_form(T, eng):
         msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), 64, hs)
         got = msd.collect()
         fell.append(bool(msd.fellback))
-        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES), "noisy channel %d" % rep)
+        rec_b = rb.cpu().numpy().reshape(-1, T.REC_BYTES)
+        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rec_b, "noisy channel %d" % rep)
+        if rep == 1:        # the long form's outcome (k_walk_big on a channel with > 8192 exceptions) against the oracle's receiver
+            nev, nrec = _oracle_check_of_a_walked_channel(T, streams[0], got[0], rec_b, code0)
+            assert nev > 8192 and nrec >= 20000 - 2
+            _oracle_check_of_a_walked_channel(T, streams[1], got[1], rec_b, code1)
     assert fell == [True, False, False], fell
     pa.close()
     pb.close()
+
+
+@pytest.mark.gpu
+def test_device_walk_batches_on_small_plans(T, eng):
+    """device-walk batches on plans of a few hundred slots, several alive at once, each channel of another cell: such plans
+    keep their upload arena in mapped host memory (where the walk's kernels must not run their atomics: they get a device
+    arena) and their mask table must hold the batch's code hash table whatever the plan's size (entries up to
+    1 + nchan + 4096).  Outcome == the host-walk batch's, for every plan, after all of them ran"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    sets = []
+    for k in range(6):
+        cells = [(262, 42 + 7 * k, 1 + k), (901, 77 + k, 9 + k)]
+        streams = [_mix_stream(T, 90 + 13 * k, 8800 + 10 * k + c, cell, ber=0.0)[0] for c, cell in enumerate(cells)]
+        d, offs, ntot = _multi_batch(T, streams)
+        assert ntot <= 256                # (the mapped-arena size class)
+        pa, pb = T.Plan(eng, ntot, 2), T.Plan(eng, ntot, 2)
+        ms = T.MultiSync(eng, pa, streams, d.data_ptr(), offs, 64, hs)
+        ref = ms.finish(burst_events=False, nthreads=2)
+        ra = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        pa.execute(d.data_ptr(), ra.data_ptr(), hs)
+        rb = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), 64, hs)
+        sets.append((ref, ra, rb, msd, pa, pb, d, streams))
+    for ref, ra, rb, msd, pa, pb, d, streams in sets:
+        got = msd.collect()
+        torch.cuda.synchronize()
+        assert not msd.fellback
+        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES), "small plan")
+        assert pb.final_codes().tolist() == pa.final_codes().tolist()
+    for s_ in sets:
+        s_[4].close()
+        s_[5].close()

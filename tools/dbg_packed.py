@@ -14,7 +14,7 @@ plan = T.Plan(eng, n + 8, 1)
 hs = torch.cuda.current_stream().cuda_stream
 res = {}
 for mode in ("1", "0"):
-    os.environ["TGPU_STREAM_V1"] = mode
+    T.set_option(T.OPT_STREAM_EXACT, int(mode))
     g = T.GridSync(eng, plan, stream, d_stream.data_ptr(), 64, hs)
     out = g.finish(burst_events=False)
     res[mode] = plan.read_packed().reshape(-1, 20).copy()

@@ -1,4 +1,4 @@
-"""experiment: k_front time vs number of workgroups (TGPU_FRONT_BLOCKS)"""
+"""experiment: k_front time vs number of workgroups (tgpu_engine_set_option: TGPU_OPT_FRONT_BLOCKS)"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
@@ -15,7 +15,7 @@ K = 30
 prof = T.Prof(K)
 st = torch.cuda.current_stream().cuda_stream
 for blocks in (4096, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192, 16384, 4096):
-    os.environ["TGPU_FRONT_BLOCKS"] = str(blocks)
+    T.set_option(T.OPT_FRONT_BLOCKS, int(blocks))
     for k in range(K): plan.execute_prof(d_stream.data_ptr(), d_rec.data_ptr(), st, prof, k)
     torch.cuda.synchronize()
     ms = prof.read(K)

@@ -6,7 +6,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); x=d.get('decode_only', 
 if x is None: x=dict(value=d['value'], ms_per_step=d['ms_per_step'], window_spread=d['timing']['window_spread'], host_cpu_ms_per_step=list(d['breakdown_ms'].values())[0])
 print('noside=$BENCH_NO_SIDE $*', round(x['value']/1e9,3), round(x['ms_per_step'],4), 'spread', round(x['window_spread'],3), 'hostcpu', round(x['host_cpu_ms_per_step'],3))"; }
 for ns in 1 0; do
-export BENCH_NO_SIDE=$ns
+
 one --depth 4
 one --depth 4
 one --depth 8

@@ -1,6 +1,6 @@
 #!/bin/bash
 F="--steps 20 --warmup 8 --no-cpu-baseline --no-secondary --no-e2e"
-export BENCH_NO_SIDE=1 BENCH_STEP_TIMES=1
+
 one() { python bench.py $F "$@" 2>gpurun_out/err.txt | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); x=d.get('decode_only', None)

@@ -20,7 +20,7 @@ plan = T.Plan(eng, n + 8, 1)
 hs = torch.cuda.current_stream().cuda_stream
 res = {}
 for mode in ("1", "0"):
-    os.environ["TGPU_STREAM_V1"] = mode
+    T.set_option(T.OPT_STREAM_EXACT, int(mode))
     ts = []
     for rep in range(12):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,7 +32,7 @@ for mode in ("1", "0"):
         ts.append(e0.elapsed_time(e1) * 1e3)
         out = g.finish(burst_events=False)
     res[mode] = (out, plan.read_packed())
-    print("TGPU_STREAM_V1=%s: front + D2H of 6 B/slot: min %.1f us  median %.1f us  (delivered %d of %d grid slots)"
+    print("TGPU_OPT_STREAM_EXACT=%s: front + D2H of 6 B/slot: min %.1f us  median %.1f us  (delivered %d of %d grid slots)"
           % (mode, min(ts), float(np.median(ts)), out["nslots"], out["ngrid"]))
 a, b = res["1"], res["0"]
 print("packed equal:", bool((a[1] == b[1]).all()), " outcome equal:", a[0]["nslots"] == b[0]["nslots"] and a[0]["events"] == b[0]["events"])

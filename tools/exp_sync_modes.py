@@ -3,7 +3,6 @@ import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
-os.environ["TGPU_SYNC_TIMING"] = "1"
 n = 1_000_000
 rng = np.random.default_rng(7)
 pat = np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8)
