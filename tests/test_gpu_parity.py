@@ -2610,7 +2610,7 @@ def test_device_walk_batches_on_small_plans(T, eng):
     sets = []
     for k in range(6):
         cells = [(262, 42 + 7 * k, 1 + k), (901, 77 + k, 9 + k)]
-        streams = [_mix_stream(T, 90 + 13 * k, 8800 + 10 * k + c, cell, ber=0.0)[0] for c, cell in enumerate(cells)]
+        streams = [_mix_stream(T, 40 + 5 * k, 8800 + 10 * k + c, cell, ber=0.0)[0] for c, cell in enumerate(cells)]
         d, offs, ntot = _multi_batch(T, streams)
         assert ntot <= 256                # (the mapped-arena size class)
         pa, pb = T.Plan(eng, ntot, 2), T.Plan(eng, ntot, 2)
