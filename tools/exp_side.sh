@@ -1,5 +1,5 @@
 #!/bin/bash
-F="--steps 20 --warmup 8 --no-cpu-baseline --no-secondary --no-e2e"
+F="--steps 20 --warmup 8 --no-cpu-baseline --no-secondary --no-e2e --no-sustained"
 one() { python bench.py $F "$@" 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); x=d.get('decode_only', None)

@@ -40,7 +40,7 @@ def main():
     tj["mix"] = {k: mix_t[k] for k in mix_t if k.startswith(("k_front_stream", "k_vit"))}
     tj["mix_valu_busy"] = {k: mix_b[k] for k in mix_b if k.startswith(("k_front_stream", "k_vit"))}
     tj["_mix_provenance"] = ("round 3: rocprofv3 --pmc passes (tools/prof_run.sh %s mix 1) on `python bench.py --steps 12 --warmup 6 "
-                             "--windows 2 --depth 1 --no-cpu-baseline --no-secondary --no-e2e`; summary in profiles/r03_mix_rocprofv3.md"
+                             "--windows 2 --depth 1 --no-cpu-baseline --no-secondary --no-e2e --no-sustained`; summary in profiles/r03_mix_rocprofv3.md"
                              % os.path.basename(sys.argv[1]).replace("prof_", ""))
     if len(sys.argv) > 2:
         c2_t, c2_b = derive(read(sys.argv[2]))
