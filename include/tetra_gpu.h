@@ -590,6 +590,21 @@ struct tgpu_sync_dev;
 int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
 			   const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *hip_stream);
 int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *out);
+/*
+ * Packed ingest (optional; the API's input format stays one bit per byte): a capture that sits in HOST memory crosses PCIe
+ * as 510 bytes per burst, which bounds the end-to-end rate near 1e8 bursts/s whatever the kernels do.  tgpu_pack_bits()
+ * packs it on the host -- bit i of packed byte k = bytes[8 k + i] & 1, the order of the kernels' own bit string; nthreads
+ * host threads, AVX2 where the CPU has it -- and returns how many pieces held a byte other than 0 / 1 (0: the packed stream
+ * is equivalent; otherwise the byte path is the one to use: such bytes break the reference's memcmp in tetra_find_train_seq()
+ * and the packed form cannot show them), or a negative TGPU_E* code.  tgpu_sync_multi_launch_packed() is
+ * tgpu_sync_multi_launch() on such a buffer: d_packed_base = the packed streams on the device, ch[c].d_off = the BIT offset
+ * of channel c's position 0 in it (a multiple of 8), ch[c].h_stream / len = the unpacked host bytes as before (the first
+ * lock of a channel is found on the host).  The buffer needs 512 readable bytes behind the last channel's last bit.
+ * Everything downstream is the same kernels on the same bits: records are byte-identical to the byte path's.
+ */
+int64_t tgpu_pack_bits(const uint8_t *bytes, uint64_t n, uint8_t *packed /* (n + 7) / 8 bytes */, unsigned int nthreads);
+int tgpu_sync_multi_launch_packed(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+				  const uint8_t *d_packed_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *hip_stream);
 uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd);
 int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd);
 uint64_t tgpu_sync_dev_cwire_bytes(const struct tgpu_sync_dev *sd);	/* after collect; tgpu_plan_set_cwire() */

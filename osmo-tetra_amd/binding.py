@@ -197,6 +197,9 @@ def lib():
     L.tgpu_sync_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, u32p, u16p, C.c_void_p]
     L.tgpu_sync_multi_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(MultiChan), C.c_void_p, C.c_uint32, C.c_void_p,
                                          C.POINTER(C.c_void_p), C.c_void_p]
+    L.tgpu_sync_multi_launch_packed.argtypes = L.tgpu_sync_multi_launch.argtypes
+    L.tgpu_pack_bits.restype = C.c_int64
+    L.tgpu_pack_bits.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint]
     L.tgpu_sync_multi_collect.argtypes = [C.c_void_p, C.POINTER(SyncResult)]
     L.tgpu_sync_multi_launch_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(MultiChan), C.c_void_p, C.c_uint32, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
@@ -784,7 +787,7 @@ class MultiSyncDev:
     decode into d_rec enqueued behind them -- the constructor returns without waiting, collect() waits and returns one
     outcome per channel (events, delivered bitmap, counts); .fellback tells whether the host walks had to decide"""
 
-    def __init__(self, engine, plan, streams, d_base_ptr, d_offs, d_rec_ptr, chunk=64, hip_stream=0, codes=None, chans=None):
+    def __init__(self, engine, plan, streams, d_base_ptr, d_offs, d_rec_ptr, chunk=64, hip_stream=0, codes=None, chans=None, packed=False):
         self.engine, self.plan, self.hip_stream = engine, plan, hip_stream
         if chans is not None:       # (a prepared channel table: the bench builds it once)
             self.streams, self._ch = chans
@@ -792,8 +795,10 @@ class MultiSyncDev:
             self.streams, self._ch = multi_chan_table(streams, d_offs, codes)
         n = len(self.streams)
         self._h = C.c_void_p()
-        _chk(lib().tgpu_sync_multi_launch(engine._h, plan._h, n, self._ch, C.c_void_p(d_base_ptr), chunk, C.c_void_p(d_rec_ptr),
-                                          C.byref(self._h), C.c_void_p(hip_stream)), "tgpu_sync_multi_launch")
+        # packed=True: d_base_ptr = the streams packed one bit per bit (pack_bits), the offsets count bits
+        fn = lib().tgpu_sync_multi_launch_packed if packed else lib().tgpu_sync_multi_launch
+        _chk(fn(engine._h, plan._h, n, self._ch, C.c_void_p(d_base_ptr), chunk, C.c_void_p(d_rec_ptr),
+                C.byref(self._h), C.c_void_p(hip_stream)), "tgpu_sync_multi_launch")
         self.ngrid = lib().tgpu_sync_dev_ngrid(self._h)
         self.fellback = False
 
@@ -849,6 +854,18 @@ def sync_multi_launch_prof(engine, plan, chans, d_base_ptr, d_rec_ptr, prof, ste
                                            C.c_void_p(hip_stream), prof._h, step, ms), "tgpu_sync_multi_launch_prof")
     lib().tgpu_sync_dev_stage_name.restype = C.c_char_p
     return {lib().tgpu_sync_dev_stage_name(i).decode(): float(ms[i]) for i in range(DEV_STAGES)}
+
+
+def pack_bits(stream, out=None, nthreads=1):
+    """tgpu_pack_bits: a 1-bit-per-byte host array -> one bit per bit (LSB first); returns (packed uint8 array, number of
+    pieces that held a byte other than 0 / 1).  out: a preallocated (pinned) uint8 array of (len + 7) // 8 bytes"""
+    x = _np_u8(stream)
+    if out is None:
+        out = np.zeros((len(x) + 7) // 8, np.uint8)
+    bad = lib().tgpu_pack_bits(C.c_void_p(x.ctypes.data), len(x), C.c_void_p(out.ctypes.data), nthreads)
+    if bad < 0:
+        _chk(int(bad), "tgpu_pack_bits")
+    return out, int(bad)
 
 
 def cwire_bound(ngrid, nchan):

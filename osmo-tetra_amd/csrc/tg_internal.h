@@ -23,13 +23,14 @@ int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uin
 /* several channels in one grid (BASELINE config 4): channel c owns grid slots gbase .. gbase + ncls - 1, gbase a
  * multiple of 32 (padding slots behind ncls are classified "nothing"); its stream lies at byte d_off of d_base */
 struct tg_chan_ent {
-	uint64_t d_off, anchor, len;
+	uint64_t d_off, anchor, len;	/* d_off | TG_CHAN_PACKED: the device buffer holds the stream one BIT per position (LSB first), d_off counts bits */
 	uint32_t gbase, ncls;
 };
+#define TG_CHAN_PACKED (1ull << 63)
 void tgk_front_stream_ev_start(void *ev);	/* timing: record 'ev' right in front of this thread's next k_front_stream launch */
 int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots,
 			   uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer,
-			   void *stream, void *ev_mid);
+			   void *stream, void *ev_mid, int packed_input /* every channel's d_off carries TG_CHAN_PACKED */);
 int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed,
 	    const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec,
 	    uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire /* or NULL */,

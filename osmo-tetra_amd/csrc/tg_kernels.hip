@@ -447,6 +447,7 @@ struct tg_stream_params {
 	 * are padding and never decoded); its stream lies at byte d_off of the buffer, anchor / len are relative to it */
 	const struct tg_chan_ent *chan;
 	uint32_t nchan;		/* 0: one stream, the fields above */
+	uint64_t pbit;		/* packed ingest (per-position form): bit position of the channel's stream position 0 in the packed buffer */
 };
 
 /* channel of grid slot 'slot' (nchan <= 64: one table word per lane, a ballot counts the channels that start at or
@@ -464,17 +465,33 @@ __device__ __forceinline__ uint32_t chan_of_slot(const tg_chan_ent *chan, uint32
  * round-1 kernel ran it on every slot (k_front_stream_v1, kept for A/B runs), the packed-bit kernel below hands
  * it the slots it cannot settle (k_front_stream_fix).
  */
+template <bool PACKED = false>
 __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ stream, const tg_stream_params &prm, uint32_t slot,
 						  uint32_t lane, uint32_t half, uint32_t bit, uint32_t wbase, uint32_t *mine,
 						  const uint8_t *lds0, const uint32_t (&a_n1)[10], const uint32_t (&a_n2)[10],
 						  const uint32_t (&a_sb)[10], uint32_t &myword, uint32_t &clsword, uint32_t &ysword)
 {
 	const uint64_t bs = prm.anchor + (uint64_t)slot * TG_SLOT_BITS;
-	const uint8_t *base = stream + bs;
-	/* 640 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack) */
-	const uint32_t d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
-	const uint32_t d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
-	const uint32_t d2 = (lane < 32) ? *(const tg_u32_unaligned *)(base + 512 + 4 * lane) : 0u;
+	uint32_t d0, d1, d2;
+	if (PACKED) {
+		/* packed ingest: 'stream' is the packed buffer and prm.anchor counts from the channel's bit 0, whose position in the
+		 * buffer the caller has added to... the bit position of the slot: every lane fetches the two bytes that hold its
+		 * four bits of each 256-byte third of the view and spreads them to the bytes the unpacked stream would have */
+		const uint64_t b0 = prm.pbit + bs + 4 * lane;
+		auto nib = [&](uint64_t b) {
+			const uint32_t w = *(const tg_u16_unaligned *)(stream + (b >> 3));
+			return spread4((w >> (b & 7)) & 15u);
+		};
+		d0 = nib(b0);
+		d1 = nib(b0 + 256);
+		d2 = (lane < 32) ? nib(b0 + 512) : 0u;
+	} else {
+		const uint8_t *base = stream + bs;
+		/* 640 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack) */
+		d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
+		d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
+		d2 = (lane < 32) ? *(const tg_u32_unaligned *)(base + 512 + 4 * lane) : 0u;
+	}
 
 	uint64_t fed = bs + TG_SLOT_BITS + prm.chunk - 1;
 	fed = prm.cshift >= 0 ? (fed >> prm.cshift) << prm.cshift : (fed / prm.chunk) * prm.chunk;
@@ -685,6 +702,7 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
  * time.  Deferred slots are rare (damaged training sequences, the end of a stream); the grid is sized for about one
  * entry per wave, a wave takes entries wave, wave + nwaves, ... */
 #define TG_DEFER_LIST 16
+template <bool PACKED>
 __global__ __launch_bounds__(256)
 void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
@@ -707,11 +725,12 @@ void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm
 					tg_stream_params q = prm;
 					q.anchor = prm.chan[c].anchor;
 					q.len = prm.chan[c].len;
-					front_stream_slot(stream + prm.chan[c].d_off, q, i, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb,
-							  myword, clsword, ys);
+					q.pbit = prm.chan[c].d_off & ~TG_CHAN_PACKED;
+					front_stream_slot<PACKED>(PACKED ? stream : stream + prm.chan[c].d_off, q, i, lane, half, bit, wbase, mine, lds0,
+								  a_n1, a_n2, a_sb, myword, clsword, ys);
 				}
 			} else
-				front_stream_slot(stream, prm, slot, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb, myword, clsword, ys);
+				front_stream_slot<PACKED>(stream, prm, slot, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb, myword, clsword, ys);
 			if (lane < TG_PACKED_WORDS)
 				packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
 			if (lane == 0) {
@@ -854,13 +873,14 @@ extern "C" int tgk_front_stream_stamps(unsigned long long *out, int reset)
 #else
 #define TGS_MARK(i) do { } while (0)
 #endif
+template <bool PACKED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TG_STREAM_WPE, TG_STREAM_WPE)))
 void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
 		    uint32_t *__restrict__ defer)
 {
 	constexpr uint64_t PY = tsq_bits(TSQ_Y), PN = tsq_bits(TSQ_N), PP = tsq_bits(TSQ_P);
-	__shared__ uint32_t s_bits[4][72];	/* per wave: the group's bit string (68 dwords used) */
+	__shared__ __attribute__((aligned(16))) uint32_t s_bits[4][72];	/* per wave: the group's bit string (68 dwords used; packed ingest: 72, 16 bytes per lane) */
 	__shared__ uint32_t s_win[4][4 * TG_VER_SLOT];	/* per wave: four slots x eight shifted copies of the 512-bit window */
 	__shared__ uint32_t s_out[4][160];	/* per wave: four packed slots on their way out, then their cls / ysum words (+ the idle lanes' dump) */
 
@@ -941,7 +961,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 				cg0 = __builtin_amdgcn_readfirstlane(e.gbase);
 				cg1 = __builtin_amdgcn_readfirstlane(nxt);
 				cncls = __builtin_amdgcn_readfirstlane(e.ncls);
-				const uint64_t f = e.d_off + e.anchor, sp = e.len - e.anchor;
+				const uint64_t f = (e.d_off & ~TG_CHAN_PACKED) + e.anchor, sp = e.len - e.anchor;
 				cfirst = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)f) |
 					 ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(f >> 32)) << 32);
 				cspan = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)sp) |
@@ -955,6 +975,16 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			first = prm.anchor;
 			gb = prm.anchor + (uint64_t)g * TG_GROUP_BYTES;
 			d.fast = gb + TG_GROUP_BYTES + TG_STREAM_VIEW <= prm.len;
+		}
+		if (PACKED) {
+			/* packed ingest: the stream lies in memory one bit per position, so a group is 255 bytes: eighteen lanes
+			 * fetch 16 bytes each from the aligned address below its first bit, a0 = how many bits in the group starts */
+			const uint64_t gbit = d.fast ? gb : first;
+			const uint8_t *p = stream + (gbit >> 3);
+			const uint32_t ab = (uint32_t)((uintptr_t)p & 15);
+			d.a0 = 8 * ab + (uint32_t)(gbit & 7);
+			d.a = *(const uint4 *)(p - ab + 16 * (lane < 18 ? lane : 17));
+			return;
 		}
 #if TGS_ABLATE & 2
 		const uint8_t *p = stream + first + 2040u * (wave & 1023u);
@@ -971,13 +1001,19 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	auto work = [&](uint32_t g, const tg_group_data &cur) {
 		TGS_MARK(0);	/* since the last mark: the next group's fetch issued */
 		/* bytes other than 0 / 1 anywhere in the group: not for this kernel */
-		const uint32_t orall = cur.a.x | cur.a.y | cur.a.z | cur.a.w | cur.b.x | cur.b.y | cur.b.z | cur.b.w |
-				       cur.c.x | cur.c.y | cur.c.z | cur.c.w;
-		const bool defer_all = !cur.fast || __ballot((orall & 0xfefefefeu) != 0) != 0;
+		bool defer_all;
+		if (PACKED) {
+			defer_all = !cur.fast;
+			TGS_MARK(1);
+			if (lane < 18)		/* the bits are the bit string: 288 bytes, as they came */
+				((uint4 *)bits)[lane] = cur.a;
+		} else {
+			const uint32_t orall = cur.a.x | cur.a.y | cur.a.z | cur.a.w | cur.b.x | cur.b.y | cur.b.z | cur.b.w |
+					       cur.c.x | cur.c.y | cur.c.z | cur.c.w;
+			defer_all = !cur.fast || __ballot((orall & 0xfefefefeu) != 0) != 0;
 
-		TGS_MARK(1);	/* the group's bytes are here */
-		/* bytes -> bits -> LDS */
-		{
+			TGS_MARK(1);	/* the group's bytes are here */
+			/* bytes -> bits -> LDS */
 			tg_u16_alias *b16 = (tg_u16_alias *)bits;
 			b16[lane] = (uint16_t)bytes16_to_bits(cur.a);
 			b16[64 + lane] = (uint16_t)bytes16_to_bits(cur.b);
@@ -3102,7 +3138,7 @@ extern "C" void tgk_front_stream_ev_start(void *ev)
 }
 
 static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &prm, uint32_t *d_packed, uint32_t *d_cls,
-			       uint16_t *d_ysum, uint32_t *d_defer, hipStream_t s, void *ev_mid)
+			       uint16_t *d_ysum, uint32_t *d_defer, hipStream_t s, void *ev_mid, bool packed_input = false)
 {
 	const uint32_t nslots = prm.nslots;
 	uint32_t blocks = ((nslots + 3) / 4 + 3) / 4;	/* a wave per group of four slots */
@@ -3116,20 +3152,26 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 		HIPCHK(hipEventRecord((hipEvent_t)tl_front_ev_start, s));
 		tl_front_ev_start = nullptr;
 	}
-	hipLaunchKernelGGL(k_front_stream, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
+	if (packed_input)
+		hipLaunchKernelGGL(k_front_stream<true>, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
+	else
+		hipLaunchKernelGGL(k_front_stream<false>, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
 	if (ev_mid)
 		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
 	uint32_t fblocks = (nslots / 128 + 3) / 4 + 1;	/* about a wave per deferred slot at 1 % of them */
 	if (fblocks > 256 * 16)
 		fblocks = 256 * 16;
-	hipLaunchKernelGGL(k_front_stream_fix, dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
+	if (packed_input)
+		hipLaunchKernelGGL(k_front_stream_fix<true>, dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
+	else
+		hipLaunchKernelGGL(k_front_stream_fix<false>, dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
 	return (int)hipGetLastError();
 }
 
 /* several channels in one grid: d_chan = device copy of nchan (<= 64) tg_chan_ent, nslots = the grid's total size */
 extern "C" int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots,
 				      uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer,
-				      void *stream, void *ev_mid)
+				      void *stream, void *ev_mid, int packed_input)
 {
 	if (!nslots)
 		return 0;
@@ -3141,7 +3183,7 @@ extern "C" int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_cha
 	prm.chan = d_chan;
 	prm.nchan = nchan;
 	stream_patterns(prm, chunk);
-	return launch_stream_front(d_base, prm, d_packed, d_cls, d_ysum, d_defer, (hipStream_t)stream, ev_mid);
+	return launch_stream_front(d_base, prm, d_packed, d_cls, d_ysum, d_defer, (hipStream_t)stream, ev_mid, packed_input != 0);
 }
 
 static void stream_patterns(tg_stream_params &prm, uint32_t chunk)
@@ -3618,7 +3660,9 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	tgw_chan wc;
 	wc.cls = g_cls + ce.gbase;
 	wc.ysum = g_ysum + ce.gbase;
-	wc.s = d_base + ce.d_off;
+	wc.packed = (ce.d_off & TG_CHAN_PACKED) != 0;
+	wc.sbit = ce.d_off & ~TG_CHAN_PACKED;
+	wc.s = wc.packed ? d_base : d_base + ce.d_off;
 	wc.len = ce.len;
 	wc.anchor = ce.anchor;
 	wc.ncalls = (ce.len + chunk - 1) >> cshift;
@@ -3985,7 +4029,9 @@ void k_walk_nodes(tg_walk_big big, uint8_t *__restrict__ scratch, uint8_t *__res
 	tgw_chan wc;
 	wc.cls = g_cls + ce.gbase;
 	wc.ysum = g_ysum + ce.gbase;
-	wc.s = d_base + ce.d_off;
+	wc.packed = (ce.d_off & TG_CHAN_PACKED) != 0;
+	wc.sbit = ce.d_off & ~TG_CHAN_PACKED;
+	wc.s = wc.packed ? d_base : d_base + ce.d_off;
 	wc.len = ce.len;
 	wc.anchor = ce.anchor;
 	wc.ncalls = (ce.len + chunk - 1) >> cshift;

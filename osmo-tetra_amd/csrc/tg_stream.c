@@ -976,7 +976,7 @@ int tgpu_sync_multi_begin(struct tgpu_engine *eng, struct tgpu_plan *plan, uint3
 			rc = tgpi_plan_chan_table(plan, st->ent, nchan, &d_tab, stream);
 		if (!rc)
 			rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
-						    tgpi_plan_defer_scratch(plan), stream, NULL);
+						    tgpi_plan_defer_scratch(plan), stream, NULL, 0);
 		if (!rc) {
 			uint32_t *d_plain, *h_plain;
 			tgpi_plan_grid_plain(plan, st->ngrid, &d_plain, &h_plain);
@@ -1127,7 +1127,7 @@ int tgpu_sync_front_prof_multi(struct tgpu_engine *eng, struct tgpu_plan *plan, 
 			rc = (int)hipEventRecord(ev[0], (hipStream_t)stream);
 			if (!rc)
 				rc = tgk_front_stream_multi(d_base, d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
-							    tgpi_plan_defer_scratch(plan), stream, ev[1]);
+							    tgpi_plan_defer_scratch(plan), stream, ev[1], 0);
 			if (!rc)
 				rc = (int)hipEventRecord(ev[2], (hipStream_t)stream);
 			if (!rc)
@@ -1197,7 +1197,7 @@ int tgpu_sync_walk_emul(const uint8_t *h_stream, uint64_t len, uint32_t chunk, u
 	 * the plan's capacity, here for the channel's own length) */
 	const int big = W > TGW_WCAP;
 	const uint32_t ncap = big ? tg_walk_big_ncap(ncls) : TGW_NCAP, evcap = big ? 4 * ncap : TGW_EVCAP;
-	struct tgw_chan wc = { cls, ysum, h_stream, len, anchor, (len + chunk - 1) / chunk, ncls, chunk, (uint32_t)__builtin_ctz(chunk) };
+	struct tgw_chan wc = { cls, ysum, h_stream, 0, 0, len, anchor, (len + chunk - 1) / chunk, ncls, chunk, (uint32_t)__builtin_ctz(chunk) };
 	uint32_t *bm = malloc((size_t)W * 4), *wpre = malloc((size_t)W * 4);
 	uint32_t *nslot = malloc((size_t)ncap * 4);
 	uint32_t *Ja = malloc(((size_t)ncap + 8) * 4), *Jb = malloc(((size_t)ncap + 8) * 4);
@@ -1390,12 +1390,22 @@ void tgpu_sync_dev_free(struct tgpu_sync_dev *sd)
  * of the decode itself (tgpu_plan_execute_prof) */
 static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
 			const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *stream,
-			hipEvent_t *evs, struct tgpu_prof *prof, uint32_t step);
+			hipEvent_t *evs, struct tgpu_prof *prof, uint32_t step, int packed_input);
 
 int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
 			   const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *stream)
 {
-	return multi_launch(eng, plan, nchan, ch, d_base, chunk, d_rec, out, stream, NULL, NULL, 0);
+	return multi_launch(eng, plan, nchan, ch, d_base, chunk, d_rec, out, stream, NULL, NULL, 0, 0);
+}
+
+int tgpu_sync_multi_launch_packed(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
+				  const uint8_t *d_packed_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *stream)
+{
+	if (ch)
+		for (uint32_t c = 0; c < nchan; c++)
+			if (ch[c].d_off & 7)
+				return TGPU_EINVAL;	/* a channel starts on a byte of the packed buffer */
+	return multi_launch(eng, plan, nchan, ch, d_packed_base, chunk, d_rec, out, stream, NULL, NULL, 0, 1);
 }
 
 const char *tgpu_sync_dev_stage_name(int stage)
@@ -1423,7 +1433,7 @@ int tgpu_sync_multi_launch_prof(struct tgpu_engine *eng, struct tgpu_plan *plan,
 		rc = (int)hipEventCreate(&evs[i]);
 	struct tgpu_sync_dev *sd = NULL;
 	if (!rc)
-		rc = multi_launch(eng, plan, nchan, ch, d_base, chunk, d_rec, &sd, stream, evs, prof, step);
+		rc = multi_launch(eng, plan, nchan, ch, d_base, chunk, d_rec, &sd, stream, evs, prof, step, 0);
 	if (!rc)
 		rc = (int)hipStreamSynchronize((hipStream_t)stream);
 	for (int i = 0; i < TGPU_NDEVSTAGES && !rc; i++)
@@ -1437,7 +1447,7 @@ int tgpu_sync_multi_launch_prof(struct tgpu_engine *eng, struct tgpu_plan *plan,
 
 static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
 			const uint8_t *d_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *stream,
-			hipEvent_t *evs, struct tgpu_prof *prof, uint32_t step)
+			hipEvent_t *evs, struct tgpu_prof *prof, uint32_t step, int packed_input)
 {
 	if (!eng || !plan || !nchan || nchan > 64 || !ch || !d_base || !d_rec || !out)
 		return TGPU_EINVAL;
@@ -1486,7 +1496,7 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			n = (ch[c].len - anchor) / TG_SLOT_BITS;
 		else
 			st->locks[c] = 0;
-		st->ent[c].d_off = ch[c].d_off;
+		st->ent[c].d_off = ch[c].d_off | (packed_input ? TG_CHAN_PACKED : 0);	/* (packed ingest: a bit offset) */
 		st->ent[c].anchor = anchor;
 		st->ent[c].len = ch[c].len;
 		st->ent[c].gbase = (uint32_t)total;
@@ -1515,7 +1525,7 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			tgk_front_stream_ev_start(evs[0]);
 		if (!rc)
 			rc = tgk_front_stream_multi(d_base, io->d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
-						    tgpi_plan_defer_scratch(plan), stream, evs ? evs[1] : NULL);
+						    tgpi_plan_defer_scratch(plan), stream, evs ? evs[1] : NULL, packed_input);
 		EVMARK(2);
 		if (!rc) {
 			/* plain bitmap + SYNC list; SB1 and the masks beside the walk (side stream), or in line when stages are timed */

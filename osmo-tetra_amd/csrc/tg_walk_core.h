@@ -68,6 +68,8 @@ struct tgw_chan {
 	const uint32_t *cls;	/* the channel's ncls classification words */
 	const uint16_t *ysum;	/* its SYNC-sequence summaries */
 	const uint8_t *s;	/* its stream bytes (read only at the stream's tail and where a summary is in doubt) */
+	uint64_t sbit;		/* packed ingest (TG_CHAN_PACKED): s = the packed buffer, the channel's bit 0 is its bit sbit */
+	int packed;
 	uint64_t len, anchor, ncalls;
 	uint32_t ncls, chunk, cshift;
 };
@@ -96,12 +98,22 @@ TGW_FN uint64_t tgw_call_reaching(const struct tgw_chan *c, uint64_t pos)
 	return k ? k : 1;
 }
 
-TGW_FN int tgw_is_y(const uint8_t *p)
+/* stream position p of the channel as the byte the reference would read there */
+TGW_FN uint32_t tgw_byte(const struct tgw_chan *c, uint64_t p)
+{
+	if (c->packed) {
+		const uint64_t b = c->sbit + p;
+		return (c->s[b >> 3] >> (b & 7)) & 1u;
+	}
+	return c->s[p];
+}
+
+TGW_FN int tgw_is_y(const struct tgw_chan *c, uint64_t p)
 {
 	/* EN 300 392-2 9.4.4.3.4, the 38-bit synchronisation training sequence */
 	const uint64_t Y = 0x3983973983ull;	/* bit i = y[i] */
 	for (int i = 0; i < 38; i++)
-		if (p[i] != ((Y >> i) & 1))
+		if (tgw_byte(c, p + i) != ((Y >> i) & 1))
 			return 0;
 	return 1;
 }
@@ -111,7 +123,7 @@ TGW_FN int tgw_is_y(const uint8_t *p)
 TGW_FN uint64_t tgw_scan_bytes(const struct tgw_chan *c, uint64_t from, uint64_t last)
 {
 	for (uint64_t p = from; p <= last; p++)
-		if (c->s[p] == 1 && c->s[p + 1] == 1 && c->s[p + 2] == 0 && tgw_is_y(c->s + p))
+		if (tgw_byte(c, p) == 1 && tgw_byte(c, p + 1) == 1 && tgw_byte(c, p + 2) == 0 && tgw_is_y(c, p))
 			return p;
 	return UINT64_MAX;
 }
@@ -147,7 +159,7 @@ TGW_FN uint64_t tgw_next_sync(const struct tgw_chan *c, uint64_t from, uint64_t 
 			/* a byte other than 0 / 1 in this slot's or the next one's window (the kernel reads it as 1), or no
 			 * next window: the bytes decide whether the summary's sequence is one */
 			const int doubt = g + 1 >= c->ncls || (((c->cls[g] | c->cls[g + 1]) >> 24) & TG_CLS_NONBINARY);
-			const int real = !doubt || tgw_is_y(c->s + fp);
+			const int real = !doubt || tgw_is_y(c, fp);
 			if (fp >= p && real)
 				return fp <= last ? fp : UINT64_MAX;
 			if ((v & TG_YS_MULTI) || !real) {

@@ -2630,3 +2630,59 @@ def test_device_walk_batches_on_small_plans(T, eng):
     for s_ in sets:
         s_[4].close()
         s_[5].close()
+
+
+@pytest.mark.gpu
+def test_packed_ingest_equals_the_byte_path(T, eng):
+    """tgpu_pack_bits + tgpu_sync_multi_launch_packed (the capture crosses PCIe one bit per bit; the front end starts behind
+    its own bytes -> bits step) against tgpu_sync_multi_launch on the bytes: eight channels of different cells, lengths and
+    lead-ins (so that the channels' bit offsets and slot alignments differ), damaged training sequences (the per-position
+    pass runs on packed input too), spurious sequences below offset 21, a channel with next to nothing in it, one that
+    ends inside a burst.  Same events, counts, bitmaps, every record byte, final codes; no fallback either way"""
+    import torch
+    from test_stream_sync_cpu import SEQ_N, SEQ_P
+    hs = torch.cuda.current_stream().cuda_stream
+    cells = [(262, 42, 1), (901, 77, 9), (234, 14, 33), (1, 2, 3), (262, 42, 2), (505, 1, 60), (208, 10, 5), (222, 99, 7)]
+    rng = np.random.default_rng(808)
+    streams = []
+    for c, cell in enumerate(cells):
+        nsl = int(rng.integers(200, 3000)) if c != 3 else 2
+        st, _ = _mix_stream(T, nsl, 2900 + c, cell, ber=0.02)
+        st = np.concatenate([rng.integers(0, 2, int(rng.integers(0, 40))).astype(np.uint8), st])      # (another lead-in per channel)
+        lead = len(st) - 700 - 510 * (nsl + 1) + 510
+        if nsl > 100:
+            for j in (17, 18, 41, nsl - 2, nsl - 1, 64, 72):
+                st[lead + 510 * j + (214 if j % 8 == 0 else 244) + 2] ^= 1
+            for j in (30, 55):
+                seq = (SEQ_N, SEQ_P)[j % 2]
+                o = lead + 510 * j + int(rng.integers(0, 21))
+                st[o:o + len(seq)] = seq
+        if c == 5:
+            st = st[:len(st) - 700 - 200]
+        streams.append(np.ascontiguousarray(st))
+    d, offs, ntot = _multi_batch(T, streams)
+    # the packed buffer: every channel packed on its own, at a 16-byte aligned place; offsets in bits
+    poffs, o = [], 0
+    for st in streams:
+        poffs.append(o)
+        o += ((len(st) + 7) // 8 + 15) & ~15
+    pbuf = np.zeros(o + 1024, np.uint8)
+    for st, f in zip(streams, poffs):
+        p, bad = T.pack_bits(st, nthreads=3)
+        assert bad == 0
+        pbuf[f:f + len(p)] = p
+    dp = torch.from_numpy(pbuf).cuda()
+    pa, pb = T.Plan(eng, ntot, len(cells)), T.Plan(eng, ntot, len(cells))
+    ra = torch.zeros(ntot * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    rb = torch.zeros(ntot * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    a = T.MultiSyncDev(eng, pa, streams, d.data_ptr(), offs, ra.data_ptr(), 64, hs)
+    ref = a.collect()
+    b = T.MultiSyncDev(eng, pb, streams, dp.data_ptr(), [8 * f for f in poffs], rb.data_ptr(), 64, hs, packed=True)
+    got = b.collect()
+    torch.cuda.synchronize()
+    assert not a.fellback and not b.fellback and a.ngrid == b.ngrid
+    assert sum(len(x["events"]) for x in ref) > 100
+    _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES), "packed ingest")
+    assert pa.final_codes().tolist() == pb.final_codes().tolist()
+    pa.close()
+    pb.close()

@@ -372,3 +372,19 @@ def test_acelp_reordering_with_the_reference_tables():
         R.tetra_acelp_type2_to_codec(C.cast(b[8:].ctypes.data, O.u8p), C.cast(want[8:].ctypes.data, O.u8p))
         got = T.acelp_type2_to_codec(b[8:282].copy(), out=np.full(274, 7, np.uint8))
         assert got.tolist() == want[8:282].tolist()
+
+
+def test_pack_bits_host():
+    """tgpu_pack_bits: bit i of packed byte k = bytes[8 k + i] & 1 for every length and thread count; a byte other than 0 / 1
+    is reported"""
+    import osmo_tetra_amd as T
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 7, 8, 9, 127, 128, 129, 1000, 100003, 1_000_000):
+        x = rng.integers(0, 2, n).astype(np.uint8)
+        for th in (1, 3, 8):
+            p, bad = T.pack_bits(x, nthreads=th)
+            assert bad == 0 and (p == np.packbits(x, bitorder="little")).all(), (n, th)
+    x = rng.integers(0, 2, 100000).astype(np.uint8)
+    x[77777] = 3
+    p, bad = T.pack_bits(x, nthreads=4)
+    assert bad > 0 and (p == np.packbits(x & 1, bitorder="little")).all()
