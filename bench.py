@@ -736,6 +736,108 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         except Exception as ex:      # pragma: no cover
             e2e = {"error": repr(ex)}
 
+    # packed ingest (optional path, never `value`; the API's input format stays 1 bit per byte): the same capture in host
+    # memory is packed one bit per BIT by host threads (tgpu_pack_bits), 64 MB cross PCIe instead of 510, and the front end
+    # starts behind its own bytes -> bits step (tgpu_sync_multi_launch_packed)
+    e2ep = None
+    if world == 1 and not args.no_e2e:
+        try:
+            NB = 3
+            nth = args.pack_threads or max(1, min(128, host_threads_default()))
+            npk = (len(buf) + 7) // 8
+            h_pk = [torch.empty(npk, dtype=torch.uint8).pin_memory() for _ in range(NB)]
+            d_pk = [torch.empty(npk, dtype=torch.uint8, device="cuda") for _ in range(NB)]
+            wr = [torch.full((cap * T.WIRE_BYTES,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(NB)]
+            h_w = [torch.empty(cap * T.WIRE_BYTES, dtype=torch.uint8).pin_memory() for _ in range(NB)]
+            s_up, s_down = torch.cuda.Stream(), torch.cuda.Stream()
+            torch.cuda.synchronize()
+            ref_rec = recs[1].clone()        # (plan 1's records as the byte path left them: the packed path must write the same bytes)
+            _, bad = T.pack_bits(buf, out=h_pk[0].numpy(), nthreads=nth)
+            assert bad == 0
+            from concurrent.futures import ThreadPoolExecutor
+            packer = ThreadPoolExecutor(max_workers=1)       # the next step's packing runs beside this step's hand-over (ctypes drops the GIL)
+
+            def pack_into(j):
+                tp = time.perf_counter()
+                T.pack_bits(buf, out=h_pk[j].numpy(), nthreads=nth)
+                return (time.perf_counter() - tp) * 1e3
+            ne = max(6, 3 * args.e2e_steps)
+            fl, done_at, per_step, pack_ms = collections.deque(), [], [], []
+            dec_done, down_done, up_done = [None] * NB, [None] * NB, [None] * NB
+
+            def pk_finish(item):
+                msd, j, down = item
+                outs_ = msd.collect(raw=True)
+                down.synchronize()
+                done_at.append(time.perf_counter())
+                return T.wire_foreach_noop(h_w[j].numpy()[:msd.ngrid * T.WIRE_BYTES], None, msd.ngrid), sum(x["nslots"] for x in outs_)
+
+            for phase, steps in (("warm", NB), ("timed", ne)):
+                if phase == "timed":
+                    torch.cuda.synchronize()
+                    done_at.clear()
+                    per_step.clear()
+                    pack_ms.clear()
+                pending = None
+                for k in range(steps):
+                    j = k % NB
+                    if pending is None:
+                        if up_done[j] is not None:
+                            up_done[j].synchronize()
+                        pending = packer.submit(pack_into, j)
+                    if len(fl) == NB:
+                        a, b = pk_finish(fl.popleft())
+                        assert a == b, (a, b)
+                        per_step.append(a)
+                    pack_ms.append(pending.result())
+                    pending = None
+                    if k + 1 < steps:               # the next step's packing starts now: its pinned buffer's last copy up is two steps old
+                        jn = (k + 1) % NB
+                        if up_done[jn] is not None:
+                            up_done[jn].synchronize()
+                        pending = packer.submit(pack_into, jn)
+                    if dec_done[j] is not None:
+                        s_up.wait_event(dec_done[j])
+                    with torch.cuda.stream(s_up):
+                        d_pk[j].copy_(h_pk[j], non_blocking=True)
+                    up_done[j] = torch.cuda.Event()
+                    up_done[j].record(s_up)
+                    strm[j].wait_event(up_done[j])
+                    if down_done[j] is not None:
+                        strm[j].wait_event(down_done[j])
+                    plans[j].set_wire(wr[j].data_ptr())
+                    msd = T.MultiSyncDev(eng, plans[j], None, d_pk[j].data_ptr(), None, recs[j].data_ptr(), 64, strm[j].cuda_stream,
+                                         chans=chans, packed=True)     # (a channel's byte offset in the capture is its bit offset in the packed copy)
+                    dec_done[j] = torch.cuda.Event()
+                    dec_done[j].record(strm[j])
+                    s_down.wait_event(dec_done[j])
+                    with torch.cuda.stream(s_down):
+                        h_w[j].copy_(wr[j], non_blocking=True)
+                    down_done[j] = torch.cuda.Event()
+                    down_done[j].record(s_down)
+                    fl.append((msd, j, down_done[j]))
+                while fl:
+                    a, b = pk_finish(fl.popleft())
+                    assert a == b, (a, b)
+                    per_step.append(a)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(recs[1], ref_rec))
+            del ref_rec
+            pm = sorted(pack_ms)
+            e2ep = {"value": sum(per_step[1:]) / (done_at[-1] - done_at[0]), "unit": "bursts/s", "steps": ne,
+                    "ms_per_step": (done_at[-1] - done_at[0]) / (ne - 1) * 1e3, "steps_in_flight": NB,
+                    "host_pack": {"threads": nth, "gb_per_s_of_input_at_the_median": len(buf) / (pm[len(pm) // 2] * 1e-3) / 1e9, "ms_per_step_median": pm[len(pm) // 2]},
+                    "h2d_bytes_per_step": int(npk), "d2h_bytes_per_step": int(cap * T.WIRE_BYTES),
+                    "records_equal_the_byte_path": same,
+                    "note": "the capture in pinned host memory (1 bit per byte, %.0f MB) -> tgpu_pack_bits on %d host threads (%.0f MB) -> "
+                            "H2D -> tgpu_sync_multi_launch_packed (same kernels behind the front end's own bytes -> bits step) -> D2H of "
+                            "the wire records -> callback per delivered record; bound by the host's packing rate" % (buf.nbytes / 1e6, nth, npk / 1e6)}
+            packer.shutdown()
+            for p_ in plans:
+                p_.set_wire(0)
+        except Exception as ex:      # pragma: no cover
+            e2ep = {"error": repr(ex)}
+
     head = gathered if gathered else decode_only
     out = {"metric": "decoded bursts/s", "value": head["value"], "unit": "bursts/s", "n_gpus": world,
            "steps": K, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
@@ -787,6 +889,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         out["sustained"] = sustained
     if e2e:
         out["end_to_end"] = e2e
+    if e2ep:
+        out["end_to_end_packed"] = e2ep
     if gathered or gather_error:
         out["decode_only"] = decode_only
         out["gathered"] = gathered if gathered else {"error": gather_error}
@@ -1131,6 +1235,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 object of the default run")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (host buffer -> H2D -> step -> D2H -> callback)")
     ap.add_argument("--e2e-steps", type=int, default=32)
+    ap.add_argument("--pack-threads", type=int, default=0, help="host threads of the packed-ingest leg (0 = the CPUs this rank may use, at most 128)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the long run (>= 2 s of GPU time in one go)")
     ap.add_argument("--sustained-steps", type=int, default=5000)
     ap.add_argument("--channels", type=int, default=8, help="mix: recorded channels per GPU (BASELINE config 4: 8), all in one batch")

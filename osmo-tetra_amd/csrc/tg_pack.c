@@ -18,13 +18,6 @@
 
 #include "tetra_gpu.h"
 
-struct pack_job {
-	const uint8_t *in;
-	uint8_t *out;
-	uint64_t nbytes;	/* input bytes of this job: a multiple of 8 except for the last job */
-	uint64_t nonbinary;
-};
-
 static uint64_t pack_scalar(const uint8_t *in, uint8_t *out, uint64_t n)
 {
 	uint64_t bad = 0, i = 0;
@@ -69,16 +62,68 @@ static uint64_t pack_avx2(const uint8_t *in, uint8_t *out, uint64_t n)
 }
 #endif
 
-static void *pack_thread(void *arg)
+static uint64_t pack_piece(const uint8_t *in, uint8_t *out, uint64_t n)
 {
-	struct pack_job *j = arg;
 #if defined(__x86_64__)
-	if (__builtin_cpu_supports("avx2")) {
-		j->nonbinary = pack_avx2(j->in, j->out, j->nbytes);
-		return NULL;
-	}
+	if (__builtin_cpu_supports("avx2"))
+		return pack_avx2(in, out, n);
 #endif
-	j->nonbinary = pack_scalar(j->in, j->out, j->nbytes);
+	return pack_scalar(in, out, n);
+}
+
+/*
+ * A pool of worker threads that lives as long as the process (created on first use, grown on demand): a 510 MB capture is
+ * packed in a few milliseconds by some tens of threads, and creating that many threads per call would cost as much as the
+ * packing.  One call at a time uses the pool (a mutex around the call); the work is cut into pieces of PIECE input bytes that
+ * the workers -- and the calling thread -- take with an atomic counter.  Workers inherit the affinity of the thread that
+ * created them: a caller pinned to its GPU's NUMA node keeps the packing there.
+ */
+#define PIECE (256u * 1024u)	/* input bytes per piece: a multiple of 1024, i.e. whole output cache lines */
+#define MAX_WORKERS 255
+
+static struct {
+	pthread_mutex_t call;		/* one tgpu_pack_bits() at a time */
+	pthread_mutex_t m;
+	pthread_cond_t go, done;
+	pthread_t th[MAX_WORKERS];
+	unsigned int nworkers, wanted;	/* wanted: workers that may take part in the current call */
+	uint64_t gen;			/* incremented per call */
+	unsigned int running;		/* workers still inside the current call */
+	const uint8_t *in;
+	uint8_t *out;
+	uint64_t n, npieces;
+	uint64_t next;			/* next piece (atomic) */
+	uint64_t bad;			/* pieces that held a byte other than 0 / 1 (atomic) */
+} P = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { 0 }, 0, 0, 0, 0,
+	NULL, NULL, 0, 0, 0, 0 };
+
+static void pack_drain(void)
+{
+	for (;;) {
+		const uint64_t i = __atomic_fetch_add(&P.next, 1, __ATOMIC_RELAXED);
+		if (i >= P.npieces)
+			return;
+		const uint64_t o = i * PIECE, len = P.n - o < PIECE ? P.n - o : PIECE;
+		if (pack_piece(P.in + o, P.out + (o >> 3), len))
+			__atomic_fetch_add(&P.bad, 1, __ATOMIC_RELAXED);
+	}
+}
+
+static void *pack_worker(void *arg)
+{
+	const unsigned int me = (unsigned int)(uintptr_t)arg;
+	uint64_t seen = 0;
+	pthread_mutex_lock(&P.m);
+	for (;;) {
+		while (P.gen == seen || me >= P.wanted)
+			pthread_cond_wait(&P.go, &P.m);
+		seen = P.gen;
+		pthread_mutex_unlock(&P.m);
+		pack_drain();
+		pthread_mutex_lock(&P.m);
+		if (--P.running == 0)
+			pthread_cond_signal(&P.done);
+	}
 	return NULL;
 }
 
@@ -86,36 +131,43 @@ int64_t tgpu_pack_bits(const uint8_t *bytes, uint64_t n, uint8_t *packed, unsign
 {
 	if ((!bytes || !packed) && n)
 		return TGPU_EINVAL;
+	if (!n)
+		return 0;
 	if (!nthreads)
 		nthreads = 1;
-	if (nthreads > 256)
-		nthreads = 256;
-	const uint64_t per = ((n / nthreads) + 1023) & ~(uint64_t)1023;	/* whole output bytes (and cache lines) per thread */
-	struct pack_job job[256];
-	pthread_t th[256];
-	unsigned int nj = 0;
-	for (uint64_t o = 0; o < n && nj < 256; o += per, nj++) {
-		job[nj].in = bytes + o;
-		job[nj].out = packed + (o >> 3);
-		job[nj].nbytes = n - o < per || nj + 1 == nthreads ? n - o : per;
-		job[nj].nonbinary = 0;
-		if (job[nj].nbytes == n - o) {
-			nj++;
-			break;
-		}
+	const uint64_t npieces = (n + PIECE - 1) / PIECE;
+	if (nthreads > npieces)
+		nthreads = (unsigned int)npieces;
+	if (nthreads > MAX_WORKERS + 1)
+		nthreads = MAX_WORKERS + 1;
+	if (nthreads == 1)
+		return (int64_t)(pack_piece(bytes, packed, n) != 0);
+	pthread_mutex_lock(&P.call);
+	pthread_mutex_lock(&P.m);
+	while (P.nworkers < nthreads - 1) {		/* (the calling thread is one of the nthreads) */
+		if (pthread_create(&P.th[P.nworkers], NULL, pack_worker, (void *)(uintptr_t)P.nworkers))
+			break;				/* no more threads to be had: the ones there are do the work */
+		pthread_detach(P.th[P.nworkers]);
+		P.nworkers++;
 	}
-	for (unsigned int k = 1; k < nj; k++)
-		if (pthread_create(&th[k], NULL, pack_thread, &job[k])) {
-			pack_thread(&job[k]);	/* no thread to be had: this one does the piece */
-			th[k] = 0;
-		}
-	if (nj)
-		pack_thread(&job[0]);
-	int64_t bad = nj ? (int64_t)job[0].nonbinary : 0;
-	for (unsigned int k = 1; k < nj; k++) {
-		if (th[k])
-			pthread_join(th[k], NULL);
-		bad += (int64_t)job[k].nonbinary;
-	}
+	P.in = bytes;
+	P.out = packed;
+	P.n = n;
+	P.npieces = npieces;
+	P.next = 0;
+	P.bad = 0;
+	P.wanted = P.nworkers < nthreads - 1 ? P.nworkers : nthreads - 1;
+	P.running = P.wanted;
+	P.gen++;
+	pthread_cond_broadcast(&P.go);
+	pthread_mutex_unlock(&P.m);
+	pack_drain();
+	pthread_mutex_lock(&P.m);
+	while (P.running)
+		pthread_cond_wait(&P.done, &P.m);
+	P.wanted = 0;
+	const int64_t bad = (int64_t)P.bad;
+	pthread_mutex_unlock(&P.m);
+	pthread_mutex_unlock(&P.call);
 	return bad;
 }
