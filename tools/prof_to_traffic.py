@@ -39,8 +39,8 @@ def main():
     mix_t, mix_b = derive(read(sys.argv[1]))
     tj["mix"] = {k: mix_t[k] for k in mix_t if k.startswith(("k_front_stream", "k_vit"))}
     tj["mix_valu_busy"] = {k: mix_b[k] for k in mix_b if k.startswith(("k_front_stream", "k_vit"))}
-    tj["_mix_provenance"] = ("round 3: rocprofv3 --pmc passes (tools/prof_run.sh %s mix 1) on `python bench.py --steps 12 --warmup 6 "
-                             "--windows 2 --depth 1 --no-cpu-baseline --no-secondary --no-e2e --no-sustained`; summary in profiles/r03_mix_rocprofv3.md"
+    tj["_mix_provenance"] = ("round 4: rocprofv3 --pmc passes (tools/prof_run.sh %s mix 1) on `python bench.py --steps 12 --warmup 6 "
+                             "--windows 2 --depth 1 --no-cpu-baseline --no-secondary --no-e2e --no-sustained`; summary in profiles/r04_mix_rocprofv3.md"
                              % os.path.basename(sys.argv[1]).replace("prof_", ""))
     if len(sys.argv) > 2:
         c2_t, c2_b = derive(read(sys.argv[2]))
@@ -49,16 +49,16 @@ def main():
                 tj[k] = c2_t[k]
             if k in c2_b:
                 tj.setdefault("valu_busy", {})[k] = c2_b[k]
-        tj["_provenance"] = ("round 3: the same recipe on `python bench.py --workload config2 ...` (tools/prof_run.sh %s config2 1; "
-                             "profiles/r03_config2_rocprofv3.md); bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
+        tj["_provenance"] = ("round 4: the same recipe on `python bench.py --workload config2 ...` (tools/prof_run.sh %s config2 1; "
+                             "profiles/r04_config2_rocprofv3.md); bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
                              % os.path.basename(sys.argv[2]).replace("prof_", ""))
     if len(sys.argv) > 3:
         c5_t, c5_b = derive(read(sys.argv[3]))
         keep = ("k_front_soft", "k_vit_soft", "k_float_to_bits")
         tj["config5"] = {k: c5_t[k] for k in c5_t if k.startswith(keep)}
         tj["config5_valu_busy"] = {k: c5_b[k] for k in c5_b if k.startswith(keep)}
-        tj["_config5_provenance"] = ("round 3: the same recipe on `python bench.py --workload config5 ...` (tools/prof_run.sh %s config5 1; "
-                                     "profiles/r03_config5_rocprofv3.md)" % os.path.basename(sys.argv[3]).replace("prof_", ""))
+        tj["_config5_provenance"] = ("round 4: the same recipe on `python bench.py --workload config5 ...` (tools/prof_run.sh %s config5 1; "
+                                     "profiles/r04_config5_rocprofv3.md)" % os.path.basename(sys.argv[3]).replace("prof_", ""))
     json.dump(tj, open(path, "w"), indent=1)
     print(json.dumps({k: tj[k] for k in ("mix", "mix_valu_busy")}, indent=1))
 
