@@ -584,7 +584,10 @@ void tgpu_sync_multi_free(struct tgpu_sync_multi *st);
  *   slots); so is a shorter one with more exceptions than the LDS form holds (8192: a noisy recording) -- from the second
  *   batch on: the first one that overflows goes through the host walks and leaves the density it saw with the plan.
  * Plan capacity as above; the plan must stay untouched between launch and collect; several batches are kept in flight
- * with several plans.
+ * with several plans.  Records: valid for the delivered slots (bit set in grid_bits).  The SB1 decode of a device-walk batch
+ * runs beside the walk, over every SYNC-classified slot, so the record (and wire record) of a SYNC-classified slot that the walk
+ * then does NOT deliver may hold that slot's SB1 fields (bits, CRC word, SYNC-PDU fields; type byte untouched) -- the host-walk
+ * path leaves such records untouched.  Nothing reads them: consumers go by the bitmap.
  */
 struct tgpu_sync_dev;
 int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
