@@ -44,7 +44,7 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(form):
 @pytest.mark.parametrize("form", ["compact", "grid"])
 def test_bench_single_rank_with_the_rccl_gather(form):
     d = _line([sys.executable, "bench.py", "--force-gather", "--steps", "4", "--warmup", "2", "--windows", "2", "--bursts", "64000",
-               "--no-secondary", "--no-e2e --no-sustained", "--wire-form", form])
+               "--no-secondary", "--no-e2e", "--no-sustained", "--wire-form", form])
     assert d["n_gpus"] == 1 and ("tgpu_comm_gatherv" if form == "compact" else "tgpu_comm_gather (") in d["gathered"]["exchange"]
     assert d["gathered"]["wire_form"].startswith(form)
     assert "collecting rank" in d["config"]["check"] and d["cpu_baseline"]["value"] > 0
