@@ -2122,6 +2122,16 @@ def test_comm_gather_single_rank(T, eng):
     comm.gather(small.data_ptr(), 100, out.data_ptr(), 0, side.cuda_stream)
     side.synchronize()
     assert torch.equal(small, out)
+    # a size per rank (the compact transport form's exchange): exact bytes at the root's offset, nothing beyond them
+    sink2 = torch.full((4096,), 0x5A, dtype=torch.uint8, device="cuda")
+    comm.gatherv(small.data_ptr(), [77], sink2.data_ptr(), [256], 0, side.cuda_stream)
+    side.synchronize()
+    got = sink2.cpu().numpy()
+    assert (got[256:256 + 77] == np.arange(77)).all() and (got[:256] == 0x5A).all() and (got[256 + 77:] == 0x5A).all()
+    comm.gatherv(0, [0], sink2.data_ptr(), [0], 0, side.cuda_stream)             # a rank with nothing to send
+    side.synchronize()
+    with pytest.raises(T.TgpuError):
+        comm.gatherv(small.data_ptr(), [77], 0, [0], 0, side.cuda_stream)         # the root needs a sink
     with pytest.raises(T.TgpuError):
         comm.gather(small.data_ptr(), 100, out.data_ptr(), 1, side.cuda_stream)      # no such root
     with pytest.raises(T.TgpuError):
