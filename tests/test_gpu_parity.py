@@ -2696,3 +2696,30 @@ def test_packed_ingest_equals_the_byte_path(T, eng):
     assert pa.final_codes().tolist() == pb.final_codes().tolist()
     pa.close()
     pb.close()
+    # a stream the device walk hands to the host walks (an inserted byte: the synchroniser re-locks beside the grid): the packed
+    # batch takes the same way back -- the host walks read the unpacked host bytes, the decode needs no stream any more
+    base, _ = _mix_stream(T, 600, 77, (262, 42, 1), ber=0.0)
+    lead = 100 + 510
+    bent = np.concatenate([base[:lead + 510 * 33 + 17], [1], base[lead + 510 * 33 + 17:]]).astype(np.uint8)
+    two = [bent, base]
+    d2, offs2, ntot2 = _multi_batch(T, two)
+    poffs2, o = [], 0
+    for st in two:
+        poffs2.append(o)
+        o += ((len(st) + 7) // 8 + 15) & ~15
+    pbuf2 = np.zeros(o + 1024, np.uint8)
+    for st, f in zip(two, poffs2):
+        pbuf2[f:f + (len(st) + 7) // 8] = T.pack_bits(st)[0]
+    dp2 = torch.from_numpy(pbuf2).cuda()
+    pa, pb = T.Plan(eng, ntot2, 2), T.Plan(eng, ntot2, 2)
+    ra = torch.zeros(ntot2 * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    rb = torch.zeros(ntot2 * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    a = T.MultiSyncDev(eng, pa, two, d2.data_ptr(), offs2, ra.data_ptr(), 64, hs)
+    ref = a.collect()
+    b = T.MultiSyncDev(eng, pb, two, dp2.data_ptr(), [8 * f for f in poffs2], rb.data_ptr(), 64, hs, packed=True)
+    got = b.collect()
+    torch.cuda.synchronize()
+    assert a.fellback and b.fellback
+    _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES), "packed ingest, handed over")
+    pa.close()
+    pb.close()
