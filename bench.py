@@ -616,11 +616,18 @@ def bench_mix(args, T, torch, dist, rank, world, local):
            "k_vit<216>": n_n2 * (14 + 124 + 124 + 3 * 16) + n_sb * (14 + 124 + 2 * 16),
            "k_vit<432>": n_n1 * (14 + 268 + 2 * 16)}
     achieved = alg.get(dom, 0) / (kern_ms[dom] * 1e-3) / 1e9
-    traffic = valu_busy = None
+    traffic = valu_busy = valu_pipe = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         traffic = tj.get("mix", {}).get(dom)
         valu_busy = tj.get("mix_valu_busy", {}).get(dom)
+        vi = tj.get("mix_valu_insts_per_step")
+        if vi:      # the whole pipelined step against what 1024 SIMDs can issue: every wave instruction at its 4-cycle minimum
+            n_in = float(sum(vi.values()))
+            valu_pipe = {"wave_instructions_per_step": int(n_in), "sclk_ghz": tj.get("mix_sclk_ghz", 2.3),
+                         "frac_of_issue_capacity": n_in * 4.0 / (1024.0 * decode_only["ms_per_step"] * 1e-3 * tj.get("mix_sclk_ghz", 2.3) * 1e9),
+                         "note": "SQ_INSTS_VALU per launch of the step's kernels (profiles/traffic.json, rocprofv3 PMC pass of the same "
+                                 "workload) x 4 cycles / (1024 SIMDs x this run's ms_per_step x the shader clock the profile saw)"}
     except Exception:
         pass
 
@@ -874,6 +881,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                         "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
                         "kernel_ms": kern_ms[dom],
                         "pipeline_achieved_gbs_per_gpu": float(decode_only["value"] / world * 820 / 1e9),
+                        "pipeline_vector_issue": valu_pipe,
                         "note": "achieved = the dominant kernel's share of SURVEY 8(d)'s algorithmic bytes (k_front_stream: the 510 "
                                 "input bytes of every grid slot; a trellis kernel: type-1 bits at 1 B/bit + 16 B per block of the "
                                 "bursts it decodes) / its mean HIP-event duration on its launch stream, measured after the timed "

@@ -20,7 +20,15 @@ def read(path):
         m = re.match(r"\| (.+?) \| (\w+) \| ([0-9.e+]+) \| (\d+) \|", line)
         if m:
             vals.setdefault(NAMES.get(m.group(1), m.group(1)), {})[m.group(2)] = float(m.group(3))
+        t = re.match(r"\| (.+?) \| (\d+) \| ([0-9.]+) \| ([0-9.]+) \| ([0-9.]+) \| ([0-9.]+) \| ([0-9.]+) \|", line)
+        if t:       # kernel trace row: calls, total, avg, min, max, %
+            vals.setdefault(NAMES.get(t.group(1), t.group(1)), {})["duration_us"] = float(t.group(4))
     return vals
+
+
+def insts(vals):
+    """wave-level vector instructions per launch (SQ_INSTS_VALU) of every kernel that issues a million or more"""
+    return {k: int(v["SQ_INSTS_VALU"]) for k, v in vals.items() if v.get("SQ_INSTS_VALU", 0) >= 1e6}
 
 
 def derive(vals):
@@ -39,6 +47,11 @@ def main():
     mix_t, mix_b = derive(read(sys.argv[1]))
     tj["mix"] = {k: mix_t[k] for k in mix_t if k.startswith(("k_front_stream", "k_vit"))}
     tj["mix_valu_busy"] = {k: mix_b[k] for k in mix_b if k.startswith(("k_front_stream", "k_vit"))}
+    mv = read(sys.argv[1])
+    tj["mix_valu_insts_per_step"] = insts(mv)
+    fs = mv.get("k_front_stream", {})
+    # shader clock while the kernels run: GRBM_GUI_ACTIVE counts every XCD's cycles
+    tj["mix_sclk_ghz"] = round(fs["GRBM_GUI_ACTIVE"] / 8 / (fs["duration_us"] * 1e3), 3) if "GRBM_GUI_ACTIVE" in fs and "duration_us" in fs else 2.3
     tj["_mix_provenance"] = ("round 4: rocprofv3 --pmc passes (tools/prof_run.sh %s mix 1) on `python bench.py --steps 12 --warmup 6 "
                              "--windows 2 --depth 1 --no-cpu-baseline --no-secondary --no-e2e --no-sustained`; summary in profiles/r04_mix_rocprofv3.md"
                              % os.path.basename(sys.argv[1]).replace("prof_", ""))
