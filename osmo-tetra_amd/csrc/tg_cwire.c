@@ -41,7 +41,7 @@ static int chans_ok(uint32_t ngrid, uint32_t nchan, const uint32_t *gbase, const
 int64_t tgpu_cwire_pack(const uint8_t *wire, const uint32_t *grid_bits, uint32_t ngrid, uint32_t nchan, const uint32_t *gbase,
 			const uint32_t *ncls, uint8_t *out, size_t cap)
 {
-	if (!wire || !grid_bits || !out || ngrid > 0x0fffffffu || !chans_ok(ngrid, nchan, gbase, ncls))
+	if (!wire || !grid_bits || !out || ngrid > 0x03ffffffu || !chans_ok(ngrid, nchan, gbase, ncls))
 		return TGPU_EINVAL;
 	struct tg_cw_layout L;
 	tg_cw_offsets(nchan, ngrid, &L);
@@ -108,7 +108,7 @@ int tgpu_cwire_info(const uint8_t *cw, size_t nbytes, struct tgpu_cwire_info *ou
 	uint32_t hdr[TG_CW_HDR_WORDS];
 	memcpy(hdr, cw, sizeof(hdr));
 	struct tg_cw_layout L;
-	if (hdr[0] != TG_CW_MAGIC || !hdr[1] || hdr[1] > 64 || hdr[2] > 0x0fffffffu)	/* (the bound keeps the layout arithmetic inside 32 bits) */
+	if (hdr[0] != TG_CW_MAGIC || !hdr[1] || hdr[1] > 64 || hdr[2] > 0x03ffffffu)	/* (2^26 grid slots: sizes and offsets stay inside 32 bits) */
 		return TGPU_EINVAL;
 	tg_cw_offsets(hdr[1], hdr[2], &L);
 	if (hdr[5] != L.o_bits || hdr[6] != L.o_blk || hdr[7] != L.o_rec || hdr[3] < L.o_rec || hdr[3] > nbytes)
@@ -205,7 +205,7 @@ int tgpu_cwire_expand(const uint8_t *cw, size_t nbytes, uint8_t *wire, uint32_t 
 int tgpu_wire_compact(struct tgpu_engine *eng, const uint8_t *d_wire, const uint32_t *d_grid_bits, uint32_t ngrid, uint32_t nchan,
 		      const uint32_t *gbase, const uint32_t *ncls, uint8_t *d_cwire, size_t cap, uint32_t *d_total, void *hip_stream)
 {
-	if (!eng || !d_wire || !d_grid_bits || !d_cwire || !ngrid || ngrid > 0x0fffffffu || !chans_ok(ngrid, nchan, gbase, ncls))
+	if (!eng || !d_wire || !d_grid_bits || !d_cwire || !ngrid || ngrid > 0x03ffffffu || !chans_ok(ngrid, nchan, gbase, ncls))
 		return TGPU_EINVAL;
 	if (((uintptr_t)d_cwire & 15) || ((uintptr_t)d_wire & 7))
 		return TGPU_EINVAL;
