@@ -261,6 +261,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     for st, f in zip(streams, offs):
         buf[f:f + len(st)] = st
     eng = T.Engine(local)
+    if args.walk_wide:
+        T.set_option(T.OPT_WALK_WIDE, 1)
     d_base = torch.from_numpy(buf).cuda()
     cap = sum(len(st) // 510 + 32 for st in streams)
     D = max(2, args.depth)
@@ -1235,6 +1237,8 @@ def main():
     ap.add_argument("--windows", type=int, default=6, help="mix: K-step windows inside the one continuous run (median reported)")
     ap.add_argument("--depth", type=int, default=8, help="mix: steps in flight per GPU (plans / streams)")
     ap.add_argument("--side-stream", action="store_true", help="mix: keep the plans' side streams in play (the round-3 form)")
+    ap.add_argument("--walk-wide", action="store_true", help="mix: the device walk's per-channel launches as 1024 threads / 128 KB of LDS "
+                                                             "(rounds 3 and 4) instead of 256 threads and LDS sized per launch")
     ap.add_argument("--streams", type=int, default=0, help="mix: streams the steps in flight run on (0 = one per step in flight; fewer: "
                                                            "plan j runs on stream j %% streams)")
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts (slots) per GPU per step")

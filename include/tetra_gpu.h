@@ -142,6 +142,8 @@ enum tgpu_option {
 					 * where the device walk hands a channel over) */
 	TGPU_OPT_WALK_MONO,		/* 1: the device walk as one launch per form instead of three (node pass over the whole chip) */
 	TGPU_OPT_FRONT_BLOCKS,		/* > 0: cap on the front-end kernels' workgroups (tests run their loops' tails with 1 and 2) */
+	TGPU_OPT_WALK_WIDE,		/* 1: the device walk's per-channel launches as 1024 threads with 128 KB of LDS each (the form of rounds
+					 * 3 and 4; default 0: 256 threads, LDS for the batch's longest channel and twice the nodes seen so far) */
 	TGPU_OPT__COUNT
 };
 int tgpu_engine_set_option(struct tgpu_engine *eng, int /* enum tgpu_option */ option, long value);

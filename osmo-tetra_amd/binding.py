@@ -242,7 +242,7 @@ def lib():
     return L
 
 
-OPT_BURST_MAX, OPT_STREAM_EXACT, OPT_WALK_HOST, OPT_WALK_MONO, OPT_FRONT_BLOCKS = range(1, 6)
+OPT_BURST_MAX, OPT_STREAM_EXACT, OPT_WALK_HOST, OPT_WALK_MONO, OPT_FRONT_BLOCKS, OPT_WALK_WIDE = range(1, 7)
 
 
 def set_option(opt, value):

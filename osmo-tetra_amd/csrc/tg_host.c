@@ -132,6 +132,7 @@ struct tgpu_plan {
 	uint8_t *d_walk_big;		/* scratch slots of k_walk_big (channels beyond TGW_WCAP bitmap words), on first need */
 	uint32_t walk_big_slots;
 	uint32_t walk_big_nodes;	/* nodes a channel of the LDS form had when it overflowed (0: never): sizes the long form's threshold */
+	uint32_t walk_nodes_seen;	/* most nodes any channel of this plan's batches had (0: no batch yet): sizes the LDS form's arrays */
 	uint32_t *d_bits_dev;		/* the delivered bitmap k_walk left in the upload arena */
 };
 
@@ -770,6 +771,25 @@ void tgpi_plan_walk_overflow(struct tgpu_plan *p, uint32_t nslots, uint32_t nnod
 		t = 4096;
 	if (!p->walk_big_nodes || t < p->walk_big_nodes)
 		p->walk_big_nodes = (uint32_t)t;
+}
+
+/* The LDS form's node arrays are laid out per launch: for twice the nodes the plan's channels have had so far (a workgroup
+ * that asks for 25 KB of LDS finds a compute unit sooner than one that asks for 70), for the full TGW_NCAP before the first
+ * batch has come back.  A batch whose channel outgrows the cap goes through the host walks (TGW_WHY_NODES), and the cap follows. */
+uint32_t tgpi_plan_walk_ncap(const struct tgpu_plan *p)
+{
+	if (!p || !p->walk_nodes_seen)
+		return TGW_NCAP;
+	uint32_t n = 512;
+	while (n < TGW_NCAP && n < 2 * p->walk_nodes_seen + 256)
+		n <<= 1;
+	return n;
+}
+
+void tgpi_plan_walk_seen(struct tgpu_plan *p, uint32_t nnodes)
+{
+	if (p && nnodes > p->walk_nodes_seen)
+		p->walk_nodes_seen = nnodes;
 }
 
 uint32_t tgpi_plan_walk_threshold(const struct tgpu_plan *p)

@@ -105,7 +105,12 @@ typedef struct { int32_t ev; uint32_t bitnum, arg; } tgpu_sync_event_rec_dev;	/*
 int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 	     uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
 	     uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp,
-	     unsigned long long skip_mask /* channels left to tgk_walk_big */, void *stream);
+	     unsigned long long skip_mask /* channels left to tgk_walk_big */,
+	     uint32_t wcap, uint32_t ncap /* the split form's LDS arrays hold channels of this many bitmap words / nodes (0: the full caps) */,
+	     int wide /* 1: the split form's per-channel launches as 1024 threads with 128 KB of LDS (rounds 3 and 4) */, void *stream);
+/* the node cap a plan asks for (tg_host.c: twice what its batches have shown so far) */
+uint32_t tgpi_plan_walk_ncap(const struct tgpu_plan *p);
+void tgpi_plan_walk_seen(struct tgpu_plan *p, uint32_t nnodes);
 /* d_tmp != NULL: the split form (node pass as a grid-wide launch between two per-channel ones); TGW_TMP_BYTES of device memory */
 #define TGW_TMP_BYTES (1024u + 64u * (TGW_NCAP + TGW_WCAP + TGW_NCAP + 8u) * 4u)
 /* channels beyond TGW_WCAP words (recordings of more than 262 144 slots): k_walk_big, one workgroup each, with its working

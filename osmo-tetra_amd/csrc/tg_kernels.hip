@@ -1079,8 +1079,8 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		uint32_t rsum = (((any & vearly) != 0) ? 0x10000u : 0u) + (uint32_t)__builtin_popcount(my);	/* (<= 510 y hits: the halves do not meet) */
 #define ROW_STEP(CTRL)													\
 		{													\
-			const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)rmin, (int)rmin, (CTRL), 0xf, 0xf, false);	\
-			const uint32_t u_ = (uint32_t)__builtin_amdgcn_update_dpp((int)rsum, (int)rsum, (CTRL), 0xf, 0xf, false);	\
+			const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rmin, (CTRL), 0xf, 0xf, true);	\
+			const uint32_t u_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rsum, (CTRL), 0xf, 0xf, true);	\
 			const cls_us2 m_ = __builtin_elementwise_min(__builtin_bit_cast(cls_us2, rmin), __builtin_bit_cast(cls_us2, t_));	\
 			rmin = __builtin_bit_cast(uint32_t, m_);							\
 			rsum += u_;											\
@@ -3561,7 +3561,11 @@ extern "C" int tgk_masks(const uint32_t *d_chan_code, uint32_t nchan, const uint
 static_assert(sizeof(tgw_rec) <= TGW_REC_BYTES, "TGW_REC_BYTES");
 
 #define TGW_THREADS 1024
-#define TGW_LDS_BYTES (TGW_WCAP * 4 + TGW_NCAP * 4 + TGW_WCAP * 2 + 2 * (TGW_NCAP + 8) * 2 + 2 * (TGW_NCAP + 8))
+#define TGW_LDS_BYTES (TGW_WCAP * 4 + TGW_NCAP * 4 + TGW_WCAP * 2 + 2 * (TGW_NCAP + 8) * 2 + 2 * (TGW_NCAP + 8))	/* MODE 0, full caps */
+#define TGW_LDS2_BYTES(wcap, ncap) ((wcap) * 4u + 2u * ((ncap) + 8u) * 2u + 2u * ((ncap) + 8u))	/* MODE 2 */
+#define TGW_THREADS_LIGHT 256	/* the three-launch form: a workgroup that takes one wave slot per SIMD and 20-70 KB of LDS finds a
+				 * place beside the heavy kernels of the other batches; 1024 threads and 128 KB wait for a nearly empty
+				 * compute unit */
 
 __device__ __forceinline__ uint32_t tgw_block_excl_scan(uint32_t v, uint32_t *sm /* 17 words */, uint32_t &total)
 {
@@ -3578,7 +3582,7 @@ __device__ __forceinline__ uint32_t tgw_block_excl_scan(uint32_t v, uint32_t *sm
 		sm[w] = inc;
 	__syncthreads();
 	uint32_t pre = 0, tot = 0;
-	for (uint32_t q = 0; q < TGW_THREADS / 64; q++) {
+	for (uint32_t q = 0; q < blockDim.x / 64; q++) {
 		const uint32_t x = sm[q];
 		if (q < w)
 			pre += x;
@@ -3618,7 +3622,7 @@ template <bool BIG, typename idx_t, int MODE>
 __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *nslot, idx_t *wpre, idx_t *Ja, idx_t *Jb, uint8_t *mark,
 					  const tg_walk_tmp tmp, const bool skip,
 					  tgw_rec *recs, tgpu_sync_event_rec_dev *ev_big, const uint32_t wcap, const uint32_t ncap,
-					  const uint32_t evcap, const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan,
+					  const uint32_t rootidx /* the head's record: recs[rootidx] */, const uint32_t evcap, const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan,
 					  const tg_walk_root *__restrict__ roots, uint32_t chunk, uint32_t cshift,
 					  const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
 					  const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, uint32_t *__restrict__ g_bits2,
@@ -3627,7 +3631,10 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	__shared__ uint32_t sm[20];
 	__shared__ uint32_t s_head, s_fb, s_why, s_nd, s_tail, s_last, s_lastdel, s_ns;
 
-	const uint32_t tid = threadIdx.x;
+	const uint32_t tid = threadIdx.x, NT = blockDim.x;
+	/* the light form (the LDS form split in three launches, MODE 1 / 2): MODE 1 keeps nothing in LDS -- node list and word
+	 * prefixes go straight to the hand-over area --, MODE 2 keeps the bitmap, the arrival pointers and the marks */
+	constexpr bool LIGHT1 = !BIG && MODE == 1, LIGHT2 = !BIG && MODE == 2;
 	const tg_chan_ent ce = chan[c];
 	const tg_walk_root rt = roots[c];
 	tg_walk_sum *sum = sums + c;
@@ -3672,22 +3679,32 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 
 	TGW_STAMP(0);
 	/* A: bitmap -> LDS (bits at and past ncls read "plain" so that they are no nodes; they are cleared again in F) */
-	const uint32_t WPT = BIG ? (W + TGW_THREADS - 1) / TGW_THREADS : TGW_WCAP / TGW_THREADS;	/* consecutive words per thread */
+	const uint32_t WPT = (W + NT - 1) / NT;	/* consecutive words per thread */
 	uint32_t cnt = 0;
 	uint32_t N, base = 0;
+	auto plain_word = [&](uint32_t w) -> uint32_t {
+		uint32_t v = g_plain[w0 + w];
+		if (w == W - 1 && (ncls & 31))
+			v |= ~0u << (ncls & 31);
+		return v;
+	};
 	if (BIG && MODE == 2) {		/* (bitmap, node list and prefixes are where MODE 1 left them) */
 		N = tmp.meta[0];
 		if (N == 0xffffffffu)
 			return;
+	} else if (LIGHT2) {		/* (node count from MODE 1; ~0: that launch has settled the channel's summary already) */
+		N = tmp.meta[0];
+		if (N == 0xffffffffu)
+			return;
+		for (uint32_t w = tid; w < W; w += NT)
+			bm[w] = plain_word(w);
 	} else {
-#pragma unroll
 	for (uint32_t q = 0; q < WPT; q++) {
 		const uint32_t w = WPT * tid + q;
 		if (w < W) {
-			uint32_t v = g_plain[w0 + w];
-			if (w == W - 1 && (ncls & 31))
-				v |= ~0u << (ncls & 31);
-			bm[w] = v;
+			const uint32_t v = plain_word(w);
+			if (!LIGHT1)
+				bm[w] = v;
 			cnt += __popc(~v);
 		}
 	}
@@ -3704,29 +3721,31 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 		return;
 	}
 	/* B: prefix counts per word, node list */
-	if (!(BIG && MODE == 2)) {
-#pragma unroll
+	if (MODE != 2) {
 	for (uint32_t q = 0; q < WPT; q++) {
 		const uint32_t w = WPT * tid + q;
 		if (w < W) {
-			wpre[w] = (idx_t)base;
-			uint32_t z = ~bm[w];
+			uint32_t z;
+			if (LIGHT1) {
+				tmp.wpre[w] = base;
+				z = ~plain_word(w);
+			} else {
+				wpre[w] = (idx_t)base;
+				z = ~bm[w];
+			}
 			while (z) {
 				const uint32_t b = __builtin_ctz(z);
 				z &= z - 1;
-				nslot[base++] = 32 * w + b;
+				if (LIGHT1)
+					tmp.nslot[base++] = 32 * w + b;
+				else
+					nslot[base++] = 32 * w + b;
 			}
 		}
 	}
 	}
 	__syncthreads();
-	if (MODE == 1) {	/* hand the lists to k_walk_nodes */
-		if (!BIG) {
-			for (uint32_t i = tid; i < N; i += TGW_THREADS)
-				tmp.nslot[i] = nslot[i];
-			for (uint32_t w = tid; w < W; w += TGW_THREADS)
-				tmp.wpre[w] = wpre[w];
-		}
+	if (MODE == 1) {	/* the lists are k_walk_nodes' now (BIG: the body's arrays are the hand-over area) */
 		if (tid == 0)
 			tmp.meta[0] = N;
 		return;
@@ -3741,7 +3760,7 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	/* C: every node, and the stream's head */
 	if (MODE == 2) {	/* (done by k_walk_nodes) */
 		if (!BIG)
-			for (uint32_t i = tid; i < N; i += TGW_THREADS)
+			for (uint32_t i = tid; i < N; i += NT)
 				Ja[i] = (idx_t)tmp.J[i];
 		if (tid == 0) {
 			s_head = tmp.meta[1];
@@ -3749,7 +3768,7 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 			s_why = tmp.meta[3];
 		}
 	} else {
-	for (uint32_t i = tid; i < N; i += TGW_THREADS) {
+	for (uint32_t i = tid; i < N; i += NT) {
 		const uint64_t bs = wc.anchor + (uint64_t)nslot[i] * TG_SLOT_BITS;
 		const uint64_t kc = (bs + TG_SLOT_BITS + chunk - 1) >> cshift;
 		tgw_rec r;
@@ -3757,10 +3776,10 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 		recs[i] = r;
 		Ja[i] = (idx_t)(r.status == TGW_OK ? rank(r.next) : N);
 	}
-	if (tid == TGW_THREADS - 1) {
+	if (tid == NT - 1) {
 		tgw_rec r;
 		tgw_run(&wc, TGW_S_KNOW_FSTART, rt.found_bs, wc.anchor, rt.found_k, &r);
-		recs[ncap] = r;
+		recs[rootidx] = r;
 		if (r.status != TGW_OK) {
 			s_fb = 1;
 			s_why = r.why;
@@ -3770,7 +3789,7 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	}
 	if (tid == 0)
 		Ja[N] = Jb[N] = (idx_t)N;
-	for (uint32_t i = tid; i <= N; i += TGW_THREADS)
+	for (uint32_t i = tid; i <= N; i += NT)
 		mark[i] = 0;
 	__syncthreads();
 	TGW_STAMP(2);
@@ -3782,10 +3801,10 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 		__syncthreads();
 		idx_t *J = Ja, *Jn = Jb;
 		for (uint32_t span = 1; span <= N; span <<= 1) {
-			for (uint32_t v = tid; v < N; v += TGW_THREADS)
+			for (uint32_t v = tid; v < N; v += NT)
 				if (mark[v] && J[v] < N)
 					mark[J[v]] = 1;
-			for (uint32_t v = tid; v < N; v += TGW_THREADS) {
+			for (uint32_t v = tid; v < N; v += NT) {
 				const uint32_t j = J[v];
 				Jn[v] = j < N ? J[j] : (idx_t)N;
 			}
@@ -3808,18 +3827,18 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 			from += n;
 		}
 	};
-	for (uint32_t i = tid; i < N; i += TGW_THREADS)
+	for (uint32_t i = tid; i < N; i += NT)
 		if (mark[i]) {
 			const tgw_rec *r = recs + i;
 			if (r->status != TGW_OK) {
 				s_fb = 1;
 				s_why = r->why;
 			}
-			clear_span(nslot[i], r->next);
+			clear_span(MODE == 2 ? tmp.nslot[i] : nslot[i], r->next);
 			atomicMax(&s_last, i + 1);
 		}
-	if (tid == TGW_THREADS - 1 && !s_fb)
-		clear_span(0, recs[ncap].next);
+	if (tid == NT - 1 && !s_fb)
+		clear_span(0, recs[rootidx].next);
 	__syncthreads();
 	if (s_fb) {
 		if (tid == 0) {
@@ -3831,10 +3850,10 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 		}
 		return;
 	}
-	for (uint32_t i = tid; i < N + 1; i += TGW_THREADS) {
+	for (uint32_t i = tid; i < N + 1; i += NT) {
 		const bool root = (i == N);
 		if (root || mark[i]) {
-			const tgw_rec *r = recs + (root ? ncap : i);
+			const tgw_rec *r = recs + (root ? rootidx : i);
 			for (uint32_t d = 0; d < r->ndel; d++)
 				atomicOr(&bm[r->del[d] >> 5], 1u << (r->del[d] & 31));
 		}
@@ -3844,7 +3863,6 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	/* F: bitmap out, delivered bursts, last delivered slot */
 	{
 		uint32_t ns = 0, lastd = 0xffffffffu;
-#pragma unroll
 		for (uint32_t q = 0; q < WPT; q++) {
 			const uint32_t w = WPT * tid + q;
 			if (w < W) {
@@ -3866,10 +3884,9 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 	__syncthreads();
 	TGW_STAMP(5);
 	/* G: events in slot order */
-	const uint32_t NPT = BIG ? (N + TGW_THREADS - 1) / TGW_THREADS : TGW_NCAP / TGW_THREADS;
-	const tgw_rec *root = recs + ncap;
+	const uint32_t NPT = (N + NT - 1) / NT;
+	const tgw_rec *root = recs + rootidx;
 	uint32_t ecnt = 0;
-#pragma unroll
 	for (uint32_t q = 0; q < NPT; q++) {
 		const uint32_t i = NPT * tid + q;
 		if (i < N && mark[i])
@@ -3895,9 +3912,8 @@ __device__ __forceinline__ void walk_body(uint32_t c, uint32_t *bm, uint32_t *ns
 			}
 		}
 	};
-	if (tid == TGW_THREADS - 1)
+	if (tid == NT - 1)
 		emit(root, 0);
-#pragma unroll
 	for (uint32_t q = 0; q < NPT; q++) {
 		const uint32_t i = NPT * tid + q;
 		if (i < N && mark[i]) {
@@ -3955,20 +3971,22 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	    const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, uint32_t *__restrict__ g_bits2,
 	    tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager,
 	    tgpu_sync_event_rec_dev *__restrict__ g_evbig, tgw_rec *__restrict__ g_recs, uint8_t *__restrict__ d_tmp,
-	    unsigned long long skip_mask)
+	    unsigned long long skip_mask, uint32_t wcap, uint32_t ncap)
 {
+	/* working arrays in LDS, laid out for the caps of this launch (tgk_walk): MODE 0 all of them, MODE 2 the bitmap, the two
+	 * arrival-pointer arrays and the marks, MODE 1 none */
 	extern __shared__ uint32_t s_dyn[];
 	uint32_t *bm = s_dyn;
-	uint32_t *nslot = bm + TGW_WCAP;
-	uint16_t *wpre = (uint16_t *)(nslot + TGW_NCAP);
-	uint16_t *Ja = wpre + TGW_WCAP, *Jb = Ja + TGW_NCAP + 8;
-	uint8_t *mark = (uint8_t *)(Jb + TGW_NCAP + 8);
+	uint32_t *nslot = bm + wcap;
+	uint16_t *wpre = (uint16_t *)(nslot + ncap);
+	uint16_t *Ja = (MODE == 2) ? (uint16_t *)(bm + wcap) : wpre + wcap, *Jb = Ja + ncap + 8;
+	uint8_t *mark = (uint8_t *)(Jb + ncap + 8);
 	const uint32_t c = blockIdx.x;
 	tg_walk_tmp tmp = { nullptr, nullptr, nullptr, nullptr };
 	if (MODE)
 		tmp = walk_tmp_small(d_tmp, c);
 	walk_body<false, uint16_t, MODE>(c, bm, nslot, wpre, Ja, Jb, mark, tmp, ((skip_mask >> c) & 1) != 0, g_recs + (size_t)c * (TGW_NCAP + 1),
-					 g_evbig + (size_t)c * TGW_EVCAP, TGW_WCAP, TGW_NCAP, TGW_EVCAP, d_base, chan, roots, chunk, cshift, g_cls,
+					 g_evbig + (size_t)c * TGW_EVCAP, wcap, ncap, TGW_NCAP, TGW_EVCAP, d_base, chan, roots, chunk, cshift, g_cls,
 					 g_ysum, g_plain, g_bits, g_bits2, sums, g_eager);
 }
 
@@ -3991,7 +4009,7 @@ void k_walk_big(tg_walk_big big, uint8_t *__restrict__ scratch, const uint8_t *_
 		tmp = walk_tmp_big(base, L, d_tmp, c);
 	walk_body<true, uint32_t, MODE>(c, (uint32_t *)(base + L.o_bm), (uint32_t *)(base + L.o_nslot), (uint32_t *)(base + L.o_wpre),
 					(uint32_t *)(base + L.o_ja), (uint32_t *)(base + L.o_jb), base + L.o_mark, tmp, false, (tgw_rec *)(base + L.o_recs),
-					(tgpu_sync_event_rec_dev *)(base + L.o_ev), big.wcap, big.ncap, big.evcap, d_base, chan, roots, chunk,
+					(tgpu_sync_event_rec_dev *)(base + L.o_ev), big.wcap, big.ncap, big.ncap, big.evcap, d_base, chan, roots, chunk,
 					cshift, g_cls, g_ysum, g_plain, g_bits, g_bits2, sums, g_eager);
 }
 
@@ -4069,16 +4087,23 @@ void k_walk_nodes(tg_walk_big big, uint8_t *__restrict__ scratch, uint8_t *__res
 extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 			uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
 			uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp,
-			unsigned long long skip_mask, void *stream)
+			unsigned long long skip_mask, uint32_t wcap, uint32_t ncap, int wide, void *stream)
 {
 	if (!nchan)
 		return 0;
 	if (!chunk || (chunk & (chunk - 1)) || nchan > 64)
 		return -1;
+	if (!d_tmp || wide || !wcap || !ncap || wcap > TGW_WCAP || ncap > TGW_NCAP) {
+		wcap = TGW_WCAP;
+		ncap = TGW_NCAP;
+	}
+	wcap = (wcap + 1u) & ~1u;
+	ncap = (ncap + 255u) & ~255u;
 	const uint32_t cshift = (uint32_t)__builtin_ctz(chunk);
 	hipStream_t s = (hipStream_t)stream;
 #define WALK_ARGS d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums, \
-		  (tgpu_sync_event_rec_dev *)d_eager, (tgpu_sync_event_rec_dev *)d_evbig, (tgw_rec *)d_recs, (uint8_t *)d_tmp, skip_mask
+		  (tgpu_sync_event_rec_dev *)d_eager, (tgpu_sync_event_rec_dev *)d_evbig, (tgw_rec *)d_recs, (uint8_t *)d_tmp, skip_mask, \
+		  wcap, ncap
 	if (!d_tmp) {
 		HIPCHK(hipFuncSetAttribute((const void *)k_walk<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
 		hipLaunchKernelGGL(k_walk<0>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);
@@ -4092,11 +4117,12 @@ extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 		HIPCHK(hipFuncSetAttribute((const void *)k_walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
 		attr_set_dev = dev;
 	}
-	hipLaunchKernelGGL(k_walk<1>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);
+	const uint32_t nt = wide ? TGW_THREADS : TGW_THREADS_LIGHT;
+	hipLaunchKernelGGL(k_walk<1>, dim3(nchan), dim3(nt), wide ? TGW_LDS_BYTES : 0, s, WALK_ARGS);
 	tg_walk_big none = {};
-	hipLaunchKernelGGL(k_walk_nodes<false>, dim3(TGW_NCAP / 256, nchan), dim3(256), 0, s, none, (uint8_t *)nullptr, (uint8_t *)d_tmp,
+	hipLaunchKernelGGL(k_walk_nodes<false>, dim3(ncap / 256, nchan), dim3(256), 0, s, none, (uint8_t *)nullptr, (uint8_t *)d_tmp,
 			   (tgw_rec *)d_recs, d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain);
-	hipLaunchKernelGGL(k_walk<2>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);
+	hipLaunchKernelGGL(k_walk<2>, dim3(nchan), dim3(nt), wide ? TGW_LDS_BYTES : TGW_LDS2_BYTES(wcap, ncap), s, WALK_ARGS);
 #undef WALK_ARGS
 	return (int)hipGetLastError();
 }

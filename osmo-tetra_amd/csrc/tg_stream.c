@@ -1539,14 +1539,17 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 		struct tg_walk_big big = { 0 };
 		unsigned long long skip = 0;
 		const uint32_t thr = tgpi_plan_walk_threshold(plan);
-		for (uint32_t c = 0; c < nchan && big.n < TGW_BIG_MAX; c++)
-			if (st->ent[c].ncls > thr) {
+		uint32_t wmax = 0;	/* bitmap words of the longest channel that stays in the LDS form */
+		for (uint32_t c = 0; c < nchan; c++)
+			if (st->ent[c].ncls > thr && big.n < TGW_BIG_MAX) {
 				big.chan[big.n++] = c;
 				skip |= 1ull << c;
-			}
+			} else if ((st->ent[c].ncls + 31) / 32 > wmax && st->ent[c].ncls <= TGW_WCAP * 32u)
+				wmax = (st->ent[c].ncls + 31) / 32;
 		if (!rc)
 			rc = tgk_walk(d_base, io->d_tab, io->d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, io->d_bits2, io->d_sums,
-				      io->d_eager, io->d_evbig, io->d_recs, tgi_option(TGPU_OPT_WALK_MONO) ? NULL : io->d_tmp, skip, stream);
+				      io->d_eager, io->d_evbig, io->d_recs, tgi_option(TGPU_OPT_WALK_MONO) ? NULL : io->d_tmp, skip,
+				      wmax ? wmax : 1, tgpi_plan_walk_ncap(plan), (int)tgi_option(TGPU_OPT_WALK_WIDE), stream);
 		if (!rc) {
 			if (big.n) {
 				rc = tgpi_plan_walk_big(plan, big.n, io);
@@ -1639,9 +1642,12 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 	for (uint32_t c = 0; c < st->nchan; c++)
 		if (st->ent[c].ncls && sd->io.h_sums[c].status != TGW_OK) {
 			fb = 1;
-			if (sd->io.h_sums[c].why == TGW_WHY_NODES)	/* more exceptions than the LDS form holds: the long form next time */
+			if (sd->io.h_sums[c].why == TGW_WHY_NODES && sd->io.h_sums[c].nnodes > TGW_NCAP)	/* more exceptions than the LDS form holds: the long form next time */
 				tgpi_plan_walk_overflow(st->plan, st->ent[c].ncls, sd->io.h_sums[c].nnodes);
 		}
+	for (uint32_t c = 0; c < st->nchan; c++)	/* (what sizes the next launch's node arrays) */
+		if (st->ent[c].ncls && sd->io.h_sums[c].nnodes <= TGW_NCAP)
+			tgpi_plan_walk_seen(st->plan, sd->io.h_sums[c].nnodes);
 	if (st->ngrid && sd->io.h_final[64])
 		fb = 1;		/* more scrambling codes in the batch than the device path's table holds */
 	if (fb || tgi_option(TGPU_OPT_WALK_HOST)) {

@@ -1894,17 +1894,20 @@ def _same_batch_outcome(T, a, b, rec_a, rec_b, what):
             assert (rec_a[idx] == rec_b[idx]).all(), (what, c)
 
 
-@pytest.mark.parametrize("chunk,mono", [(64, 0), (32, 0), (64, 1)])
-def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, mono, topt):
+@pytest.mark.parametrize("chunk,mono,wide", [(64, 0, 0), (32, 0, 0), (64, 1, 0), (64, 0, 1)])
+def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, mono, wide, topt):
     """tgpu_sync_multi_launch / _collect (the synchroniser walks on the device: k_walk) against tgpu_sync_multi_begin /
     _finish (host walks) on the same multi-channel batch: eight channels of different cells, lengths, lead-ins and damage
     -- damaged training sequences in runs, right behind SYNC bursts (the one-call backlog) and in the last slots, spurious
     sequences below offset 21 (the reference's skewed look-ahead rule, now evaluated by the kernels), a channel with next
     to nothing in it, one that ends inside a burst.  Per channel: events, counts, final state, delivered bitmap, every
-    delivered record byte, final codes.  No fallback on these; then once more with the fallback forced (same results)"""
+    delivered record byte, final codes.  No fallback on these -- neither in the plan's first batch (node arrays laid out
+    for the full cap) nor in its second (laid out for twice the nodes the first one showed); then once more with the
+    fallback forced (same results)"""
     import torch
     from test_stream_sync_cpu import SEQ_N, SEQ_P
     topt("WALK_MONO", mono)         # (the walk as one launch per form instead of three: same outcome)
+    topt("WALK_WIDE", wide)         # (the per-channel launches as 1024 threads / 128 KB of LDS: same outcome)
     hs = torch.cuda.current_stream().cuda_stream
     cells = [(262, 42, 1), (901, 77, 9), (234, 14, 33), (1, 2, 3), (262, 42, 2), (505, 1, 60), (208, 10, 5), (222, 99, 7)]
     rng = np.random.default_rng(4040 + chunk)
@@ -1937,15 +1940,51 @@ def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, mono, topt):
     torch.cuda.synchronize()
     rec_a = ra.cpu().numpy().reshape(-1, T.REC_BYTES)
     assert all(x["noffgrid"] == 0 for x in ref) and sum(len(x["events"]) for x in ref) > 300
-    for forced in (False, True):
+    for what, forced in (("device", False), ("device, second batch of the plan", False), ("forced", True)):
         if forced:
             topt("WALK_HOST", int("1"))
         rb = torch.zeros(max(ms.ngrid, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
         msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), chunk, hs)
         got = msd.collect()
         assert msd.fellback == forced and msd.ngrid == ms.ngrid
-        _same_batch_outcome(T, ref, got, rec_a, rb.cpu().numpy().reshape(-1, T.REC_BYTES), "forced" if forced else "device")
+        _same_batch_outcome(T, ref, got, rec_a, rb.cpu().numpy().reshape(-1, T.REC_BYTES), what)
         assert pb.final_codes().tolist() == pa.final_codes().tolist()
+    pa.close()
+    pb.close()
+
+
+def test_device_walk_node_arrays_follow_the_channels(T, eng):
+    """the LDS form's node arrays are laid out per launch for twice the nodes the plan's batches have shown: a quiet batch
+    first (a few dozen nodes: the smallest cap), then one whose channel has over a thousand damaged slots -- that batch comes
+    back through the host walks (.fellback, same outcome), the cap follows, and the same batch once more stays on the device"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    cell = (262, 42, 1)
+    quiet, _ = _mix_stream(T, 2000, 61, cell, ber=0.0)
+    noisy, _ = _mix_stream(T, 5000, 62, cell, ber=0.0)
+    noisy = noisy.copy()
+    rng = np.random.default_rng(99)
+    lead = 100 + 510
+    nbad = 0
+    for i in range(5000):
+        if i % 8 and rng.random() < 0.3:
+            noisy[lead + 510 * i + 244 + 4] ^= 1
+            nbad += 1
+    assert nbad > 1100
+    d1, offs1, n1 = _multi_batch(T, [quiet, quiet])
+    d2, offs2, n2 = _multi_batch(T, [quiet, noisy])
+    pa, pb = T.Plan(eng, max(n1, n2), 2), T.Plan(eng, max(n1, n2), 2)
+    for streams, d, offs, fb in (([quiet, quiet], d1, offs1, False), ([quiet, noisy], d2, offs2, True), ([quiet, noisy], d2, offs2, False)):
+        ms = T.MultiSync(eng, pa, streams, d.data_ptr(), offs, 64, hs)
+        ref = ms.finish(burst_events=False, nthreads=2)
+        ra = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        pa.execute(d.data_ptr(), ra.data_ptr(), hs)
+        rb = torch.zeros(ms.ngrid * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), 64, hs)
+        got = msd.collect()
+        torch.cuda.synchronize()
+        assert msd.fellback == fb, (fb, msd.fellback)
+        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES), "cap follows")
     pa.close()
     pb.close()
 
