@@ -127,7 +127,7 @@ struct tgpu_plan {
 	int have_final;			/* ... and the codes after the batch are in h_final_code */
 	uint32_t h_final_code[64];
 	uint8_t *d_walk, *h_walk;	/* k_walk's blocks (tg_walk_io): up, down, device-only events (device / pinned mirror) */
-	void *d_walk_recs;		/* max_chan * (TGW_NCAP + 1) node records */
+	void *d_walk_recs;		/* max_chan * (min(TGW_NCAP, max_slots) + 1) node records */
 	void *d_walk_tmp;		/* hand-over area of the split walk */
 	uint8_t *d_walk_big;		/* scratch slots of k_walk_big (channels beyond TGW_WCAP bitmap words), on first need */
 	uint32_t walk_big_slots;
@@ -717,7 +717,8 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 		}
 	}
 	if (!p->d_walk_recs) {
-		hipError_t e = hipMalloc(&p->d_walk_recs, nc * (size_t)(TGW_NCAP + 1) * TGW_REC_BYTES);
+		/* (a channel has at most as many nodes as slots) */
+		hipError_t e = hipMalloc(&p->d_walk_recs, nc * (size_t)((p->max_slots < TGW_NCAP ? p->max_slots : TGW_NCAP) + 1) * TGW_REC_BYTES);
 		if (e != hipSuccess) {
 			p->d_walk_recs = NULL;
 			return (int)e;
@@ -754,6 +755,7 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 	io->down_bytes = (size_t)((uint8_t *)(io->d_bits2 + ((size_t)ngrid + 31) / 32) - io->d_down0);
 	io->d_evbig = (tgpu_sync_event_rec_dev *)(p->d_walk + o_big);
 	io->d_recs = p->d_walk_recs;
+	io->rec_stride = (p->max_slots < TGW_NCAP ? p->max_slots : TGW_NCAP) + 1;
 	return TGPU_OK;
 }
 

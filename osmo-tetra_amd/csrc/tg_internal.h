@@ -107,6 +107,7 @@ int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const stru
 	     uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp,
 	     unsigned long long skip_mask /* channels left to tgk_walk_big */,
 	     uint32_t wcap, uint32_t ncap /* the split form's LDS arrays hold channels of this many bitmap words / nodes (0: the full caps) */,
+	     uint32_t rec_stride /* node records per channel in d_recs, the head's record last: min(TGW_NCAP, the plan's slots) + 1 */,
 	     int wide /* 1: the split form's per-channel launches as 1024 threads with 128 KB of LDS (rounds 3 and 4) */, void *stream);
 /* the node cap a plan asks for (tg_host.c: twice what its batches have shown so far) */
 uint32_t tgpi_plan_walk_ncap(const struct tgpu_plan *p);
@@ -163,6 +164,7 @@ struct tg_walk_io {
 	uint32_t *d_final, *h_final;	/* 64 codes after the batch + the code table's overflow flag */
 	tgpu_sync_event_rec_dev *d_evbig;
 	void *d_recs;
+	uint32_t rec_stride;	/* node records per channel in d_recs */
 	void *d_tmp;			/* hand-over area of the split walk (TGW_TMP_BYTES) */
 	struct tg_walk_big big;		/* the batch's channels beyond TGW_WCAP words (n = 0: none) and the scratch caps */
 	uint8_t *d_big;			/* big.n scratch slots (tg_walk_big_offsets) */

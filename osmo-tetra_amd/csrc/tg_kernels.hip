@@ -3971,7 +3971,7 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	    const uint32_t *__restrict__ g_plain, uint32_t *__restrict__ g_bits, uint32_t *__restrict__ g_bits2,
 	    tg_walk_sum *__restrict__ sums, tgpu_sync_event_rec_dev *__restrict__ g_eager,
 	    tgpu_sync_event_rec_dev *__restrict__ g_evbig, tgw_rec *__restrict__ g_recs, uint8_t *__restrict__ d_tmp,
-	    unsigned long long skip_mask, uint32_t wcap, uint32_t ncap)
+	    unsigned long long skip_mask, uint32_t wcap, uint32_t ncap, uint32_t rec_stride)
 {
 	/* working arrays in LDS, laid out for the caps of this launch (tgk_walk): MODE 0 all of them, MODE 2 the bitmap, the two
 	 * arrival-pointer arrays and the marks, MODE 1 none */
@@ -3985,8 +3985,8 @@ void k_walk(const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ 
 	tg_walk_tmp tmp = { nullptr, nullptr, nullptr, nullptr };
 	if (MODE)
 		tmp = walk_tmp_small(d_tmp, c);
-	walk_body<false, uint16_t, MODE>(c, bm, nslot, wpre, Ja, Jb, mark, tmp, ((skip_mask >> c) & 1) != 0, g_recs + (size_t)c * (TGW_NCAP + 1),
-					 g_evbig + (size_t)c * TGW_EVCAP, wcap, ncap, TGW_NCAP, TGW_EVCAP, d_base, chan, roots, chunk, cshift, g_cls,
+	walk_body<false, uint16_t, MODE>(c, bm, nslot, wpre, Ja, Jb, mark, tmp, ((skip_mask >> c) & 1) != 0, g_recs + (size_t)c * rec_stride,
+					 g_evbig + (size_t)c * TGW_EVCAP, wcap, ncap < rec_stride - 1 ? ncap : rec_stride - 1, rec_stride - 1, TGW_EVCAP, d_base, chan, roots, chunk, cshift, g_cls,
 					 g_ysum, g_plain, g_bits, g_bits2, sums, g_eager);
 }
 
@@ -4020,7 +4020,7 @@ __global__ __launch_bounds__(256)
 void k_walk_nodes(tg_walk_big big, uint8_t *__restrict__ scratch, uint8_t *__restrict__ d_tmp, tgw_rec *__restrict__ g_recs,
 		  const uint8_t *__restrict__ d_base, const tg_chan_ent *__restrict__ chan, const tg_walk_root *__restrict__ roots,
 		  uint32_t chunk, uint32_t cshift, const uint32_t *__restrict__ g_cls, const uint16_t *__restrict__ g_ysum,
-		  const uint32_t *__restrict__ g_plain)
+		  const uint32_t *__restrict__ g_plain, uint32_t rec_stride)
 {
 	const uint32_t c = BIG ? big.chan[blockIdx.y] : blockIdx.y;
 	tg_walk_tmp tmp;
@@ -4035,8 +4035,8 @@ void k_walk_nodes(tg_walk_big big, uint8_t *__restrict__ scratch, uint8_t *__res
 		ncap = big.ncap;
 	} else {
 		tmp = walk_tmp_small(d_tmp, c);
-		recs = g_recs + (size_t)c * (TGW_NCAP + 1);
-		ncap = TGW_NCAP;
+		recs = g_recs + (size_t)c * rec_stride;
+		ncap = rec_stride - 1;
 	}
 	const uint32_t N = tmp.meta[0];
 	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -4087,11 +4087,11 @@ void k_walk_nodes(tg_walk_big big, uint8_t *__restrict__ scratch, uint8_t *__res
 extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const struct tg_walk_root *d_roots, uint32_t nchan,
 			uint32_t chunk, const uint32_t *d_cls, const uint16_t *d_ysum, const uint32_t *d_plain, uint32_t *d_bits,
 			uint32_t *d_bits2, struct tg_walk_sum *d_sums, void *d_eager, void *d_evbig, void *d_recs, void *d_tmp,
-			unsigned long long skip_mask, uint32_t wcap, uint32_t ncap, int wide, void *stream)
+			unsigned long long skip_mask, uint32_t wcap, uint32_t ncap, uint32_t rec_stride, int wide, void *stream)
 {
 	if (!nchan)
 		return 0;
-	if (!chunk || (chunk & (chunk - 1)) || nchan > 64)
+	if (!chunk || (chunk & (chunk - 1)) || nchan > 64 || rec_stride < 2 || rec_stride > TGW_NCAP + 1)
 		return -1;
 	if (!d_tmp || wide || !wcap || !ncap || wcap > TGW_WCAP || ncap > TGW_NCAP) {
 		wcap = TGW_WCAP;
@@ -4103,7 +4103,7 @@ extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 	hipStream_t s = (hipStream_t)stream;
 #define WALK_ARGS d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain, d_bits, d_bits2, d_sums, \
 		  (tgpu_sync_event_rec_dev *)d_eager, (tgpu_sync_event_rec_dev *)d_evbig, (tgw_rec *)d_recs, (uint8_t *)d_tmp, skip_mask, \
-		  wcap, ncap
+		  wcap, ncap, rec_stride
 	if (!d_tmp) {
 		HIPCHK(hipFuncSetAttribute((const void *)k_walk<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TGW_LDS_BYTES));
 		hipLaunchKernelGGL(k_walk<0>, dim3(nchan), dim3(TGW_THREADS), TGW_LDS_BYTES, s, WALK_ARGS);
@@ -4121,7 +4121,7 @@ extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 	hipLaunchKernelGGL(k_walk<1>, dim3(nchan), dim3(nt), wide ? TGW_LDS_BYTES : 0, s, WALK_ARGS);
 	tg_walk_big none = {};
 	hipLaunchKernelGGL(k_walk_nodes<false>, dim3(ncap / 256, nchan), dim3(256), 0, s, none, (uint8_t *)nullptr, (uint8_t *)d_tmp,
-			   (tgw_rec *)d_recs, d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain);
+			   (tgw_rec *)d_recs, d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain, rec_stride);
 	hipLaunchKernelGGL(k_walk<2>, dim3(nchan), dim3(nt), wide ? TGW_LDS_BYTES : TGW_LDS2_BYTES(wcap, ncap), s, WALK_ARGS);
 #undef WALK_ARGS
 	return (int)hipGetLastError();
@@ -4146,7 +4146,7 @@ extern "C" int tgk_walk_big(const struct tg_walk_big *big, void *d_scratch, cons
 	}
 	hipLaunchKernelGGL(k_walk_big<1>, dim3(big->n), dim3(TGW_THREADS), 0, s, WALK_ARGS);
 	hipLaunchKernelGGL(k_walk_nodes<true>, dim3((big->ncap + 255) / 256, big->n), dim3(256), 0, s, *big, (uint8_t *)d_scratch,
-			   (uint8_t *)d_tmp, (tgw_rec *)nullptr, d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain);
+			   (uint8_t *)d_tmp, (tgw_rec *)nullptr, d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain, 0u);
 	hipLaunchKernelGGL(k_walk_big<2>, dim3(big->n), dim3(TGW_THREADS), 0, s, WALK_ARGS);
 #undef WALK_ARGS
 	return (int)hipGetLastError();

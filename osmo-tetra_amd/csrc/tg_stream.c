@@ -1549,7 +1549,7 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 		if (!rc)
 			rc = tgk_walk(d_base, io->d_tab, io->d_roots, nchan, chunk, d_cls, d_ysum, d_plain, d_bits, io->d_bits2, io->d_sums,
 				      io->d_eager, io->d_evbig, io->d_recs, tgi_option(TGPU_OPT_WALK_MONO) ? NULL : io->d_tmp, skip,
-				      wmax ? wmax : 1, tgpi_plan_walk_ncap(plan), (int)tgi_option(TGPU_OPT_WALK_WIDE), stream);
+				      wmax ? wmax : 1, tgpi_plan_walk_ncap(plan), io->rec_stride, (int)tgi_option(TGPU_OPT_WALK_WIDE), stream);
 		if (!rc) {
 			if (big.n) {
 				rc = tgpi_plan_walk_big(plan, big.n, io);
