@@ -579,7 +579,7 @@ void tgpu_sync_multi_free(struct tgpu_sync_multi *st);
  *   tgpu_sync_multi_collect() waits for the batch and fills out[nchan] like tgpu_sync_multi_finish() does (events without
  *   TGPU_EV_BURST; release each with tgpu_sync_result_free()).  Where the device walk cannot settle a channel -- only the
  *   bytes can decide (a byte other than 0 / 1 near an exception, a sequence in the first 21 bytes of a search buffer, a
- *   re-lock off the grid, a window beyond the kernel's view: feeds of 128 / 256 bytes) -- the batch is redone through the
+ *   re-lock off the grid) -- the batch is redone through the
  *   host walks and decoded again before the call returns: same results (tgpu_sync_dev_fellback() tells).  A channel of
  *   more than 262 144 slots (an hour of one carrier) is walked on the device as well, with its working arrays in a scratch
  *   area of the plan instead of LDS (k_walk_big: up to 8 such channels per batch, exceptions up to an eighth of the plan's
@@ -612,6 +612,12 @@ int tgpu_sync_multi_launch_packed(struct tgpu_engine *eng, struct tgpu_plan *pla
 				  const uint8_t *d_packed_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *hip_stream);
 uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd);
 int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd);
+/* after collect: why the device walk handed channel c to the host walks (0: it did not).  1 a flagged slot (a byte other than
+ * 0 / 1, a sequence below offset 21) on the walk's way, 2 a search window the kernel's view does not settle, 3 a SYNC sequence in
+ * the first 21 bytes of a search buffer, 4 a lock beside the slot grid, 5 / 6 / 7 / 8 / 9 internal bounds (iterations, events or
+ * deliveries per exception, SYNC summaries), 10 more exceptions than this launch's arrays hold, 11 a channel beyond the LDS
+ * form's length that found no place in the long form */
+int tgpu_sync_dev_why(const struct tgpu_sync_dev *sd, uint32_t chan);
 uint64_t tgpu_sync_dev_cwire_bytes(const struct tgpu_sync_dev *sd);	/* after collect; tgpu_plan_set_cwire() */
 void tgpu_sync_dev_free(struct tgpu_sync_dev *sd);
 /* measurement aid: one such batch, synchronously, with HIP events between all of its stages on hip_stream: dev_ms[] =

@@ -206,6 +206,7 @@ def lib():
     L.tgpu_sync_dev_ngrid.argtypes = [C.c_void_p]
     L.tgpu_sync_dev_ngrid.restype = C.c_uint32
     L.tgpu_sync_dev_fellback.argtypes = [C.c_void_p]
+    L.tgpu_sync_dev_why.argtypes = [C.c_void_p, C.c_uint32]
     L.tgpu_sync_dev_free.argtypes = [C.c_void_p]
     L.tgpu_sync_dev_free.restype = None
     L.tgpu_sync_walk_emul.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint64, u32p, u16p, u32p, C.c_uint32, C.POINTER(SyncResult),
@@ -810,6 +811,7 @@ class MultiSyncDev:
         try:
             _chk(lib().tgpu_sync_multi_collect(self._h, self._res), "tgpu_sync_multi_collect")
             self.fellback = bool(lib().tgpu_sync_dev_fellback(self._h))
+            self.why = [int(lib().tgpu_sync_dev_why(self._h, c)) for c in range(n)] if self.fellback else [0] * n
             self.cwire_bytes = int(lib().tgpu_sync_dev_cwire_bytes(self._h))
         finally:
             lib().tgpu_sync_dev_free(self._h)

@@ -419,7 +419,7 @@ void k_bbk_blocks(const uint32_t *__restrict__ items, uint32_t nitems, const uin
  * search window of slot n is what the reference's synchroniser would hold when it gets to that
  * slot while being fed 'chunk' bytes per call (phy/tetra_burst_sync.c:106-120):
  *     w = min(chunk * ceil((bs + 510) / chunk), len) - bs        (510 .. 573 for chunk = 64)
- * Per wave and slot: 640 bytes -> LDS; ten 64-bit ballots turn them into a 640-bit string held in
+ * Per wave and slot: 832 bytes -> LDS; thirteen 64-bit ballots turn them into an 832-bit string held in
  * SGPRs; every lane then tests one window position per round against y (38 bits), n and p (22 bits)
  * with two v_alignbit_b32 -- the first hit in ascending position is tetra_find_train_seq()'s answer
  * (phy/tetra_burst.c:269-339).  Positions 0..255 are always scanned (the expected hits sit at 214
@@ -459,8 +459,9 @@ __device__ __forceinline__ uint32_t chan_of_slot(const tg_chan_ent *chan, uint32
 }
 
 /*
- * One grid slot through the per-position search: the wave's 640-byte view goes to LDS, ten ballots turn it into a
- * 640-bit string in SGPRs, every lane tests one window position per round.  This is the exact form for ANY slot
+ * One grid slot through the per-position search: the wave's 832-byte view (510 + the longest feed of the device path, 256,
+ * + a sequence's 38, rounded up to 64) goes to LDS, thirteen ballots turn it into an
+ * 832-bit string in SGPRs, every lane tests one window position per round.  This is the exact form for ANY slot
  * (stream end, windows longer than the slot, bytes other than 0 / 1, nothing found where a burst should be): the
  * round-1 kernel ran it on every slot (k_front_stream_v1, kept for A/B runs), the packed-bit kernel below hands
  * it the slots it cannot settle (k_front_stream_fix).
@@ -472,7 +473,10 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 						  const uint32_t (&a_sb)[10], uint32_t &myword, uint32_t &clsword, uint32_t &ysword)
 {
 	const uint64_t bs = prm.anchor + (uint64_t)slot * TG_SLOT_BITS;
-	uint32_t d0, d1, d2;
+	uint32_t d0, d1, d2, d3;
+	/* (the last 64 bytes of the view lie up to 322 bytes past the slot: read only where the buffer's slack covers them --
+	 * bytes past the stream's end count as zeros anyway) */
+	const bool tail_ok = lane < 16 && bs + 768 + 4 * lane + 16 <= prm.len + TG_STREAM_SLACK;
 	if (PACKED) {
 		/* packed ingest: 'stream' is the packed buffer and prm.anchor counts from the channel's bit 0, whose position in the
 		 * buffer the caller has added to... the bit position of the slot: every lane fetches the two bytes that hold its
@@ -484,13 +488,15 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 		};
 		d0 = nib(b0);
 		d1 = nib(b0 + 256);
-		d2 = (lane < 32) ? nib(b0 + 512) : 0u;
+		d2 = (bs + 512 + 4 * lane + 16 <= prm.len + TG_STREAM_SLACK) ? nib(b0 + 512) : 0u;
+		d3 = tail_ok ? nib(b0 + 768) : 0u;
 	} else {
 		const uint8_t *base = stream + bs;
-		/* 640 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack) */
+		/* 832 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack) */
 		d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
 		d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
-		d2 = (lane < 32) ? *(const tg_u32_unaligned *)(base + 512 + 4 * lane) : 0u;
+		d2 = (bs + 512 + 4 * lane + 4 <= prm.len + TG_STREAM_SLACK) ? *(const tg_u32_unaligned *)(base + 512 + 4 * lane) : 0u;
+		d3 = tail_ok ? *(const tg_u32_unaligned *)(base + 768 + 4 * lane) : 0u;
 	}
 
 	uint64_t fed = bs + TG_SLOT_BITS + prm.chunk - 1;
@@ -504,39 +510,43 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 
 	mine[lane] = d0;
 	mine[64 + lane] = d1;
-	if (lane < 32)
-		mine[128 + lane] = d2;
+	mine[128 + lane] = d2;
+	if (lane < 16)
+		mine[192 + lane] = d3;
 
-	/* bytes -> 640-bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes past the stream end read as 0
+	/* bytes -> 832-bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes past the stream end read as 0
 	 * (every test below bounds itself by the window, so bytes past the window need no masking) */
-	unsigned long long B[11];
+	constexpr int NR = TG_STREAM_VIEW / 64;	/* rounds of 64 window positions: 13 */
+	unsigned long long B[NR + 1];
 	if (vis == TG_STREAM_VIEW) {	/* everywhere but at the very end of the stream: no per-lane bound */
 #pragma unroll
-		for (int r = 0; r < 10; r++)
+		for (int r = 0; r < NR; r++)
 			B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0);
 	} else {
 #pragma unroll
-		for (int r = 0; r < 10; r++)
+		for (int r = 0; r < NR; r++)
 			B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0 && 64u * r + lane < vis);
 	}
-	B[10] = 0;
+	B[NR] = 0;
 	/* a byte other than 0 / 1 inside the search window: from the three dwords of the lane (byte k of dword q
 	 * is window byte 256 q + 4 lane + k), bytes at or past the window end masked off */
 	uint32_t anyb;
 	{
-		const uint32_t p0 = 4 * lane, p1 = 256 + 4 * lane, p2 = 512 + 4 * lane;
-		const uint32_t k0 = wv > p0 ? wv - p0 : 0, k1 = wv > p1 ? wv - p1 : 0, k2 = wv > p2 ? wv - p2 : 0;
+		const uint32_t p0 = 4 * lane, p1 = 256 + 4 * lane, p2 = 512 + 4 * lane, p3 = 768 + 4 * lane;
+		const uint32_t k0 = wv > p0 ? wv - p0 : 0, k1 = wv > p1 ? wv - p1 : 0, k2 = wv > p2 ? wv - p2 : 0, k3 = wv > p3 ? wv - p3 : 0;
 		const uint32_t m0 = k0 >= 4 ? 0xffffffffu : ((1u << (8 * k0)) - 1u);
 		const uint32_t m1 = k1 >= 4 ? 0xffffffffu : ((1u << (8 * k1)) - 1u);
 		const uint32_t m2 = k2 >= 4 ? 0xffffffffu : ((1u << (8 * k2)) - 1u);
-		anyb = (((d0 & m0) | (d1 & m1) | (d2 & m2)) & 0xfefefefeu) ? 2u : 0u;
+		const uint32_t m3 = k3 >= 4 ? 0xffffffffu : ((1u << (8 * k3)) - 1u);
+		anyb = (((d0 & m0) | (d1 & m1) | (d2 & m2) | (d3 & m3)) & 0xfefefefeu) ? 2u : 0u;
 	}
 
 	uint32_t rc = TG_BURST_NONE, offs = 0, flags = 0;
 	uint32_t ys = TG_YS_NONE;	/* where SYNC sequences start inside this slot, window or not */
 	bool found = false, inview = false;	/* inview: a sequence that ends inside the view, inside the window or not */
+	uint32_t voffs = 0, vtype = 0;		/* the first of those */
 #pragma unroll
-	for (int r = 0; r < 10; r++) {
+	for (int r = 0; r < NR; r++) {
 		const bool full = (r < 4 || !found) && 64u * r < wv;
 		const bool look = r >= 7 && !found && 64u * r < vis;	/* nothing so far: anything in the rest of the view? */
 		if (full || r < 8 || look) {
@@ -564,9 +574,17 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 						ys |= TG_YS_MULTI;
 				}
 			}
-			if (look)	/* (rounds 0..6: whatever starts there ends inside every window) */
-				inview = inview || __ballot((y38 && c + 38 <= vis) ||
-							    (((win & 0x3fffff) == prm.n22 || (win & 0x3fffff) == prm.p22) && c + 22 <= vis)) != 0;
+			if (look && !inview) {	/* (rounds 0..6: whatever starts there ends inside every window) */
+				const bool vy = y38 && c + 38 <= vis, vn = (win & 0x3fffff) == prm.n22 && c + 22 <= vis;
+				const bool vp = (win & 0x3fffff) == prm.p22 && c + 22 <= vis;
+				const unsigned long long mv = __ballot(vy || vn || vp);
+				if (mv) {
+					const uint32_t l0 = __builtin_ctzll(mv);
+					inview = true;
+					voffs = 64 * r + l0;
+					vtype = __builtin_amdgcn_readlane(vy ? (uint32_t)TG_BURST_SYNC : vn ? (uint32_t)TG_BURST_NORM_1 : (uint32_t)TG_BURST_NORM_2, l0);
+				}
+			}
 			if (full) {
 				/* the window holds at least 510 bytes: rounds 0..6 (c + 38 <= 485) need no bound */
 				const bool in38 = (r < 7) || (c + 38 <= w), in22 = (r < 7) || (c + 22 <= w);
@@ -610,6 +628,11 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 		flags |= TG_CLS_CLIPPED;
 	if (!found && !inview)
 		flags |= TG_CLS_NOVIEW;
+	const uint32_t metaoffs = offs;
+	if (!found && inview) {		/* what a longer window finds first (tg_layout.h) */
+		offs = voffs;
+		flags |= (vtype + 1u) << TG_CLS_VIEWHIT_SHIFT;
+	}
 
 	/* what tetra_burst_sync_in() would hand to tetra_burst_rx_cb() (phy/tetra_burst_sync.c:121-141) */
 	uint32_t dtype = TG_BURST_NONE;
@@ -626,7 +649,7 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 	else if (dtype == TG_BURST_SYNC)
 		myword = front_gather(lds0, a_sb);
 	if (lane == TG_PW_META)
-		myword = dtype | (((flags & TG_CLS_NONBINARY) ? TG_FLAG_NONBINARY : 0u) << 8) | (offs << 16);
+		myword = dtype | (((flags & TG_CLS_NONBINARY) ? TG_FLAG_NONBINARY : 0u) << 8) | (metaoffs << 16);
 	clsword = rc | (offs << 8) | (flags << 24);
 	ysword = ys;
 }
@@ -655,11 +678,11 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 		a_sb[r] = wbase + (o2 == 0xffff ? TG_STREAM_VIEW : o2);					\
 	}
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
 void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		       uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
 {
-	STREAM_SLOT_TABLES(TG_STREAM_VIEW / 4 + 4)	/* 160 data dwords + one zero pad row */
+	STREAM_SLOT_TABLES(TG_STREAM_VIEW / 4 + 4)	/* 208 data dwords + one zero pad row */
 	__shared__ uint32_t s_out[4][128];	/* per wave: four packed slots on their way out, then their cls / ysum words */
 	uint32_t *mo = s_out[wib];
 
@@ -694,7 +717,7 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	}
 }
 
-/* classification word of a slot the packed-bit kernel leaves to k_front_stream_fix (never a valid word: offsets stay below 640) */
+/* classification word of a slot the packed-bit kernel leaves to k_front_stream_fix (never a valid word: offsets stay below 832) */
 #define TG_CLS_DEFER 0xffffffffu
 
 /* second pass of the packed-bit front end: every slot the first pass deferred (it appended them to a list: defer[0] =

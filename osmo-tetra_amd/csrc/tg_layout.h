@@ -71,16 +71,21 @@
  */
 #define TG_CLS_EARLY21    0x01	/* a full match exists at an offset < 21 and was NOT evaluated */
 #define TG_CLS_NONBINARY  0x02
-#define TG_CLS_CLIPPED    0x04	/* window longer than the kernel's 640-byte view and nothing found in view */
-#define TG_CLS_NOVIEW     0x08	/* nothing found, and nothing in the rest of the 640-byte view (bounded by the stream's end)
+#define TG_CLS_CLIPPED    0x04	/* window longer than the kernel's 832-byte view and nothing found in view */
+#define TG_CLS_NOVIEW     0x08	/* nothing found, and nothing in the rest of the 832-byte view (bounded by the stream's end)
 				 * either: "nothing" is then also the answer for any longer window up to the view -- what the
 				 * synchroniser searches while it works off a backlog (tg_walk_core.h) */
+/* a word that says "nothing in the window" and does not carry TG_CLS_NOVIEW: bits 4..6 of the flags = 1 + type of the FIRST
+ * sequence that starts inside the view and ends past the window, bits 8..23 of the word its offset -- what a longer window
+ * (a slot handled some calls late, feeds of 128 / 256 bytes) finds first, if it reaches that far */
+#define TG_CLS_VIEWHIT_SHIFT 4
+#define TG_CLS_VIEWHIT(flags) (((flags) >> TG_CLS_VIEWHIT_SHIFT) & 7u)
 /* SYNC-sequence summary of a grid slot (uint16): where the 38-bit y sequence starts inside the slot's own
  * 510 positions, regardless of any search window -- what an UNLOCKED synchroniser scans for */
 #define TG_YS_NONE        0xffffu	/* no y sequence starts in this slot */
 #define TG_YS_MULTI       0x8000u	/* more than one does; bits 0..8 hold the first */
 #define TG_YS_FIRST(v)    ((v) & 0x1ffu)
-#define TG_STREAM_VIEW    640	/* bytes of a slot's search window the kernel looks at */
+#define TG_STREAM_VIEW    832	/* bytes of a slot's search window the kernel looks at: 510 + 255 (feeds of up to 256 bytes) + 38, in rounds of 64 */
 #define TG_STREAM_SLACK   192	/* readable bytes the stream buffer must have after its last byte */
 
 /* soft area of a slot (config 5): int8 values in trellis order, see k_front_soft */

@@ -1606,6 +1606,16 @@ int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd)
 	return sd ? sd->fellback : 0;
 }
 
+/* why the device walk handed channel c over (after collect): 0 = it did not; TGPU_WHY_* otherwise */
+int tgpu_sync_dev_why(const struct tgpu_sync_dev *sd, uint32_t c)
+{
+	if (!sd || c >= sd->st->nchan || !sd->st->ngrid || !sd->io.h_sums || !sd->st->ent[c].ncls)
+		return 0;
+	if (sd->io.h_sums[c].status == TGW_OK)
+		return 0;
+	return sd->io.h_sums[c].why ? (int)sd->io.h_sums[c].why : -1;
+}
+
 uint64_t tgpu_sync_dev_cwire_bytes(const struct tgpu_sync_dev *sd)
 {
 	return sd ? sd->cwire_bytes : 0;

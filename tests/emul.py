@@ -80,7 +80,7 @@ CLS_LIB = os.path.join(HERE, "host_emul", "libcls_emul.so")
 _cls_lib = None
 
 
-def cls_ysum(stream, anchor, chunk, view=640):
+def cls_ysum(stream, anchor, chunk, view=832):
     """(cls, ysum) as tests/test_stream_sync_cpu.py's emul_cls / emul_ysum give them, in C: streams of bench size"""
     global _cls_lib
     if _cls_lib is None:

@@ -531,6 +531,26 @@ def test_stream_classification_kernel(T, eng):
         assert ys.tolist() == emul_ysum(s, anchor).tolist()
         assert (ys != 0xFFFF).sum() >= 3
         assert T.sync_classify(eng, d.data_ptr(), len(s), 64, anchor, n).tolist() == got.tolist()
+        # feeds of 128 / 256 bytes: the search window reaches up to 765 bytes from the slot's start, all of it inside the
+        # kernel's 832-byte view (no TG_CLS_CLIPPED); hits beyond the slot and its successor's first bytes included
+        from test_stream_sync_cpu import SEQ_N
+        for chunk in (128, 256):
+            s2 = s.copy()
+            planted = []
+            for i in range(5, n - 2):         # slots whose own sequence is damaged and whose window (chunk-aligned end) reaches far
+                bs = anchor + 510 * i
+                w = min(-(-(bs + 510) // chunk) * chunk, len(s2)) - bs
+                if (got[i] & 0xFFFFFE) == (244 << 8) and w >= 604 and len(planted) < 3 and (not planted or i > planted[-1] + 3):
+                    s2[bs + 244 + 3] ^= 1
+                    s2[bs + 580:bs + 602] = SEQ_N
+                    planted.append(i)
+            assert planted
+            d2 = torch.from_numpy(np.concatenate([s2, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
+            g2 = T.sync_classify(eng, d2.data_ptr(), len(s2), chunk, anchor, n)
+            want = emul_cls(s2, anchor, chunk)
+            assert (g2 & 0x7DFFFFFF).tolist() == (want & 0x7DFFFFFF).tolist(), chunk
+            assert not (g2 >> 24 & 4).any()
+            assert all((g2[i] >> 8 & 0xFFFF) == 580 for i in planted), "a hit beyond a 64-byte feed's window"
 
 
 def _hostile_stream(T, seed, nslots, lead_in, shift=True):
@@ -1894,7 +1914,7 @@ def _same_batch_outcome(T, a, b, rec_a, rec_b, what):
             assert (rec_a[idx] == rec_b[idx]).all(), (what, c)
 
 
-@pytest.mark.parametrize("chunk,mono,wide", [(64, 0, 0), (32, 0, 0), (64, 1, 0), (64, 0, 1)])
+@pytest.mark.parametrize("chunk,mono,wide", [(64, 0, 0), (32, 0, 0), (64, 1, 0), (64, 0, 1), (128, 0, 0), (256, 0, 0)])
 def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, mono, wide, topt):
     """tgpu_sync_multi_launch / _collect (the synchroniser walks on the device: k_walk) against tgpu_sync_multi_begin /
     _finish (host walks) on the same multi-channel batch: eight channels of different cells, lengths, lead-ins and damage
@@ -1946,7 +1966,7 @@ def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, mono, wide, top
         rb = torch.zeros(max(ms.ngrid, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
         msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), chunk, hs)
         got = msd.collect()
-        assert msd.fellback == forced and msd.ngrid == ms.ngrid
+        assert msd.fellback == forced and msd.ngrid == ms.ngrid, (what, msd.why)
         _same_batch_outcome(T, ref, got, rec_a, rb.cpu().numpy().reshape(-1, T.REC_BYTES), what)
         assert pb.final_codes().tolist() == pa.final_codes().tolist()
     pa.close()

@@ -46,7 +46,7 @@ def oracle_view(stream, chunk):
     return bursts, events, pos
 
 
-def emul_cls(stream, anchor, chunk, view=640):
+def emul_cls(stream, anchor, chunk, view=832):
     """numpy statement of k_front_stream's classification words"""
     L = len(stream)
     n = (L - anchor) // 510 if L >= anchor + 510 else 0
@@ -57,7 +57,7 @@ def emul_cls(stream, anchor, chunk, view=640):
         f = min(-(-(bs + 510) // chunk) * chunk, L)
         w = f - bs
         wv = min(w, view)
-        buf = pad[bs:bs + 700].copy()
+        buf = pad[bs:bs + 900].copy()
         buf[wv:] = 0
         rc, off = 0xFF, 0
         for c in range(0, wv):
@@ -77,10 +77,16 @@ def emul_cls(stream, anchor, chunk, view=640):
         flags = 4 if (rc == 0xFF and w > view) else 0
         if rc == 0xFF:      # TG_CLS_NOVIEW: nothing in the rest of the view (up to the stream's end) either
             vis = min(L - bs, view)
-            full = pad[bs:bs + 700]
-            anyv = any(((c + 38 <= vis and (full[c:c + 38] == SEQ_Y).all()) or
-                        (c + 22 <= vis and ((full[c:c + 22] == SEQ_N).all() or (full[c:c + 22] == SEQ_P).all())))
-                       for c in range(21, vis))
+            full = pad[bs:bs + 900]
+            anyv = False
+            for c in range(21, vis):    # the first sequence that ends inside the view: 1 + type in bits 4..6 of the flags, offset in the word
+                t = 3 if (c + 38 <= vis and (full[c:c + 38] == SEQ_Y).all()) else \
+                    0 if (c + 22 <= vis and (full[c:c + 22] == SEQ_N).all()) else \
+                    1 if (c + 22 <= vis and (full[c:c + 22] == SEQ_P).all()) else None
+                if t is not None:
+                    anyv, off = True, c
+                    flags |= (t + 1) << 4
+                    break
             if not anyv:
                 flags |= 8
         out[i] = rc | (off << 8) | (flags << 24)
@@ -101,7 +107,7 @@ def emul_ysum(stream, anchor):
         if p < anchor:
             continue
         g = (p - anchor) // 510
-        if g >= n or (p - anchor) % 510 + 38 > min(L - (anchor + 510 * g), 640):
+        if g >= n or (p - anchor) % 510 + 38 > min(L - (anchor + 510 * g), 832):
             continue
         if out[g] == 0xFFFF:
             out[g] = (p - anchor) % 510
@@ -416,3 +422,36 @@ def test_device_form_on_a_recording_beyond_one_workgroups_arrays():
     st, _, _ = bench.make_mix_stream(T, 266000, 3, mnc=44, cc=9)
     r = _dev_form(np.ascontiguousarray(st), 64)
     assert r[0] == "ok" and r[1] > 3000
+
+
+def test_device_form_with_feeds_of_128_and_256_bytes():
+    """the search window of a slot reaches up to 765 bytes with such feeds: the classification word of a slot with nothing
+    in its window carries the first sequence further on in the 832-byte view (TG_CLS_VIEWHIT), which is what the longer
+    windows of these feeds find -- the device form settles damaged streams of these feeds without the bytes (before: every
+    damaged slot was a hand-over), outcome == host walk == oracle"""
+    rng = np.random.default_rng(1357)
+    res = {128: [0, 0], 256: [0, 0]}
+    for trial in range(40):
+        stream, slots = synth.frame_stream(seed=300 + trial, nframes=int(rng.integers(3, 24)), lead_in=int(rng.integers(0, 400)),
+                                           pad=int(rng.integers(600, 900)))
+        s = stream.copy()
+        tr = [i for i in range(0, len(s) - 60) if (s[i:i + 22] == SEQ_N).all() or (s[i:i + 22] == SEQ_P).all() or (s[i:i + 38] == SEQ_Y).all()]
+        for i in tr:
+            if rng.random() < 0.15:
+                s[i + int(rng.integers(0, 22))] ^= 1
+        if trial % 4 == 0 and len(tr) > 6:
+            j = int(rng.integers(0, len(tr) - 3))
+            for i in tr[j:j + 3] + tr[-2:]:
+                s[i + 3] ^= 1
+        for _ in range(int(rng.integers(0, 4))):        # spurious sequences anywhere: also in the stretch behind a damaged slot
+            p = int(rng.integers(0, len(s) - 60))
+            seq = (SEQ_N, SEQ_P, SEQ_Y)[int(rng.integers(0, 3))]
+            s[p:p + len(seq)] = seq
+        chunk = (128, 256)[trial & 1]
+        r = _dev_form(np.ascontiguousarray(s), chunk)
+        if r is None:
+            continue
+        res[chunk][0 if r[0] == "ok" else 1] += 1
+        if r[0] != "ok":
+            assert r[1] in (2, 3, 4), r
+    assert res[128][0] >= 12 and res[256][0] >= 12, res
