@@ -1007,6 +1007,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			const uint32_t ab = (uint32_t)((uintptr_t)p & 15);
 			d.a0 = 8 * ab + (uint32_t)(gbit & 7);
 			d.a = *(const uint4 *)(p - ab + 16 * (lane < 18 ? lane : 17));
+			d.b = d.c = make_uint4(0, 0, 0, 0);	/* (unused here; left unset they keep the whole struct in scratch memory) */
 			return;
 		}
 #if TGS_ABLATE & 2
