@@ -972,15 +972,44 @@ def bench_config5(args, T, torch, rank, world, local):
     plan = T.Plan(eng, n, 1)
     plan.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types, None, np.array([code], np.uint32))
     hs = torch.cuda.current_stream().cuda_stream
-    # the timed region: K fused passes
-    for k in range(args.warmup):
+    # the timed region: K fused passes, D of them in flight -- every pass on a plan and a stream (= a hardware queue) of its
+    # own, so that one pass' slicer (memory-shaped) runs beside another's trellis kernels (issue-shaped), as in the mix
+    D = max(1, min(args.depth5, args.steps))
+    plans = [plan] + [T.Plan(eng, n, 1) for _ in range(D - 1)]
+    recs = [d_rec] + [torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D - 1)]
+    strm = [torch.cuda.Stream() for _ in range(D)]
+    for p_ in plans[1:]:
+        p_.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types, None, np.array([code], np.uint32))
+    if D > 1 and not args.side_stream:
+        for p_ in plans:
+            p_.set_side_stream(False)
+    torch.cuda.synchronize()
+
+    def passes(count):
+        for k in range(count):
+            j = k % D
+            plans[j].execute_float(d_phi.data_ptr(), len(phi), recs[j].data_ptr(), strm[j].cuda_stream if D > 1 else hs)
+    passes(max(args.warmup, D))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    passes(args.steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    for j in range(1, D):
+        assert torch.equal(recs[j], d_rec), "passes in flight gave different records"
+    for p_ in plans[1:]:
+        p_.close()
+    del recs[1:]
+    plan.set_side_stream(True)
+    # the same passes one at a time (rounds 2-4's form: one plan, its side stream in play)
+    for k in range(3):
         plan.execute_float(d_phi.data_ptr(), len(phi), d_rec.data_ptr(), hs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         plan.execute_float(d_phi.data_ptr(), len(phi), d_rec.data_ptr(), hs)
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    el_serial = time.perf_counter() - t0
     # the two-stage path, same steps
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t_f2b = t_dec = 0.0
@@ -1044,6 +1073,10 @@ def bench_config5(args, T, torch, rank, world, local):
                                   "(packed 16-bit trellis), records left in HBM" % n,
                       "crc_ok_blocks_first_4096_slots": int(p["crc_ok"].sum()),
                       "checked": "records of the first %d slots == the oracle's soft chain; fused == two-stage on every byte" % chk},
+           "passes_in_flight": D,
+           "one_pass_at_a_time": {"ms_per_step": el_serial / args.steps * 1e3, "value": n * args.steps / el_serial,
+                                  "note": "one plan, one pass behind the other on one stream (k_vit_soft<432> on the plan's side stream "
+                                          "beside k_vit_soft<216>): the form of rounds 2-4"},
            "two_stage": {"ms_per_step": el2 / args.steps * 1e3, "value": n * args.steps / el2,
                          "k_float_to_bits_ms (255 floats in, 510 B bits + 510 B soft values out per burst)": t_f2b / args.steps,
                          "execute_soft_ms (k_front_soft + trellis kernels)": t_dec / args.steps},
@@ -1053,9 +1086,9 @@ def bench_config5(args, T, torch, rank, world, local):
                         "stage_ms": {names[i]: float(stage_ms[i]) for i in range(len(names))},
                         "algorithmic_bytes_per_launch": int(alg),
                         "pipeline_achieved_gbs": float(n * args.steps / el * (whole / n) / 1e9),
-                        "note": "stage durations from HIP events between the stages on the launch stream (the trellis launches "
-                                "run one after the other there; in the timed region k_vit_soft<432> runs on a side stream beside "
-                                "k_vit_soft<216>); the trellis kernels are bound by vector-instruction issue, not by HBM"}}
+                        "note": "stage durations from HIP events between the stages on the launch stream of a pass that runs alone; in the "
+                                "timed region passes_in_flight passes run side by side, each on a stream of its own (one pass' slicer beside "
+                                "another's trellis kernels); the trellis kernels are bound by vector-instruction issue, not by HBM"}}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_config5(phi, types, code)
     print(json.dumps(out))
@@ -1168,14 +1201,43 @@ def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(warmup):
+    # D passes in flight, each on a plan and a stream (= a hardware queue) of its own: one pass' gather (memory-shaped) beside
+    # another's trellis kernels (issue-shaped), as in the mix
+    D = max(1, min(args.depth5, steps))
+    plans = [plan] + [T.Plan(eng, n, 1) for _ in range(D - 1)]
+    recs = [d_rec] + [torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D - 1)]
+    strm = [torch.cuda.Stream() for _ in range(D)]
+    for p_ in plans[1:]:
+        p_.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types)
+    if D > 1 and not args.side_stream:
+        for p_ in plans:
+            p_.set_side_stream(False)
+
+    def passes(count):
+        for k in range(count):
+            j = k % D
+            plans[j].execute(d_stream.data_ptr(), recs[j].data_ptr(), strm[j].cuda_stream if D > 1 else stream)
+    passes(max(warmup, D))
+    sync_all()
+    t0 = time.perf_counter()
+    passes(steps)
+    sync_all()
+    el = time.perf_counter() - t0
+    for j in range(1, D):
+        assert torch.equal(recs[j], d_rec), "passes in flight gave different records"
+    for p_ in plans[1:]:
+        p_.close()
+    del recs[1:]
+    plan.set_side_stream(True)
+    # the same passes one at a time (rounds 1-4's form: one plan, k_vit<432> on its side stream beside k_vit<216>)
+    for k in range(3):
         plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), stream)
     sync_all()
     t0 = time.perf_counter()
     for k in range(steps):
         plan.execute(d_stream.data_ptr(), d_rec.data_ptr(), stream)
     sync_all()
-    el = time.perf_counter() - t0
+    el_serial = time.perf_counter() - t0
 
     # per-stage durations: the same K steps once more with one HIP event between stages on the launch stream
     for k in range(steps):
@@ -1217,6 +1279,8 @@ def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_
         "config": {"workload": "BASELINE config 2: per GPU %d NDB bursts (50%% NORM_1 SCH/F, 50%% NORM_2 2xNDB, + AACH), "
                                "scramb_init=0, BER %g, aligned 510-B slots resident in HBM, no sync front end, records left in HBM" % (n, args.ber),
                    "bursts_per_gpu": n, "parallelism": "independent channels per GPU, no collective in decoding"},
+        "passes_in_flight": D,
+        "one_pass_at_a_time": {"ms_per_step": el_serial / steps * 1e3, "value": world * n * steps / el_serial},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
                      "kernel_ms": float(stage_ms[dom]),
@@ -1236,6 +1300,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--windows", type=int, default=6, help="mix: K-step windows inside the one continuous run (median reported)")
     ap.add_argument("--depth", type=int, default=8, help="mix: steps in flight per GPU (plans / streams)")
+    ap.add_argument("--depth5", type=int, default=4, help="config2 / config5: passes in flight (plans / streams)")
     ap.add_argument("--side-stream", action="store_true", help="mix: keep the plans' side streams in play (the round-3 form)")
     ap.add_argument("--walk-wide", action="store_true", help="mix: the device walk's per-channel launches as 1024 threads / 128 KB of LDS "
                                                              "(rounds 3 and 4) instead of 256 threads and LDS sized per launch")
@@ -1336,7 +1401,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_stream(stream)
             if not args.no_secondary:
                 c2 = bench_config2(args, T, torch, dist, rank, world, local, 40, 10, with_cpu=False)
-                out["config2"] = {k: c2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline")}
+                out["config2"] = {k: c2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "passes_in_flight", "one_pass_at_a_time",
+                                                      "config", "roofline")}
     # RCCL prints a version banner through C stdio when its first communicator comes up; on a pipe that text would be
     # flushed at exit, i.e. after the result line.  Push it out on every rank now, then let rank 0 print last.
     import ctypes
