@@ -463,7 +463,16 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         if rank == 0:
             single = measure(False, alone=True)
         sync_all()
+    if args.trace_dump:     # (a -DTG_TRACE build of the library: tools/trace_untraced.py)
+        import ctypes
+        ctypes.CDLL(None)
+        T.lib().tgk_trace_read(None, ctypes.byref(ctypes.c_uint(0)), 1)
     decode_only = measure(False)
+    if args.trace_dump:
+        nrec = ctypes.c_uint(0)
+        buf = np.zeros((1 << 20, 3), np.uint64)
+        T.lib().tgk_trace_read(buf.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nrec), 1)
+        np.save(args.trace_dump, buf[:nrec.value])
     # the round-3 form beside it: four batches in flight, each plan's side stream in play
     r3form = None
     if world == 1 and not args.no_secondary and not args.side_stream:
@@ -1300,6 +1309,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--windows", type=int, default=6, help="mix: K-step windows inside the one continuous run (median reported)")
     ap.add_argument("--depth", type=int, default=8, help="mix: steps in flight per GPU (plans / streams)")
+    ap.add_argument("--trace-dump", default=None, help="mix, with a -DTG_TRACE build of the library: the heavy kernels' workgroup "
+                                                       "time stamps of the decode-only run go to this .npy file")
     ap.add_argument("--depth5", type=int, default=4, help="config2 / config5: passes in flight (plans / streams)")
     ap.add_argument("--side-stream", action="store_true", help="mix: keep the plans' side streams in play (the round-3 form)")
     ap.add_argument("--walk-wide", action="store_true", help="mix: the device walk's per-channel launches as 1024 threads / 128 KB of LDS "

@@ -53,6 +53,36 @@ struct tg_const_tables {
 
 __constant__ __attribute__((aligned(16))) tg_const_tables c_tab;
 
+#ifdef TG_TRACE
+/* measurement build (tools/trace_untraced.py): the heavy kernels' workgroups leave (kind, first and last tick of the 100 MHz
+ * clock) in a device array -- what runs beside what in the pipelined bench WITHOUT a profiler slowing the launching thread */
+struct tg_trace_rec { uint32_t kind, block; unsigned long long t0, t1; };
+#define TG_TRACE_CAP (1u << 20)
+__device__ tg_trace_rec g_trace[TG_TRACE_CAP];
+__device__ unsigned int g_trace_n;
+extern "C" int tgk_trace_read(void *out, unsigned int *n, int reset)
+{
+	unsigned int cnt = 0;
+	int rc = (int)hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_trace_n), sizeof(cnt));
+	if (!rc && out)
+		rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)(cnt < TG_TRACE_CAP ? cnt : TG_TRACE_CAP) * sizeof(tg_trace_rec));
+	if (n)
+		*n = cnt < TG_TRACE_CAP ? cnt : TG_TRACE_CAP;
+	const unsigned int z = 0;
+	if (!rc && reset)
+		rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &z, sizeof(z));
+	return rc;
+}
+#define TG_TRACE_BEGIN const unsigned long long tr_t0_ = wall_clock64()
+#define TG_TRACE_END(KIND_, EVERY_) do { if (threadIdx.x == 0 && (blockIdx.x % (EVERY_)) == 0) {			\
+		const unsigned int i_ = atomicAdd(&g_trace_n, 1u);							\
+		if (i_ < TG_TRACE_CAP) { g_trace[i_].kind = (KIND_); g_trace[i_].block = blockIdx.x; g_trace[i_].t0 = tr_t0_;	\
+					 g_trace[i_].t1 = wall_clock64(); } } } while (0)
+#else
+#define TG_TRACE_BEGIN do { } while (0)
+#define TG_TRACE_END(KIND_, EVERY_) do { } while (0)
+#endif
+
 /* clean-block fast path (k_clean): [0..4095] 12 received bits of an 8-step block -> g1 bits | g2 bits << 8;
  * [4096..8191] (state << 8 | g1 bits) -> input bits | expected g2 bits << 8 | next state << 12 */
 __device__ uint16_t g_clean_lut[8192];
@@ -896,24 +926,28 @@ extern "C" int tgk_front_stream_stamps(unsigned long long *out, int reset)
 #else
 #define TGS_MARK(i) do { } while (0)
 #endif
+#ifndef TG_STREAM_WPB
+#define TG_STREAM_WPB 4	/* waves per workgroup (they share nothing: each has its own staging areas) */
+#endif
 template <bool PACKED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TG_STREAM_WPE, TG_STREAM_WPE)))
+__global__ __launch_bounds__(64 * TG_STREAM_WPB) __attribute__((amdgpu_waves_per_eu(TG_STREAM_WPE, TG_STREAM_WPE)))
 void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
 		    uint32_t *__restrict__ defer)
 {
 	constexpr uint64_t PY = tsq_bits(TSQ_Y), PN = tsq_bits(TSQ_N), PP = tsq_bits(TSQ_P);
-	__shared__ __attribute__((aligned(16))) uint32_t s_bits[4][72];	/* per wave: the group's bit string (68 dwords used; packed ingest: 72, 16 bytes per lane) */
-	__shared__ uint32_t s_win[4][4 * TG_VER_SLOT];	/* per wave: four slots x eight shifted copies of the 512-bit window */
-	__shared__ uint32_t s_out[4][160];	/* per wave: four packed slots on their way out, then their cls / ysum words (+ the idle lanes' dump) */
+	__shared__ __attribute__((aligned(16))) uint32_t s_bits[TG_STREAM_WPB][72];	/* per wave: the group's bit string (68 dwords used; packed ingest: 72, 16 bytes per lane) */
+	__shared__ uint32_t s_win[TG_STREAM_WPB][4 * TG_VER_SLOT];	/* per wave: four slots x eight shifted copies of the 512-bit window */
+	__shared__ uint32_t s_out[TG_STREAM_WPB][160];	/* per wave: four packed slots on their way out, then their cls / ysum words (+ the idle lanes' dump) */
 
 #ifdef TGS_TIMING
 	unsigned long long tgs_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tgs_last = __builtin_amdgcn_s_memtime();
 #endif
+	TG_TRACE_BEGIN;
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t wave = blockIdx.x * 4 + wib;
-	const uint32_t nwaves = gridDim.x * 4;
+	const uint32_t wave = blockIdx.x * TG_STREAM_WPB + wib;
+	const uint32_t nwaves = gridDim.x * TG_STREAM_WPB;
 	const uint32_t col = lane & 15;			/* 32-position column of the lane's slot */
 	uint32_t *bits = s_bits[wib];
 	uint32_t *win = s_win[wib];
@@ -1216,6 +1250,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			break;
 		g = gA;
 	}
+	TG_TRACE_END(0u, 4u / TG_STREAM_WPB);
 #ifdef TGS_TIMING
 	if (lane == 0)
 		for (int i = 0; i < 8; i++)
@@ -1859,6 +1894,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code, uint8_t *__restrict__ wire,
 	   const uint32_t *__restrict__ softarea, int kflags, const uint32_t *__restrict__ nitems_dev)
 {
+	TG_TRACE_BEGIN;
 	constexpr int NBLK = vit_cfg<KIND>::NBLK;
 	constexpr int NW = NBLK / 2;			/* code words */
 	if (nitems_dev) {	/* after k_clean: the list of blocks that still need the trellis was counted on the device */
@@ -2097,6 +2133,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	__syncthreads();	/* s_crc visible (single wave, but keep the compiler honest) */
 	vit_finish<KIND, HMODE>(od, s_crc, valid, slot, which, idx, midx, packed, masks, rec, sb_ok, sb_code, wire, softarea, kflags,
 				(KIND == TG_KIND_432) ? s_stage : nullptr);
+	TG_TRACE_END(1u + (uint32_t)KIND, 8u);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -3176,10 +3213,11 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 		HIPCHK(hipEventRecord((hipEvent_t)tl_front_ev_start, s));
 		tl_front_ev_start = nullptr;
 	}
+	const dim3 fgrid(blocks * (4 / TG_STREAM_WPB)), fblock(64 * TG_STREAM_WPB);
 	if (packed_input)
-		hipLaunchKernelGGL(k_front_stream<true>, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
+		hipLaunchKernelGGL(k_front_stream<true>, fgrid, fblock, 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
 	else
-		hipLaunchKernelGGL(k_front_stream<false>, dim3(blocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
+		hipLaunchKernelGGL(k_front_stream<false>, fgrid, fblock, 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
 	if (ev_mid)
 		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
 	uint32_t fblocks = (nslots / 128 + 3) / 4 + 1;	/* about a wave per deferred slot at 1 % of them */
