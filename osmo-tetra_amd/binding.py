@@ -243,7 +243,7 @@ def lib():
     return L
 
 
-OPT_BURST_MAX, OPT_STREAM_EXACT, OPT_WALK_HOST, OPT_WALK_MONO, OPT_FRONT_BLOCKS, OPT_WALK_WIDE = range(1, 7)
+OPT_BURST_MAX, OPT_STREAM_EXACT, OPT_WALK_HOST, OPT_WALK_MONO, OPT_FRONT_BLOCKS, OPT_WALK_WIDE, OPT_RING = range(1, 8)
 
 
 def set_option(opt, value):

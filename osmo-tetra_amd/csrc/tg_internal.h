@@ -109,6 +109,33 @@ int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan, const stru
 	     uint32_t wcap, uint32_t ncap /* the split form's LDS arrays hold channels of this many bitmap words / nodes (0: the full caps) */,
 	     uint32_t rec_stride /* node records per channel in d_recs, the head's record last: min(TGW_NCAP, the plan's slots) + 1 */,
 	     int wide /* 1: the split form's per-channel launches as 1024 threads with 128 KB of LDS (rounds 3 and 4) */, void *stream);
+/* k_burst_ring (TGPU_OPT_RING): the request line in mapped host memory and the workgroups' box in device memory.  The two
+ * begin alike on purpose: dwords 1 .. 11 of the line are copied to the box as they are. */
+#define TG_RING_MAX  4u			/* bursts per request = workgroups that stay */
+#define TG_RING_STOP 0xffffffffu
+struct tg_ring_msg {
+	uint32_t req;			/* request number (written last); TG_RING_STOP: leave */
+	uint32_t n, have_sync, code;	/* slots, "a SYNC slot among them", the channel's carry-in scrambling code */
+	uint64_t desc[TG_RING_MAX];	/* slot descriptors (offset | type << 56) */
+	uint32_t pad[3];
+	uint32_t req2;			/* = req, in the line's other half (written before that half's fields ... see k_burst_ring) */
+	/* device -> host */
+	uint32_t served;		/* last request the workgroups have finished */
+	uint32_t alive;			/* the host sets it in front of a launch, workgroup 0 clears it when it leaves */
+	uint32_t pad2[14];
+};
+struct tg_ring_box {
+	uint32_t seq;			/* the request the workgroups are to work on (workgroup 0 writes it last) */
+	uint32_t n, have_sync, code;
+	uint64_t desc[TG_RING_MAX];
+	uint32_t chan[TG_RING_MAX];	/* zeros: one channel */
+	uint32_t bar;			/* barrier counter, only grows */
+	uint32_t stop;			/* = the launch's number when workgroup 0 has decided to leave */
+	uint32_t pad[2];
+};
+int tgk_burst_ring(struct tg_ring_msg *d_ring, struct tg_ring_box *d_box, const uint8_t *d_stream, uint32_t nwg, uint32_t *d_sb_ok,
+		   uint32_t *d_sb_code, uint8_t *d_rec, uint32_t *d_maskidx, uint32_t *d_masks, uint32_t start_seq,
+		   uint32_t launch_no, unsigned long long idle_ticks, void *stream);
 /* the node cap a plan asks for (tg_host.c: twice what its batches have shown so far) */
 uint32_t tgpi_plan_walk_ncap(const struct tgpu_plan *p);
 void tgpi_plan_walk_seen(struct tgpu_plan *p, uint32_t nnodes);
@@ -208,6 +235,7 @@ int tgpi_engine_bind(const struct tgpu_engine *eng);
 void tgpi_plan_grid_plain(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_plain, uint32_t **h_plain);
 int tgk_cls_plain(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, void *stream);
 int tgpi_plan_last_burst(const struct tgpu_plan *p);
+int tgpi_plan_ring(struct tgpu_plan *p, uint32_t **sb_ok, uint32_t **sb_code, uint32_t **maskidx, uint32_t **masks, int note_run);
 void tgpi_plan_set_marks(struct tgpu_plan *p, int on);	/* the caller polls completion marks in mapped records (tg_sync.c) */	/* the last execute wrote completion marks (k_burst) */
 
 /* plan internals used by the stream synchroniser (tg_stream.c) */

@@ -2195,12 +2195,13 @@ extern "C" int tgk_burst_stamps(unsigned long long *out)
 #define TGB_STAMP(k) do { } while (0)
 #endif
 
-template <bool SB1_PASS>
-__global__ __launch_bounds__(256)
-void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_desc, const uint32_t *__restrict__ slot_chan,
-	     const uint32_t *__restrict__ chan_code, uint32_t nslots, uint32_t nchan, uint32_t *__restrict__ sb_ok,
-	     uint32_t *__restrict__ sb_code, uint8_t *__restrict__ rec, uint32_t *__restrict__ maskidx, uint32_t *__restrict__ masks,
-	     int marks)
+/* the body: slot i of the batch by the calling workgroup (256 threads).  SB1_PASS is a constant at k_burst's two call sites;
+ * the ring kernel below calls it with both values in turn (one copy of the LDS areas: the function's own) */
+__device__ __forceinline__
+void burst_body(const bool SB1_PASS, const uint32_t i, const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_desc,
+		const uint32_t *__restrict__ slot_chan, const uint32_t *__restrict__ chan_code, uint32_t nslots, uint32_t nchan,
+		uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_code, uint8_t *__restrict__ rec, uint32_t *__restrict__ maskidx,
+		uint32_t *__restrict__ masks, int marks)
 {
 	__shared__ uint32_t s_slot32[128];
 	/* the descriptors and channels of this slot and the 255 before it, the channels' carry-in codes: small batches keep
@@ -2212,7 +2213,7 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	__shared__ uint8_t s_od[2][40];			/* decoded bytes (8 bits per trellis block) */
 	__shared__ uint32_t s_code, s_nonbin;
 	uint8_t *s_slot = (uint8_t *)s_slot32;
-	const uint32_t i = blockIdx.x, tid = threadIdx.x;
+	const uint32_t tid = threadIdx.x;
 	const uint32_t back = i < 255u ? i : 255u;
 	TGB_STAMP(0);
 	if (tid <= back) {
@@ -2542,6 +2543,144 @@ void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ sl
 	if (tid == 0)
 		*(volatile uint8_t *)(r + TG_REC_TYPE) = (uint8_t)type;
 	TGB_STAMP(8);
+}
+
+template <bool SB1_PASS>
+__global__ __launch_bounds__(256)
+void k_burst(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_desc, const uint32_t *__restrict__ slot_chan,
+	     const uint32_t *__restrict__ chan_code, uint32_t nslots, uint32_t nchan, uint32_t *__restrict__ sb_ok,
+	     uint32_t *__restrict__ sb_code, uint8_t *__restrict__ rec, uint32_t *__restrict__ maskidx, uint32_t *__restrict__ masks,
+	     int marks)
+{
+	burst_body(SB1_PASS, blockIdx.x, stream, slot_desc, slot_chan, chan_code, nslots, nchan, sb_ok, sb_code, rec, maskidx, masks, marks);
+}
+
+/*
+ * k_burst_ring: the same decode by workgroups that STAY (TGPU_OPT_RING; the channel API's flushes of up to TG_RING_MAX
+ * bursts).  A flush through k_burst is a kernel launch (7.5 us from the host's call to the first instruction's result back
+ * on the host, tools/ubench/persist_rtt.hip) and two dependent reads over PCIe (descriptors, then the slot); a kernel that is
+ * already running sees a request in mapped host memory after one PCIe read and answers in 2.9 us.
+ *   - the request = one cache line the host fills (struct tg_ring_msg: descriptors, carry-in code, count) and numbers last;
+ *     workgroup 0 polls it, takes the line in one 16-lane load (the number stands in both 32-byte halves: a half that shows
+ *     the new number shows its new fields), hands it to the other workgroups through a box in device memory and all decode
+ *     slot blockIdx.x: pass 1 (SB1 of SYNC slots), a barrier across the workgroups when more than one slot may need the
+ *     result, pass 2; records and completion marks as k_burst writes them (the host polls the marks);
+ *   - the workgroups leave on the host's stop request or when no request has come for idle_ticks of the 100 MHz clock
+ *     (workgroup 0 decides and tells the others through the box; it clears `alive` last): a channel that falls silent frees
+ *     its compute units, and the next flush starts the kernel again -- from `served`, so a request that was posted while the
+ *     workgroups were leaving is not lost.
+ */
+__device__ __forceinline__ void ring_barrier(uint32_t *bar, uint32_t &epoch, uint32_t G)
+{
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		epoch++;
+		__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch * G)
+			__builtin_amdgcn_s_sleep(1);
+	}
+	__syncthreads();
+}
+
+__global__ __launch_bounds__(256)
+void k_burst_ring(tg_ring_msg *ring, tg_ring_box *box, const uint8_t *__restrict__ stream, uint32_t *__restrict__ sb_ok,
+		  uint32_t *__restrict__ sb_code, uint8_t *__restrict__ rec, uint32_t *__restrict__ maskidx,
+		  uint32_t *__restrict__ masks, uint32_t start_seq, uint32_t launch_no, unsigned long long idle_ticks)
+{
+	__shared__ uint32_t s_cmd[4];
+	const uint32_t tid = threadIdx.x, w = blockIdx.x, G = gridDim.x;
+	uint32_t last = start_seq, epoch = box->bar / G;	/* (the counter only grows: a new launch goes on where the last one stopped) */
+	for (;;) {
+		if (tid < 64) {
+			uint32_t r = last, n = 0, hs = 0;
+			if (w == 0) {
+				const unsigned long long t0 = wall_clock64();
+				for (;;) {
+					/* the request line: lane l takes dword l */
+					const uint32_t v = tid < 16 ? __hip_atomic_load((uint32_t *)ring + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+					const uint32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 15);
+					if (r0 == r1 && r0 != last) {
+						r = r0;
+						n = __builtin_amdgcn_readlane(v, 1);
+						hs = __builtin_amdgcn_readlane(v, 2);
+						if (r != TG_RING_STOP) {
+							if (tid >= 3 && tid < 12)	/* code, four descriptors */
+								((uint32_t *)box)[tid] = v;
+							if (tid == 1 || tid == 2)
+								((uint32_t *)box)[tid] = v;
+						}
+						break;
+					}
+					if (wall_clock64() - t0 > idle_ticks) {
+						r = TG_RING_STOP;
+						break;
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				if (tid == 0) {		/* (leaving is told in a word of its own: the next launch must not find a stale "stop" in seq) */
+					if (r == TG_RING_STOP)
+						__hip_atomic_store(&box->stop, launch_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					else
+						__hip_atomic_store(&box->seq, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			} else {
+				if (tid == 0)
+					for (;;) {
+						r = __hip_atomic_load(&box->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+						if (r != last)
+							break;
+						if (__hip_atomic_load(&box->stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == launch_no) {
+							r = TG_RING_STOP;
+							break;
+						}
+						__builtin_amdgcn_s_sleep(2);
+					}
+				r = __builtin_amdgcn_readfirstlane(r);
+				n = box->n;
+				hs = box->have_sync;
+			}
+			if (tid == 0) {
+				s_cmd[0] = r;
+				s_cmd[1] = n;
+				s_cmd[2] = hs;
+			}
+		}
+		__syncthreads();
+		const uint32_t r = s_cmd[0], n = s_cmd[1], hs = s_cmd[2];
+		if (r == TG_RING_STOP)
+			break;
+		/* (what the host and workgroup 0 wrote is read past this compute unit's vector cache) */
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+		if (hs) {
+			if (w < n)
+				burst_body(true, w, stream, box->desc, box->chan, &box->code, n, 1u, sb_ok, sb_code, rec, maskidx, masks, 0);
+			if (n > 1) {
+				__threadfence();
+				ring_barrier(&box->bar, epoch, G);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			} else
+				__syncthreads();
+		}
+		if (w < n)
+			burst_body(false, w, stream, box->desc, box->chan, &box->code, n, 1u, sb_ok, sb_code, rec, maskidx, masks, 1);
+		__syncthreads();
+		last = r;
+		if (w == 0 && tid == 0)
+			__hip_atomic_store(&ring->served, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	if (w == 0 && tid == 0)
+		__hip_atomic_store(&ring->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int tgk_burst_ring(struct tg_ring_msg *d_ring, struct tg_ring_box *d_box, const uint8_t *d_stream, uint32_t nwg,
+			      uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_rec, uint32_t *d_maskidx, uint32_t *d_masks,
+			      uint32_t start_seq, uint32_t launch_no, unsigned long long idle_ticks, void *stream)
+{
+	if (!nwg || nwg > TG_RING_MAX || !launch_no)
+		return -1;
+	hipLaunchKernelGGL(k_burst_ring, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d_ring, d_box, d_stream, d_sb_ok, d_sb_code, d_rec,
+			   d_maskidx, d_masks, start_seq, launch_no, idle_ticks);
+	return (int)hipGetLastError();
 }
 
 /* one bit per grid slot: the classification word alone says "delivered" (a training sequence of the right type at its

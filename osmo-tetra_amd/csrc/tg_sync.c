@@ -161,6 +161,13 @@ struct tgpu_channel {
 	int last_error;
 	int zero_copy;		/* h_slots / h_rec are mapped: d_slots / d_rec alias them */
 
+	/* TGPU_OPT_RING: flushes go to workgroups that stay (k_burst_ring) */
+	int ring;			/* 1: in use; 0: not asked for, or given up after a failure */
+	struct tg_ring_msg *h_ring, *d_ring;	/* mapped host memory: the request line and the kernel's two words back */
+	struct tg_ring_box *d_box;
+	hipStream_t rstream;		/* the kernel's own stream */
+	uint32_t ring_seq, ring_launches;
+
 	/* block queue of the tp_sap_udata_ind() seam (allocated on first use) */
 	struct tgpu_plan *bplan;
 	uint32_t bq_cap, bq_n;
@@ -184,6 +191,94 @@ struct bq_item {
 	uint32_t burst_seq;
 	struct tetra_tdma_time time;	/* t_phy_state.time when the block was handed over (tetra_lower_mac.c:167) */
 };
+
+/* ---- TGPU_OPT_RING: the decoder workgroups that stay (k_burst_ring; protocol in tg_kernels.hip) ---- */
+#define RING_IDLE_TICKS 2000000ull	/* 20 ms of the device's 100 MHz clock without a request: the workgroups leave */
+
+static void ring_post(struct tg_ring_msg *m, uint32_t seq, uint32_t n, uint32_t have_sync, uint32_t code, const uint64_t *desc)
+{
+	/* either half of the line carries the request number behind its own fields (k_burst_ring takes the line in one load and
+	 * believes a half whose number is new) */
+	volatile struct tg_ring_msg *v = m;
+	v->desc[2] = n > 2 ? desc[2] : 0;
+	v->desc[3] = n > 3 ? desc[3] : 0;
+	__atomic_store_n(&m->req2, seq, __ATOMIC_RELEASE);
+	v->n = n;
+	v->have_sync = have_sync;
+	v->code = code;
+	v->desc[0] = desc[0];
+	v->desc[1] = n > 1 ? desc[1] : 0;
+	__atomic_store_n(&m->req, seq, __ATOMIC_RELEASE);
+}
+
+static int ring_start(struct tgpu_channel *ch)
+{
+	uint32_t *sb_ok, *sb_code, *maskidx, *masks;
+	int rc = tgpi_plan_ring(ch->plan, &sb_ok, &sb_code, &maskidx, &masks, 0);
+	if (rc)
+		return rc;
+	__atomic_store_n(&ch->h_ring->alive, 1u, __ATOMIC_RELEASE);
+	rc = tgk_burst_ring(ch->d_ring, ch->d_box, ch->d_slots, ch->batch_slots, sb_ok, sb_code, ch->d_rec, maskidx, masks,
+			    __atomic_load_n(&ch->h_ring->served, __ATOMIC_ACQUIRE), ++ch->ring_launches, RING_IDLE_TICKS, ch->rstream);
+	if (rc)
+		__atomic_store_n(&ch->h_ring->alive, 0u, __ATOMIC_RELEASE);
+	return rc;
+}
+
+/* make the workgroups leave and wait until they have (at most one poll of theirs away) */
+static void ring_stop(struct tgpu_channel *ch)
+{
+	if (!ch->h_ring || !ch->rstream)
+		return;
+	if (__atomic_load_n(&ch->h_ring->alive, __ATOMIC_ACQUIRE)) {
+		static const uint64_t none[TG_RING_MAX] = { 0 };
+		ring_post(ch->h_ring, TG_RING_STOP, 0, 0, 0, none);
+	}
+	(void)hipStreamSynchronize(ch->rstream);
+	ch->ring = 0;
+}
+
+/* one flush through the ring: 1 = every record complete; 0 = given up (the caller decodes the batch the ordinary way) */
+static int ring_flush(struct tgpu_channel *ch, uint32_t n)
+{
+	uint32_t *a, *b, *c, *d;
+	if (tgpi_plan_ring(ch->plan, &a, &b, &c, &d, 1))
+		return 0;
+	uint64_t desc[TG_RING_MAX] = { 0 };
+	uint32_t hs = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		desc[i] = ch->h_off[i] | ((uint64_t)ch->h_type[i] << 56);
+		hs |= ch->h_type[i] == TETRA_TRAIN_SYNC;
+	}
+	if (++ch->ring_seq == TG_RING_STOP || !ch->ring_seq)
+		ch->ring_seq = 1;
+	ring_post(ch->h_ring, ch->ring_seq, n, hs, ch->scramb_init, desc);
+	int starts = 0;
+	struct timespec t0, t;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (uint32_t i = 0; i < n; i++) {
+		const volatile uint8_t *mark = ch->h_rec + (size_t)i * TGPU_REC_BYTES + TG_REC_TYPE;
+		for (unsigned spins = 0; *mark == TG_REC_PENDING; spins++) {
+			if ((spins & 255) == 0 && !__atomic_load_n(&ch->h_ring->alive, __ATOMIC_ACQUIRE) &&
+			    __atomic_load_n(&ch->h_ring->served, __ATOMIC_ACQUIRE) != ch->ring_seq) {
+				/* nobody there (the first flush, or the workgroups left while idle): start them; they begin behind
+				 * `served`, i.e. with this request */
+				if (starts++ == 3 || ring_start(ch))
+					return 0;
+			}
+			if ((spins & 1023) == 1023) {
+				clock_gettime(CLOCK_MONOTONIC, &t);
+				if ((t.tv_sec - t0.tv_sec) * 1000000000L + (t.tv_nsec - t0.tv_nsec) > 20000000L)
+					return 0;
+			}
+#if defined(__x86_64__) || defined(__i386__)
+			__builtin_ia32_pause();
+#endif
+		}
+	}
+	__atomic_thread_fence(__ATOMIC_ACQUIRE);
+	return 1;
+}
 
 int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unitdata_cb cb, tgpu_event_cb ev,
 			void *priv, struct tgpu_channel **out)
@@ -229,6 +324,17 @@ int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unit
 		if (e == hipSuccess) e = hipMalloc((void **)&ch->d_rec, n * TGPU_REC_BYTES);
 	}
 	if (e == hipSuccess) e = hipStreamCreate(&ch->stream);
+	if (e == hipSuccess && ch->zero_copy && batch_slots <= TG_RING_MAX && tgi_option(TGPU_OPT_RING)) {
+		e = hipHostMalloc((void **)&ch->h_ring, sizeof(*ch->h_ring), hipHostMallocMapped);
+		if (e == hipSuccess) {
+			memset(ch->h_ring, 0, sizeof(*ch->h_ring));
+			e = hipHostGetDevicePointer((void **)&ch->d_ring, ch->h_ring, 0);
+		}
+		if (e == hipSuccess) e = hipMalloc((void **)&ch->d_box, sizeof(*ch->d_box));
+		if (e == hipSuccess) e = hipMemset(ch->d_box, 0, sizeof(*ch->d_box));
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&ch->rstream, hipStreamNonBlocking);
+		ch->ring = e == hipSuccess;
+	}
 	if (e != hipSuccess || !ch->pend || !ch->h_off || !ch->h_type || !ch->h_chan) {
 		tgpu_channel_destroy(ch);
 		return e != hipSuccess ? (int)e : TGPU_ENOMEM;
@@ -243,6 +349,10 @@ void tgpu_channel_destroy(struct tgpu_channel *ch)
 {
 	if (!ch)
 		return;
+	ring_stop(ch);
+	if (ch->rstream) (void)hipStreamDestroy(ch->rstream);
+	if (ch->d_box) (void)hipFree(ch->d_box);
+	if (ch->h_ring) (void)hipHostFree(ch->h_ring);
 	if (ch->stream) (void)hipStreamDestroy(ch->stream);
 	if (ch->h_slots) (void)hipHostFree(ch->h_slots);
 	if (ch->h_rec) (void)hipHostFree(ch->h_rec);
@@ -490,12 +600,21 @@ static int flush_slots(struct tgpu_channel *ch)
 	if (!rc && ch->zero_copy)		/* completion marks: see wait_records() */
 		for (uint32_t i = 0; i < n; i++)
 			ch->h_rec[(size_t)i * TGPU_REC_BYTES + TG_REC_TYPE] = TG_REC_PENDING;
-	if (!rc)
+	int ringed = 0;
+	if (!rc && ch->ring && n <= TG_RING_MAX) {
+		ringed = ring_flush(ch, n);
+		if (!ringed) {		/* the ring has failed: without it from now on, this batch included */
+			ring_stop(ch);
+			for (uint32_t i = 0; i < n; i++)
+				ch->h_rec[(size_t)i * TGPU_REC_BYTES + TG_REC_TYPE] = TG_REC_PENDING;
+		}
+	}
+	if (!rc && !ringed)
 		rc = tgpu_plan_execute(ch->plan, ch->d_slots, ch->d_rec, ch->stream);
 	if (!rc && !ch->zero_copy &&
 	    (e = hipMemcpyAsync(ch->h_rec, ch->d_rec, (size_t)n * TGPU_REC_BYTES, hipMemcpyDeviceToHost, ch->stream)))
 		rc = (int)e;
-	if (!rc && !(ch->zero_copy && tgpi_plan_last_burst(ch->plan) && wait_records(ch, n)) &&
+	if (!rc && !ringed && !(ch->zero_copy && tgpi_plan_last_burst(ch->plan) && wait_records(ch, n)) &&
 	    (e = hipStreamSynchronize(ch->stream)))
 		rc = (int)e;
 	ch->n_pending = 0;

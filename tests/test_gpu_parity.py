@@ -277,6 +277,49 @@ def test_channel_stream_parity(T, eng, batch, ber):
     ch.close()
 
 
+@pytest.mark.parametrize("batch", [1, 3, 4])
+@pytest.mark.parametrize("ber", [0.0, 0.03])
+def test_channel_through_workgroups_that_stay(T, eng, batch, ber, topt):
+    """TGPU_OPT_RING: flushes of up to four bursts go to k_burst_ring -- workgroups that poll a request line in mapped host
+    memory instead of being launched per flush.  Same records and events as the oracle's receiver; a pause longer than the
+    workgroups' idle time in the middle of the stream (they leave, the next flush brings them back), a loss of lock, an ignored
+    burst type through the tetra_burst_rx_cb() seam, two channels at once, and a channel that is closed while its
+    workgroups are still polling"""
+    import time
+    topt("RING", 1)
+    stream, _ = synth.frame_stream(seed=31, nframes=7, ber=ber)
+    s = stream.copy()
+    s[100 + 510 + 510 * 9 + 244 + 5] ^= 1
+    want, wev = O.run_rx(s)
+    ch = T.Channel(eng, batch_slots=batch)
+    other = T.Channel(eng, batch_slots=2)
+    half = (len(s) // 2) & ~63
+    ch.feed(s[:half])
+    other.feed(s[:half])
+    time.sleep(0.06)
+    ch.feed(s[half:])
+    other.feed(s[half:])
+    ch.flush()
+    other.flush()
+    assert_same_records(ch.records, want)
+    assert ch.events == wev
+    assert_same_records(other.records, want)
+    res = T.sync_walk(s)
+    ch2 = T.Channel(eng, batch_slots=batch)
+    sl = res["slots"]
+    for i, (off, typ, seq, tn) in enumerate(sl):
+        ch2.burst_rx(s[off:off + 510], 2 if i == 3 else typ, tn)      # (2: TETRA_TRAIN_NORM_3, ignored)
+    ch2.flush()
+    assert_same_records(ch2.records, [r for r in want if r["burst_seq"] != sl[3][2]])
+    topt("RING", 0)
+    plain = T.Channel(eng, batch_slots=batch)
+    plain.feed(s)
+    plain.flush()
+    assert_same_records(plain.records, want)
+    for c in (ch, other, ch2, plain):
+        c.close()
+
+
 def test_channel_relock_and_spurious_training_sequence(T, eng):
     stream, slots = synth.frame_stream(seed=22, nframes=5)
     s = stream.copy()

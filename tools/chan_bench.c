@@ -11,12 +11,21 @@
 #include "tetra_gpu.h"
 
 static unsigned long nblocks, ncrc;
+static unsigned long long digest;	/* FNV-1a over what every block delivers: equal runs deliver equal blocks */
 static int on_block(const struct tgpu_unitdata *ud, unsigned int offset, void *priv)
 {
 	(void)priv;
 	if (offset == 0 || offset == 0xffffffffu) {
 		nblocks++;
 		ncrc += ud->crc_ok != 0;
+		unsigned long long h = digest ? digest : 1469598103934665603ull;
+#define MIX(v) do { h ^= (unsigned long long)(v); h *= 1099511628211ull; } while (0)
+		MIX(ud->type); MIX(ud->blk_num); MIX(ud->crc_ok); MIX(ud->crc); MIX(ud->scrambling_code); MIX(ud->burst_seq);
+		MIX(ud->tdma_time.tn); MIX(ud->tdma_time.fn); MIX(ud->tdma_time.mn);
+		for (unsigned i = 0; ud->type1 && i < ud->type1_len; i++)
+			MIX(ud->type1[i]);
+#undef MIX
+		digest = h;
 	}
 	return -1;
 }
@@ -49,9 +58,14 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	unsigned batches[32] = { 1, 64, 1024, 16384 }, nb = 4;
-	if (argc > 2) {		/* chan_bench N b1 b2 ...: the batch sizes to try */
+	int a0 = 2;
+	if (argc > 2 && !strcmp(argv[2], "ring")) {	/* chan_bench N ring b1 ...: flushes of up to 4 bursts through workgroups that stay */
+		tgpu_engine_set_option(eng, TGPU_OPT_RING, 1);
+		a0 = 3;
+	}
+	if (argc > a0) {		/* chan_bench N [ring] b1 b2 ...: the batch sizes to try */
 		nb = 0;
-		for (int a = 2; a < argc && nb < 32; a++)
+		for (int a = a0; a < argc && nb < 32; a++)
 			batches[nb++] = (unsigned)atoi(argv[a]);
 	}
 	for (unsigned b = 0; b < nb; b++) {
@@ -62,14 +76,15 @@ int main(int argc, char **argv)
 			return 1;
 		trs.burst_cb_priv = ch;
 		nblocks = ncrc = 0;
+		digest = 0;
 		const size_t use = batches[b] < 16 ? len / 8 : len;	/* near-synchronous modes are slow: shorter sample */
 		const double t0 = now();
 		for (size_t o = 0; o < use; o += 64)
 			tetra_burst_sync_in(&trs, stream + o, (unsigned)(use - o < 64 ? use - o : 64));
 		tgpu_channel_flush(ch);
 		const double el = now() - t0;
-		printf("batch %5u: %8.0f bursts/s end to end (%.2f s, %lu blocks delivered, %lu CRC ok)\n", batches[b],
-		       (double)(use / 510) / el, el, nblocks, ncrc);
+		printf("batch %5u: %8.0f bursts/s end to end (%.2f s, %lu blocks delivered, %lu CRC ok, digest %016llx)\n", batches[b],
+		       (double)(use / 510) / el, el, nblocks, ncrc, digest);
 		tgpu_channel_destroy(ch);
 	}
 	tgpu_engine_destroy(eng);
