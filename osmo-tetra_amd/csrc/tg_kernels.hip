@@ -2616,6 +2616,7 @@ void k_burst_ring(tg_ring_msg *ring, tg_ring_box *box, const uint8_t *__restrict
 						break;
 					}
 				}
+				TGB_STAMP(9);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 				if (tid == 0) {		/* (leaving is told in a word of its own: the next launch must not find a stale "stop" in seq) */
 					if (r == TG_RING_STOP)

@@ -167,6 +167,7 @@ struct tgpu_channel {
 	struct tg_ring_box *d_box;
 	hipStream_t rstream;		/* the kernel's own stream */
 	uint32_t ring_seq, ring_launches;
+	int ring_counted;		/* this channel is one of RING_MAX_CHANNELS */
 
 	/* block queue of the tp_sap_udata_ind() seam (allocated on first use) */
 	struct tgpu_plan *bplan;
@@ -194,6 +195,9 @@ struct bq_item {
 
 /* ---- TGPU_OPT_RING: the decoder workgroups that stay (k_burst_ring; protocol in tg_kernels.hip) ---- */
 #define RING_IDLE_TICKS 2000000ull	/* 20 ms of the device's 100 MHz clock without a request: the workgroups leave */
+#define RING_MAX_CHANNELS 32		/* channels of a process that may hold workgroups at a time (each up to four, 43 KB of LDS
+					 * apiece, for as long as its flushes keep coming): the others flush by launch */
+static int ring_channels;
 
 static void ring_post(struct tg_ring_msg *m, uint32_t seq, uint32_t n, uint32_t have_sync, uint32_t code, const uint64_t *desc)
 {
@@ -324,7 +328,11 @@ int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unit
 		if (e == hipSuccess) e = hipMalloc((void **)&ch->d_rec, n * TGPU_REC_BYTES);
 	}
 	if (e == hipSuccess) e = hipStreamCreate(&ch->stream);
-	if (e == hipSuccess && ch->zero_copy && batch_slots <= TG_RING_MAX && tgi_option(TGPU_OPT_RING)) {
+	if (e == hipSuccess && ch->zero_copy && batch_slots <= TG_RING_MAX && tgi_option(TGPU_OPT_RING) &&
+	    __atomic_add_fetch(&ring_channels, 1, __ATOMIC_RELAXED) > RING_MAX_CHANNELS)
+		__atomic_sub_fetch(&ring_channels, 1, __ATOMIC_RELAXED);
+	else if (e == hipSuccess && ch->zero_copy && batch_slots <= TG_RING_MAX && tgi_option(TGPU_OPT_RING)) {
+		ch->ring_counted = 1;
 		e = hipHostMalloc((void **)&ch->h_ring, sizeof(*ch->h_ring), hipHostMallocMapped);
 		if (e == hipSuccess) {
 			memset(ch->h_ring, 0, sizeof(*ch->h_ring));
@@ -350,6 +358,8 @@ void tgpu_channel_destroy(struct tgpu_channel *ch)
 	if (!ch)
 		return;
 	ring_stop(ch);
+	if (ch->ring_counted)
+		__atomic_sub_fetch(&ring_channels, 1, __ATOMIC_RELAXED);
 	if (ch->rstream) (void)hipStreamDestroy(ch->rstream);
 	if (ch->d_box) (void)hipFree(ch->d_box);
 	if (ch->h_ring) (void)hipHostFree(ch->h_ring);

@@ -311,6 +311,16 @@ def test_channel_through_workgroups_that_stay(T, eng, batch, ber, topt):
         ch2.burst_rx(s[off:off + 510], 2 if i == 3 else typ, tn)      # (2: TETRA_TRAIN_NORM_3, ignored)
     ch2.flush()
     assert_same_records(ch2.records, [r for r in want if r["burst_seq"] != sl[3][2]])
+    if batch == 1 and ber == 0.0:       # more channels than may hold workgroups at a time: the ones beyond flush by launch
+        many = [T.Channel(eng, batch_slots=1) for _ in range(34)]
+        short, _ = synth.frame_stream(seed=32, nframes=2)
+        wshort, _ = O.run_rx(short)
+        for c in (many[0], many[-1]):
+            c.feed(short)
+            c.flush()
+            assert_same_records(c.records, wshort)
+        for c in many:
+            c.close()
     topt("RING", 0)
     plain = T.Channel(eng, batch_slots=batch)
     plain.feed(s)
