@@ -976,8 +976,10 @@ def bench_config5(args, T, torch, rank, world, local):
     d_phi = torch.from_numpy(phi).cuda()
     d_bits = torch.empty(2 * len(phi) + 64, dtype=torch.uint8, device="cuda")
     d_soft = torch.empty(2 * len(phi) + 64, dtype=torch.int8, device="cuda")
-    d_rec = torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
-    d_rec2 = torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    # (zeroed: a record has bytes no kernel writes -- the SYNC fields of a NORM burst's header, the tail --, and the runs below
+    # are compared byte for byte)
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    d_rec2 = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
     plan = T.Plan(eng, n, 1)
     plan.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types, None, np.array([code], np.uint32))
     hs = torch.cuda.current_stream().cuda_stream
@@ -985,7 +987,7 @@ def bench_config5(args, T, torch, rank, world, local):
     # own, so that one pass' slicer (memory-shaped) runs beside another's trellis kernels (issue-shaped), as in the mix
     D = max(1, min(args.depth5, args.steps))
     plans = [plan] + [T.Plan(eng, n, 1) for _ in range(D - 1)]
-    recs = [d_rec] + [torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D - 1)]
+    recs = [d_rec] + [torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D - 1)]
     strm = [torch.cuda.Stream() for _ in range(D)]
     for p_ in plans[1:]:
         p_.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types, None, np.array([code], np.uint32))
@@ -1198,7 +1200,7 @@ def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_
 
     eng = T.Engine(local)
     d_stream = torch.from_numpy(slots.reshape(-1)).cuda()
-    d_rec = torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")   # (zeroed: compared byte for byte below)
     plan = T.Plan(eng, n, 1)
     plan.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types)
     prof = T.Prof(steps)
@@ -1214,7 +1216,7 @@ def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_
     # another's trellis kernels (issue-shaped), as in the mix
     D = max(1, min(args.depth5, steps))
     plans = [plan] + [T.Plan(eng, n, 1) for _ in range(D - 1)]
-    recs = [d_rec] + [torch.empty(n * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D - 1)]
+    recs = [d_rec] + [torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D - 1)]
     strm = [torch.cuda.Stream() for _ in range(D)]
     for p_ in plans[1:]:
         p_.load(np.arange(n, dtype=np.uint64) * T.SLOT_BYTES, types)
