@@ -189,7 +189,9 @@ int tgpu_plan_load(struct tgpu_plan *plan, uint32_t nslots, const uint64_t *slot
 /*
  * Run the loaded batch: d_stream (device, 1 bit per byte) -> d_rec (device,
  * nslots * TGPU_REC_BYTES).  Asynchronous on 'hip_stream'; launches only, no
- * allocation and no host synchronisation (hipGraph-capturable).
+ * allocation and no host synchronisation (hipGraph-capturable).  Of a record the fields its burst type has are
+ * written (tgpu_record_blocks() reads only those): the SYNC fields in the header of a NORM burst and the bytes behind
+ * the last block keep what the buffer held -- clear it once if records are to be compared byte for byte.
  */
 int tgpu_plan_execute(struct tgpu_plan *plan, const uint8_t *d_stream, uint8_t *d_rec, void *hip_stream);
 
