@@ -3765,7 +3765,13 @@ static_assert(sizeof(tgw_rec) <= TGW_REC_BYTES, "TGW_REC_BYTES");
 #define TGW_THREADS 1024
 #define TGW_LDS_BYTES (TGW_WCAP * 4 + TGW_NCAP * 4 + TGW_WCAP * 2 + 2 * (TGW_NCAP + 8) * 2 + 2 * (TGW_NCAP + 8))	/* MODE 0, full caps */
 #define TGW_LDS2_BYTES(wcap, ncap) ((wcap) * 4u + 2u * ((ncap) + 8u) * 2u + 2u * ((ncap) + 8u))	/* MODE 2 */
-#define TGW_THREADS_LIGHT 256	/* the three-launch form: a workgroup that takes one wave slot per SIMD and 20-70 KB of LDS finds a
+#ifndef TGW_THREADS_LIGHT
+#define TGW_THREADS_LIGHT 256
+#endif
+#ifndef TGW_NODES_THREADS
+#define TGW_NODES_THREADS 256
+#endif
+/* TGW_THREADS_LIGHT: the three-launch form: a workgroup that takes one wave slot per SIMD and 20-70 KB of LDS finds a
 				 * place beside the heavy kernels of the other batches; 1024 threads and 128 KB wait for a nearly empty
 				 * compute unit */
 
@@ -4241,7 +4247,7 @@ void k_walk_nodes(tg_walk_big big, uint8_t *__restrict__ scratch, uint8_t *__res
 		ncap = rec_stride - 1;
 	}
 	const uint32_t N = tmp.meta[0];
-	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (N == 0xffffffffu || (i >= N && i != 0))
 		return;
 	const tg_chan_ent ce = chan[c];
@@ -4322,7 +4328,7 @@ extern "C" int tgk_walk(const uint8_t *d_base, const struct tg_chan_ent *d_chan,
 	const uint32_t nt = wide ? TGW_THREADS : TGW_THREADS_LIGHT;
 	hipLaunchKernelGGL(k_walk<1>, dim3(nchan), dim3(nt), wide ? TGW_LDS_BYTES : 0, s, WALK_ARGS);
 	tg_walk_big none = {};
-	hipLaunchKernelGGL(k_walk_nodes<false>, dim3(ncap / 256, nchan), dim3(256), 0, s, none, (uint8_t *)nullptr, (uint8_t *)d_tmp,
+	hipLaunchKernelGGL(k_walk_nodes<false>, dim3(ncap / TGW_NODES_THREADS, nchan), dim3(TGW_NODES_THREADS), 0, s, none, (uint8_t *)nullptr, (uint8_t *)d_tmp,
 			   (tgw_rec *)d_recs, d_base, d_chan, d_roots, chunk, cshift, d_cls, d_ysum, d_plain, rec_stride);
 	hipLaunchKernelGGL(k_walk<2>, dim3(nchan), dim3(nt), wide ? TGW_LDS_BYTES : TGW_LDS2_BYTES(wcap, ncap), s, WALK_ARGS);
 #undef WALK_ARGS
