@@ -147,7 +147,8 @@ enum tgpu_option {
 	TGPU_OPT_RING,			/* 1: channels created from now on with a batch size of up to 4 bursts decode their flushes through
 					 * workgroups that stay on the device and take requests from mapped host memory (k_burst_ring) instead of
 					 * a kernel launch per flush; they leave after 20 ms without a request and come back with the next one
-					 * (default 0) */
+					 * (default 0).  While they are there, calls that wait for the whole device (hipDeviceSynchronize(),
+					 * hipFree()) wait for them too: up to those 20 ms behind the channel's last flush */
 	TGPU_OPT__COUNT
 };
 int tgpu_engine_set_option(struct tgpu_engine *eng, int /* enum tgpu_option */ option, long value);
