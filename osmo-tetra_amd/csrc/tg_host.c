@@ -1219,9 +1219,9 @@ int tgpi_plan_last_burst(const struct tgpu_plan *p)
 	return p && p->last_burst && p->marks;
 }
 
-/* the ring kernel (k_burst_ring) decodes a loaded batch of this plan in k_burst's place: what it needs of the plan, and the
- * state an execute through k_burst would have left */
-int tgpi_plan_ring(struct tgpu_plan *p, uint32_t **sb_ok, uint32_t **sb_code, uint32_t **maskidx, uint32_t **masks, int note_run)
+/* the ring kernel (k_burst_ring) decodes batches in k_burst's place without a load: what it needs of the plan are the scratch
+ * arrays k_burst uses (a later tgpu_plan_load() starts from scratch as always) */
+int tgpi_plan_ring(struct tgpu_plan *p, uint32_t **sb_ok, uint32_t **sb_code, uint32_t **maskidx, uint32_t **masks)
 {
 	if (!p || p->rm_decode || p->d_wire || p->fastpath || p->block_mode)
 		return TGPU_ESTATE;
@@ -1229,12 +1229,6 @@ int tgpi_plan_ring(struct tgpu_plan *p, uint32_t **sb_ok, uint32_t **sb_code, ui
 	*sb_code = p->d_sb_code;
 	*maskidx = p->d_maskidx;
 	*masks = p->d_masks;
-	if (note_run) {
-		if (!p->loaded || p->packed_ready || !p->nslots)
-			return TGPU_ESTATE;
-		p->static_pending = p->static_masks;
-		p->last_burst = 1;
-	}
 	return TGPU_OK;
 }
 

@@ -235,7 +235,7 @@ int tgpi_engine_bind(const struct tgpu_engine *eng);
 void tgpi_plan_grid_plain(struct tgpu_plan *p, uint32_t ngrid, uint32_t **d_plain, uint32_t **h_plain);
 int tgk_cls_plain(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, void *stream);
 int tgpi_plan_last_burst(const struct tgpu_plan *p);
-int tgpi_plan_ring(struct tgpu_plan *p, uint32_t **sb_ok, uint32_t **sb_code, uint32_t **maskidx, uint32_t **masks, int note_run);
+int tgpi_plan_ring(struct tgpu_plan *p, uint32_t **sb_ok, uint32_t **sb_code, uint32_t **maskidx, uint32_t **masks);
 void tgpi_plan_set_marks(struct tgpu_plan *p, int on);	/* the caller polls completion marks in mapped records (tg_sync.c) */	/* the last execute wrote completion marks (k_burst) */
 
 /* plan internals used by the stream synchroniser (tg_stream.c) */

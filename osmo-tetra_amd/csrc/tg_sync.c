@@ -218,7 +218,9 @@ static void ring_post(struct tg_ring_msg *m, uint32_t seq, uint32_t n, uint32_t 
 static int ring_start(struct tgpu_channel *ch)
 {
 	uint32_t *sb_ok, *sb_code, *maskidx, *masks;
-	int rc = tgpi_plan_ring(ch->plan, &sb_ok, &sb_code, &maskidx, &masks, 0);
+	int rc = tgpi_engine_bind(ch->eng);
+	if (!rc)
+		rc = tgpi_plan_ring(ch->plan, &sb_ok, &sb_code, &maskidx, &masks);
 	if (rc)
 		return rc;
 	__atomic_store_n(&ch->h_ring->alive, 1u, __ATOMIC_RELEASE);
@@ -245,9 +247,6 @@ static void ring_stop(struct tgpu_channel *ch)
 /* one flush through the ring: 1 = every record complete; 0 = given up (the caller decodes the batch the ordinary way) */
 static int ring_flush(struct tgpu_channel *ch, uint32_t n)
 {
-	uint32_t *a, *b, *c, *d;
-	if (tgpi_plan_ring(ch->plan, &a, &b, &c, &d, 1))
-		return 0;
 	uint64_t desc[TG_RING_MAX] = { 0 };
 	uint32_t hs = 0;
 	for (uint32_t i = 0; i < n; i++) {
@@ -598,20 +597,14 @@ static int flush_slots(struct tgpu_channel *ch)
 	if (!n)
 		return TGPU_OK;
 	hipError_t e = hipSuccess;
-	int rc;
-	if ((rc = tgpi_engine_bind(ch->eng)))
-		return channel_fail(ch, rc, n);
+	int rc = TGPU_OK;
 	for (uint32_t i = 0; i < n; i++)
 		ch->h_type[i] = ch->pend[i].type;
-	rc = tgpu_plan_load(ch->plan, n, ch->h_off, ch->h_type, ch->h_chan, 1, &ch->scramb_init);
-	if (!rc && !ch->zero_copy &&
-	    (e = hipMemcpyAsync(ch->d_slots, ch->h_slots, (size_t)n * SLOT_STRIDE, hipMemcpyHostToDevice, ch->stream)))
-		rc = (int)e;
-	if (!rc && ch->zero_copy)		/* completion marks: see wait_records() */
+	if (ch->zero_copy)		/* completion marks: see wait_records() */
 		for (uint32_t i = 0; i < n; i++)
 			ch->h_rec[(size_t)i * TGPU_REC_BYTES + TG_REC_TYPE] = TG_REC_PENDING;
 	int ringed = 0;
-	if (!rc && ch->ring && n <= TG_RING_MAX) {
+	if (ch->ring && n <= TG_RING_MAX) {	/* (the workgroups that stay need nothing of the plan but its scratch arrays: no load) */
 		ringed = ring_flush(ch, n);
 		if (!ringed) {		/* the ring has failed: without it from now on, this batch included */
 			ring_stop(ch);
@@ -619,6 +612,14 @@ static int flush_slots(struct tgpu_channel *ch)
 				ch->h_rec[(size_t)i * TGPU_REC_BYTES + TG_REC_TYPE] = TG_REC_PENDING;
 		}
 	}
+	if (!ringed) {
+		if ((rc = tgpi_engine_bind(ch->eng)))
+			return channel_fail(ch, rc, n);
+		rc = tgpu_plan_load(ch->plan, n, ch->h_off, ch->h_type, ch->h_chan, 1, &ch->scramb_init);
+	}
+	if (!rc && !ch->zero_copy &&
+	    (e = hipMemcpyAsync(ch->d_slots, ch->h_slots, (size_t)n * SLOT_STRIDE, hipMemcpyHostToDevice, ch->stream)))
+		rc = (int)e;
 	if (!rc && !ringed)
 		rc = tgpu_plan_execute(ch->plan, ch->d_slots, ch->d_rec, ch->stream);
 	if (!rc && !ch->zero_copy &&
