@@ -1307,7 +1307,7 @@ def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="K: steps per timed window")
+    ap.add_argument("--steps", type=int, default=40, help="K: steps per timed window")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--windows", type=int, default=6, help="mix: K-step windows inside the one continuous run (median reported)")
     ap.add_argument("--depth", type=int, default=8, help="mix: steps in flight per GPU (plans / streams)")
