@@ -455,3 +455,31 @@ def test_device_form_with_feeds_of_128_and_256_bytes():
         if r[0] != "ok":
             assert r[1] in (2, 3, 4), r
     assert res[128][0] >= 12 and res[256][0] >= 12, res
+
+
+def test_device_form_finds_the_next_slots_sequence_in_a_late_window():
+    """feeds of 256 bytes: the slot in front of a SYNC burst loses the lock, the SYNC burst gives it back, the slot behind it
+    is handled one call late -- and has lost its own training sequence too: the reference's longer window then finds the NEXT
+    slot's sequence at offset 754 (a misplaced NORM sequence, lock kept).  The device form takes that from the word's
+    TG_CLS_VIEWHIT field wherever the late window ends inside the kernel's 832-byte view (same events as the host walk and
+    the oracle); where it ends beyond, the channel is handed over (TGW_WHY_WINDOW), nothing else"""
+    found = handed = 0
+    for lead in range(0, 256, 6):
+        stream, slots = synth.frame_stream(seed=78, nframes=5, lead_in=lead, pad=700)
+        s = stream.copy()
+        ys = [i for i in range(0, len(s) - 60) if (s[i:i + 38] == SEQ_Y).all()]
+        sb = ys[2] - 214
+        s[sb - 510 + 244 + 3] ^= 1
+        s[sb + 510 + 244 + 3] ^= 1
+        s = np.ascontiguousarray(s)
+        r = _dev_form(s, 256)
+        assert r is not None
+        if r[0] == "ok":
+            ev = T.sync_walk(s, chunk=256, burst_events=False)["events"]
+            far = [e for e in ev if e[0] in (3, 4) and e[2] >= 510]        # misplaced-sequence events beyond the slot itself
+            assert all(e[0] == 4 and e[2] == 754 for e in far), far
+            found += bool(far)          # (a late window that ends in front of offset 776 finds nothing: also settled on the device)
+        else:
+            assert r[1] == 2, r
+            handed += 1
+    assert found >= 8 and handed >= 8, (found, handed)
