@@ -598,12 +598,19 @@ def test_stream_classification_kernel(T, eng):
                     s2[bs + 580:bs + 602] = SEQ_N
                     planted.append(i)
             assert planted
+            bare = planted[-1] + 5          # a slot that loses its sequence and gets nothing in exchange: "nothing in the window",
+            while (got[bare] & 0xFFFFFE) != (244 << 8) or (got[bare + 1] & 0xFF) == 0xFF:     # with the next slot's sequence as the view's first
+                bare += 1
+            s2[anchor + 510 * bare + 244 + 3] ^= 1
             d2 = torch.from_numpy(np.concatenate([s2, np.zeros(T.STREAM_SLACK, np.uint8)])).cuda()
             g2 = T.sync_classify(eng, d2.data_ptr(), len(s2), chunk, anchor, n)
             want = emul_cls(s2, anchor, chunk)
             assert (g2 & 0x7DFFFFFF).tolist() == (want & 0x7DFFFFFF).tolist(), chunk
             assert not (g2 >> 24 & 4).any()
             assert all((g2[i] >> 8 & 0xFFFF) == 580 for i in planted), "a hit beyond a 64-byte feed's window"
+            nxt = int(got[bare + 1])
+            assert (g2[bare] & 0xFF) == 0xFF and (g2[bare] >> 8 & 0xFFFF) == 510 + (nxt >> 8 & 0xFFFF) and \
+                (g2[bare] >> 28 & 7) == (nxt & 0xFF) + 1, hex(int(g2[bare]))
 
 
 def _hostile_stream(T, seed, nslots, lead_in, shift=True):
