@@ -2033,6 +2033,65 @@ def test_device_walk_batch_equals_host_walk_batch(T, eng, chunk, mono, wide, top
     pb.close()
 
 
+def test_fuzz_device_walk_batches_with_feeds_of_32_to_256_bytes(T, eng):
+    """random batches of randomly damaged channels (bit flips in training sequences, spurious sequences, zeroed stretches,
+    inserted / deleted bytes, payload noise), replayed with feeds of 32 / 64 / 128 / 256 bytes: tgpu_sync_multi_launch /
+    _collect == tgpu_sync_multi_begin / _finish per channel (events, counts, final state, bitmap, every delivered record),
+    whether the device walk settles the batch or hands it over; the reasons it gives are the documented ones, and most
+    batches of the on-grid kind stay on the device"""
+    import torch
+    from test_stream_sync_cpu import SEQ_Y, SEQ_N
+    rng = np.random.default_rng(90210)
+    hs = torch.cuda.current_stream().cuda_stream
+    stayed = handed = 0
+    for trial in range(12):
+        chunk = int(rng.choice([32, 64, 128, 256]))
+        gentle = trial % 3 != 2          # two of three batches: damage that leaves the slot grid where it is
+        streams = []
+        for c in range(int(rng.integers(2, 6))):
+            st, _ = synth.frame_stream(seed=int(rng.integers(1, 1 << 30)), nframes=int(rng.integers(3, 40)),
+                                       lead_in=int(rng.integers(0, 600)), pad=int(rng.integers(700, 900)),
+                                       ber=float(rng.choice([0.0, 0.02])))
+            s = st.copy()
+            tr = [i for i in range(0, len(s) - 60) if (s[i:i + 22] == SEQ_N).all() or (s[i:i + 38] == SEQ_Y).all()]
+            for i in tr:
+                if rng.random() < 0.1:
+                    s[i + int(rng.integers(0, 22))] ^= 1
+            for _ in range(int(rng.integers(0, 4))):
+                kind = int(rng.integers(0, 3 if gentle else 5))
+                p = int(rng.integers(600, len(s) - 800))
+                if kind == 0:
+                    s[p:p + 22] = SEQ_N
+                elif kind == 1:
+                    s[p:p + int(rng.integers(1, 1500))] = 0
+                elif kind == 2:
+                    s[p] ^= 1
+                elif kind == 3:
+                    s = np.concatenate([s[:p], rng.integers(0, 2, int(rng.integers(1, 40))).astype(np.uint8), s[p:]])
+                else:
+                    s[p:p + 38] = SEQ_Y
+            streams.append(np.ascontiguousarray(s))
+        d, offs, ntot = _multi_batch(T, streams)
+        pa, pb = T.Plan(eng, ntot, len(streams)), T.Plan(eng, ntot, len(streams))
+        ms = T.MultiSync(eng, pa, streams, d.data_ptr(), offs, chunk, hs)
+        ref = ms.finish(burst_events=False, nthreads=2)
+        ra = torch.zeros(max(ms.ngrid, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        pa.execute(d.data_ptr(), ra.data_ptr(), hs)
+        rb = torch.zeros(max(ms.ngrid, 1) * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        msd = T.MultiSyncDev(eng, pb, streams, d.data_ptr(), offs, rb.data_ptr(), chunk, hs)
+        got = msd.collect()
+        torch.cuda.synchronize()
+        _same_batch_outcome(T, ref, got, ra.cpu().numpy().reshape(-1, T.REC_BYTES), rb.cpu().numpy().reshape(-1, T.REC_BYTES),
+                            "fuzz batch %d, feeds of %d" % (trial, chunk))
+        assert all(w in (0, 1, 2, 3, 4, 5, 6, 7, 8) for w in msd.why), msd.why
+        if gentle:
+            stayed += not msd.fellback
+            handed += bool(msd.fellback)
+        pa.close()
+        pb.close()
+    assert stayed >= 4, (stayed, handed)
+
+
 def test_device_walk_node_arrays_follow_the_channels(T, eng):
     """the LDS form's node arrays are laid out per launch for twice the nodes the plan's batches have shown: a quiet batch
     first (a few dozen nodes: the smallest cap), then one whose channel has over a thousand damaged slots -- that batch comes
