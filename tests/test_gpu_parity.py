@@ -2821,7 +2821,8 @@ def test_device_walk_batches_on_small_plans(T, eng):
 
 
 @pytest.mark.gpu
-def test_packed_ingest_equals_the_byte_path(T, eng):
+@pytest.mark.parametrize("chunk", [64, 256])
+def test_packed_ingest_equals_the_byte_path(T, eng, chunk):
     """tgpu_pack_bits + tgpu_sync_multi_launch_packed (the capture crosses PCIe one bit per bit; the front end starts behind
     its own bytes -> bits step) against tgpu_sync_multi_launch on the bytes: eight channels of different cells, lengths and
     lead-ins (so that the channels' bit offsets and slot alignments differ), damaged training sequences (the per-position
@@ -2863,9 +2864,9 @@ def test_packed_ingest_equals_the_byte_path(T, eng):
     pa, pb = T.Plan(eng, ntot, len(cells)), T.Plan(eng, ntot, len(cells))
     ra = torch.zeros(ntot * T.REC_BYTES, dtype=torch.uint8, device="cuda")
     rb = torch.zeros(ntot * T.REC_BYTES, dtype=torch.uint8, device="cuda")
-    a = T.MultiSyncDev(eng, pa, streams, d.data_ptr(), offs, ra.data_ptr(), 64, hs)
+    a = T.MultiSyncDev(eng, pa, streams, d.data_ptr(), offs, ra.data_ptr(), chunk, hs)
     ref = a.collect()
-    b = T.MultiSyncDev(eng, pb, streams, dp.data_ptr(), [8 * f for f in poffs], rb.data_ptr(), 64, hs, packed=True)
+    b = T.MultiSyncDev(eng, pb, streams, dp.data_ptr(), [8 * f for f in poffs], rb.data_ptr(), chunk, hs, packed=True)
     got = b.collect()
     torch.cuda.synchronize()
     assert not a.fellback and not b.fellback and a.ngrid == b.ngrid
