@@ -449,7 +449,7 @@ void k_bbk_blocks(const uint32_t *__restrict__ items, uint32_t nitems, const uin
  * search window of slot n is what the reference's synchroniser would hold when it gets to that
  * slot while being fed 'chunk' bytes per call (phy/tetra_burst_sync.c:106-120):
  *     w = min(chunk * ceil((bs + 510) / chunk), len) - bs        (510 .. 573 for chunk = 64)
- * Per wave and slot: 832 bytes -> LDS; thirteen 64-bit ballots turn them into an 832-bit string held in
+ * Per wave and slot: the view's 640 ... 1088 bytes -> LDS; ten ... seventeen 64-bit ballots turn them into a bit string held in
  * SGPRs; every lane then tests one window position per round against y (38 bits), n and p (22 bits)
  * with two v_alignbit_b32 -- the first hit in ascending position is tetra_find_train_seq()'s answer
  * (phy/tetra_burst.c:269-339).  Positions 0..255 are always scanned (the expected hits sit at 214
@@ -489,9 +489,9 @@ __device__ __forceinline__ uint32_t chan_of_slot(const tg_chan_ent *chan, uint32
 }
 
 /*
- * One grid slot through the per-position search: the wave's 832-byte view (510 + the longest feed of the device path, 256,
- * + a sequence's 38, rounded up to 64) goes to LDS, thirteen ballots turn it into an
- * 832-bit string in SGPRs, every lane tests one window position per round.  This is the exact form for ANY slot
+ * One grid slot through the per-position search: the wave's view (TG_VIEW_OF: 510 + what two feeds of the replay add to a
+ * window + a sequence's 38, rounded up to 64: 640 / 832 / 1088 bytes) goes to LDS, ten to seventeen ballots turn it into a
+ * bit string in SGPRs, every lane tests one window position per round.  This is the exact form for ANY slot
  * (stream end, windows longer than the slot, bytes other than 0 / 1, nothing found where a burst should be): the
  * round-1 kernel ran it on every slot (k_front_stream_v1, kept for A/B runs), the packed-bit kernel below hands
  * it the slots it cannot settle (k_front_stream_fix).
@@ -503,10 +503,13 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 						  const uint32_t (&a_sb)[10], uint32_t &myword, uint32_t &clsword, uint32_t &ysword)
 {
 	const uint64_t bs = prm.anchor + (uint64_t)slot * TG_SLOT_BITS;
-	uint32_t d0, d1, d2, d3;
-	/* (the last 64 bytes of the view lie up to 322 bytes past the slot: read only where the buffer's slack covers them --
-	 * bytes past the stream's end count as zeros anyway) */
-	const bool tail_ok = lane < 16 && bs + 768 + 4 * lane + 16 <= prm.len + TG_STREAM_SLACK;
+	uint32_t d0, d1, d2, d3, d4;
+	/* how far the view reaches depends on the feeds (TG_VIEW_OF: 640 / 832 / 1088 bytes for feeds of up to 64 / 128 / 256);
+	 * its far end lies up to 578 bytes past the slot: read only where the buffer's slack covers it -- bytes past the stream's
+	 * end count as zeros anyway */
+	const uint32_t view = TG_VIEW_OF(prm.chunk);
+	const bool ok3 = view > 768 && bs + 768 + 4 * lane + 16 <= prm.len + TG_STREAM_SLACK;
+	const bool ok4 = view > 1024 && lane < 16 && bs + 1024 + 4 * lane + 16 <= prm.len + TG_STREAM_SLACK;
 	if (PACKED) {
 		/* packed ingest: 'stream' is the packed buffer and prm.anchor counts from the channel's bit 0, whose position in the
 		 * buffer the caller has added to... the bit position of the slot: every lane fetches the two bytes that hold its
@@ -519,14 +522,16 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 		d0 = nib(b0);
 		d1 = nib(b0 + 256);
 		d2 = (bs + 512 + 4 * lane + 16 <= prm.len + TG_STREAM_SLACK) ? nib(b0 + 512) : 0u;
-		d3 = tail_ok ? nib(b0 + 768) : 0u;
+		d3 = ok3 ? nib(b0 + 768) : 0u;
+		d4 = ok4 ? nib(b0 + 1024) : 0u;
 	} else {
 		const uint8_t *base = stream + bs;
-		/* 832 bytes of view (the buffer carries TG_STREAM_SLACK readable bytes of slack) */
+		/* (the buffer carries TG_STREAM_SLACK readable bytes of slack) */
 		d0 = *(const tg_u32_unaligned *)(base + 4 * lane);
 		d1 = *(const tg_u32_unaligned *)(base + 256 + 4 * lane);
 		d2 = (bs + 512 + 4 * lane + 4 <= prm.len + TG_STREAM_SLACK) ? *(const tg_u32_unaligned *)(base + 512 + 4 * lane) : 0u;
-		d3 = tail_ok ? *(const tg_u32_unaligned *)(base + 768 + 4 * lane) : 0u;
+		d3 = ok3 ? *(const tg_u32_unaligned *)(base + 768 + 4 * lane) : 0u;
+		d4 = ok4 ? *(const tg_u32_unaligned *)(base + 1024 + 4 * lane) : 0u;
 	}
 
 	uint64_t fed = bs + TG_SLOT_BITS + prm.chunk - 1;
@@ -534,41 +539,43 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 	if (fed > prm.len)
 		fed = prm.len;
 	const uint32_t w = (uint32_t)(fed - bs);			/* search window, >= 510 */
-	const uint32_t wv = w < TG_STREAM_VIEW ? w : TG_STREAM_VIEW;	/* what we can see of it */
+	const uint32_t wv = w < view ? w : view;	/* what we can see of it */
 	const uint64_t rest = prm.len - bs;
-	const uint32_t vis = rest < TG_STREAM_VIEW ? (uint32_t)rest : TG_STREAM_VIEW;	/* stream bytes in view */
+	const uint32_t vis = rest < view ? (uint32_t)rest : view;	/* stream bytes in view */
 
 	mine[lane] = d0;
 	mine[64 + lane] = d1;
 	mine[128 + lane] = d2;
+	mine[192 + lane] = d3;
 	if (lane < 16)
-		mine[192 + lane] = d3;
+		mine[256 + lane] = d4;
 
-	/* bytes -> 832-bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes past the stream end read as 0
+	/* bytes -> bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes past the stream end read as 0
 	 * (every test below bounds itself by the window, so bytes past the window need no masking) */
-	constexpr int NR = TG_STREAM_VIEW / 64;	/* rounds of 64 window positions: 13 */
+	constexpr int NR = TG_STREAM_VIEW / 64;	/* rounds of 64 window positions: at most 17 (10 with feeds of up to 64 bytes) */
 	unsigned long long B[NR + 1];
-	if (vis == TG_STREAM_VIEW) {	/* everywhere but at the very end of the stream: no per-lane bound */
+	if (vis == view) {	/* everywhere but at the very end of the stream: no per-lane bound */
 #pragma unroll
 		for (int r = 0; r < NR; r++)
-			B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0);
+			B[r] = 64u * r < view ? __ballot(lds0[wbase + 64 * r + lane] != 0) : 0ull;
 	} else {
 #pragma unroll
 		for (int r = 0; r < NR; r++)
-			B[r] = __ballot(lds0[wbase + 64 * r + lane] != 0 && 64u * r + lane < vis);
+			B[r] = 64u * r < vis ? __ballot(lds0[wbase + 64 * r + lane] != 0 && 64u * r + lane < vis) : 0ull;
 	}
 	B[NR] = 0;
 	/* a byte other than 0 / 1 inside the search window: from the three dwords of the lane (byte k of dword q
 	 * is window byte 256 q + 4 lane + k), bytes at or past the window end masked off */
 	uint32_t anyb;
 	{
-		const uint32_t p0 = 4 * lane, p1 = 256 + 4 * lane, p2 = 512 + 4 * lane, p3 = 768 + 4 * lane;
+		const uint32_t p0 = 4 * lane, p1 = 256 + 4 * lane, p2 = 512 + 4 * lane, p3 = 768 + 4 * lane, p4 = 1024 + 4 * lane;
 		const uint32_t k0 = wv > p0 ? wv - p0 : 0, k1 = wv > p1 ? wv - p1 : 0, k2 = wv > p2 ? wv - p2 : 0, k3 = wv > p3 ? wv - p3 : 0;
+		const uint32_t k4 = wv > p4 ? wv - p4 : 0, m4 = k4 >= 4 ? 0xffffffffu : ((1u << (8 * k4)) - 1u);
 		const uint32_t m0 = k0 >= 4 ? 0xffffffffu : ((1u << (8 * k0)) - 1u);
 		const uint32_t m1 = k1 >= 4 ? 0xffffffffu : ((1u << (8 * k1)) - 1u);
 		const uint32_t m2 = k2 >= 4 ? 0xffffffffu : ((1u << (8 * k2)) - 1u);
 		const uint32_t m3 = k3 >= 4 ? 0xffffffffu : ((1u << (8 * k3)) - 1u);
-		anyb = (((d0 & m0) | (d1 & m1) | (d2 & m2) | (d3 & m3)) & 0xfefefefeu) ? 2u : 0u;
+		anyb = (((d0 & m0) | (d1 & m1) | (d2 & m2) | (d3 & m3) | (d4 & m4)) & 0xfefefefeu) ? 2u : 0u;
 	}
 
 	uint32_t rc = TG_BURST_NONE, offs = 0, flags = 0;
@@ -654,7 +661,7 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 	}
 	if (__ballot(anyb > 1))
 		flags |= TG_CLS_NONBINARY;
-	if (!found && w > TG_STREAM_VIEW)
+	if (!found && w > view)
 		flags |= TG_CLS_CLIPPED;
 	if (!found && !inview)
 		flags |= TG_CLS_NOVIEW;
@@ -712,7 +719,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
 void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		       uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
 {
-	STREAM_SLOT_TABLES(TG_STREAM_VIEW / 4 + 4)	/* 208 data dwords + one zero pad row */
+	STREAM_SLOT_TABLES(TG_STREAM_VIEW / 4 + 4)	/* 272 data dwords + one zero pad row */
 	__shared__ uint32_t s_out[4][128];	/* per wave: four packed slots on their way out, then their cls / ysum words */
 	uint32_t *mo = s_out[wib];
 
@@ -747,7 +754,7 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	}
 }
 
-/* classification word of a slot the packed-bit kernel leaves to k_front_stream_fix (never a valid word: offsets stay below 832) */
+/* classification word of a slot the packed-bit kernel leaves to k_front_stream_fix (never a valid word: offsets stay below 1088) */
 #define TG_CLS_DEFER 0xffffffffu
 
 /* second pass of the packed-bit front end: every slot the first pass deferred (it appended them to a list: defer[0] =
@@ -1027,11 +1034,11 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			const uint32_t i0 = s0 - cg0;
 			first = cfirst;
 			gb = first + (uint64_t)i0 * TG_SLOT_BITS;
-			d.fast = i0 + 4u <= cncls && (uint64_t)i0 * TG_SLOT_BITS + TG_GROUP_BYTES + TG_STREAM_VIEW <= cspan;
+			d.fast = i0 + 4u <= cncls && (uint64_t)i0 * TG_SLOT_BITS + TG_GROUP_BYTES + TG_VIEW_OF(prm.chunk) <= cspan;
 		} else {
 			first = prm.anchor;
 			gb = prm.anchor + (uint64_t)g * TG_GROUP_BYTES;
-			d.fast = gb + TG_GROUP_BYTES + TG_STREAM_VIEW <= prm.len;
+			d.fast = gb + TG_GROUP_BYTES + TG_VIEW_OF(prm.chunk) <= prm.len;
 		}
 		if (PACKED) {
 			/* packed ingest: the stream lies in memory one bit per position, so a group is 255 bytes: eighteen lanes

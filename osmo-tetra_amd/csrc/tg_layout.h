@@ -71,8 +71,8 @@
  */
 #define TG_CLS_EARLY21    0x01	/* a full match exists at an offset < 21 and was NOT evaluated */
 #define TG_CLS_NONBINARY  0x02
-#define TG_CLS_CLIPPED    0x04	/* window longer than the kernel's 832-byte view and nothing found in view */
-#define TG_CLS_NOVIEW     0x08	/* nothing found, and nothing in the rest of the 832-byte view (bounded by the stream's end)
+#define TG_CLS_CLIPPED    0x04	/* window longer than the kernel's view (TG_VIEW_OF) and nothing found in view */
+#define TG_CLS_NOVIEW     0x08	/* nothing found, and nothing in the rest of the view (bounded by the stream's end)
 				 * either: "nothing" is then also the answer for any longer window up to the view -- what the
 				 * synchroniser searches while it works off a backlog (tg_walk_core.h) */
 /* a word that says "nothing in the window" and does not carry TG_CLS_NOVIEW: bits 4..6 of the flags = 1 + type of the FIRST
@@ -85,7 +85,12 @@
 #define TG_YS_NONE        0xffffu	/* no y sequence starts in this slot */
 #define TG_YS_MULTI       0x8000u	/* more than one does; bits 0..8 hold the first */
 #define TG_YS_FIRST(v)    ((v) & 0x1ffu)
-#define TG_STREAM_VIEW    832	/* bytes of a slot's search window the kernel looks at: 510 + 255 (feeds of up to 256 bytes) + 38, in rounds of 64 */
+#define TG_STREAM_VIEW    1088	/* most bytes of a slot's search window the kernel looks at (LDS rows, loop bounds) */
+/* ... and what it looks at for a replay with feeds of 'chunk' bytes: a slot's own window ends at most chunk - 1 bytes past
+ * the slot, the window of a slot that is handled a call late (tg_walk_core.h) another chunk further, and a 38-byte
+ * sequence that starts inside must end inside: 510 + 63 + 64 = 637 -> 640, 510 + 127 + 128 = 765 (+ 38) -> 832,
+ * 510 + 255 + 256 = 1021 (+ 38) -> 1088 */
+#define TG_VIEW_OF(chunk) ((chunk) <= 64u ? 640u : (chunk) <= 128u ? 832u : 1088u)
 #define TG_STREAM_SLACK   192	/* readable bytes the stream buffer must have after its last byte */
 
 /* soft area of a slot (config 5): int8 values in trellis order, see k_front_soft */

@@ -344,13 +344,13 @@ TGW_FN void tgw_run(const struct tgw_chan *c, int state, uint64_t bs, uint64_t n
 			const uint32_t type = cw & 0xff, offs = (cw >> 8) & 0xffff;
 			if (type == TG_BURST_NONE) {
 				/* "nothing" is the kernel's answer for the window it looked at (the steady-state one, unless clipped) and,
-				 * with TG_CLS_NOVIEW, for every longer window its 832-byte view covers: a slot that is handled one or two
+				 * with TG_CLS_NOVIEW, for every longer window its view (TG_VIEW_OF) covers: a slot that is handled one or two
 				 * calls late (the first burst after a re-lock onto the very next SYNC burst) */
 				const uint64_t fj = tgw_fed(c, kj);
 				int vt = -1;	/* the longer window's find, if it has one */
 				int settled = (canonical && !(cflags & TG_CLS_CLIPPED)) ||
-					      ((cflags & TG_CLS_NOVIEW) && fj - bs <= TG_STREAM_VIEW);
-				if (!settled && !(cflags & TG_CLS_NOVIEW) && TG_CLS_VIEWHIT(cflags) && fj - bs <= TG_STREAM_VIEW) {
+					      ((cflags & TG_CLS_NOVIEW) && fj - bs <= TG_VIEW_OF(c->chunk));
+				if (!settled && !(cflags & TG_CLS_NOVIEW) && TG_CLS_VIEWHIT(cflags) && fj - bs <= TG_VIEW_OF(c->chunk)) {
 					/* the first sequence that starts in view and ends past the kernel's window: a window that holds all of
 					 * it finds it (nothing starts before it); one that ends before a 22-bit sequence would fit there finds
 					 * nothing; in between (a 38-bit one cut off, room for a 22-bit one behind its start) only the bytes tell */

@@ -80,7 +80,7 @@ CLS_LIB = os.path.join(HERE, "host_emul", "libcls_emul.so")
 _cls_lib = None
 
 
-def cls_ysum(stream, anchor, chunk, view=832):
+def cls_ysum(stream, anchor, chunk, view=None):
     """(cls, ysum) as tests/test_stream_sync_cpu.py's emul_cls / emul_ysum give them, in C: streams of bench size"""
     global _cls_lib
     if _cls_lib is None:
@@ -89,6 +89,8 @@ def cls_ysum(stream, anchor, chunk, view=832):
         _cls_lib = C.CDLL(CLS_LIB)
         _cls_lib.emul_cls_ysum.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p, C.POINTER(C.c_uint16)]
         _cls_lib.emul_cls_ysum.restype = None
+    if view is None:        # TG_VIEW_OF (csrc/tg_layout.h)
+        view = 640 if chunk <= 64 else 832 if chunk <= 128 else 1088
     s = np.ascontiguousarray(stream, np.uint8)
     L = len(s)
     n = (L - anchor) // 510 if L >= anchor + 510 else 0

@@ -32,7 +32,7 @@ static int skewed_gate(const uint8_t *in, uint32_t c)
 void emul_cls_ysum(const uint8_t *s, uint64_t L, uint64_t anchor, uint32_t chunk, uint32_t view, uint32_t *cls, uint16_t *ysum)
 {
 	const uint64_t n = L >= anchor + 510 ? (L - anchor) / 510 : 0;
-	uint8_t buf[1024];
+	uint8_t buf[1280];
 	for (uint64_t i = 0; i < n; i++) {
 		const uint64_t bs = anchor + 510 * i;
 		uint64_t f = (bs + 510 + chunk - 1) / chunk * chunk;
@@ -40,7 +40,7 @@ void emul_cls_ysum(const uint8_t *s, uint64_t L, uint64_t anchor, uint32_t chunk
 			f = L;
 		const uint32_t w = (uint32_t)(f - bs), wv = w < view ? w : view;
 		memset(buf, 0, sizeof(buf));
-		const uint64_t have = L - bs < 900 ? L - bs : 900;
+		const uint64_t have = L - bs < 1200 ? L - bs : 1200;
 		memcpy(buf, s + bs, have < wv ? have : wv);
 		uint32_t rc = 0xff, off = 0;
 		for (uint32_t c = 0; c < wv; c++) {
@@ -62,7 +62,7 @@ void emul_cls_ysum(const uint8_t *s, uint64_t L, uint64_t anchor, uint32_t chunk
 		}
 		uint32_t flags = (rc == 0xff && w > view) ? 4u : 0u;
 		if (rc == 0xff) {	/* TG_CLS_NOVIEW: nothing in the rest of the view (up to the stream's end) either */
-			uint8_t full[1024];
+			uint8_t full[1280];
 			const uint32_t vis = (uint32_t)(L - bs < view ? L - bs : view);
 			memset(full, 0, sizeof(full));
 			memcpy(full, s + bs, have);
@@ -93,8 +93,8 @@ void emul_cls_ysum(const uint8_t *s, uint64_t L, uint64_t anchor, uint32_t chunk
 		if (g >= n)
 			continue;
 		uint64_t vis = L - (anchor + 510 * g);
-		if (vis > view)
-			vis = view;
+		if (vis > 640)
+			vis = 640;	/* (any bound past 510 + 38 will do: the summary is about the slot's own positions) */
 		if (o + 38 > vis)
 			continue;
 		if (ysum[g] == 0xffff)

@@ -585,7 +585,7 @@ def test_stream_classification_kernel(T, eng):
         assert (ys != 0xFFFF).sum() >= 3
         assert T.sync_classify(eng, d.data_ptr(), len(s), 64, anchor, n).tolist() == got.tolist()
         # feeds of 128 / 256 bytes: the search window reaches up to 765 bytes from the slot's start, all of it inside the
-        # kernel's 832-byte view (no TG_CLS_CLIPPED); hits beyond the slot and its successor's first bytes included
+        # kernel's view for such feeds (TG_VIEW_OF; no TG_CLS_CLIPPED); hits beyond the slot and its successor's first bytes included
         from test_stream_sync_cpu import SEQ_N
         for chunk in (128, 256):
             s2 = s.copy()
@@ -2688,7 +2688,7 @@ def test_stages_step_by_step_and_against_the_fused_path(T, eng, ber):
         T.Stages(eng, 9)
 
 
-def _oracle_check_of_a_walked_channel(T, st, out, rec, code, nrec=20000):
+def _oracle_check_of_a_walked_channel(T, st, out, rec, code, nrec=20000, chunk=64):
     """a channel of a device-walk batch against the ORACLE's receiver on the same bytes (not against the product's own host
     walk): every synchroniser event, the number of delivered bursts, and the records of a slice of the delivered bursts
     (nrec of them: from the start, the middle and the end) against the oracle's decode"""
@@ -2698,7 +2698,7 @@ def _oracle_check_of_a_walked_channel(T, st, out, rec, code, nrec=20000):
     ecb = O.EVENT_CB(lambda ev, bitnum, arg, priv: want_ev.append((ev, bitnum, arg)) if ev != 2 else None)
     O.lib().orc_rx_init(C.byref(rx), O.UPPER_CB(), ecb, None)
     rx.use_acc = 1
-    O.lib().orc_rx_feed(C.byref(rx), O._p(st), len(st), 64)
+    O.lib().orc_rx_feed(C.byref(rx), O._p(st), len(st), chunk)
     assert out["events"] == want_ev
     dropped = sum(1 for e in want_ev if e[0] in (3, 4, 5))
     assert out["noffgrid"] == 0 and out["nslots"] == rx.burst_seq - dropped
@@ -2714,6 +2714,31 @@ def _oracle_check_of_a_walked_channel(T, st, out, rec, code, nrec=20000):
     ok, p = check_against_oracle(T, r, ty, slots, code, use_acc=1)
     assert (p["code"][ty != 3] == code).all()
     return len(want_ev), len(pick)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [128, 256])
+def test_device_walk_with_long_feeds_against_the_oracle(T, eng, chunk):
+    """three bench channels of 40 000 slots (1 % damaged training sequences) replayed with feeds of 128 / 256 bytes, walks on
+    the device: no hand-over, and per channel the oracle receiver's events (fed the same bytes in the same feeds), its number of
+    delivered bursts, and 6 000 delivered records against the oracle's decode"""
+    import torch
+    import bench
+    hs = torch.cuda.current_stream().cuda_stream
+    made = [bench.make_mix_stream(T, 40000, 20 + c, mnc=70 + c, cc=2 + c) for c in range(3)]
+    streams = [np.ascontiguousarray(m[0]) for m in made]
+    d, offs, ntot = _multi_batch(T, streams)
+    plan = T.Plan(eng, ntot, 3)
+    rec = torch.zeros(ntot * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    msd = T.MultiSyncDev(eng, plan, streams, d.data_ptr(), offs, rec.data_ptr(), chunk, hs)
+    outs = msd.collect()
+    torch.cuda.synchronize()
+    assert not msd.fellback, msd.why
+    r = rec.cpu().numpy().reshape(-1, T.REC_BYTES)
+    for c in range(3):
+        nev, npick = _oracle_check_of_a_walked_channel(T, streams[c], outs[c], r, made[c][2], nrec=6000, chunk=chunk)
+        assert nev > 400 and npick >= 5000
+    plan.close()
 
 
 @pytest.mark.gpu
