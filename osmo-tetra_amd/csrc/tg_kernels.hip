@@ -496,7 +496,9 @@ __device__ __forceinline__ uint32_t chan_of_slot(const tg_chan_ent *chan, uint32
  * round-1 kernel ran it on every slot (k_front_stream_v1, kept for A/B runs), the packed-bit kernel below hands
  * it the slots it cannot settle (k_front_stream_fix).
  */
-template <bool PACKED = false>
+/* VIEWT: the view in bytes when the caller knows it at compile time (k_front_stream_fix is built for each of the three:
+ * the 64-byte feeds of the metric then run the ten-round code), 0: TG_VIEW_OF(prm.chunk) at run time, arrays for the largest */
+template <bool PACKED = false, int VIEWT = 0>
 __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ stream, const tg_stream_params &prm, uint32_t slot,
 						  uint32_t lane, uint32_t half, uint32_t bit, uint32_t wbase, uint32_t *mine,
 						  const uint8_t *lds0, const uint32_t (&a_n1)[10], const uint32_t (&a_n2)[10],
@@ -507,7 +509,7 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 	/* how far the view reaches depends on the feeds (TG_VIEW_OF: 640 / 832 / 1088 bytes for feeds of up to 64 / 128 / 256);
 	 * its far end lies up to 578 bytes past the slot: read only where the buffer's slack covers it -- bytes past the stream's
 	 * end count as zeros anyway */
-	const uint32_t view = TG_VIEW_OF(prm.chunk);
+	const uint32_t view = VIEWT ? (uint32_t)VIEWT : TG_VIEW_OF(prm.chunk);
 	const bool ok3 = view > 768 && bs + 768 + 4 * lane + 16 <= prm.len + TG_STREAM_SLACK;
 	const bool ok4 = view > 1024 && lane < 16 && bs + 1024 + 4 * lane + 16 <= prm.len + TG_STREAM_SLACK;
 	if (PACKED) {
@@ -545,14 +547,17 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 
 	mine[lane] = d0;
 	mine[64 + lane] = d1;
-	mine[128 + lane] = d2;
-	mine[192 + lane] = d3;
-	if (lane < 16)
+	constexpr uint32_t ROWDW = (VIEWT ? VIEWT : TG_STREAM_VIEW) / 4;	/* the row's data dwords: a lane's dword goes there if it lies inside */
+	if (128 + lane < ROWDW)
+		mine[128 + lane] = d2;
+	if (192 + lane < ROWDW)
+		mine[192 + lane] = d3;
+	if (256 + lane < ROWDW)
 		mine[256 + lane] = d4;
 
 	/* bytes -> bit string in SGPRs (bit i of B[r] = byte 64 r + i); bytes past the stream end read as 0
 	 * (every test below bounds itself by the window, so bytes past the window need no masking) */
-	constexpr int NR = TG_STREAM_VIEW / 64;	/* rounds of 64 window positions: at most 17 (10 with feeds of up to 64 bytes) */
+	constexpr int NR = (VIEWT ? VIEWT : TG_STREAM_VIEW) / 64;	/* rounds of 64 window positions: at most 17 (10 with feeds of up to 64 bytes) */
 	unsigned long long B[NR + 1];
 	if (vis == view) {	/* everywhere but at the very end of the stream: no per-lane bound */
 #pragma unroll
@@ -691,8 +696,8 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 	ysword = ys;
 }
 
-#define STREAM_SLOT_TABLES(WIN)										\
-	constexpr int WINDW = (WIN);									\
+#define STREAM_SLOT_TABLES(VIEWB)									\
+	constexpr int WINDW = (VIEWB) / 4 + 4;	/* the view's dwords + one zero pad row */			\
 	__shared__ uint32_t s_slot[4][WINDW];								\
 	const uint32_t lane = threadIdx.x & 63;								\
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);				\
@@ -703,23 +708,23 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];						\
 	const uint32_t wbase = wib * WINDW * 4;								\
 	if (lane < 4)											\
-		mine[TG_STREAM_VIEW / 4 + lane] = 0;	/* "no source" gathers read this */		\
+		mine[(VIEWB) / 4 + lane] = 0;	/* "no source" gathers read this */			\
 	uint32_t a_n1[10], a_n2[10], a_sb[10];								\
 	_Pragma("unroll")										\
 	for (int r = 0; r < 10; r++) {									\
 		const uint32_t o0 = c_tab.front_src[0][2 * r + half][bit];				\
 		const uint32_t o1 = c_tab.front_src[1][2 * r + half][bit];				\
 		const uint32_t o2 = c_tab.front_src[2][2 * r + half][bit];				\
-		a_n1[r] = wbase + (o0 == 0xffff ? TG_STREAM_VIEW : o0);					\
-		a_n2[r] = wbase + (o1 == 0xffff ? TG_STREAM_VIEW : o1);					\
-		a_sb[r] = wbase + (o2 == 0xffff ? TG_STREAM_VIEW : o2);					\
+		a_n1[r] = wbase + (o0 == 0xffff ? (VIEWB) : o0);						\
+		a_n2[r] = wbase + (o1 == 0xffff ? (VIEWB) : o1);						\
+		a_sb[r] = wbase + (o2 == 0xffff ? (VIEWB) : o2);						\
 	}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
 void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		       uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum)
 {
-	STREAM_SLOT_TABLES(TG_STREAM_VIEW / 4 + 4)	/* 272 data dwords + one zero pad row */
+	STREAM_SLOT_TABLES(TG_STREAM_VIEW)
 	__shared__ uint32_t s_out[4][128];	/* per wave: four packed slots on their way out, then their cls / ysum words */
 	uint32_t *mo = s_out[wib];
 
@@ -762,13 +767,13 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
  * time.  Deferred slots are rare (damaged training sequences, the end of a stream); the grid is sized for about one
  * entry per wave, a wave takes entries wave, wave + nwaves, ... */
 #define TG_DEFER_LIST 16
-template <bool PACKED>
+template <bool PACKED, int VIEWT>
 __global__ __launch_bounds__(256)
 void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
 			const uint32_t *__restrict__ defer)
 {
-	STREAM_SLOT_TABLES(TG_STREAM_VIEW / 4 + 4)
+	STREAM_SLOT_TABLES(VIEWT)
 	const uint32_t count = defer[0];
 	for (uint32_t e = wave; e < count; e += nwaves) {
 		{
@@ -786,11 +791,11 @@ void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm
 					q.anchor = prm.chan[c].anchor;
 					q.len = prm.chan[c].len;
 					q.pbit = prm.chan[c].d_off & ~TG_CHAN_PACKED;
-					front_stream_slot<PACKED>(PACKED ? stream : stream + prm.chan[c].d_off, q, i, lane, half, bit, wbase, mine, lds0,
+					front_stream_slot<PACKED, VIEWT>(PACKED ? stream : stream + prm.chan[c].d_off, q, i, lane, half, bit, wbase, mine, lds0,
 								  a_n1, a_n2, a_sb, myword, clsword, ys);
 				}
 			} else
-				front_stream_slot<PACKED>(stream, prm, slot, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb, myword, clsword, ys);
+				front_stream_slot<PACKED, VIEWT>(stream, prm, slot, lane, half, bit, wbase, mine, lds0, a_n1, a_n2, a_sb, myword, clsword, ys);
 			if (lane < TG_PACKED_WORDS)
 				packed[(size_t)slot * TG_PACKED_WORDS + lane] = myword;
 			if (lane == 0) {
@@ -3370,10 +3375,14 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 	uint32_t fblocks = (nslots / 128 + 3) / 4 + 1;	/* about a wave per deferred slot at 1 % of them */
 	if (fblocks > 256 * 16)
 		fblocks = 256 * 16;
-	if (packed_input)
-		hipLaunchKernelGGL(k_front_stream_fix<true>, dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
-	else
-		hipLaunchKernelGGL(k_front_stream_fix<false>, dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
+#define FIX_LAUNCH(P, V) hipLaunchKernelGGL((k_front_stream_fix<P, V>), dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer)
+	const uint32_t view = TG_VIEW_OF(prm.chunk);	/* (the kernel built for this view) */
+	if (packed_input) {
+		if (view == 640) FIX_LAUNCH(true, 640); else if (view == 832) FIX_LAUNCH(true, 832); else FIX_LAUNCH(true, 1088);
+	} else {
+		if (view == 640) FIX_LAUNCH(false, 640); else if (view == 832) FIX_LAUNCH(false, 832); else FIX_LAUNCH(false, 1088);
+	}
+#undef FIX_LAUNCH
 	return (int)hipGetLastError();
 }
 
