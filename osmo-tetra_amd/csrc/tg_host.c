@@ -246,7 +246,7 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	 * rewrites that memory -- larger plans copy at load time and may be reloaded while an execute is in flight only
 	 * in so far as the copy is ordered behind it by the caller (include/tetra_gpu.h, tgpu_plan_load) */
 	p->up_mapped = max_slots <= TGPU_SMALL_PLAN;
-	if (hipHostMalloc((void **)&p->h_up, p->up_bytes, p->up_mapped ? hipHostMallocMapped : hipHostMallocDefault) != hipSuccess) {
+	if (hipHostMalloc((void **)&p->h_up, p->up_bytes, p->up_mapped ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault) != hipSuccess) {
 		p->h_up = NULL;
 		tgpu_plan_destroy(p);
 		return TGPU_ENOMEM;

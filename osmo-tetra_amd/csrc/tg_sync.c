@@ -316,8 +316,8 @@ int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unit
 	/* small batches are round trips: the bursts stay in pinned host memory, the kernels read them and write the
 	 * records in place over PCIe (no copy operations in a flush); larger ones go through device buffers */
 	ch->zero_copy = batch_slots <= 64;
-	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_slots, n * SLOT_STRIDE + 64, ch->zero_copy ? hipHostMallocMapped : 0);
-	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_rec, n * TGPU_REC_BYTES, ch->zero_copy ? hipHostMallocMapped : 0);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_slots, n * SLOT_STRIDE + 64, ch->zero_copy ? (hipHostMallocMapped | hipHostMallocCoherent) : 0);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ch->h_rec, n * TGPU_REC_BYTES, ch->zero_copy ? (hipHostMallocMapped | hipHostMallocCoherent) : 0);
 	if (ch->zero_copy) {
 		tgpi_plan_set_marks(ch->plan, 1);	/* records in mapped memory: wait_records() polls their completion marks */
 		if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ch->d_slots, ch->h_slots, 0);
@@ -332,7 +332,7 @@ int tgpu_channel_create(struct tgpu_engine *eng, uint32_t batch_slots, tgpu_unit
 		__atomic_sub_fetch(&ring_channels, 1, __ATOMIC_RELAXED);
 	else if (e == hipSuccess && ch->zero_copy && batch_slots <= TG_RING_MAX && tgi_option(TGPU_OPT_RING)) {
 		ch->ring_counted = 1;
-		e = hipHostMalloc((void **)&ch->h_ring, sizeof(*ch->h_ring), hipHostMallocMapped);
+		e = hipHostMalloc((void **)&ch->h_ring, sizeof(*ch->h_ring), hipHostMallocMapped | hipHostMallocCoherent);
 		if (e == hipSuccess) {
 			memset(ch->h_ring, 0, sizeof(*ch->h_ring));
 			e = hipHostGetDevicePointer((void **)&ch->d_ring, ch->h_ring, 0);
