@@ -214,16 +214,16 @@ def host_threads_default():
     return n
 
 
-def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1, damaged=0.01):  # noqa: D401
+def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1, damaged=0.01, ber=0.0):  # noqa: D401
     """config 3's stream: 100 random lead-in bits, a lock-only SB, n slots in frames of 8, 1 % damaged training
-    sequences, 700 pad bytes"""
+    sequences, 700 pad bytes; `ber` = bit error rate in the coded fields (the payload the trellis kernels decode)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     rng = np.random.default_rng(7 + seed)
     pat = np.array([3, 0, 1, 0, 1, 0, 1, 0], np.uint8)
     types = np.tile(pat, n // 8 + 1)[:n]
     code = (((mcc & 0x3ff) << 20) | ((mnc & 0x3fff) << 6) | (cc & 0x3f)) << 2 | 3
     slots = T.synth_slots(np.concatenate([[3], types]).astype(np.uint8), seed=11 + seed, scramb_init=code,
-                          mcc=mcc, mnc=mnc, cc=cc)
+                          mcc=mcc, mnc=mnc, cc=cc, ber=ber)
     bad = np.flatnonzero(rng.random(n) < damaged) + 1
     y = slots[0, 214:252].tolist()
     for i in bad:
@@ -247,25 +247,42 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     import collections
     n, C = args.bursts, max(1, args.channels)
     per = n // C
-    streams, codes = [], []
-    for c in range(C):
-        g = rank * C + c
-        st, _, code = make_mix_stream(T, per, g, mnc=42 + g, cc=1 + g % 60)
-        streams.append(st)
-        codes.append(code)
-    offs, o = [], 0
-    for st in streams:
-        offs.append(o)
-        o += (len(st) + T.STREAM_SLACK + 15) & ~15
-    buf = np.zeros(o + 4096, np.uint8)
-    for st, f in zip(streams, offs):
-        buf[f:f + len(st)] = st
+    D = max(2, args.depth)
+    # INPUT ROTATION (round 5): a receiver sees every byte once (tetra-rx.c:82-95), so the steps in flight must not read the
+    # same bytes -- NB distinct captures (own seed each: other payload bits, other damaged slots; the cells, and with them the
+    # channel table, are the same), step k decodes capture k % NB.  Default NB = steps in flight: no two concurrent front
+    # ends share a byte, and a capture comes round again only after NB x 510 MB of other input went through the caches.
+    NB = max(1, args.input_buffers if args.input_buffers > 0 else D)
+
+    def capture(b, ber):
+        """capture number b of this rank: C channel recordings in one buffer (16-byte aligned starts, slack behind each)"""
+        sts, cds = [], []
+        for c in range(C):
+            g = rank * C + c
+            st, _, code = make_mix_stream(T, per, g + 1000 * b, mnc=42 + g, cc=1 + g % 60, ber=ber)
+            sts.append(st)
+            cds.append(code)
+        fs, o = [], 0
+        for st in sts:
+            fs.append(o)
+            o += (len(st) + T.STREAM_SLACK + 15) & ~15
+        bb = np.zeros(o + 4096, np.uint8)
+        for st, f in zip(sts, fs):
+            bb[f:f + len(st)] = st
+        return sts, cds, fs, bb
+
+    streams, codes, offs, buf = capture(0, args.ber)
     eng = T.Engine(local)
     if args.walk_wide:
         T.set_option(T.OPT_WALK_WIDE, 1)
-    d_base = torch.from_numpy(buf).cuda()
+    d_bases = [torch.from_numpy(buf).cuda()]
+    for b in range(1, NB):
+        sts_b, cds_b, offs_b, buf_b = capture(b, args.ber)
+        assert cds_b == codes and offs_b == offs and [len(x) for x in sts_b] == [len(x) for x in streams]
+        d_bases.append(torch.from_numpy(buf_b).cuda())
+        del sts_b, buf_b
+    d_base = d_bases[0]
     cap = sum(len(st) // 510 + 32 for st in streams)
-    D = max(2, args.depth)
     K, R, W = args.steps, max(1, args.windows), max(args.warmup, 6 * D) + D     # (the first ~20 steps of a run are 4 % slower: clocks, queues filling)
     chans = T.multi_chan_table(streams, offs)         # carry-in codes 0: every cell's code is learnt from SB1 inside the batch
     D2 = D
@@ -307,43 +324,69 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             strm[j].synchronize()
             dist.gather(w.cpu(), gather_list=list(sink[j].view(world, -1)[:, :nbytes].unbind(0)) if rank == 0 else None, dst=0)
 
+    G = max(1, min(args.gather_every, D))              # compact form: steps whose blocks go to rank 0 in ONE exchange
+    batch = []                                         # collected steps waiting for their batch to fill: (bytes, buffer, step)
+    unposted = set()                                   # buffers of steps that are collected but not handed to the exchange yet
+    nposted = [0]
+
     def post_compact(evs):
-        """the oldest pending step: its sizes have been round the ranks (control plane: the gloo group), now the payload --
-        every rank's compact buffer to rank 0, exact sizes, grouped RCCL send / receive on the exchange's own stream"""
-        work, szs, mine, buf, slot = pend.popleft()
+        """the oldest pending batch: its sizes have been round the ranks (control plane: the gloo group), now the payload --
+        every rank's compact buffers of the batch's steps to rank 0, exact sizes, ONE grouped RCCL send / receive on the
+        exchange's own stream (tgpu_comm_gatherv_batch; a batch of one step = tgpu_comm_gatherv)"""
+        work, szs, items, slot = pend.popleft()
         work.wait()
-        sizes = [int(x.item()) for x in szs]
-        assert sizes[rank] == mine
-        state["sizes"], state["last_slot"] = sizes, slot
-        offs = [r * cwcap for r in range(world)]
+        sizes = [[int(szs[r][m].item()) for r in range(world)] for m in range(len(items))]
+        assert all(sizes[m][rank] == items[m][0] for m in range(len(items)))
+        offs_ = [[(m * world + r) * cwcap for r in range(world)] for m in range(len(items))]
+        state["sizes"], state["last_slot"], state["last_off"] = sizes[-1], slot, offs_[-1][0]
         if nccl and state["ccomm"] is not None:
-            state["ccomm"].gatherv(buf.data_ptr(), sizes, csink[slot].data_ptr() if rank == 0 else 0, offs if rank == 0 else None, 0,
-                                   cstream.cuda_stream)
+            if len(items) == 1:
+                state["ccomm"].gatherv(items[0][1].data_ptr(), sizes[0], csink[slot].data_ptr() if rank == 0 else 0,
+                                       offs_[0] if rank == 0 else None, 0, cstream.cuda_stream)
+            else:
+                state["ccomm"].gatherv_batch([it[1].data_ptr() for it in items], sizes, csink[slot].data_ptr() if rank == 0 else 0,
+                                             offs_ if rank == 0 else None, 0, cstream.cuda_stream)
         else:       # torch.distributed.gather wants one size: padded to the largest (nccl: --torch-gather; gloo: staged through the host)
-            m = (max(sizes) + 15) & ~15
-            with torch.cuda.stream(cstream):
-                if nccl:
-                    dist.gather(buf[:m], gather_list=list(csink[slot].view(world, -1)[:, :m].unbind(0)) if rank == 0 else None, dst=0)
-                else:
-                    cstream.synchronize()
-                    dist.gather(buf[:m].cpu(), gather_list=list(csink[slot].view(world, -1)[:, :m].unbind(0)) if rank == 0 else None, dst=0)
+            for m_, it in enumerate(items):
+                m = (max(sizes[m_]) + 15) & ~15
+                lst = list(csink[slot][offs_[m_][0]:offs_[m_][0] + world * cwcap].view(world, -1)[:, :m].unbind(0)) if rank == 0 else None
+                with torch.cuda.stream(cstream):
+                    if nccl:
+                        dist.gather(it[1][:m], gather_list=lst, dst=0)
+                    else:
+                        cstream.synchronize()
+                        dist.gather(it[1][:m].cpu(), gather_list=lst, dst=0)
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(cstream)
-        gdone[buf.data_ptr()] = ev
-        evs.append(ev)          # the step is complete when its blocks are on the collecting rank
+        for it in items:
+            gdone[it[1].data_ptr()] = ev
+            unposted.discard(it[1].data_ptr())
+            evs.append(ev)          # a step is complete when its blocks are on the collecting rank
 
-    def start_compact(ms, buf, k, evs):
-        """a collected step: its compact size starts its way round the ranks (asynchronous); the step before it is posted"""
-        assert ms.fellback or ms.cwire_bytes > 0
-        mine = int(ms.cwire_bytes)
-        szs = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        work = dist.all_gather(szs, torch.tensor([mine], dtype=torch.int64), group=gg, async_op=True)
-        pend.append((work, szs, mine, buf, k & 1))
+    def flush_batch(evs):
+        """the collected steps' compact sizes start their way round the ranks (asynchronous); the batch before is posted"""
+        items = batch[:]
+        del batch[:]
+        mine = torch.tensor([it[0] for it in items] + [0] * (G - len(items)), dtype=torch.int64)
+        szs = [torch.zeros(G, dtype=torch.int64) for _ in range(world)]
+        work = dist.all_gather(szs, mine, group=gg, async_op=True)
+        pend.append((work, szs, items, nposted[0] & 1))
+        nposted[0] += 1
         while len(pend) > 1:
             post_compact(evs)
 
-    def run(total, with_gather, D=D, S=None):
-        """`total` steps back to back, at most D in flight; returns (delivered bursts per step, completion events)"""
+    def start_compact(ms, buf, k, evs):
+        """a collected step joins the batch; a full batch is sent on its way"""
+        assert ms.fellback or ms.cwire_bytes > 0
+        batch.append((int(ms.cwire_bytes), buf, k))
+        unposted.add(buf.data_ptr())
+        if len(batch) == G:
+            flush_batch(evs)
+
+    def run(total, with_gather, D=D, S=None, bases=None):
+        """`total` steps back to back, at most D in flight, step k on capture k % len(bases); returns (delivered bursts per
+        step, completion events)"""
+        bases = bases or d_bases
         evs, fl, delivered = [], collections.deque(), []
         S = S or D           # (S < D: plan j runs on stream j % S -- a stream then holds its next batch before the host has collected the last)
         for k in range(total):
@@ -356,12 +399,17 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             buf = None
             if with_gather and compact:
                 buf = cws[j][(k // D) & 1]
+                if buf.data_ptr() in unposted:  # (a batch that has not gone out yet still holds this buffer: send it on its way now)
+                    if batch:
+                        flush_batch(evs)
+                    while pend:
+                        post_compact(evs)
                 if buf.data_ptr() in gdone:     # the gather that last read this buffer (2 D steps ago) must be through with it
                     gdone.pop(buf.data_ptr()).synchronize()
                 plans[j].set_cwire(buf.data_ptr(), cwcap)
             else:
                 plans[j].set_cwire(0)
-            fl.append((T.MultiSyncDev(eng, plans[j], None, d_base.data_ptr(), None, recs[j].data_ptr(), 64,
+            fl.append((T.MultiSyncDev(eng, plans[j], None, bases[k % len(bases)].data_ptr(), None, recs[j].data_ptr(), 64,
                                       strm[j % S].cuda_stream, chans=chans), buf, k))
             if with_gather and not compact:
                 exchange(j)
@@ -379,6 +427,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             if with_gather and compact:
                 start_compact(old[0], old[1], old[2], evs)
             delivered.append(finish(old[0]))
+        if batch:
+            flush_batch(evs)
         while pend:
             post_compact(evs)
         return delivered, evs
@@ -391,12 +441,13 @@ def bench_mix(args, T, torch, dist, rank, world, local):
 
     S0 = min(D, args.streams) if args.streams else None
 
-    def measure(with_gather, alone=False, D=D, W=W, S=S0, K=K, R=R):
+    def measure(with_gather, alone=False, D=D, W=W, S=S0, K=K, R=R, bases=None):
         """one continuous run of W + R K + D steps (the pipeline stays full before, through and after the timed steps);
         window r = completion of step W - 1 + r K  ->  completion of step W - 1 + (r + 1) K: exactly K classifications,
         K walks, K decodes (and K exchanges) complete inside it.  Plus the contract's form: K steps between two
         synchronisations (ramp-up and drain included)."""
-        run(max(D, K if not alone else D), with_gather, D, S)    # allocations, first-use paths, clocks
+        nb = len(bases or d_bases)
+        run(max(D, K if not alone else D), with_gather, D, S, bases)    # allocations, first-use paths, clocks
         if not alone:
             sync_all()
         else:
@@ -405,7 +456,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         gc.disable()          # (a collection of the interpreter's in the middle of the run is a multi-millisecond hole in one window)
         c0, t0, h0 = time.process_time(), time.perf_counter(), time.thread_time()
         try:
-            delivered, evs = run(W + R * K + D, with_gather, D, S)
+            delivered, evs = run(W + R * K + D, with_gather, D, S, bases)
         finally:
             gc.enable()
         torch.cuda.synchronize()
@@ -423,12 +474,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         tk = tk[D - 1:]
         if os.environ.get("BENCH_STEP_TIMES"):
             print("step completion deltas (ms), depth %d:" % D, [round(tk[i + 1] - tk[i], 3) for i in range(min(48, len(tk) - 1))], file=sys.stderr)
-        per_step = delivered[W]
-        assert all(x == per_step for x in delivered), "the same recording gave different numbers of bursts"
+        assert all(x == delivered[i % nb] for i, x in enumerate(delivered)), "the same recording gave different numbers of bursts"
+        per_step = sum(delivered[W:W + R * K]) / float(R * K)      # (captures differ in their damaged slots: the mean over the timed steps)
         if not alone:
             sync_all()
         t1 = time.perf_counter()
-        run(K, with_gather, D, S)
+        run(K, with_gather, D, S, bases)
         if not alone:
             sync_all()
         else:
@@ -441,7 +492,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             win, bracket = t[:-1].tolist(), float(t[-1].item())
             d = torch.tensor([float(per_step)], dtype=torch.float64, device=dev)
             dist.all_reduce(d, op=dist.ReduceOp.SUM)
-            tot = int(d.item())
+            tot = float(d.item())
         else:
             tot = per_step
         med = _median(win)
@@ -473,6 +524,25 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         buf = np.zeros((1 << 20, 3), np.uint64)
         T.lib().tgk_trace_read(buf.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nrec), 1)
         np.save(args.trace_dump, buf[:nrec.value])
+    # what the rotation is worth: the same run with every step in flight on ONE capture (rounds 1-4 measured this)
+    one_input = None
+    if world == 1 and not args.no_secondary and NB > 1:
+        one_input = measure(False, bases=[d_base], R=max(2, R // 2))
+    # the rate does not depend on the payload: the same run on captures with bit errors in the coded fields (own seeds), with
+    # its own oracle check of delivered records (below)
+    ber2 = ber2_streams = ber2_base = None
+    if world == 1 and not args.no_secondary and args.ber_secondary > 0:
+        bases2 = []
+        for b in range(max(1, min(NB, args.ber_buffers))):
+            sts_b, cds_b, offs_b, buf_b = capture(500 + b, args.ber_secondary)
+            assert cds_b == codes and offs_b == offs
+            bases2.append(torch.from_numpy(buf_b).cuda())
+            if b == 0:
+                ber2_streams = sts_b
+            del buf_b
+        ber2 = measure(False, bases=bases2, R=max(2, R // 2))
+        ber2_base = bases2[0]
+        del bases2
     # the round-3 form beside it: four batches in flight, each plan's side stream in play
     r3form = None
     if world == 1 and not args.no_secondary and not args.side_stream:
@@ -509,7 +579,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                     for _ in range(D)] if rank == 0 else [None] * D
             if compact:
                 cws = [[torch.zeros(cwcap, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in range(D)]
-                csink = [torch.zeros(world * cwcap, dtype=torch.uint8, device="cuda" if nccl else "cpu") for _ in range(2)] if rank == 0 else [None] * 2
+                csink = [torch.zeros(G * world * cwcap, dtype=torch.uint8, device="cuda" if nccl else "cpu") for _ in range(2)] if rank == 0 else [None] * 2
                 cstream = torch.cuda.Stream()
                 gg = dist.new_group(backend="gloo") if nccl else None      # the sizes' way round the ranks (control plane)
             state["impl"] = "torch.distributed.gather (gloo, staged through the host)"
@@ -540,6 +610,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                                  "a failed CRC) + the delivered bitmap; made on the device behind every step's decode (k_cw_*)" if compact else
                                  "grid: one 40-byte wire record per grid slot")
         gathered["bytes_per_rank_and_step"] = sent
+        gathered["steps_per_exchange"] = G if compact else 1
+        # one direction of one xGMI link (~77 GB/s) carries a peer's blocks to rank 0: the step cannot be shorter than that takes
+        gathered["link_bound"] = {"xgmi_one_direction_gbs": 77.0, "min_ms_per_step": sent / 77e9 * 1e3,
+                                  "max_per_gpu_efficiency": min(1.0, ref_ms / (sent / 77e9 * 1e3)),
+                                  "note": "bytes_per_rank_and_step over one direction of the peer's own link to rank 0; efficiency bound = the "
+                                          "single-GPU step time (%.3f ms) / that, capped at 1 -- whatever RCCL does, `gathered` cannot scale better" % ref_ms}
         if compact:
             gathered["bytes_per_rank_and_step_all_ranks"] = state["sizes"]
             gathered["bytes_per_delivered_burst"] = sent / (gathered["bursts_delivered_per_step"] / world)
@@ -549,6 +625,9 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                                        % (sent / 1e6, sent / 1e6 / ref_ms, ref_ms, sent / 1e6 / ref_ms / 77.0, sent / 1e6 / gathered["ms_per_step"],
                                           (world - 1) * sent / 1e6 / gathered["ms_per_step"], cap * T.WIRE_BYTES / 1e6,
                                           cap * T.WIRE_BYTES / 1e6 / ref_ms))
+    if gathered and NB > 1:     # the check below compares the collecting rank's copy with a step on capture 0: make that the last one gathered
+        run(D, True, D, S0, [d_base])
+        sync_all()
     if rank != 0:
         return None
     hs = torch.cuda.current_stream().cuda_stream
@@ -566,13 +645,16 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     handed_over = state["fellback"] + int(ms.fellback)
     check = None
     rec_all = recs[0].view(-1, T.REC_BYTES)
-    if not args.no_cpu_baseline:
-        # correctness guard on the timed output: delivered bursts of every channel against the oracle (checker only) --
-        # type-1 bits, BBK, CRC words and codes of up to 512 delivered grid slots per channel
+
+    def oracle_check(sts, outs_, with_wire):
+        """correctness guard on the timed output: delivered bursts of every channel against the oracle (checker only) --
+        type-1 bits, BBK, CRC words and codes of up to 512 delivered grid slots per channel; returns (bursts checked,
+        blocks whose CRC failed among them)"""
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oraclelib as O
-        nchk = 0
-        for c, (st, out) in enumerate(zip(streams, outs)):
+        nchk = nbad = 0
+        wgrid = None
+        for c, (st, out) in enumerate(zip(sts, outs_)):
             first = T.grid_indices(out)[:512]
             p = T.parse_records(rec_all[torch.from_numpy(out["grid_base"] + first).cuda()].cpu().numpy())
             anchor = out["anchor"]
@@ -587,11 +669,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                 (n1 | n2 | sb).all() and (p["code"][~sb] == codes[c]).all()
             assert good, "decoded records of channel %d differ from the oracle" % c
             nchk += len(first)
-            if gathered:        # ... and what arrived on the collecting rank is this rank's share, byte for byte
+            nbad += int((p["crc_ok"][:, 0] == 0).sum() + (p["crc_ok"][n2 | sb, 1] == 0).sum())
+            if with_wire:        # ... and what arrived on the collecting rank is this rank's share, byte for byte
                 idx = torch.from_numpy(out["grid_base"] + first)
-                if compact:     # (the timed steps decoded the same recording: rank 0's share of the last gather is this step's buffer)
+                if compact:     # (the last gathered step decoded capture 0: rank 0's share of that gather is this step's buffer)
                     if c == 0:
-                        got = csink[state["last_slot"]][:ms.cwire_bytes].cpu().numpy()
+                        got = csink[state["last_slot"]][state["last_off"]:state["last_off"] + ms.cwire_bytes].cpu().numpy()
                         mine_cw = cws[0][0][:ms.cwire_bytes].cpu().numpy()
                         assert ms.cwire_bytes == state["sizes"][0] and (got == mine_cw).all()
                         wgrid, _ = T.cwire_expand(got)
@@ -602,14 +685,28 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                 back = T.wire_unpack(w0[idx.to(w0.device)].cpu().numpy(), (out["grid_base"] + first).tolist(), [codes[c]] * len(first))
                 pw = T.parse_records(back)
                 assert (pw["bbk"] == p["bbk"]).all() and (pw["crc"][:, 0] == p["crc"][:, 0]).all()
+        return nchk, nbad
+
+    if not args.no_cpu_baseline:
+        nchk, _ = oracle_check(streams, outs, bool(gathered))
         check = "type-1 bits, BBK, CRC words and scrambling codes of %d delivered bursts (all %d channels) equal the oracle's%s" % (
             nchk, C, "; the same bursts' wire records on the collecting rank equal the sender's" if gathered else "")
+        if ber2:
+            plans[0].set_wire(0)
+            plans[0].set_cwire(0)
+            ms2 = T.MultiSyncDev(eng, plans[0], None, ber2_base.data_ptr(), None, recs[0].data_ptr(), 64, strm[0].cuda_stream, chans=chans)
+            outs2 = ms2.collect()
+            torch.cuda.synchronize()
+            n2_, bad2 = oracle_check(ber2_streams, outs2, False)
+            ber2["check"] = "type-1 bits, BBK, CRC words and codes of %d delivered bursts equal the oracle's (%d of their blocks fail the CRC on both sides)" % (n2_, bad2)
+            del ms2, outs2
+    ber2_base = ber2_streams = None
 
     # per-kernel durations: the same step with HIP events between all of its stages, on the launch stream
     prof = T.Prof(8)
     dev = []
     for q in range(8):
-        dev.append(T.sync_multi_launch_prof(eng, plans[1], chans, d_base.data_ptr(), recs[1].data_ptr(), prof, q, 64, hs))
+        dev.append(T.sync_multi_launch_prof(eng, plans[1], chans, d_bases[(7 - q) % NB].data_ptr(), recs[1].data_ptr(), prof, q, 64, hs))   # (the last pass leaves capture 0's records in recs[1])
     st_ms = prof.read(8)[2:].mean(axis=0)
     names = T.Prof.stage_names()
     kern_ms = {k: float(np.mean([x[k] for x in dev[2:]])) for k in dev[0]}
@@ -627,10 +724,14 @@ def bench_mix(args, T, torch, dist, rank, world, local):
            "k_vit<216>": n_n2 * (14 + 124 + 124 + 3 * 16) + n_sb * (14 + 124 + 2 * 16),
            "k_vit<432>": n_n1 * (14 + 268 + 2 * 16)}
     achieved = alg.get(dom, 0) / (kern_ms[dom] * 1e-3) / 1e9
-    traffic = valu_busy = valu_pipe = None
+    traffic = valu_busy = valu_pipe = traffic_prov = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        traffic = tj.get("mix", {}).get(dom)
+        # the pipelined configuration's own counters where they exist (mix_depth8: PMC passes of the run with 8 steps in flight
+        # on rotating captures), else the one-step-at-a-time passes
+        tsrc = "mix_depth8" if dom in tj.get("mix_depth8", {}) else "mix"
+        traffic = tj.get(tsrc, {}).get(dom)
+        traffic_prov = {"key": tsrc, "provenance": tj.get("_%s_provenance" % tsrc)}
         valu_busy = tj.get("mix_valu_busy", {}).get(dom)
         vi = tj.get("mix_valu_insts_per_step")
         if vi:      # the whole pipelined step against what 1024 SIMDs can issue: every wave instruction at its 4-cycle minimum
@@ -862,11 +963,14 @@ def bench_mix(args, T, torch, dist, rank, world, local):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
            "config": {"workload": "SB+NDB mix through the burst-sync front end (BASELINE configs[2] composition in configs[3]'s layout): "
                                   "per GPU %d recorded channels of %d slots each (own cell each), frames [SB,N1,N2,N1,N2,N1,N2,N1], cell "
-                                  "code from SB1, 1%% damaged training sequences, resident in HBM; step = one pass over all of a GPU's "
+                                  "code from SB1, 1%% damaged training sequences, payload BER %g (bit errors in the coded fields), %d distinct "
+                                  "captures resident in HBM (own seed each; step k decodes capture k mod %d, so steps in flight never read "
+                                  "the same bytes); step = one pass over all of a GPU's "
                                   "channels as ONE batch (GPU sequence search + demux of every grid slot, the synchroniser walks of "
                                   "all channels on the GPU at 64-byte feeds, device lists, SB1 / fill / masks / trellis); value = "
                                   "delivered bursts/s%s; one host thread per GPU, %d steps in flight" %
-                                  (C, per, ", every step's decoded blocks gathered to rank 0 (40-B wire records, RCCL)" if gathered else "", D),
+                                  (C, per, args.ber, NB, NB, ", every step's decoded blocks gathered to rank 0 (40-B wire records, RCCL)" if gathered else "", D),
+                      "payload_ber": args.ber, "input_buffers": NB, "input_bytes_resident_per_gpu": int(sum(x.numel() for x in d_bases)),
                       "channels_per_gpu": C, "slots_per_channel": per, "grid_slots_per_step": int(ngrid),
                       "delivered_per_step": int(nd), "host_threads_per_gpu": 1, "steps_in_flight": D,
                       "batches_handed_to_the_host_walk": handed_over,
@@ -893,6 +997,10 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                         "kernel_ms": kern_ms[dom],
                         "pipeline_achieved_gbs_per_gpu": float(decode_only["value"] / world * 820 / 1e9),
                         "pipeline_vector_issue": valu_pipe,
+                        "measured_in_this_run": ["achieved", "frac", "kernel_ms", "pipeline_achieved_gbs_per_gpu"],
+                        "read_from_profiles/traffic.json (rocprofv3 PMC passes of this command, committed; NOT measured by this run)":
+                            ["traffic", "valu_busy_frac", "pipeline_vector_issue.wave_instructions_per_step", "pipeline_vector_issue.sclk_ghz"],
+                        "traffic_provenance": traffic_prov,
                         "note": "achieved = the dominant kernel's share of SURVEY 8(d)'s algorithmic bytes (k_front_stream: the 510 "
                                 "input bytes of every grid slot; a trellis kernel: type-1 bits at 1 B/bit + 16 B per block of the "
                                 "bursts it decodes) / its mean HIP-event duration on its launch stream, measured after the timed "
@@ -904,6 +1012,14 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         out["round3_form"]["note"] = ("the same measurement as round 3 ran it: 4 batches in flight and the plans' side streams in play (k_vit<432> beside "
                                       "k_vit<216>, the SB1 decode beside the walk): 12 streams on the runtime's 4 hardware queues, batches spread unevenly "
                                       "over them; host_cpu_ms_per_step includes a runtime thread that spins on the cross-stream events")
+    if one_input:
+        out["one_input_buffer"] = {k_: one_input[k_] for k_ in ("value", "ms_per_step", "windows_ms_per_step", "window_spread")}
+        out["one_input_buffer"]["note"] = ("the same run with all %d steps in flight reading ONE capture (what rounds 1-4 reported): the difference to "
+                                           "`value` is what a shared input was worth in L2 / Infinity Cache hits" % D)
+    if ber2:
+        out["ber_%g" % args.ber_secondary] = {k_: ber2[k_] for k_ in ("value", "ms_per_step", "windows_ms_per_step", "window_spread", "bursts_delivered_per_step", "check") if k_ in ber2}
+        out["ber_%g" % args.ber_secondary]["note"] = ("the same run on %d other captures with bit error rate %g in the coded fields: the rate is independent "
+                                                      "of the payload (a Viterbi and a CRC do the same work whatever the bits)" % (max(1, min(NB, args.ber_buffers)), args.ber_secondary))
     if sustained:
         out["sustained"] = sustained
     if e2e:
@@ -917,7 +1033,13 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         out["single_gpu_reference"] = single
         out["per_gpu_efficiency"] = {"decode_only": decode_only["value"] / world / single["value"],
                                      "gathered": (gathered["value"] / world / single["value"]) if gathered else None,
-                                     "note": "per-GPU rate / the rate of rank 0 running alone in this same job (single_gpu_reference)"}
+                                     "gathered_link_bound": gathered["link_bound"]["max_per_gpu_efficiency"] if gathered else None,
+                                     "scaling_claim": "decode_only",
+                                     "note": "per-GPU rate / the rate of rank 0 running alone in this same job (single_gpu_reference).  The scaling "
+                                             "claim of this path is decode_only: channels shard with no exchange (the reference runs one process per "
+                                             "channel, src/receiver1).  `gathered` ships EVERY step's decoded blocks of every rank to rank 0 -- an "
+                                             "aggregation the reference does not have -- and is bound by one xGMI link per peer (gathered_link_bound), "
+                                             "not by the decode"}
     return out
 
 
@@ -1320,7 +1442,10 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="mix: streams the steps in flight run on (0 = one per step in flight; fewer: "
                                                            "plan j runs on stream j %% streams)")
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts (slots) per GPU per step")
-    ap.add_argument("--ber", type=float, default=0.0)
+    ap.add_argument("--ber", type=float, default=0.0, help="bit error rate in the coded fields of the synthetic captures (mix: the headline's captures)")
+    ap.add_argument("--input-buffers", type=int, default=0, help="mix: distinct captures resident per GPU, step k decodes capture k %% N (0 = one per step in flight)")
+    ap.add_argument("--ber-secondary", type=float, default=0.02, help="mix: payload BER of the secondary run (ber_<x> in the line; 0 = skip)")
+    ap.add_argument("--ber-buffers", type=int, default=3, help="mix: distinct captures of the secondary BER run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 object of the default run")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (host buffer -> H2D -> step -> D2H -> callback)")
@@ -1338,6 +1463,9 @@ def main():
     ap.add_argument("--wire-form", default="compact", choices=["compact", "grid"],
                     help="what a rank hands to the gather: the compact form (delivered bursts only, csrc/tg_cwire.h) or one 40-byte "
                          "wire record per grid slot")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1, compact form: the decoded blocks of this many steps go to rank 0 in ONE exchange (one RCCL group = one "
+                         "launch per rank; at most the steps in flight).  1 = an exchange behind every step")
     ap.add_argument("--torch-gather", action="store_true",
                     help="N > 1: exchange through torch.distributed.gather instead of the library's tgpu_comm_gather")
     ap.add_argument("--gather-timeout", type=int, default=150,
@@ -1410,7 +1538,7 @@ def main():
         if rank == 0 and world == 1:
             if not args.no_cpu_baseline:
                 # channel 0 of rank 0 as the timed run had it (the generator is deterministic)
-                stream, _, _ = make_mix_stream(T, args.bursts // max(1, args.channels), 0, mnc=42, cc=1)
+                stream, _, _ = make_mix_stream(T, args.bursts // max(1, args.channels), 0, mnc=42, cc=1, ber=args.ber)
                 out["cpu_baseline"] = cpu_baseline_stream(stream)
             if not args.no_secondary:
                 c2 = bench_config2(args, T, torch, dist, rank, world, local, 40, 10, with_cpu=False)

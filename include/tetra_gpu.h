@@ -269,8 +269,10 @@ int tgpu_wire_pack(const uint8_t *rec, uint8_t *wire);
  *   tgpu_plan_set_cwire()   device-walk batches (tgpu_sync_multi_launch) of this plan leave the compact form of their wire
  *                           records (tgpu_plan_set_wire() must be set too) in d_cwire (16-byte aligned), enqueued behind
  *                           the decode; tgpu_sync_dev_cwire_bytes() after tgpu_sync_multi_collect() = the bytes to send
- *                           (0: no compact form was made -- no cwire buffer, an empty grid, or the batch fell back to the
- *                           host walks, whose decode does not redo it: use tgpu_wire_compact() with the bitmap of the outcome)
+ *                           (0: no compact form was made -- no cwire buffer, an empty grid, a buffer smaller than the batch
+ *                           needed (cap_bytes may be less than tgpu_cwire_bound(); tgpu_sync_dev_cwire_needed() then says how
+ *                           much it takes), or the batch fell back to the host walks, whose decode does not redo it: use
+ *                           tgpu_wire_compact() with the bitmap of the outcome)
  *   tgpu_wire_compact()     the same for any batch: d_wire = ngrid 40-byte records, d_grid_bits = its delivered bitmap
  *                           (device), channel c = grid slots gbase[c] .. gbase[c] + ncls[c] - 1 (gbase multiples of 32,
  *                           ascending, <= 64 channels); d_total (optional, device): two words -- the bytes the batch needs
@@ -318,6 +320,11 @@ int tgpu_comm_gather(struct tgpu_comm *comm, const void *d_send, size_t nbytes, 
  * How the sizes reach the root is the job's business, like the id (they are known after tgpu_sync_multi_collect()). */
 int tgpu_comm_gatherv(struct tgpu_comm *comm, const void *d_send, const size_t *nbytes, void *d_recv, const size_t *offs, int root,
 		      void *hip_stream);
+/* nmsg of those in ONE exchange (the decoded blocks of nmsg steps gathered together: north star's "final" gather; one RCCL
+ * group = one launch per rank, whatever nmsg): message m's rank-r share (nbytes[m * world + r] bytes at d_send[m] on rank r)
+ * arrives at the root's d_recv + offs[m * world + r]. */
+int tgpu_comm_gatherv_batch(struct tgpu_comm *comm, int nmsg, const void *const *d_send, const size_t *nbytes, void *d_recv,
+			    const size_t *offs, int root, void *hip_stream);
 void tgpu_comm_destroy(struct tgpu_comm *comm);
 
 /* diagnostic: copy the front kernel's packed slots (20 dwords per slot, csrc/tg_layout.h) of the
@@ -611,7 +618,8 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
  * and the packed form cannot show them), or a negative TGPU_E* code.  tgpu_sync_multi_launch_packed() is
  * tgpu_sync_multi_launch() on such a buffer: d_packed_base = the packed streams on the device, ch[c].d_off = the BIT offset
  * of channel c's position 0 in it (a multiple of 8), ch[c].h_stream / len = the unpacked host bytes as before (the first
- * lock of a channel is found on the host).  The buffer needs 512 readable bytes behind the last channel's last bit.
+ * lock of a channel is found on the host).  d_packed_base must be 16-byte aligned (TGPU_EINVAL otherwise: groups are fetched
+ * from 16-byte aligned addresses counted from it) and needs 512 readable bytes behind the last channel's last bit.
  * Everything downstream is the same kernels on the same bits: records are byte-identical to the byte path's.
  */
 int64_t tgpu_pack_bits(const uint8_t *bytes, uint64_t n, uint8_t *packed /* (n + 7) / 8 bytes */, unsigned int nthreads);
@@ -626,6 +634,9 @@ int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd);
  * form's length that found no place in the long form */
 int tgpu_sync_dev_why(const struct tgpu_sync_dev *sd, uint32_t chan);
 uint64_t tgpu_sync_dev_cwire_bytes(const struct tgpu_sync_dev *sd);	/* after collect; tgpu_plan_set_cwire() */
+/* after collect: non-zero when the buffer given to tgpu_plan_set_cwire() was too small for this batch -- the bytes it needs
+ * (tgpu_sync_dev_cwire_bytes() is 0 then and the buffer holds no records; the batch itself is complete and collect returns OK) */
+uint64_t tgpu_sync_dev_cwire_needed(const struct tgpu_sync_dev *sd);
 void tgpu_sync_dev_free(struct tgpu_sync_dev *sd);
 /* measurement aid: one such batch, synchronously, with HIP events between all of its stages on hip_stream: dev_ms[] =
  * the stages in front of the decode (names: tgpu_sync_dev_stage_name), the decode's stages in prof / step as

@@ -160,6 +160,7 @@ def lib():
     L.tgpu_comm_destroy.argtypes = [C.c_void_p]
     L.tgpu_comm_destroy.restype = None
     L.tgpu_comm_gatherv.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]
+    L.tgpu_comm_gatherv_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]
     L.tgpu_cwire_bound.restype = C.c_uint64
     L.tgpu_cwire_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.tgpu_plan_set_cwire.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -174,6 +175,8 @@ def lib():
     L.tgpu_cwire_expand.argtypes = [u8p, C.c_size_t, u8p, u32p]
     L.tgpu_sync_dev_cwire_bytes.restype = C.c_uint64
     L.tgpu_sync_dev_cwire_bytes.argtypes = [C.c_void_p]
+    L.tgpu_sync_dev_cwire_needed.restype = C.c_uint64
+    L.tgpu_sync_dev_cwire_needed.argtypes = [C.c_void_p]
     L.tgpu_plan_execute_float_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.tgpu_prof_read.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.tgpu_stage_name.restype = C.c_char_p
@@ -416,6 +419,15 @@ class Comm:
         of = (C.c_size_t * len(nbytes))(*[int(x) for x in offs]) if offs is not None else None
         _chk(lib().tgpu_comm_gatherv(self._h, C.c_void_p(d_send_ptr), nb, C.c_void_p(d_recv_ptr), of, root, C.c_void_p(hip_stream)),
              "tgpu_comm_gatherv")
+
+    def gatherv_batch(self, d_send_ptrs, nbytes, d_recv_ptr, offs, root=0, hip_stream=0):
+        """len(d_send_ptrs) messages in one exchange: nbytes / offs are [message][rank]"""
+        m, w = len(d_send_ptrs), self.world
+        ptrs = (C.c_void_p * m)(*[int(x) for x in d_send_ptrs])
+        nb = (C.c_size_t * (m * w))(*[int(x) for row in nbytes for x in row])
+        of = (C.c_size_t * (m * w))(*[int(x) for row in offs for x in row]) if offs is not None else None
+        _chk(lib().tgpu_comm_gatherv_batch(self._h, m, ptrs, nb, C.c_void_p(d_recv_ptr), of, root, C.c_void_p(hip_stream)),
+             "tgpu_comm_gatherv_batch")
 
     def gather(self, d_send_ptr, nbytes, d_recv_ptr, root=0, hip_stream=0):
         _chk(lib().tgpu_comm_gather(self._h, C.c_void_p(d_send_ptr), nbytes, C.c_void_p(d_recv_ptr or 0), root,
@@ -813,6 +825,12 @@ class MultiSyncDev:
             self.fellback = bool(lib().tgpu_sync_dev_fellback(self._h))
             self.why = [int(lib().tgpu_sync_dev_why(self._h, c)) for c in range(n)] if self.fellback else [0] * n
             self.cwire_bytes = int(lib().tgpu_sync_dev_cwire_bytes(self._h))
+            self.cwire_needed = int(lib().tgpu_sync_dev_cwire_needed(self._h))
+        except Exception:
+            for c in range(n):          # (the C side hands back nothing half-filled with an error; whatever is there goes)
+                lib().tgpu_sync_result_free(C.byref(self._res[c]))
+            self._res = None
+            raise
         finally:
             lib().tgpu_sync_dev_free(self._h)
             self._h = C.c_void_p()

@@ -177,6 +177,36 @@ int tgpu_comm_gatherv(struct tgpu_comm *c, const void *d_send, const size_t *nby
 	return (e == ncclSuccess && e2 == ncclSuccess) ? TGPU_OK : TGPU_ECOMM;
 }
 
+int tgpu_comm_gatherv_batch(struct tgpu_comm *c, int nmsg, const void *const *d_send, const size_t *nbytes, void *d_recv,
+			    const size_t *offs, int root, void *hip_stream)
+{
+	if (!c || nmsg < 0 || (nmsg && (!d_send || !nbytes)) || root < 0 || root >= c->world || (nmsg && c->rank == root && (!d_recv || !offs)))
+		return TGPU_EINVAL;
+	if (!nmsg)
+		return TGPU_OK;
+	for (int m = 0; m < nmsg; m++)
+		if (nbytes[(size_t)m * c->world + c->rank] && !d_send[m])
+			return TGPU_EINVAL;
+	int r = tgpi_engine_bind(c->eng);
+	if (r)
+		return r;
+	hipStream_t s = (hipStream_t)hip_stream;
+	/* ONE group for all the messages: the sends and receives between a pair of ranks are matched in the order they are
+	 * issued (message by message on both sides), and the group is one launch on every rank */
+	ncclResult_t e = rc.group_start();
+	for (int m = 0; m < nmsg && e == ncclSuccess; m++) {
+		const size_t *nb = nbytes + (size_t)m * c->world;
+		if (c->rank == root)
+			for (int p = 0; p < c->world && e == ncclSuccess; p++)
+				if (nb[p])
+					e = rc.recv((uint8_t *)d_recv + offs[(size_t)m * c->world + p], nb[p], ncclUint8, p, c->comm, s);
+		if (e == ncclSuccess && nb[c->rank])
+			e = rc.send(d_send[m], nb[c->rank], ncclUint8, root, c->comm, s);
+	}
+	ncclResult_t e2 = rc.group_end();
+	return (e == ncclSuccess && e2 == ncclSuccess) ? TGPU_OK : TGPU_ECOMM;
+}
+
 void tgpu_comm_destroy(struct tgpu_comm *c)
 {
 	if (!c)

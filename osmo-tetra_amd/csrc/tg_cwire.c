@@ -113,6 +113,29 @@ int tgpu_cwire_info(const uint8_t *cw, size_t nbytes, struct tgpu_cwire_info *ou
 	tg_cw_offsets(hdr[1], hdr[2], &L);
 	if (hdr[5] != L.o_bits || hdr[6] != L.o_blk || hdr[7] != L.o_rec || hdr[3] < L.o_rec || hdr[3] > nbytes)
 		return TGPU_EINVAL;
+	/* this reader checks a buffer that came over a link: nothing in it is trusted.  Records are padded to dwords per
+	 * bitmap word, so the record area is a whole number of dwords; no delivered bit at or above ngrid; the channel table
+	 * names slot ranges inside the grid, in order, with ordinals and record offsets that do not run backwards */
+	if ((hdr[3] - L.o_rec) & 3u)
+		return TGPU_EINVAL;
+	if ((hdr[2] & 31u) && L.nwords) {
+		uint32_t last;
+		memcpy(&last, cw + L.o_bits + 4 * (size_t)(L.nwords - 1), 4);
+		if (last >> (hdr[2] & 31u))
+			return TGPU_EINVAL;
+	}
+	uint64_t end = 0;
+	uint32_t ord = 0, off = 0;
+	for (uint32_t c = 0; c < hdr[1]; c++) {
+		uint32_t e[4];
+		memcpy(e, cw + TG_CW_HDR_WORDS * 4 + 16 * (size_t)c, sizeof(e));
+		if ((e[0] & 31u) || e[0] < end || (uint64_t)e[0] + e[1] > hdr[2] || e[2] < ord || e[2] > hdr[4] || e[3] < off ||
+		    e[3] > hdr[3] - L.o_rec)
+			return TGPU_EINVAL;
+		end = (uint64_t)e[0] + e[1];
+		ord = e[2];
+		off = e[3];
+	}
 	out->nchan = hdr[1];
 	out->ngrid = hdr[2];
 	out->total_bytes = hdr[3];
@@ -160,6 +183,8 @@ int64_t tgpu_cwire_foreach(const uint8_t *cw, size_t nbytes, tgpu_wire_cb cb, vo
 		memcpy(&z, cw + L.o_bits + 4 * (size_t)wd, 4);
 		for (; z; z &= z - 1) {
 			uint32_t w[TG_WIRE_WORDS];
+			if (o >= rbytes)	/* (more delivered bits than records) */
+				return TGPU_EINVAL;
 			const uint32_t size = tg_cw_decode(rec + o, rbytes - o, w);
 			if (!size)
 				return TGPU_EINVAL;
@@ -169,6 +194,8 @@ int64_t tgpu_cwire_foreach(const uint8_t *cw, size_t nbytes, tgpu_wire_cb cb, vo
 			n++;
 		}
 		o = (o + 3) & ~(size_t)3;
+		if (o > rbytes)
+			return TGPU_EINVAL;
 	}
 	if (o != rbytes || n != (int64_t)in.ndelivered)
 		return TGPU_EINVAL;

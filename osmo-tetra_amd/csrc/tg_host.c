@@ -22,6 +22,7 @@
 #include "tetra_gpu.h"
 #include "tg_layout.h"
 #include "tg_internal.h"
+#include "tg_cwire.h"
 
 struct tgpu_engine {
 	int device;
@@ -1334,6 +1335,17 @@ int tgpi_plan_cwire(struct tgpu_plan *p, const struct tg_cw_chans *ch, uint32_t 
 	if (!p->d_cwire || !p->d_wire || !p->d_bits_dev || !p->nslots)
 		return TGPU_OK;
 	BIND(p->eng);
+	/* the kernels write the header, the channel table, the bitmap and the block table without asking: a buffer that does not
+	 * hold those (plus one record row) is not touched at all -- the batch reports the shortfall like any other (total 0 = not
+	 * computed, marker 0xffffffff: tgpu_sync_multi_collect() returns TGPU_ECAPACITY) */
+	struct tg_cw_layout L;
+	tg_cw_offsets(ch->n, p->nslots, &L);
+	if (p->cwire_cap < (size_t)L.o_rec + 16) {
+		if (!d_total)
+			return TGPU_ECAPACITY;
+		static const uint32_t shortfall[2] = { 0u, 0xffffffffu };
+		return (int)hipMemcpyAsync(d_total, shortfall, sizeof(shortfall), hipMemcpyHostToDevice, (hipStream_t)stream);
+	}
 	return tgk_cwire(p->d_wire, p->d_bits_dev, p->nslots, ch, p->d_cwire, (uint32_t)p->cwire_cap, d_total, stream);
 }
 

@@ -1262,7 +1262,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			break;
 		g = gA;
 	}
-	TG_TRACE_END(0u, 4u / TG_STREAM_WPB);
+	TG_TRACE_END(0u, (TG_STREAM_WPB <= 4 ? 4u / TG_STREAM_WPB : 1u));
 #ifdef TGS_TIMING
 	if (lane == 0)
 		for (int i = 0; i < 8; i++)

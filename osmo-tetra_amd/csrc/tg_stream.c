@@ -1374,6 +1374,7 @@ struct tgpu_sync_dev {
 	int fellback;
 	int cwire;		/* the compact transport form was enqueued behind the decode (tgpu_plan_set_cwire) */
 	uint64_t cwire_bytes;	/* ... its size, known after collect */
+	uint64_t cwire_needed;	/* ... or, when the caller's buffer was too small, the bytes it would have taken */
 };
 
 void tgpu_sync_dev_free(struct tgpu_sync_dev *sd)
@@ -1401,6 +1402,10 @@ int tgpu_sync_multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint
 int tgpu_sync_multi_launch_packed(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_t nchan, const struct tgpu_multi_chan *ch,
 				  const uint8_t *d_packed_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *stream)
 {
+	/* the front end fetches a group from the 16-byte aligned address below its first byte, counted from the buffer's start: a
+	 * base that is not 16-byte aligned itself (a sub-buffer) would be read up to 15 bytes in front of it */
+	if ((uintptr_t)d_packed_base & 15)
+		return TGPU_EINVAL;
 	if (ch)
 		for (uint32_t c = 0; c < nchan; c++)
 			if (ch[c].d_off & 7)
@@ -1621,6 +1626,11 @@ uint64_t tgpu_sync_dev_cwire_bytes(const struct tgpu_sync_dev *sd)
 	return sd ? sd->cwire_bytes : 0;
 }
 
+uint64_t tgpu_sync_dev_cwire_needed(const struct tgpu_sync_dev *sd)
+{
+	return sd ? sd->cwire_needed : 0;
+}
+
 int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *out)
 {
 	if (!sd || !out)
@@ -1739,8 +1749,11 @@ int tgpu_sync_multi_collect(struct tgpu_sync_dev *sd, struct tgpu_sync_result *o
 	if (!rc && st->ngrid)
 		tgpi_plan_set_final_codes(st->plan, sd->io.h_final, st->nchan);
 	if (!rc && st->ngrid && sd->cwire) {
+		/* the buffer given to tgpu_plan_set_cwire() may be smaller than tgpu_cwire_bound(); a batch that needed more is a
+		 * valid batch all the same (records, bitmap, events are the caller's): it has no compact form (cwire_bytes 0) and
+		 * says what it would have taken */
 		if (sd->io.h_final[67] == 0xffffffffu)
-			rc = TGPU_ECAPACITY;	/* the buffer given to tgpu_plan_set_cwire() is smaller than tgpu_cwire_bound() and this batch needed more */
+			sd->cwire_needed = sd->io.h_final[66] ? sd->io.h_final[66] : tgpu_cwire_bound(st->ngrid, st->nchan);
 		else
 			sd->cwire_bytes = sd->io.h_final[66];
 	}

@@ -167,6 +167,7 @@ struct tgpu_channel {
 	struct tg_ring_box *d_box;
 	hipStream_t rstream;		/* the kernel's own stream */
 	uint32_t ring_seq, ring_launches;
+	int ring_fails;		/* flushes in a row the ring did not answer (ring_failed()) */
 	int ring_counted;		/* this channel is one of RING_MAX_CHANNELS */
 
 	/* block queue of the tp_sap_udata_ind() seam (allocated on first use) */
@@ -242,6 +243,19 @@ static void ring_stop(struct tgpu_channel *ch)
 	}
 	(void)hipStreamSynchronize(ch->rstream);
 	ch->ring = 0;
+}
+
+/* a flush the ring did not answer in time.  The protocol assumes that all of a channel's workgroups (up to four, 43 KB of LDS
+ * each) are RESIDENT together -- they meet at a spin barrier -- which a GPU saturated by other work does not promise: the
+ * workgroups are told to leave, this batch goes by launch, and the next flush starts them again.  Only a ring that fails
+ * RING_MAX_FAILS flushes in a row is given up for good. */
+#define RING_MAX_FAILS 4
+static void ring_failed(struct tgpu_channel *ch)
+{
+	const int give_up = ++ch->ring_fails >= RING_MAX_FAILS;
+	ring_stop(ch);
+	if (!give_up)
+		ch->ring = 1;
 }
 
 /* one flush through the ring: 1 = every record complete; 0 = given up (the caller decodes the batch the ordinary way) */
@@ -606,8 +620,10 @@ static int flush_slots(struct tgpu_channel *ch)
 	int ringed = 0;
 	if (ch->ring && n <= TG_RING_MAX) {	/* (the workgroups that stay need nothing of the plan but its scratch arrays: no load) */
 		ringed = ring_flush(ch, n);
-		if (!ringed) {		/* the ring has failed: without it from now on, this batch included */
-			ring_stop(ch);
+		if (ringed)
+			ch->ring_fails = 0;
+		if (!ringed) {		/* the ring did not answer: this batch by launch (ring_failed() says what happens next) */
+			ring_failed(ch);
 			for (uint32_t i = 0; i < n; i++)
 				ch->h_rec[(size_t)i * TGPU_REC_BYTES + TG_REC_TYPE] = TG_REC_PENDING;
 		}

@@ -99,6 +99,71 @@ def test_record_sizes_of_the_mix():
     assert (w3 == wire2).all()
 
 
+def test_reader_refuses_damaged_buffers_without_touching_memory_beyond_them():
+    """the reader runs on a buffer that came over a link: delivered bits at or above ngrid, a size that is not a whole
+    number of dwords behind the tables, a channel table outside the grid, random damage anywhere -- every call returns
+    (an error or a consistent parse) and writes nothing outside ngrid x 40 bytes of the caller's array (guard rows)"""
+    import ctypes as C
+    T = _T()
+    L = T.lib()
+    u8p = C.POINTER(C.c_uint8)
+    rng = np.random.default_rng(5)
+
+    def expand_guarded(cw, ngrid):
+        guard = 64
+        arr = np.full((ngrid + 2 * guard) * T.WIRE_BYTES, 0xa5, np.uint8)
+        body = arr[guard * T.WIRE_BYTES:(guard + ngrid) * T.WIRE_BYTES]
+        rc = L.tgpu_cwire_expand(cw.ctypes.data_as(u8p), len(cw), body.ctypes.data_as(u8p), None)
+        assert (arr[:guard * T.WIRE_BYTES] == 0xa5).all() and (arr[(guard + ngrid) * T.WIRE_BYTES:] == 0xa5).all(), "wrote outside the grid"
+        return rc
+
+    # the advisor's case: ngrid = 33, bit 63 of the bitmap set
+    ngrid, gbase, ncls = 33, [0], [33]
+    wire, bits, dl = _random_batch(T, rng, ngrid, gbase, ncls, p_deliv=1.0)
+    cw = T.cwire_pack(wire, bits, ngrid, gbase, ncls)
+    hdr = np.frombuffer(cw[:32].tobytes(), np.uint32)
+    o_bits = int(hdr[5])
+    bad = cw.copy()
+    bad[o_bits + 7] |= 0x80
+    assert expand_guarded(bad, ngrid) != 0
+    with pytest.raises(T.TgpuError):
+        T.cwire_info(bad)
+    # a total that leaves the record area a non-multiple of 4 (with the bytes to back it)
+    bad = np.concatenate([cw, np.zeros(8, np.uint8)])
+    bad[12:16] = np.frombuffer(np.uint32(len(cw) + 1).tobytes(), np.uint8)
+    assert expand_guarded(bad, ngrid) != 0 and L.tgpu_cwire_foreach(bad.ctypes.data_as(u8p), len(bad), None, None) < 0
+    # a channel table that leaves the grid / runs backwards
+    ngrid, gbase, ncls = 4096, [0, 2048], [2048, 2048]
+    wire, bits, dl = _random_batch(T, rng, ngrid, gbase, ncls)
+    cw = T.cwire_pack(wire, bits, ngrid, gbase, ncls)
+    for word, val in ((32 + 16 + 4, 4096), (32 + 16, 0x7fffffe0), (32 + 16, 32), (32 + 8, 0xffffffff), (32 + 16 + 12, 0xfffffff0)):
+        bad = cw.copy()
+        bad[word:word + 4] = np.frombuffer(np.uint32(val).tobytes(), np.uint8)
+        with pytest.raises(T.TgpuError):
+            T.cwire_info(bad)
+    # random damage: single bytes, whole dwords in the tables, truncation -- never a write outside, never a crash
+    refused = 0
+    for it in range(3000):
+        bad = cw.copy()
+        kind = it % 3
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                bad[int(rng.integers(0, len(bad)))] = rng.integers(0, 256)
+        elif kind == 1:
+            o = 4 * int(rng.integers(0, int(hdr_o_rec(cw)) // 4))
+            bad[o:o + 4] = rng.integers(0, 256, 4)
+        else:
+            bad = bad[:int(rng.integers(0, len(bad)))].copy()
+        rc = expand_guarded(bad, ngrid) if len(bad) >= 32 and np.frombuffer(bad[8:12].tobytes(), np.uint32)[0] == ngrid else \
+            L.tgpu_cwire_foreach(bad.ctypes.data_as(u8p), len(bad), None, None)
+        refused += rc != 0 if kind != 2 else rc < 0 or rc != int(dl.sum())
+    assert refused > 1000
+
+
+def hdr_o_rec(cw):
+    return np.frombuffer(cw[28:32].tobytes(), np.uint32)[0]
+
+
 # ----------------------------------------------------------------------------------------------------------------
 gpu = pytest.mark.gpu
 
@@ -182,22 +247,22 @@ def _batch(T, streams):
     return torch.from_numpy(buf).cuda(), offs, sum((len(st) // 510 + 32) for st in streams)
 
 
-def _run_with_cwire(T, eng, streams, wire_only=False):
+def _run_with_cwire(T, eng, streams, wire_only=False, cap=None, guard=0):
     import torch
     hs = torch.cuda.current_stream().cuda_stream
     d, offs, ntot = _batch(T, streams)
     plan = T.Plan(eng, ntot, len(streams))
     d_rec = torch.zeros(ntot * T.REC_BYTES, dtype=torch.uint8, device="cuda")
     d_wire = torch.full((ntot * T.WIRE_BYTES,), 0xff, dtype=torch.uint8, device="cuda")
-    cap = T.cwire_bound(ntot, len(streams))
-    d_cw = torch.full((cap,), 0xCD, dtype=torch.uint8, device="cuda")
+    cap = cap or T.cwire_bound(ntot, len(streams))
+    d_cw = torch.full((cap + guard,), 0xCD, dtype=torch.uint8, device="cuda")
     plan.set_wire(d_wire.data_ptr())
     plan.set_wire_only(wire_only)
     plan.set_cwire(d_cw.data_ptr(), cap)
     msd = T.MultiSyncDev(eng, plan, streams, d.data_ptr(), offs, d_rec.data_ptr(), 64, hs)
     outs = msd.collect()
     torch.cuda.synchronize()
-    res = dict(outs=outs, ngrid=msd.ngrid, fellback=msd.fellback, nbytes=msd.cwire_bytes,
+    res = dict(outs=outs, ngrid=msd.ngrid, fellback=msd.fellback, nbytes=msd.cwire_bytes, needed=msd.cwire_needed,
                rec=d_rec.cpu().numpy().reshape(-1, T.REC_BYTES)[:max(msd.ngrid, 1)],
                wire=d_wire.cpu().numpy().reshape(-1, T.WIRE_BYTES)[:max(msd.ngrid, 1)], cw=d_cw.cpu().numpy(), codes=plan.final_codes())
     plan.close()
@@ -265,6 +330,30 @@ def test_compact_wire_of_a_decoded_batch_unpacks_to_its_records(T, eng):
             assert known.mean() > 0.9
             check_against_oracle(T, r["rec"][idx][known], ty[known], slots[known], codes[c], use_acc=1)
         assert nbad > 50          # (escape records were in play)
+
+
+@gpu
+def test_a_cwire_buffer_that_is_too_small_is_left_alone_and_the_batch_stays_valid(T, eng):
+    """tgpu_plan_set_cwire() takes any capacity >= 4096: one that does not even hold the tables (header, channel table,
+    bitmap, block table) is not written at all, one that holds the tables but not the records carries no records; either
+    way collect succeeds, the records are the full-capacity run's, cwire_bytes is 0 and cwire_needed says what it takes"""
+    rng = np.random.default_rng(78)
+    streams = [_mix_stream(T, 30000 + 500 * c, 5200 + c, (262, 42 + c, 1 + c), 0.0)[0] for c in range(3)]
+    full = _run_with_cwire(T, eng, streams)
+    assert not full["fellback"] and full["nbytes"] > 0 and full["needed"] == 0
+    hdr = np.frombuffer(full["cw"][:32].tobytes(), np.uint32)
+    o_rec = int(hdr[7])
+    assert o_rec > 4096 + 16
+    for cap in (4096, (o_rec + 15) & ~15, (o_rec + 4096) & ~15, (full["nbytes"] - 16) & ~15):
+        r = _run_with_cwire(T, eng, streams, cap=cap, guard=1 << 20)
+        assert not r["fellback"] and r["nbytes"] == 0 and r["needed"] >= full["nbytes"], cap
+        assert (r["cw"][cap:] == 0xCD).all(), "wrote behind a %d-byte cwire buffer" % cap
+        if cap < o_rec + 16:
+            assert (r["cw"] == 0xCD).all()
+        assert (r["rec"] == full["rec"]).all() and (r["wire"] == full["wire"]).all()
+        assert [o["nslots"] for o in r["outs"]] == [o["nslots"] for o in full["outs"]]
+    r = _run_with_cwire(T, eng, streams, cap=(full["nbytes"] + 15) & ~15, guard=4096)       # exactly enough
+    assert r["nbytes"] == full["nbytes"] and (r["cw"][:r["nbytes"]] == full["cw"][:r["nbytes"]]).all()
 
 
 @gpu
