@@ -271,6 +271,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             bb[f:f + len(st)] = st
         return sts, cds, fs, bb
 
+    t_gen = time.perf_counter()
     streams, codes, offs, buf = capture(0, args.ber)
     eng = T.Engine(local)
     if args.walk_wide:
@@ -282,6 +283,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         d_bases.append(torch.from_numpy(buf_b).cuda())
         del sts_b, buf_b
     d_base = d_bases[0]
+    t_gen = time.perf_counter() - t_gen
     cap = sum(len(st) // 510 + 32 for st in streams)
     K, R, W = args.steps, max(1, args.windows), max(args.warmup, 6 * D) + D     # (the first ~20 steps of a run are 4 % slower: clocks, queues filling)
     chans = T.multi_chan_table(streams, offs)         # carry-in codes 0: every cell's code is learnt from SB1 inside the batch
@@ -646,7 +648,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     check = None
     rec_all = recs[0].view(-1, T.REC_BYTES)
 
-    def oracle_check(sts, outs_, with_wire):
+    def oracle_check(sts, outs_, with_wire, noisy=False):
         """correctness guard on the timed output: delivered bursts of every channel against the oracle (checker only) --
         type-1 bits, BBK, CRC words and codes of up to 512 delivered grid slots per channel; returns (bursts checked,
         blocks whose CRC failed among them)"""
@@ -662,14 +664,20 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             ty = p["type"].astype(np.uint8)
             ok, want, wcrc = O.bench_decode_slots(sl, ty, codes[c], use_acc=1, want_out=True, want_crc=True)
             n1, n2, sb = ty == 0, ty == 1, ty == 3
-            good = (p["bbk"] == want[:, :14]).all() and (p["bits1"][n1] == want[n1, 14:282]).all() and \
+            # (with payload errors a channel's first SB1 may fail its CRC: the bursts in front of the first good SYNC PDU are
+            # decoded under the carry-in code 0, by the reference as by this path -- the oracle call below knows one code, so
+            # those are left out; with BER 0 every burst is in)
+            kn = p["code"] == codes[c]
+            assert kn.mean() > (0.9 if noisy else 0.999), "channel %d: %d of %d bursts not under the cell's code" % (c, int((~kn).sum()), len(kn))
+            n1, n2, sb = n1 & kn, n2 & kn, sb & kn
+            good = (p["bbk"][kn] == want[kn, :14]).all() and (p["bits1"][n1] == want[n1, 14:282]).all() and \
                 (p["bits1"][n2][:, :124] == want[n2, 14:138]).all() and (p["bits2"][n2] == want[n2, 138:262]).all() and \
                 (p["bits1"][sb][:, :60] == want[sb, 14:74]).all() and (p["bits2"][sb] == want[sb, 138:262]).all() and \
-                (p["crc"][:, 0] == wcrc[:, 0]).all() and (p["crc"][n2 | sb, 1] == wcrc[n2 | sb, 1]).all() and \
-                (n1 | n2 | sb).all() and (p["code"][~sb] == codes[c]).all()
+                (p["crc"][kn, 0] == wcrc[kn, 0]).all() and (p["crc"][n2 | sb, 1] == wcrc[n2 | sb, 1]).all() and \
+                ((ty == 0) | (ty == 1) | (ty == 3)).all()
             assert good, "decoded records of channel %d differ from the oracle" % c
-            nchk += len(first)
-            nbad += int((p["crc_ok"][:, 0] == 0).sum() + (p["crc_ok"][n2 | sb, 1] == 0).sum())
+            nchk += int(kn.sum())
+            nbad += int((p["crc_ok"][kn, 0] == 0).sum() + (p["crc_ok"][n2 | sb, 1] == 0).sum())
             if with_wire:        # ... and what arrived on the collecting rank is this rank's share, byte for byte
                 idx = torch.from_numpy(out["grid_base"] + first)
                 if compact:     # (the last gathered step decoded capture 0: rank 0's share of that gather is this step's buffer)
@@ -697,7 +705,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             ms2 = T.MultiSyncDev(eng, plans[0], None, ber2_base.data_ptr(), None, recs[0].data_ptr(), 64, strm[0].cuda_stream, chans=chans)
             outs2 = ms2.collect()
             torch.cuda.synchronize()
-            n2_, bad2 = oracle_check(ber2_streams, outs2, False)
+            n2_, bad2 = oracle_check(ber2_streams, outs2, False, noisy=True)
             ber2["check"] = "type-1 bits, BBK, CRC words and codes of %d delivered bursts equal the oracle's (%d of their blocks fail the CRC on both sides)" % (n2_, bad2)
             del ms2, outs2
     ber2_base = ber2_streams = None
@@ -970,7 +978,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                                   "all channels on the GPU at 64-byte feeds, device lists, SB1 / fill / masks / trellis); value = "
                                   "delivered bursts/s%s; one host thread per GPU, %d steps in flight" %
                                   (C, per, args.ber, NB, NB, ", every step's decoded blocks gathered to rank 0 (40-B wire records, RCCL)" if gathered else "", D),
-                      "payload_ber": args.ber, "input_buffers": NB, "input_bytes_resident_per_gpu": int(sum(x.numel() for x in d_bases)),
+                      "payload_ber": args.ber, "input_buffers": NB, "input_generation_s (host synthesis of the captures, before any timing)": round(t_gen, 2), "input_bytes_resident_per_gpu": int(sum(x.numel() for x in d_bases)),
                       "channels_per_gpu": C, "slots_per_channel": per, "grid_slots_per_step": int(ngrid),
                       "delivered_per_step": int(nd), "host_threads_per_gpu": 1, "steps_in_flight": D,
                       "batches_handed_to_the_host_walk": handed_over,
