@@ -804,6 +804,33 @@ int tgpu_gsmtap_batch(struct tgpu_engine *eng, const uint8_t *d_rec, const struc
  * from an uninitialised local array; here they are bit 0.
  */
 void tgpu_traffic_block(const uint8_t *type4, unsigned int len, int16_t out[690]);
+/*
+ * The same for a whole decoded batch on the device (k_traffic, csrc/tg_traffic.hip): what tp_sap_udata_ind() does with the
+ * blocks of a burst the upper MAC has marked as traffic (tetra_lower_mac.c:194-241).  d_traffic = byte per slot in the shape
+ * tgpu_gsmtap_batch() takes: bit 0 = the burst is a traffic burst (cur_burst.is_traffic), bit 1 = its second block was stolen
+ * (cur_burst.blk2_stolen: it is signalling after all).  For a flagged slot the batch decoded:
+ *   NORM_1          the SCH/F block is dumped: 432 descrambled type-4 bits
+ *   NORM_2 / SYNC   the second block (BLK2 / SB2: the reference's test is blk_num == BLK_2) is dumped unless bit 1 is set:
+ *                   216 descrambled type-4 bits; the first block stays decoded (a stolen BLK1 is signalling)
+ * d_type4 (optional): 432 bytes per slot, the dumped block's descrambled type-4 bits, one per byte (struct tgpu_unitdata.type4
+ * of the callback path; bytes past the block's length are 0).  d_blocks (optional): 690 int16 per slot, the dump block of
+ * tgpu_traffic_block().  d_lens: bits dumped per slot (432, 216, or 0: nothing of this slot was dumped) -- cleared and
+ * written for all of the batch's slots.  The records are marked: TGPU_FLAG_TRAFFIC in the flags byte and crc_ok = 0 for
+ * the dumped block (the reference does not decode or indicate it; the type-1 bits the batch decoded speculatively stay
+ * where they are), TGPU_FLAG_BLK1_STOLEN for a traffic NORM_2 burst; wire records carry the same flags (tgpu_wire_unpack()
+ * clears the dumped block's crc_ok).  Slot batches (tgpu_plan_load) and stream batches (tgpu_sync_*: slot = grid slot) alike;
+ * not for block-mode plans (the tp_sap_udata_ind() seam has the flags at hand and hands traffic blocks to the callback).
+ *   tgpu_plan_set_traffic()  every execute / stream batch of the plan ends with this stage (d_traffic NULL: off).  For a
+ *                            caller that knows its traffic slots beforehand (an assigned timeslot of a call).
+ *   tgpu_plan_traffic()      the stage on its own, on the batch the plan executed last -- for a caller that reads the
+ *                            usage markers out of the batch's own AACH blocks first.  d_rec = the batch's records.
+ */
+#define TGPU_FLAG_NONBINARY   0x01	/* record flags byte: a byte other than 0 / 1 in the slot */
+#define TGPU_FLAG_TRAFFIC     0x02
+#define TGPU_FLAG_BLK1_STOLEN 0x04
+int tgpu_plan_set_traffic(struct tgpu_plan *plan, const uint8_t *d_traffic, uint8_t *d_type4, int16_t *d_blocks, uint16_t *d_lens);
+int tgpu_plan_traffic(struct tgpu_plan *plan, const uint8_t *d_traffic, uint8_t *d_rec, uint8_t *d_type4, int16_t *d_blocks,
+		      uint16_t *d_lens, void *hip_stream);
 
 /*
  * The tetra_burst_rx_cb() seam (phy/tetra_burst.c:341-379: void tetra_burst_rx_cb(const uint8_t *burst,

@@ -164,6 +164,8 @@ def lib():
     L.tgpu_cwire_bound.restype = C.c_uint64
     L.tgpu_cwire_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.tgpu_plan_set_cwire.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.tgpu_plan_set_traffic.argtypes = [C.c_void_p] * 5
+    L.tgpu_plan_traffic.argtypes = [C.c_void_p] * 7
     L.tgpu_wire_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, u32p, u32p, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_void_p]
     L.tgpu_cwire_pack.restype = C.c_int64
@@ -366,6 +368,16 @@ class Plan:
 
     def set_wire_only(self, on=True):
         _chk(lib().tgpu_plan_set_wire_only(self._h, int(bool(on))), "tgpu_plan_set_wire_only")
+
+    def set_traffic(self, d_traffic_ptr, d_type4_ptr=0, d_blocks_ptr=0, d_lens_ptr=0):
+        """every batch of the plan ends with the traffic stage (tgpu_plan_set_traffic); d_traffic_ptr 0 = off"""
+        _chk(lib().tgpu_plan_set_traffic(self._h, C.c_void_p(d_traffic_ptr), C.c_void_p(d_type4_ptr), C.c_void_p(d_blocks_ptr),
+                                         C.c_void_p(d_lens_ptr)), "tgpu_plan_set_traffic")
+
+    def traffic(self, d_traffic_ptr, d_rec_ptr, d_type4_ptr, d_blocks_ptr, d_lens_ptr, hip_stream=0):
+        """the traffic stage on the batch the plan executed last (tgpu_plan_traffic)"""
+        _chk(lib().tgpu_plan_traffic(self._h, C.c_void_p(d_traffic_ptr), C.c_void_p(d_rec_ptr), C.c_void_p(d_type4_ptr),
+                                     C.c_void_p(d_blocks_ptr), C.c_void_p(d_lens_ptr), C.c_void_p(hip_stream)), "tgpu_plan_traffic")
 
     def set_cwire(self, d_cwire_ptr, cap_bytes=0):
         """device-walk batches of this plan leave the compact transport form of their wire records (set_wire() too) here"""

@@ -103,6 +103,10 @@ struct tgpu_plan {
 	uint8_t *d_wire;	/* caller-owned, optional */
 	uint8_t *d_cwire;	/* caller-owned, optional: compact form of a device-walk batch's wire records (tgpu_plan_set_cwire) */
 	size_t cwire_cap;
+	const uint8_t *d_traffic;	/* caller-owned, optional (tgpu_plan_set_traffic): byte per slot, bit 0 traffic burst, bit 1 second block stolen */
+	uint8_t *d_type4;		/* ... descrambled type-4 bits of the dumped blocks, 432 bytes per slot */
+	int16_t *d_tblocks;		/* ... their 690-word dump blocks */
+	uint16_t *d_tlens;		/* ... bits per slot (0: nothing dumped) */
 	uint32_t *d_softarea;	/* max_slots * 512 B, allocated on the first soft execute */
 	uint32_t *d_grid;	/* stream mode: classification words + SYNC summaries, max_slots * 6 B, allocated on first use */
 	uint32_t *h_grid;	/* pinned host mirror of d_grid */
@@ -907,6 +911,43 @@ static uint32_t tgpi_burst_max(void)
 	return (uint32_t)tgi_option(TGPU_OPT_BURST_MAX);
 }
 
+/* the traffic stage on the batch the plan holds (its packed slots, mask entries and item lists) */
+static int plan_traffic(struct tgpu_plan *p, const uint8_t *d_traffic, uint8_t *d_rec, uint8_t *d_type4, int16_t *d_blocks,
+			uint16_t *d_lens, void *stream)
+{
+	if (p->block_mode || p->last_burst)
+		return TGPU_ESTATE;
+	const int wo = p->wire_only && p->d_wire;
+	return tgk_traffic(p->d_list_432, p->n432, p->d_list_216, p->n216, p->d_counts, d_traffic, p->d_packed, p->d_masks, p->d_maskidx,
+			   wo ? NULL : d_rec, p->d_wire, p->nslots, d_type4, d_blocks, d_lens, stream);
+}
+
+int tgpu_plan_set_traffic(struct tgpu_plan *p, const uint8_t *d_traffic, uint8_t *d_type4, int16_t *d_blocks, uint16_t *d_lens)
+{
+	if (!p || (d_traffic && !d_lens) || ((uintptr_t)d_type4 & 3) || ((uintptr_t)d_blocks & 3) || ((uintptr_t)d_lens & 1))
+		return TGPU_EINVAL;
+	p->d_traffic = d_traffic;
+	p->d_type4 = d_traffic ? d_type4 : NULL;
+	p->d_tblocks = d_traffic ? d_blocks : NULL;
+	p->d_tlens = d_traffic ? d_lens : NULL;
+	return TGPU_OK;
+}
+
+int tgpu_plan_traffic(struct tgpu_plan *p, const uint8_t *d_traffic, uint8_t *d_rec, uint8_t *d_type4, int16_t *d_blocks,
+		      uint16_t *d_lens, void *stream)
+{
+	if (!p || !d_traffic || !d_lens || ((uintptr_t)d_type4 & 3) || ((uintptr_t)d_blocks & 3) || ((uintptr_t)d_lens & 1))
+		return TGPU_EINVAL;
+	if (!p->loaded)
+		return TGPU_ESTATE;
+	if (!d_rec && !(p->wire_only && p->d_wire))
+		return TGPU_EINVAL;
+	BIND(p->eng);
+	if (!p->nslots)
+		return TGPU_OK;
+	return plan_traffic(p, d_traffic, d_rec, d_type4, d_blocks, d_lens, stream);
+}
+
 /* soft: 0 = bits (1 per byte), 1 = int8 soft values, 2 = float phases (nfloats of them) */
 static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec, void *stream, hipEvent_t *ev, int soft,
 		    uint64_t nfloats)
@@ -924,7 +965,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 		return TGPU_EINVAL;
 	/* small batches: one workgroup per burst, trellis states across lanes, two launches (k_burst).
 	 * TGPU_BURST_MAX = largest batch that takes this path (0 = never) */
-	if (!soft && !ev && !p->packed_ready && !p->rm_decode && !p->d_wire && !p->fastpath && p->nslots &&
+	if (!soft && !ev && !p->packed_ready && !p->rm_decode && !p->d_wire && !p->fastpath && !p->d_traffic && p->nslots &&
 	    p->nslots <= tgpi_burst_max()) {
 		if ((rc = tgk_burst(d_stream, p->d_slot_off, p->d_slot_chan, p->d_chan_code, p->nslots, p->nchan, p->nsb != 0, p->d_sb_ok,
 				    p->d_sb_code, d_rec, p->d_maskidx, p->d_masks, p->marks, stream)))
@@ -1038,6 +1079,10 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	}
 	MARK(6);
 #undef MARK
+	/* traffic bursts the caller marked (tgpu_plan_set_traffic): their SCH/F / second blocks as type-4 bits and dump blocks,
+	 * their records marked -- behind both trellis kernels, in front of whatever packs the wire records */
+	if (p->d_traffic && p->nslots)
+		return plan_traffic(p, p->d_traffic, d_rec, p->d_type4, p->d_tblocks, p->d_tlens, stream);
 	return TGPU_OK;
 }
 
@@ -1440,6 +1485,8 @@ int tgpu_wire_unpack(const uint8_t *wire, uint32_t slot_id, uint32_t scrambling_
 		rec[TG_REC_CRC_OK + 1] = crc[1] == TG_CRC_OK;
 	}
 	memcpy(rec + TG_REC_CRC, crc, 4);
+	if (rec[TG_REC_FLAGS] & TG_FLAG_TRAFFIC)	/* the block that went to the traffic dump was not indicated (tg_traffic.hip) */
+		rec[TG_REC_CRC_OK + (type == TETRA_TRAIN_NORM_1 ? 0 : 1)] = 0;
 	if (type == TETRA_TRAIN_SYNC) {
 		/* SYNC-PDU fields (lower_mac/tetra_lower_mac.c:284-297) from the SB1 bits */
 		const uint8_t *b = rec + TG_REC_BITS1;

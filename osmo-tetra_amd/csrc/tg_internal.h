@@ -212,6 +212,13 @@ int tgk_stages(const uint8_t *d_type5, const uint32_t *d_codes, uint32_t fixed_c
 int tgk_stages_crc(const uint8_t *d_type2, unsigned long long nblocks, uint32_t type2_len, uint32_t n, uint16_t *d_crc,
 		   void *stream);
 
+/* traffic blocks of a decoded batch (tg_traffic.hip): driven by the batch's item lists (d_counts: their device-side lengths or
+ * NULL), d_rec / d_wire: the records to mark (either may be NULL), d_type4 / d_blocks may be NULL, d_lens is cleared first */
+int tgk_traffic(const uint32_t *d_items432, uint32_t n432, const uint32_t *d_items216, uint32_t n216, const uint32_t *d_counts,
+		const uint8_t *d_traffic, const uint32_t *d_packed, const uint32_t *d_masks, const uint32_t *d_maskidx,
+		uint8_t *d_rec, uint8_t *d_wire, uint32_t nslots, uint8_t *d_type4, int16_t *d_blocks, uint16_t *d_lens,
+		void *stream);
+
 /* optional RM(30,14) decoder (tg_rm.c): coset-leader table (65536 words, built on first use) and the generator's
  * parity rows; tgk_rm_enable() uploads both for the kernels (flag TGK_F_RM of tgk_vit / tgk_bbk_blocks) */
 const uint32_t *tgi_rm_leader_table(void);

@@ -99,6 +99,10 @@
 #define TG_SOFT_BBK        448	/* 30 BBK values */
 
 #define TG_FLAG_NONBINARY 0x01	/* a byte other than 0/1 was seen in the slot (block mode: in the block) */
+/* set by the traffic stage (tg_traffic.hip, tgpu_plan_set_traffic / tgpu_plan_traffic) on bursts the caller marked as traffic: */
+#define TG_FLAG_TRAFFIC   0x02	/* the burst's SCH/F block (NORM_1) or its second block (NORM_2, SYNC) went to the traffic dump and
+				 * was not indicated (tetra_lower_mac.c:198-241): its crc_ok reads 0 */
+#define TG_FLAG_BLK1_STOLEN 0x04	/* first half of a traffic NORM_2 burst: cur_burst.blk1_stolen (tetra_lower_mac.c:194-195) */
 
 /* scrambling-mask table entry: 40 dwords, same bit layout as the code words */
 #define TG_MASK_WORDS     40
