@@ -46,7 +46,7 @@ int tgpu_gsmtap_makemsg(const struct tetra_tdma_time *tm, enum tetra_log_chan lc
 	return (int)(16u + packed_len);
 }
 
-/* the batch form: one launch for all CRC-OK blocks of a decoded batch (k_gsmtap, tg_kernels.hip) */
+/* the batch form: one launch for all CRC-OK blocks of a decoded batch (k_gsmtap, tg_k_aux.hip) */
 int tgpu_gsmtap_batch(struct tgpu_engine *eng, const uint8_t *d_rec, const struct tetra_tdma_time *d_times, const uint8_t *d_traffic,
 		      uint32_t nslots, uint8_t *d_msgs, uint8_t *d_lens, void *hip_stream)
 {

@@ -551,7 +551,7 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 
 /*
  * Device-walk batches (tg_stream.c: tgpu_sync_multi_launch): nothing comes back to the host before the decode, and what
- * lies between the front end and the trellis kernels is five small launches (tg_kernels.hip, k_lists2):
+ * lies between the front end and the trellis kernels is five small launches (tg_k_aux.hip, k_lists2):
  *   stage 1 (before k_walk)  one memset (counters, code table, okbits), k_cls_plain2; then beside the walk, on the plan's
  *                            side stream: k_vit<SB1> over the SYNC-classified slots, k_masks2
  *   stage 2 (after k_walk)   k_lb_scan, k_lists2 (mask entry per delivered slot, item lists), the two trellis kernels with

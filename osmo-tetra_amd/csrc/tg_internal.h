@@ -1,4 +1,4 @@
-/* tg_internal.h -- launch layer between the C host code and tg_kernels.hip */
+/* tg_internal.h -- launch layer between the C host code and the HIP units (tg_dev.h has the map: tg_k_front / _trellis / _walk / _aux .hip) */
 #ifndef TG_INTERNAL_H
 #define TG_INTERNAL_H
 
@@ -228,7 +228,7 @@ int tgk_rm_enable(const uint32_t *h_leader, const uint16_t *h_parity);
 #define TGK_F_RM    2	/* correct the BBK with the RM(30,14) decoder before its first 14 bits are kept */
 #define TGK_F_WIREONLY 8	/* only the 40-byte wire records are written (tgpu_plan_set_wire_only): no 320-byte records */
 #define TGK_F_LOOKBACK 16	/* SB1 launch of a device-walk batch: d_sb_ok = okbits (bit per grid slot), d_sb_code = mask entry per slot, d_masks =
-				 * the code table (TGK_LB_TBL + 1 words), flags >> 8 = number of channels (tg_kernels.hip, k_lists2) */
+				 * the code table (TGK_LB_TBL + 1 words), flags >> 8 = number of channels (tg_k_aux.hip, k_lists2) */
 #define TGK_LB_TBL 4096u
 
 /* make the engine's device the calling thread's current HIP device (every allocating / launching entry point does) */
@@ -256,7 +256,7 @@ int tgpi_plan_chan_table(struct tgpu_plan *p, const struct tg_chan_ent *ents, ui
 int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_bits, uint32_t nchan, const uint32_t *codes,
 			const struct tg_chan_ent *ents, void *stream);
 
-/* device-walk batches: everything between the front end and the trellis kernels (tg_kernels.hip, k_lists2) */
+/* device-walk batches: everything between the front end and the trellis kernels (tg_k_aux.hip, k_lists2) */
 int tgk_cls_plain2(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, uint32_t *d_list_sb, uint32_t *d_cnt_sb,
 		   uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, void *stream);
 int tgk_masks2(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_tbl, uint32_t *d_masks, void *stream);

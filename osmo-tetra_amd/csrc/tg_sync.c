@@ -194,7 +194,7 @@ struct bq_item {
 	struct tetra_tdma_time time;	/* t_phy_state.time when the block was handed over (tetra_lower_mac.c:167) */
 };
 
-/* ---- TGPU_OPT_RING: the decoder workgroups that stay (k_burst_ring; protocol in tg_kernels.hip) ---- */
+/* ---- TGPU_OPT_RING: the decoder workgroups that stay (k_burst_ring; protocol in tg_k_trellis.hip) ---- */
 #define RING_IDLE_TICKS 2000000ull	/* 20 ms of the device's 100 MHz clock without a request: the workgroups leave */
 #define RING_MAX_CHANNELS 32		/* channels of a process that may hold workgroups at a time (each up to four, 43 KB of LDS
 					 * apiece, for as long as its flushes keep coming): the others flush by launch */

@@ -25,7 +25,7 @@
  * TGW_FALLBACK and the caller runs the host walk for the batch.  Only power-of-two feed sizes inside the closed form's
  * range, no per-burst events (TGPU_SYNC_NO_BURST_EVENTS), grid mode.
  *
- * The same source is compiled for the device (tg_kernels.hip) and for the host (tgpu_sync_walk_emul(), which runs the
+ * The same source is compiled for the device (tg_k_walk.hip) and for the host (tgpu_sync_walk_emul(), which runs the
  * kernel's phases one after the other on the CPU and is what the CPU test-suite fuzzes against sync_walk() and the
  * oracle).
  */
