@@ -42,6 +42,10 @@ extern "C" {
 /* types mirrored from the reference (values and layouts are ABI)             */
 /* ------------------------------------------------------------------------- */
 
+/* A translation unit that includes the reference's own headers next to this one (the adapter of INTEGRATION.md section 3,
+ * tools/tgpu_adapter.c) takes these types from there: every mirror below stands behind the include guard of the reference
+ * header it restates, so include the reference's headers FIRST. */
+#ifndef TETRA_BURST_H
 /* phy/tetra_burst.h:6-7 */
 #define BLK_1 1
 #define BLK_2 2
@@ -64,7 +68,9 @@ enum tetra_train_seq {
 	TETRA_TRAIN_SYNC,
 	TETRA_TRAIN_EXT,
 };
+#endif
 
+#ifndef TETRA_COMMON_H
 /* tetra_common.h:22-39 */
 enum tetra_log_chan {
 	TETRA_LC_UNKNOWN,
@@ -80,7 +86,10 @@ enum tetra_log_chan {
 	TETRA_LC_BSCH,
 	TETRA_LC_BNCH,
 };
+#define TETRA_CRC_OK 0x1d0f	/* tetra_common.h:69 */
+#endif
 
+#ifndef TETRA_TDMA_H
 /* tetra_tdma.h:6-12 */
 struct tetra_tdma_time {
 	uint16_t hn;
@@ -89,7 +98,9 @@ struct tetra_tdma_time {
 	uint32_t fn;
 	uint32_t mn;
 };
+#endif
 
+#ifndef TETRA_BURST_SYNC_H
 /* phy/tetra_burst_sync.h:6-20 */
 enum rx_state {
 	RX_S_UNLOCKED,
@@ -105,9 +116,11 @@ struct tetra_rx_state {
 	unsigned int next_frame_start_bitnum;
 	void *burst_cb_priv;	/* must hold the struct tgpu_channel* (see tgpu_channel_create) */
 };
+#endif
 
-#define TETRA_CRC_OK 0x1d0f	/* tetra_common.h:69 */
+#ifndef TETRA_SCRAMB_H
 #define SCRAMB_INIT  3		/* lower_mac/tetra_scramb.h:14 */
+#endif
 
 /* ------------------------------------------------------------------------- */
 /* error codes                                                                */
@@ -466,10 +479,12 @@ void tgpu_channel_clear_error(struct tgpu_channel *ch);
  * and time it brings apply to the next block as in the reference; the rest is delivered when the queue fills, at
  * the next SB1 or by tgpu_channel_flush().  Delivery = the channel's tgpu_unitdata_cb, same order, same contents.
  */
+#ifndef TETRA_COMMON_H	/* tetra_common.h:44-47 */
 struct tetra_phy_state {
 	struct tetra_tdma_time time;
 };
 extern struct tetra_phy_state t_phy_state;
+#endif
 void tp_sap_udata_ind(enum tp_sap_data_type type, int blk_num, const uint8_t *bits, unsigned int len, void *priv);
 void tetra_burst_rx_cb(const uint8_t *burst, unsigned int len, enum tetra_train_seq type, void *priv);
 

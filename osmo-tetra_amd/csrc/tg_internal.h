@@ -16,7 +16,9 @@ int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 /* stream mode: grid slot n at anchor + 510 n; writes packed slots and one classification word per slot.
  * d_defer: scratch of TG_DEFER_WORDS(nslots) dwords (the slots the packed-bit pass hands to the exact pass);
  * ev_mid: hipEvent_t recorded between the two passes, or NULL */
-#define TG_DEFER_WORDS(nslots) ((size_t)(nslots) + 16)
+/* (a count per wave of the first pass + 16 + a list per wave of 4 x the groups it can meet: <= nslots + 5 waves + 16 with at most a
+ * wave per group) */
+#define TG_DEFER_WORDS(nslots) ((size_t)(nslots) + 5 * (((size_t)(nslots) + 3) / 4 + 4) + 80)
 int tgk_front_stream(const uint8_t *d_stream, uint64_t anchor, uint64_t len, uint32_t nslots,
 		     uint32_t chunk, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer,
 		     void *stream, void *ev_mid);

@@ -116,8 +116,11 @@ __device__ __forceinline__ void front_flush(const uint32_t *mo, uint32_t lane, u
 {
 	const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)first * TG_PACKED_WORDS, 0,
 									       cnt * TG_PACKED_WORDS * 4, 0x00027000);
-	__builtin_amdgcn_raw_buffer_store_b32(mo[lane], out, lane * 4, 0, 0);
-	__builtin_amdgcn_raw_buffer_store_b32(mo[64 + lane], out, 256 + lane * 4, 0, 0);
+#ifndef TGS_ST_AUX
+#define TGS_ST_AUX 0
+#endif
+	__builtin_amdgcn_raw_buffer_store_b32(mo[lane], out, lane * 4, 0, TGS_ST_AUX);
+	__builtin_amdgcn_raw_buffer_store_b32(mo[64 + lane], out, 256 + lane * 4, 0, TGS_ST_AUX);
 }
 
 __global__ __launch_bounds__(256)
@@ -624,22 +627,45 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
 /* classification word of a slot the packed-bit kernel leaves to k_front_stream_fix (never a valid word: offsets stay below 1088) */
 #define TG_CLS_DEFER 0xffffffffu
 
-/* second pass of the packed-bit front end: every slot the first pass deferred (it appended them to a list: defer[0] =
- * count, slots from defer[TG_DEFER_LIST]) goes through the exact per-position search, one wave per list entry at a
- * time.  Deferred slots are rare (damaged training sequences, the end of a stream); the grid is sized for about one
- * entry per wave, a wave takes entries wave, wave + nwaves, ... */
-#define TG_DEFER_LIST 16
+/* second pass of the packed-bit front end: every slot the first pass deferred goes through the exact per-position search.
+ * Round 5: the first pass keeps one list PER WAVE -- defer[w] = how many slots wave w of k_front_stream deferred, its
+ * slots from defer[TG_DEFER_L0(fw) + w * capw] (fw = waves of that launch, capw = slots a wave can meet at most) -- and
+ * appends with a counter of its own.  (Rounds 2-4 had one list and one counter for the launch: an atomicAdd with a
+ * return value, at device scope -- on this part that is a trip to the memory side of the fabric, every wave's goes to the
+ * same address, and the wait for its answer also waits for the wave's prefetched group: 15 of the kernel's 155 us at
+ * 1 % deferred slots, tools/front_ablate.sh "-DTGS_ABLATE=64".)  A wave of k_front_stream takes groups wave, wave +
+ * nwaves, ..., so every list is an even sample of the grid whatever the damage looks like; a wave of this kernel takes the
+ * lists w = wave, wave + nwaves, ... one entry at a time. */
+#define TG_DEFER_L0(fw) (((fw) + 15u) & ~15u)
 template <bool PACKED, int VIEWT>
 __global__ __launch_bounds__(256)
 void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
-			const uint32_t *__restrict__ defer)
+			const uint32_t *__restrict__ defer, uint32_t fw, uint32_t capw)
 {
 	STREAM_SLOT_TABLES(VIEWT)
-	const uint32_t count = defer[0];
-	for (uint32_t e = wave; e < count; e += nwaves) {
-		{
-			const uint32_t slot = defer[TG_DEFER_LIST + e];
+	(void)wave;
+	(void)nwaves;
+#if TGS_DEFER_ATOMIC	/* (A/B builds: the rounds 2-4 form, one list for the launch, its counter in the last word of the scratch) */
+	for (uint32_t w = 0; w < 1; w++) {
+		const uint32_t count = defer[TG_DEFER_L0(fw) + (size_t)fw * capw];
+		const uint32_t *list = defer + TG_DEFER_L0(fw);
+		for (uint32_t e = wave; e < count; e += nwaves) {
+#else
+	/* a workgroup takes four neighbouring lists at a time and deals their entries round its four waves: a list holds a
+	 * handful of slots at most (0.8 on average at 1 % deferred), dealt out singly the longest queue of a wave is 2-3 */
+	for (uint32_t w4 = 4 * blockIdx.x; w4 < fw; w4 += 4 * gridDim.x) {
+		uint32_t cum[5];
+		cum[0] = 0;
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			cum[q + 1] = cum[q] + (w4 + q < fw ? defer[w4 + q] : 0u);
+		for (uint32_t e4 = wib; e4 < cum[4]; e4 += 4) {
+			const uint32_t q = (e4 >= cum[1]) + (e4 >= cum[2]) + (e4 >= cum[3]);
+			const uint32_t *list = defer + TG_DEFER_L0(fw) + (size_t)(w4 + q) * capw;
+			const uint32_t e = e4 - (q == 0 ? cum[0] : q == 1 ? cum[1] : q == 2 ? cum[2] : cum[3]);
+#endif
+			const uint32_t slot = list[e];
 			uint32_t myword, clsword, ys;
 			if (prm.nchan) {
 				const uint32_t c = chan_of_slot(prm.chan, prm.nchan, slot, lane);
@@ -762,9 +788,23 @@ struct tg_group_data {
 	bool fast;	/* all four windows of the group lie inside the stream */
 };
 
+#ifndef TGS_SYNC_LDS
+#define TGS_SYNC_LDS 1	/* the SYNC burst's gather addresses wait in LDS, not in registers */
+#endif
+#ifndef TGS_DEFER_ATOMIC
+#define TGS_DEFER_ATOMIC 0	/* A/B builds only: 1 = one deferred-slot list per launch, appended to with an atomicAdd (rounds 2-4) */
+#endif
+#ifndef TGS_PLAIN
+#define TGS_PLAIN 1	/* 1: search and outcome verify "one sequence, at its place, nothing else" and hand everything else to the exact pass
+			 * (round 5); 0: the round-3/4 form (first hit, SYNC summary and the rule's inputs for every slot) -- same outputs */
+#endif
 #ifndef TG_STREAM_WPE
-#define TG_STREAM_WPE 6	/* waves per SIMD (80 VGPRs: 6 fit).  With the grid at two rounds of resident workgroups (launch_stream_front):
-			 * 4 -> 161-168 us per 1 M slots, 5 -> 156-161, 6 -> 155-159, 8 (64 VGPRs) -> 195-200 (tools/front_grid.sh) */
+#define TG_STREAM_WPE 5	/* waves per SIMD.  Round 5: five (96 VGPRs allowed, 86 used).  The kernel had sat exactly at the 80 VGPRs of six waves
+			 * since round 3; taking the atomicAdd of the deferred-slot list out (above) let the scheduler reorder across that
+			 * point and the same source needed 91: eleven spills to scratch, reloaded in front of every gather (164 us at six
+			 * waves with spills, 135 at five without, 148 at four; tools/front_ablate.sh).  Rounds 3-4, with the grid at two
+			 * rounds of resident workgroups (launch_stream_front): 4 -> 161-168 us per 1 M slots, 5 -> 156-161, 6 -> 155-159,
+			 * 8 (64 VGPRs, spills) -> 195-200 */
 #endif
 /* acc & (t0 == p0) & (t1 == p1), sel = 2 p0 + p1 (a constant once the caller's loop is unrolled): one v_bitop3_b32 */
 __device__ __forceinline__ uint32_t tsq_and2(uint32_t acc, uint32_t t0, uint32_t t1, int sel)
@@ -813,6 +853,9 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	__shared__ __attribute__((aligned(16))) uint32_t s_bits[TG_STREAM_WPB][72];	/* per wave: the group's bit string (68 dwords used; packed ingest: 72, 16 bytes per lane) */
 	__shared__ uint32_t s_win[TG_STREAM_WPB][4 * TG_VER_SLOT];	/* per wave: four slots x eight shifted copies of the 512-bit window */
 	__shared__ uint32_t s_out[TG_STREAM_WPB][160];	/* per wave: four packed slots on their way out, then their cls / ysum words (+ the idle lanes' dump) */
+	/* per wave: the SYNC burst's eight gather addresses of every lane.  One slot in eight is a SYNC burst: its table waits
+	 * here (two 16-byte reads in front of such a gather) instead of in eight of the 80 VGPRs six waves per SIMD allow */
+	__shared__ __attribute__((aligned(16))) uint32_t s_sadr[TG_STREAM_WPB][TGS_SYNC_LDS ? 64 * 8 : 4];
 
 #ifdef TGS_TIMING
 	unsigned long long tgs_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tgs_last = __builtin_amdgcn_s_memtime();
@@ -852,8 +895,12 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 				g_adr[x][r] = ver0 + wib * (4 * TG_VER_SLOT * 4) + (o == 0xffff ? 64u : (o & 7) * (TG_VER_STRIDE * 4) + (o >> 3));
 			}
 		}
+#if TGS_SYNC_LDS
+		*(uint4 *)&s_sadr[wib][8 * lane] = make_uint4(g_adr[2][0], g_adr[2][1], g_adr[2][2], g_adr[2][3]);
+		*(uint4 *)&s_sadr[wib][8 * lane + 4] = make_uint4(g_adr[2][4], g_adr[2][5], g_adr[2][6], g_adr[2][7]);
+#endif
 #pragma unroll
-		for (int x = 0; x < 3; x++)
+		for (int x = 0; x < (TGS_SYNC_LDS ? 2 : 3); x++)
 #pragma unroll
 			for (int r = 0; r < 8; r++)
 				asm volatile("" : "+v"(g_adr[x][r]));	/* the whole address in the register: the slot's offset is the immediate */
@@ -867,10 +914,32 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	const uint32_t vearly = (col == 0) ? 0x001fffffu : 0u;
 	const uint32_t vys = (col == 15) ? 0x3fffffffu : 0xffffffffu;
 	const uint32_t pos0 = (lane >> 4) * TG_SLOT_BITS + 32 * col;	/* first bit of the column inside the group */
+#if TGS_PLAIN
+	/* round 5, the "plain slot" form of search and outcome.  What this kernel may settle on its own is a slot that holds
+	 * exactly ONE training sequence, of a downlink type, at its nominal offset (y at 214 = column 6 bit 22, n / p at 244 =
+	 * column 7 bit 20) -- 99 % of a recording.  So it only has to VERIFY that: the expected hit is there, and nothing else
+	 * is: no n / p at any other position 0..472, no y anywhere in the slot.  "No y" is checked on y's first 22 bits (a
+	 * necessary condition: the three sequences then share 21 shifted copies of the string instead of 37) and the one
+	 * expected y is confirmed on its last 16.  Every other slot -- a damaged or misplaced sequence, a second hit, a payload
+	 * coincidence (3e-4 of the slots), anything below offset 21 -- goes to k_front_stream_fix, which evaluates
+	 * tetra_find_train_seq()'s rule position by position as before.  The words this kernel does write are the exact
+	 * pass's words for the same slot (test_stream_front_packed_bits_equals_per_position). */
+	const uint32_t m_enp = (col == 7) ? (1u << 20) : 0u;			/* the expected n / p hit */
+	const uint32_t m_ey = (col == 6) ? (1u << 22) : 0u;			/* the expected y hit */
+	const uint32_t c_np = (vmain | vearly) & ~m_enp;			/* n / p hits that are not the expected one */
+	const uint32_t c_y = vys & ~m_ey;					/* y (prefix) hits that are not the expected one */
+#endif
 
 	const uint32_t ngroups = (prm.nslots + 3) >> 2;
-	if (wave >= ngroups)
+	if (wave >= ngroups) {
+		if (lane == 0)
+			defer[wave] = 0;
 		return;
+	}
+	/* this wave's list of slots for the exact pass (k_front_stream_fix) and how many are on it */
+	/* (wave-uniform, and kept in scalar registers by hand: the kernel sits at the 80 VGPRs that six waves per SIMD allow) */
+	uint32_t dpos = __builtin_amdgcn_readfirstlane(TG_DEFER_L0(nwaves) + wave * (4u * ((ngroups + nwaves - 1) / nwaves)));
+	const uint32_t dpos0 = dpos;
 
 	/* request a group: 16 bytes per lane from the 16-byte aligned address below the group's first byte.  Groups the
 	 * fast path may not touch (their windows or the exact form's 640-byte views reach past the stream) fetch group 0
@@ -974,6 +1043,22 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		/* match masks of the three sequences at the column's 32 positions */
 		/* one accumulator per sequence, two positions per step: acc & (t_j == p_j) & (t_j+1 == p_j+1) is one
 		 * three-input logic instruction (v_bitop3_b32) whatever the two pattern bits are */
+#if TGS_PLAIN
+		uint32_t my = 0xffffffffu, mn = 0xffffffffu, mp = 0xffffffffu;	/* (my: the first 22 bits of y only) */
+#pragma unroll
+		for (int j = 0; j < 22; j += 2) {
+			const uint32_t t0 = (j == 0) ? W0 : __builtin_amdgcn_alignbit(W1, W0, j);
+			const int k = j + 1;
+			const uint32_t t1 = __builtin_amdgcn_alignbit(W1, W0, k);
+#define TSQ_STEP(acc, P) acc = tsq_and2(acc, t0, t1, 2 * (int)(((P) >> j) & 1) + (int)(((P) >> k) & 1))
+			TSQ_STEP(my, PY);
+			TSQ_STEP(mn, PN);
+			TSQ_STEP(mp, PP);
+#undef TSQ_STEP
+		}
+		const uint32_t any = my | mn | mp;
+		(void)W2;
+#else
 		uint32_t my = vys, mn = 0xffffffffu, mp = 0xffffffffu;
 #pragma unroll
 		for (int j = 0; j < ((TGS_ABLATE & 8) ? 2 : 38); j += 2) {
@@ -993,6 +1078,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		}
 		const uint32_t any = my | mn | mp;
 
+#endif
 		TGS_MARK(3);	/* shifted copies stored, match masks, ballots */
 #if !(TGS_ABLATE & (8 | 32 | 256))
 		/* per slot (= 16-lane row): the first hit and the SYNC summary by reductions inside the row -- every lane makes a
@@ -1001,6 +1087,32 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 		 * rotate-and-combine steps (DPP row_ror 8 4 2 1) leave the row's result in all of its lanes.  Vector
 		 * instructions only: the form with ballots, per-lane shifts of them and the LDS crossbar cost 24 us per 1 M
 		 * slots in round trips between the vector unit, scalar registers and LDS (TGS_ABLATE), this one */
+#if TGS_PLAIN
+		/* per lane: "something that is not the expected hit" (bit 23) and the expected hits it holds (y 22, n 21, p 20); OR over
+		 * the slot's 16-lane row in four DPP steps; the row's four bits decide: exactly one expected hit and nothing else,
+		 * or the slot is the exact pass's */
+		(void)any;
+		uint32_t rest = __builtin_amdgcn_bitop3_b32(mn, mp, c_np, 0xa8);		/* (mn | mp) & c_np */
+		rest = __builtin_amdgcn_bitop3_b32(my, c_y, rest, 0xea);			/* (my & c_y) | rest */
+		/* y's last 16 bits behind the expected prefix hit: positions 236..251 = bits 12..27 of column 6's second word */
+		const bool ytail = ((W1 >> 12) & 0xffffu) == (uint32_t)((PY >> 22) & 0xffffu);
+		uint32_t ex = ((mn & m_enp) << 1) | (mp & m_enp);
+		ex = (my & (ytail ? m_ey : 0u)) | ex;
+		uint32_t rowc = ((rest != 0u ? 1u : 0u) << 23) | ex;
+#define ROW_STEP(CTRL) rowc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rowc, (CTRL), 0xf, 0xf, true);
+		ROW_STEP(0x128)	/* row_ror:8 */
+		ROW_STEP(0x124)
+		ROW_STEP(0x122)
+		ROW_STEP(0x121)
+#undef ROW_STEP
+		/* 0b0001 p alone -> NORM_2, 0b0010 n alone -> NORM_1, 0b0100 y alone -> SYNC; anything else: not this kernel's slot */
+		const uint32_t kk = rowc >> 20;
+		const uint32_t rc = (0xfff3f01fu >> (4u * (kk < 8u ? kk : 7u))) & 0xfu;
+		const bool dfr = defer_all || rc == 0xfu;
+		const uint32_t offs = rc == TG_BURST_SYNC ? (uint32_t)TG_SYNC_TRAIN_OFF : (uint32_t)TG_NORM_TRAIN_OFF;
+		const uint32_t dtype = dfr ? (uint32_t)TG_BURST_NONE : rc;
+		uint32_t ys = rc == TG_BURST_SYNC ? (uint32_t)TG_SYNC_TRAIN_OFF : (uint32_t)TG_YS_NONE;
+#else
 		typedef unsigned short cls_us2 __attribute__((ext_vector_type(2)));
 		const uint32_t hm = any & vmain;
 		const uint32_t hb = (uint32_t)__builtin_ctz(hm | 0x80000000u);
@@ -1033,6 +1145,7 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			dtype = rc;
 		if (dfr)
 			dtype = TG_BURST_NONE;
+#endif
 #define CLS_OWNER      ((lane & 15u) == 0u)	/* the lane that writes the slot's words */
 #define CLS_SLOT       (lane >> 4)
 #define CLS_LANE_OF(K) (16 * (K))
@@ -1066,8 +1179,14 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 0>(g_adr[0]);			\
 			else if (dt == TG_BURST_NORM_2)									\
 				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 1>(g_adr[1]);			\
-			else if (dt == TG_BURST_SYNC)									\
-				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 2>(g_adr[2]);			\
+			else if (dt == TG_BURST_SYNC) {									\
+				if (TGS_SYNC_LDS) {										\
+					const uint4 a0_ = *(const uint4 *)&s_sadr[wib][8 * lane], a1_ = *(const uint4 *)&s_sadr[wib][8 * lane + 4];	\
+					const uint32_t sa_[8] = { a0_.x, a0_.y, a0_.z, a0_.w, a1_.x, a1_.y, a1_.z, a1_.w };	\
+					mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 2>(sa_);			\
+				} else												\
+					mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 2>(g_adr[2]);		\
+			}													\
 			((uint8_t *)mo)[(K) * TG_PACKED_WORDS * 4 + obyte] = (uint8_t)mybyte;				\
 		}
 		TGS_MARK(4);	/* classification of the four slots */
@@ -1082,16 +1201,29 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			mo[80 + CLS_SLOT] = clsword;
 			mo[84 + CLS_SLOT] = ys;
 		}
-		{	/* slots this pass could not settle: onto the list of k_front_stream_fix (one atomic per group that has any) */
+		{	/* slots this pass could not settle: onto this wave's list for k_front_stream_fix */
+#if TGS_SB & 1
+			__builtin_amdgcn_sched_barrier(0);
+#endif
+#if TGS_SB & 2
+			asm volatile("" ::: "memory");
+#endif
 			const bool mine = CLS_OWNER && CLS_SLOT < cnt && dfr;
 			const unsigned long long dm = __ballot(mine);
 			if (dm) {
+#if TGS_DEFER_ATOMIC
 				uint32_t pos = 0;
-				if (lane == 0 && !(TGS_ABLATE & 64))
-					pos = atomicAdd(defer, (uint32_t)__builtin_popcountll(dm));
+				if (lane == 0)
+					pos = atomicAdd(defer + TG_DEFER_L0(nwaves) + (size_t)nwaves * capw, (uint32_t)__builtin_popcountll(dm));
 				pos = __builtin_amdgcn_readfirstlane(pos);
 				if (mine)
-					defer[TG_DEFER_LIST + pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] = first + CLS_SLOT;
+					defer[TG_DEFER_L0(nwaves) + pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] = first + CLS_SLOT;
+#else
+				if (mine)
+					defer[dpos + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] = first + CLS_SLOT;
+				if (!(TGS_ABLATE & 64))
+					dpos = __builtin_amdgcn_readfirstlane(dpos + (uint32_t)__builtin_popcountll(dm));
+#endif
 			}
 		}
 #undef CLS_OWNER
@@ -1110,20 +1242,32 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	/* two register sets with fixed roles: the next group is requested before this one is worked on, no copies */
 	tg_group_data dA, dB;
 	uint32_t g = wave;
+#if TGS_SB & 4
+#define TGS_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define TGS_FENCE do { } while (0)
+#endif
 	fetch(g, dA);
 	for (;;) {
 		const uint32_t gB = g + nwaves;
+		TGS_FENCE;
 		fetch(gB < ngroups ? gB : g, dB);
+		TGS_FENCE;
 		work(g, dA);
 		if (gB >= ngroups)
 			break;
 		const uint32_t gA = gB + nwaves;
+		TGS_FENCE;
 		fetch(gA < ngroups ? gA : gB, dA);
+		TGS_FENCE;
 		work(gB, dB);
 		if (gA >= ngroups)
 			break;
 		g = gA;
 	}
+#undef TGS_FENCE
+	if (lane == 0)
+		defer[wave] = dpos - dpos0;
 	TG_TRACE_END(0u, (TG_STREAM_WPB <= 4 ? 4u / TG_STREAM_WPB : 1u));
 #ifdef TGS_TIMING
 	if (lane == 0)
@@ -1446,9 +1590,8 @@ static uint32_t host_pattern_bits(const uint8_t *seq, int from, int n)
 
 static void stream_patterns(tg_stream_params &prm, uint32_t chunk);
 
-/* both passes of the packed-bit front end; d_defer: scratch of TG_DEFER_WORDS(nslots) dwords (count + list) */
-/* per-kernel timing: an event to be recorded right in front of the next k_front_stream launch of this thread (behind the
- * clearing of the deferred-slot counter, which is a launch of its own) */
+/* both passes of the packed-bit front end; d_defer: scratch of TG_DEFER_WORDS(nslots) dwords (a count and a list per wave of the first pass) */
+/* per-kernel timing: an event to be recorded right in front of the next k_front_stream launch of this thread */
 static __thread void *tl_front_ev_start;
 extern "C" void tgk_front_stream_ev_start(void *ev)
 {
@@ -1465,7 +1608,12 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 		cap = (uint32_t)tgi_option(TGPU_OPT_FRONT_BLOCKS);
 	if (blocks > cap)
 		blocks = cap;
-	HIPCHK(hipMemsetAsync(d_defer, 0, 4, s));
+#if TGS_DEFER_ATOMIC
+	{
+		const uint32_t fw_ = (blocks * (4 / TG_STREAM_WPB)) * TG_STREAM_WPB, fg_ = (nslots + 3) / 4, cw_ = 4u * ((fg_ + fw_ - 1) / fw_);
+		HIPCHK(hipMemsetAsync(d_defer + TG_DEFER_L0(fw_) + (size_t)fw_ * cw_, 0, 4, s));
+	}
+#endif
 	if (tl_front_ev_start) {
 		HIPCHK(hipEventRecord((hipEvent_t)tl_front_ev_start, s));
 		tl_front_ev_start = nullptr;
@@ -1480,7 +1628,13 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 	uint32_t fblocks = (nslots / 128 + 3) / 4 + 1;	/* about a wave per deferred slot at 1 % of them */
 	if (fblocks > 256 * 16)
 		fblocks = 256 * 16;
-#define FIX_LAUNCH(P, V) hipLaunchKernelGGL((k_front_stream_fix<P, V>), dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer)
+#if !TGS_DEFER_ATOMIC
+	fblocks = fgrid.x * TG_STREAM_WPB / 4;		/* a wave per list of the first pass */
+	if (!fblocks)
+		fblocks = 1;
+#endif
+	const uint32_t fw = fgrid.x * TG_STREAM_WPB, fgroups = (nslots + 3) / 4, capw = 4u * ((fgroups + fw - 1) / fw);	/* (as k_front_stream computes them) */
+#define FIX_LAUNCH(P, V) hipLaunchKernelGGL((k_front_stream_fix<P, V>), dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer, fw, capw)
 	const uint32_t view = TG_VIEW_OF(prm.chunk);	/* (the kernel built for this view) */
 	if (packed_input) {
 		if (view == 640) FIX_LAUNCH(true, 640); else if (view == 832) FIX_LAUNCH(true, 832); else FIX_LAUNCH(true, 1088);
