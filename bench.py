@@ -516,7 +516,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         if rank == 0:
             single = measure(False, alone=True)
         sync_all()
-    if args.trace_dump:     # (a -DTG_TRACE build of the library: tools/trace_untraced.py)
+    if args.trace_dump:     # (a -DTG_TRACE build of the library: tools/experiments/trace_untraced.py)
         import ctypes
         ctypes.CDLL(None)
         T.lib().tgk_trace_read(None, ctypes.byref(ctypes.c_uint(0)), 1)

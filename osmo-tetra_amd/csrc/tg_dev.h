@@ -54,7 +54,7 @@ extern "C" int tgk_upload_trellis(const tg_const_tables *host);
 extern "C" int tgk_upload_aux(const tg_const_tables *host);
 
 #ifdef TG_TRACE
-/* measurement build (tools/trace_untraced.py): the heavy kernels' workgroups leave (kind, first and last tick of the 100 MHz
+/* measurement build (tools/experiments/trace_untraced.py): the heavy kernels' workgroups leave (kind, first and last tick of the 100 MHz
  * clock) in a device array -- what runs beside what in the pipelined bench WITHOUT a profiler slowing the launching thread.
  * One array per unit; tgk_trace_read() (tg_k_aux.hip) reads them one after the other */
 struct tg_trace_rec { uint32_t kind, block; unsigned long long t0, t1; };

@@ -714,7 +714,8 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 	const size_t o_down = (up + 255) & ~(size_t)255, o_big = (o_down + down_max + 255) & ~(size_t)255;
 	if (!p->d_walk) {
 		HCHK(hipMalloc((void **)&p->d_walk, o_big + big));
-		if (hipHostMalloc((void **)&p->h_walk, o_big, hipHostMallocDefault) != hipSuccess) {
+		/* (mapped and coherent: the batch's outcome is stored into it by a kernel, tgk_copy16) */
+		if (hipHostMalloc((void **)&p->h_walk, o_big, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
 			p->h_walk = NULL;
 			(void)hipFree(p->d_walk);
 			p->d_walk = NULL;
@@ -749,6 +750,10 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 	io->h_codes = (uint32_t *)(io->h_roots + 64);
 	io->d_down0 = p->d_walk + o_down;
 	io->h_down0 = p->h_walk + o_down;
+	{
+		void *dv = NULL;
+		io->hd_down0 = (hipHostGetDevicePointer(&dv, p->h_walk, 0) == hipSuccess && dv) ? (uint8_t *)dv + o_down : NULL;
+	}
 	io->d_sums = (struct tg_walk_sum *)io->d_down0;
 	io->h_sums = (struct tg_walk_sum *)io->h_down0;
 	io->d_final = (uint32_t *)(io->d_sums + 64);

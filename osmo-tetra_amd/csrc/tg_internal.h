@@ -186,6 +186,7 @@ struct tg_walk_io {
 	struct tg_walk_root *d_roots, *h_roots;
 	uint32_t *d_codes, *h_codes;
 	uint8_t *d_down0, *h_down0;
+	uint8_t *hd_down0;	/* h_down0 as the device sees it (mapped, coherent host memory), or NULL */
 	size_t down_bytes;
 	struct tg_walk_sum *d_sums, *h_sums;
 	tgpu_sync_event_rec_dev *d_eager, *h_eager;
@@ -220,6 +221,9 @@ int tgk_traffic(const uint32_t *d_items432, uint32_t n432, const uint32_t *d_ite
 		const uint8_t *d_traffic, const uint32_t *d_packed, const uint32_t *d_masks, const uint32_t *d_maskidx,
 		uint8_t *d_rec, uint8_t *d_wire, uint32_t nslots, uint8_t *d_type4, int16_t *d_blocks, uint16_t *d_lens,
 		void *stream);
+
+/* nbytes (rounded up to 16; both ends 16-byte aligned and that long) from one device-visible address to another, by a kernel */
+int tgk_copy16(const void *d_src, void *d_dst, size_t nbytes, void *stream);
 
 /* optional RM(30,14) decoder (tg_rm.c): coset-leader table (65536 words, built on first use) and the generator's
  * parity rows; tgk_rm_enable() uploads both for the kernels (flag TGK_F_RM of tgk_vit / tgk_bbk_blocks) */

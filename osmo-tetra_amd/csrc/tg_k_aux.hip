@@ -236,6 +236,32 @@ void k_masks(const uint32_t *chan_code, uint32_t nchan, const uint32_t *sb_ok, c
 
 
 /* ------------------------------------------------------------------------- */
+/* k_copy16: a small block between device memory and mapped host memory        */
+/* ------------------------------------------------------------------------- */
+/* What a device-walk batch hands back (summaries, eager events, delivered bitmap: ~140 KB) goes to the host's mapped, coherent
+ * buffer by stores of this kernel instead of hipMemcpyAsync: the runtime's copy path now and then holds the CALLING thread
+ * for the 7 ms the stream's queued work takes (tools/experiments/bracket_times.py: one launch call in twenty, always the
+ * copy down) -- a launch cannot. */
+__global__ __launch_bounds__(256)
+void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16)
+{
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256)
+		dst[i] = src[i];
+}
+
+extern "C" int tgk_copy16(const void *d_src, void *d_dst, size_t nbytes, void *stream)
+{
+	const uint32_t n16 = (uint32_t)((nbytes + 15) / 16);
+	if (!n16)
+		return 0;
+	uint32_t blocks = (n16 + 255) / 256;
+	if (blocks > 64)
+		blocks = 64;
+	hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_src, (uint4 *)d_dst, n16);
+	return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
 /* the constant tables and the process-wide init                              */
 /* ------------------------------------------------------------------------- */
 static uint32_t lfsr_next(uint32_t *st)

@@ -633,7 +633,7 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
  * appends with a counter of its own.  (Rounds 2-4 had one list and one counter for the launch: an atomicAdd with a
  * return value, at device scope -- on this part that is a trip to the memory side of the fabric, every wave's goes to the
  * same address, and the wait for its answer also waits for the wave's prefetched group: 15 of the kernel's 155 us at
- * 1 % deferred slots, tools/front_ablate.sh "-DTGS_ABLATE=64".)  A wave of k_front_stream takes groups wave, wave +
+ * 1 % deferred slots, tools/experiments/front_ablate.sh "-DTGS_ABLATE=64".)  A wave of k_front_stream takes groups wave, wave +
  * nwaves, ..., so every list is an even sample of the grid whatever the damage looks like; a wave of this kernel takes the
  * lists w = wave, wave + nwaves, ... one entry at a time. */
 #define TG_DEFER_L0(fw) (((fw) + 15u) & ~15u)
@@ -802,7 +802,7 @@ struct tg_group_data {
 #define TG_STREAM_WPE 5	/* waves per SIMD.  Round 5: five (96 VGPRs allowed, 86 used).  The kernel had sat exactly at the 80 VGPRs of six waves
 			 * since round 3; taking the atomicAdd of the deferred-slot list out (above) let the scheduler reorder across that
 			 * point and the same source needed 91: eleven spills to scratch, reloaded in front of every gather (164 us at six
-			 * waves with spills, 135 at five without, 148 at four; tools/front_ablate.sh).  Rounds 3-4, with the grid at two
+			 * waves with spills, 135 at five without, 148 at four; tools/experiments/front_ablate.sh).  Rounds 3-4, with the grid at two
 			 * rounds of resident workgroups (launch_stream_front): 4 -> 161-168 us per 1 M slots, 5 -> 156-161, 6 -> 155-159,
 			 * 8 (64 VGPRs, spills) -> 195-200 */
 #endif
@@ -818,14 +818,14 @@ __device__ __forceinline__ uint32_t tsq_and2(uint32_t acc, uint32_t t0, uint32_t
 }
 
 #ifndef TGS_ABLATE
-#define TGS_ABLATE 0	/* measurement builds only (tools/front_ablate.sh): 1 no stores, 2 every group from one address, 4 no
+#define TGS_ABLATE 0	/* measurement builds only (tools/experiments/front_ablate.sh): 1 no stores, 2 every group from one address, 4 no
 			 * gathers, 8 no search and no classification, 16 no shifted copies, 32 no classification, 64 no atomic for the deferred slots,
 			 * 128 classification kept but the gather always NORM_1's, 256 no classification but the gather's type varies -- the kernel's
 			 * results are wrong with any of them */
 #endif
 #ifdef TGS_TIMING
 /* measurement build: reference-clock ticks (s_memtime, 100 MHz) a wave spends between the marks of a group, summed over
- * all waves; tools/front_phases.py */
+ * all waves; tools/experiments/front_phases.py */
 __device__ unsigned long long g_tgs_acc[8];
 extern "C" int tgk_front_stream_stamps(unsigned long long *out, int reset)
 {
@@ -1553,7 +1553,7 @@ extern "C" int tgk_front(const uint8_t *d_stream, const uint64_t *d_slot_desc,
 	if (!nslots)
 		return 0;
 	uint32_t blocks = (nslots + 3) / 4;
-	uint32_t cap = 256 * 32;	/* measured on MI355X (tools/exp_front_grid.py): 2048 156 us, 4096 154 us, 8192 144 us */
+	uint32_t cap = 256 * 32;	/* measured on MI355X (tools/experiments/exp_front_grid.py): 2048 156 us, 4096 154 us, 8192 144 us */
 	if (tgi_option(TGPU_OPT_FRONT_BLOCKS) > 0)
 		cap = (uint32_t)tgi_option(TGPU_OPT_FRONT_BLOCKS);
 	if (blocks > cap)

@@ -1481,8 +1481,17 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 	st->ent = calloc(nchan, sizeof(*st->ent));
 	st->locks = calloc(nchan, sizeof(int));
 	rc = (st->ch && st->ent && st->locks) ? TGPU_OK : TGPU_ENOMEM;
+#ifdef TG_LAUNCH_TIMING	/* measurement builds: which call of a launch takes the time (stderr, launches above 1 ms only) */
+	struct timespec lt_[16];
+	int ltn_ = 0;
+#define LT_MARK() do { if (ltn_ < 16) clock_gettime(CLOCK_MONOTONIC, &lt_[ltn_++]); } while (0)
+#else
+#define LT_MARK() do { } while (0)
+#endif
+	LT_MARK();
 	if (!rc)
 		rc = (int)hipEventCreateWithFlags(&sd->done, hipEventDisableTiming);
+	LT_MARK();
 	if (!rc)
 		memcpy(st->ch, ch, (size_t)nchan * sizeof(*ch));
 	uint64_t total = 0;
@@ -1523,7 +1532,9 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			memcpy(io->h_tab, st->ent, (size_t)nchan * sizeof(*st->ent));
 			memcpy(io->h_roots, roots, (size_t)nchan * sizeof(*roots));
 			memcpy(io->h_codes, codes, (size_t)nchan * 4);
+			LT_MARK();
 			rc = (int)hipMemcpyAsync(io->d_up0, io->h_up0, io->up_bytes, hipMemcpyHostToDevice, sd->stream);
+			LT_MARK();
 		}
 #define EVMARK(i) do { if (evs && !rc) rc = (int)hipEventRecord(evs[i], sd->stream); } while (0)
 		if (evs && !rc)		/* (armed only when the launch it is for follows: the caller destroys the event) */
@@ -1531,6 +1542,7 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 		if (!rc)
 			rc = tgk_front_stream_multi(d_base, io->d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
 						    tgpi_plan_defer_scratch(plan), stream, evs ? evs[1] : NULL, packed_input);
+		LT_MARK();
 		EVMARK(2);
 		if (!rc) {
 			/* plain bitmap + SYNC list; SB1 and the masks beside the walk (side stream), or in line when stages are timed */
@@ -1584,11 +1596,23 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			rc = tgpi_plan_cwire(plan, &cw, io->d_final + 66, stream);
 		}
 		/* what the host wants to know -- summaries, the first events of every channel, the bitmap -- in one copy */
+		LT_MARK();
 		if (!rc)
-			rc = (int)hipMemcpyAsync(io->h_down0, io->d_down0, io->down_bytes, hipMemcpyDeviceToHost, sd->stream);
+			rc = io->hd_down0 ? tgk_copy16(io->d_down0, io->hd_down0, io->down_bytes, sd->stream)
+					  : (int)hipMemcpyAsync(io->h_down0, io->d_down0, io->down_bytes, hipMemcpyDeviceToHost, sd->stream);
+		LT_MARK();
 	}
 	if (!rc)
 		rc = (int)hipEventRecord(sd->done, sd->stream);
+	LT_MARK();
+#ifdef TG_LAUNCH_TIMING
+	if (ltn_ > 1 && (lt_[ltn_ - 1].tv_sec - lt_[0].tv_sec) * 1e3 + (lt_[ltn_ - 1].tv_nsec - lt_[0].tv_nsec) * 1e-6 > 1.0) {
+		fprintf(stderr, "launch marks (ms):");
+		for (int i = 1; i < ltn_; i++)
+			fprintf(stderr, " %.3f", (lt_[i].tv_sec - lt_[i - 1].tv_sec) * 1e3 + (lt_[i].tv_nsec - lt_[i - 1].tv_nsec) * 1e-6);
+		fprintf(stderr, "\n");
+	}
+#endif
 	if (rc) {
 		/* stage 1 may have forked work onto the plan's side stream and part of the batch may be running: nothing of it may
 		 * outlive the objects freed here, and this thread's armed start event must not reach a later launch */

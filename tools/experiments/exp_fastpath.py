@@ -1,6 +1,6 @@
 """clean-block fast path (tgpu_plan_set_fastpath): step time of config 2 with the flag off / on at several channel BERs"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 n = 1_000_000

@@ -1,7 +1,7 @@
 """experiment: k_front time vs slot alignment (510-byte pitch = 2-byte aligned slots, 512 = dword-aligned,
 640 = line-aligned)"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 n = 1_000_000

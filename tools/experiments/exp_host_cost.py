@@ -1,6 +1,6 @@
 """host cost of a device-walk step: wall time of tgpu_sync_multi_launch and _collect per step, steady state"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 import bench

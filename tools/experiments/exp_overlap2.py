@@ -1,7 +1,7 @@
 """experiment: do consecutive batches overlap (front end of batch n+1 under the trellis kernels of batch n)
 when they are issued on two streams with two plans?"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 n = 1_000_000

@@ -1,7 +1,7 @@
 """experiment helper: k_front_stream (packed bits) vs k_front_stream_v1 (per position) on a 1 M-slot config-3 stream:
 classification outputs equal, microseconds per launch (HIP events around tgk_front_stream's launches)"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000

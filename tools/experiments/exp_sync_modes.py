@@ -1,6 +1,6 @@
 """compare the host-walk cost of tgpu_sync_stream (slot table) and tgpu_sync_stream_grid (bitmap) on one box"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 n = 1_000_000

@@ -1,6 +1,6 @@
 """host-walk cost split: steady-state per slot vs per re-lock (grid mode, no per-burst events)"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 n = 1_000_000

@@ -1,6 +1,6 @@
 """config 2 step time with full records / full + wire records / wire records only (tgpu_plan_set_wire_only)"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 n = 1_000_000

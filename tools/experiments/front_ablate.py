@@ -1,7 +1,7 @@
 """k_front_stream alone on the bench's batch of 8 channels: mean microseconds over nrep launches (HIP events around the
 kernel).  Used with measurement builds of the library (tools/front_ablate.sh)."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 import bench
@@ -20,3 +20,18 @@ plan = T.Plan(eng, cap, Cn)
 hs = torch.cuda.current_stream().cuda_stream
 r = [T.sync_front_prof_multi(eng, plan, streams, d_base.data_ptr(), offs, 64, 20, hs) for _ in range(3)]
 print(sys.argv[1] if len(sys.argv) > 1 else "", " ".join("front %.1f us fix %.1f us" % (a, b) for a, b in r))
+if os.environ.get("FRONT_COLD"):
+    # the same launch on NB copies of the batch in turn (as bench.py rotates its captures), one launch per measurement;
+    # "dirty": 1.2 GB of other traffic between the launches (what the rest of a step puts through the caches)
+    NB = 8
+    bases = [d_base] + [d_base.clone() for _ in range(NB - 1)]
+    junk = torch.empty(600_000_000, dtype=torch.uint8, device="cuda")
+    for dirty in (0, 1):
+        xs = []
+        for i in range(4 * NB):
+            if dirty:
+                junk.add_(1)
+            xs.append(T.sync_front_prof_multi(eng, plan, streams, bases[i % NB].data_ptr(), offs, 64, 1, hs))
+        xs = xs[NB:]
+        print("   rotating %d copies%s: front %.1f us fix %.1f us" % (NB, ", caches dirtied between launches" if dirty else "",
+              sum(a for a, _ in xs) / len(xs), sum(b for _, b in xs) / len(xs)))

@@ -3,5 +3,5 @@
 # usage: tools/front_ablate.sh "<flags A>" "<flags B>" ...   ("" = the product build)
 for flags in "$@"; do
   TGPU_HIPCC_FLAGS="$flags" python -c "import osmo_tetra_amd as T; T.build_library(force=True)" >/dev/null 2>&1
-  python tools/front_ablate.py "[$flags]" 2>/dev/null
+  python tools/experiments/front_ablate.py "[$flags]" 2>/dev/null
 done

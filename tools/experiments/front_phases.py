@@ -2,7 +2,7 @@
 ticks (100 MHz) between the marks of a group, summed over all waves of one launch on the bench's batch of 8 channels,
 printed per group and as shares"""
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 import osmo_tetra_amd as T
 import bench

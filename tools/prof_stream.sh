@@ -1,10 +1,10 @@
 #!/bin/bash
-# rocprofv3 passes over tools/exp_stream_front.py (stream front end only).  Outputs under gpurun_out/prof_$TAG/.
+# rocprofv3 passes over tools/experiments/exp_stream_front.py (stream front end only).  Outputs under gpurun_out/prof_$TAG/.
 TAG=${1:-sf}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $PWD/tools/exp_stream_front.py"
+CMD="python $PWD/tools/experiments/exp_stream_front.py"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 if [ "$2" != "trace" ]; then

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_stream(const uint4 *in, size_t n16, uin
 	}
 	if (acc == 0x12345678u) out[0] = acc;
 }
-template <bool STORE>
+template <int STORE>
 __global__ __launch_bounds__(256) void k_groups(const uint8_t *in, uint32_t ngroups, uint32_t *packed, uint32_t *out)
 {
 	const uint32_t lane = threadIdx.x & 63;
@@ -39,13 +39,13 @@ __global__ __launch_bounds__(256) void k_groups(const uint8_t *in, uint32_t ngro
 		fetch(g1 < ngroups ? g1 : g, a1, b1, c1);
 		uint32_t v = a0.x ^ a0.y ^ a0.z ^ a0.w ^ b0.x ^ b0.y ^ b0.z ^ b0.w ^ c0.x ^ c0.y ^ c0.z ^ c0.w;
 		acc ^= v;
-		if (STORE) { packed[(size_t)g * 80 + lane] = v; if (lane < 16) packed[(size_t)g * 80 + 64 + lane] = v; }
+		if (STORE == 1) { packed[(size_t)g * 80 + lane] = v; if (lane < 16) packed[(size_t)g * 80 + 64 + lane] = v; } else if (STORE == 2) packed[(size_t)g * 64 + lane] = v;
 		if (g1 >= ngroups) break;
 		const uint32_t g2 = g1 + nwaves;
 		fetch(g2 < ngroups ? g2 : g1, a0, b0, c0);
 		v = a1.x ^ a1.y ^ a1.z ^ a1.w ^ b1.x ^ b1.y ^ b1.z ^ b1.w ^ c1.x ^ c1.y ^ c1.z ^ c1.w;
 		acc ^= v;
-		if (STORE) { packed[(size_t)g1 * 80 + lane] = v; if (lane < 16) packed[(size_t)g1 * 80 + 64 + lane] = v; }
+		if (STORE == 1) { packed[(size_t)g1 * 80 + lane] = v; if (lane < 16) packed[(size_t)g1 * 80 + 64 + lane] = v; } else if (STORE == 2) packed[(size_t)g1 * 64 + lane] = v;
 		if (g2 >= ngroups) break;
 		g = g2;
 	}
@@ -57,6 +57,8 @@ int main()
 	const uint32_t n = 1000000; const size_t bytes = (size_t)n * 510 + 4096;
 	std::vector<uint8_t *> d(NB);
 	uint32_t *o, *pk;
+	std::vector<uint32_t *> pks(NB);
+	for (int i = 0; i < NB; i++) (void)hipMalloc(&pks[i], (size_t)n * 80 + 4096);
 	for (int i = 0; i < NB; i++) { (void)hipMalloc(&d[i], bytes); (void)hipMemset(d[i], 1 + i, bytes); }
 	(void)hipMalloc(&o, 4); (void)hipMalloc(&pk, (size_t)n * 80 + 4096);
 	hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -79,9 +81,13 @@ int main()
 			    [&](uint8_t *p) { hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, 0, (const uint4 *)p, (size_t)n * 510 / 16, o); });
 		for (int blocks : {2560, 3072, 5120})
 			run(blocks == 2560 ? "group pattern, 2560 blocks" : blocks == 3072 ? "group pattern, 3072 blocks" : "group pattern, 5120 blocks", nb,
-			    [&](uint8_t *p) { hipLaunchKernelGGL(k_groups<false>, dim3(blocks), dim3(256), 0, 0, p, ngroups, pk, o); });
+			    [&](uint8_t *p) { hipLaunchKernelGGL(k_groups<0>, dim3(blocks), dim3(256), 0, 0, p, ngroups, pk, o); });
 		run("group pattern + packed-slot stores, 2560 blocks", nb,
-		    [&](uint8_t *p) { hipLaunchKernelGGL(k_groups<true>, dim3(2560), dim3(256), 0, 0, p, ngroups, pk, o); });
+		    [&](uint8_t *p) { hipLaunchKernelGGL(k_groups<1>, dim3(2560), dim3(256), 0, 0, p, ngroups, pk, o); });
+		run("group pattern + stores, OUTPUT rotating too", nb,
+		    [&](uint8_t *p) { int w = 0; for (int i = 0; i < NB; i++) if (d[i] == p) w = i; hipLaunchKernelGGL(k_groups<1>, dim3(2560), dim3(256), 0, 0, p, ngroups, pks[w], o); });
+		run("group pattern + 64-byte packed slots, 2560 blocks", nb,
+		    [&](uint8_t *p) { hipLaunchKernelGGL(k_groups<2>, dim3(2560), dim3(256), 0, 0, p, ngroups, pk, o); });
 	}
 	return 0;
 }
