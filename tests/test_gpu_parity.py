@@ -1498,6 +1498,44 @@ def test_generic_trellis_full_size_roundtrip(T, eng):
         cv.close()
 
 
+@pytest.mark.parametrize("L,K,mother,pu", [(8, 12, 4, 0), (8, 24, 4, 1), (8, 24, 3, 1)])
+def test_generic_trellis_is_maximum_likelihood_with_the_stated_tie_rule_exhaustively(T, eng, L, K, mother, pu):
+    """every received word of a short block through k_conv (tgpu_conv_execute), erasures included: the brute-force
+    minimum-distance sequence under the stated tie rule (tests/ml_exhaustive.py), which is also the oracle's answer
+    (test_oracle_props.py does the same on the CPU).  One launch per erasure pattern, up to 4096 blocks each."""
+    import torch
+    import ml_exhaustive as ML
+    try:
+        cv = T.ConvDecoder(eng, pu, mother, K, L)
+    except T.TgpuError:
+        pytest.skip("shape not accepted for this puncturer")
+    if O.conv_decode_block(pu, mother, np.zeros(K, np.uint8), L, 0) is None:
+        pytest.skip("shape not valid for the oracle")
+    hs = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(L * 100 + K + mother)
+    xs, cb = ML.codebook(L, K, mother, pu)
+    words = ((np.arange(1 << K)[:, None] >> np.arange(K)[None, :]) & 1).astype(np.uint8) if K <= 12 else \
+        rng.integers(0, 2, (4096, K)).astype(np.uint8)
+    tied = total = 0
+    for pat in ML.erasure_patterns(K, rng):
+        rx = words.copy()
+        rx[:, pat] = 0xff
+        rx = np.unique(rx, axis=0)
+        want, dmin, nties = ML.ml_decode(xs, cb, rx)
+        n = len(rx)
+        d_in = torch.from_numpy(rx.reshape(-1)).cuda()
+        d_out = torch.full((n * L,), 9, dtype=torch.uint8, device="cuda")
+        cv.execute(d_in.data_ptr(), n, d_out.data_ptr(), hs)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().reshape(n, L)
+        bad = np.flatnonzero((got != want).any(1))
+        assert not len(bad), (pat.nonzero()[0].tolist(), rx[bad[0]].tolist(), got[bad[0]].tolist(), want[bad[0]].tolist(), int(nties[bad[0]]))
+        tied += int((nties > 1).sum())
+        total += n
+    assert tied > total // 8
+    cv.close()
+
+
 def test_generic_trellis_rejects_bad_shapes(T, eng):
     for args in ((7, 4, 120, 80), (0, 5, 120, 80), (0, 4, 432, 80), (0, 4, 15, 10), (0, 4, 1200, 800)):
         with pytest.raises(T.TgpuError):

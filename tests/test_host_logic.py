@@ -388,3 +388,62 @@ def test_pack_bits_host():
     x[77777] = 3
     p, bad = T.pack_bits(x, nthreads=4)
     assert bad > 0 and (p == np.packbits(x & 1, bitorder="little")).all()
+
+
+def test_adapter_uses_only_what_the_header_declares(tmp_path):
+    """tools/tgpu_adapter.c is the file a maintainer of the reference adds; it needs libosmocore
+    and the reference's headers, which are not here -- and nothing imitates them.  What CAN rot on this side is its use
+    of include/tetra_gpu.h: every tgpu_* function it calls and every struct tgpu_unitdata field it reads is put into a
+    probe that includes only tetra_gpu.h (the field must exist, the function must be declared and take that many
+    arguments) and compiled with gcc -fsyntax-only.  Also: tetra_gpu.h behind the reference headers' include guards
+    (the adapter includes those first) still declares the library's own API."""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "tools", "tgpu_adapter.c")).read()
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    fields = sorted(set(re.findall(r"\bud->(\w+)", code)))
+    calls = {}
+    for m in re.finditer(r"\b(tgpu_(?!adapter_)\w+)\s*\(", code):
+        depth, i, nargs, start = 1, m.end(), 0, m.end()
+        while depth:
+            c = code[i]
+            depth += c == "("
+            depth -= c == ")"
+            nargs += (c == "," and depth == 1)
+            i += 1
+        calls[m.group(1)] = nargs + (1 if code[start:i - 1].strip() else 0)
+    assert {"type1", "type1_len", "type4", "type4_len", "traffic", "lchan", "crc_ok", "scrambling_code", "blk_num", "tdma_time"} <= set(fields)
+    assert {"tgpu_traffic_block", "tgpu_engine_create", "tgpu_channel_create", "tgpu_channel_bind_flags"} <= set(calls)
+    probe = ["#include \"tetra_gpu.h\"", "static void probe(const struct tgpu_unitdata *ud)", "{"]
+    probe += ["\t(void)sizeof(ud->%s);" % f for f in fields]
+    probe += ["}"]
+    for fn, n in sorted(calls.items()):       # a call with n null arguments type-checks iff the function is declared with n parameters
+        probe += ["static void call_%s(void) { (void)%s(%s); }" % (fn, fn, ", ".join(["0"] * n))] if fn != "tgpu_traffic_block" and fn != "tgpu_channel_bind_flags" else \
+                 ["static void call_%s(void) { %s(%s); }" % (fn, fn, ", ".join(["0"] * n))]
+    # the callback has upper_mac_prim_recv()'s contract: the adapter's function must be assignable to tgpu_unitdata_cb
+    sig = re.search(r"int\s+tgpu_adapter_unitdata\s*\(([^)]*)\)", code).group(1)
+    probe += ["static int cb(%s) { (void)ud; (void)offset; (void)priv; return -1; }" % sig, "static tgpu_unitdata_cb check_cb = cb;",
+              "int main(void) { (void)probe; (void)check_cb; %s return 0; }" % " ".join("(void)call_%s;" % fn for fn in sorted(calls))]
+    f = tmp_path / "probe.c"
+    f.write_text("\n".join(probe) + "\n")
+    gcc = shutil.which("gcc")
+    assert gcc
+    r = subprocess.run([gcc, "-std=gnu11", "-Wall", "-Werror", "-Wno-unused-function", "-Wno-unused-variable", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(f)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # the mirrored reference types stand behind the reference headers' include guards: with those defined (as when the
+    # adapter has included the reference's headers first) the header must still parse given the types from elsewhere
+    g = tmp_path / "guards.c"
+    g.write_text("\n".join([
+        "#include <stdint.h>", "#include <stdbool.h>",
+        "#define TETRA_BURST_H", "#define TETRA_COMMON_H", "#define TETRA_TDMA_H", "#define TETRA_BURST_SYNC_H", "#define TETRA_SCRAMB_H",
+        "/* what the reference's own headers would have declared (phy/tetra_burst.h, tetra_common.h, tetra_tdma.h, phy/tetra_burst_sync.h) */",
+        "enum tp_sap_data_type { TPSAP_T_SB1, TPSAP_T_SB2, TPSAP_T_NDB, TPSAP_T_BBK, TPSAP_T_SCH_HU, TPSAP_T_SCH_F };",
+        "enum tetra_train_seq { TETRA_TRAIN_NORM_1, TETRA_TRAIN_NORM_2, TETRA_TRAIN_NORM_3, TETRA_TRAIN_SYNC, TETRA_TRAIN_EXT };",
+        "enum tetra_log_chan { TETRA_LC_UNKNOWN };", "struct tetra_tdma_time { uint16_t hn; uint32_t sn, tn, fn, mn; };",
+        "struct tetra_phy_state { struct tetra_tdma_time time; };", "struct tetra_rx_state;",
+        "#include \"tetra_gpu.h\"", "int main(void) { return (int)sizeof(struct tgpu_unitdata) * 0; }"]) + "\n")
+    r = subprocess.run([gcc, "-std=gnu11", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(g)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
