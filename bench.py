@@ -526,6 +526,19 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         buf = np.zeros((1 << 20, 3), np.uint64)
         T.lib().tgk_trace_read(buf.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nrec), 1)
         np.save(args.trace_dump, buf[:nrec.value])
+    # what a caller who waits for every batch sees: launch, collect, next -- one batch in flight, rotating captures
+    one_at_a_time = None
+    if world == 1:
+        xs = []
+        for k in range(28):
+            t0_ = time.perf_counter()
+            m_ = T.MultiSyncDev(eng, plans[0], None, d_bases[k % NB].data_ptr(), None, recs[0].data_ptr(), 64, strm[0].cuda_stream, chans=chans)
+            m_.collect_begin()
+            m_.collect_end(raw=True)
+            xs.append((time.perf_counter() - t0_) * 1e3)
+        one_at_a_time = {"ms_per_batch_median": _median(xs[4:]), "ms_per_batch_max": max(xs[4:]), "batches": len(xs) - 4,
+                         "note": "tgpu_sync_multi_launch + tgpu_sync_multi_collect of one 1 M-slot batch at a time (host wall clock, the launch "
+                                 "call, all kernels, the outcome's way down and the wait included)"}
     # what the rotation is worth: the same run with every step in flight on ONE capture (rounds 1-4 measured this)
     one_input = None
     if world == 1 and not args.no_secondary and NB > 1:
@@ -994,7 +1007,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                       "windows_ms_per_step_without_the_averaging": head["unsmoothed_windows_ms_per_step"],
                       "all_windows_ms_per_step": head["all_windows_ms_per_step"],
                       "sync_bracketed_ms_per_step (K steps between two synchronisations, ramp-up and drain included)": head["sync_bracketed_ms_per_step"],
-                      "front_end_launches_per_window": K},
+                      "front_end_launches_per_window": K, "one_batch_at_a_time": one_at_a_time},
            "breakdown_ms": {"host cpu per step (process_time over the continuous run: the launching thread + the HIP runtime's own)": head["host_cpu_ms_per_step"],
                             "host cpu per step, the launching thread alone (thread_time: launch call, collect, the polled wait, the interpreter); "
                             "the rest is a thread of the HIP runtime that spins while kernel completions arrive back to back": head["launch_thread_cpu_ms_per_step"],

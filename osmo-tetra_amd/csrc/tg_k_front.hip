@@ -637,6 +637,9 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
  * nwaves, ..., so every list is an even sample of the grid whatever the damage looks like; a wave of this kernel takes the
  * lists w = wave, wave + nwaves, ... one entry at a time. */
 #define TG_DEFER_L0(fw) (((fw) + 15u) & ~15u)
+#ifndef TG_FIX_LISTS
+#define TG_FIX_LISTS 4
+#endif
 template <bool PACKED, int VIEWT>
 __global__ __launch_bounds__(256)
 void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm,
@@ -652,18 +655,27 @@ void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm
 		const uint32_t *list = defer + TG_DEFER_L0(fw);
 		for (uint32_t e = wave; e < count; e += nwaves) {
 #else
-	/* a workgroup takes four neighbouring lists at a time and deals their entries round its four waves: a list holds a
-	 * handful of slots at most (0.8 on average at 1 % deferred), dealt out singly the longest queue of a wave is 2-3 */
-	for (uint32_t w4 = 4 * blockIdx.x; w4 < fw; w4 += 4 * gridDim.x) {
-		uint32_t cum[5];
+	/* a workgroup takes TG_FIX_LISTS neighbouring lists at a time and deals their entries round its four waves: a list holds a
+	 * handful of slots at most (0.8 on average at 1 % deferred).  Measured, 1 M slots, 1 % deferred: four lists per workgroup
+	 * 26-28 us, two 28-29, one (a wave's queue is then a whole list) 35-37; the single list of rounds 2-4 took 18 -- its
+	 * entries came in the order the atomics were served, these come wave by wave */
+	for (uint32_t w4 = TG_FIX_LISTS * blockIdx.x; w4 < fw; w4 += TG_FIX_LISTS * gridDim.x) {
+		uint32_t cum[TG_FIX_LISTS + 1];
 		cum[0] = 0;
 #pragma unroll
-		for (int q = 0; q < 4; q++)
+		for (int q = 0; q < TG_FIX_LISTS; q++)
 			cum[q + 1] = cum[q] + (w4 + q < fw ? defer[w4 + q] : 0u);
-		for (uint32_t e4 = wib; e4 < cum[4]; e4 += 4) {
-			const uint32_t q = (e4 >= cum[1]) + (e4 >= cum[2]) + (e4 >= cum[3]);
+		for (uint32_t e4 = wib; e4 < cum[TG_FIX_LISTS]; e4 += 4) {
+			uint32_t q = 0;
+#pragma unroll
+			for (int k = 1; k < TG_FIX_LISTS; k++)
+				q += e4 >= cum[k];
+			uint32_t base = 0;
+#pragma unroll
+			for (int k = 1; k < TG_FIX_LISTS; k++)
+				base = q == (uint32_t)k ? cum[k] : base;
 			const uint32_t *list = defer + TG_DEFER_L0(fw) + (size_t)(w4 + q) * capw;
-			const uint32_t e = e4 - (q == 0 ? cum[0] : q == 1 ? cum[1] : q == 2 ? cum[2] : cum[3]);
+			const uint32_t e = e4 - base;
 #endif
 			const uint32_t slot = list[e];
 			uint32_t myword, clsword, ys;
@@ -782,6 +794,43 @@ __device__ __forceinline__ uint32_t front_gather_bytes(const uint32_t (&a)[8])
 	return acc;
 }
 
+/* the same in two halves (round 5, TGS_GPIPE): the eight reads of a slot are issued, and taken one slot later -- the next
+ * slot's reads are in flight behind them, so a group pays two exposed LDS round trips for its four gathers, not four.
+ * LDS answers in order: "my byte i is here" = at most NEWER + 7 - i younger reads outstanding, NEWER = the eight reads of
+ * the slot issued in between (every slot issues exactly eight: one the kernel does not decode reads the zero word).  Reads
+ * the compiler puts in between only make the waits longer than needed. */
+template <int KOFF, int X>
+__device__ __forceinline__ void front_gather_issue(const uint32_t (&a)[8], uint32_t (&t)[8])
+{
+	asm volatile("; gather issue %16\n\t"
+		     "ds_read_u8 %0, %8 offset:%17\n\tds_read_u8 %1, %9 offset:%17\n\tds_read_u8 %2, %10 offset:%17\n\t"
+		     "ds_read_u8 %3, %11 offset:%17\n\tds_read_u8 %4, %12 offset:%17\n\tds_read_u8 %5, %13 offset:%17\n\t"
+		     "ds_read_u8 %6, %14 offset:%17\n\tds_read_u8 %7, %15 offset:%17"
+		     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+		     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "n"(X), "n"(KOFF)
+		     : "memory");
+}
+
+template <int NEWER>
+__device__ __forceinline__ uint32_t front_gather_take(uint32_t (&t)[8])
+{
+	uint32_t acc;
+	asm volatile("; gather take\n\t"
+		     "s_waitcnt lgkmcnt(%9)\n\tv_lshlrev_b32 %0, 31, %1\n\t"
+		     "s_waitcnt lgkmcnt(%10)\n\tv_alignbit_b32 %0, %2, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(%11)\n\tv_alignbit_b32 %0, %3, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(%12)\n\tv_alignbit_b32 %0, %4, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(%13)\n\tv_alignbit_b32 %0, %5, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(%14)\n\tv_alignbit_b32 %0, %6, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(%15)\n\tv_alignbit_b32 %0, %7, %0, 1\n\t"
+		     "s_waitcnt lgkmcnt(%16)\n\tv_alignbit_b32 %0, %8, %0, 1\n\t"
+		     "v_lshrrev_b32 %0, 24, %0"
+		     : "=&v"(acc), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])
+		     : "n"(NEWER + 7), "n"(NEWER + 6), "n"(NEWER + 5), "n"(NEWER + 4), "n"(NEWER + 3), "n"(NEWER + 2), "n"(NEWER + 1), "n"(NEWER + 0)
+		     : "memory");
+	return acc;
+}
+
 struct tg_group_data {
 	uint4 a, b, c;	/* bytes 16 l .., 1024 + 16 l .., 2048 + 16 min(l, 7) .. of the group's aligned range */
 	uint32_t a0;	/* the group starts a0 bytes into that range */
@@ -790,6 +839,9 @@ struct tg_group_data {
 
 #ifndef TGS_SYNC_LDS
 #define TGS_SYNC_LDS 1	/* the SYNC burst's gather addresses wait in LDS, not in registers */
+#endif
+#ifndef TGS_GPIPE
+#define TGS_GPIPE 0	/* 1: a slot's gather reads are issued one slot ahead of their use (front_gather_issue / _take) */
 #endif
 #ifndef TGS_DEFER_ATOMIC
 #define TGS_DEFER_ATOMIC 0	/* A/B builds only: 1 = one deferred-slot list per launch, appended to with an atomicAdd (rounds 2-4) */
@@ -905,6 +957,8 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			for (int r = 0; r < 8; r++)
 				asm volatile("" : "+v"(g_adr[x][r]));	/* the whole address in the register: the slot's offset is the immediate */
 	}
+	uint32_t zadr = ver0 + wib * (4 * TG_VER_SLOT * 4) + 64u;	/* the zero word of slot 0's window, as the asm blocks address LDS */
+	asm volatile("" : "+v"(zadr));
 	if (lane < 4)
 		win[lane * TG_VER_SLOT + 16] = 0;	/* "no source" reads this */
 	for (int i = lane; i < 128; i += 64)
@@ -1190,10 +1244,40 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			((uint8_t *)mo)[(K) * TG_PACKED_WORDS * 4 + obyte] = (uint8_t)mybyte;				\
 		}
 		TGS_MARK(4);	/* classification of the four slots */
+#if TGS_GPIPE && !TGS_ABLATE
+#define GP_ISSUE(K, T)													\
+		{													\
+			const uint32_t dt = (uint32_t)__builtin_amdgcn_readlane(dtype, CLS_LANE_OF(K));		\
+			if (dt == TG_BURST_NORM_1)										\
+				front_gather_issue<4 * TG_VER_SLOT * (K), 0>(g_adr[0], T);				\
+			else if (dt == TG_BURST_NORM_2)									\
+				front_gather_issue<4 * TG_VER_SLOT * (K), 1>(g_adr[1], T);				\
+			else if (dt == TG_BURST_SYNC)									\
+				front_gather_issue<4 * TG_VER_SLOT * (K), 2>(g_adr[2], T);				\
+			else		/* not this kernel's slot: eight reads of the zero word (the waits count on eight) */	\
+				front_gather_issue<0, 3>(g_zero, T);							\
+		}
+#define GP_TAKE(K, T, NEWER) ((uint8_t *)mo)[(K) * TG_PACKED_WORDS * 4 + obyte] = (uint8_t)front_gather_take<NEWER>(T);
+		{
+			uint32_t tA[8], tB[8];
+			const uint32_t g_zero[8] = { zadr, zadr, zadr, zadr, zadr, zadr, zadr, zadr };
+			GP_ISSUE(0, tA)
+			GP_ISSUE(1, tB)
+			GP_TAKE(0, tA, 8)
+			GP_ISSUE(2, tA)
+			GP_TAKE(1, tB, 8)
+			GP_ISSUE(3, tB)
+			GP_TAKE(2, tA, 8)
+			GP_TAKE(3, tB, 0)
+		}
+#undef GP_ISSUE
+#undef GP_TAKE
+#else
 		STREAM_SLOT_K(0)
 		STREAM_SLOT_K(1)
 		STREAM_SLOT_K(2)
 		STREAM_SLOT_K(3)
+#endif
 #undef STREAM_SLOT_K
 		TGS_MARK(5);	/* the four gathers */
 		if (CLS_OWNER) {
@@ -1629,7 +1713,7 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 	if (fblocks > 256 * 16)
 		fblocks = 256 * 16;
 #if !TGS_DEFER_ATOMIC
-	fblocks = fgrid.x * TG_STREAM_WPB / 4;		/* a wave per list of the first pass */
+	fblocks = (fgrid.x * TG_STREAM_WPB + TG_FIX_LISTS - 1) / TG_FIX_LISTS;	/* a workgroup per TG_FIX_LISTS lists of the first pass */
 	if (!fblocks)
 		fblocks = 1;
 #endif
