@@ -54,8 +54,8 @@ def main():
     fs = mv.get("k_front_stream", {})
     # shader clock while the kernels run: GRBM_GUI_ACTIVE counts every XCD's cycles
     tj["mix_sclk_ghz"] = round(fs["GRBM_GUI_ACTIVE"] / 8 / (fs["duration_us"] * 1e3), 3) if "GRBM_GUI_ACTIVE" in fs and "duration_us" in fs else 2.3
-    tj["_mix_provenance"] = ("round 4: rocprofv3 --pmc passes (tools/prof_run.sh %s mix 1) on `python bench.py --steps 12 --warmup 6 "
-                             "--windows 2 --depth 1 --no-cpu-baseline --no-secondary --no-e2e --no-sustained`; summary in profiles/r04_mix_rocprofv3.md"
+    tj["_mix_provenance"] = ("round 5: rocprofv3 --pmc passes (tools/prof_run.sh %s mix 1) on `python bench.py --steps 12 --warmup 6 "
+                             "--windows 2 --depth 1 --no-cpu-baseline --no-secondary --no-e2e --no-sustained`; summary in profiles/r05_mix_rocprofv3.md"
                              % os.path.basename(sys.argv[1]).replace("prof_", ""))
     if len(sys.argv) > 2:
         c2_t, c2_b = derive(read(sys.argv[2]))
@@ -64,16 +64,27 @@ def main():
                 tj[k] = c2_t[k]
             if k in c2_b:
                 tj.setdefault("valu_busy", {})[k] = c2_b[k]
-        tj["_provenance"] = ("round 4: the same recipe on `python bench.py --workload config2 ...` (tools/prof_run.sh %s config2 1; "
-                             "profiles/r04_config2_rocprofv3.md); bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
+        tj["_provenance"] = ("round 5: the same recipe on `python bench.py --workload config2 ...` (tools/prof_run.sh %s config2 1; "
+                             "profiles/r05_config2_rocprofv3.md); bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
                              % os.path.basename(sys.argv[2]).replace("prof_", ""))
     if len(sys.argv) > 3:
         c5_t, c5_b = derive(read(sys.argv[3]))
         keep = ("k_front_soft", "k_vit_soft", "k_float_to_bits")
         tj["config5"] = {k: c5_t[k] for k in c5_t if k.startswith(keep)}
         tj["config5_valu_busy"] = {k: c5_b[k] for k in c5_b if k.startswith(keep)}
-        tj["_config5_provenance"] = ("round 4: the same recipe on `python bench.py --workload config5 ...` (tools/prof_run.sh %s config5 1; "
-                                     "profiles/r04_config5_rocprofv3.md)" % os.path.basename(sys.argv[3]).replace("prof_", ""))
+        tj["_config5_provenance"] = ("round 5: the same recipe on `python bench.py --workload config5 ...` (tools/prof_run.sh %s config5 1; "
+                                     "profiles/r05_config5_rocprofv3.md)" % os.path.basename(sys.argv[3]).replace("prof_", ""))
+    if len(sys.argv) > 4:       # the pipelined configuration: PMC passes of `--depth 8` on rotating captures
+        d8 = read(sys.argv[4])
+        d8_t, d8_b = derive(d8)
+        tj["mix_depth8"] = {k: d8_t[k] for k in d8_t if k.startswith(("k_front_stream", "k_vit"))}
+        tj["mix_depth8_fetch_x2_bytes"] = {k: int(2 * v["FETCH_SIZE"] * 1024) for k, v in d8.items() if k.startswith(("k_front_stream", "k_vit")) and "FETCH_SIZE" in v}
+        tj["mix_depth8_valu_insts_per_step"] = insts(d8)
+        tj["_mix_depth8_provenance"] = ("round 5: the same PMC passes on the PIPELINED configuration (tools/prof_run.sh %s mix 8): `python bench.py --steps 12 "
+                                        "--warmup 6 --windows 2 --depth 8 --no-cpu-baseline --no-secondary --no-e2e --no-sustained` -- 8 steps in flight on 8 "
+                                        "distinct captures (a counter pass serialises the kernels; what it shows is each launch's traffic on input that no "
+                                        "other launch has touched for 8 steps); summary in profiles/r05_mix_depth8_rocprofv3.md"
+                                        % os.path.basename(sys.argv[4]).replace("prof_", ""))
     json.dump(tj, open(path, "w"), indent=1)
     print(json.dumps({k: tj[k] for k in ("mix", "mix_valu_busy")}, indent=1))
 
