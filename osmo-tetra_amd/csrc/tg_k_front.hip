@@ -561,13 +561,14 @@ __device__ __forceinline__ void front_stream_slot(const uint8_t *__restrict__ st
 	ysword = ys;
 }
 
-#define STREAM_SLOT_TABLES(VIEWB)									\
+#define STREAM_SLOT_TABLES(VIEWB) STREAM_SLOT_TABLES_W(VIEWB, 4)
+#define STREAM_SLOT_TABLES_W(VIEWB, NW)									\
 	constexpr int WINDW = (VIEWB) / 4 + 4;	/* the view's dwords + one zero pad row */			\
-	__shared__ uint32_t s_slot[4][WINDW];								\
+	__shared__ uint32_t s_slot[NW][WINDW];								\
 	const uint32_t lane = threadIdx.x & 63;								\
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);				\
-	const uint32_t wave = blockIdx.x * 4 + wib;							\
-	const uint32_t nwaves = gridDim.x * 4;								\
+	const uint32_t wave = blockIdx.x * (NW) + wib;							\
+	const uint32_t nwaves = gridDim.x * (NW);							\
 	const uint32_t half = lane >> 5, bit = lane & 31;						\
 	uint32_t *mine = s_slot[wib];									\
 	const uint8_t *lds0 = (const uint8_t *)&s_slot[0][0];						\
@@ -640,13 +641,16 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
 #ifndef TG_FIX_LISTS
 #define TG_FIX_LISTS 4
 #endif
+#ifndef TG_FIX_WAVES
+#define TG_FIX_WAVES 4	/* waves per workgroup of k_front_stream_fix: they share the workgroup's lists */
+#endif
 template <bool PACKED, int VIEWT>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64 * TG_FIX_WAVES)
 void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm,
 			uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
 			const uint32_t *__restrict__ defer, uint32_t fw, uint32_t capw)
 {
-	STREAM_SLOT_TABLES(VIEWT)
+	STREAM_SLOT_TABLES_W(VIEWT, TG_FIX_WAVES)
 	(void)wave;
 	(void)nwaves;
 #if TGS_DEFER_ATOMIC	/* (A/B builds: the rounds 2-4 form, one list for the launch, its counter in the last word of the scratch) */
@@ -655,17 +659,18 @@ void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm
 		const uint32_t *list = defer + TG_DEFER_L0(fw);
 		for (uint32_t e = wave; e < count; e += nwaves) {
 #else
-	/* a workgroup takes TG_FIX_LISTS neighbouring lists at a time and deals their entries round its four waves: a list holds a
-	 * handful of slots at most (0.8 on average at 1 % deferred).  Measured, 1 M slots, 1 % deferred: four lists per workgroup
-	 * 26-28 us, two 28-29, one (a wave's queue is then a whole list) 35-37; the single list of rounds 2-4 took 18 -- its
-	 * entries came in the order the atomics were served, these come wave by wave */
+	/* a workgroup takes TG_FIX_LISTS neighbouring lists at a time and deals their entries round its TG_FIX_WAVES waves: a list
+	 * holds a handful of slots at most (0.8 on average at 1 % deferred) and the kernel is as long as its longest queue.  The
+	 * single list of rounds 2-4 gave every wave one or two entries (18 us per 1 M slots with the round-4 front end).  Measured
+	 * with this round's front end: 4 lists / 4 waves 26-28 us, 8 / 8 the same, 16 / 16 29-30, 2 / 4 28-29, 1 / 4 35-37 -- and the
+	 * single atomic list 33: the kernel's time is no longer a matter of how its entries are dealt (open) */
 	for (uint32_t w4 = TG_FIX_LISTS * blockIdx.x; w4 < fw; w4 += TG_FIX_LISTS * gridDim.x) {
 		uint32_t cum[TG_FIX_LISTS + 1];
 		cum[0] = 0;
 #pragma unroll
 		for (int q = 0; q < TG_FIX_LISTS; q++)
 			cum[q + 1] = cum[q] + (w4 + q < fw ? defer[w4 + q] : 0u);
-		for (uint32_t e4 = wib; e4 < cum[TG_FIX_LISTS]; e4 += 4) {
+		for (uint32_t e4 = wib; e4 < cum[TG_FIX_LISTS]; e4 += TG_FIX_WAVES) {
 			uint32_t q = 0;
 #pragma unroll
 			for (int k = 1; k < TG_FIX_LISTS; k++)
@@ -1718,7 +1723,7 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 		fblocks = 1;
 #endif
 	const uint32_t fw = fgrid.x * TG_STREAM_WPB, fgroups = (nslots + 3) / 4, capw = 4u * ((fgroups + fw - 1) / fw);	/* (as k_front_stream computes them) */
-#define FIX_LAUNCH(P, V) hipLaunchKernelGGL((k_front_stream_fix<P, V>), dim3(fblocks), dim3(256), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer, fw, capw)
+#define FIX_LAUNCH(P, V) hipLaunchKernelGGL((k_front_stream_fix<P, V>), dim3(fblocks), dim3(64 * TG_FIX_WAVES), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer, fw, capw)
 	const uint32_t view = TG_VIEW_OF(prm.chunk);	/* (the kernel built for this view) */
 	if (packed_input) {
 		if (view == 640) FIX_LAUNCH(true, 640); else if (view == 832) FIX_LAUNCH(true, 832); else FIX_LAUNCH(true, 1088);
