@@ -247,7 +247,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     import collections
     n, C = args.bursts, max(1, args.channels)
     per = n // C
-    D = max(2, args.depth)
+    D = max(1, args.depth)      # (1: one step at a time -- what the profiles of single kernels are taken with)
     # INPUT ROTATION (round 5): a receiver sees every byte once (tetra-rx.c:82-95), so the steps in flight must not read the
     # same bytes -- NB distinct captures (own seed each: other payload bits, other damaged slots; the cells, and with them the
     # channel table, are the same), step k decodes capture k % NB.  Default NB = steps in flight: no two concurrent front

@@ -839,11 +839,15 @@ __device__ __forceinline__ uint32_t front_gather_take(uint32_t (&t)[8])
 struct tg_group_data {
 	uint4 a, b, c;	/* bytes 16 l .., 1024 + 16 l .., 2048 + 16 min(l, 7) .. of the group's aligned range */
 	uint32_t a0;	/* the group starts a0 bytes into that range */
+	uint32_t touch;	/* (TGS_TOUCH: one dword per 128-byte line of the group TGS_TOUCH rounds further on -- requested, never used) */
 	bool fast;	/* all four windows of the group lie inside the stream */
 };
 
 #ifndef TGS_SYNC_LDS
 #define TGS_SYNC_LDS 1	/* the SYNC burst's gather addresses wait in LDS, not in registers */
+#endif
+#ifndef TGS_TOUCH
+#define TGS_TOUCH 0	/* n > 0: every fetch also touches the lines of the group n rounds further on (one dword per 128-byte line) */
 #endif
 #ifndef TGS_GPIPE
 #define TGS_GPIPE 0	/* 1: a slot's gather reads are issued one slot ahead of their use (front_gather_issue / _take) */
@@ -1053,12 +1057,25 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 #endif
 		d.a0 = (uint32_t)((uintptr_t)p & 15);
 		const uint8_t *base16 = p - d.a0;
+#if TGS_TOUCH
+		{	/* pull the lines of the group this wave takes TGS_TOUCH rounds after the one being fetched towards the L2 (a cold capture:
+			 * DRAM page misses, translations), one dword per line, as long as that group lies in the same channel's bytes */
+			const uint64_t adv = (uint64_t)TGS_TOUCH * nwaves * TG_GROUP_BYTES;
+			const bool ahead = d.fast && (prm.nchan ? (gb - first) + adv + TG_GROUP_LOAD + 256 <= cspan : gb + adv + TG_GROUP_LOAD + 256 <= prm.len);
+			d.touch = 0;
+			if (ahead && lane < 18)
+				d.touch = *(const volatile uint32_t *)(base16 + adv + 128 * lane);
+		}
+#endif
 		d.a = *(const uint4 *)(base16 + 16 * lane);
 		d.b = *(const uint4 *)(base16 + 1024 + 16 * lane);
 		d.c = *(const uint4 *)(base16 + 2048 + 16 * (lane < 7 ? lane : 7));
 	};
 
 	auto work = [&](uint32_t g, const tg_group_data &cur) {
+#if TGS_TOUCH
+		asm volatile("" :: "v"(cur.touch));	/* (the touch load's register stays its own until the group's own bytes are here) */
+#endif
 		TGS_MARK(0);	/* since the last mark: the next group's fetch issued */
 		/* bytes other than 0 / 1 anywhere in the group: not for this kernel */
 		bool defer_all;

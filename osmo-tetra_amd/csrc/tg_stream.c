@@ -1537,6 +1537,11 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			LT_MARK();
 		}
 #define EVMARK(i) do { if (evs && !rc) rc = (int)hipEventRecord(evs[i], sd->stream); } while (0)
+		/* per-kernel timing: the front end's start event must not be passed while the copy up is still on its way (the copy engine's
+		 * work is a dependency of the kernel, not of the event: the kernel's "duration" then began with the wait for it, ~20 us):
+		 * a 16-byte kernel in between waits in the event's place */
+		if (evs && !rc && io->hd_down0)
+			rc = tgk_copy16(io->d_down0, io->d_down0, 16, sd->stream);
 		if (evs && !rc)		/* (armed only when the launch it is for follows: the caller destroys the event) */
 			tgk_front_stream_ev_start(evs[0]);
 		if (!rc)

@@ -26,12 +26,17 @@ if os.environ.get("FRONT_COLD"):
     NB = 8
     bases = [d_base] + [d_base.clone() for _ in range(NB - 1)]
     junk = torch.empty(600_000_000, dtype=torch.uint8, device="cuda")
-    for dirty in (0, 1):
+    chans = T.multi_chan_table(streams, offs)
+    rec = torch.empty(cap * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan2 = T.Plan(eng, cap, Cn)
+    for dirty in (0, 1, 2):
         xs = []
         for i in range(4 * NB):
-            if dirty:
+            if dirty == 1:
                 junk.add_(1)
+            if dirty == 2:      # a whole step (walk, trellis kernels) in front of the launch, as in bench.py's per-kernel pass
+                T.MultiSyncDev(eng, plan2, None, bases[(i + 3) % NB].data_ptr(), None, rec.data_ptr(), 64, hs, chans=chans).collect(raw=True)
             xs.append(T.sync_front_prof_multi(eng, plan, streams, bases[i % NB].data_ptr(), offs, 64, 1, hs))
         xs = xs[NB:]
-        print("   rotating %d copies%s: front %.1f us fix %.1f us" % (NB, ", caches dirtied between launches" if dirty else "",
+        print("   rotating %d copies%s: front %.1f us fix %.1f us" % (NB, ["", ", caches dirtied between launches", ", a whole decode step between launches"][dirty],
               sum(a for a, _ in xs) / len(xs), sum(b for _, b in xs) / len(xs)))
