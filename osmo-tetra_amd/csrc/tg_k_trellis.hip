@@ -529,11 +529,23 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	__shared__ uint32_t s_cw[(HMODE != 2) ? NW * 64 : 1];
 	/* branch-metric table (vit_core.h, tg_bm_entry): six dwords per step pair and received triple */
 	__shared__ __attribute__((aligned(16))) uint32_t s_bm[(HMODE != 2) ? TG_BM_WORDS : TG_PSOFT_TAB];
-	auto bm = [&](int p, uint32_t e, uint32_t w[6]) {
+	/* (the entry's last two dwords -- P and P' with their halves swapped -- are taken where the kernel has registers to spare:
+	 * 16 v_alignbit_b32 fewer per 16 steps; the SCH/F kernel sits at its 168 and would spill 41 of them) */
+#ifndef TG_BM8_MASK
+#define TG_BM8_MASK 0xbu	/* kinds SB1, 216, 168 */
+#endif
+	constexpr bool BM8 = (HMODE != 2) && ((TG_BM8_MASK >> KIND) & 1u);
+	auto bm = [&](int p, uint32_t e, uint32_t w[8]) {
 		const uint32_t *q = s_bm + (8 * p + e) * 8;
 		const uint4 a = *(const uint4 *)q;
-		const uint2 b = *(const uint2 *)(q + 4);
-		w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y;
+		w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+		if (BM8) {
+			const uint4 b = *(const uint4 *)(q + 4);
+			w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+		} else {
+			const uint2 b = *(const uint2 *)(q + 4);
+			w[4] = b.x; w[5] = b.y;
+		}
 	};
 	tg_vit_state v;
 	uint32_t cur = 0;
@@ -546,7 +558,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		__syncthreads();
 		tg_vit_init(v);
 		cur = s_cw[lane];
-		tg_vit_leadin_bm(v, cur >> 24, bm);
+		tg_vit_leadin_bm<BM8>(v, cur >> 24, bm);
 	}
 
 	if (HMODE == 2) {
@@ -670,11 +682,11 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 				const int g = 4 * c + it;
 				const uint32_t nxt = s_cw[(g + 1) * 64 + lane];
 				uint32_t h[4];
-				tg_vit_block_bm<false>(v, cur, h, bm);
+				tg_vit_block_bm<false, BM8>(v, cur, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * it + d] = h[d];
-				tg_vit_block_bm<false>(v, cur >> 12, h, bm);
+				tg_vit_block_bm<false, BM8>(v, cur >> 12, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * it + 4 + d] = h[d];
@@ -684,11 +696,11 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 			}
 			if (lastchunk) {
 				uint32_t h[4];
-				tg_vit_block_bm<false>(v, cur, h, bm);
+				tg_vit_block_bm<false, BM8>(v, cur, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * (nit - 1) + d] = h[d];
-				tg_vit_block_bm<true>(v, cur >> 12, h, bm);
+				tg_vit_block_bm<true, BM8>(v, cur >> 12, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * (nit - 1) + 4 + d] = h[d];

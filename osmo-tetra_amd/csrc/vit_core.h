@@ -111,8 +111,10 @@ TG_HD void tg_vit_init(tg_vit_state &v)
  *   SWMASK : bit j set -> butterfly j uses the swapped pair (w, m)
  *   QMASK  : bit j set -> butterfly j uses Q/Qt instead of P/Pt
  */
-template <unsigned SWMASK, unsigned QMASK, typename State>
-TG_HD void tg_acs(State &v, tg_us2 P, tg_us2 Pt, tg_us2 Q, tg_us2 Qt)
+/* (Pyx: P with its halves swapped, handed in by callers that have it for nothing -- the table entries of tg_bm_entry carry it;
+ * hipcc folds most half swaps into the packed add's op_sel bits but builds P.yx with a v_alignbit_b32 per step otherwise) */
+template <unsigned SWMASK, unsigned QMASK, bool HAVE_PYX = false, typename State>
+TG_HD void tg_acs(State &v, tg_us2 P, tg_us2 Pt, tg_us2 Q, tg_us2 Qt, tg_us2 Pyx = tg_us2{0, 0})
 {
 	tg_us2 N[8];
 #pragma unroll
@@ -123,7 +125,8 @@ TG_HD void tg_acs(State &v, tg_us2 P, tg_us2 Pt, tg_us2 Q, tg_us2 Qt)
 		const tg_us2 inc = ((QMASK >> j) & 1) ? Q : P;
 		const tg_us2 inct = ((QMASK >> j) & 1) ? Qt : Pt;
 		const bool sw = (SWMASK >> j) & 1;
-		const tg_us2 x = a + (sw ? inc.yx : inc);
+		const tg_us2 incs = (HAVE_PYX && !((QMASK >> j) & 1)) ? Pyx : inc.yx;
+		const tg_us2 x = a + (sw ? incs : inc);
 		const tg_us2 y = b + (sw ? inct : inct.yx);
 		N[j] = tg_min(x, y);
 	}
@@ -252,7 +255,8 @@ TG_HD void tg_bm_entry(int p, uint32_t e, uint32_t w[8])
 	w[3] = w[2] + tie_a;
 	w[4] = (e & 4) ? 0x00000100u : 0x01000000u;
 	w[5] = w[4] + tie_b;
-	w[6] = w[7] = 0;
+	w[6] = (w[0] >> 16) | (w[0] << 16);	/* P and P' with their halves swapped (tg_step_pair8) */
+	w[7] = (w[4] >> 16) | (w[4] << 16);
 }
 
 TG_HD void tg_bm_build(uint32_t *tab)
@@ -269,29 +273,47 @@ TG_HD void tg_step_pair(tg_vit_state &v, const uint32_t w[6])
 	tg_acs<TG_SW_B, TG_Q_B>(v, tg_as_us2(w[4]), tg_as_us2(w[5]), tg_as_us2(w[4]), tg_as_us2(w[5]));
 }
 
-/* bm(p, e, w): fetch the six dwords of pair p, triple e.  Same results as tg_vit_leadin / tg_vit_block. */
-template <typename Bm>
+/* the same from all eight dwords of the entry: the swapped forms come from the table */
+TG_HD void tg_step_pair8(tg_vit_state &v, const uint32_t w[8])
+{
+	tg_acs<TG_SW_A, TG_Q_A, true>(v, tg_as_us2(w[0]), tg_as_us2(w[1]), tg_as_us2(w[2]), tg_as_us2(w[3]), tg_as_us2(w[6]));
+	tg_acs<TG_SW_B, TG_Q_B, true>(v, tg_as_us2(w[4]), tg_as_us2(w[5]), tg_as_us2(w[4]), tg_as_us2(w[5]), tg_as_us2(w[7]));
+}
+
+/* bm(p, e, w): fetch the dwords of pair p, triple e into w[8] (six of them, or all eight for BM8: then the swapped forms come
+ * from the table -- one v_alignbit_b32 less per step, two more registers per pair in flight; k_vit takes it where it has the
+ * registers).  Same results as tg_vit_leadin / tg_vit_block. */
+template <bool BM8 = false, typename Bm>
 TG_HD void tg_vit_leadin_bm(tg_vit_state &v, uint32_t six, Bm bm)
 {
-	uint32_t w[2][6];
+	uint32_t w[2][8];
 	bm(0, six & 7, w[0]);
 	bm(1, (six >> 3) & 7, w[1]);
-	tg_step_pair(v, w[0]);
-	tg_step_pair(v, w[1]);
+	if (BM8) {
+		tg_step_pair8(v, w[0]);
+		tg_step_pair8(v, w[1]);
+	} else {
+		tg_step_pair(v, w[0]);
+		tg_step_pair(v, w[1]);
+	}
 	tg_vit_clean(v);
 }
 
-template <bool LAST, typename Bm>
+template <bool LAST, bool BM8 = false, typename Bm>
 TG_HD void tg_vit_block_bm(tg_vit_state &v, uint32_t tw, uint32_t h[4], Bm bm)
 {
 	constexpr int NP = LAST ? 2 : 4;
-	uint32_t w[NP][6];
+	uint32_t w[NP][8];
 #pragma unroll
 	for (int p = 0; p < NP; p++)
 		bm(p, (tw >> (3 * p)) & 7, w[p]);
 #pragma unroll
-	for (int p = 0; p < NP; p++)
-		tg_step_pair(v, w[p]);
+	for (int p = 0; p < NP; p++) {
+		if (BM8)
+			tg_step_pair8(v, w[p]);
+		else
+			tg_step_pair(v, w[p]);
+	}
 	if (LAST)
 		tg_flush4(v);
 #pragma unroll

@@ -54,18 +54,20 @@ extern "C" unsigned emul_decode_words(int kind, const uint32_t *words, uint8_t *
 	/* the kernels' branch-metric table (LDS there) */
 	static uint32_t bmtab[TG_BM_WORDS];
 	tg_bm_build(bmtab);
-	auto bm = [&](int p, uint32_t e, uint32_t w[6]) { memcpy(w, bmtab + (8 * p + e) * 8, 24); };
+	auto bm = [&](int p, uint32_t e, uint32_t w[8]) { memcpy(w, bmtab + (8 * p + e) * 8, 32); };
 	tg_vit_state v;
 	tg_vit_init(v);
-	tg_vit_leadin_bm(v, words[0] >> 24, bm);
+	const bool bm8 = kind != TG_KIND_432;		/* (as k_vit: the entries' swapped forms where the kernel takes them) */
+	if (bm8) tg_vit_leadin_bm<true>(v, words[0] >> 24, bm); else tg_vit_leadin_bm<false>(v, words[0] >> 24, bm);
 	for (int it = 0; it < nw; it++) {
 		uint32_t h[4];
-		tg_vit_block_bm<false>(v, words[it], h, bm);
+		if (bm8) tg_vit_block_bm<false, true>(v, words[it], h, bm); else tg_vit_block_bm<false, false>(v, words[it], h, bm);
 		memcpy(hist[2 * it], h, 16);
-		if (it == nw - 1)
-			tg_vit_block_bm<true>(v, words[it] >> 12, h, bm);
-		else
-			tg_vit_block_bm<false>(v, words[it] >> 12, h, bm);
+		if (it == nw - 1) {
+			if (bm8) tg_vit_block_bm<true, true>(v, words[it] >> 12, h, bm); else tg_vit_block_bm<true, false>(v, words[it] >> 12, h, bm);
+		} else {
+			if (bm8) tg_vit_block_bm<false, true>(v, words[it] >> 12, h, bm); else tg_vit_block_bm<false, false>(v, words[it] >> 12, h, bm);
+		}
 		memcpy(hist[2 * it + 1], h, 16);
 		if (kind == TG_KIND_432 && it == 8)
 			tg_vit_normalize(v);
@@ -275,28 +277,33 @@ extern "C" int emul_bm_selfcheck(uint32_t seed, int nblocks)
 {
 	static uint32_t bmtab[TG_BM_WORDS];
 	tg_bm_build(bmtab);
-	auto bm = [&](int p, uint32_t e, uint32_t w[6]) { memcpy(w, bmtab + (8 * p + e) * 8, 24); };
-	tg_vit_state a, b;
+	auto bm = [&](int p, uint32_t e, uint32_t w[8]) { memcpy(w, bmtab + (8 * p + e) * 8, 32); };
+	tg_vit_state a, b, c;	/* arithmetic / table entries of six dwords / of eight (swapped forms from the table) */
 	tg_vit_init(a);
 	tg_vit_init(b);
+	tg_vit_init(c);
 	uint32_t x = seed;
 	tg_vit_leadin(a, x & 63);
-	tg_vit_leadin_bm(b, x & 63, bm);
+	tg_vit_leadin_bm<false>(b, x & 63, bm);
+	tg_vit_leadin_bm<true>(c, x & 63, bm);
 	for (int i = 0; i < nblocks; i++) {
-		uint32_t ha[4], hb[4];
+		uint32_t ha[4], hb[4], hc[4];
 		x = x * 1664525u + 1013904223u;
 		if (i == nblocks - 1) {
 			tg_vit_block<true>(a, x >> 8, ha);
-			tg_vit_block_bm<true>(b, x >> 8, hb, bm);
+			tg_vit_block_bm<true, false>(b, x >> 8, hb, bm);
+			tg_vit_block_bm<true, true>(c, x >> 8, hc, bm);
 		} else {
 			tg_vit_block<false>(a, x >> 8, ha);
-			tg_vit_block_bm<false>(b, x >> 8, hb, bm);
+			tg_vit_block_bm<false, false>(b, x >> 8, hb, bm);
+			tg_vit_block_bm<false, true>(c, x >> 8, hc, bm);
 		}
-		if (memcmp(ha, hb, 16) || memcmp(&a.Z, &b.Z, sizeof(a.Z)))
+		if (memcmp(ha, hb, 16) || memcmp(&a.Z, &b.Z, sizeof(a.Z)) || memcmp(ha, hc, 16) || memcmp(&a.Z, &c.Z, sizeof(a.Z)))
 			return i + 1;
 		if ((i & 7) == 7) {
 			tg_vit_normalize(a);
 			tg_vit_normalize(b);
+			tg_vit_normalize(c);
 		}
 	}
 	return 0;
