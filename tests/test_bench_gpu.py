@@ -20,11 +20,16 @@ def _line(cmd):
     return json.loads(p.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("form", ["compact", "grid"])
+@pytest.mark.parametrize("form", ["compact", "grid", "compact-every-2"])
 def test_bench_two_ranks_over_gloo_on_one_gpu(form):
+    every = ["--gather-every", "2"] if form.endswith("every-2") else []
+    port = {"compact": "29533", "grid": "29534", "compact-every-2": "29535"}[form]
+    form = form.split("-")[0]
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29533" if form == "compact" else "29534", "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4",
-               "--warmup", "2", "--windows", "2", "--bursts", "64000", "--wire-form", form])
+               "--master-port", port, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4",
+               "--warmup", "2", "--windows", "2", "--bursts", "64000", "--wire-form", form] + every)
+    assert d["per_gpu_efficiency"]["scaling_claim"] == "decode_only" and 0 < d["per_gpu_efficiency"]["gathered_link_bound"] <= 1
+    assert d["gathered"]["steps_per_exchange"] == (2 if every and form == "compact" else 1)
     assert d["gathered"]["wire_form"].startswith(form)
     per_rank = d["gathered"]["bursts_delivered_per_step"] / 2
     if form == "compact":       # delivered bursts only, ~33.5 bytes each (+ bitmap and tables), against 40 per grid slot
@@ -41,10 +46,15 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(form):
     assert len(d["timing"]["windows_ms_per_step"]) == 2
 
 
-@pytest.mark.parametrize("form", ["compact", "grid"])
+@pytest.mark.parametrize("form", ["compact", "grid", "compact-every-3"])
 def test_bench_single_rank_with_the_rccl_gather(form):
+    """(compact-every-3: three steps' blocks in ONE exchange -- tgpu_comm_gatherv_batch, a grouped send / receive of three messages)"""
+    every = ["--gather-every", "3"] if form.endswith("every-3") else []
+    form = form.split("-")[0]
     d = _line([sys.executable, "bench.py", "--force-gather", "--steps", "4", "--warmup", "2", "--windows", "2", "--bursts", "64000",
-               "--no-secondary", "--no-e2e", "--no-sustained", "--wire-form", form])
+               "--no-secondary", "--no-e2e", "--no-sustained", "--wire-form", form] + every)
+    assert d["gathered"]["steps_per_exchange"] == (3 if every else 1)
+    assert 0 < d["gathered"]["link_bound"]["max_per_gpu_efficiency"] <= 1
     assert d["n_gpus"] == 1 and ("tgpu_comm_gatherv" if form == "compact" else "tgpu_comm_gather (") in d["gathered"]["exchange"]
     assert d["gathered"]["wire_form"].startswith(form)
     assert "collecting rank" in d["config"]["check"] and d["cpu_baseline"]["value"] > 0
