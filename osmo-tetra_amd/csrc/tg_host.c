@@ -753,6 +753,7 @@ int tgpi_plan_walk_io(struct tgpu_plan *p, uint32_t nchan, uint32_t ngrid, struc
 	{
 		void *dv = NULL;
 		io->hd_down0 = (hipHostGetDevicePointer(&dv, p->h_walk, 0) == hipSuccess && dv) ? (uint8_t *)dv + o_down : NULL;
+		io->hd_up0 = io->hd_down0 ? (uint8_t *)dv : NULL;
 	}
 	io->d_sums = (struct tg_walk_sum *)io->d_down0;
 	io->h_sums = (struct tg_walk_sum *)io->h_down0;

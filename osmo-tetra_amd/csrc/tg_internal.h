@@ -187,6 +187,7 @@ struct tg_walk_io {
 	uint32_t *d_codes, *h_codes;
 	uint8_t *d_down0, *h_down0;
 	uint8_t *hd_down0;	/* h_down0 as the device sees it (mapped, coherent host memory), or NULL */
+	uint8_t *hd_up0;	/* ... and h_up0 */
 	size_t down_bytes;
 	struct tg_walk_sum *d_sums, *h_sums;
 	tgpu_sync_event_rec_dev *d_eager, *h_eager;

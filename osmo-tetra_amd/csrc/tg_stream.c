@@ -1533,14 +1533,17 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 			memcpy(io->h_roots, roots, (size_t)nchan * sizeof(*roots));
 			memcpy(io->h_codes, codes, (size_t)nchan * 4);
 			LT_MARK();
-			rc = (int)hipMemcpyAsync(io->d_up0, io->h_up0, io->up_bytes, hipMemcpyHostToDevice, sd->stream);
+			/* (a few KB: fetched by a kernel from the mapped block -- no copy engine, no dependency between engines in front of
+			 * the front end, a cheaper call; the block is this plan's until the batch is collected) */
+			rc = io->hd_up0 ? tgk_copy16(io->hd_up0, io->d_up0, io->up_bytes, sd->stream)
+					: (int)hipMemcpyAsync(io->d_up0, io->h_up0, io->up_bytes, hipMemcpyHostToDevice, sd->stream);
 			LT_MARK();
 		}
 #define EVMARK(i) do { if (evs && !rc) rc = (int)hipEventRecord(evs[i], sd->stream); } while (0)
 		/* per-kernel timing: the front end's start event must not be passed while the copy up is still on its way (the copy engine's
 		 * work is a dependency of the kernel, not of the event: the kernel's "duration" then began with the wait for it, ~20 us):
 		 * a 16-byte kernel in between waits in the event's place */
-		if (evs && !rc && io->hd_down0)
+		if (evs && !rc && !io->hd_up0)
 			rc = tgk_copy16(io->d_down0, io->d_down0, 16, sd->stream);
 		if (evs && !rc)		/* (armed only when the launch it is for follows: the caller destroys the event) */
 			tgk_front_stream_ev_start(evs[0]);
