@@ -13,6 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    """a rendezvous port nobody listens on right now (fixed ports collide with a run that has not let go of its socket yet)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
+
 def _line(cmd):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
@@ -23,7 +31,7 @@ def _line(cmd):
 @pytest.mark.parametrize("form", ["compact", "grid", "compact-every-2"])
 def test_bench_two_ranks_over_gloo_on_one_gpu(form):
     every = ["--gather-every", "2"] if form.endswith("every-2") else []
-    port = {"compact": "29533", "grid": "29534", "compact-every-2": "29535"}[form]
+    port = _free_port()
     form = form.split("-")[0]
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", port, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4",
