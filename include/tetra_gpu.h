@@ -12,7 +12,9 @@
  *                          320-byte record per slot in HBM.  Replaces the arithmetic
  *                          of tetra_burst_rx_cb() (phy/tetra_burst.c:341-379) and
  *                          tp_sap_udata_ind() (lower_mac/tetra_lower_mac.c:143-357)
- *                          for many bursts at once.
+ *                          for many bursts at once.  tgpu_plan_set_traffic() /
+ *                          tgpu_plan_traffic(): the traffic-channel branch of
+ *                          tp_sap_udata_ind() (:194-241) for a batch.
  *  2. channel API (host buffers in, callbacks out):
  *       tetra_burst_sync_in()   same symbol, same struct tetra_rx_state layout and
  *                          same return values as phy/tetra_burst_sync.c:54-154.
