@@ -846,6 +846,9 @@ struct tg_group_data {
 #ifndef TGS_SYNC_LDS
 #define TGS_SYNC_LDS 1	/* the SYNC burst's gather addresses wait in LDS, not in registers */
 #endif
+#ifndef TGS_LOAD_NT
+#define TGS_LOAD_NT 0
+#endif
 #ifndef TGS_TOUCH
 #define TGS_TOUCH 0	/* n > 0: every fetch also touches the lines of the group n rounds further on (one dword per 128-byte line) */
 #endif
@@ -1067,9 +1070,21 @@ void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
 				d.touch = *(const volatile uint32_t *)(base16 + adv + 128 * lane);
 		}
 #endif
+#if TGS_LOAD_NT	/* (A/B: the capture is read once -- non-temporal loads) */
+		typedef uint32_t tgs_u4v __attribute__((ext_vector_type(4)));
+		{
+			const tgs_u4v va = __builtin_nontemporal_load((const tgs_u4v *)(base16 + 16 * lane));
+			const tgs_u4v vb = __builtin_nontemporal_load((const tgs_u4v *)(base16 + 1024 + 16 * lane));
+			const tgs_u4v vc = __builtin_nontemporal_load((const tgs_u4v *)(base16 + 2048 + 16 * (lane < 7 ? lane : 7)));
+			d.a = make_uint4(va.x, va.y, va.z, va.w);
+			d.b = make_uint4(vb.x, vb.y, vb.z, vb.w);
+			d.c = make_uint4(vc.x, vc.y, vc.z, vc.w);
+		}
+#else
 		d.a = *(const uint4 *)(base16 + 16 * lane);
 		d.b = *(const uint4 *)(base16 + 1024 + 16 * lane);
 		d.c = *(const uint4 *)(base16 + 2048 + 16 * (lane < 7 ? lane : 7));
+#endif
 	};
 
 	auto work = [&](uint32_t g, const tg_group_data &cur) {

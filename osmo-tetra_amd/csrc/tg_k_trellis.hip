@@ -92,6 +92,24 @@ __device__ __forceinline__ uint32_t hist_byte(uint32_t w0, uint32_t w1, uint32_t
  * CRC-16, type-1 bits at one byte per bit, record header / BBK / SYNC-PDU fields, optional wire record.
  * od[]: decoded type-2 bits, LSB first (bit i = input bit i of the encoder).
  */
+/* the records' type-1 bits are output only: nobody on the device reads them again.  TG_REC_NT = 1 stores them non-temporally
+ * (A/B builds; round 5: see DESIGN.md section 4) */
+#ifndef TG_REC_NT
+#define TG_REC_NT 1	/* bit 0: the SCH/F kernel's staged 64-byte segments (default), bit 1: the 16-byte stores of the other kernels */
+#endif
+typedef uint32_t tg_u4v __attribute__((ext_vector_type(4)));
+#define TG_REC_STORE_NT(P, V) __builtin_nontemporal_store(tg_u4v{ (V).x, (V).y, (V).z, (V).w }, (tg_u4v *)(P))
+#define TG_REC_STORE_PLAIN(P, V) (*(P) = (V))
+#if TG_REC_NT & 1	/* the SCH/F kernel's staged stores: whole 64-byte segments */
+#define TG_REC_STORE_SEG TG_REC_STORE_NT
+#else
+#define TG_REC_STORE_SEG TG_REC_STORE_PLAIN
+#endif
+#if TG_REC_NT & 2	/* the other kernels' stores: 16 bytes per lane, every lane in a record of its own */
+#define TG_REC_STORE TG_REC_STORE_NT
+#else
+#define TG_REC_STORE TG_REC_STORE_PLAIN
+#endif
 template <int KIND, int HMODE>
 __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::NBLK + 3) / 4 + 1], const uint16_t *s_crc, bool valid,
 					    uint32_t slot, uint32_t which, uint32_t idx, uint32_t midx,
@@ -176,7 +194,7 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 				const uint32_t rr = (lane >> 2) + 16 * i;
 				const uint4 v = *(const uint4 *)(stage + rr * TG_STAGE_PITCH + 4 * (lane & 3));
 				uint4 *dst = (uint4 *)(rec + (size_t)st_slot[rr] * TG_REC_BYTES + 64 * c + 16 * (lane & 3));
-				*dst = v;
+				TG_REC_STORE_SEG(dst, v);
 			}
 			__builtin_amdgcn_wave_barrier();
 		}
@@ -214,7 +232,7 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 #ifdef TG_EXP_NOSTORE
 			if (q == 0 || hw == 0x12345u)
 #endif
-			dst[q] = o;
+			TG_REC_STORE(dst + q, o);
 		}
 	}
 	if (!wire_only) {
