@@ -233,6 +233,16 @@ def make_mix_stream(T, n, seed, mcc=262, mnc=42, cc=1, damaged=0.01, ber=0.0):  
     return stream, types, code
 
 
+def pick_roofline_kernel(ms_by_kernel, alg_bytes):
+    """the kernel the roofline object is about: the longest one -- and where several are within 5 % of the longest (the
+    front end and the SCH/F trellis kernel are, since round 5), the one among those that moves the most algorithmic
+    bytes: that is the kernel HBM bounds; the others' bound is vector issue and they are listed beside it.  Returns
+    (kernel, the kernels that tied)"""
+    longest = max(ms_by_kernel.values())
+    tied = [k for k, v in ms_by_kernel.items() if v >= 0.95 * longest]
+    return max(tied, key=lambda k: (alg_bytes.get(k, 0), ms_by_kernel[k])), tied
+
+
 def _median(xs):
     xs = sorted(xs)
     m = len(xs) // 2
@@ -735,7 +745,6 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         if names[i] not in kern_ms:          # (SB1, code fill and masks are stages in front of the walk on this path)
             kern_ms[names[i]] = float(st_ms[i])
     kern_ms = {k: v for k, v in kern_ms.items() if not (k in ("k_fill", "k_masks") and v < 8e-3)}
-    dom = max(kern_ms, key=kern_ms.get)
     ngrid = sum(x["ngrid"] for x in outs)
     nd = sum(x["nslots"] for x in outs)
     n_sb, n_n1, n_n2 = nd // 8, nd // 2, nd - nd // 8 - nd // 2     # delivered bursts by type (the damage is uniform)
@@ -744,8 +753,10 @@ def bench_mix(args, T, torch, dist, rank, world, local):
            "k_vit<SB1>": n_sb * (60 + 16),
            "k_vit<216>": n_n2 * (14 + 124 + 124 + 3 * 16) + n_sb * (14 + 124 + 2 * 16),
            "k_vit<432>": n_n1 * (14 + 268 + 2 * 16)}
+    dom, tied = pick_roofline_kernel(kern_ms, alg)
     achieved = alg.get(dom, 0) / (kern_ms[dom] * 1e-3) / 1e9
     traffic = valu_busy = valu_pipe = traffic_prov = None
+    per_kernel = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         # the pipelined configuration's own counters where they exist (mix_depth8: PMC passes of the run with 8 steps in flight
@@ -755,6 +766,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         traffic_prov = {"key": tsrc, "provenance": tj.get("_%s_provenance" % tsrc)}
         valu_busy = tj.get("mix_valu_busy", {}).get(dom)
         vi = tj.get("mix_valu_insts_per_step")
+        # every heavy kernel against both of its bounds: HBM (algorithmic bytes / this run's duration) and vector issue (the
+        # profile's wave instructions x 4 cycles / 1024 SIMDs / this run's duration at the profile's clock)
+        per_kernel = {k: {"ms": kern_ms[k], "hbm_frac": alg[k] / (kern_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "vector_issue_frac (instruction count from profiles/traffic.json)":
+                              (vi[k] * 4.0 / (1024.0 * kern_ms[k] * 1e-3 * tj.get("mix_sclk_ghz", 2.3) * 1e9)) if vi and k in vi else None}
+                      for k in alg if k in kern_ms}
         if vi:      # the whole pipelined step against what 1024 SIMDs can issue: every wave instruction at its 4-cycle minimum
             n_in = float(sum(vi.values()))
             valu_pipe = {"wave_instructions_per_step": int(n_in), "sclk_ghz": tj.get("mix_sclk_ghz", 2.3),
@@ -1016,6 +1033,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
                         "kernel_ms": kern_ms[dom],
+                        "kernels_within_5_percent_of_the_longest": {k: kern_ms[k] for k in tied},
+                        "heavy_kernels": per_kernel,
                         "pipeline_achieved_gbs_per_gpu": float(decode_only["value"] / world * 820 / 1e9),
                         "pipeline_vector_issue": valu_pipe,
                         "measured_in_this_run": ["achieved", "frac", "kernel_ms", "pipeline_achieved_gbs_per_gpu"],
@@ -1026,8 +1045,10 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                                 "input bytes of every grid slot; a trellis kernel: type-1 bits at 1 B/bit + 16 B per block of the "
                                 "bursts it decodes) / its mean HIP-event duration on its launch stream, measured after the timed "
                                 "region; traffic = PMC bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes) and "
-                                "valu_busy_frac from profiles/traffic.json of the same command; every kernel of this path is bound by "
-                                "vector-instruction issue, not by HBM (DESIGN.md section 4)"}}
+                                "valu_busy_frac from profiles/traffic.json of the same command.  kernel = the longest kernel of a step; "
+                                "where several are within 5 % of the longest, the one of them with the most algorithmic bytes (the one "
+                                "HBM bounds: the front end; the trellis kernels are bound by vector issue -- heavy_kernels has both "
+                                "fractions for each; DESIGN.md sections 4 and 5)"}}
     if r3form:
         out["round3_form"] = {k_: r3form[k_] for k_ in ("value", "ms_per_step", "windows_ms_per_step", "window_spread", "all_windows_ms_per_step", "host_cpu_ms_per_step")}
         out["round3_form"]["note"] = ("the same measurement as round 3 ran it: 4 batches in flight and the plans' side streams in play (k_vit<432> beside "
@@ -1411,10 +1432,11 @@ def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_
     ms = prof.read(steps)  # (steps, stages) milliseconds from HIP events on the launch stream
     stage_ms = ms[min(2, steps - 1):].mean(axis=0)
     names = T.Prof.stage_names()
-    dom = int(np.argmax(stage_ms))
     n1 = int((types == T.TRAIN_NORM_1).sum())
     n2 = n - n1
     units_bytes = {"k_front": n * 510, "k_vit<432>": n1 * (ALG_BYTES[0] - 510), "k_vit<216>": n2 * (ALG_BYTES[1] - 510)}
+    domname, tied2 = pick_roofline_kernel({names[i]: float(stage_ms[i]) for i in range(len(names))}, units_bytes)
+    dom = names.index(domname)
     alg = units_bytes.get(names[dom], n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1])
     achieved = alg / (stage_ms[dom] * 1e-3) / 1e9
     value = world * n * steps / el
@@ -1437,7 +1459,7 @@ def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_
         "one_pass_at_a_time": {"ms_per_step": el_serial / steps * 1e3, "value": world * n * steps / el_serial},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": float(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": float(achieved) / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
-                     "kernel_ms": float(stage_ms[dom]),
+                     "kernel_ms": float(stage_ms[dom]), "kernels_within_5_percent_of_the_longest": tied2,
                      "stage_ms": {names[i]: float(stage_ms[i]) for i in range(len(names))},
                      "pipeline_achieved_gbs_per_gpu": float(value / world * ((n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1]) / n) / 1e9)},
     }
