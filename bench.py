@@ -303,7 +303,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     # unevenly over the runtime's four hardware queues (tgpu_plan_set_side_stream; DESIGN.md section 5 has the A/B)
     for p_ in plans:
         p_.set_side_stream(args.side_stream)
-    recs = [torch.empty(cap * T.REC_BYTES, dtype=torch.uint8, device="cuda") for _ in range(D2)]
+    # (pre-set to a value no record holds: what a step fails to write must not read as the previous step's -- equal -- answer)
+    recs = [torch.full((cap * T.REC_BYTES,), 0xa5, dtype=torch.uint8, device="cuda") for _ in range(D2)]
     strm = [torch.cuda.Stream() for _ in range(D2)]
     gather = world > 1 or args.force_gather
     nccl = args.backend == "nccl"
@@ -662,6 +663,9 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     plans[0].set_wire(wires[0].data_ptr() if gathered else 0)
     if gathered and compact:
         plans[0].set_cwire(cws[0][0].data_ptr(), cwcap)
+    torch.cuda.synchronize()
+    recs[0].fill_(0xa5)         # (the checked step writes into records that hold nothing of the timed steps' -- equal -- output)
+    torch.cuda.synchronize()
     ms = T.MultiSyncDev(eng, plans[0], None, d_base.data_ptr(), None, recs[0].data_ptr(), 64, strm[0].cuda_stream, chans=chans)
     outs = ms.collect()
     torch.cuda.synchronize()
@@ -693,12 +697,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             kn = p["code"] == codes[c]
             assert kn.mean() > (0.9 if noisy else 0.999), "channel %d: %d of %d bursts not under the cell's code" % (c, int((~kn).sum()), len(kn))
             n1, n2, sb = n1 & kn, n2 & kn, sb & kn
-            good = (p["bbk"][kn] == want[kn, :14]).all() and (p["bits1"][n1] == want[n1, 14:282]).all() and \
-                (p["bits1"][n2][:, :124] == want[n2, 14:138]).all() and (p["bits2"][n2] == want[n2, 138:262]).all() and \
-                (p["bits1"][sb][:, :60] == want[sb, 14:74]).all() and (p["bits2"][sb] == want[sb, 138:262]).all() and \
-                (p["crc"][kn, 0] == wcrc[kn, 0]).all() and (p["crc"][n2 | sb, 1] == wcrc[n2 | sb, 1]).all() and \
-                ((ty == 0) | (ty == 1) | (ty == 3)).all()
-            assert good, "decoded records of channel %d differ from the oracle" % c
+            parts = {"bbk": (p["bbk"][kn] == want[kn, :14]).all(), "SCH/F bits": (p["bits1"][n1] == want[n1, 14:282]).all(),
+                     "NDB block 1": (p["bits1"][n2][:, :124] == want[n2, 14:138]).all(), "NDB block 2": (p["bits2"][n2] == want[n2, 138:262]).all(),
+                     "SB1": (p["bits1"][sb][:, :60] == want[sb, 14:74]).all(), "SB2": (p["bits2"][sb] == want[sb, 138:262]).all(),
+                     "crc 1": (p["crc"][kn, 0] == wcrc[kn, 0]).all(), "crc 2": (p["crc"][n2 | sb, 1] == wcrc[n2 | sb, 1]).all(),
+                     "types": ((ty == 0) | (ty == 1) | (ty == 3)).all()}
+            assert all(parts.values()), "decoded records of channel %d differ from the oracle: %s" % (c, [k for k, v in parts.items() if not v])
             nchk += int(kn.sum())
             nbad += int((p["crc_ok"][kn, 0] == 0).sum() + (p["crc_ok"][n2 | sb, 1] == 0).sum())
             if with_wire:        # ... and what arrived on the collecting rank is this rank's share, byte for byte
@@ -725,6 +729,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         if ber2:
             plans[0].set_wire(0)
             plans[0].set_cwire(0)
+            recs[0].fill_(0xa5)
+            torch.cuda.synchronize()
             ms2 = T.MultiSyncDev(eng, plans[0], None, ber2_base.data_ptr(), None, recs[0].data_ptr(), 64, strm[0].cuda_stream, chans=chans)
             outs2 = ms2.collect()
             torch.cuda.synchronize()

@@ -97,6 +97,9 @@ __device__ __forceinline__ uint32_t hist_byte(uint32_t w0, uint32_t w1, uint32_t
 #ifndef TG_REC_NT
 #define TG_REC_NT 1	/* bit 0: the SCH/F kernel's staged 64-byte segments (default), bit 1: the 16-byte stores of the other kernels */
 #endif
+#ifndef TG_REC_PAIR
+#define TG_REC_PAIR 0	/* 1: the 216 kernel sends the records of NORM_2 slots whose two blocks sit in one wave out in 64-byte segments (measured: front end -7 us, this kernel +6 us per step -- off) */
+#endif
 typedef uint32_t tg_u4v __attribute__((ext_vector_type(4)));
 #define TG_REC_STORE_NT(P, V) __builtin_nontemporal_store(tg_u4v{ (V).x, (V).y, (V).z, (V).w }, (tg_u4v *)(P))
 #define TG_REC_STORE_PLAIN(P, V) (*(P) = (V))
@@ -213,12 +216,104 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 		return;
 	}
 
+	/* NORM_2 records of the 216 kernel (round 5, TG_REC_PAIR): the two blocks of a slot are neighbouring items -- lanes L and L + 1 of
+	 * a wave, almost always -- and between them the two lanes own the whole 320-byte record.  Such a pair sends it out the way the
+	 * SCH/F kernel does: five 64-byte segments through LDS, four lanes per segment, stored non-temporally (output-only lines that
+	 * the next batch's front end would otherwise have to push out of the caches).  Lanes without their partner in the wave (the
+	 * SB2 of a SYNC burst, a pair cut by a wave boundary, a block k_clean took) keep the 16-byte stores below. */
+	bool staged = false;
+	uint32_t st_bb = 0, st_nerr = 0;
+	if (KIND == TG_KIND_216 && TG_REC_PAIR && stage && !block_mode && !wire_only) {
+		const uint32_t lane = threadIdx.x & 63;
+		const uint32_t v_ = valid ? 1u : 0u;
+		/* (every lane takes part in every exchange: a lane that sits out a ds_bpermute hands its reader nothing defined) */
+		const uint32_t key = slot << 2 | which << 1 | v_;
+		const uint32_t key_n = __shfl_down(key, 1), key_p = __shfl_up(key, 1);
+		const bool nxt_ok = lane < 63 && key_n == (slot << 2 | 3u);
+		const bool prv_ok = lane > 0 && key_p == (slot << 2 | 1u);
+		const bool isA = valid && which == 0 && nxt_ok, isB = valid && which == 1 && prv_ok;
+		const unsigned long long mA = __ballot(isA);
+		staged = isA || isB;
+		if (mA) {	/* wave-uniform */
+			const uint32_t npairs = (uint32_t)__builtin_popcountll(mA);
+			const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
+			const uint32_t row = isA ? below : below - 1u;		/* (a B lane's partner is the lane below it) */
+			uint32_t *st_slot = stage + 32 * TG_STAGE_PITCH;	/* the pairs' slot numbers */
+			uint4 *mine = (uint4 *)(stage + (staged ? row : 0u) * TG_STAGE_PITCH);
+			/* what the partner knows: the header needs both CRC words */
+			const uint32_t crc_n = __shfl_down(crc, 1), ok_n = __shfl_down(crc_ok, 1);
+			uint32_t meta = 0, code = 0;
+			if (isA) {
+				st_slot[row] = slot;
+				meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
+				uint32_t bbraw;
+				if (HMODE == 2) {
+					const uint32_t *sb = softarea + (size_t)slot * (TG_SOFT_SLOT_BYTES / 4) + TG_SOFT_BBK / 4;
+					bbraw = 0;
+#pragma unroll
+					for (int q = 0; q < 4; q++)
+						bbraw |= ((((sb[q] >> 7) & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
+				} else
+					bbraw = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_BBK];
+				st_bb = bbraw ^ masks[(size_t)midx * TG_MASK_WORDS + TG_MW_BBK];
+				if (kflags & TGK_F_RM)
+					st_bb = rm3014_correct(st_bb, st_nerr);
+				code = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
+			}
+			auto bits16 = [&](int q) {	/* type-1 bits 16 q .. 16 q + 15, one per byte */
+				const uint32_t hw = (od[q >> 1] >> ((q & 1) * 16)) & 0xffff;
+				uint4 o;
+				o.x = spread4(hw);
+				o.y = spread4(hw >> 4);
+				o.z = spread4(hw >> 8);
+				o.w = (q * 16 + 12 < TYPE1) ? spread4(hw >> 12) : 0u;
+				return o;
+			};
+#pragma unroll
+			for (int c = 0; c < 5; c++) {
+				if (isA) {
+					if (c == 0) {
+						mine[0] = make_uint4((meta & 0xffffu) | (crc_ok << 16) | (ok_n << 24), (crc & 0xffffu) | (crc_n << 16), code, slot);
+						mine[1] = make_uint4(0u, 0u, 0u, st_nerr);
+						mine[2] = make_uint4(spread4(st_bb), spread4(st_bb >> 4), spread4(st_bb >> 8), spread4(st_bb >> 12) & 0x0000ffffu);
+						mine[3] = bits16(0);
+					} else if (c == 1) {
+						mine[0] = bits16(1); mine[1] = bits16(2); mine[2] = bits16(3); mine[3] = bits16(4);
+					} else if (c == 2) {
+						mine[0] = bits16(5); mine[1] = bits16(6); mine[2] = bits16(7);
+					}
+				}
+				if (isB) {
+					if (c == 2) {
+						mine[3] = bits16(0);
+					} else if (c == 3) {
+						mine[0] = bits16(1); mine[1] = bits16(2); mine[2] = bits16(3); mine[3] = bits16(4);
+					} else if (c == 4) {
+						mine[0] = bits16(5); mine[1] = bits16(6); mine[2] = bits16(7); mine[3] = make_uint4(0u, 0u, 0u, 0u);
+					}
+				}
+				__builtin_amdgcn_s_waitcnt(0xc07f);	/* lgkmcnt(0): single wave, LDS visible */
+				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (int i = 0; i < 2; i++) {
+					const uint32_t rr = (lane >> 2) + 16 * i;
+					if (rr < npairs) {
+						const uint4 v = *(const uint4 *)(stage + rr * TG_STAGE_PITCH + 4 * (lane & 3));
+						uint4 *dst = (uint4 *)(rec + (size_t)st_slot[rr] * TG_REC_BYTES + 64 * c + 16 * (lane & 3));
+						TG_REC_STORE_SEG(dst, v);
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+	}
+
 	if (!valid)
 		return;
 
 	/* ---- outputs ---- */
 	uint8_t *r = rec + (size_t)slot * TG_REC_BYTES;
-	if (!wire_only) {
+	if (!wire_only && !staged) {
 		uint4 *dst = (uint4 *)(r + (which ? TG_REC_BITS2 : TG_REC_BITS1));
 		constexpr int NST = (TYPE1 + 15) / 16;
 #pragma unroll
@@ -235,7 +330,7 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 			TG_REC_STORE(dst + q, o);
 		}
 	}
-	if (!wire_only) {
+	if (!wire_only && !staged) {
 		r[TG_REC_CRC_OK + which] = (uint8_t)crc_ok;
 		*(uint16_t *)(r + TG_REC_CRC + 2 * which) = (uint16_t)crc;
 	}
@@ -337,7 +432,10 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 		const uint32_t meta = packed[(size_t)slot * TG_PACKED_WORDS + TG_PW_META];
 		const uint32_t btype = meta & 0xff;
 		const bool primary = (KIND == TG_KIND_432) || (btype == TG_BURST_SYNC ? which == 1 : which == 0);
-		if (primary) {
+		if (primary && staged) {	/* (the record went out in segments above: the wire record's header word is left) */
+			if (wr)
+				wr[0] = btype | (((meta >> 8) & 0xff) << 8) | ((st_bb & 0x3fff) << 16);
+		} else if (primary) {
 			uint32_t bbraw;
 			if (HMODE == 2) {
 				/* hard decision of the first 16 BBK soft values: bit = (value < 0) */
@@ -501,7 +599,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 
 	__shared__ uint16_t s_crc[512];
 	/* record staging of the SCH/F kernel (vit_finish): 64 lanes x four dwordx4 at a pitch of 20 dwords + 64 slot numbers */
-	__shared__ __attribute__((aligned(16))) uint32_t s_stage[(KIND == TG_KIND_432) ? 64 * TG_STAGE_PITCH + 64 : 4];
+	__shared__ __attribute__((aligned(16))) uint32_t s_stage[(KIND == TG_KIND_432) ? 64 * TG_STAGE_PITCH + 64 : (KIND == TG_KIND_216 && TG_REC_PAIR) ? 32 * TG_STAGE_PITCH + 32 : 4];
 
 	const uint32_t lane = threadIdx.x;
 	for (int i = lane; i < 256; i += 64) {
@@ -738,7 +836,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 
 	__syncthreads();	/* s_crc visible (single wave, but keep the compiler honest) */
 	vit_finish<KIND, HMODE>(od, s_crc, valid, slot, which, idx, midx, packed, masks, rec, sb_ok, sb_code, wire, softarea, kflags,
-				(KIND == TG_KIND_432) ? s_stage : nullptr);
+				(KIND == TG_KIND_432 || (KIND == TG_KIND_216 && TG_REC_PAIR)) ? s_stage : nullptr);
 	TG_TRACE_END(1u + (uint32_t)KIND, 8u);
 }
 
