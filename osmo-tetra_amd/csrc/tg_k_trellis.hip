@@ -643,7 +643,25 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	 * touches its own cache lines; back to back they are fetched from HBM once) and parked in LDS, one column per
 	 * lane; the trellis loop then has no global loads.  Reading them one per 16 steps instead refetched the same
 	 * lines ~4x (FETCH_SIZE 183 MB for 42 MB of input on 500 k SCH/F blocks). */
-	__shared__ uint32_t s_cw[(HMODE != 2) ? NW * 64 : 1];
+	/* round 5, -DTG_CW_STAGED=1 (off): VERDICT r4 read the trellis kernels' FETCH_SIZE (2 x 70 MB each per million-slot batch) as
+	 * packed slots coming in from memory more than once and asked for one coalesced fetch per wave.  Built here: the wave fetches its
+	 * items' 16-byte pieces side by side -- five lanes cover an SCH/F slot's 80 bytes, three a half-slot block's 36 (pieces 0..2 or
+	 * 2..4 of the slot) -- in 5 / 3 load instructions that use every byte they touch, parks them row-wise (a row per item), each
+	 * lane folds its row's mask words in and the trellis reads its row (pitch 20 / 12 dwords).  Measured (tools/experiments/
+	 * fetch_quick.sh, one box, both builds): FETCH_SIZE 70.28 -> 67.74 MB (SCH/F), 70.62 -> 70.62 MB (half slots), the kernels 2 and
+	 * 4 us slower.  So the slots are NOT re-fetched; what the counter holds is (a) the whole 80 MB packed area per kernel -- SCH/F
+	 * and half-slot bursts alternate, each kernel uses every other 80-byte slot and so every 128-byte line -- and (b) ~60 MB of line
+	 * fills under the record stores: a 320-byte record is 2.5 lines, the half line it shares with a neighbour written by the OTHER
+	 * kernel is filled before the 64-byte segment lands (500 k x 128 B = 64 MB).  Neither is this fetch's to fix (DESIGN.md s. 5). */
+#ifndef TG_CW_STAGED
+#define TG_CW_STAGED 0
+#endif
+	constexpr bool CWS = (HMODE != 2) && TG_CW_STAGED && (KIND == TG_KIND_432 || KIND == TG_KIND_216);
+	constexpr int CW_P = (KIND == TG_KIND_432) ? 5 : 3;	/* 16-byte pieces per item */
+	constexpr int CW_PITCH = 4 * CW_P;
+	__shared__ __attribute__((aligned(16))) uint32_t s_cw[(HMODE != 2) ? (CWS ? 64 * CW_PITCH : NW * 64) : 4];
+	const uint32_t cw_row = CWS ? lane * CW_PITCH + ((KIND == TG_KIND_216) ? which : 0u) : lane;	/* (BLK2 = words 9..17: one word into piece 2) */
+	constexpr int CW_STEP = CWS ? 1 : 64;
 	/* branch-metric table (vit_core.h, tg_bm_entry): six dwords per step pair and received triple */
 	__shared__ __attribute__((aligned(16))) uint32_t s_bm[(HMODE != 2) ? TG_BM_WORDS : TG_PSOFT_TAB];
 	/* (the entry's last two dwords -- P and P' with their halves swapped -- are taken where the kernel has registers to spare:
@@ -669,12 +687,30 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	if (HMODE != 2) {
 		if (lane < 32)
 			tg_bm_entry(lane >> 3, lane & 7, s_bm + 8 * lane);
+		if (CWS) {
+			const uint32_t myoff = slot * TG_PACKED_WORDS + ((KIND == TG_KIND_216 && which) ? 8u : 0u);
+			uint4 t[CW_P];
 #pragma unroll
-		for (int g = 0; g < NW; g++)
-			s_cw[g * 64 + lane] = pw[g] ^ mw[g];
+			for (int k = 0; k < CW_P; k++) {
+				const uint32_t i = lane + 64u * k, r = i / CW_P, pc = i - CW_P * r;
+				const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * r), (int)myoff);
+				t[k] = *(const uint4 *)(packed + (size_t)off + 4 * pc);
+			}
+#pragma unroll
+			for (int k = 0; k < CW_P; k++)
+				*(uint4 *)(s_cw + 4 * (lane + 64u * k)) = t[k];
+			__syncthreads();
+#pragma unroll
+			for (int g = 0; g < NW; g++)
+				s_cw[cw_row + g] ^= mw[g];
+		} else {
+#pragma unroll
+			for (int g = 0; g < NW; g++)
+				s_cw[g * 64 + lane] = pw[g] ^ mw[g];
+		}
 		__syncthreads();
 		tg_vit_init(v);
-		cur = s_cw[lane];
+		cur = s_cw[cw_row];
 		tg_vit_leadin_bm<BM8>(v, cur >> 24, bm);
 	}
 
@@ -797,7 +833,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 #pragma unroll 1
 			for (int it = 0; it < nloop; it++) {
 				const int g = 4 * c + it;
-				const uint32_t nxt = s_cw[(g + 1) * 64 + lane];
+				const uint32_t nxt = s_cw[cw_row + (g + 1) * CW_STEP];
 				uint32_t h[4];
 				tg_vit_block_bm<false, BM8>(v, cur, h, bm);
 #pragma unroll
