@@ -3,6 +3,7 @@
  * (one of the four HIP units of the library: tg_dev.h has the map)
  */
 #include "tg_dev.h"
+#include <utility>
 
 
 /* clean-block fast path (k_clean): [0..4095] 12 received bits of an 8-step block -> g1 bits | g2 bits << 8;
@@ -75,6 +76,21 @@ __device__ __forceinline__ uint32_t field_msb(uint32_t lo, uint32_t hi, int sh, 
 #define FIELD_MSB(od, n0, len) field_msb((od)[(n0) >> 5], (od)[((n0) >> 5) + 1], (n0) & 31, (len))
 
 typedef uint32_t tg_v32 __attribute__((ext_vector_type(32)));
+
+/* f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop over the history chunks that is unrolled by the
+ * language, not by a pass with a size threshold (the packed operations of vit_core.h's difference form are inline assembly, which
+ * the unroller prices like calls: "#pragma unroll" over the chunks gave up, and a chunk index that is not a constant puts the
+ * whole survivor history into scratch memory) */
+template <typename F, int... I>
+__device__ __forceinline__ void tg_static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+	(f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void tg_static_for(F &&f)
+{
+	tg_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 #define TG_STAGE_PITCH 20	/* dwords per lane in the record staging area: 16 + 4 (dwordx4 rows of neighbouring lanes in different banks) */
 
@@ -663,7 +679,14 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	const uint32_t cw_row = CWS ? lane * CW_PITCH + ((KIND == TG_KIND_216) ? which : 0u) : lane;	/* (BLK2 = words 9..17: one word into piece 2) */
 	constexpr int CW_STEP = CWS ? 1 : 64;
 	/* branch-metric table (vit_core.h, tg_bm_entry): six dwords per step pair and received triple */
-	__shared__ __attribute__((aligned(16))) uint32_t s_bm[(HMODE != 2) ? TG_BM_WORDS : TG_PSOFT_TAB];
+	/* round 5, TG_ACS_D (default): the difference form of vit_core.h (tg_step_pair_d) -- the two-bit step of a pair with one add and
+	 * one min per butterfly, the one-bit step repaying the bias: 40 packed operations per pair instead of 48; ten dwords per entry in
+	 * three arrays.  -DTG_ACS_D=0 is the form of rounds 1-5 (A/B: tools/ab_lib.sh "" "-DTG_ACS_D=0"). */
+#ifndef TG_ACS_D
+#define TG_ACS_D 1
+#endif
+	constexpr bool ACSD = (HMODE != 2) && TG_ACS_D;
+	__shared__ __attribute__((aligned(16))) uint32_t s_bm[(HMODE != 2) ? (ACSD ? TG_BMD_WORDS : TG_BM_WORDS) : TG_PSOFT_TAB];
 	/* (the entry's last two dwords -- P and P' with their halves swapped -- are taken where the kernel has registers to spare:
 	 * 16 v_alignbit_b32 fewer per 16 steps; the SCH/F kernel sits at its 168 and would spill 41 of them) */
 #ifndef TG_BM8_MASK
@@ -682,10 +705,25 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 			w[4] = b.x; w[5] = b.y;
 		}
 	};
+	auto bmd = [&](int p, uint32_t o, uint32_t w[10]) {	/* o = 16 x triple: the three reads differ in their immediate offsets only */
+		const uint8_t *q = (const uint8_t *)s_bm + o;
+		const uint4 a = *(const uint4 *)(q + 4 * TG_BMD_A0 + 128 * p);
+		const uint4 b = *(const uint4 *)(q + 4 * TG_BMD_A1 + 128 * p);
+		const uint2 c = *(const uint2 *)(q + 4 * TG_BMD_A2 + 128 * p);
+		w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+		w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+		w[8] = c.x; w[9] = c.y;
+	};
 	tg_vit_state v;
 	uint32_t cur = 0;
 	if (HMODE != 2) {
-		if (lane < 32)
+		if (ACSD) {
+			if (lane < 32) {
+				uint32_t w[10];
+				tg_bmd_entry(lane >> 3, lane & 7, w);
+				tg_bmd_store(s_bm, (int)lane, w);
+			}
+		} else if (lane < 32)
 			tg_bm_entry(lane >> 3, lane & 7, s_bm + 8 * lane);
 		if (CWS) {
 			const uint32_t myoff = slot * TG_PACKED_WORDS + ((KIND == TG_KIND_216 && which) ? 8u : 0u);
@@ -711,7 +749,10 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		__syncthreads();
 		tg_vit_init(v);
 		cur = s_cw[cw_row];
-		tg_vit_leadin_bm<BM8>(v, cur >> 24, bm);
+		if (ACSD)
+			tg_vit_leadin_bmd(v, cur >> 24, bmd);
+		else
+			tg_vit_leadin_bm<BM8>(v, cur >> 24, bm);
 	}
 
 	if (HMODE == 2) {
@@ -824,41 +865,53 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		}
 	} else {
 		tg_v32 H[NCH];
-#pragma unroll
-		for (int c = 0; c < NCH; c++) {
-			const int nblk_c = (NBLK - 8 * c >= 8) ? 8 : (NBLK - 8 * c);
-			const int nit = nblk_c / 2;
-			const bool lastchunk = (c == NCH - 1);
-			const int nloop = lastchunk ? nit - 1 : nit;
+		tg_static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+			constexpr int c = decltype(cc)::value;
+			constexpr int nblk_c = (NBLK - 8 * c >= 8) ? 8 : (NBLK - 8 * c);
+			constexpr int nit = nblk_c / 2;
+			constexpr bool lastchunk = (c == NCH - 1);
+			constexpr int nloop = lastchunk ? nit - 1 : nit;
 #pragma unroll 1
 			for (int it = 0; it < nloop; it++) {
 				const int g = 4 * c + it;
 				const uint32_t nxt = s_cw[cw_row + (g + 1) * CW_STEP];
 				uint32_t h[4];
-				tg_vit_block_bm<false, BM8>(v, cur, h, bm);
+				if (ACSD)
+					tg_vit_block_bmd<false>(v, cur, h, bmd);
+				else
+					tg_vit_block_bm<false, BM8>(v, cur, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * it + d] = h[d];
-				tg_vit_block_bm<false, BM8>(v, cur >> 12, h, bm);
+				if (ACSD)
+					tg_vit_block_bmd<false>(v, cur >> 12, h, bmd);
+				else
+					tg_vit_block_bm<false, BM8>(v, cur >> 12, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * it + 4 + d] = h[d];
 				if (KIND == TG_KIND_432 && g == 8)
-					tg_vit_normalize(v);
+					tg_vit_normalize_floor(v);
 				cur = nxt;
 			}
 			if (lastchunk) {
 				uint32_t h[4];
-				tg_vit_block_bm<false, BM8>(v, cur, h, bm);
+				if (ACSD)
+					tg_vit_block_bmd<false>(v, cur, h, bmd);
+				else
+					tg_vit_block_bm<false, BM8>(v, cur, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * (nit - 1) + d] = h[d];
-				tg_vit_block_bm<true, BM8>(v, cur >> 12, h, bm);
+				if (ACSD)
+					tg_vit_block_bmd<true>(v, cur >> 12, h, bmd);
+				else
+					tg_vit_block_bm<true, BM8>(v, cur >> 12, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * (nit - 1) + 4 + d] = h[d];
 			}
-		}
+		});
 		/* block-wise traceback from state 0, all register indices static */
 		uint32_t s = 0;
 #pragma unroll

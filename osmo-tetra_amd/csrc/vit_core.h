@@ -52,6 +52,34 @@ TG_HD tg_us2 tg_as_us2(uint32_t x) { return __builtin_bit_cast(tg_us2, x); }
 TG_HD uint32_t tg_as_u32(tg_us2 x) { return __builtin_bit_cast(uint32_t, x); }
 TG_HD tg_us2 tg_min(tg_us2 a, tg_us2 b) { return __builtin_elementwise_min(a, b); }
 
+/* (a[ALO] + b[BLO], a[AHI] + b[BHI]) and the same with min: one v_pk_add_u16 / v_pk_min_u16 whose op_sel bits pick the halves.
+ * Written out for the device because hipcc's instruction selection folds most but not all half swaps into op_sel (it built
+ * three of the difference form's ten entry dwords a second time with v_alignbit_b32, per step pair). */
+template <int ALO, int AHI, int BLO, int BHI>
+TG_HD tg_us2 tg_pk_add_sel(tg_us2 a, tg_us2 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	tg_us2 d;
+	asm("v_pk_add_u16 %0, %1, %2 op_sel:[%3,%4] op_sel_hi:[%5,%6]" : "=v"(d) : "v"(a), "v"(b), "n"(ALO), "n"(BLO), "n"(AHI), "n"(BHI));
+	return d;
+#else
+	return tg_us2{ (unsigned short)(a[ALO] + b[BLO]), (unsigned short)(a[AHI] + b[BHI]) };
+#endif
+}
+
+template <int ALO, int AHI, int BLO, int BHI>
+TG_HD tg_us2 tg_pk_min_sel(tg_us2 a, tg_us2 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	tg_us2 d;
+	asm("v_pk_min_u16 %0, %1, %2 op_sel:[%3,%4] op_sel_hi:[%5,%6]" : "=v"(d) : "v"(a), "v"(b), "n"(ALO), "n"(BLO), "n"(AHI), "n"(BHI));
+	return d;
+#else
+	const unsigned short x0 = a[ALO], y0 = b[BLO], x1 = a[AHI], y1 = b[BHI];
+	return tg_us2{ x0 < y0 ? x0 : y0, x1 < y1 ? x1 : y1 };
+#endif
+}
+
 TG_HD uint32_t tg_pack_bytes02(uint32_t z0, uint32_t z1)
 {
 	/* (z0.b0, z0.b2, z1.b0, z1.b2) -> one dword; a single v_perm_b32 on gfx950 */
@@ -72,7 +100,10 @@ TG_HD uint32_t tg_brev4(uint32_t x)
 #endif
 }
 
-#define TG_VIT_INF   0x4000u	/* metric 64: large enough to lose, small enough not to wrap */
+#define TG_VIT_INF   0x4200u	/* metric 64 above the floor: large enough to lose, small enough not to wrap */
+/* every path metric is kept at or above 2: the difference form of a two-bit step (tg_acs_d2) adds n - 2m >= -2 to a
+ * predecessor's metric before the compare, and the packed arithmetic is unsigned.  A common offset changes no decision. */
+#define TG_VIT_FLOOR 0x0200u
 
 struct tg_vit_state {
 	tg_us2 Z[8];
@@ -94,7 +125,7 @@ struct tg_vit_state {
 
 TG_HD void tg_vit_init(tg_vit_state &v)
 {
-	v.Z[0] = tg_as_us2(TG_VIT_INF << 16);	/* state 0: metric 0, state 1: INF */
+	v.Z[0] = tg_as_us2(TG_VIT_FLOOR | (TG_VIT_INF << 16));	/* state 0: the floor (= "metric 0"), state 1: INF */
 #pragma unroll
 	for (int k = 1; k < 8; k++)
 		v.Z[k] = tg_as_us2(TG_VIT_INF | (TG_VIT_INF << 16));
@@ -322,6 +353,163 @@ TG_HD void tg_vit_block_bm(tg_vit_state &v, uint32_t tw, uint32_t h[4], Bm bm)
 	tg_vit_clean(v);
 }
 
+/*
+ * Difference form of a step pair (round 5): 40 packed operations per pair instead of 48.
+ *
+ * Subtract the j candidate's increment from BOTH candidates of a butterfly and the comparison -- metrics, tie bit, history
+ * byte -- is the same one, but the j candidate needs no add:
+ *     S[2j]   = min(pm[j], pm[j+8] + (n - 2m) + tie)        = new[2j]   - m
+ *     S[2j+1] = min(pm[j], pm[j+8] - (n - 2m) + tie)        = new[2j+1] - (n - m)
+ * One v_pk_add_u16 + one v_pk_min_u16 per butterfly (tg_acs_d2), and the states are left short of their true metrics by a
+ * bias beta(2j) = m_j, beta(2j+1) = n - m_j that depends on the received bits and on the state, not on the path.  The next
+ * step repays it inside its own increments (tg_acs_d3: two adds and a min as before, the increments being
+ * beta(k) + m'_k, beta(k) + 1 - m'_k for the k candidate and beta(k+8) + 1 - m'_k, beta(k+8) + m'_k for the k+8 candidate).
+ * The two-bit step of a pair runs in the difference form, the one-bit step after it repays: its increments are functions of
+ * the pair's received triple alone, every butterfly's pair of them is one of four dwords or its half swap (op_sel), and
+ * after the pair the states hold their true metrics again -- blocks, history extraction, normalisation and the flush steps
+ * see what they saw before.  (Letting the bias run on instead makes every later increment depend on the last four steps'
+ * received bits: eight different dwords per step and lane, no static selection -- more work, not less.)
+ * The unsigned packed add needs pm[j+8] + (n - 2m) >= 0: all metrics are kept at or above TG_VIT_FLOOR.
+ *
+ * With s = r1 + r2 (mismatches of a two-bit step's bits against (0,0)), u = 1 - r1 + r2 (against (1,0)), r the one-bit
+ * step's bit, tA / tB the pair's two tie bits (in both halves):
+ *   w[0] = U  = ( 2 - 2s,  2s - 2) + tA      butterflies 0, 6; swapped: 3, 5        (TG_SW_A / TG_Q_A as in tg_step_a)
+ *   w[1] = V  = ( 2 - 2u,  2u - 2) + tA      butterflies 1, 7; swapped: 2, 4
+ *   A1..A4 = (b + r, b + 1 - r) for b = s, 2 - s, u, 2 - u                          (b = the bias of the predecessor)
+ *   w[2 + 2g] = A(g+1), w[3 + 2g] = A(4-g) + tB, g = 0..3: what butterflies g and 7 - g of the one-bit step take -- the
+ *   k candidate w[2 + 2g] (half-swapped for odd k), the k+8 candidate w[3 + 2g] (half-swapped for even k) -- so a kernel
+ *   short of registers can take the entry in as it goes (dwords 0..3, 4..7, 8..9)
+ * all << 8 in each half.  Entry = ten dwords; in LDS as three arrays with a stride of 16 bytes per entry (the third holds 8) so
+ * that the eight entries of a pair stay within 32 banks per read instruction and one address serves the three reads.
+ */
+#define TG_BMD_WORDS (3 * 32 * 4)
+#define TG_BMD_A0 0		/* dwords 0..3 of entry q at 4 q       */
+#define TG_BMD_A1 (32 * 4)	/* dwords 4..7 of entry q at 128 + 4 q  */
+#define TG_BMD_A2 (32 * 8)	/* dwords 8..9 of entry q at 256 + 4 q (one 16-byte stride for all three: one address per entry) */
+
+TG_HD void tg_bmd_entry(int p, uint32_t e, uint32_t w[10])
+{
+	const uint32_t r1 = e & 1, r2 = (e >> 1) & 1, r = (e >> 2) & 1;
+	const int s = (int)(r1 + r2), u = (int)(1 - r1 + r2);
+	const uint32_t tA = 0x00010001u << (2 * p), tB = tA << 1;
+	auto pk = [](int lo, int hi) -> uint32_t { return (((uint32_t)lo << 8) & 0xffffu) | (((uint32_t)hi << 8) << 16); };
+	w[0] = pk(2 - 2 * s, 2 * s - 2) + tA;
+	w[1] = pk(2 - 2 * u, 2 * u - 2) + tA;
+	const int b[4] = { s, 2 - s, u, 2 - u };
+	for (int g = 0; g < 4; g++) {
+		w[2 + 2 * g] = pk(b[g] + (int)r, b[g] + 1 - (int)r);
+		w[3 + 2 * g] = pk(b[3 - g] + (int)r, b[3 - g] + 1 - (int)r) + tB;
+	}
+}
+
+/* the table as the kernels hold it (TG_BMD_WORDS dwords) */
+TG_HD void tg_bmd_store(uint32_t *tab, int q, const uint32_t w[10])
+{
+	for (int i = 0; i < 4; i++) {
+		tab[TG_BMD_A0 + 4 * q + i] = w[i];
+		tab[TG_BMD_A1 + 4 * q + i] = w[4 + i];
+	}
+	tab[TG_BMD_A2 + 4 * q] = w[8];
+	tab[TG_BMD_A2 + 4 * q + 1] = w[9];
+	tab[TG_BMD_A2 + 4 * q + 2] = 0;
+	tab[TG_BMD_A2 + 4 * q + 3] = 0;
+}
+
+TG_HD void tg_bmd_build(uint32_t *tab)
+{
+	for (int p = 0; p < 4; p++)
+		for (uint32_t e = 0; e < 8; e++) {
+			uint32_t w[10];
+			tg_bmd_entry(p, e, w);
+			tg_bmd_store(tab, 8 * p + (int)e, w);
+		}
+}
+
+/* the two-bit step in the difference form: U, V as above */
+template <unsigned SWMASK, unsigned QMASK>
+TG_HD void tg_acs_d2(tg_vit_state &v, tg_us2 U, tg_us2 V)
+{
+	tg_us2 N[8];
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		const tg_us2 za = v.Z[j >> 1], zb = v.Z[4 + (j >> 1)];
+		const tg_us2 D = ((QMASK >> j) & 1) ? V : U;
+		const bool sw = (SWMASK >> j) & 1;
+		tg_us2 y;
+		if (j & 1)
+			y = sw ? tg_pk_add_sel<1, 1, 1, 0>(zb, D) : tg_pk_add_sel<1, 1, 0, 1>(zb, D);
+		else
+			y = sw ? tg_pk_add_sel<0, 0, 1, 0>(zb, D) : tg_pk_add_sel<0, 0, 0, 1>(zb, D);
+		N[j] = (j & 1) ? tg_pk_min_sel<1, 1, 0, 1>(za, y) : tg_pk_min_sel<0, 0, 0, 1>(za, y);
+	}
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		v.Z[j] = N[j];
+}
+
+/* the one-bit step that repays the bias, from dwords 2..9 of the entry: butterflies in the order 0, 7, 1, 6, 2, 5, 3, 4 */
+TG_HD void tg_acs_d3(tg_vit_state &v, const uint32_t *w)
+{
+	tg_us2 N[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		const int g = i >> 1, k = (i & 1) ? 7 - g : g;
+		const tg_us2 za = v.Z[k >> 1], zb = v.Z[4 + (k >> 1)];
+		const tg_us2 A = tg_as_us2(w[2 + 2 * g]), Bt = tg_as_us2(w[3 + 2 * g]);
+		tg_us2 x, y;
+		if (k & 1) {
+			x = tg_pk_add_sel<1, 1, 1, 0>(za, A);
+			y = tg_pk_add_sel<1, 1, 0, 1>(zb, Bt);
+		} else {
+			x = tg_pk_add_sel<0, 0, 0, 1>(za, A);
+			y = tg_pk_add_sel<0, 0, 1, 0>(zb, Bt);
+		}
+		N[k] = tg_min(x, y);
+	}
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		v.Z[k] = N[k];
+}
+
+TG_HD void tg_step_pair_d(tg_vit_state &v, const uint32_t w[10])
+{
+	tg_acs_d2<TG_SW_A, TG_Q_A>(v, tg_as_us2(w[0]), tg_as_us2(w[1]));
+	tg_acs_d3(v, w);
+}
+
+/* bmd(p, o, w): fetch the ten dwords of pair p, triple e, o = 16 e (the entry's byte offset inside its array's part for pair p:
+ * a shift and a mask per pair, the rest of the address is the reads' immediate offset).  Same results as tg_vit_leadin /
+ * tg_vit_block. */
+template <typename Bm>
+TG_HD void tg_vit_leadin_bmd(tg_vit_state &v, uint32_t six, Bm bmd)
+{
+	uint32_t w[2][10];
+	bmd(0, (six << 4) & 0x70u, w[0]);
+	bmd(1, (six << 1) & 0x70u, w[1]);
+	tg_step_pair_d(v, w[0]);
+	tg_step_pair_d(v, w[1]);
+	tg_vit_clean(v);
+}
+
+template <bool LAST, typename Bm>
+TG_HD void tg_vit_block_bmd(tg_vit_state &v, uint32_t tw, uint32_t h[4], Bm bmd)
+{
+	constexpr int NP = LAST ? 2 : 4;
+	uint32_t w[NP][10];
+#pragma unroll
+	for (int p = 0; p < NP; p++)
+		bmd(p, (p < 2 ? tw << (4 - 3 * p) : tw >> (3 * p - 4)) & 0x70u, w[p]);
+#pragma unroll
+	for (int p = 0; p < NP; p++)
+		tg_step_pair_d(v, w[p]);
+	if (LAST)
+		tg_flush4(v);
+#pragma unroll
+	for (int d = 0; d < 4; d++)
+		h[d] = tg_pack_bytes02(tg_as_u32(v.Z[2 * d]), tg_as_u32(v.Z[2 * d + 1]));
+	tg_vit_clean(v);
+}
+
 /* subtract the smallest path metric from all 16 (only between blocks: low bytes are clear) */
 template <typename State>
 TG_HD void tg_vit_normalize(State &v)
@@ -330,6 +518,18 @@ TG_HD void tg_vit_normalize(State &v)
 	tg_us2 m45 = tg_min(v.Z[4], v.Z[5]), m67 = tg_min(v.Z[6], v.Z[7]);
 	tg_us2 m = tg_min(tg_min(m01, m23), tg_min(m45, m67));
 	m = tg_min(m, m.yx);
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		v.Z[k] = v.Z[k] - m;
+}
+
+/* the same for the hard trellis: the smallest metric goes back to the floor (TG_VIT_FLOOR), not to 0 */
+TG_HD void tg_vit_normalize_floor(tg_vit_state &v)
+{
+	tg_us2 m01 = tg_min(v.Z[0], v.Z[1]), m23 = tg_min(v.Z[2], v.Z[3]);
+	tg_us2 m45 = tg_min(v.Z[4], v.Z[5]), m67 = tg_min(v.Z[6], v.Z[7]);
+	tg_us2 m = tg_min(tg_min(m01, m23), tg_min(m45, m67));
+	m = tg_min(m, m.yx) - tg_as_us2(TG_VIT_FLOOR * 0x10001u);
 #pragma unroll
 	for (int k = 0; k < 8; k++)
 		v.Z[k] = v.Z[k] - m;

@@ -51,26 +51,29 @@ extern "C" unsigned emul_decode_words(int kind, const uint32_t *words, uint8_t *
 	crc_init();
 	const int nblk = tg_kind_nblk(kind), nw = nblk / 2;
 	static uint8_t hist[36][16];
-	/* the kernels' branch-metric table (LDS there) */
-	static uint32_t bmtab[TG_BM_WORDS];
-	tg_bm_build(bmtab);
-	auto bm = [&](int p, uint32_t e, uint32_t w[8]) { memcpy(w, bmtab + (8 * p + e) * 8, 32); };
+	/* the kernels' branch-metric table (LDS there): the difference form's ten dwords per pair and triple, three arrays */
+	static uint32_t bmdtab[TG_BMD_WORDS];
+	tg_bmd_build(bmdtab);
+	auto bmd = [&](int p, uint32_t o, uint32_t w[10]) {
+		const int q = 8 * p + (int)(o >> 4);
+		memcpy(w, bmdtab + TG_BMD_A0 + 4 * q, 16);
+		memcpy(w + 4, bmdtab + TG_BMD_A1 + 4 * q, 16);
+		memcpy(w + 8, bmdtab + TG_BMD_A2 + 4 * q, 8);
+	};
 	tg_vit_state v;
 	tg_vit_init(v);
-	const bool bm8 = kind != TG_KIND_432;		/* (as k_vit: the entries' swapped forms where the kernel takes them) */
-	if (bm8) tg_vit_leadin_bm<true>(v, words[0] >> 24, bm); else tg_vit_leadin_bm<false>(v, words[0] >> 24, bm);
+	tg_vit_leadin_bmd(v, words[0] >> 24, bmd);
 	for (int it = 0; it < nw; it++) {
 		uint32_t h[4];
-		if (bm8) tg_vit_block_bm<false, true>(v, words[it], h, bm); else tg_vit_block_bm<false, false>(v, words[it], h, bm);
+		tg_vit_block_bmd<false>(v, words[it], h, bmd);
 		memcpy(hist[2 * it], h, 16);
-		if (it == nw - 1) {
-			if (bm8) tg_vit_block_bm<true, true>(v, words[it] >> 12, h, bm); else tg_vit_block_bm<true, false>(v, words[it] >> 12, h, bm);
-		} else {
-			if (bm8) tg_vit_block_bm<false, true>(v, words[it] >> 12, h, bm); else tg_vit_block_bm<false, false>(v, words[it] >> 12, h, bm);
-		}
+		if (it == nw - 1)
+			tg_vit_block_bmd<true>(v, words[it] >> 12, h, bmd);
+		else
+			tg_vit_block_bmd<false>(v, words[it] >> 12, h, bmd);
 		memcpy(hist[2 * it + 1], h, 16);
 		if (kind == TG_KIND_432 && it == 8)
-			tg_vit_normalize(v);
+			tg_vit_normalize_floor(v);
 	}
 	uint8_t bytes[37] = { 0 };
 	uint32_t s = 0;
@@ -278,32 +281,49 @@ extern "C" int emul_bm_selfcheck(uint32_t seed, int nblocks)
 	static uint32_t bmtab[TG_BM_WORDS];
 	tg_bm_build(bmtab);
 	auto bm = [&](int p, uint32_t e, uint32_t w[8]) { memcpy(w, bmtab + (8 * p + e) * 8, 32); };
-	tg_vit_state a, b, c;	/* arithmetic / table entries of six dwords / of eight (swapped forms from the table) */
+	static uint32_t bmdtab[TG_BMD_WORDS];
+	tg_bmd_build(bmdtab);
+	auto bmd = [&](int p, uint32_t o, uint32_t w[10]) {	/* (the kernels' three-array layout; o = 16 x triple) */
+		const int q = 8 * p + (int)(o >> 4);
+		memcpy(w, bmdtab + TG_BMD_A0 + 4 * q, 16);
+		memcpy(w + 4, bmdtab + TG_BMD_A1 + 4 * q, 16);
+		memcpy(w + 8, bmdtab + TG_BMD_A2 + 4 * q, 8);
+	};
+	tg_vit_state a, b, c, d;	/* arithmetic / table entries of six dwords / of eight (swapped forms from the table) / difference form */
 	tg_vit_init(a);
 	tg_vit_init(b);
 	tg_vit_init(c);
+	tg_vit_init(d);
 	uint32_t x = seed;
 	tg_vit_leadin(a, x & 63);
 	tg_vit_leadin_bm<false>(b, x & 63, bm);
 	tg_vit_leadin_bm<true>(c, x & 63, bm);
+	tg_vit_leadin_bmd(d, x & 63, bmd);
+	if (memcmp(&a.Z, &d.Z, sizeof(a.Z)))
+		return -1;
 	for (int i = 0; i < nblocks; i++) {
-		uint32_t ha[4], hb[4], hc[4];
+		uint32_t ha[4], hb[4], hc[4], hd[4];
 		x = x * 1664525u + 1013904223u;
 		if (i == nblocks - 1) {
 			tg_vit_block<true>(a, x >> 8, ha);
 			tg_vit_block_bm<true, false>(b, x >> 8, hb, bm);
 			tg_vit_block_bm<true, true>(c, x >> 8, hc, bm);
+			tg_vit_block_bmd<true>(d, x >> 8, hd, bmd);
 		} else {
 			tg_vit_block<false>(a, x >> 8, ha);
 			tg_vit_block_bm<false, false>(b, x >> 8, hb, bm);
 			tg_vit_block_bm<false, true>(c, x >> 8, hc, bm);
+			tg_vit_block_bmd<false>(d, x >> 8, hd, bmd);
 		}
 		if (memcmp(ha, hb, 16) || memcmp(&a.Z, &b.Z, sizeof(a.Z)) || memcmp(ha, hc, 16) || memcmp(&a.Z, &c.Z, sizeof(a.Z)))
 			return i + 1;
+		if (memcmp(ha, hd, 16) || memcmp(&a.Z, &d.Z, sizeof(a.Z)))
+			return 1000 + i + 1;
 		if ((i & 7) == 7) {
-			tg_vit_normalize(a);
-			tg_vit_normalize(b);
-			tg_vit_normalize(c);
+			tg_vit_normalize_floor(a);
+			tg_vit_normalize_floor(b);
+			tg_vit_normalize_floor(c);
+			tg_vit_normalize_floor(d);
 		}
 	}
 	return 0;
