@@ -686,6 +686,10 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 #define TG_ACS_D 1
 #endif
 	constexpr bool ACSD = (HMODE != 2) && TG_ACS_D;
+#ifndef TG_BMJ_MASK
+#define TG_BMJ_MASK 0x4u	/* kinds whose blocks take their table entries one pair at a time: 432 */
+#endif
+	constexpr bool BMJ = (TG_BMJ_MASK >> KIND) & 1u;
 	__shared__ __attribute__((aligned(16))) uint32_t s_bm[(HMODE != 2) ? (ACSD ? TG_BMD_WORDS : TG_BM_WORDS) : TG_PSOFT_TAB];
 	/* (the entry's last two dwords -- P and P' with their halves swapped -- are taken where the kernel has registers to spare:
 	 * 16 v_alignbit_b32 fewer per 16 steps; the SCH/F kernel sits at its 168 and would spill 41 of them) */
@@ -877,14 +881,14 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 				const uint32_t nxt = s_cw[cw_row + (g + 1) * CW_STEP];
 				uint32_t h[4];
 				if (ACSD)
-					tg_vit_block_bmd<false>(v, cur, h, bmd);
+					tg_vit_block_bmd<false, BMJ>(v, cur, h, bmd);
 				else
 					tg_vit_block_bm<false, BM8>(v, cur, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * it + d] = h[d];
 				if (ACSD)
-					tg_vit_block_bmd<false>(v, cur >> 12, h, bmd);
+					tg_vit_block_bmd<false, BMJ>(v, cur >> 12, h, bmd);
 				else
 					tg_vit_block_bm<false, BM8>(v, cur >> 12, h, bm);
 #pragma unroll
@@ -897,14 +901,14 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 			if (lastchunk) {
 				uint32_t h[4];
 				if (ACSD)
-					tg_vit_block_bmd<false>(v, cur, h, bmd);
+					tg_vit_block_bmd<false, BMJ>(v, cur, h, bmd);
 				else
 					tg_vit_block_bm<false, BM8>(v, cur, h, bm);
 #pragma unroll
 				for (int d = 0; d < 4; d++)
 					H[c][8 * (nit - 1) + d] = h[d];
 				if (ACSD)
-					tg_vit_block_bmd<true>(v, cur >> 12, h, bmd);
+					tg_vit_block_bmd<true, BMJ>(v, cur >> 12, h, bmd);
 				else
 					tg_vit_block_bm<true, BM8>(v, cur >> 12, h, bm);
 #pragma unroll

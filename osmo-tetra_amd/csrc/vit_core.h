@@ -491,17 +491,26 @@ TG_HD void tg_vit_leadin_bmd(tg_vit_state &v, uint32_t six, Bm bmd)
 	tg_vit_clean(v);
 }
 
-template <bool LAST, typename Bm>
+template <bool LAST, bool JIT = false, typename Bm>
 TG_HD void tg_vit_block_bmd(tg_vit_state &v, uint32_t tw, uint32_t h[4], Bm bmd)
 {
 	constexpr int NP = LAST ? 2 : 4;
-	uint32_t w[NP][10];
+	if (JIT) {	/* a kernel short of registers: one entry at a time in the source (the scheduler moves the reads up as far as it has room) */
 #pragma unroll
-	for (int p = 0; p < NP; p++)
-		bmd(p, (p < 2 ? tw << (4 - 3 * p) : tw >> (3 * p - 4)) & 0x70u, w[p]);
+		for (int p = 0; p < NP; p++) {
+			uint32_t w[10];
+			bmd(p, (p < 2 ? tw << (4 - 3 * p) : tw >> (3 * p - 4)) & 0x70u, w);
+			tg_step_pair_d(v, w);
+		}
+	} else {
+		uint32_t w[NP][10];
 #pragma unroll
-	for (int p = 0; p < NP; p++)
-		tg_step_pair_d(v, w[p]);
+		for (int p = 0; p < NP; p++)
+			bmd(p, (p < 2 ? tw << (4 - 3 * p) : tw >> (3 * p - 4)) & 0x70u, w[p]);
+#pragma unroll
+		for (int p = 0; p < NP; p++)
+			tg_step_pair_d(v, w[p]);
+	}
 	if (LAST)
 		tg_flush4(v);
 #pragma unroll
