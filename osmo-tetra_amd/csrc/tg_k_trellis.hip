@@ -595,7 +595,10 @@ void k_clean(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t
  */
 template <int KIND, int HMODE>
 /* (the SCH/F kernel at two waves per SIMD -- 189 VGPRs, no spills, the swapped table forms too -- runs 143-146 us against 138 at three) */
-__global__ __launch_bounds__(64, (HMODE == 2) ? (KIND == TG_KIND_SB1 ? 4 : 2) : (KIND == TG_KIND_432 ? 3 : 4))
+#ifndef TG_VIT_WAVES_216
+#define TG_VIT_WAVES_216 4	/* waves per SIMD the half-slot kernels are compiled for */
+#endif
+__global__ __launch_bounds__(64, (HMODE == 2) ? (KIND == TG_KIND_SB1 ? 4 : 2) : (KIND == TG_KIND_432 ? 3 : TG_VIT_WAVES_216))
 void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	   const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks,
 	   const uint32_t *__restrict__ maskidx, uint8_t *__restrict__ rec,
