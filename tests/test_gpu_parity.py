@@ -1062,6 +1062,54 @@ def test_block_mode_all_block_types(T, eng, ber):
     plan.close()
 
 
+def test_block_mode_extreme_inputs(T, eng):
+    """the trellis kernels on inputs that drive the path metrics to their extremes -- all zeros, all ones, alternating and
+    period-3 patterns, pure noise (BER 0.5), a clean code word with one burst of errors -- for every block kind and several
+    scrambling codes == the oracle.  (vit_core.h keeps all metrics at or above a floor of 2 because the difference form of
+    a two-bit step adds n - 2m >= -2 to a predecessor's metric in unsigned packed arithmetic; eight bits hold the metric.)"""
+    import torch
+    rng = np.random.default_rng(77)
+    kinds = [O.T_SB1, O.T_SB2, O.T_NDB, O.T_SCH_HU, O.T_SCH_F]
+    codes_pool = [0, 3, 0x41802A07, 0xFFFFFFFF]
+    blocks = []
+    for t in kinds:
+        K, n2, n1, a = O.BLK[t]
+        pats = [np.zeros(K, np.uint8), np.ones(K, np.uint8), (np.arange(K) % 2).astype(np.uint8), (np.arange(K) % 3 == 0).astype(np.uint8),
+                (np.arange(K) % 3 != 1).astype(np.uint8)]
+        pats += [rng.integers(0, 2, K).astype(np.uint8) for _ in range(40)]
+        for _ in range(20):
+            code = 3 if t == O.T_SB1 else int(rng.choice(codes_pool))
+            t5 = O.encode_block(t, rng.integers(0, 2, n1).astype(np.uint8), code)
+            p0 = int(rng.integers(0, K - 24))
+            t5[p0:p0 + 24] ^= 1
+            pats.append(t5)
+        for q in pats:
+            blocks.append((t, 3 if t == O.T_SB1 else int(rng.choice(codes_pool)), q))
+    n = len(blocks)
+    types = np.array([b[0] for b in blocks], np.uint8)
+    codes = np.array([b[1] for b in blocks], np.uint32)
+    offs, pos = [], 3
+    for t, _, q in blocks:
+        offs.append(pos)
+        pos += len(q) + 1
+    buf = np.zeros(pos, np.uint8)
+    for o, (_, _, q) in zip(offs, blocks):
+        buf[o:o + len(q)] = q
+    d = torch.from_numpy(buf).cuda()
+    d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+    plan = T.Plan(eng, n, 8)
+    plan.load_blocks(np.array(offs, np.uint64), types, codes)
+    plan.execute(d.data_ptr(), d_rec.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    p = T.parse_records(d_rec.cpu().numpy().reshape(n, T.REC_BYTES))
+    for i, (t, code, q) in enumerate(blocks):
+        K, n2, n1, a = O.BLK[t]
+        w1, wcrc, wok, _ = O.decode_block(t, q, code)
+        assert (p["bits1"][i][:n1] == w1).all(), (i, t)
+        assert p["crc"][i, 0] == wcrc and p["crc_ok"][i, 0] == int(wok), (i, t)
+    plan.close()
+
+
 def test_rm3014_decode_flag(T, eng):
     """optional AACH decoding: with the flag on, BBK bit errors are corrected exactly like the oracle's exhaustive
     minimum-distance decoder (slot mode and block mode); with the flag off the reference's behaviour stays"""
