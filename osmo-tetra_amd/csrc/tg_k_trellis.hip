@@ -94,6 +94,32 @@ __device__ __forceinline__ void tg_static_for(F &&f)
 
 #define TG_STAGE_PITCH 20	/* dwords per lane in the record staging area: 16 + 4 (dwordx4 rows of neighbouring lanes in different banks) */
 
+/* sixteen decoded bits (half h of W) as sixteen bytes of 0 / 1, from a 16-entry table in LDS (nibble -> dword, behind the CRC tables:
+ * TG_SP_LUT) instead of a multiply and two masks per nibble: the table index times four is bits 2..5 of a byte of W << 2 (even
+ * nibbles) or of W >> 2 (odd nibbles) -- one masked byte select each */
+#define TG_CRC_WORDS 512	/* uint16_t entries of the two CRC tables in front of the spread table */
+#define TG_SP_LUT(s_crc) ((const uint32_t *)((s_crc) + TG_CRC_WORDS))
+__device__ __forceinline__ uint32_t tg_sp_at(const uint32_t *lut, uint32_t byteoff)
+{
+	return *(const uint32_t *)((const uint8_t *)lut + byteoff);
+}
+__device__ __forceinline__ uint4 tg_bits16(const uint32_t *lut, uint32_t W, int h, bool with_last = true)
+{
+	const uint32_t W2 = W << 2, W6 = W >> 2;
+	uint4 o;
+	o.x = tg_sp_at(lut, (W2 >> (16 * h)) & 0x3cu);
+	o.y = tg_sp_at(lut, (W6 >> (16 * h)) & 0x3cu);
+	o.z = tg_sp_at(lut, (W2 >> (16 * h + 8)) & 0x3cu);
+	o.w = with_last ? tg_sp_at(lut, (W6 >> (16 * h + 8)) & 0x3cu) : 0u;
+	return o;
+}
+/* the table's fill (lanes 0..15 of a wave) */
+__device__ __forceinline__ void tg_sp_fill(uint16_t *s_crc, uint32_t lane)
+{
+	if (lane < 16)
+		((uint32_t *)(s_crc + TG_CRC_WORDS))[lane] = spread4(lane);
+}
+
 /* byte 's' (0..15) of the 16 history bytes held in four dwords: two v_perm_b32 + one select */
 __device__ __forceinline__ uint32_t hist_byte(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t s)
 {
@@ -184,13 +210,7 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 			bb = rm3014_correct(bb, nerr);
 		const uint32_t code = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
 		auto bits16 = [&](int q) {	/* type-1 bits 16 q .. 16 q + 15, one per byte */
-			const uint32_t hw = (od[q >> 1] >> ((q & 1) * 16)) & 0xffff;
-			uint4 o;
-			o.x = spread4(hw);
-			o.y = spread4(hw >> 4);
-			o.z = spread4(hw >> 8);
-			o.w = (q * 16 + 12 < TYPE1) ? spread4(hw >> 12) : 0u;
-			return o;
+			return tg_bits16(TG_SP_LUT(s_crc), od[q >> 1], q & 1, q * 16 + 12 < TYPE1);
 		};
 		uint4 *mine = (uint4 *)(stage + lane * TG_STAGE_PITCH);
 #pragma unroll
@@ -199,7 +219,7 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 				/* bytes 0..15: type, flags, crc_ok[2], crc[2], code, slot; 16..31: SYNC fields (none), BBK errors */
 				mine[0] = make_uint4((meta & 0xffffu) | (crc_ok << 16), crc, code, slot);
 				mine[1] = make_uint4(0u, 0u, 0u, nerr);
-				mine[2] = make_uint4(spread4(bb), spread4(bb >> 4), spread4(bb >> 8), spread4(bb >> 12) & 0x0000ffffu);
+				{ uint4 b4 = tg_bits16(TG_SP_LUT(s_crc), bb, 0); b4.w &= 0x0000ffffu; mine[2] = b4; }
 				mine[3] = bits16(0);
 			} else {
 #pragma unroll
@@ -277,13 +297,7 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 				code = masks[(size_t)midx * TG_MASK_WORDS + TG_MW_CODE];
 			}
 			auto bits16 = [&](int q) {	/* type-1 bits 16 q .. 16 q + 15, one per byte */
-				const uint32_t hw = (od[q >> 1] >> ((q & 1) * 16)) & 0xffff;
-				uint4 o;
-				o.x = spread4(hw);
-				o.y = spread4(hw >> 4);
-				o.z = spread4(hw >> 8);
-				o.w = (q * 16 + 12 < TYPE1) ? spread4(hw >> 12) : 0u;
-				return o;
+				return tg_bits16(TG_SP_LUT(s_crc), od[q >> 1], q & 1, q * 16 + 12 < TYPE1);
 			};
 #pragma unroll
 			for (int c = 0; c < 5; c++) {
@@ -291,7 +305,7 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 					if (c == 0) {
 						mine[0] = make_uint4((meta & 0xffffu) | (crc_ok << 16) | (ok_n << 24), (crc & 0xffffu) | (crc_n << 16), code, slot);
 						mine[1] = make_uint4(0u, 0u, 0u, st_nerr);
-						mine[2] = make_uint4(spread4(st_bb), spread4(st_bb >> 4), spread4(st_bb >> 8), spread4(st_bb >> 12) & 0x0000ffffu);
+						{ uint4 b4 = tg_bits16(TG_SP_LUT(s_crc), st_bb, 0); b4.w &= 0x0000ffffu; mine[2] = b4; }
 						mine[3] = bits16(0);
 					} else if (c == 1) {
 						mine[0] = bits16(1); mine[1] = bits16(2); mine[2] = bits16(3); mine[3] = bits16(4);
@@ -334,12 +348,8 @@ __device__ __forceinline__ void vit_finish(const uint32_t (&od)[(vit_cfg<KIND>::
 		constexpr int NST = (TYPE1 + 15) / 16;
 #pragma unroll
 		for (int q = 0; q < NST; q++) {
-			const uint32_t hw = (od[q >> 1] >> ((q & 1) * 16)) & 0xffff;
-			uint4 o;
-			o.x = spread4(hw);
-			o.y = spread4(hw >> 4);
-			o.z = spread4(hw >> 8);
-			o.w = (q * 16 + 12 < TYPE1) ? spread4(hw >> 12) : 0u;	/* TYPE1 = 12 mod 16 */
+			const uint32_t hw = od[q >> 1];
+			const uint4 o = tg_bits16(TG_SP_LUT(s_crc), hw, q & 1, q * 16 + 12 < TYPE1);	/* TYPE1 = 12 mod 16 */
 #ifdef TG_EXP_NOSTORE
 			if (q == 0 || hw == 0x12345u)
 #endif
@@ -507,13 +517,14 @@ void k_clean(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t
 	constexpr int NW = NBLK / 2;
 	constexpr int NOD = (NBLK + 3) / 4;
 	__shared__ uint16_t s_lut[8192];
-	__shared__ uint16_t s_crc[512];
+	__shared__ __attribute__((aligned(16))) uint16_t s_crc[TG_CRC_WORDS + 32];	/* + the 16-dword spread table (tg_bits16) */
 	for (int i = threadIdx.x; i < 8192 / 8; i += 256)
 		((uint4 *)s_lut)[i] = ((const uint4 *)g_clean_lut)[i];
 	for (int i = threadIdx.x; i < 256; i += 256) {
 		s_crc[i] = c_tab.crc_lsb[i];
 		s_crc[256 + i] = c_tab.crc_msb[i];
 	}
+	tg_sp_fill(s_crc, threadIdx.x);
 	__syncthreads();
 	const uint16_t *lutA = s_lut, *lutB = s_lut + 4096;
 	const uint32_t lane = threadIdx.x & 63;
@@ -616,7 +627,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 	constexpr int NOD = (NBLK + 3) / 4;		/* dwords of decoded bits */
 	constexpr int NCH = (NBLK + 7) / 8;		/* history chunks of 8 blocks */
 
-	__shared__ uint16_t s_crc[512];
+	__shared__ __attribute__((aligned(16))) uint16_t s_crc[TG_CRC_WORDS + 32];	/* + the 16-dword spread table (tg_bits16) */
 	/* record staging of the SCH/F kernel (vit_finish): 64 lanes x four dwordx4 at a pitch of 20 dwords + 64 slot numbers */
 	__shared__ __attribute__((aligned(16))) uint32_t s_stage[(KIND == TG_KIND_432) ? 64 * TG_STAGE_PITCH + 64 : (KIND == TG_KIND_216 && TG_REC_PAIR) ? 32 * TG_STAGE_PITCH + 32 : 4];
 
@@ -625,6 +636,7 @@ void k_vit(const uint32_t *__restrict__ items, uint32_t nitems,
 		s_crc[i] = c_tab.crc_lsb[i];
 		s_crc[256 + i] = c_tab.crc_msb[i];
 	}
+	tg_sp_fill(s_crc, lane);
 
 	uint32_t idx = blockIdx.x * 64 + lane;
 	const bool valid = idx < nitems;
