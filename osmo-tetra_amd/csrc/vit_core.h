@@ -34,6 +34,12 @@
  *    next s = bitreverse4(hist & 15).  len/8 dependent LDS reads instead of len+4.
  *  - Hamming metrics: spread <= 6 after the lead-in, growth <= 1.5/step, so 8 bits
  *    suffice for 148 steps; the 292-step SCH/F trellis subtracts the minimum once.
+ *  - Round 5: what the kernels run is the DIFFERENCE FORM of a step pair (tg_step_pair_d
+ *    below): the two-bit step compares pm[j] with pm[j+8] + (n - 2m) -- one add and one
+ *    min per butterfly --, the one-bit step after it repays the bias inside its own
+ *    increments.  Same decisions, ties and history bytes; 20 packed operations per step
+ *    instead of 24.  tg_acs / tg_step_a / tg_step_b remain as the arithmetic statement
+ *    the table forms are checked against (tests/host_emul).
  */
 #ifndef VIT_CORE_H
 #define VIT_CORE_H
