@@ -35,7 +35,7 @@ The JSON line also carries
   N > 1        : single_gpu_reference (rank 0 alone, same job), decode_only and gathered (every step's 40-byte wire
                  blocks to rank 0 in the compact transport form -- delivered bursts only, csrc/tg_cwire.h -- through the
                  library's tgpu_comm_gatherv, RCCL, on a stream of its own; under a watchdog), per_gpu_efficiency of
-                 both; value = the gathered rate
+                 both; value = the decode rate of all ranks (no data-path collective), `gathered` beside it
 --workload config5 | conv | config2: the other BASELINE configs / the generic trellis (own roofline, cpu_baseline).
 """
 import argparse
@@ -1001,7 +1001,12 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         except Exception as ex:      # pragma: no cover
             e2ep = {"error": repr(ex)}
 
-    head = gathered if gathered else decode_only
+    # N > 1: the headline is the decode rate of all ranks -- channels shard with no exchange (the reference runs a process per
+    # channel), and the task's rule for a path that partitions is "no data-path collective".  The per-step gather of every rank's
+    # decoded blocks to rank 0 (north_star's "final decoded-block gather", done here per step or per --gather-every steps) runs in
+    # the same job, is checked record by record on the collecting rank, and stands beside it as `gathered` with the link bound that
+    # caps it (33 B per burst x the decode rate is more than one xGMI link direction carries).
+    head = decode_only
     out = {"metric": "decoded bursts/s", "value": head["value"], "unit": "bursts/s", "n_gpus": world,
            "steps": K, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
@@ -1013,13 +1018,13 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                                   "channels as ONE batch (GPU sequence search + demux of every grid slot, the synchroniser walks of "
                                   "all channels on the GPU at 64-byte feeds, device lists, SB1 / fill / masks / trellis); value = "
                                   "delivered bursts/s%s; one host thread per GPU, %d steps in flight" %
-                                  (C, per, args.ber, NB, NB, ", every step's decoded blocks gathered to rank 0 (40-B wire records, RCCL)" if gathered else "", D),
+                                  (C, per, args.ber, NB, NB, " of all ranks (decode_only); every step's decoded blocks gathered to rank 0 in the same job (wire records, RCCL): `gathered`" if gathered else "", D),
                       "payload_ber": args.ber, "input_buffers": NB, "input_generation_s (host synthesis of the captures, before any timing)": round(t_gen, 2), "input_bytes_resident_per_gpu": int(sum(x.numel() for x in d_bases)),
                       "channels_per_gpu": C, "slots_per_channel": per, "grid_slots_per_step": int(ngrid),
                       "delivered_per_step": int(nd), "host_threads_per_gpu": 1, "steps_in_flight": D,
                       "batches_handed_to_the_host_walk": handed_over,
                       "parallelism": "channels sharded over GPUs (%d per GPU), no collective in decoding" % C +
-                                     ("; one gather of wire records per step to rank 0, on the step's stream" if gathered else ""),
+                                     ("; `gathered`: one gather of wire records per step to rank 0, on a stream of its own" if gathered else ""),
                       "check": check},
            "timing": {"method": "one continuous run of %d warm-up steps + %d x %d steps + tail with %d steps in flight; a HIP event behind each "
                                 "step's last operation; window boundary = mean completion time of the %d most recent steps (batches in flight "
@@ -1075,6 +1080,7 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     if e2ep:
         out["end_to_end_packed"] = e2ep
     if gathered or gather_error:
+        out["value_is"] = "decode_only"
         out["decode_only"] = decode_only
         out["gathered"] = gathered if gathered else {"error": gather_error}
     if single:

@@ -47,7 +47,8 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(form):
     assert d["n_gpus"] == 2 and d["metric"] == "decoded bursts/s" and d["scaling"] == "weak" and d["steps"] == 4
     for k in ("decode_only", "gathered", "single_gpu_reference", "per_gpu_efficiency", "roofline", "timing"):
         assert k in d, k
-    assert "error" not in d["gathered"] and d["value"] == d["gathered"]["value"] > 0
+    assert "error" not in d["gathered"] and d["gathered"]["value"] > 0
+    assert d["value_is"] == "decode_only" and d["value"] == d["decode_only"]["value"] > 0
     assert d["gathered"]["bursts_delivered_per_step"] == d["decode_only"]["bursts_delivered_per_step"] > 2 * 0.9 * 64000 * 0.9
     assert "equal the oracle's" in d["config"]["check"] and "collecting rank" in d["config"]["check"]
     assert 0 < d["per_gpu_efficiency"]["decode_only"] < 1.5
