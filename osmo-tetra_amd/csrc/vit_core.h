@@ -810,6 +810,7 @@ struct tg_pvit_state {
 };
 
 #define TG_PSOFT_TAB 512
+#define TG_PVIT_INF 0x4000u	/* an unreachable start state of the soft trellis: 1024 << 4 (its own constant: the hard trellis' TG_VIT_INF carries the floor) */
 
 TG_HD uint32_t tg_psoft_entry(uint32_t idx)
 {
@@ -822,10 +823,10 @@ TG_HD uint32_t tg_psoft_entry(uint32_t idx)
 
 TG_HD void tg_pvit_init(tg_pvit_state &v)
 {
-	v.Z[0] = tg_as_us2(TG_VIT_INF << 16);	/* state 0: metric 0; the others: 1024 << 4 */
+	v.Z[0] = tg_as_us2(TG_PVIT_INF << 16);	/* state 0: metric 0; the others: 1024 << 4 */
 #pragma unroll
 	for (int k = 1; k < 8; k++)
-		v.Z[k] = tg_as_us2(TG_VIT_INF | (TG_VIT_INF << 16));
+		v.Z[k] = tg_as_us2(TG_PVIT_INF | (TG_PVIT_INF << 16));
 }
 
 TG_HD void tg_pstep_a(tg_pvit_state &v, uint32_t ta, uint32_t tb, uint32_t tie2)
