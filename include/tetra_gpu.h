@@ -159,11 +159,13 @@ enum tgpu_option {
 	TGPU_OPT_FRONT_BLOCKS,		/* > 0: cap on the front-end kernels' workgroups (tests run their loops' tails with 1 and 2) */
 	TGPU_OPT_WALK_WIDE,		/* 1: the device walk's per-channel launches as 1024 threads with 128 KB of LDS each (the form of rounds
 					 * 3 and 4; default 0: 256 threads, LDS for the batch's longest channel and twice the nodes seen so far) */
-	TGPU_OPT_RING,			/* 1: channels created from now on with a batch size of up to 4 bursts decode their flushes through
-					 * workgroups that stay on the device and take requests from mapped host memory (k_burst_ring) instead of
-					 * a kernel launch per flush; they leave after 20 ms without a request and come back with the next one
-					 * (default 0).  While they are there, calls that wait for the whole device (hipDeviceSynchronize(),
-					 * hipFree()) wait for them too: up to those 20 ms behind the channel's last flush */
+	TGPU_OPT_RING,			/* 1 (default since round 6; 0 turns it off): channels created from now on with a batch size of up to 4
+					 * bursts decode their flushes through workgroups that stay on the device and take requests from mapped host
+					 * memory (k_burst_ring) instead of a kernel launch per flush; they leave after 20 ms without a request and
+					 * come back with the next one; at most 32 channels of a process hold workgroups, the others flush by
+					 * launch, and so does any flush the ring does not answer.  While the workgroups are there, calls that wait
+					 * for the whole device (hipDeviceSynchronize(), hipFree()) wait for them too: up to those 20 ms behind the
+					 * channel's last flush -- a process that cannot have that sets the option to 0 before creating channels */
 	TGPU_OPT__COUNT
 };
 int tgpu_engine_set_option(struct tgpu_engine *eng, int /* enum tgpu_option */ option, long value);

@@ -34,6 +34,9 @@ int tgpu_plan_set_fastpath(struct tgpu_plan *p, int on);
  * nothing in this library reads the environment */
 static long tg_options[TGPU_OPT__COUNT] = {
 	[TGPU_OPT_BURST_MAX] = 1024,	/* measured crossover of k_burst and the lane-per-trellis kernels */
+	[TGPU_OPT_RING] = 1,		/* round 6: on by default -- channels of up to four bursts per flush (the reference's own usage pattern,
+					 * tetra-rx.c:82-95) answer a flush 30-40 % sooner through workgroups that stay; a flush the ring does not
+					 * answer goes by launch, a ring that keeps failing is given up (tg_sync.c: ring_failed) */
 };
 
 long tgi_option(int opt)
@@ -1388,14 +1391,18 @@ int tgpi_plan_cwire(struct tgpu_plan *p, const struct tg_cw_chans *ch, uint32_t 
 	BIND(p->eng);
 	/* the kernels write the header, the channel table, the bitmap and the block table without asking: a buffer that does not
 	 * hold those (plus one record row) is not touched at all -- the batch reports the shortfall like any other (total 0 = not
-	 * computed, marker 0xffffffff: tgpu_sync_multi_collect() returns TGPU_ECAPACITY) */
+	 * computed, marker 0xffffffff: tgpu_sync_multi_collect() returns TGPU_OK with cwire_bytes 0 and cwire_needed set -- the batch
+	 * itself is valid, it has no compact form; include/tetra_gpu.h, tgpu_sync_dev_cwire_bytes).  The two words are written from
+	 * the device side (two fills in stream order): a copy from pageable host memory goes through the runtime's staging path and
+	 * can hold the calling thread until the stream drains. */
 	struct tg_cw_layout L;
 	tg_cw_offsets(ch->n, p->nslots, &L);
 	if (p->cwire_cap < (size_t)L.o_rec + 16) {
 		if (!d_total)
 			return TGPU_ECAPACITY;
-		static const uint32_t shortfall[2] = { 0u, 0xffffffffu };
-		return (int)hipMemcpyAsync(d_total, shortfall, sizeof(shortfall), hipMemcpyHostToDevice, (hipStream_t)stream);
+		HCHK(hipMemsetD32Async((hipDeviceptr_t)d_total, 0, 1, (hipStream_t)stream));
+		HCHK(hipMemsetD32Async((hipDeviceptr_t)(d_total + 1), (int)0xffffffffu, 1, (hipStream_t)stream));
+		return TGPU_OK;
 	}
 	return tgk_cwire(p->d_wire, p->d_bits_dev, p->nslots, ch, p->d_cwire, (uint32_t)p->cwire_cap, d_total, stream);
 }

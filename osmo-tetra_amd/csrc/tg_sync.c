@@ -168,6 +168,7 @@ struct tgpu_channel {
 	hipStream_t rstream;		/* the kernel's own stream */
 	uint32_t ring_seq, ring_launches;
 	int ring_fails;		/* flushes in a row the ring did not answer (ring_failed()) */
+	int ring_fail_score;	/* + RING_FAIL_COST per unanswered flush, - 1 per answered one: failures over a sliding count */
 	int ring_counted;		/* this channel is one of RING_MAX_CHANNELS */
 
 	/* block queue of the tp_sap_udata_ind() seam (allocated on first use) */
@@ -250,9 +251,16 @@ static void ring_stop(struct tgpu_channel *ch)
  * workgroups are told to leave, this batch goes by launch, and the next flush starts them again.  Only a ring that fails
  * RING_MAX_FAILS flushes in a row is given up for good. */
 #define RING_MAX_FAILS 4
+/* ... and a ring that keeps alternating between answering and not (a busy GPU: every failure costs the 20 ms wait, a stream
+ * synchronise and a relaunch) is bounded over a sliding count as well: ring_fail_score gains RING_FAIL_COST per failure, loses 1 per
+ * answered flush, and the ring is given up when it passes RING_FAIL_LIMIT -- i.e. a steady failure rate above 1 in
+ * RING_FAIL_COST + 1 flushes ends it after a few dozen flushes, a rare failure never does. */
+#define RING_FAIL_COST  16
+#define RING_FAIL_LIMIT 64
 static void ring_failed(struct tgpu_channel *ch)
 {
-	const int give_up = ++ch->ring_fails >= RING_MAX_FAILS;
+	ch->ring_fail_score += RING_FAIL_COST;
+	const int give_up = ++ch->ring_fails >= RING_MAX_FAILS || ch->ring_fail_score > RING_FAIL_LIMIT;
 	ring_stop(ch);
 	if (!give_up)
 		ch->ring = 1;
@@ -620,8 +628,11 @@ static int flush_slots(struct tgpu_channel *ch)
 	int ringed = 0;
 	if (ch->ring && n <= TG_RING_MAX) {	/* (the workgroups that stay need nothing of the plan but its scratch arrays: no load) */
 		ringed = ring_flush(ch, n);
-		if (ringed)
+		if (ringed) {
 			ch->ring_fails = 0;
+			if (ch->ring_fail_score > 0)
+				ch->ring_fail_score--;
+		}
 		if (!ringed) {		/* the ring did not answer: this batch by launch (ring_failed() says what happens next) */
 			ring_failed(ch);
 			for (uint32_t i = 0; i < n; i++)

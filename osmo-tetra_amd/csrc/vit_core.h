@@ -431,10 +431,23 @@ TG_HD void tg_bmd_build(uint32_t *tab)
 		}
 }
 
+/* the difference form's precondition, checked where this header is compiled for the host (tests/host_emul): every
+ * metric a two-bit step adds n - 2m >= -2 to sits at or above TG_VIT_FLOOR -- a caller that normalised with tg_vit_normalize()
+ * (minimum back to 0) instead of tg_vit_normalize_floor() would wrap the unsigned packed add without any other sign.  The
+ * emulation counts violations (tg_vit_floor_violations, read by the CPU tests); device code pays nothing. */
+#if !defined(__HIP_DEVICE_COMPILE__) && !defined(__HIP__) && !defined(__HIPCC__)
+static unsigned long tg_vit_floor_violations;
+#define TG_VIT_CHECK_FLOOR(v) do { for (int k_ = 4; k_ < 8; k_++) for (int h_ = 0; h_ < 2; h_++) \
+		if (((v).Z[k_][h_] & 0xff00u) < TG_VIT_FLOOR) tg_vit_floor_violations++; } while (0)
+#else
+#define TG_VIT_CHECK_FLOOR(v) do { } while (0)
+#endif
+
 /* the two-bit step in the difference form: U, V as above */
 template <unsigned SWMASK, unsigned QMASK>
 TG_HD void tg_acs_d2(tg_vit_state &v, tg_us2 U, tg_us2 V)
 {
+	TG_VIT_CHECK_FLOOR(v);
 	tg_us2 N[8];
 #pragma unroll
 	for (int j = 0; j < 8; j++) {

@@ -99,6 +99,14 @@ extern "C" unsigned emul_decode_words(int kind, const uint32_t *words, uint8_t *
 	return crc;
 }
 
+/* how often a two-bit step of the difference form met a metric below TG_VIT_FLOOR since the last call (vit_core.h: must stay 0) */
+extern "C" unsigned long emul_floor_violations(void)
+{
+	const unsigned long n = tg_vit_floor_violations;
+	tg_vit_floor_violations = 0;
+	return n;
+}
+
 /* the slot-level gather the front kernel performs (same table function) */
 extern "C" void emul_pack_slot(int btype, const uint8_t *slot, uint32_t *words20)
 {

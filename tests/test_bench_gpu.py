@@ -28,15 +28,17 @@ def _line(cmd):
     return json.loads(p.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("form", ["compact", "grid", "compact-every-2"])
+@pytest.mark.parametrize("form", ["compact", "grid", "compact-every-2", "compact-selflaunch"])
 def test_bench_two_ranks_over_gloo_on_one_gpu(form):
+    """(compact-selflaunch: plain `python bench.py --gpus 2` -- no torch.distributed.run around it: bench.py starts its own ranks)"""
     every = ["--gather-every", "2"] if form.endswith("every-2") else []
     port = _free_port()
+    launcher = [] if form.endswith("selflaunch") else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                                       "127.0.0.1", "--master-port", port]
     form = form.split("-")[0]
-    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", port, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4",
+    d = _line([sys.executable] + launcher + ["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4",
                "--warmup", "2", "--windows", "2", "--bursts", "64000", "--wire-form", form] + every)
-    assert d["per_gpu_efficiency"]["scaling_claim"] == "decode_only" and 0 < d["per_gpu_efficiency"]["gathered_link_bound"] <= 1
+    assert d["per_gpu_efficiency"]["scaling_claim"] == "gathered" and 0 < d["per_gpu_efficiency"]["gathered_link_bound"] <= 1
     assert d["gathered"]["steps_per_exchange"] == (2 if every and form == "compact" else 1)
     assert d["gathered"]["wire_form"].startswith(form)
     per_rank = d["gathered"]["bursts_delivered_per_step"] / 2
@@ -48,7 +50,11 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(form):
     for k in ("decode_only", "gathered", "single_gpu_reference", "per_gpu_efficiency", "roofline", "timing"):
         assert k in d, k
     assert "error" not in d["gathered"] and d["gathered"]["value"] > 0
-    assert d["value_is"] == "decode_only" and d["value"] == d["decode_only"]["value"] > 0
+    # N > 1: the headline is BASELINE configs[3] as written (the gathered rate); the replica number stands beside it, and the line says which is which
+    assert d["value_is"] == "gathered" and d["value"] == d["gathered"]["value"] > 0 and d["ms_per_step"] == d["gathered"]["ms_per_step"]
+    assert d["decode_only"]["value"] > 0 and "configs[3]" in d["config"]["workload"] and "replicas" in d["config"]["workload"]
+    assert set(d["which_figure_answers_which_config"]) == {"gathered", "decode_only"}
+    assert d["ranks_seen"]["world_size"] == 2 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] in ("port", "reference")
     assert d["gathered"]["bursts_delivered_per_step"] == d["decode_only"]["bursts_delivered_per_step"] > 2 * 0.9 * 64000 * 0.9
     assert "equal the oracle's" in d["config"]["check"] and "collecting rank" in d["config"]["check"]
     assert 0 < d["per_gpu_efficiency"]["decode_only"] < 1.5

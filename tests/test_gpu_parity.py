@@ -286,7 +286,9 @@ def test_channel_through_workgroups_that_stay(T, eng, batch, ber, topt):
     burst type through the tetra_burst_rx_cb() seam, two channels at once, and a channel that is closed while its
     workgroups are still polling"""
     import time
-    topt("RING", 1)
+    if batch != 3:          # (batch 3 runs on the library's default: the ring is on without anybody asking since round 6)
+        topt("RING", 1)
+    assert T.get_option(T.OPT_RING) == 1
     stream, _ = synth.frame_stream(seed=31, nframes=7, ber=ber)
     s = stream.copy()
     s[100 + 510 + 510 * 9 + 244 + 5] ^= 1
@@ -1546,19 +1548,17 @@ def test_generic_trellis_full_size_roundtrip(T, eng):
         cv.close()
 
 
-@pytest.mark.parametrize("L,K,mother,pu", [(8, 12, 4, 0), (8, 24, 4, 1), (8, 24, 3, 1)])
+@pytest.mark.parametrize("L,K,mother,pu", [(8, 12, 4, 0), (8, 24, 4, 1), (8, 12, 3, 4)])
 def test_generic_trellis_is_maximum_likelihood_with_the_stated_tie_rule_exhaustively(T, eng, L, K, mother, pu):
     """every received word of a short block through k_conv (tgpu_conv_execute), erasures included: the brute-force
     minimum-distance sequence under the stated tie rule (tests/ml_exhaustive.py), which is also the oracle's answer
     (test_oracle_props.py does the same on the CPU).  One launch per erasure pattern, up to 4096 blocks each."""
     import torch
     import ml_exhaustive as ML
-    try:
-        cv = T.ConvDecoder(eng, pu, mother, K, L)
-    except T.TgpuError:
-        pytest.skip("shape not accepted for this puncturer")
-    if O.conv_decode_block(pu, mother, np.zeros(K, np.uint8), L, 0) is None:
-        pytest.skip("shape not valid for the oracle")
+    # (the third case is the rate-1/3 speech code under its 8/12 puncturer, tetra_conv_enc.c:164-171; round 5 had the 1/3
+    # puncturer of the OTHER mother code there -- a shape neither side accepts, so the case always skipped and read as coverage)
+    cv = T.ConvDecoder(eng, pu, mother, K, L)
+    assert O.conv_decode_block(pu, mother, np.zeros(K, np.uint8), L, 0) is not None
     hs = torch.cuda.current_stream().cuda_stream
     rng = np.random.default_rng(L * 100 + K + mother)
     xs, cb = ML.codebook(L, K, mother, pu)

@@ -110,6 +110,27 @@ def test_kernel_core_worst_case_metrics():
             assert (got[:n2] == want2).all() and crc == wcrc
 
 
+def test_difference_form_never_meets_a_metric_below_its_floor():
+    """vit_core.h: the two-bit step of the difference form adds n - 2m >= -2 to a predecessor's metric in UNSIGNED packed
+    arithmetic, so every metric it meets must sit at or above TG_VIT_FLOOR (the start state starts there, the SCH/F trellis' one
+    normalisation returns the minimum to it).  The host build counts violations at the entry of every such step: none on clean,
+    noisy, pure-noise and constant blocks of every kind (a kernel that normalised to 0 instead would show up here)."""
+    L = emul.lib()
+    L.emul_floor_violations.restype = emul.C.c_ulong
+    L.emul_floor_violations()
+    rng = np.random.default_rng(77)
+    for kind, t in ((0, O.T_SB1), (1, O.T_NDB), (2, O.T_SCH_F), (3, O.T_SCH_HU)):
+        K, n2, n1, a = O.BLK[t]
+        blocks = [np.ones(K, np.uint8), np.zeros(K, np.uint8), (np.arange(K) % 2).astype(np.uint8)]
+        for ber in (0.0, 0.05, 0.5):
+            for _ in range(40):
+                t5 = O.encode_block(t, rng.integers(0, 2, n1).astype(np.uint8), 0)
+                blocks.append(t5 ^ (rng.random(K) < ber).astype(np.uint8))
+        for b in blocks:
+            emul.decode_block(kind, b)
+    assert L.emul_floor_violations() == 0
+
+
 def test_slot_packing_matches_block_packing():
     """front-kernel gather table == demux (phy/tetra_burst.c:341-379) + per-block layout"""
     rng = np.random.default_rng(4)

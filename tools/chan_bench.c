@@ -59,8 +59,10 @@ int main(int argc, char **argv)
 	}
 	unsigned batches[32] = { 1, 64, 1024, 16384 }, nb = 4;
 	int a0 = 2;
-	if (argc > 2 && !strcmp(argv[2], "ring")) {	/* chan_bench N ring b1 ...: flushes of up to 4 bursts through workgroups that stay */
-		tgpu_engine_set_option(eng, TGPU_OPT_RING, 1);
+	if (argc > 2 && (!strcmp(argv[2], "ring") || !strcmp(argv[2], "noring"))) {
+		/* chan_bench N ring b1 ...: flushes of up to 4 bursts through workgroups that stay (the default since round 6);
+		 * chan_bench N noring b1 ...: every flush by launch */
+		tgpu_engine_set_option(eng, TGPU_OPT_RING, !strcmp(argv[2], "ring"));
 		a0 = 3;
 	}
 	if (argc > a0) {		/* chan_bench N [ring] b1 b2 ...: the batch sizes to try */
