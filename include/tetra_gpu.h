@@ -166,6 +166,11 @@ enum tgpu_option {
 					 * launch, and so does any flush the ring does not answer.  While the workgroups are there, calls that wait
 					 * for the whole device (hipDeviceSynchronize(), hipFree()) wait for them too: up to those 20 ms behind the
 					 * channel's last flush -- a process that cannot have that sets the option to 0 before creating channels */
+	TGPU_OPT_SLOT,			/* how the plan API's batches run their trellises (round 6; records are the same bytes either way):
+					 * 0: k_vit<216> and k_vit<432>, one lane per BLOCK (rounds 1-5);
+					 * 1 (default): k_slot_t, one lane per SLOT -- one launch over the batch's delivered slots of any type,
+					 *    a SYNC burst's SB1 included, every record written as whole 64-byte segments
+					 * (soft input, block mode, the RM(30,14) option and the clean-block fast path keep the lane-per-block kernels) */
 	TGPU_OPT__COUNT
 };
 int tgpu_engine_set_option(struct tgpu_engine *eng, int /* enum tgpu_option */ option, long value);

@@ -248,7 +248,7 @@ def lib():
     return L
 
 
-OPT_BURST_MAX, OPT_STREAM_EXACT, OPT_WALK_HOST, OPT_WALK_MONO, OPT_FRONT_BLOCKS, OPT_WALK_WIDE, OPT_RING = range(1, 8)
+OPT_BURST_MAX, OPT_STREAM_EXACT, OPT_WALK_HOST, OPT_WALK_MONO, OPT_FRONT_BLOCKS, OPT_WALK_WIDE, OPT_RING, OPT_SLOT = range(1, 9)
 
 
 def set_option(opt, value):

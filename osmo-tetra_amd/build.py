@@ -14,9 +14,9 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libtetra_gpu.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
-HIP_SRCS = ["tg_k_front.hip", "tg_k_trellis.hip", "tg_k_walk.hip", "tg_k_aux.hip", "tg_cwire.hip", "tg_traffic.hip"]
+HIP_SRCS = ["tg_k_front.hip", "tg_k_trellis.hip", "tg_k_slot.hip", "tg_k_walk.hip", "tg_k_aux.hip", "tg_cwire.hip", "tg_traffic.hip"]
 C_SRCS = ["tg_host.c", "tg_sync.c", "tg_stream.c", "tg_synth.c", "tg_rm.c", "tg_conv.c", "tg_gsmtap.c", "tg_reorder.c", "tg_comm.c", "tg_stages.c", "tg_cwire.c", "tg_pack.c"]
-HEADERS = ["tg_layout.h", "vit_core.h", "tg_internal.h", "tg_dev.h", "tg_conv.h", "tg_cwire.h", "tg_walk_core.h", os.path.join(ROOT, "include", "tetra_gpu.h")]
+HEADERS = ["tg_layout.h", "vit_core.h", "slot_core.h", "tg_internal.h", "tg_dev.h", "tg_dev_vit.h", "tg_conv.h", "tg_cwire.h", "tg_walk_core.h", os.path.join(ROOT, "include", "tetra_gpu.h")]
 
 
 def _newer(src_list, target):

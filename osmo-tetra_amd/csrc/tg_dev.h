@@ -52,6 +52,7 @@ static __constant__ __attribute__((aligned(16))) tg_const_tables c_tab;
 extern "C" int tgk_upload_front(const tg_const_tables *host);
 extern "C" int tgk_upload_trellis(const tg_const_tables *host);
 extern "C" int tgk_upload_aux(const tg_const_tables *host);
+extern "C" int tgk_upload_slot(const tg_const_tables *host);
 
 #ifdef TG_TRACE
 /* measurement build (tools/experiments/trace_untraced.py): the heavy kernels' workgroups leave (kind, first and last tick of the 100 MHz
@@ -76,6 +77,7 @@ static inline int tg_trace_read_unit(void *out, unsigned int *n, int reset)
 }
 extern "C" int tgk_trace_read_front(void *out, unsigned int *n, int reset);
 extern "C" int tgk_trace_read_trellis(void *out, unsigned int *n, int reset);
+extern "C" int tgk_trace_read_slot(void *out, unsigned int *n, int reset);
 #define TG_TRACE_BEGIN const unsigned long long tr_t0_ = wall_clock64()
 #define TG_TRACE_END(KIND_, EVERY_) do { if (threadIdx.x == 0 && (blockIdx.x % (EVERY_)) == 0) {			\
 		const unsigned int i_ = atomicAdd(&g_trace_n, 1u);							\

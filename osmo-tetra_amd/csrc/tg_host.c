@@ -34,6 +34,7 @@ int tgpu_plan_set_fastpath(struct tgpu_plan *p, int on);
  * nothing in this library reads the environment */
 static long tg_options[TGPU_OPT__COUNT] = {
 	[TGPU_OPT_BURST_MAX] = 1024,	/* measured crossover of k_burst and the lane-per-trellis kernels */
+	[TGPU_OPT_SLOT] = 1,		/* round 6: the trellises of a batch by one lane per slot (tg_k_slot.hip); 0 = k_vit<216> + k_vit<432> */
 	[TGPU_OPT_RING] = 1,		/* round 6: on by default -- channels of up to four bursts per flush (the reference's own usage pattern,
 					 * tetra-rx.c:82-95) answer a flush 30-40 % sooner through workgroups that stay; a flush the ring does not
 					 * answer goes by launch, a ring that keeps failing is given up (tg_sync.c: ring_failed) */
@@ -96,6 +97,8 @@ struct tgpu_plan {
 	uint32_t *d_slot_chan;
 	int32_t *d_slot_sbord;
 	uint32_t *d_list_sb, *d_list_216, *d_list_432;
+	uint32_t *d_list_all;	/* the batch's slots of type NORM_1 / NORM_2 / SYNC, once each: the lane-per-slot kernel's items (NULL: not built) */
+	uint32_t nall;
 	uint32_t *d_packed;
 	uint32_t *d_maskidx;
 	uint32_t *d_idx_stage;	/* static batches: the mask indices as uploaded (copied to d_maskidx by the first execute) */
@@ -246,8 +249,8 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	p->max_slots = max_slots;
 	p->max_chan = max_chan;
 	const size_t n = max_slots;
-	/* descriptors 8n, chan 4n, sbord 4n, lists <= 8n in total, static mask indices 4n, codes, padding */
-	p->up_bytes = 28 * n + 4 * (size_t)max_chan + 16 * UP_ALIGN + 4 * (TGK_LB_TBL + 1);	/* (+ the code table of device-walk batches) */
+	/* descriptors 8n, chan 4n, sbord 4n, lists <= 8n in total, the slot list 4n, static mask indices 4n, codes, padding */
+	p->up_bytes = 32 * n + 4 * (size_t)max_chan + 20 * UP_ALIGN + 4 * (TGK_LB_TBL + 1);	/* (+ the code table of device-walk batches) */
 	/* small plans (the drop-in channel API at small batch sizes: a flush is a round trip, and every copy in it costs
 	 * more than the bytes): descriptors and lists stay in pinned host memory and the kernels read them in place.
 	 * Consequence for callers: a small plan must be idle (its last execute complete) before the next tgpu_plan_load*()
@@ -350,7 +353,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 #define UP_PLACE(dptr, hptr, type, count) do { dptr = (type *)(p->d_up + o); hptr = (type *)(p->h_up + o); \
 		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
 	uint64_t *h_desc;
-	uint32_t *h_chan, *h_list_sb, *h_list_216, *h_list_432, *h_code, *h_idx, *d_idx_stage;
+	uint32_t *h_chan, *h_list_sb, *h_list_216, *h_list_432, *h_list_all, *h_code, *h_idx, *d_idx_stage;
 	int32_t *h_sbord;
 	UP_PLACE(p->d_slot_off, h_desc, uint64_t, nslots);
 	UP_PLACE(p->d_slot_chan, h_chan, uint32_t, nslots);
@@ -358,6 +361,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 	UP_PLACE(p->d_list_sb, h_list_sb, uint32_t, nsb);
 	UP_PLACE(p->d_list_216, h_list_216, uint32_t, n216);
 	UP_PLACE(p->d_list_432, h_list_432, uint32_t, n432);
+	UP_PLACE(p->d_list_all, h_list_all, uint32_t, nsb + n432 + (n216 - nsb) / 2);
 	UP_PLACE(p->d_chan_code, h_code, uint32_t, nchan);
 	UP_PLACE(d_idx_stage, h_idx, uint32_t, is_static ? nslots : 0);
 #undef UP_PLACE
@@ -367,10 +371,12 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 	/* pass 2: fill the pinned mirror */
 	for (uint32_t c = 0; c < nchan; c++)
 		p->h_last_slot_of_chan[c] = 0xffffffffu;
-	uint32_t isb = 0, i216 = 0, i432 = 0;
+	uint32_t isb = 0, i216 = 0, i432 = 0, iall = 0;
 	for (uint32_t i = 0; i < nslots; i++) {
 		const uint8_t t = SLOT_TYPE(i);
 		const uint32_t ch = SLOT_CHAN(i);
+		if (t == TETRA_TRAIN_SYNC || t == TETRA_TRAIN_NORM_2 || t == TETRA_TRAIN_NORM_1)
+			h_list_all[iall++] = i;
 		p->h_last_slot_of_chan[ch] = i;
 		/* descriptor = offset | type << 56 (one scalar load per slot in the front kernel) */
 		h_desc[i] = SLOT_OFF(i) | ((uint64_t)t << 56);
@@ -415,6 +421,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 	p->nsb = nsb;
 	p->n216 = n216;
 	p->n432 = n432;
+	p->nall = iall;
 	p->loaded = 1;
 	return TGPU_OK;
 }
@@ -512,6 +519,8 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 	UP_AT(d_blk, uint32_t, 3 * (nblk + 1));
 #undef UP_AT
 	p->d_slot_off = NULL;
+	p->d_list_all = NULL;	/* (host-walk grid batches keep the lane-per-block kernels: their lists come from k_grid_lists) */
+	p->nall = 0;
 	if (o > p->up_bytes)
 		return TGPU_ECAPACITY;
 	memcpy(p->h_up, codes, (size_t)nchan * 4);
@@ -597,6 +606,7 @@ int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, co
 	UP_AT(p->d_list_sb, uint32_t, ngrid);
 	UP_AT(p->d_list_216, uint32_t, 2 * (size_t)ngrid);
 	UP_AT(p->d_list_432, uint32_t, ngrid);
+	UP_AT(p->d_list_all, uint32_t, ngrid);
 #undef UP_AT
 	p->d_slot_off = NULL;
 	p->d_slot_chan = NULL;
@@ -660,7 +670,7 @@ int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, u
 	if (evs)
 		HCHK(hipEventRecord((hipEvent_t)evs[0], s));
 	rc = tgk_lists2(p->d_grid, p->d_bits_dev, ngrid, p->d_lb_ok, p->d_lb_prevw, p->d_lb_wchan, (const uint32_t *)p->d_slot_sbord,
-			p->d_maskidx, p->d_list_216, p->d_list_432, (uint32_t *)p->d_counts, stream);
+			p->d_maskidx, p->d_list_216, p->d_list_432, p->d_list_all, (uint32_t *)p->d_counts, stream);
 	if (rc)
 		return rc;
 	if (evs)
@@ -676,6 +686,7 @@ int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, u
 	p->nsb = ngrid;		/* upper bounds: the launches are sized for them */
 	p->n216 = 2 * ngrid;
 	p->n432 = ngrid;
+	p->nall = ngrid;
 	p->loaded = 1;
 	return TGPU_OK;
 }
@@ -1036,7 +1047,8 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	/* the two trellis kernels do not depend on each other: unless per-stage timing was asked for,
 	 * k_vit<432> goes to a side stream (fork/join with events, still capturable) so that the tails
 	 * of the two launches overlap */
-	const int fork = (ev == NULL) && !p->no_side && p->n216 && p->n432 && p->nslots > 4096;	/* (a small batch gains nothing from the side stream) */
+	const int fork = (ev == NULL) && !p->no_side && p->n216 && p->n432 && p->nslots > 4096 &&	/* (a small batch gains nothing from the side stream) */
+			 !(tgi_option(TGPU_OPT_SLOT) && !soft && !(p->fastpath && !p->d_counts) && !p->rm_decode && p->d_list_all && p->nall);
 	if (fork) {
 		hipError_t e_ = hipEventRecord(p->ev_fork, (hipStream_t)stream);
 		if (e_ == hipSuccess)
@@ -1068,6 +1080,15 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 		cnt216 = p->d_dirty;
 		cnt432 = p->d_dirty + 1;
 	}
+	/* round 6: one lane per SLOT (k_slot_t) in place of the two launches -- hard input, slot or device-walk batches (the ones that
+	 * have the slot list), no option that only the lane-per-block kernels implement */
+	const int by_slot = tgi_option(TGPU_OPT_SLOT) && !soft && !fast && !p->rm_decode && p->d_list_all && p->nall;
+	if (by_slot) {
+		if ((rc = tgk_slot_t(p->d_list_all, p->nall, p->d_counts ? p->d_counts + 3 : NULL, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
+				     p->d_wire, kf, stream)))
+			return rc;
+		MARK(5);
+	} else {
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_216, items216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
 				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, kf, cnt216, stream)))
@@ -1078,6 +1099,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 		if ((rc = tgk_vit(TG_KIND_432, items432, p->n432, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
 				  p->d_sb_ok, p->d_sb_code, p->d_wire, soft ? p->d_softarea : NULL, kf, cnt432, s432)))
 			return rc;
+	}
 	}
 	if (fork) {
 		hipError_t e_ = hipEventRecord(p->ev_join, p->side);
@@ -1218,6 +1240,8 @@ int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t 
 	p->d_list_sb = d_list[TG_KIND_SB1];
 	p->d_list_216 = d_list[TG_KIND_216];
 	p->d_list_432 = d_list[TG_KIND_432];
+	p->d_list_all = NULL;
+	p->nall = 0;
 	p->d_list_168 = d_list[TG_KIND_168];
 	p->d_list_bbk = d_list[TGPU_NKINDS];
 	p->nsb = cnt[TG_KIND_SB1];

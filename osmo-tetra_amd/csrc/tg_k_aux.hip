@@ -376,18 +376,22 @@ extern "C" int tgk_init(void)
 		rc = tgk_upload_trellis(&host);
 	if (!rc)
 		rc = tgk_upload_aux(&host);
+	if (!rc)
+		rc = tgk_upload_slot(&host);
 	return rc;
 }
 
 #ifdef TG_TRACE
 extern "C" int tgk_trace_read(void *out, unsigned int *n, int reset)
 {
-	unsigned int a = 0, b = 0;
+	unsigned int a = 0, b = 0, c = 0;
 	int rc = tgk_trace_read_front(out, &a, reset);
 	if (!rc)
 		rc = tgk_trace_read_trellis(out ? (tg_trace_rec *)out + a : NULL, &b, reset);
+	if (!rc)
+		rc = tgk_trace_read_slot(out ? (tg_trace_rec *)out + a + b : NULL, &c, reset);
 	if (n)
-		*n = a + b;
+		*n = a + b + c;
 	return rc;
 }
 #endif
@@ -962,12 +966,13 @@ __global__ __launch_bounds__(1024)
 void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbits, uint32_t n, const uint32_t *__restrict__ okbits,
 	      const uint32_t *__restrict__ prevw, const uint8_t *__restrict__ word_chan, const uint32_t *__restrict__ slot_entry,
 	      uint32_t *__restrict__ maskidx, uint32_t *__restrict__ list_216, uint32_t *__restrict__ list_432,
-	      uint32_t *__restrict__ cnt /* [1]: 216 items, [2]: 432 items */)
+	      uint32_t *__restrict__ list_all /* or NULL: every delivered slot once, for the lane-per-slot kernel (tg_k_slot.hip) */,
+	      uint32_t *__restrict__ cnt /* [1]: 216 items, [2]: 432 items, [3]: delivered slots */)
 {
-	__shared__ uint32_t s_c216[TG_MID_CHUNKS][16], s_c432[TG_MID_CHUNKS][16], s_b216, s_b432;
+	__shared__ uint32_t s_c216[TG_MID_CHUNKS][16], s_c432[TG_MID_CHUNKS][16], s_call[TG_MID_CHUNKS][16], s_b216, s_b432, s_ball;
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const unsigned long long below = (1ull << lane) - 1;
-	uint32_t t[TG_MID_CHUNKS], in216[TG_MID_CHUNKS], in432[TG_MID_CHUNKS];
+	uint32_t t[TG_MID_CHUNKS], in216[TG_MID_CHUNKS], in432[TG_MID_CHUNKS], inall[TG_MID_CHUNKS];
 #pragma unroll
 	for (int j = 0; j < TG_MID_CHUNKS; j++) {
 		const uint32_t g = (blockIdx.x * TG_MID_CHUNKS + j) * 1024 + threadIdx.x;
@@ -982,9 +987,11 @@ void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbi
 		const unsigned long long mn1 = __ballot(t[j] == TG_BURST_NORM_1);
 		in216[j] = __builtin_popcountll(msb & below) + 2 * __builtin_popcountll(mn2 & below);
 		in432[j] = __builtin_popcountll(mn1 & below);
+		inall[j] = __builtin_popcountll((msb | mn2 | mn1) & below);
 		if (lane == 0) {
 			s_c216[j][wv] = __builtin_popcountll(msb) + 2 * __builtin_popcountll(mn2);
 			s_c432[j][wv] = __builtin_popcountll(mn1);
+			s_call[j][wv] = __builtin_popcountll(msb | mn2 | mn1);
 		}
 	}
 	__syncthreads();
@@ -998,22 +1005,33 @@ void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbi
 		else
 			s_b216 = base;
 	}
+	if (threadIdx.x == 64) {	/* the delivered slots of any type, once each */
+		uint32_t tot = 0;
+		for (int q = 0; q < TG_MID_CHUNKS * 16; q++)
+			tot += s_call[0][q];
+		s_ball = (tot && list_all) ? atomicAdd(cnt + 3, tot) : 0u;
+	}
 	__syncthreads();
-	uint32_t r216 = s_b216, r432 = s_b432;
+	uint32_t r216 = s_b216, r432 = s_b432, rall = s_ball;
 #pragma unroll
 	for (int j = 0; j < TG_MID_CHUNKS; j++) {
 		const uint32_t g = (blockIdx.x * TG_MID_CHUNKS + j) * 1024 + threadIdx.x;
-		uint32_t p216 = r216, p432 = r432;
+		uint32_t p216 = r216, p432 = r432, pall = rall;
 		for (uint32_t q = 0; q < 16; q++) {
 			if (q < wv) {
 				p216 += s_c216[j][q];
 				p432 += s_c432[j][q];
+				pall += s_call[j][q];
 			}
 			r216 += s_c216[j][q];
 			r432 += s_c432[j][q];
+			rall += s_call[j][q];
 		}
 		p216 += in216[j];
 		p432 += in432[j];
+		pall += inall[j];
+		if (list_all && (t[j] == TG_BURST_SYNC || t[j] == TG_BURST_NORM_2 || t[j] == TG_BURST_NORM_1))
+			list_all[pall] = g;
 		if (t[j] == TG_BURST_SYNC)
 			list_216[p216] = (g << 1) | 1;		/* SB2 */
 		else if (t[j] == TG_BURST_NORM_2) {
@@ -1054,11 +1072,11 @@ extern "C" int tgk_lb_scan(const uint32_t *d_okbits, const uint32_t *d_dbits, co
 
 extern "C" int tgk_lists2(const uint32_t *d_cls, const uint32_t *d_dbits, uint32_t n, const uint32_t *d_okbits, const uint32_t *d_prevw,
 			  const uint8_t *d_word_chan, const uint32_t *d_slot_entry, uint32_t *d_maskidx, uint32_t *d_list_216,
-			  uint32_t *d_list_432, uint32_t *d_cnt, void *stream)
+			  uint32_t *d_list_432, uint32_t *d_list_all, uint32_t *d_cnt, void *stream)
 {
 	if (!n)
 		return 0;
 	hipLaunchKernelGGL(k_lists2, dim3((n + 1024 * TG_MID_CHUNKS - 1) / (1024 * TG_MID_CHUNKS)), dim3(1024), 0, (hipStream_t)stream, d_cls, d_dbits, n, d_okbits, d_prevw,
-			   d_word_chan, d_slot_entry, d_maskidx, d_list_216, d_list_432, d_cnt);
+			   d_word_chan, d_slot_entry, d_maskidx, d_list_216, d_list_432, d_list_all, d_cnt);
 	return (int)hipGetLastError();
 }

@@ -18,7 +18,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        deps = [SRC] + [os.path.join(ROOT, "osmo-tetra_amd", "csrc", h) for h in ("vit_core.h", "tg_layout.h", "tg_conv.h")]
+        deps = [SRC] + [os.path.join(ROOT, "osmo-tetra_amd", "csrc", h) for h in ("vit_core.h", "slot_core.h", "tg_layout.h", "tg_conv.h")]
         if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
             subprocess.check_call([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared",
                                    "-I" + os.path.join(ROOT, "osmo-tetra_amd", "csrc"), SRC, "-o", LIB])
@@ -99,3 +99,17 @@ def cls_ysum(stream, anchor, chunk, view=None):
     _cls_lib.emul_cls_ysum(s.ctypes.data_as(u8p), L, anchor, chunk, view, cls.ctypes.data_as(u32p),
                            ys.ctypes.data_as(C.POINTER(C.c_uint16)))
     return cls[:n], ys[:n]
+
+
+def decode_slot(btype, words20):
+    """the lane-per-slot schedule (slot_core.h) on a packed slot whose blocks are descrambled: returns (decoded bytes [36], crc [2],
+    record bytes 48..319 [272], SYNC PDU words [3])"""
+    w = np.ascontiguousarray(words20, np.uint32)
+    od = np.zeros(36, np.uint8)
+    crc = np.zeros(2, np.uint32)
+    bits = np.zeros(272, np.uint8)
+    sy = np.zeros(3, np.uint32)
+    rc = lib().emul_decode_slot(int(btype), w.ctypes.data_as(u32p), od.ctypes.data_as(u8p), crc.ctypes.data_as(u32p),
+                                bits.ctypes.data_as(u8p), sy.ctypes.data_as(u32p))
+    assert rc == 0
+    return od, crc, bits, sy

@@ -11,6 +11,7 @@
 #include "tg_layout.h"
 #include "tg_conv.h"
 #include "vit_core.h"
+#include "slot_core.h"
 
 static uint16_t crc_lsb[256], crc_msb[256];
 static bool crc_ready;
@@ -334,5 +335,70 @@ extern "C" int emul_bm_selfcheck(uint32_t seed, int nblocks)
 			tg_vit_normalize_floor(d);
 		}
 	}
+	return 0;
+}
+
+/* ---- one lane = one slot (slot_core.h): the schedule k_slot / k_slot_t run, for the host ----
+ * words20: a packed slot (emul_pack_slot) whose blocks are already descrambled.  out: od[36] decoded bytes, crc[2],
+ * bits[17][16] = the record's bytes 48..319 as the pieces say, sync[3] = the SYNC PDU words (SYNC bursts).  Returns 0. */
+extern "C" int emul_decode_slot(int btype, const uint32_t *words20, uint8_t *od_bytes, uint32_t *crc, uint8_t *bits272, uint32_t *sync3)
+{
+	crc_init();
+	if (btype != TG_BURST_NORM_1 && btype != TG_BURST_NORM_2 && btype != TG_BURST_SYNC)
+		return -1;
+	const bool sb = btype == TG_BURST_SYNC, two = btype != TG_BURST_NORM_1;
+	/* the staging step of the kernels: code word g of the schedule */
+	uint32_t col[18];
+	for (int g = 0; g < 18; g++) {
+		if (!sb)
+			col[g] = words20[g];
+		else
+			col[g] = (g >= 9) ? words20[g] : (g >= TG_SLOT_SB1_G0) ? words20[g - TG_SLOT_SB1_G0] : 0u;
+	}
+	static uint32_t bmdtab[TG_BMD_WORDS];
+	tg_bmd_build(bmdtab);
+	auto bmdo = [&](uint32_t o, uint32_t w[10]) {
+		const int q = (int)(o >> 4);
+		memcpy(w, bmdtab + TG_BMD_A0 + 4 * q, 16);
+		memcpy(w + 4, bmdtab + TG_BMD_A1 + 4 * q, 16);
+		memcpy(w + 8, bmdtab + TG_BMD_A2 + 4 * q, 8);
+	};
+	uint32_t H[TG_SLOT_NBLK][4];
+	tg_vit_state v;
+	tg_slot_state_init(v);
+	uint32_t cur = col[0];
+	tg_slot_leadin(v, cur >> 24, bmdo);
+	for (int g = 0; g < 18; g++) {
+		const uint32_t nxt = g < 17 ? col[g + 1] : 0u;
+		if (g == TG_SLOT_SB1_G0)
+			tg_slot_sb_prologue(v, sb, cur, bmdo);
+		tg_slot_block(v, cur, H[2 * g], bmdo);
+		if (g == 8) {
+			tg_slot_mid(v, two, cur >> 12, nxt >> 24, H[2 * g + 1], bmdo);
+			tg_vit_normalize_floor(v);
+		} else if (g == 17)
+			tg_slot_block_last(v, cur >> 12, H[2 * g + 1], bmdo);
+		else
+			tg_slot_block(v, cur >> 12, H[2 * g + 1], bmdo);
+		cur = nxt;
+	}
+	uint32_t od[TG_SLOT_NOD + 1] = { 0 };
+	uint32_t s = 0;
+#define HOP(B) tg_slot_hop<B>(od, s, two, H[B][0], H[B][1], H[B][2], H[B][3]);
+	HOP(35) HOP(34) HOP(33) HOP(32) HOP(31) HOP(30) HOP(29) HOP(28) HOP(27) HOP(26) HOP(25) HOP(24) HOP(23) HOP(22) HOP(21) HOP(20) HOP(19) HOP(18)
+	HOP(17) HOP(16) HOP(15) HOP(14) HOP(13) HOP(12) HOP(11) HOP(10) HOP(9) HOP(8) HOP(7) HOP(6) HOP(5) HOP(4) HOP(3) HOP(2) HOP(1) HOP(0)
+#undef HOP
+	memcpy(od_bytes, od, 36);
+	auto tl = [](uint32_t x) -> uint32_t { return crc_lsb[x & 255]; };
+	auto tm = [](uint32_t x) -> uint32_t { return crc_msb[x & 255]; };
+	tg_slot_crc(od, two, sb, tl, tm, crc[0], crc[1]);
+#define PIECE(P) { bool full, empty; const uint32_t h16 = tg_slot_piece_bits<P>(od, two, sb, full, empty); uint32_t o[4]; \
+		   tg_slot_spread16(h16, o); if (!full) o[3] = 0; if (empty) o[0] = o[1] = o[2] = o[3] = 0; memcpy(bits272 + 16 * (P), o, 16); }
+	PIECE(0) PIECE(1) PIECE(2) PIECE(3) PIECE(4) PIECE(5) PIECE(6) PIECE(7) PIECE(8) PIECE(9) PIECE(10) PIECE(11) PIECE(12) PIECE(13)
+	PIECE(14) PIECE(15) PIECE(16)
+#undef PIECE
+	sync3[0] = sync3[1] = sync3[2] = 0;
+	if (sb)
+		tg_slot_sync_fields(od + 2, sync3[0], sync3[1], sync3[2]);
 	return 0;
 }

@@ -1367,6 +1367,70 @@ def test_batch_size_sweep(T, eng, fast, topt):
         check_against_oracle(T, rec, ty, slots, 0)
 
 
+@pytest.mark.parametrize("ber", [0.0, 0.04, 0.5])
+def test_lane_per_slot_kernel_equals_the_lane_per_block_kernels(T, eng, ber, topt):
+    """round 6, TGPU_OPT_SLOT: k_slot_t (one lane per SLOT: both blocks of a burst and a SYNC burst's SB1 on one 36-block
+    schedule, slot_core.h) against k_vit<216> + k_vit<432> (one lane per BLOCK) on the same loads -- mixed types in every
+    arrangement inside a wave (runs of one type, alternating, random), three channels with carry-in codes, SYNC bursts that
+    change the code mid-batch, a failed SB1, ignored burst types, clean / noisy / pure-noise payloads, ragged sizes: every byte
+    of every record and of every wire record equal, and equal to the oracle's decode"""
+    import torch
+    topt("BURST_MAX", 0)
+    hs = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(int(ber * 100) + 41)
+    c1, c2, c3 = O.scramb_get_init(262, 42, 1), O.scramb_get_init(901, 77, 9), O.scramb_get_init(1, 2, 3)
+    for n in (1, 63, 64, 65, 200, 4099):
+        ty = np.concatenate([np.full(n // 3, O.TRAIN_NORM_1), np.full(n // 3, O.TRAIN_NORM_2),
+                             rng.choice([O.TRAIN_NORM_1, O.TRAIN_NORM_2, O.TRAIN_SYNC], n - 2 * (n // 3), p=[0.4, 0.4, 0.2])]).astype(np.uint8)
+        if n > 70:
+            ty[5::17] = O.TRAIN_NORM_3          # ignored by the path (no record)
+            ty[64:128:2], ty[65:128:2] = O.TRAIN_NORM_1, O.TRAIN_NORM_2
+        chan = np.sort(rng.integers(0, 3, n)).astype(np.uint32)
+        carry = np.array([c1, c2, 0], np.uint32)
+        # every channel's cell: its SYNC bursts carry that cell's SYNC PDU, so the code in force follows the oracle's rule
+        cell_of = [(262, 42, 1), (901, 77, 9), (1, 2, 3)]
+        slots = np.zeros((n, 510), np.uint8)
+        for c in range(3):
+            m = chan == c
+            if m.any():
+                mcc, mnc, cc = cell_of[c]
+                slots[m] = T.synth_slots(ty[m], seed=100 + c + n, scramb_init=[c1, c2, c3][c], ber=min(ber, 0.2), mcc=mcc, mnc=mnc, cc=cc)
+        if ber >= 0.5:
+            slots[n // 2:] = rng.integers(0, 2, (n - n // 2, 510)).astype(np.uint8)     # pure noise: ties everywhere
+        out = {}
+        for mode in (0, 1):
+            topt("SLOT", mode)
+            d = torch.from_numpy(np.concatenate([slots.reshape(-1), np.zeros(64, np.uint8)])).cuda()
+            d_rec = torch.zeros(n * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+            d_wire = torch.full((n * T.WIRE_BYTES,), 0xff, dtype=torch.uint8, device="cuda")
+            plan = T.Plan(eng, n, 3)
+            plan.set_wire(d_wire.data_ptr())
+            plan.load(np.arange(n, dtype=np.uint64) * 510, ty, chan, carry)
+            plan.execute(d.data_ptr(), d_rec.data_ptr(), hs)
+            torch.cuda.synchronize()
+            out[mode] = (d_rec.cpu().numpy().reshape(n, T.REC_BYTES), d_wire.cpu().numpy().reshape(n, T.WIRE_BYTES), plan.final_codes().tolist())
+            plan.close()
+        assert (out[0][0] == out[1][0]).all(), n
+        assert (out[0][1] == out[1][1]).all(), n
+        assert out[0][2] == out[1][2]
+        # ... and against the oracle, channel by channel: the code in force at a slot = the latest good SB1 at or before it, else the carry-in
+        rec = out[1][0]
+        p = T.parse_records(rec)
+        dec = np.isin(ty, [O.TRAIN_NORM_1, O.TRAIN_NORM_2, O.TRAIN_SYNC])
+        assert (p["type"][dec] == ty[dec]).all()
+        assert (rec[~dec][:, 0] == 0xff).all() and (rec[~dec][:, 1:] == 0).all()      # an ignored burst type: the front end's "nothing" mark, no decode
+        for i in np.flatnonzero(dec)[:: max(1, n // 300)]:
+            ok, want, wcrc = O.bench_decode_slots(slots[i:i + 1], ty[i:i + 1], int(p["code"][i]), want_out=True, want_crc=True)
+            t = ty[i]
+            assert (p["bbk"][i] == want[0, :14]).all()
+            if t == O.TRAIN_NORM_1:
+                assert (p["bits1"][i] == want[0, 14:282]).all() and p["crc"][i, 0] == wcrc[0, 0]
+            else:
+                n1 = 60 if t == O.TRAIN_SYNC else 124
+                assert (p["bits1"][i][:n1] == want[0, 14:14 + n1]).all() and (p["bits2"][i] == want[0, 138:262]).all()
+                assert p["crc"][i, 0] == wcrc[0, 0] and p["crc"][i, 1] == wcrc[0, 1]
+
+
 def test_grid_plan_multi_block_scan(T, eng):
     """a longer stream (several 1024-slot blocks in the device-side list building, lock losses in between):
     the grid plan's records == the slot-table plan's"""

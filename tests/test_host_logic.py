@@ -468,3 +468,51 @@ def test_adapter_uses_only_what_the_header_declares(tmp_path):
         "#include \"tetra_gpu.h\"", "int main(void) { return (int)sizeof(struct tgpu_unitdata) * 0; }"]) + "\n")
     r = subprocess.run([gcc, "-std=gnu11", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(g)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("ber", [0.0, 0.03, 0.08, 0.5])
+def test_lane_per_slot_schedule_on_host_bit_exact(ber):
+    """slot_core.h (round 6: one lane = one slot; what k_slot / k_slot_t run): a NORM_1, NORM_2 or SYNC burst through the ONE
+    36-block schedule -- SB1 started at block slot 8, the first block of a two-block burst flushed in the middle of slot 17 with
+    the second block's lead-in behind it, traceback and CRC register re-started there -- gives the oracle's type-2 bits and CRC
+    words for every block, ties included, and the record pieces hold the type-1 bits where tg_layout.h puts them"""
+    rng = np.random.default_rng(int(ber * 1000) + 5)
+    code = O.scramb_get_init(262, 42, 1)
+
+    def block(t, c):
+        K, n2, n1, a = O.BLK[t]
+        t5 = O.encode_block(t, rng.integers(0, 2, n1).astype(np.uint8), c)
+        t5 ^= (rng.random(K) < ber).astype(np.uint8)
+        return t5
+
+    for rep in range(60):
+        for bt in (O.TRAIN_NORM_1, O.TRAIN_NORM_2, O.TRAIN_SYNC):
+            slot = rng.integers(0, 2, 510).astype(np.uint8)
+            if bt == O.TRAIN_NORM_1:
+                blks = [(O.T_SCH_F, code, block(O.T_SCH_F, code))]
+                slot[14:230], slot[282:498] = O.scramb(code, blks[0][2])[:216], O.scramb(code, blks[0][2])[216:]
+            elif bt == O.TRAIN_NORM_2:
+                blks = [(O.T_NDB, code, block(O.T_NDB, code)), (O.T_NDB, code, block(O.T_NDB, code))]
+                slot[14:230], slot[282:498] = O.scramb(code, blks[0][2]), O.scramb(code, blks[1][2])
+            else:
+                blks = [(O.T_SB1, 3, block(O.T_SB1, 3)), (O.T_SB2, code, block(O.T_SB2, code))]
+                slot[94:214], slot[282:498] = O.scramb(3, blks[0][2]), O.scramb(code, blks[1][2])
+            od, crc, bits, sy = emul.decode_slot(bt, emul.pack_slot(bt, slot))
+            odbits = np.unpackbits(od, bitorder="little")
+            for i, (t, c, t5) in enumerate(blks):
+                want1, wcrc, ok, want2 = O.decode_block(t, t5, c)
+                n2, n1 = O.BLK[t][1], O.BLK[t][2]
+                o0 = 0 if (i == 0 and bt != O.TRAIN_SYNC) else 64 if i == 0 else 144
+                assert (odbits[o0:o0 + n2] == want2).all(), (rep, bt, i)
+                assert int(crc[i]) == wcrc, (rep, bt, i)
+                r0 = 0 if i == 0 else 128
+                assert (bits[r0:r0 + n1] == want1).all() and not bits[r0 + n1:r0 + ((n1 + 15) & ~15)].any()
+            if bt == O.TRAIN_NORM_1:
+                assert int(crc[1]) == 0
+            if bt == O.TRAIN_SYNC:
+                w = odbits[64:]
+                f = lambda a, n: int("".join(str(int(x)) for x in w[a:a + n]), 2)
+                cc, tn, fn, mn, mcc, mnc = f(4, 6), f(10, 2) + 1, f(12, 5), f(17, 6), f(31, 10), f(41, 14)
+                assert int(sy[0]) == cc | tn << 8 | fn << 16 | mn << 24 and int(sy[1]) == mcc | mnc << 16
+                assert int(sy[2]) == O.scramb_get_init(mcc, mnc, cc)
+                assert not bits[64:128].any()
