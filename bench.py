@@ -286,6 +286,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
     eng = T.Engine(local)
     if args.walk_wide:
         T.set_option(T.OPT_WALK_WIDE, 1)
+    if args.slot_mode >= 0:
+        T.set_option(T.OPT_SLOT, args.slot_mode)
     d_bases = [torch.from_numpy(buf).cuda()]
     for b in range(1, NB):
         sts_b, cds_b, offs_b, buf_b = capture(b, args.ber)
@@ -1510,6 +1512,8 @@ def main():
     ap.add_argument("--side-stream", action="store_true", help="mix: keep the plans' side streams in play (the round-3 form)")
     ap.add_argument("--walk-wide", action="store_true", help="mix: the device walk's per-channel launches as 1024 threads / 128 KB of LDS "
                                                              "(rounds 3 and 4) instead of 256 threads and LDS sized per launch")
+    ap.add_argument("--slot-mode", type=int, default=-1, help="TGPU_OPT_SLOT for this run (A/B): 0 = k_vit<216> + k_vit<432> (rounds 1-5), 1 = k_slot_t, 2 = k_slot "
+                                                             "(front end + trellises in one launch) where a channel has a code to decode on; -1 = the library's default")
     ap.add_argument("--streams", type=int, default=0, help="mix: streams the steps in flight run on (0 = one per step in flight; fewer: "
                                                            "plan j runs on stream j %% streams)")
     ap.add_argument("--bursts", type=int, default=1_000_000, help="bursts (slots) per GPU per step")

@@ -168,9 +168,17 @@ enum tgpu_option {
 					 * channel's last flush -- a process that cannot have that sets the option to 0 before creating channels */
 	TGPU_OPT_SLOT,			/* how the plan API's batches run their trellises (round 6; records are the same bytes either way):
 					 * 0: k_vit<216> and k_vit<432>, one lane per BLOCK (rounds 1-5);
-					 * 1 (default): k_slot_t, one lane per SLOT -- one launch over the batch's delivered slots of any type,
-					 *    a SYNC burst's SB1 included, every record written as whole 64-byte segments
-					 * (soft input, block mode, the RM(30,14) option and the clean-block fast path keep the lane-per-block kernels) */
+					 * 1: k_slot_t, one lane per SLOT -- one launch over the batch's delivered slots of any type, a SYNC burst's
+					 *    SB1 included, every record written as whole 64-byte segments;
+					 * 2 (default): as 1, and device-walk batches (tgpu_sync_multi_launch) whose channels have a scrambling code to
+					 *    decode on -- the caller's carry-in code, else the code the plan's last batch of the channel ended with --
+					 *    run the stream front end AND the trellises in one launch (k_slot): a wave packs and classifies 64
+					 *    neighbouring grid slots, keeps them in LDS and decodes them there and then; after the walk and the code
+					 *    look-back every delivered slot whose code in force is not the one it was decoded under (or that the exact
+					 *    pass settled) goes through k_slot_t.  Records of UNDELIVERED grid slots are unspecified in that form (they
+					 *    may hold a decode nobody asked for); tgpu_sync_dev_fused() tells which form a batch took.
+					 * (soft input, block mode, the RM(30,14) option, the clean-block fast path and the traffic stage keep the
+					 * earlier forms) */
 	TGPU_OPT__COUNT
 };
 int tgpu_engine_set_option(struct tgpu_engine *eng, int /* enum tgpu_option */ option, long value);
@@ -651,6 +659,9 @@ int tgpu_sync_multi_launch_packed(struct tgpu_engine *eng, struct tgpu_plan *pla
 				  const uint8_t *d_packed_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *hip_stream);
 uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd);
 int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd);
+/* 1: this batch's front end and trellises ran as ONE launch (k_slot, TGPU_OPT_SLOT 2) on hinted scrambling codes; 0: the front end
+ * on its own (a plan's first batch without carry-in codes, another setting of the option) -- same records either way */
+int tgpu_sync_dev_fused(const struct tgpu_sync_dev *sd);
 /* after collect: why the device walk handed channel c to the host walks (0: it did not).  1 a flagged slot (a byte other than
  * 0 / 1, a sequence below offset 21) on the walk's way, 2 a search window the kernel's view does not settle, 3 a SYNC sequence in
  * the first 21 bytes of a search buffer, 4 a lock beside the slot grid, 5 / 6 / 7 / 8 / 9 internal bounds (iterations, events or

@@ -211,6 +211,7 @@ def lib():
     L.tgpu_sync_dev_ngrid.argtypes = [C.c_void_p]
     L.tgpu_sync_dev_ngrid.restype = C.c_uint32
     L.tgpu_sync_dev_fellback.argtypes = [C.c_void_p]
+    L.tgpu_sync_dev_fused.argtypes = [C.c_void_p]
     L.tgpu_sync_dev_why.argtypes = [C.c_void_p, C.c_uint32]
     L.tgpu_sync_dev_free.argtypes = [C.c_void_p]
     L.tgpu_sync_dev_free.restype = None
@@ -825,6 +826,7 @@ class MultiSyncDev:
         _chk(fn(engine._h, plan._h, n, self._ch, C.c_void_p(d_base_ptr), chunk, C.c_void_p(d_rec_ptr),
                 C.byref(self._h), C.c_void_p(hip_stream)), "tgpu_sync_multi_launch")
         self.ngrid = lib().tgpu_sync_dev_ngrid(self._h)
+        self.fused = bool(lib().tgpu_sync_dev_fused(self._h))      # front end + trellises as one launch (k_slot, OPT_SLOT 2)
         self.fellback = False
 
     def collect_begin(self):

@@ -34,7 +34,7 @@ int tgpu_plan_set_fastpath(struct tgpu_plan *p, int on);
  * nothing in this library reads the environment */
 static long tg_options[TGPU_OPT__COUNT] = {
 	[TGPU_OPT_BURST_MAX] = 1024,	/* measured crossover of k_burst and the lane-per-trellis kernels */
-	[TGPU_OPT_SLOT] = 1,		/* round 6: the trellises of a batch by one lane per slot (tg_k_slot.hip); 0 = k_vit<216> + k_vit<432> */
+	[TGPU_OPT_SLOT] = 2,		/* round 6: the trellises of a batch by one lane per slot, fused with the stream front end where a channel has a code to decode on (tg_k_slot.hip); 1 = k_slot_t only; 0 = k_vit<216> + k_vit<432> */
 	[TGPU_OPT_RING] = 1,		/* round 6: on by default -- channels of up to four bursts per flush (the reference's own usage pattern,
 					 * tetra-rx.c:82-95) answer a flush 30-40 % sooner through workgroups that stay; a flush the ring does not
 					 * answer goes by launch, a ring that keeps failing is given up (tg_sync.c: ring_failed) */
@@ -145,6 +145,15 @@ struct tgpu_plan {
 	uint32_t walk_big_nodes;	/* nodes a channel of the LDS form had when it overflowed (0: never): sizes the long form's threshold */
 	uint32_t walk_nodes_seen;	/* most nodes any channel of this plan's batches had (0: no batch yet): sizes the LDS form's arrays */
 	uint32_t *d_bits_dev;		/* the delivered bitmap k_walk left in the upload arena */
+	/* k_slot batches (TGPU_OPT_SLOT 2; tg_k_slot.hip): front end and trellis in one launch, decoding on hinted scrambling codes */
+	uint32_t *d_specbits;		/* bit per grid slot "decoded by k_slot under its channel's hint" (upload arena) */
+	uint32_t hint_base;		/* mask-table entry of channel 0's hint (behind the batch kernels' entries) */
+	uint32_t hint_last[64];		/* the codes this plan's last device-walk batch ended with, per channel index (hints of the next one) */
+	uint32_t hint_last_n;
+	uint32_t hint_built[64];	/* the codes whose masks sit in entries hint_base + c */
+	uint32_t hint_now[64];		/* this batch's hints (0: none) */
+	int dev_prepared;		/* tgpi_plan_dev_prepare() laid this batch's arena out */
+	int fused;			/* this batch's front end ran as k_slot */
 };
 
 const char *tgpu_strerror(int err)
@@ -275,7 +284,9 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	DALLOC(p->d_maskidx, n * 4);
 	/* mask entries: 0 = the fixed code 3, 1 + c = channel c's carry-in code, then one per SYNC slot of a batch (<= n) or --
 	 * device-walk batches -- one per slot of the batch's code hash table (1 + nchan + h, h < TGK_LB_TBL), whatever n is */
-	DALLOC(p->d_masks, (1 + (size_t)max_chan + (n > TGK_LB_TBL ? n : TGK_LB_TBL)) * TG_MASK_WORDS * 4);
+	/* ... and behind those, k_slot's hints: one entry per channel */
+	p->hint_base = (uint32_t)(1 + (size_t)max_chan + (n > TGK_LB_TBL ? n : TGK_LB_TBL));
+	DALLOC(p->d_masks, ((size_t)p->hint_base + 64) * TG_MASK_WORDS * 4);
 	DALLOC(p->d_sb_ok, n * 4);
 	DALLOC(p->d_sb_code, n * 4);
 	DALLOC(p->d_block_tmp, ((n + 1023) / 1024 + 1) * sizeof(unsigned long long));
@@ -573,10 +584,11 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
  * of the code table (in the block that goes to the host); *d_bits_out: where k_walk is to leave the delivered bitmap.
  * serial != 0: everything on the caller's stream in program order (per-stage profiling).
  */
-int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const struct tg_chan_ent *d_tab, uint32_t *d_codes,
-			 uint32_t *d_plain, uint32_t **d_bits_out, void *stream, int serial, void **evs)
+/* round 6: the arena's layout and the one memset moved in front of the front end (tgpi_plan_dev_prepare) -- k_slot's SYNC lanes run the
+ * code look-back's atomics from inside the front-end launch */
+int tgpi_plan_dev_prepare(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, uint32_t *d_codes, uint32_t **d_bits_out, void *stream)
 {
-	if (!p || !ngrid || !p->d_grid || !nchan || !d_codes || !d_tab || !d_bits_out)
+	if (!p || !ngrid || !p->d_grid || !nchan || !d_codes || !d_bits_out)
 		return TGPU_EINVAL;
 	BIND(p->eng);
 	if (ngrid > p->max_slots || nchan > p->max_chan)
@@ -607,6 +619,7 @@ int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, co
 	UP_AT(p->d_list_216, uint32_t, 2 * (size_t)ngrid);
 	UP_AT(p->d_list_432, uint32_t, ngrid);
 	UP_AT(p->d_list_all, uint32_t, ngrid);
+	UP_AT(p->d_specbits, uint32_t, nwords + 2);
 #undef UP_AT
 	p->d_slot_off = NULL;
 	p->d_slot_chan = NULL;
@@ -625,7 +638,62 @@ int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, co
 	p->nchan = nchan;
 	hipStream_t s = (hipStream_t)stream;
 	HCHK(hipMemsetAsync(base, 0, zero_bytes, s));
-	int rc = tgk_cls_plain2(p->d_grid, ngrid, d_plain, p->d_list_sb, d_cnt, d_wchan, d_tab, nchan, stream);
+	p->dev_prepared = 1;
+	p->fused = 0;
+	return TGPU_OK;
+}
+
+/*
+ * k_slot batches (TGPU_OPT_SLOT 2): the front end and the trellises in one launch, decoding on hinted codes -- hints[c] (host, nchan
+ * words; 0 = none): the caller's carry-in code, else what this plan's last batch of the channel ended with.  *fused = 1 when the batch
+ * was launched that way, 0 when it is not for this form (no hint at all, an option only the other kernels implement: the caller runs
+ * tgk_front_stream_multi).  Wants tgpi_plan_dev_prepare() and tgpi_plan_set_rec() in front.
+ */
+int tgpi_plan_dev_front_fused(struct tgpu_plan *p, const uint8_t *d_base, const struct tg_chan_ent *d_tab, uint32_t nchan, uint32_t ngrid,
+			      uint32_t chunk, const uint32_t *carry, void *stream, void *ev_mid, int packed_input, int *fused)
+{
+	if (!p || !p->dev_prepared || !p->d_rec_dev || nchan > 64 || !fused)
+		return TGPU_EINVAL;
+	*fused = 0;
+	if (tgi_option(TGPU_OPT_SLOT) < 2 || tgi_option(TGPU_OPT_STREAM_EXACT) || p->rm_decode || p->fastpath || p->d_traffic || ngrid < 64)
+		return TGPU_OK;
+	BIND(p->eng);
+	int any = 0, rebuild = 0;
+	for (uint32_t c = 0; c < nchan; c++) {
+		p->hint_now[c] = carry[c] ? carry[c] : (c < p->hint_last_n ? p->hint_last[c] : 0u);
+		any |= p->hint_now[c] != 0;
+		rebuild |= p->hint_now[c] != p->hint_built[c];
+	}
+	if (!any)
+		return TGPU_OK;
+	int rc;
+	if (rebuild) {
+		if ((rc = tgk_masks_list(p->hint_now, nchan, p->d_masks + (size_t)p->hint_base * TG_MASK_WORDS, stream)))
+			return rc;
+		memcpy(p->hint_built, p->hint_now, (size_t)nchan * 4);
+	}
+	const int kf = TGK_F_LOOKBACK | (int)(nchan << 8) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0);
+	rc = tgk_slot_fused(d_base, d_tab, nchan, ngrid, chunk, p->d_packed, p->d_grid, (uint16_t *)(p->d_grid + ngrid), p->d_defer,
+			    p->d_masks, p->hint_base, p->hint_now, p->d_specbits, p->d_rec_dev, p->d_wire, p->d_lb_tbl, p->d_lb_ok,
+			    (uint32_t *)p->d_slot_sbord, kf, stream, ev_mid, packed_input);
+	if (rc)
+		return rc;
+	p->fused = 1;
+	*fused = 1;
+	return TGPU_OK;
+}
+
+int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const struct tg_chan_ent *d_tab, uint32_t *d_codes,
+			 uint32_t *d_plain, void *stream, int serial, void **evs)
+{
+	if (!p || !p->dev_prepared || !ngrid || !nchan || !d_codes || !d_tab)
+		return TGPU_EINVAL;
+	BIND(p->eng);
+	hipStream_t s = (hipStream_t)stream;
+	uint32_t *d_cnt = (uint32_t *)p->d_counts, *d_tbl = p->d_lb_tbl, *d_ok = p->d_lb_ok;
+	uint8_t *d_wchan = p->d_lb_wchan;
+	p->dev_prepared = 0;
+	int rc = tgk_cls_plain2(p->d_grid, ngrid, d_plain, p->d_list_sb, d_cnt, d_wchan, d_tab, nchan, p->fused ? p->d_specbits : NULL, stream);
 	if (rc)
 		return rc;
 	if (evs)
@@ -670,7 +738,8 @@ int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, u
 	if (evs)
 		HCHK(hipEventRecord((hipEvent_t)evs[0], s));
 	rc = tgk_lists2(p->d_grid, p->d_bits_dev, ngrid, p->d_lb_ok, p->d_lb_prevw, p->d_lb_wchan, (const uint32_t *)p->d_slot_sbord,
-			p->d_maskidx, p->d_list_216, p->d_list_432, p->d_list_all, (uint32_t *)p->d_counts, stream);
+			p->d_maskidx, p->d_list_216, p->d_list_432, p->d_list_all, (uint32_t *)p->d_counts,
+			p->fused ? p->d_specbits : NULL, p->hint_now, p->d_chan_code, p->d_lb_tbl, p->nchan, stream);
 	if (rc)
 		return rc;
 	if (evs)
@@ -705,6 +774,11 @@ void tgpi_plan_set_final_codes(struct tgpu_plan *p, const uint32_t *codes, uint3
 		return;
 	memcpy(p->h_final_code, codes, (size_t)nchan * 4);
 	p->have_final = 1;
+	/* what the next batch of these channels on this plan may decode on before its own SYNC bursts are looked at (k_slot) */
+	if (nchan <= 64) {
+		memcpy(p->hint_last, codes, (size_t)nchan * 4);
+		p->hint_last_n = nchan;
+	}
 }
 
 void tgpi_plan_set_last_slot(struct tgpu_plan *p, uint32_t chan, uint32_t slot)

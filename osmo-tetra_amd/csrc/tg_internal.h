@@ -269,14 +269,23 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 
 /* device-walk batches: everything between the front end and the trellis kernels (tg_k_aux.hip, k_lists2) */
 int tgk_cls_plain2(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, uint32_t *d_list_sb, uint32_t *d_cnt_sb,
-		   uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, void *stream);
+		   uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_specbits /* or NULL */, void *stream);
+/* k_slot batches (tg_k_slot.hip): front end + trellis in one launch on hinted codes, then the exact pass; tgk_masks_list builds the
+ * hints' mask entries (codes by value, n <= 64) */
+int tgk_slot_fused(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots, uint32_t chunk,
+		   uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer, const uint32_t *d_masks,
+		   uint32_t hint_base, const uint32_t *hints, uint32_t *d_specbits, uint8_t *d_rec, uint8_t *d_wire,
+		   uint32_t *d_tbl, uint32_t *d_sb_ok, uint32_t *d_sb_entry, int flags, void *stream, void *ev_mid, int packed_input);
+int tgk_masks_list(const uint32_t *codes, uint32_t n, uint32_t *d_masks_out, void *stream);
 int tgk_masks2(const uint32_t *d_chan_code, uint32_t nchan, const uint32_t *d_tbl, uint32_t *d_masks, void *stream);
 int tgk_lb_scan(const uint32_t *d_okbits, const uint32_t *d_dbits, const uint8_t *d_word_chan, uint32_t nwords,
 		uint32_t *d_prevw, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_chan_code,
 		const uint32_t *d_slot_entry, const uint32_t *d_masks, const uint32_t *d_tbl, uint32_t *d_final_code, void *stream);
 int tgk_lists2(const uint32_t *d_cls, const uint32_t *d_dbits, uint32_t n, const uint32_t *d_okbits, const uint32_t *d_prevw,
 	       const uint8_t *d_word_chan, const uint32_t *d_slot_entry, uint32_t *d_maskidx, uint32_t *d_list_216,
-	       uint32_t *d_list_432, uint32_t *d_list_all /* or NULL */, uint32_t *d_cnt, void *stream);
+	       uint32_t *d_list_432, uint32_t *d_list_all /* or NULL */, uint32_t *d_cnt,
+	       const uint32_t *d_specbits /* or NULL */, const uint32_t *hints /* host, nchan words */, const uint32_t *d_chan_code,
+	       const uint32_t *d_tbl, uint32_t nchan, void *stream);
 /* compact transport form of a batch (tg_cwire.h / tg_cwire.hip): the delivered slots' 40-byte wire records -> one buffer of
  * header, channel table, bitmap, block table and 25 / 33 / 36 (41) byte records; d_total (optional): two words, the bytes the
  * batch needs and its delivered bursts (0xffffffff: cap was too small and no record was written) */
@@ -290,8 +299,11 @@ int tgpi_plan_cwire(struct tgpu_plan *p, const struct tg_cw_chans *ch, uint32_t 
 int tgpi_plan_has_cwire(const struct tgpu_plan *p);
 /* stream mode with the walk on the device (tg_stream.c: tgpu_sync_multi_launch) */
 /* evs (optional, serial mode): HIP events recorded behind stage 1's three launches / stage 2's two */
+int tgpi_plan_dev_prepare(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, uint32_t *d_codes, uint32_t **d_bits_out, void *stream);
+int tgpi_plan_dev_front_fused(struct tgpu_plan *p, const uint8_t *d_base, const struct tg_chan_ent *d_tab, uint32_t nchan, uint32_t ngrid,
+			      uint32_t chunk, const uint32_t *carry, void *stream, void *ev_mid, int packed_input, int *fused);
 int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, const struct tg_chan_ent *d_tab, uint32_t *d_codes,
-			 uint32_t *d_plain, uint32_t **d_bits_out, void *stream, int serial, void **evs);
+			 uint32_t *d_plain, void *stream, int serial, void **evs);
 int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, uint32_t *d_final, void *stream, int serial, void **evs);
 void tgpi_plan_set_rec(struct tgpu_plan *p, uint8_t *d_rec);
 void tgpi_plan_set_final_codes(struct tgpu_plan *p, const uint32_t *codes, uint32_t nchan);

@@ -783,10 +783,56 @@ extern "C" int tgk_stages_crc(const uint8_t *d_type2, unsigned long long nblocks
  * An undelivered SYNC slot may be decoded (its SB1 costs 84 trellis steps) but never counts: the look-back ANDs okbits
  * with the delivered bitmap.
  */
+struct tg_lists_hints {
+	uint32_t code[64];	/* k_slot batches: the code every channel's slots were decoded under there (0: none) */
+};
+
+/* the scrambling masks of up to 64 codes handed over by value (k_slot's hints: entries hint_base + c of the mask table) */
+__global__ __launch_bounds__(64)
+void k_masks_list(tg_lists_hints codes, uint32_t n, uint32_t *__restrict__ masks)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t half = lane >> 5, bit = lane & 31;
+	uint32_t lin[TG_MW_ROUNDS];
+#pragma unroll
+	for (int r = 0; r < TG_MW_ROUNDS; r++) {
+		const uint16_t pos = c_tab.mask_pos[2 * r + half][bit];
+		lin[r] = (pos != 0xffff) ? c_tab.lfsr_lin[pos] : 0u;
+	}
+	for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+		uint32_t code = 0;
+		for (uint32_t c = 0; c < 64; c++)
+			code = (c == e) ? codes.code[c] : code;
+		uint32_t myword = 0;
+#pragma unroll
+		for (int r = 0; r < TG_MW_ROUNDS; r++) {
+			const unsigned long long bal = __ballot(__popc(code & lin[r]) & 1);
+			myword = (lane == (uint32_t)(2 * r)) ? (uint32_t)bal : myword;
+			myword = (lane == (uint32_t)(2 * r + 1)) ? (uint32_t)(bal >> 32) : myword;
+		}
+		if (lane == TG_MW_CODE)
+			myword = code;
+		if (lane < TG_MASK_WORDS)
+			masks[(size_t)e * TG_MASK_WORDS + lane] = myword;
+	}
+}
+
+extern "C" int tgk_masks_list(const uint32_t *codes, uint32_t n, uint32_t *d_masks_out, void *stream)
+{
+	if (!n || n > 64)
+		return n ? -1 : 0;
+	tg_lists_hints h;
+	memset(&h, 0, sizeof(h));
+	memcpy(h.code, codes, (size_t)n * 4);
+	hipLaunchKernelGGL(k_masks_list, dim3(n), dim3(64), 0, (hipStream_t)stream, h, n, d_masks_out);
+	return (int)hipGetLastError();
+}
+
 #define TG_MID_CHUNKS 4		/* 1024-slot chunks per workgroup of k_cls_plain2 / k_lists2: one atomic per 4096 slots and list */
 __global__ __launch_bounds__(1024)
 void k_cls_plain2(const uint32_t *__restrict__ cls, uint32_t n, uint32_t *__restrict__ plain, uint32_t *__restrict__ list_sb,
-		  uint32_t *__restrict__ cnt_sb, uint8_t *__restrict__ word_chan, const tg_chan_ent *__restrict__ chan, uint32_t nchan)
+		  uint32_t *__restrict__ cnt_sb, uint8_t *__restrict__ word_chan, const tg_chan_ent *__restrict__ chan, uint32_t nchan,
+		  const uint32_t *__restrict__ specbits /* or NULL; k_slot batches: SYNC slots whose SB1 that kernel decoded stay off the list */)
 {
 	/* (a single word takes ~90 atomics per microsecond: one per wave would be 15 000 of them) */
 	__shared__ uint32_t s_cnt[TG_MID_CHUNKS][16], s_base;
@@ -798,8 +844,9 @@ void k_cls_plain2(const uint32_t *__restrict__ cls, uint32_t n, uint32_t *__rest
 		const uint32_t i = (blockIdx.x * TG_MID_CHUNKS + j) * 1024 + threadIdx.x;
 		const uint32_t w = i >> 5;
 		const uint32_t v = i < n ? cls[i] & 0x03ffffffu : 0xffu;
-		sb[j] = v == (TG_BURST_SYNC | TG_SYNC_TRAIN_OFF << 8);
-		const bool ok = sb[j] || v == (TG_BURST_NORM_1 | TG_NORM_TRAIN_OFF << 8) || v == (TG_BURST_NORM_2 | TG_NORM_TRAIN_OFF << 8);
+		const bool issb = v == (TG_BURST_SYNC | TG_SYNC_TRAIN_OFF << 8);
+		sb[j] = issb && !(specbits && i < n && ((specbits[w] >> (i & 31)) & 1));
+		const bool ok = issb || v == (TG_BURST_NORM_1 | TG_NORM_TRAIN_OFF << 8) || v == (TG_BURST_NORM_2 | TG_NORM_TRAIN_OFF << 8);
 		const unsigned long long b = __ballot(ok);
 		sbm[j] = __ballot(sb[j]);
 		if (lane == 0 && 32 * w < n)
@@ -967,8 +1014,13 @@ void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbi
 	      const uint32_t *__restrict__ prevw, const uint8_t *__restrict__ word_chan, const uint32_t *__restrict__ slot_entry,
 	      uint32_t *__restrict__ maskidx, uint32_t *__restrict__ list_216, uint32_t *__restrict__ list_432,
 	      uint32_t *__restrict__ list_all /* or NULL: every delivered slot once, for the lane-per-slot kernel (tg_k_slot.hip) */,
-	      uint32_t *__restrict__ cnt /* [1]: 216 items, [2]: 432 items, [3]: delivered slots */)
+	      uint32_t *__restrict__ cnt /* [1]: 216 items, [2]: 432 items, [3]: delivered slots */,
+	      const uint32_t *__restrict__ specbits, tg_lists_hints hints, const uint32_t *__restrict__ chan_code, const uint32_t *__restrict__ tbl,
+	      uint32_t nchan)
 {
+	/* k_slot batches (specbits != NULL): a delivered slot that kernel decoded under its channel's hint is DONE if the code in force at
+	 * the slot -- the entry found here -- is the hint's; it then goes onto no list.  Every other delivered slot (decoded under another
+	 * code: a channel's first batch, a cell change; or not decoded there at all: the exact pass's slots) is listed as before. */
 	__shared__ uint32_t s_c216[TG_MID_CHUNKS][16], s_c432[TG_MID_CHUNKS][16], s_call[TG_MID_CHUNKS][16], s_b216, s_b432, s_ball;
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const unsigned long long below = (1ull << lane) - 1;
@@ -981,7 +1033,17 @@ void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbi
 			t[j] = cls[g] & 0xff;
 		if (t[j] != TG_BURST_NONE) {
 			const uint32_t gs = tg_lb_find(g, okbits, dbits, prevw, word_chan);
-			maskidx[g] = gs != 0xffffffffu ? slot_entry[gs] : 1u + word_chan[g >> 5];
+			const uint32_t wc = word_chan[g >> 5];
+			const uint32_t e = gs != 0xffffffffu ? slot_entry[gs] : 1u + wc;
+			maskidx[g] = e;
+			if (specbits && ((specbits[g >> 5] >> (g & 31)) & 1)) {
+				const uint32_t code = e <= nchan ? chan_code[e - 1] : tbl[e - 1 - nchan];	/* (e >= 1: entry 0 is SB1's fixed code, never a slot's) */
+				uint32_t hc = 0;
+				for (uint32_t c = 0; c < nchan; c++)
+					hc = (c == wc) ? hints.code[c] : hc;
+				if (code == hc && hc != 0u)
+					t[j] = TG_BURST_NONE;
+			}
 		}
 		const unsigned long long msb = __ballot(t[j] == TG_BURST_SYNC), mn2 = __ballot(t[j] == TG_BURST_NORM_2);
 		const unsigned long long mn1 = __ballot(t[j] == TG_BURST_NORM_1);
@@ -1043,12 +1105,12 @@ void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbi
 }
 
 extern "C" int tgk_cls_plain2(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, uint32_t *d_list_sb, uint32_t *d_cnt_sb,
-			      uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, void *stream)
+			      uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_specbits, void *stream)
 {
 	if (!n)
 		return 0;
 	hipLaunchKernelGGL(k_cls_plain2, dim3((n + 1024 * TG_MID_CHUNKS - 1) / (1024 * TG_MID_CHUNKS)), dim3(1024), 0, (hipStream_t)stream, d_cls, n, d_plain, d_list_sb, d_cnt_sb,
-			   d_word_chan, d_chan, nchan);
+			   d_word_chan, d_chan, nchan, d_specbits);
 	return (int)hipGetLastError();
 }
 
@@ -1072,11 +1134,17 @@ extern "C" int tgk_lb_scan(const uint32_t *d_okbits, const uint32_t *d_dbits, co
 
 extern "C" int tgk_lists2(const uint32_t *d_cls, const uint32_t *d_dbits, uint32_t n, const uint32_t *d_okbits, const uint32_t *d_prevw,
 			  const uint8_t *d_word_chan, const uint32_t *d_slot_entry, uint32_t *d_maskidx, uint32_t *d_list_216,
-			  uint32_t *d_list_432, uint32_t *d_list_all, uint32_t *d_cnt, void *stream)
+			  uint32_t *d_list_432, uint32_t *d_list_all, uint32_t *d_cnt, const uint32_t *d_specbits, const uint32_t *hints,
+			  const uint32_t *d_chan_code, const uint32_t *d_tbl, uint32_t nchan, void *stream)
 {
 	if (!n)
 		return 0;
+	tg_lists_hints h;
+	memset(&h, 0, sizeof(h));
+	if (d_specbits && hints)
+		memcpy(h.code, hints, (size_t)(nchan < 64 ? nchan : 64) * 4);
 	hipLaunchKernelGGL(k_lists2, dim3((n + 1024 * TG_MID_CHUNKS - 1) / (1024 * TG_MID_CHUNKS)), dim3(1024), 0, (hipStream_t)stream, d_cls, d_dbits, n, d_okbits, d_prevw,
-			   d_word_chan, d_slot_entry, d_maskidx, d_list_216, d_list_432, d_list_all, d_cnt);
+			   d_word_chan, d_slot_entry, d_maskidx, d_list_216, d_list_432, d_list_all, d_cnt, (d_specbits && hints) ? d_specbits : NULL, h, d_chan_code,
+			   d_tbl, nchan);
 	return (int)hipGetLastError();
 }

@@ -20,9 +20,8 @@
  * Three slots are kept in flight per wave (the dwords of slot i+3 are requested as soon as slot i
  * is parked in LDS).  LDS operations of one wave execute in order: no barrier between the stages.
  */
-typedef uint32_t __attribute__((aligned(1))) tg_u32_unaligned;
-typedef uint16_t __attribute__((aligned(1))) tg_u16_unaligned;
-typedef uint16_t __attribute__((may_alias)) tg_u16_alias;
+#include "tg_dev_stream.h"	/* typedefs, front_flush, tg_stream_params, chan_of_slot, the packed-bit front end's pieces */
+
 
 __device__ __forceinline__ void front_fetch(const uint8_t *base, uint32_t lane, uint32_t &d0, uint32_t &d1)
 {
@@ -109,19 +108,6 @@ __device__ __forceinline__ void front_process(uint32_t slot, uint32_t type, uint
 		stage[lane] = myword;
 }
 
-/* write cnt (1..4) consecutive packed slots, first = slot index 'first', from the wave's staging area: two
- * range-checked buffer stores (lanes past cnt * 80 bytes are dropped), 320 contiguous bytes for a full group */
-__device__ __forceinline__ void front_flush(const uint32_t *mo, uint32_t lane, uint32_t first, uint32_t cnt,
-					     uint32_t *__restrict__ packed)
-{
-	const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(packed + (size_t)first * TG_PACKED_WORDS, 0,
-									       cnt * TG_PACKED_WORDS * 4, 0x00027000);
-#ifndef TGS_ST_AUX
-#define TGS_ST_AUX 0
-#endif
-	__builtin_amdgcn_raw_buffer_store_b32(mo[lane], out, lane * 4, 0, TGS_ST_AUX);
-	__builtin_amdgcn_raw_buffer_store_b32(mo[64 + lane], out, 256 + lane * 4, 0, TGS_ST_AUX);
-}
 
 __global__ __launch_bounds__(256)
 void k_front(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ slot_desc,
@@ -329,29 +315,7 @@ __device__ __forceinline__ uint32_t pattern_bits(const uint8_t *seq, int from, i
 	return v;
 }
 
-struct tg_stream_params {
-	uint64_t anchor;	/* stream offset of grid slot 0 */
-	uint64_t len;		/* stream length in bytes */
-	uint32_t nslots;
-	uint32_t chunk;		/* bytes per tetra_burst_sync_in() call being emulated */
-	int32_t cshift;		/* log2(chunk) when it is a power of two, else -1 */
-	uint32_t y32, y6, n22, p22;
-	uint32_t q22, x22;	/* first 22 bits of the other two sequences the reference's look-ahead filter passes */
-	/* several recorded channels in one grid (BASELINE config 4: a GPU's share of the channels in one batch): channel
-	 * c owns grid slots gbase .. gbase + ncls - 1 (gbase a multiple of 32, the slots up to the next channel's gbase
-	 * are padding and never decoded); its stream lies at byte d_off of the buffer, anchor / len are relative to it */
-	const struct tg_chan_ent *chan;
-	uint32_t nchan;		/* 0: one stream, the fields above */
-	uint64_t pbit;		/* packed ingest (per-position form): bit position of the channel's stream position 0 in the packed buffer */
-};
 
-/* channel of grid slot 'slot' (nchan <= 64: one table word per lane, a ballot counts the channels that start at or
- * before the slot); wave-uniform */
-__device__ __forceinline__ uint32_t chan_of_slot(const tg_chan_ent *chan, uint32_t nchan, uint32_t slot, uint32_t lane)
-{
-	const uint32_t gb = lane < nchan ? chan[lane].gbase : 0xffffffffu;
-	return (uint32_t)__builtin_popcountll(__ballot(gb <= slot)) - 1u;
-}
 
 /*
  * One grid slot through the per-position search: the wave's view (TG_VIEW_OF: 510 + what two feeds of the replay add to a
@@ -625,8 +589,6 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
 	}
 }
 
-/* classification word of a slot the packed-bit kernel leaves to k_front_stream_fix (never a valid word: offsets stay below 1088) */
-#define TG_CLS_DEFER 0xffffffffu
 
 /* second pass of the packed-bit front end: every slot the first pass deferred goes through the exact per-position search.
  * Round 5: the first pass keeps one list PER WAVE -- defer[w] = how many slots wave w of k_front_stream deferred, its
@@ -637,7 +599,6 @@ void k_front_stream_v1(const uint8_t *__restrict__ stream, tg_stream_params prm,
  * 1 % deferred slots, tools/experiments/front_ablate.sh "-DTGS_ABLATE=64".)  A wave of k_front_stream takes groups wave, wave +
  * nwaves, ..., so every list is an even sample of the grid whatever the damage looks like; a wave of this kernel takes the
  * lists w = wave, wave + nwaves, ... one entry at a time. */
-#define TG_DEFER_L0(fw) (((fw) + 15u) & ~15u)
 #ifndef TG_FIX_LISTS
 #define TG_FIX_LISTS 4
 #endif
@@ -712,181 +673,6 @@ void k_front_stream_fix(const uint8_t *__restrict__ stream, tg_stream_params prm
 	}
 }
 
-/*
- * k_front_stream: the stream front end on packed bits.
- *
- * The grid slots of a stream are contiguous, so a wave takes GROUPS of four neighbouring slots = 2040 contiguous
- * stream bytes (+ look-ahead), fetched as 16 bytes per lane from a 16-byte aligned base -- the access pattern that
- * reaches the HBM read rate -- and turned into bits at once: two chained v_dot4_u32_u8 (weights 1,2,4,8 / 16..128)
- * make 8 bits of 8 bytes.  The group's 2176-bit string is parked in LDS (272 bytes); everything after works on bits:
- *   - lane (k, i) = (slot of the group, 32-position column) re-aligns its slot: W0..W2 = bits 32 i .. 32 i + 95 of
- *     slot k (two LDS reads, three v_alignbit_b32); W0 also goes back to LDS as the slot-aligned 512-bit window the
- *     gather reads;
- *   - training-sequence search, bit-parallel: t_j = the slot's bit string shifted down by j (one v_alignbit_b32),
- *     match mask of a sequence = AND of t_j over its 1-bits AND NOT (OR of t_j over its 0-bits); y (38 bits), n
- *     and p (22 bits) share the t_j: ~100 vector instructions give the exact match masks of all three sequences at
- *     all 4 x 512 positions (the per-position form needs ~8 per 64 positions and pattern);
- *   - ballots of the (masked) match words + s_ff1 / v_readlane give, per slot, tetra_find_train_seq()'s answer
- *     restricted to positions 21..472 (every window holds the slot's own 510 bytes, so a match that ends inside the
- *     slot is valid whatever the window), the "hit below 21" flag and the SYNC summary of the slot;
- *   - the de-interleaving gather reads single bytes of the 64-byte window (16 dwords in 16 banks: conflict-free,
- *     the byte form had 2-3 way conflicts), isolates its bit with a per-lane mask and ballots as before.
- * Anything this cannot settle exactly -- nothing found up to position 472, a byte other than 0 / 1 in the group, the
- * last groups of the stream -- is marked TG_CLS_DEFER and redone by k_front_stream_fix with the per-position form.
- */
-static constexpr uint8_t TSQ_N[22] = { 1,1,0,1,0,0,0,0,1,1,1,0,1,0,0,1,1,1,0,1,0,0 };
-static constexpr uint8_t TSQ_P[22] = { 0,1,1,1,1,0,1,0,0,1,0,0,0,0,1,1,0,1,1,1,1,0 };
-static constexpr uint8_t TSQ_Y[38] = { 1,1,0,0,0,0,0,1,1,0,0,1,1,1,0,0,1,1,1,0,1,0,0,1,1,1,0,0,0,0,0,1,1,0,0,1,1,1 };
-
-template <int N> static constexpr uint64_t tsq_bits(const uint8_t (&seq)[N])
-{
-	uint64_t v = 0;
-	for (int i = 0; i < N; i++)
-		v |= (uint64_t)seq[i] << i;
-	return v;
-}
-
-#define TG_GROUP_SLOTS   4
-#define TG_GROUP_BYTES   (TG_GROUP_SLOTS * TG_SLOT_BITS)	/* 2040 */
-#define TG_GROUP_LOAD    2176					/* bytes fetched per group: 2 x 1024 + 128 */
-#define TG_FAST_LAST_POS (TG_SLOT_BITS - 38)			/* 472: a 38-bit match starting here still ends inside the slot */
-
-__device__ __forceinline__ uint32_t bytes16_to_bits(const uint4 &x)
-{
-	const uint32_t lo = __builtin_amdgcn_udot4(x.y, 0x80402010u, __builtin_amdgcn_udot4(x.x, 0x08040201u, 0u, false), false);
-	const uint32_t hi = __builtin_amdgcn_udot4(x.w, 0x80402010u, __builtin_amdgcn_udot4(x.z, 0x08040201u, 0u, false), false);
-	return lo | (hi << 8);
-}
-
-/*
- * The gather of round 3: a lane owns one BYTE of the packed slot (60 of its 80 bytes carry bits: three per code word,
- * the lead-in bits of the two blocks, four BBK bytes) and collects its eight bits in eight rounds of one LDS byte read
- * and ONE vector instruction.  What makes one instruction enough: the slot's bit window lies in LDS eight times,
- * version s shifted down by s bits, so that window bit p is bit 0 of byte p >> 3 of version p & 7 -- the wanted bit
- * arrives at a fixed position, and v_alignbit_b32 (acc:byte >> 1) shifts it into the accumulator's top while the
- * accumulator moves down: after eight rounds the top byte holds the lane's output byte, round r at bit r.  No masks,
- * no compares, no ballots, no v_writelane: 8 + 1 instructions per slot instead of 41, plus 7 alignbits and 7 LDS
- * stores per GROUP for the shifted copies.  Layout: slot k at k * TG_VER_SLOT dwords (= 16 mod 32: the copies' stores
- * are conflict-free), version s at s * TG_VER_STRIDE dwords inside it (the byte reads' conflicts were counted over the
- * three gather tables for every stride: 57 LDS cycles for the 48 half-wave reads at 24, 69 at 64); dword 16 of version 0
- * stays zero: where "no source" points.
- */
-#define TG_VER_STRIDE 24	/* dwords between the versions of a slot's window */
-#define TG_VER_SLOT   208	/* dwords per slot: 8 versions + pad */
-/* (one asm block per burst type and slot of the group: the slot's offset is the reads' immediate, the eight reads are
- * in flight together and each shift waits for its own byte only; written as asm because hipcc otherwise merges the
- * three burst types' gathers into one tail behind eight register moves / adds per slot.  X only makes the blocks differ.) */
-template <int KOFF, int X>
-__device__ __forceinline__ uint32_t front_gather_bytes(const uint32_t (&a)[8])
-{
-	uint32_t acc, t0, t1, t2, t3, t4, t5, t6, t7;
-	asm volatile("; gather %18\n\t"
-		     "ds_read_u8 %1, %9 offset:%17\n\tds_read_u8 %2, %10 offset:%17\n\tds_read_u8 %3, %11 offset:%17\n\t"
-		     "ds_read_u8 %4, %12 offset:%17\n\tds_read_u8 %5, %13 offset:%17\n\tds_read_u8 %6, %14 offset:%17\n\t"
-		     "ds_read_u8 %7, %15 offset:%17\n\tds_read_u8 %8, %16 offset:%17\n\t"
-		     "s_waitcnt lgkmcnt(7)\n\tv_lshlrev_b32 %0, 31, %1\n\t"
-		     "s_waitcnt lgkmcnt(6)\n\tv_alignbit_b32 %0, %2, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(5)\n\tv_alignbit_b32 %0, %3, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(4)\n\tv_alignbit_b32 %0, %4, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(3)\n\tv_alignbit_b32 %0, %5, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(2)\n\tv_alignbit_b32 %0, %6, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(1)\n\tv_alignbit_b32 %0, %7, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(0)\n\tv_alignbit_b32 %0, %8, %0, 1\n\t"
-		     "v_lshrrev_b32 %0, 24, %0"
-		     : "=&v"(acc), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
-		     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "n"(KOFF), "n"(X)
-		     : "memory");
-	return acc;
-}
-
-/* the same in two halves (round 5, TGS_GPIPE): the eight reads of a slot are issued, and taken one slot later -- the next
- * slot's reads are in flight behind them, so a group pays two exposed LDS round trips for its four gathers, not four.
- * LDS answers in order: "my byte i is here" = at most NEWER + 7 - i younger reads outstanding, NEWER = the eight reads of
- * the slot issued in between (every slot issues exactly eight: one the kernel does not decode reads the zero word).  Reads
- * the compiler puts in between only make the waits longer than needed. */
-template <int KOFF, int X>
-__device__ __forceinline__ void front_gather_issue(const uint32_t (&a)[8], uint32_t (&t)[8])
-{
-	asm volatile("; gather issue %16\n\t"
-		     "ds_read_u8 %0, %8 offset:%17\n\tds_read_u8 %1, %9 offset:%17\n\tds_read_u8 %2, %10 offset:%17\n\t"
-		     "ds_read_u8 %3, %11 offset:%17\n\tds_read_u8 %4, %12 offset:%17\n\tds_read_u8 %5, %13 offset:%17\n\t"
-		     "ds_read_u8 %6, %14 offset:%17\n\tds_read_u8 %7, %15 offset:%17"
-		     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
-		     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "n"(X), "n"(KOFF)
-		     : "memory");
-}
-
-template <int NEWER>
-__device__ __forceinline__ uint32_t front_gather_take(uint32_t (&t)[8])
-{
-	uint32_t acc;
-	asm volatile("; gather take\n\t"
-		     "s_waitcnt lgkmcnt(%9)\n\tv_lshlrev_b32 %0, 31, %1\n\t"
-		     "s_waitcnt lgkmcnt(%10)\n\tv_alignbit_b32 %0, %2, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(%11)\n\tv_alignbit_b32 %0, %3, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(%12)\n\tv_alignbit_b32 %0, %4, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(%13)\n\tv_alignbit_b32 %0, %5, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(%14)\n\tv_alignbit_b32 %0, %6, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(%15)\n\tv_alignbit_b32 %0, %7, %0, 1\n\t"
-		     "s_waitcnt lgkmcnt(%16)\n\tv_alignbit_b32 %0, %8, %0, 1\n\t"
-		     "v_lshrrev_b32 %0, 24, %0"
-		     : "=&v"(acc), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])
-		     : "n"(NEWER + 7), "n"(NEWER + 6), "n"(NEWER + 5), "n"(NEWER + 4), "n"(NEWER + 3), "n"(NEWER + 2), "n"(NEWER + 1), "n"(NEWER + 0)
-		     : "memory");
-	return acc;
-}
-
-struct tg_group_data {
-	uint4 a, b, c;	/* bytes 16 l .., 1024 + 16 l .., 2048 + 16 min(l, 7) .. of the group's aligned range */
-	uint32_t a0;	/* the group starts a0 bytes into that range */
-	uint32_t touch;	/* (TGS_TOUCH: one dword per 128-byte line of the group TGS_TOUCH rounds further on -- requested, never used) */
-	bool fast;	/* all four windows of the group lie inside the stream */
-};
-
-#ifndef TGS_SYNC_LDS
-#define TGS_SYNC_LDS 1	/* the SYNC burst's gather addresses wait in LDS, not in registers */
-#endif
-#ifndef TGS_LOAD_NT
-#define TGS_LOAD_NT 0
-#endif
-#ifndef TGS_TOUCH
-#define TGS_TOUCH 0	/* n > 0: every fetch also touches the lines of the group n rounds further on (one dword per 128-byte line) */
-#endif
-#ifndef TGS_GPIPE
-#define TGS_GPIPE 0	/* 1: a slot's gather reads are issued one slot ahead of their use (front_gather_issue / _take) */
-#endif
-#ifndef TGS_DEFER_ATOMIC
-#define TGS_DEFER_ATOMIC 0	/* A/B builds only: 1 = one deferred-slot list per launch, appended to with an atomicAdd (rounds 2-4) */
-#endif
-#ifndef TGS_PLAIN
-#define TGS_PLAIN 1	/* 1: search and outcome verify "one sequence, at its place, nothing else" and hand everything else to the exact pass
-			 * (round 5); 0: the round-3/4 form (first hit, SYNC summary and the rule's inputs for every slot) -- same outputs */
-#endif
-#ifndef TG_STREAM_WPE
-#define TG_STREAM_WPE 5	/* waves per SIMD.  Round 5: five (96 VGPRs allowed, 86 used).  The kernel had sat exactly at the 80 VGPRs of six waves
-			 * since round 3; taking the atomicAdd of the deferred-slot list out (above) let the scheduler reorder across that
-			 * point and the same source needed 91: eleven spills to scratch, reloaded in front of every gather (164 us at six
-			 * waves with spills, 135 at five without, 148 at four; tools/experiments/front_ablate.sh).  Rounds 3-4, with the grid at two
-			 * rounds of resident workgroups (launch_stream_front): 4 -> 161-168 us per 1 M slots, 5 -> 156-161, 6 -> 155-159,
-			 * 8 (64 VGPRs, spills) -> 195-200 */
-#endif
-/* acc & (t0 == p0) & (t1 == p1), sel = 2 p0 + p1 (a constant once the caller's loop is unrolled): one v_bitop3_b32 */
-__device__ __forceinline__ uint32_t tsq_and2(uint32_t acc, uint32_t t0, uint32_t t1, int sel)
-{
-	switch (sel) {
-	case 0: return __builtin_amdgcn_bitop3_b32(acc, t0, t1, 0x10);
-	case 1: return __builtin_amdgcn_bitop3_b32(acc, t0, t1, 0x20);
-	case 2: return __builtin_amdgcn_bitop3_b32(acc, t0, t1, 0x40);
-	default: return __builtin_amdgcn_bitop3_b32(acc, t0, t1, 0x80);
-	}
-}
-
-#ifndef TGS_ABLATE
-#define TGS_ABLATE 0	/* measurement builds only (tools/experiments/front_ablate.sh): 1 no stores, 2 every group from one address, 4 no
-			 * gathers, 8 no search and no classification, 16 no shifted copies, 32 no classification, 64 no atomic for the deferred slots,
-			 * 128 classification kept but the gather always NORM_1's, 256 no classification but the gather's type varies -- the kernel's
-			 * results are wrong with any of them */
-#endif
 #ifdef TGS_TIMING
 /* measurement build: reference-clock ticks (s_memtime, 100 MHz) a wave spends between the marks of a group, summed over
  * all waves; tools/experiments/front_phases.py */
@@ -904,498 +690,8 @@ extern "C" int tgk_front_stream_stamps(unsigned long long *out, int reset)
 #else
 #define TGS_MARK(i) do { } while (0)
 #endif
-#ifndef TG_STREAM_WPB
-#define TG_STREAM_WPB 4	/* waves per workgroup (they share nothing: each has its own staging areas) */
-#endif
-template <bool PACKED>
-__global__ __launch_bounds__(64 * TG_STREAM_WPB) __attribute__((amdgpu_waves_per_eu(TG_STREAM_WPE, TG_STREAM_WPE)))
-void k_front_stream(const uint8_t *__restrict__ stream, tg_stream_params prm,
-		    uint32_t *__restrict__ packed, uint32_t *__restrict__ cls, uint16_t *__restrict__ ysum,
-		    uint32_t *__restrict__ defer)
-{
-	constexpr uint64_t PY = tsq_bits(TSQ_Y), PN = tsq_bits(TSQ_N), PP = tsq_bits(TSQ_P);
-	__shared__ __attribute__((aligned(16))) uint32_t s_bits[TG_STREAM_WPB][72];	/* per wave: the group's bit string (68 dwords used; packed ingest: 72, 16 bytes per lane) */
-	__shared__ uint32_t s_win[TG_STREAM_WPB][4 * TG_VER_SLOT];	/* per wave: four slots x eight shifted copies of the 512-bit window */
-	__shared__ uint32_t s_out[TG_STREAM_WPB][160];	/* per wave: four packed slots on their way out, then their cls / ysum words (+ the idle lanes' dump) */
-	/* per wave: the SYNC burst's eight gather addresses of every lane.  One slot in eight is a SYNC burst: its table waits
-	 * here (two 16-byte reads in front of such a gather) instead of in eight of the 80 VGPRs six waves per SIMD allow */
-	__shared__ __attribute__((aligned(16))) uint32_t s_sadr[TG_STREAM_WPB][TGS_SYNC_LDS ? 64 * 8 : 4];
-
-#ifdef TGS_TIMING
-	unsigned long long tgs_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tgs_last = __builtin_amdgcn_s_memtime();
-#endif
-	TG_TRACE_BEGIN;
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t wave = blockIdx.x * TG_STREAM_WPB + wib;
-	const uint32_t nwaves = gridDim.x * TG_STREAM_WPB;
-	const uint32_t col = lane & 15;			/* 32-position column of the lane's slot */
-	uint32_t *bits = s_bits[wib];
-	uint32_t *win = s_win[wib];
-	uint32_t *mo = s_out[wib];
-
-	/* the lane's byte of the packed slot: lanes 0..53 byte l % 3 of code word l / 3, 54 / 55 the lead-in bits of the two
-	 * blocks (byte 3 of words 0 and 9), 56..59 the BBK word, 60..63 none; per burst type and round the LDS byte that
-	 * carries the wanted bit at its bit 0 */
-	const uint32_t ow = lane < 54 ? lane / 3 : lane == 54 ? 0u : lane == 55 ? (uint32_t)TG_PW_BLK2 : (uint32_t)TG_PW_BBK;
-	const uint32_t ob = lane < 54 ? lane % 3 : lane < 56 ? 3u : lane - 56;
-	const uint32_t obyte = lane < 60 ? 4 * ow + ob : 4 * 88 + (lane - 60);	/* (the idle lanes write behind the staged slots: < 640 with the last slot's offset) */
-	uint32_t g_adr[3][8];
-	/* (the asm block takes LDS addresses as the hardware sees them: the array's offset inside the workgroup's LDS) */
-	const uint32_t ver0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)&s_win[0][0];
-	{
-		/* the lane's 24 table entries = 8 consecutive ushorts of three rows: three 16-byte loads in flight together (one
-		 * load and one wait per entry cost every wave ~24 memory latencies before its first group: 186 -> 174 us) */
-		uint4 row[3];
-#pragma unroll
-		for (int x = 0; x < 3; x++)
-			row[x] = *(const uint4 *)&c_tab.front_src[x][lane < 60 ? ow : 0][lane < 60 ? 8 * ob : 0];
-#pragma unroll
-		for (int x = 0; x < 3; x++) {
-			const uint32_t w4[4] = { row[x].x, row[x].y, row[x].z, row[x].w };
-#pragma unroll
-			for (int r = 0; r < 8; r++) {
-				const uint32_t o = lane < 60 ? (w4[r >> 1] >> (16 * (r & 1))) & 0xffffu : 0xffffu;
-				g_adr[x][r] = ver0 + wib * (4 * TG_VER_SLOT * 4) + (o == 0xffff ? 64u : (o & 7) * (TG_VER_STRIDE * 4) + (o >> 3));
-			}
-		}
-#if TGS_SYNC_LDS
-		*(uint4 *)&s_sadr[wib][8 * lane] = make_uint4(g_adr[2][0], g_adr[2][1], g_adr[2][2], g_adr[2][3]);
-		*(uint4 *)&s_sadr[wib][8 * lane + 4] = make_uint4(g_adr[2][4], g_adr[2][5], g_adr[2][6], g_adr[2][7]);
-#endif
-#pragma unroll
-		for (int x = 0; x < (TGS_SYNC_LDS ? 2 : 3); x++)
-#pragma unroll
-			for (int r = 0; r < 8; r++)
-				asm volatile("" : "+v"(g_adr[x][r]));	/* the whole address in the register: the slot's offset is the immediate */
-	}
-	uint32_t zadr = ver0 + wib * (4 * TG_VER_SLOT * 4) + 64u;	/* the zero word of slot 0's window, as the asm blocks address LDS */
-	asm volatile("" : "+v"(zadr));
-	if (lane < 4)
-		win[lane * TG_VER_SLOT + 16] = 0;	/* "no source" reads this */
-	for (int i = lane; i < 128; i += 64)
-		mo[i] = 0;				/* bytes of the staged slots that nobody owns stay zero */
-	/* which positions of the lane's column count: main search 21..472, "early" 0..20, SYNC summary 0..509 */
-	const uint32_t vmain = (col == 0) ? 0xffe00000u : (col == 14) ? 0x01ffffffu : (col == 15) ? 0u : 0xffffffffu;
-	const uint32_t vearly = (col == 0) ? 0x001fffffu : 0u;
-	const uint32_t vys = (col == 15) ? 0x3fffffffu : 0xffffffffu;
-	const uint32_t pos0 = (lane >> 4) * TG_SLOT_BITS + 32 * col;	/* first bit of the column inside the group */
-#if TGS_PLAIN
-	/* round 5, the "plain slot" form of search and outcome.  What this kernel may settle on its own is a slot that holds
-	 * exactly ONE training sequence, of a downlink type, at its nominal offset (y at 214 = column 6 bit 22, n / p at 244 =
-	 * column 7 bit 20) -- 99 % of a recording.  So it only has to VERIFY that: the expected hit is there, and nothing else
-	 * is: no n / p at any other position 0..472, no y anywhere in the slot.  "No y" is checked on y's first 22 bits (a
-	 * necessary condition: the three sequences then share 21 shifted copies of the string instead of 37) and the one
-	 * expected y is confirmed on its last 16.  Every other slot -- a damaged or misplaced sequence, a second hit, a payload
-	 * coincidence (3e-4 of the slots), anything below offset 21 -- goes to k_front_stream_fix, which evaluates
-	 * tetra_find_train_seq()'s rule position by position as before.  The words this kernel does write are the exact
-	 * pass's words for the same slot (test_stream_front_packed_bits_equals_per_position). */
-	const uint32_t m_enp = (col == 7) ? (1u << 20) : 0u;			/* the expected n / p hit */
-	const uint32_t m_ey = (col == 6) ? (1u << 22) : 0u;			/* the expected y hit */
-	const uint32_t c_np = (vmain | vearly) & ~m_enp;			/* n / p hits that are not the expected one */
-	const uint32_t c_y = vys & ~m_ey;					/* y (prefix) hits that are not the expected one */
-#endif
-
-	const uint32_t ngroups = (prm.nslots + 3) >> 2;
-	if (wave >= ngroups) {
-		if (lane == 0)
-			defer[wave] = 0;
-		return;
-	}
-	/* this wave's list of slots for the exact pass (k_front_stream_fix) and how many are on it */
-	/* (wave-uniform, and kept in scalar registers by hand: the kernel sits at the 80 VGPRs that six waves per SIMD allow) */
-	uint32_t dpos = __builtin_amdgcn_readfirstlane(TG_DEFER_L0(nwaves) + wave * (4u * ((ngroups + nwaves - 1) / nwaves)));
-	const uint32_t dpos0 = dpos;
-
-	/* request a group: 16 bytes per lane from the 16-byte aligned address below the group's first byte.  Groups the
-	 * fast path may not touch (their windows or the exact form's 640-byte views reach past the stream) fetch group 0
-	 * instead, so that every step issues the same loads */
-	/* multi-channel batches: the channel a wave is in changes a handful of times over its groups, so its table entry
-	 * is kept in scalar registers and looked up again only when a group falls outside [cg0, cg1) */
-	uint32_t cg0 = 1, cg1 = 0, cncls = 0;
-	uint64_t cfirst = 0, cspan = 0;		/* stream offset of the channel's grid slot 0; bytes from there to its end */
-	auto fetch = [&](uint32_t g, tg_group_data &d) {
-		uint64_t gb, first;
-		if (prm.nchan) {
-			const uint32_t s0 = 4u * g;
-			if (s0 < cg0 || s0 >= cg1) {
-				/* (readfirstlane: the values are wave-uniform and must live in scalar registers, so that the wait
-				 * for these loads stays inside this rarely taken branch and does not drain the prefetch) */
-				const uint32_t c = chan_of_slot(prm.chan, prm.nchan, s0, lane);
-				const tg_chan_ent e = prm.chan[c];
-				const uint32_t nxt = c + 1 < prm.nchan ? prm.chan[c + 1].gbase : prm.nslots;
-				cg0 = __builtin_amdgcn_readfirstlane(e.gbase);
-				cg1 = __builtin_amdgcn_readfirstlane(nxt);
-				cncls = __builtin_amdgcn_readfirstlane(e.ncls);
-				const uint64_t f = (e.d_off & ~TG_CHAN_PACKED) + e.anchor, sp = e.len - e.anchor;
-				cfirst = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)f) |
-					 ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(f >> 32)) << 32);
-				cspan = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)sp) |
-					((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32)) << 32);
-			}
-			const uint32_t i0 = s0 - cg0;
-			first = cfirst;
-			gb = first + (uint64_t)i0 * TG_SLOT_BITS;
-			d.fast = i0 + 4u <= cncls && (uint64_t)i0 * TG_SLOT_BITS + TG_GROUP_BYTES + TG_VIEW_OF(prm.chunk) <= cspan;
-		} else {
-			first = prm.anchor;
-			gb = prm.anchor + (uint64_t)g * TG_GROUP_BYTES;
-			d.fast = gb + TG_GROUP_BYTES + TG_VIEW_OF(prm.chunk) <= prm.len;
-		}
-		if (PACKED) {
-			/* packed ingest: the stream lies in memory one bit per position, so a group is 255 bytes: eighteen lanes
-			 * fetch 16 bytes each from the aligned address below its first bit, a0 = how many bits in the group starts */
-			const uint64_t gbit = d.fast ? gb : first;
-			const uint8_t *p = stream + (gbit >> 3);
-			const uint32_t ab = (uint32_t)((uintptr_t)p & 15);
-			d.a0 = 8 * ab + (uint32_t)(gbit & 7);
-			d.a = *(const uint4 *)(p - ab + 16 * (lane < 18 ? lane : 17));
-			d.b = d.c = make_uint4(0, 0, 0, 0);	/* (unused here; left unset they keep the whole struct in scratch memory) */
-			return;
-		}
-#if TGS_ABLATE & 2
-		const uint8_t *p = stream + first + 2040u * (wave & 1023u);
-#else
-		const uint8_t *p = stream + (d.fast ? gb : first);
-#endif
-		d.a0 = (uint32_t)((uintptr_t)p & 15);
-		const uint8_t *base16 = p - d.a0;
-#if TGS_TOUCH
-		{	/* pull the lines of the group this wave takes TGS_TOUCH rounds after the one being fetched towards the L2 (a cold capture:
-			 * DRAM page misses, translations), one dword per line, as long as that group lies in the same channel's bytes */
-			const uint64_t adv = (uint64_t)TGS_TOUCH * nwaves * TG_GROUP_BYTES;
-			const bool ahead = d.fast && (prm.nchan ? (gb - first) + adv + TG_GROUP_LOAD + 256 <= cspan : gb + adv + TG_GROUP_LOAD + 256 <= prm.len);
-			d.touch = 0;
-			if (ahead && lane < 18)
-				d.touch = *(const volatile uint32_t *)(base16 + adv + 128 * lane);
-		}
-#endif
-#if TGS_LOAD_NT	/* (A/B: the capture is read once -- non-temporal loads) */
-		typedef uint32_t tgs_u4v __attribute__((ext_vector_type(4)));
-		{
-			const tgs_u4v va = __builtin_nontemporal_load((const tgs_u4v *)(base16 + 16 * lane));
-			const tgs_u4v vb = __builtin_nontemporal_load((const tgs_u4v *)(base16 + 1024 + 16 * lane));
-			const tgs_u4v vc = __builtin_nontemporal_load((const tgs_u4v *)(base16 + 2048 + 16 * (lane < 7 ? lane : 7)));
-			d.a = make_uint4(va.x, va.y, va.z, va.w);
-			d.b = make_uint4(vb.x, vb.y, vb.z, vb.w);
-			d.c = make_uint4(vc.x, vc.y, vc.z, vc.w);
-		}
-#else
-		d.a = *(const uint4 *)(base16 + 16 * lane);
-		d.b = *(const uint4 *)(base16 + 1024 + 16 * lane);
-		d.c = *(const uint4 *)(base16 + 2048 + 16 * (lane < 7 ? lane : 7));
-#endif
-	};
-
-	auto work = [&](uint32_t g, const tg_group_data &cur) {
-#if TGS_TOUCH
-		asm volatile("" :: "v"(cur.touch));	/* (the touch load's register stays its own until the group's own bytes are here) */
-#endif
-		TGS_MARK(0);	/* since the last mark: the next group's fetch issued */
-		/* bytes other than 0 / 1 anywhere in the group: not for this kernel */
-		bool defer_all;
-		if (PACKED) {
-			defer_all = !cur.fast;
-			TGS_MARK(1);
-			if (lane < 18)		/* the bits are the bit string: 288 bytes, as they came */
-				((uint4 *)bits)[lane] = cur.a;
-		} else {
-			const uint32_t orall = cur.a.x | cur.a.y | cur.a.z | cur.a.w | cur.b.x | cur.b.y | cur.b.z | cur.b.w |
-					       cur.c.x | cur.c.y | cur.c.z | cur.c.w;
-			defer_all = !cur.fast || __ballot((orall & 0xfefefefeu) != 0) != 0;
-
-			TGS_MARK(1);	/* the group's bytes are here */
-			/* bytes -> bits -> LDS */
-			tg_u16_alias *b16 = (tg_u16_alias *)bits;
-			b16[lane] = (uint16_t)bytes16_to_bits(cur.a);
-			b16[64 + lane] = (uint16_t)bytes16_to_bits(cur.b);
-			if (lane < 8)
-				b16[128 + lane] = (uint16_t)bytes16_to_bits(cur.c);
-		}
-		/* the lane's column of its slot: 96 bits from position pos0 + a0 of the string */
-		uint32_t W0, W1, W2;
-		{
-			const uint32_t p = pos0 + cur.a0;
-			const uint32_t *q = bits + (p >> 5);
-			const uint32_t D0 = q[0], D1 = q[1], D2 = q[2], D3 = q[3];
-			W0 = __builtin_amdgcn_alignbit(D1, D0, p);
-			W1 = __builtin_amdgcn_alignbit(D2, D1, p);
-			W2 = __builtin_amdgcn_alignbit(D3, D2, p);
-		}
-		TGS_MARK(2);	/* bits through LDS, the lane's column */
-		{
-			uint32_t *v = win + (lane >> 4) * TG_VER_SLOT + col;
-			v[0] = W0;
-#pragma unroll
-			for (int sft = 1; sft < ((TGS_ABLATE & 16) ? 1 : 8); sft++)
-				v[sft * TG_VER_STRIDE] = __builtin_amdgcn_alignbit(W1, W0, sft);
-		}
-
-		/* match masks of the three sequences at the column's 32 positions */
-		/* one accumulator per sequence, two positions per step: acc & (t_j == p_j) & (t_j+1 == p_j+1) is one
-		 * three-input logic instruction (v_bitop3_b32) whatever the two pattern bits are */
-#if TGS_PLAIN
-		uint32_t my = 0xffffffffu, mn = 0xffffffffu, mp = 0xffffffffu;	/* (my: the first 22 bits of y only) */
-#pragma unroll
-		for (int j = 0; j < 22; j += 2) {
-			const uint32_t t0 = (j == 0) ? W0 : __builtin_amdgcn_alignbit(W1, W0, j);
-			const int k = j + 1;
-			const uint32_t t1 = __builtin_amdgcn_alignbit(W1, W0, k);
-#define TSQ_STEP(acc, P) acc = tsq_and2(acc, t0, t1, 2 * (int)(((P) >> j) & 1) + (int)(((P) >> k) & 1))
-			TSQ_STEP(my, PY);
-			TSQ_STEP(mn, PN);
-			TSQ_STEP(mp, PP);
-#undef TSQ_STEP
-		}
-		const uint32_t any = my | mn | mp;
-		(void)W2;
-#else
-		uint32_t my = vys, mn = 0xffffffffu, mp = 0xffffffffu;
-#pragma unroll
-		for (int j = 0; j < ((TGS_ABLATE & 8) ? 2 : 38); j += 2) {
-			const uint32_t t0 = (j == 0) ? W0 : (j < 32) ? __builtin_amdgcn_alignbit(W1, W0, j)
-					  : (j == 32) ? W1 : __builtin_amdgcn_alignbit(W2, W1, j - 32);
-			const int k = j + 1;
-			const uint32_t t1 = (k < 32) ? __builtin_amdgcn_alignbit(W1, W0, k)
-					  : (k == 32) ? W1 : __builtin_amdgcn_alignbit(W2, W1, k - 32);
-			/* truth table index = acc << 2 | t0 << 1 | t1: the one entry with acc = 1, t0 = p_j, t1 = p_k */
-#define TSQ_STEP(acc, P) acc = tsq_and2(acc, t0, t1, 2 * (int)(((P) >> j) & 1) + (int)(((P) >> k) & 1))
-			TSQ_STEP(my, PY);
-			if (j < 22) {
-				TSQ_STEP(mn, PN);
-				TSQ_STEP(mp, PP);
-			}
-#undef TSQ_STEP
-		}
-		const uint32_t any = my | mn | mp;
-
-#endif
-		TGS_MARK(3);	/* shifted copies stored, match masks, ballots */
-#if !(TGS_ABLATE & (8 | 32 | 256))
-		/* per slot (= 16-lane row): the first hit and the SYNC summary by reductions inside the row -- every lane makes a
-		 * key of its own first hit ((position << 2 | type) in the high half, first y position in the low half: one
-		 * v_pk_min_u16 reduces both) and a count word (hit below 21 in the high half, number of y hits in the low), four
-		 * rotate-and-combine steps (DPP row_ror 8 4 2 1) leave the row's result in all of its lanes.  Vector
-		 * instructions only: the form with ballots, per-lane shifts of them and the LDS crossbar cost 24 us per 1 M
-		 * slots in round trips between the vector unit, scalar registers and LDS (TGS_ABLATE), this one */
-#if TGS_PLAIN
-		/* per lane: "something that is not the expected hit" (bit 23) and the expected hits it holds (y 22, n 21, p 20); OR over
-		 * the slot's 16-lane row in four DPP steps; the row's four bits decide: exactly one expected hit and nothing else,
-		 * or the slot is the exact pass's */
-		(void)any;
-		uint32_t rest = __builtin_amdgcn_bitop3_b32(mn, mp, c_np, 0xa8);		/* (mn | mp) & c_np */
-		rest = __builtin_amdgcn_bitop3_b32(my, c_y, rest, 0xea);			/* (my & c_y) | rest */
-		/* y's last 16 bits behind the expected prefix hit: positions 236..251 = bits 12..27 of column 6's second word */
-		const bool ytail = ((W1 >> 12) & 0xffffu) == (uint32_t)((PY >> 22) & 0xffffu);
-		uint32_t ex = ((mn & m_enp) << 1) | (mp & m_enp);
-		ex = (my & (ytail ? m_ey : 0u)) | ex;
-		uint32_t rowc = ((rest != 0u ? 1u : 0u) << 23) | ex;
-#define ROW_STEP(CTRL) rowc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rowc, (CTRL), 0xf, 0xf, true);
-		ROW_STEP(0x128)	/* row_ror:8 */
-		ROW_STEP(0x124)
-		ROW_STEP(0x122)
-		ROW_STEP(0x121)
-#undef ROW_STEP
-		/* 0b0001 p alone -> NORM_2, 0b0010 n alone -> NORM_1, 0b0100 y alone -> SYNC; anything else: not this kernel's slot */
-		const uint32_t kk = rowc >> 20;
-		const uint32_t rc = (0xfff3f01fu >> (4u * (kk < 8u ? kk : 7u))) & 0xfu;
-		const bool dfr = defer_all || rc == 0xfu;
-		const uint32_t offs = rc == TG_BURST_SYNC ? (uint32_t)TG_SYNC_TRAIN_OFF : (uint32_t)TG_NORM_TRAIN_OFF;
-		const uint32_t dtype = dfr ? (uint32_t)TG_BURST_NONE : rc;
-		uint32_t ys = rc == TG_BURST_SYNC ? (uint32_t)TG_SYNC_TRAIN_OFF : (uint32_t)TG_YS_NONE;
-#else
-		typedef unsigned short cls_us2 __attribute__((ext_vector_type(2)));
-		const uint32_t hm = any & vmain;
-		const uint32_t hb = (uint32_t)__builtin_ctz(hm | 0x80000000u);
-		const uint32_t ht = ((my >> hb) & 1) ? (uint32_t)TG_BURST_SYNC : ((mn >> hb) & 1) ? (uint32_t)TG_BURST_NORM_1 : (uint32_t)TG_BURST_NORM_2;
-		const uint32_t hkey = hm ? (((32u * col + hb) << 2) | ht) : 0xffffu;
-		const uint32_t ykey = my ? (32u * col + (uint32_t)__builtin_ctz(my | 0x80000000u)) : 0xffffu;
-		uint32_t rmin = (hkey << 16) | ykey;
-		uint32_t rsum = (((any & vearly) != 0) ? 0x10000u : 0u) + (uint32_t)__builtin_popcount(my);	/* (<= 510 y hits: the halves do not meet) */
-#define ROW_STEP(CTRL)													\
-		{													\
-			const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rmin, (CTRL), 0xf, 0xf, true);	\
-			const uint32_t u_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rsum, (CTRL), 0xf, 0xf, true);	\
-			const cls_us2 m_ = __builtin_elementwise_min(__builtin_bit_cast(cls_us2, rmin), __builtin_bit_cast(cls_us2, t_));	\
-			rmin = __builtin_bit_cast(uint32_t, m_);							\
-			rsum += u_;											\
-		}
-		ROW_STEP(0x128)	/* row_ror:8 */
-		ROW_STEP(0x124)
-		ROW_STEP(0x122)
-		ROW_STEP(0x121)
-#undef ROW_STEP
-		const uint32_t k16 = rmin >> 16, yfirst = rmin & 0xffffu, ycnt = rsum & 0xffffu;
-		const uint32_t offs = k16 >> 2, rc = k16 & 3u;
-		uint32_t ys = ycnt ? (yfirst | (ycnt > 1 ? (uint32_t)TG_YS_MULTI : 0u)) : (uint32_t)TG_YS_NONE;
-		/* a sequence below offset 21 is accepted or not by the reference's skewed look-ahead window: the exact pass
-		 * evaluates that rule (rare: a payload coincidence, about ten slots in a million) */
-		const bool dfr = defer_all || k16 == 0xffffu || (rsum >> 16) != 0;
-		uint32_t dtype = TG_BURST_NONE;
-		if (rc == TG_BURST_SYNC ? offs == TG_SYNC_TRAIN_OFF : offs == TG_NORM_TRAIN_OFF)
-			dtype = rc;
-		if (dfr)
-			dtype = TG_BURST_NONE;
-#endif
-#define CLS_OWNER      ((lane & 15u) == 0u)	/* the lane that writes the slot's words */
-#define CLS_SLOT       (lane >> 4)
-#define CLS_LANE_OF(K) (16 * (K))
-#endif
-#if TGS_ABLATE & (8 | 32 | 256)
-#define CLS_OWNER      (lane < 4u)
-#define CLS_SLOT       lane
-#define CLS_LANE_OF(K) (K)
-		/* (measurement builds: every slot "a NORM_1 burst at its place", whatever the search said) */
-		const bool dfr = false;
-		const uint32_t dtype = TG_BURST_NORM_1;
-		const uint32_t clsword = TG_BURST_NORM_1 | (TG_NORM_TRAIN_OFF << 8);
-		const uint32_t meta = (dtype | (TG_NORM_TRAIN_OFF << 16)) ^ ((TGS_ABLATE & (32 | 256)) ? (any & 1u) : 0u);
-		uint32_t ys = TG_YS_NONE;
-#else
-		const uint32_t clsword = dfr ? TG_CLS_DEFER : (rc | (offs << 8));
-		const uint32_t meta = dfr ? 0u : (dtype | (offs << 16));
-#endif
-
-		const uint32_t first = 4u * g;
-		const uint32_t cnt = (prm.nslots - first < 4u) ? prm.nslots - first : 4u;
-#define STREAM_SLOT_K(K)												\
-		{													\
-			const uint32_t dt = (TGS_ABLATE & 128) ? (uint32_t)TG_BURST_NORM_1 :					\
-					    (TGS_ABLATE & 256) ? (((g + (K)) & 1) ? (uint32_t)TG_BURST_NORM_1 : (uint32_t)TG_BURST_NORM_2) : \
-					    (uint32_t)__builtin_amdgcn_readlane(dtype, CLS_LANE_OF(K));		\
-			uint32_t mybyte = 0;										\
-			if (TGS_ABLATE & 4)											\
-				mybyte = dt;											\
-			else if (dt == TG_BURST_NORM_1)									\
-				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 0>(g_adr[0]);			\
-			else if (dt == TG_BURST_NORM_2)									\
-				mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 1>(g_adr[1]);			\
-			else if (dt == TG_BURST_SYNC) {									\
-				if (TGS_SYNC_LDS) {										\
-					const uint4 a0_ = *(const uint4 *)&s_sadr[wib][8 * lane], a1_ = *(const uint4 *)&s_sadr[wib][8 * lane + 4];	\
-					const uint32_t sa_[8] = { a0_.x, a0_.y, a0_.z, a0_.w, a1_.x, a1_.y, a1_.z, a1_.w };	\
-					mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 2>(sa_);			\
-				} else												\
-					mybyte = front_gather_bytes<4 * TG_VER_SLOT * (K), 2>(g_adr[2]);		\
-			}													\
-			((uint8_t *)mo)[(K) * TG_PACKED_WORDS * 4 + obyte] = (uint8_t)mybyte;				\
-		}
-		TGS_MARK(4);	/* classification of the four slots */
-#if TGS_GPIPE && !TGS_ABLATE
-#define GP_ISSUE(K, T)													\
-		{													\
-			const uint32_t dt = (uint32_t)__builtin_amdgcn_readlane(dtype, CLS_LANE_OF(K));		\
-			if (dt == TG_BURST_NORM_1)										\
-				front_gather_issue<4 * TG_VER_SLOT * (K), 0>(g_adr[0], T);				\
-			else if (dt == TG_BURST_NORM_2)									\
-				front_gather_issue<4 * TG_VER_SLOT * (K), 1>(g_adr[1], T);				\
-			else if (dt == TG_BURST_SYNC)									\
-				front_gather_issue<4 * TG_VER_SLOT * (K), 2>(g_adr[2], T);				\
-			else		/* not this kernel's slot: eight reads of the zero word (the waits count on eight) */	\
-				front_gather_issue<0, 3>(g_zero, T);							\
-		}
-#define GP_TAKE(K, T, NEWER) ((uint8_t *)mo)[(K) * TG_PACKED_WORDS * 4 + obyte] = (uint8_t)front_gather_take<NEWER>(T);
-		{
-			uint32_t tA[8], tB[8];
-			const uint32_t g_zero[8] = { zadr, zadr, zadr, zadr, zadr, zadr, zadr, zadr };
-			GP_ISSUE(0, tA)
-			GP_ISSUE(1, tB)
-			GP_TAKE(0, tA, 8)
-			GP_ISSUE(2, tA)
-			GP_TAKE(1, tB, 8)
-			GP_ISSUE(3, tB)
-			GP_TAKE(2, tA, 8)
-			GP_TAKE(3, tB, 0)
-		}
-#undef GP_ISSUE
-#undef GP_TAKE
-#else
-		STREAM_SLOT_K(0)
-		STREAM_SLOT_K(1)
-		STREAM_SLOT_K(2)
-		STREAM_SLOT_K(3)
-#endif
-#undef STREAM_SLOT_K
-		TGS_MARK(5);	/* the four gathers */
-		if (CLS_OWNER) {
-			mo[CLS_SLOT * TG_PACKED_WORDS + TG_PW_META] = meta;
-			mo[80 + CLS_SLOT] = clsword;
-			mo[84 + CLS_SLOT] = ys;
-		}
-		{	/* slots this pass could not settle: onto this wave's list for k_front_stream_fix */
-#if TGS_SB & 1
-			__builtin_amdgcn_sched_barrier(0);
-#endif
-#if TGS_SB & 2
-			asm volatile("" ::: "memory");
-#endif
-			const bool mine = CLS_OWNER && CLS_SLOT < cnt && dfr;
-			const unsigned long long dm = __ballot(mine);
-			if (dm) {
-#if TGS_DEFER_ATOMIC
-				uint32_t pos = 0;
-				if (lane == 0)
-					pos = atomicAdd(defer + TG_DEFER_L0(nwaves) + (size_t)nwaves * capw, (uint32_t)__builtin_popcountll(dm));
-				pos = __builtin_amdgcn_readfirstlane(pos);
-				if (mine)
-					defer[TG_DEFER_L0(nwaves) + pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] = first + CLS_SLOT;
-#else
-				if (mine)
-					defer[dpos + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] = first + CLS_SLOT;
-				if (!(TGS_ABLATE & 64))
-					dpos = __builtin_amdgcn_readfirstlane(dpos + (uint32_t)__builtin_popcountll(dm));
-#endif
-			}
-		}
-#undef CLS_OWNER
-#undef CLS_SLOT
-#undef CLS_LANE_OF
-		if (!(TGS_ABLATE & 1) || prm.nslots == 0xffffffffu)
-			front_flush(mo, lane, first, cnt, packed);
-		if (lane < cnt && (!(TGS_ABLATE & 1) || prm.nslots == 0xffffffffu)) {
-			cls[first + lane] = mo[80 + lane];
-			if (ysum)
-				ysum[first + lane] = (uint16_t)mo[84 + lane];
-		}
-		TGS_MARK(6);	/* staged stores */
-	};
-
-	/* two register sets with fixed roles: the next group is requested before this one is worked on, no copies */
-	tg_group_data dA, dB;
-	uint32_t g = wave;
-#if TGS_SB & 4
-#define TGS_FENCE __builtin_amdgcn_sched_barrier(0)
-#else
-#define TGS_FENCE do { } while (0)
-#endif
-	fetch(g, dA);
-	for (;;) {
-		const uint32_t gB = g + nwaves;
-		TGS_FENCE;
-		fetch(gB < ngroups ? gB : g, dB);
-		TGS_FENCE;
-		work(g, dA);
-		if (gB >= ngroups)
-			break;
-		const uint32_t gA = gB + nwaves;
-		TGS_FENCE;
-		fetch(gA < ngroups ? gA : gB, dA);
-		TGS_FENCE;
-		work(gB, dB);
-		if (gA >= ngroups)
-			break;
-		g = gA;
-	}
-#undef TGS_FENCE
-	if (lane == 0)
-		defer[wave] = dpos - dpos0;
-	TG_TRACE_END(0u, (TG_STREAM_WPB <= 4 ? 4u / TG_STREAM_WPB : 1u));
-#ifdef TGS_TIMING
-	if (lane == 0)
-		for (int i = 0; i < 8; i++)
-			atomicAdd(&g_tgs_acc[i], tgs_acc[i]);
-#endif
-}
+#define TGS_FUSED 0
+#include "tg_front_stream_body.h"
 
 /* ------------------------------------------------------------------------- */
 /* soft input (BASELINE config 5): float phases -> bits / soft values, soft gather  */
@@ -1735,10 +1031,8 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 		HIPCHK(hipMemsetAsync(d_defer + TG_DEFER_L0(fw_) + (size_t)fw_ * cw_, 0, 4, s));
 	}
 #endif
-	if (tl_front_ev_start) {
-		HIPCHK(hipEventRecord((hipEvent_t)tl_front_ev_start, s));
-		tl_front_ev_start = nullptr;
-	}
+	if (int rc_ = tgk_front_stream_ev_fire(s))
+		return rc_;
 	const dim3 fgrid(blocks * (4 / TG_STREAM_WPB)), fblock(64 * TG_STREAM_WPB);
 	if (packed_input)
 		hipLaunchKernelGGL(k_front_stream<true>, fgrid, fblock, 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
@@ -1746,15 +1040,34 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 		hipLaunchKernelGGL(k_front_stream<false>, fgrid, fblock, 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer);
 	if (ev_mid)
 		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
+	const uint32_t fw = fgrid.x * TG_STREAM_WPB, fgroups = (nslots + 3) / 4, capw = 4u * ((fgroups + fw - 1) / fw);	/* (as k_front_stream computes them) */
+	return tgk_front_stream_fix(d_stream, &prm, d_packed, d_cls, d_ysum, d_defer, fw, capw, s, packed_input);
+}
+
+/* per-kernel timing: the event armed by tgk_front_stream_ev_start() goes onto the stream now (the front-end launch follows) */
+int tgk_front_stream_ev_fire(hipStream_t s)
+{
+	if (tl_front_ev_start) {
+		HIPCHK(hipEventRecord((hipEvent_t)tl_front_ev_start, s));
+		tl_front_ev_start = nullptr;
+	}
+	return 0;
+}
+
+/* the exact pass over the lists a first pass left: fw lists (one per wave of k_front_stream / per task of k_slot) of up to capw slots */
+int tgk_front_stream_fix(const uint8_t *d_stream, const tg_stream_params *prmp, uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum,
+			 uint32_t *d_defer, uint32_t fw, uint32_t capw, hipStream_t s, bool packed_input)
+{
+	const tg_stream_params &prm = *prmp;
+	const uint32_t nslots = prm.nslots;
 	uint32_t fblocks = (nslots / 128 + 3) / 4 + 1;	/* about a wave per deferred slot at 1 % of them */
 	if (fblocks > 256 * 16)
 		fblocks = 256 * 16;
 #if !TGS_DEFER_ATOMIC
-	fblocks = (fgrid.x * TG_STREAM_WPB + TG_FIX_LISTS - 1) / TG_FIX_LISTS;	/* a workgroup per TG_FIX_LISTS lists of the first pass */
+	fblocks = (fw + TG_FIX_LISTS - 1) / TG_FIX_LISTS;	/* a workgroup per TG_FIX_LISTS lists of the first pass */
 	if (!fblocks)
 		fblocks = 1;
 #endif
-	const uint32_t fw = fgrid.x * TG_STREAM_WPB, fgroups = (nslots + 3) / 4, capw = 4u * ((fgroups + fw - 1) / fw);	/* (as k_front_stream computes them) */
 #define FIX_LAUNCH(P, V) hipLaunchKernelGGL((k_front_stream_fix<P, V>), dim3(fblocks), dim3(64 * TG_FIX_WAVES), 0, s, d_stream, prm, d_packed, d_cls, d_ysum, d_defer, fw, capw)
 	const uint32_t view = TG_VIEW_OF(prm.chunk);	/* (the kernel built for this view) */
 	if (packed_input) {
@@ -1764,6 +1077,16 @@ static int launch_stream_front(const uint8_t *d_stream, const tg_stream_params &
 	}
 #undef FIX_LAUNCH
 	return (int)hipGetLastError();
+}
+
+/* the parameter block of a multi-channel launch (tgk_front_stream_multi, tgk_slot_fused) */
+void tgk_stream_params_multi(tg_stream_params *prm, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots, uint32_t chunk)
+{
+	memset(prm, 0, sizeof(*prm));
+	prm->nslots = nslots;
+	prm->chan = d_chan;
+	prm->nchan = nchan;
+	stream_patterns(*prm, chunk);
 }
 
 /* several channels in one grid: d_chan = device copy of nchan (<= 64) tg_chan_ent, nslots = the grid's total size */
@@ -1776,11 +1099,7 @@ extern "C" int tgk_front_stream_multi(const uint8_t *d_base, const struct tg_cha
 	if (!chunk || !nchan || nchan > 64 || (nslots & 31))
 		return -1;
 	tg_stream_params prm;
-	memset(&prm, 0, sizeof(prm));
-	prm.nslots = nslots;
-	prm.chan = d_chan;
-	prm.nchan = nchan;
-	stream_patterns(prm, chunk);
+	tgk_stream_params_multi(&prm, d_chan, nchan, nslots, chunk);
 	return launch_stream_front(d_base, prm, d_packed, d_cls, d_ysum, d_defer, (hipStream_t)stream, ev_mid, packed_input != 0);
 }
 

@@ -14,7 +14,16 @@
  * Reference: lower_mac/tetra_lower_mac.c:143-282 (tp_sap_udata_ind: one block's chain), phy/tetra_burst.c:341-379 (the blocks of a burst).
  */
 #include "tg_dev_vit.h"
+#include "tg_dev_stream.h"
 #include "slot_core.h"
+
+/* the front phase of k_slot: the packed-bit stream front end's own text, in its fused form (tg_front_stream_body.h) */
+#define TGS_FUSED 1
+#ifndef TGS_FUSED_DEPTH
+#define TGS_FUSED_DEPTH 4	/* groups' loads in flight per wave in k_slot's front phase (2: as k_front_stream) */
+#endif
+#define TGS_MARK(i) do { } while (0)
+#include "tg_front_stream_body.h"
 
 #ifndef TG_SLOT_WAVES
 #define TG_SLOT_WAVES 3		/* waves per SIMD the kernel is compiled for: 36 history blocks x 4 dwords = 144 VGPRs of a lane's 168 */
@@ -23,17 +32,35 @@
 /* per-launch flags of the slot kernels (beside TGK_F_*) */
 #define TGS_F_LOOKBACK TGK_F_LOOKBACK	/* SYNC lanes with a good SB1 take a code-table entry and set their okbit (as k_vit<SB1> does) */
 
-struct tg_slot_lds {
+struct tg_slot_tabs {
 	uint16_t crc[TG_CRC_WORDS + 32];			/* the two CRC tables + the 16-dword spread table (tg_bits16) */
 	uint32_t bm[TG_BMD_WORDS];				/* branch-metric entries of the difference form (vit_core.h) */
+};
+#define TG_SLOT_STAGE_WORDS (64 * TG_STAGE_PITCH + 64)		/* the record on its way out: 64 lanes x four dwordx4 at a pitch of 20 dwords + 64 slot numbers */
+
+/* k_slot_t's LDS: tables, and the code words as columns -- word g of lane l at g * 64 + l, descrambled -- whose place the record's
+ * staging area takes after the trellis */
+struct tg_slot_lds {
+	tg_slot_tabs t;
 	union {
-		uint32_t cw[18 * 64];				/* code word g of lane l at g * 64 + l (descrambled) */
-		uint32_t stage[64 * TG_STAGE_PITCH + 64];	/* the record on its way out (after the trellis: the columns are dead) */
+		uint32_t cw[18 * 64];
+		uint32_t stage[TG_SLOT_STAGE_WORDS];
 	} u;
 };
 
+/* k_slot's LDS: tables, the task's sixteen groups of packed slots as the front phase leaves them (word g of lane l at 20 l + g: the
+ * trellis phase's columns; the staging area afterwards), the front phase's own areas */
+struct tg_kslot_lds {
+	tg_slot_tabs t;
+	union {
+		uint32_t out[1][16 * 80];
+		uint32_t stage[TG_SLOT_STAGE_WORDS];
+	} u;
+	tg_slot_front_lds F;
+};
+
 /* fill the wave's tables (one wave per workgroup) */
-__device__ __forceinline__ void slot_tables(tg_slot_lds &L, uint32_t lane)
+__device__ __forceinline__ void slot_tables(tg_slot_tabs &L, uint32_t lane)
 {
 	for (int i = lane; i < 256; i += 64) {
 		L.crc[i] = c_tab.crc_lsb[i];
@@ -48,11 +75,14 @@ __device__ __forceinline__ void slot_tables(tg_slot_lds &L, uint32_t lane)
 }
 
 /*
- * The trellis side of a wave's 64 slots.  In: the lanes' code words as LDS columns (L.u.cw, descrambled, a SYNC burst's SB1 words
- * at g = 4..8: slot_core.h), the burst type per lane.  Out: od[] (36 decoded bytes), the two CRC words.
+ * The trellis side of a wave's 64 slots.  In: the lanes' code words as LDS columns, descrambled -- word g of this lane at col[g * GS];
+ * colA: the same for g <= 8 (a SYNC burst's SB1 words are read at g = 4..8, slot_core.h: k_slot_t stages them there, colA = col; k_slot
+ * keeps the packed slot's layout and hands a SYNC lane col - 4 * GS) --, the burst type per lane.  Out: od[] (36 decoded bytes), the
+ * two CRC words.
  */
-__device__ __forceinline__ void slot_trellis(tg_slot_lds &L, uint32_t lane, bool two, bool sb, uint32_t (&od)[TG_SLOT_NOD + 1],
-					     uint32_t &crc0, uint32_t &crc1)
+template <int GS>
+__device__ __forceinline__ void slot_trellis(const tg_slot_tabs &L, const uint32_t *col, const uint32_t *colA, bool two, bool sb,
+					     uint32_t (&od)[TG_SLOT_NOD + 1], uint32_t &crc0, uint32_t &crc1)
 {
 	auto bmdo = [&](uint32_t o, uint32_t w[10]) {
 		const uint8_t *q = (const uint8_t *)L.bm + o;
@@ -63,20 +93,22 @@ __device__ __forceinline__ void slot_trellis(tg_slot_lds &L, uint32_t lane, bool
 		w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
 		w[8] = c.x; w[9] = c.y;
 	};
-	const uint32_t *col = L.u.cw + lane;
 	tg_v32 H[5];
 	tg_vit_state v;
 	tg_slot_state_init(v);
 	uint32_t cur = col[0];
 	tg_slot_leadin(v, cur >> 24, bmdo);
+	/* (one block slot per loop iteration, a loop per history chunk of eight: 1.7 KB of code each -- the kernel's waves are NOT in step
+	 * with each other, by design, and what they execute between them should fit the instruction cache) */
+	uint32_t nxt = 0;
 	tg_static_for<5>([&](auto cc) __attribute__((always_inline)) {
 		constexpr int c = decltype(cc)::value;
-		constexpr int it0 = (c == 2) ? 1 : 0;			/* chunk 2's first iteration (code word 8) is written out: block slot 17 */
-		constexpr int nloop = (c == 4) ? 1 : 4;			/* chunk 4: code words 16 and 17, the second one written out (the last block) */
+		constexpr int b0 = (c == 2) ? 2 : 0;			/* chunk 2's first two block slots (code word 8: slots 16, 17) are written out */
+		constexpr int nb = (c == 4) ? 3 : 8;			/* chunk 4: block slots 32..35, the last one written out */
 		if (c == 1)
 			tg_slot_sb_prologue(v, sb, cur, bmdo);		/* in front of code word 4: a SYNC lane starts SB1 */
 		if (c == 2) {
-			const uint32_t nxt = col[9 * 64];
+			nxt = col[9 * GS];
 			uint32_t h[4];
 			tg_slot_block(v, cur, h, bmdo);
 #pragma unroll
@@ -90,26 +122,20 @@ __device__ __forceinline__ void slot_trellis(tg_slot_lds &L, uint32_t lane, bool
 			cur = nxt;
 		}
 #pragma unroll 1
-		for (int it = it0; it < nloop; it++) {
-			const int g = 4 * c + it;
-			const uint32_t nxt = col[(g + 1) * 64];
+		for (int b = b0; b < nb; b++) {
+			const int g = 4 * c + (b >> 1);
 			uint32_t h[4];
-			tg_slot_block(v, cur, h, bmdo);
+			if (!(b & 1) && g < 17)		/* (wave-uniform) */
+				nxt = (c < 2 ? colA : col)[(g + 1) * GS];	/* (c < 2: g + 1 <= 8) */
+			tg_slot_block(v, cur >> (12 * (b & 1)), h, bmdo);
 #pragma unroll
 			for (int d = 0; d < 4; d++)
-				H[c][8 * it + d] = h[d];
-			tg_slot_block(v, cur >> 12, h, bmdo);
-#pragma unroll
-			for (int d = 0; d < 4; d++)
-				H[c][8 * it + 4 + d] = h[d];
-			cur = nxt;
+				H[c][4 * b + d] = h[d];
+			if (b & 1)
+				cur = nxt;
 		}
 		if (c == 4) {
 			uint32_t h[4];
-			tg_slot_block(v, cur, h, bmdo);
-#pragma unroll
-			for (int d = 0; d < 4; d++)
-				H[c][8 + d] = h[d];
 			tg_slot_block_last(v, cur >> 12, h, bmdo);
 #pragma unroll
 			for (int d = 0; d < 4; d++)
@@ -137,7 +163,7 @@ __device__ __forceinline__ void slot_trellis(tg_slot_lds &L, uint32_t lane, bool
  * instruction, non-temporal: records are output only), the wire record, and for SYNC lanes what the code look-back wants.
  * Lanes past the end of the list hold a copy of the last item and store the same bytes again.
  */
-__device__ __forceinline__ void slot_finish(tg_slot_lds &L, uint32_t lane, bool valid, bool two, bool sb, uint32_t slot, uint32_t meta,
+__device__ __forceinline__ void slot_finish(const tg_slot_tabs &L, uint32_t *stage, uint32_t lane, bool valid, bool two, bool sb, uint32_t slot, uint32_t meta,
 					    uint32_t bb, uint32_t code, const uint32_t (&od)[TG_SLOT_NOD + 1], uint32_t crc0, uint32_t crc1,
 					    uint8_t *__restrict__ rec, uint8_t *__restrict__ wire, uint32_t *__restrict__ tbl,
 					    uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_entry, int kflags)
@@ -148,9 +174,9 @@ __device__ __forceinline__ void slot_finish(tg_slot_lds &L, uint32_t lane, bool 
 		tg_slot_sync_fields(od + 2, f0, f1, sbcode);
 	const uint32_t *lut = TG_SP_LUT(L.crc);
 	if (!(kflags & TGK_F_WIREONLY)) {
-		uint32_t *stage = L.u.stage;
 		uint32_t *st_slot = stage + 64 * TG_STAGE_PITCH;
-		st_slot[lane] = slot;
+		st_slot[lane] = valid ? slot : 0xffffffffu;	/* (k_slot_t's lanes past the end of the list come in as copies of the last item, "valid"
+								 * for this purpose: they store the same bytes again; a lane of k_slot that decodes nothing stores nothing) */
 		uint4 *mine = (uint4 *)(stage + lane * TG_STAGE_PITCH);
 		tg_static_for<5>([&](auto cc) __attribute__((always_inline)) {
 			constexpr int c = decltype(cc)::value;
@@ -180,8 +206,11 @@ __device__ __forceinline__ void slot_finish(tg_slot_lds &L, uint32_t lane, bool 
 			for (int i = 0; i < 4; i++) {
 				const uint32_t rr = (lane >> 2) + 16 * i;
 				const uint4 vv = *(const uint4 *)(stage + rr * TG_STAGE_PITCH + 4 * (lane & 3));
-				uint4 *dst = (uint4 *)(rec + (size_t)st_slot[rr] * TG_REC_BYTES + 64 * c + 16 * (lane & 3));
-				TG_REC_STORE_SEG(dst, vv);
+				const uint32_t rs = st_slot[rr];
+				if (rs != 0xffffffffu) {
+					uint4 *dst = (uint4 *)(rec + (size_t)rs * TG_REC_BYTES + 64 * c + 16 * (lane & 3));
+					TG_REC_STORE_SEG(dst, vv);
+				}
 			}
 			__builtin_amdgcn_wave_barrier();
 		});
@@ -266,7 +295,7 @@ void k_slot_t(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_
 			return;
 	}
 	const uint32_t lane = threadIdx.x;
-	slot_tables(L, lane);
+	slot_tables(L.t, lane);
 	uint32_t idx = blockIdx.x * 64 + lane;
 	const bool valid = idx < nitems;
 	if (!valid)
@@ -295,10 +324,120 @@ void k_slot_t(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_
 	const uint32_t code = mk[TG_MW_CODE];
 	__syncthreads();
 	uint32_t od[TG_SLOT_NOD + 1], crc0, crc1;
-	slot_trellis(L, lane, two, sb, od, crc0, crc1);
+	slot_trellis<64>(L.t, L.u.cw + lane, L.u.cw + lane, two, sb, od, crc0, crc1);
 	__syncthreads();		/* (single wave: the columns are dead, the staging area takes their place) */
-	slot_finish(L, lane, valid, two, sb, slot, meta, bb, code, od, crc0, crc1, rec, wire, nullptr, nullptr, nullptr, kflags & ~TGS_F_LOOKBACK);
+	/* (lanes past the end of the list are copies of the last item: they store its bytes again) */
+	slot_finish(L.t, L.u.stage, lane, true, two, sb, slot, meta, bb, code, od, crc0, crc1, rec, valid ? wire : nullptr, nullptr, nullptr, nullptr,
+		    kflags & ~TGS_F_LOOKBACK);
 	TG_TRACE_END(5u, 8u);
+}
+
+/*
+ * k_slot: front end and trellis of a task's 64 neighbouring grid slots in ONE wave (round 6; VERDICT r5 "next" 1).
+ *
+ *   front phase    the packed-bit stream front end as it is (tg_front_stream_body.h, fused form): bytes -> bits, the training-sequence
+ *                  search of every slot, the de-interleaving / de-puncturing gather; packed slots, classification words and SYNC
+ *                  summaries go out to memory as k_front_stream writes them (the exact pass, the walk and the traffic stage read them),
+ *                  and the packed slots STAY in LDS;
+ *   trellis phase  every lane takes the slot it holds -- if the front phase settled it as a plain NORM_1 / NORM_2 / SYNC burst -- through
+ *                  slot_core.h's schedule: no packed-slot read from memory, no item list, no second launch; a wave that waits for
+ *                  its next group's bytes in the front phase shares its SIMD with waves that issue add-compare-selects.
+ *
+ * The trellis phase runs BEFORE the synchroniser's walk and the code look-back, so it decodes on a HINT: the scrambling code the
+ * caller's channel table carries in (or, without one, the code the plan's last batch of that channel ended with) -- hint.code[c], its
+ * mask in entry hint_base + c.  Nothing is taken on trust: a SYNC lane's own SB1 (fixed code) tells the batch's code table what it
+ * decoded, as k_vit<SB1> does; after the walk k_lists2 compares, slot by slot, the code in force (the latest delivered good SB1 at or
+ * before the slot, else the carry-in: lower_mac/tetra_lower_mac.c:179-186, 291-300) with the hint's, and every delivered slot that
+ * was decoded under another code, or not at all (the exact pass's slots), goes through k_slot_t behind it.  A recording has one cell:
+ * after a channel's first batch that list is the handful of delivered slots the exact pass settled.  Records of slots the walk does not
+ * deliver are written all the same (their bits are never read: the delivered bitmap says what counts).
+ * specbits: one bit per grid slot, "decoded here under the hint".
+ */
+struct tg_slot_hints {
+	uint32_t code[64];	/* per channel; 0 = no hint (the channel's slots are left to k_slot_t) */
+};
+
+#ifdef TG_SLOT_TIMING	/* measurement build (tools/experiments/slot_phases.py): per task HW_ID and the 100 MHz clock at start / front phase done /
+			 * trellis done / end -- which waves of a SIMD are in which phase when */
+__device__ unsigned long long g_slot_stamp[5 * 16384];
+extern "C" int tgk_slot_stamps(unsigned long long *out)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slot_stamp), sizeof(g_slot_stamp));
+}
+#define TGSL_STAMP(k) do { if (lane == 0 && task < 16384u) g_slot_stamp[5 * task + (k)] = (k) ? __builtin_amdgcn_s_memtime() : (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)); } while (0)
+#else
+#define TGSL_STAMP(k) do { } while (0)
+#endif
+
+template <bool PACKED>
+__global__ __launch_bounds__(64, TG_SLOT_WAVES)
+void k_slot(const uint8_t *__restrict__ stream, tg_stream_params prm, uint32_t *__restrict__ packed, uint32_t *__restrict__ cls,
+	    uint16_t *__restrict__ ysum, uint32_t *__restrict__ defer, const uint32_t *__restrict__ masks, uint32_t hint_base,
+	    tg_slot_hints hint, uint32_t *__restrict__ specbits, uint8_t *__restrict__ rec, uint8_t *__restrict__ wire,
+	    uint32_t *__restrict__ tbl, uint32_t *__restrict__ sb_ok, uint32_t *__restrict__ sb_entry, int kflags)
+{
+	TG_TRACE_BEGIN;
+	__shared__ __attribute__((aligned(16))) tg_kslot_lds S;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t task = blockIdx.x, ntasks = gridDim.x;
+#ifndef TG_SLOT_STAGGER
+#define TG_SLOT_STAGGER 0
+#endif
+#if TG_SLOT_STAGGER
+	/* (experiment) the first generation of workgroups starts the three waves of a SIMD a third of a task's duration apart, so that
+	 * one wave's front phase -- waiting for memory -- lies beside the others' trellis phases; later workgroups take over a slot when
+	 * it falls free and inherit its phase */
+	if (blockIdx.x < 3072u) {
+		const uint32_t wid = __builtin_amdgcn_s_getreg(4 | (3 << 11)) % 3u;	/* HW_ID bits 0..3: the wave's slot on its SIMD */
+		const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+		while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)wid * TG_SLOT_STAGGER)
+			__builtin_amdgcn_s_sleep(64);
+	}
+#endif
+	TGSL_STAMP(0);
+	TGSL_STAMP(1);
+	slot_tables(S.t, lane);
+	slot_front_phase<PACKED>(stream, prm, packed, cls, ysum, defer, S.F, S.u.out, task, ntasks);
+	__syncthreads();
+	TGSL_STAMP(2);
+	const uint32_t slot = 64u * task + lane;
+	const uint32_t dt = S.F.s_dtype[lane], ch = S.F.s_chan[lane];
+	uint32_t hc = 0;
+#pragma unroll 1
+	for (uint32_t c = 0; c < 64; c++)	/* (the hints are kernel arguments: scalar registers, picked by a wave-uniform loop) */
+		hc = (c == ch) ? hint.code[c] : hc;
+	const bool spec = dt != TG_BURST_NONE && hc != 0u && slot < prm.nslots;
+	const unsigned long long sm = __ballot(spec);
+	if (lane == 0 && 64u * task < prm.nslots)
+		specbits[2 * task] = (uint32_t)sm;
+	if (lane == 32 && 64u * task + 32u < prm.nslots)
+		specbits[2 * task + 1] = (uint32_t)(sm >> 32);
+	if (!sm)
+		return;		/* (wave-uniform: nothing to decode here -- a channel without a hint, a stretch of damaged slots) */
+	const bool sb = dt == TG_BURST_SYNC, two = dt != TG_BURST_NORM_1;
+	uint32_t *col = S.u.out[0] + lane * TG_PACKED_WORDS;
+	const uint32_t *mk = masks + (size_t)(hint_base + ch) * TG_MASK_WORDS;
+	/* descramble in place: NORM_1 its 18 words under the 432-bit mask, a two-block burst words 0..8 and 9..17 under the 216-bit mask
+	 * each, a SYNC burst's SB1 words 0..4 under the fixed code's (what went out to memory is the scrambled slot, as ever) */
+#pragma unroll
+	for (int g = 0; g < 18; g++) {
+		const uint32_t m432 = mk[TG_MW_432 + g], m216 = mk[TG_MW_216 + (g < 9 ? g : g - 9)];
+		uint32_t m = two ? m216 : m432;
+		if (g < 5)
+			m = sb ? c_tab.sb1_mask[g] : m;
+		col[g] ^= m;
+	}
+	const uint32_t bb = col[TG_PW_BBK] ^ mk[TG_MW_BBK];
+	const uint32_t meta = col[TG_PW_META];
+	const uint32_t code = mk[TG_MW_CODE];
+	__syncthreads();
+	uint32_t od[TG_SLOT_NOD + 1], crc0, crc1;
+	slot_trellis<1>(S.t, col, sb ? col - TG_SLOT_SB1_G0 : col, two, sb, od, crc0, crc1);
+	__syncthreads();		/* (single wave: the columns are dead, the staging area takes their place) */
+	TGSL_STAMP(3);
+	slot_finish(S.t, S.u.stage, lane, spec, two, sb, slot, meta, bb, code, od, crc0, crc1, rec, spec ? wire : nullptr, tbl, sb_ok, sb_entry, kflags);
+	TGSL_STAMP(4);
+	TG_TRACE_END(6u, 8u);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -325,4 +464,39 @@ extern "C" int tgk_slot_t(const uint32_t *d_items, uint32_t nitems, const uint32
 	hipLaunchKernelGGL(k_slot_t, dim3((nitems + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_items, nitems, d_nitems, d_packed, d_masks,
 			   d_maskidx, d_rec, d_wire, flags);
 	return (int)hipGetLastError();
+}
+
+/* front end + trellis of a device-walk batch in one launch (k_slot), then the exact pass over what the front phase deferred.  Arguments
+ * as tgk_front_stream_multi takes them, plus: the mask table and the entry of channel 0's hint, the hints (nchan of them; 0 = none), the
+ * "decoded here" bitmap, records / wire records, and the code look-back's table, okbits and per-slot entries (cleared by the caller) */
+extern "C" int tgk_slot_fused(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots, uint32_t chunk,
+			      uint32_t *d_packed, uint32_t *d_cls, uint16_t *d_ysum, uint32_t *d_defer, const uint32_t *d_masks,
+			      uint32_t hint_base, const uint32_t *hints, uint32_t *d_specbits, uint8_t *d_rec, uint8_t *d_wire,
+			      uint32_t *d_tbl, uint32_t *d_sb_ok, uint32_t *d_sb_entry, int flags, void *stream, void *ev_mid, int packed_input)
+{
+	if (!nslots)
+		return 0;
+	if (!chunk || !nchan || nchan > 64 || (nslots & 31) || !hints)
+		return -1;
+	tg_stream_params prm;
+	tgk_stream_params_multi(&prm, d_chan, nchan, nslots, chunk);
+	tg_slot_hints h;
+	memset(&h, 0, sizeof(h));
+	memcpy(h.code, hints, (size_t)nchan * 4);
+	const uint32_t ngroups = (nslots + 3) / 4, ntasks = (ngroups + 15) / 16;
+	hipStream_t s = (hipStream_t)stream;
+	tgk_front_stream_ev_fire(s);
+	if (packed_input)
+		hipLaunchKernelGGL(k_slot<true>, dim3(ntasks), dim3(64), 0, s, d_base, prm, d_packed, d_cls, d_ysum, d_defer, d_masks, hint_base, h,
+				   d_specbits, d_rec, d_wire, d_tbl, d_sb_ok, d_sb_entry, flags);
+	else
+		hipLaunchKernelGGL(k_slot<false>, dim3(ntasks), dim3(64), 0, s, d_base, prm, d_packed, d_cls, d_ysum, d_defer, d_masks, hint_base, h,
+				   d_specbits, d_rec, d_wire, d_tbl, d_sb_ok, d_sb_entry, flags);
+	int rc = (int)hipGetLastError();
+	if (rc)
+		return rc;
+	if (ev_mid)
+		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
+	/* the exact pass: a list per task, as many entries as the task's groups can hold (tg_front_stream_body.h) */
+	return tgk_front_stream_fix(d_base, &prm, d_packed, d_cls, d_ysum, d_defer, ntasks, 4u * ((ngroups + ntasks - 1) / ntasks), s, packed_input);
 }

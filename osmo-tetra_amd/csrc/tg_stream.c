@@ -1372,6 +1372,7 @@ struct tgpu_sync_dev {
 	hipEvent_t done;
 	struct tg_walk_io io;	/* the batch's blocks: one copy up, one copy down */
 	int fellback;
+	int fused;		/* the front end and the trellises of this batch ran as one launch (k_slot) */
 	int cwire;		/* the compact transport form was enqueued behind the decode (tgpu_plan_set_cwire) */
 	uint64_t cwire_bytes;	/* ... its size, known after collect */
 	uint64_t cwire_needed;	/* ... or, when the caller's buffer was too small, the bytes it would have taken */
@@ -1545,20 +1546,29 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 		 * a 16-byte kernel in between waits in the event's place */
 		if (evs && !rc && !io->hd_up0)
 			rc = tgk_copy16(io->d_down0, io->d_down0, 16, sd->stream);
+		/* the batch's arena (counters, code table, okbits: cleared) in front of the front end: a k_slot launch runs the code
+		 * look-back's atomics itself */
+		if (!rc) {
+			tgpi_plan_grid_plain(plan, st->ngrid, &d_plain, &h_plain);
+			tgpi_plan_set_rec(plan, d_rec);
+			rc = tgpi_plan_dev_prepare(plan, st->ngrid, nchan, io->d_codes, &d_bits, stream);
+		}
 		if (evs && !rc)		/* (armed only when the launch it is for follows: the caller destroys the event) */
 			tgk_front_stream_ev_start(evs[0]);
+		/* round 6: front end and trellises in one launch (k_slot) where the channels have a code to decode on -- the caller's carry-in,
+		 * else what the plan's last batch ended with; otherwise (a plan's first batch, TGPU_OPT_SLOT < 2) the front end on its own */
+		int fused = 0;
 		if (!rc)
+			rc = tgpi_plan_dev_front_fused(plan, d_base, io->d_tab, nchan, st->ngrid, chunk, codes, stream, evs ? evs[1] : NULL, packed_input, &fused);
+		sd->fused = fused;
+		if (!rc && !fused)
 			rc = tgk_front_stream_multi(d_base, io->d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
 						    tgpi_plan_defer_scratch(plan), stream, evs ? evs[1] : NULL, packed_input);
 		LT_MARK();
 		EVMARK(2);
-		if (!rc) {
-			/* plain bitmap + SYNC list; SB1 and the masks beside the walk (side stream), or in line when stages are timed */
-			tgpi_plan_grid_plain(plan, st->ngrid, &d_plain, &h_plain);
-			tgpi_plan_set_rec(plan, d_rec);
-			rc = tgpi_plan_dev_stage1(plan, st->ngrid, nchan, io->d_tab, io->d_codes, d_plain, &d_bits, stream, evs != NULL,
+		if (!rc)	/* plain bitmap + SYNC list; SB1 and the masks beside the walk (side stream), or in line when stages are timed */
+			rc = tgpi_plan_dev_stage1(plan, st->ngrid, nchan, io->d_tab, io->d_codes, d_plain, stream, evs != NULL,
 						  evs ? (void **)(evs + 3) : NULL);
-		}
 		/* channels of more than 262 144 slots -- or of fewer, once the plan has seen the LDS form overflow with exceptions
 		 * (tgpi_plan_walk_threshold) --: the same walk with its arrays in global memory, behind the first */
 		struct tg_walk_big big = { 0 };
@@ -1641,6 +1651,11 @@ uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd)
 int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd)
 {
 	return sd ? sd->fellback : 0;
+}
+
+int tgpu_sync_dev_fused(const struct tgpu_sync_dev *sd)
+{
+	return sd ? sd->fused : 0;
 }
 
 /* why the device walk handed channel c over (after collect): 0 = it did not; TGPU_WHY_* otherwise */

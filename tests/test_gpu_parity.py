@@ -1882,6 +1882,111 @@ def _mix_stream(T, n, seed, code_cell=(262, 42, 1), ber=0.02):
     return np.concatenate([rng.integers(0, 2, 100).astype(np.uint8), slots.reshape(-1), np.zeros(700, np.uint8)]), code
 
 
+@pytest.mark.parametrize("ber,per", [(0.0, 3000), (0.03, 9000)])
+def test_front_end_and_trellis_in_one_launch_equal_the_separate_kernels(T, eng, ber, per, topt):
+    """round 6, TGPU_OPT_SLOT 2: k_slot -- a wave packs and classifies 64 neighbouring grid slots, keeps them in LDS and decodes them
+    there, on a HINTED scrambling code (the carry-in, else what the plan's last batch of the channel ended with); after the walk
+    every delivered slot whose code in force differs, or that the exact pass settled, goes through k_slot_t.  Against the same
+    batches with the option at 1 (front end, then k_slot_t on the exact lists): events, bitmaps, counts, final codes, and every
+    byte of every DELIVERED slot's record and wire record -- for a plan's first batch (no hint: not fused), its second (hints from
+    the first), carry-in codes given (fused at once), WRONG hints (another cell's codes: everything is decoded twice), a channel
+    whose cell changes in mid-recording, channels that start inside a wave's 64 slots (grids are padded to 32), 1 % damaged
+    training sequences, payload noise"""
+    import torch
+    hs = torch.cuda.current_stream().cuda_stream
+    cells = [(262, 42, 1), (901, 77, 9), (234, 14, 33), (1, 2, 3), (505, 1, 60)]
+    lens = [per, per // 2 + 37, 96, per, per // 3]          # (96 slots: the next channel starts 32 slots into a wave's task)
+    streams, codes = [], []
+    for c, cell in enumerate(cells):
+        st, code = _mix_stream(T, lens[c], 7000 + c, cell, ber=ber)
+        if c == 3:      # a recording whose cell changes half way: the second half carries another cell's SYNC PDUs and code
+            st2, _ = _mix_stream(T, lens[c], 7100, (208, 10, 5), ber=ber)
+            cut = 100 + 510 * (1 + lens[c] // 2)
+            st = np.concatenate([st[:cut], st2[cut:]])
+        streams.append(st)
+        codes.append(code)
+    offs, o = [], 0
+    for st in streams:
+        offs.append(o)
+        o += (len(st) + T.STREAM_SLACK + 15) & ~15
+    buf = np.zeros(o + 4096, np.uint8)
+    for st, f in zip(streams, offs):
+        buf[f:f + len(st)] = st
+    d = torch.from_numpy(buf).cuda()
+    ntot = sum((len(st) // 510 + 32) for st in streams)
+
+    def batch(plan, carry=None, sts=None):
+        d_rec = torch.zeros(ntot * T.REC_BYTES, dtype=torch.uint8, device="cuda")
+        d_wire = torch.full((ntot * T.WIRE_BYTES,), 0xff, dtype=torch.uint8, device="cuda")
+        plan.set_wire(d_wire.data_ptr())
+        msd = T.MultiSyncDev(eng, plan, sts or streams, d.data_ptr(), offs, d_rec.data_ptr(), 64, hs, codes=carry)
+        fused = msd.fused
+        outs = msd.collect()
+        assert not msd.fellback
+        torch.cuda.synchronize()
+        return (fused, outs, d_rec.cpu().numpy().reshape(-1, T.REC_BYTES), d_wire.cpu().numpy().reshape(-1, T.WIRE_BYTES), plan.final_codes().tolist())
+
+    def same(a, b):
+        assert len(a[1]) == len(b[1])
+        n = 0
+        for c, (x, y) in enumerate(zip(a[1], b[1])):
+            assert x["events"] == y["events"], c
+            for k in ("nslots", "ngrid", "noffgrid", "anchor", "final_state", "burst_seq", "tail_tn_adds", "grid_base"):
+                assert x[k] == y[k], (c, k)
+            assert (np.asarray(x["grid_bits"]) == np.asarray(y["grid_bits"])).all()
+            idx = x["grid_base"] + T.grid_indices(x)
+            assert (a[2][idx] == b[2][idx]).all(), c
+            assert (a[3][idx] == b[3][idx]).all(), c
+            n += len(idx)
+        assert a[4] == b[4]
+        return n
+
+    topt("SLOT", 1)
+    pa = T.Plan(eng, ntot, len(cells))
+    ref0 = batch(pa)                                    # carry-in codes 0
+    ref1 = batch(pa, carry=codes)                       # carry-in codes = the cells'
+    assert not ref0[0] and not ref1[0]
+    pa.close()
+    topt("SLOT", 2)
+    pb = T.Plan(eng, ntot, len(cells))
+    b1 = batch(pb)
+    assert not b1[0]                                    # nothing to decode on yet
+    assert same(ref0, b1) > 0.9 * sum(lens)
+    b2 = batch(pb)
+    assert b2[0]                                        # hints: the codes the first batch ended with
+    same(ref0, b2)
+    b3 = batch(pb, carry=codes)
+    assert b3[0]
+    same(ref1, b3)
+    pb.close()
+    pc = T.Plan(eng, ntot, len(cells))
+    c1 = batch(pc, carry=codes)                         # a plan's first batch with carry-in codes: fused at once
+    assert c1[0]
+    same(ref1, c1)
+    wrong = [codes[(c + 1) % len(codes)] for c in range(len(codes))]
+    c2 = batch(pc, carry=wrong)                         # every channel decoded on another cell's code first
+    refw = None
+    topt("SLOT", 1)
+    pd = T.Plan(eng, ntot, len(cells))
+    refw = batch(pd, carry=wrong)
+    pd.close()
+    assert c2[0] and not refw[0]
+    same(refw, c2)
+    pc.close()
+    # ... and the reference itself against the oracle: every delivered burst of the two-cell channel under the code in force
+    out = ref0[1][3]
+    idx = T.grid_indices(out)
+    r = ref0[2][out["grid_base"] + idx]
+    st = streams[3]
+    slots = st[out["anchor"]:out["anchor"] + 510 * (int(idx[-1]) + 1)].reshape(-1, 510)[idx]
+    p = T.parse_records(r)
+    assert len(set(p["code"].tolist())) == 2            # the two cells' codes (the first delivered burst is a SYNC burst: its own SB1 sets the code)
+    for i in range(0, len(idx), max(1, len(idx) // 400)):
+        ty = p["type"][i:i + 1].astype(np.uint8)
+        ok, want, wcrc = O.bench_decode_slots(slots[i:i + 1], ty, int(p["code"][i]), use_acc=1, want_out=True, want_crc=True)
+        assert (p["bbk"][i] == want[0, :14]).all() and p["crc"][i, 0] == wcrc[0, 0]
+
+
 def test_config3_full_size_stream_against_the_oracle(T, eng):
     """BASELINE config 3 at 100 000 slots through the GPU front end + grid plan: the synchroniser's events == the
     oracle receiver's (every lock loss and re-lock of ~1000 damaged slots), every delivered burst's type-1 bits,
