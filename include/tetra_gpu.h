@@ -168,15 +168,16 @@ enum tgpu_option {
 					 * channel's last flush -- a process that cannot have that sets the option to 0 before creating channels */
 	TGPU_OPT_SLOT,			/* how the plan API's batches run their trellises (round 6; records are the same bytes either way):
 					 * 0: k_vit<216> and k_vit<432>, one lane per BLOCK (rounds 1-5);
-					 * 1: k_slot_t, one lane per SLOT -- one launch over the batch's delivered slots of any type, a SYNC burst's
-					 *    SB1 included, every record written as whole 64-byte segments;
-					 * 2 (default): as 1, and device-walk batches (tgpu_sync_multi_launch) whose channels have a scrambling code to
+					 * 1 (default): k_slot_t, one lane per SLOT -- the batch's NORM_1 / NORM_2 slots, then its SYNC slots (SB1
+					 *    included), both blocks of a burst on one schedule, every record written as whole 64-byte segments;
+					 * 2: as 1, and device-walk batches (tgpu_sync_multi_launch) whose channels have a scrambling code to
 					 *    decode on -- the caller's carry-in code, else the code the plan's last batch of the channel ended with --
 					 *    run the stream front end AND the trellises in one launch (k_slot): a wave packs and classifies 64
 					 *    neighbouring grid slots, keeps them in LDS and decodes them there and then; after the walk and the code
 					 *    look-back every delivered slot whose code in force is not the one it was decoded under (or that the exact
 					 *    pass settled) goes through k_slot_t.  Records of UNDELIVERED grid slots are unspecified in that form (they
-					 *    may hold a decode nobody asked for); tgpu_sync_dev_fused() tells which form a batch took.
+					 *    may hold a decode nobody asked for); tgpu_sync_dev_fused() tells which form a batch took.  Same records
+					 *    for delivered slots; measured slower than 1 on the metric's workload, so not the default.
 					 * (soft input, block mode, the RM(30,14) option, the clean-block fast path and the traffic stage keep the
 					 * earlier forms) */
 	TGPU_OPT__COUNT

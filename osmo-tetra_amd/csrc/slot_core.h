@@ -194,13 +194,14 @@ TG_HD uint32_t tg_slot_crc_nibble(uint32_t crc, uint32_t nib)
 	return crc;
 }
 
-template <typename TabL, typename TabM>
+/* (I0: the first decoded byte to look at -- 8 where every lane holds a SYNC burst: SB1 starts there) */
+template <int I0 = 0, typename TabL, typename TabM>
 TG_HD void tg_slot_crc(const uint32_t (&od)[TG_SLOT_NOD + 1], bool two, bool sb, TabL tl, TabM tm, uint32_t &crc0, uint32_t &crc1)
 {
 	uint32_t crc = 0xffff;
 	crc0 = crc1 = 0;
 #pragma unroll
-	for (int i = 0; i < TG_SLOT_NBLK; i++) {
+	for (int i = I0; i < TG_SLOT_NBLK; i++) {
 		const uint32_t byte = (od[i >> 2] >> ((i & 3) * 8)) & 0xff;
 		if (i == 2 * TG_SLOT_SB1_G0)
 			crc = sb ? 0xffffu : crc;

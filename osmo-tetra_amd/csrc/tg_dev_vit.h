@@ -20,6 +20,7 @@ __device__ __forceinline__ uint32_t field_msb(uint32_t lo, uint32_t hi, int sh, 
 #define FIELD_MSB(od, n0, len) field_msb((od)[(n0) >> 5], (od)[((n0) >> 5) + 1], (n0) & 31, (len))
 
 typedef uint32_t tg_v32 __attribute__((ext_vector_type(32)));
+typedef uint32_t tg_v16 __attribute__((ext_vector_type(16)));
 
 /* f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop over the history chunks that is unrolled by the
  * language, not by a pass with a size threshold (the packed operations of vit_core.h's difference form are inline assembly, which

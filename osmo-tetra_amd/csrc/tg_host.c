@@ -34,7 +34,9 @@ int tgpu_plan_set_fastpath(struct tgpu_plan *p, int on);
  * nothing in this library reads the environment */
 static long tg_options[TGPU_OPT__COUNT] = {
 	[TGPU_OPT_BURST_MAX] = 1024,	/* measured crossover of k_burst and the lane-per-trellis kernels */
-	[TGPU_OPT_SLOT] = 2,		/* round 6: the trellises of a batch by one lane per slot, fused with the stream front end where a channel has a code to decode on (tg_k_slot.hip); 1 = k_slot_t only; 0 = k_vit<216> + k_vit<432> */
+	[TGPU_OPT_SLOT] = 1,		/* round 6: the trellises of a batch by one lane per slot (k_slot_t, tg_k_slot.hip); 0 = k_vit<216> + k_vit<432>; 2 = k_slot as
+					 * well: front end and trellises of a device-walk batch in one launch -- built, bit-exact, and measured SLOWER than
+					 * 1 on the metric's workload (0.45 against 0.39 ms per step: DESIGN.md section 4), hence not the default */
 	[TGPU_OPT_RING] = 1,		/* round 6: on by default -- channels of up to four bursts per flush (the reference's own usage pattern,
 					 * tetra-rx.c:82-95) answer a flush 30-40 % sooner through workgroups that stay; a flush the ring does not
 					 * answer goes by launch, a ring that keeps failing is given up (tg_sync.c: ring_failed) */
@@ -97,8 +99,9 @@ struct tgpu_plan {
 	uint32_t *d_slot_chan;
 	int32_t *d_slot_sbord;
 	uint32_t *d_list_sb, *d_list_216, *d_list_432;
-	uint32_t *d_list_all;	/* the batch's slots of type NORM_1 / NORM_2 / SYNC, once each: the lane-per-slot kernel's items (NULL: not built) */
-	uint32_t nall;
+	uint32_t *d_list_all;	/* the batch's slots of type NORM_1 / NORM_2, once each: the lane-per-slot kernel's items (NULL: not built) */
+	uint32_t *d_list_sync;	/* ... and its SYNC slots: a list of their own (k_slot_t runs a shorter schedule where every lane holds one) */
+	uint32_t nall, nsync;
 	uint32_t *d_packed;
 	uint32_t *d_maskidx;
 	uint32_t *d_idx_stage;	/* static batches: the mask indices as uploaded (copied to d_maskidx by the first execute) */
@@ -259,7 +262,7 @@ int tgpu_plan_create(struct tgpu_engine *eng, uint32_t max_slots, uint32_t max_c
 	p->max_chan = max_chan;
 	const size_t n = max_slots;
 	/* descriptors 8n, chan 4n, sbord 4n, lists <= 8n in total, the slot list 4n, static mask indices 4n, codes, padding */
-	p->up_bytes = 32 * n + 4 * (size_t)max_chan + 20 * UP_ALIGN + 4 * (TGK_LB_TBL + 1);	/* (+ the code table of device-walk batches) */
+	p->up_bytes = 36 * n + 4 * (size_t)max_chan + 24 * UP_ALIGN + 4 * (TGK_LB_TBL + 1);	/* (+ the code table of device-walk batches) */
 	/* small plans (the drop-in channel API at small batch sizes: a flush is a round trip, and every copy in it costs
 	 * more than the bytes): descriptors and lists stay in pinned host memory and the kernels read them in place.
 	 * Consequence for callers: a small plan must be idle (its last execute complete) before the next tgpu_plan_load*()
@@ -364,7 +367,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 #define UP_PLACE(dptr, hptr, type, count) do { dptr = (type *)(p->d_up + o); hptr = (type *)(p->h_up + o); \
 		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
 	uint64_t *h_desc;
-	uint32_t *h_chan, *h_list_sb, *h_list_216, *h_list_432, *h_list_all, *h_code, *h_idx, *d_idx_stage;
+	uint32_t *h_chan, *h_list_sb, *h_list_216, *h_list_432, *h_list_all, *h_list_sync, *h_code, *h_idx, *d_idx_stage;
 	int32_t *h_sbord;
 	UP_PLACE(p->d_slot_off, h_desc, uint64_t, nslots);
 	UP_PLACE(p->d_slot_chan, h_chan, uint32_t, nslots);
@@ -372,7 +375,8 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 	UP_PLACE(p->d_list_sb, h_list_sb, uint32_t, nsb);
 	UP_PLACE(p->d_list_216, h_list_216, uint32_t, n216);
 	UP_PLACE(p->d_list_432, h_list_432, uint32_t, n432);
-	UP_PLACE(p->d_list_all, h_list_all, uint32_t, nsb + n432 + (n216 - nsb) / 2);
+	UP_PLACE(p->d_list_all, h_list_all, uint32_t, n432 + (n216 - nsb) / 2);
+	UP_PLACE(p->d_list_sync, h_list_sync, uint32_t, nsb);
 	UP_PLACE(p->d_chan_code, h_code, uint32_t, nchan);
 	UP_PLACE(d_idx_stage, h_idx, uint32_t, is_static ? nslots : 0);
 #undef UP_PLACE
@@ -382,12 +386,14 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 	/* pass 2: fill the pinned mirror */
 	for (uint32_t c = 0; c < nchan; c++)
 		p->h_last_slot_of_chan[c] = 0xffffffffu;
-	uint32_t isb = 0, i216 = 0, i432 = 0, iall = 0;
+	uint32_t isb = 0, i216 = 0, i432 = 0, iall = 0, isync = 0;
 	for (uint32_t i = 0; i < nslots; i++) {
 		const uint8_t t = SLOT_TYPE(i);
 		const uint32_t ch = SLOT_CHAN(i);
-		if (t == TETRA_TRAIN_SYNC || t == TETRA_TRAIN_NORM_2 || t == TETRA_TRAIN_NORM_1)
+		if (t == TETRA_TRAIN_NORM_2 || t == TETRA_TRAIN_NORM_1)
 			h_list_all[iall++] = i;
+		else if (t == TETRA_TRAIN_SYNC)
+			h_list_sync[isync++] = i;
 		p->h_last_slot_of_chan[ch] = i;
 		/* descriptor = offset | type << 56 (one scalar load per slot in the front kernel) */
 		h_desc[i] = SLOT_OFF(i) | ((uint64_t)t << 56);
@@ -433,6 +439,7 @@ static int plan_load_strided(struct tgpu_plan *p, uint32_t nslots, const uint8_t
 	p->n216 = n216;
 	p->n432 = n432;
 	p->nall = iall;
+	p->nsync = isync;
 	p->loaded = 1;
 	return TGPU_OK;
 }
@@ -530,8 +537,8 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 	UP_AT(d_blk, uint32_t, 3 * (nblk + 1));
 #undef UP_AT
 	p->d_slot_off = NULL;
-	p->d_list_all = NULL;	/* (host-walk grid batches keep the lane-per-block kernels: their lists come from k_grid_lists) */
-	p->nall = 0;
+	p->d_list_all = p->d_list_sync = NULL;	/* (host-walk grid batches keep the lane-per-block kernels: their lists come from k_grid_lists) */
+	p->nall = p->nsync = 0;
 	if (o > p->up_bytes)
 		return TGPU_ECAPACITY;
 	memcpy(p->h_up, codes, (size_t)nchan * 4);
@@ -607,7 +614,7 @@ int tgpi_plan_dev_prepare(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, u
 		o = (o + (size_t)(count) * sizeof(type) + UP_ALIGN - 1) & ~(size_t)(UP_ALIGN - 1); } while (0)
 	uint32_t *d_cnt, *d_tbl, *d_ok, *d_bits, *d_prevw;
 	uint8_t *d_wchan;
-	UP_AT(d_cnt, uint32_t, 4);
+	UP_AT(d_cnt, uint32_t, 8);
 	UP_AT(d_tbl, uint32_t, TGK_LB_TBL + 1);
 	UP_AT(d_ok, uint32_t, nwords);
 	const size_t zero_bytes = o;		/* counters, code table (+ overflow flag), okbits: cleared per batch in one go */
@@ -619,6 +626,7 @@ int tgpi_plan_dev_prepare(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, u
 	UP_AT(p->d_list_216, uint32_t, 2 * (size_t)ngrid);
 	UP_AT(p->d_list_432, uint32_t, ngrid);
 	UP_AT(p->d_list_all, uint32_t, ngrid);
+	UP_AT(p->d_list_sync, uint32_t, ngrid);
 	UP_AT(p->d_specbits, uint32_t, nwords + 2);
 #undef UP_AT
 	p->d_slot_off = NULL;
@@ -738,7 +746,7 @@ int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, u
 	if (evs)
 		HCHK(hipEventRecord((hipEvent_t)evs[0], s));
 	rc = tgk_lists2(p->d_grid, p->d_bits_dev, ngrid, p->d_lb_ok, p->d_lb_prevw, p->d_lb_wchan, (const uint32_t *)p->d_slot_sbord,
-			p->d_maskidx, p->d_list_216, p->d_list_432, p->d_list_all, (uint32_t *)p->d_counts,
+			p->d_maskidx, p->d_list_216, p->d_list_432, p->d_list_all, p->d_list_sync, (uint32_t *)p->d_counts,
 			p->fused ? p->d_specbits : NULL, p->hint_now, p->d_chan_code, p->d_lb_tbl, p->nchan, stream);
 	if (rc)
 		return rc;
@@ -756,6 +764,7 @@ int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, u
 	p->n216 = 2 * ngrid;
 	p->n432 = ngrid;
 	p->nall = ngrid;
+	p->nsync = ngrid;
 	p->loaded = 1;
 	return TGPU_OK;
 }
@@ -1122,7 +1131,7 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	 * k_vit<432> goes to a side stream (fork/join with events, still capturable) so that the tails
 	 * of the two launches overlap */
 	const int fork = (ev == NULL) && !p->no_side && p->n216 && p->n432 && p->nslots > 4096 &&	/* (a small batch gains nothing from the side stream) */
-			 !(tgi_option(TGPU_OPT_SLOT) && !soft && !(p->fastpath && !p->d_counts) && !p->rm_decode && p->d_list_all && p->nall);
+			 !(tgi_option(TGPU_OPT_SLOT) && !soft && !(p->fastpath && !p->d_counts) && !p->rm_decode && p->d_list_all && (p->nall || p->nsync));
 	if (fork) {
 		hipError_t e_ = hipEventRecord(p->ev_fork, (hipStream_t)stream);
 		if (e_ == hipSuccess)
@@ -1156,12 +1165,17 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	}
 	/* round 6: one lane per SLOT (k_slot_t) in place of the two launches -- hard input, slot or device-walk batches (the ones that
 	 * have the slot list), no option that only the lane-per-block kernels implement */
-	const int by_slot = tgi_option(TGPU_OPT_SLOT) && !soft && !fast && !p->rm_decode && p->d_list_all && p->nall;
+	const int by_slot = tgi_option(TGPU_OPT_SLOT) && !soft && !fast && !p->rm_decode && p->d_list_all && (p->nall || p->nsync);
 	if (by_slot) {
-		if ((rc = tgk_slot_t(p->d_list_all, p->nall, p->d_counts ? p->d_counts + 3 : NULL, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
-				     p->d_wire, kf, stream)))
+		/* two launches: the NORM_1 / NORM_2 slots (no SYNC lane: their prologue and selects compiled away), then the SYNC slots (every lane
+		 * one: the schedule starts at block slot 8) */
+		if (p->nall && (rc = tgk_slot_t(1, p->d_list_all, p->nall, p->d_counts ? p->d_counts + 3 : NULL, p->d_packed, p->d_masks, p->d_maskidx,
+						d_rec, p->d_wire, kf, stream)))
 			return rc;
 		MARK(5);
+		if (p->nsync && (rc = tgk_slot_t(2, p->d_list_sync, p->nsync, p->d_counts ? p->d_counts + 4 : NULL, p->d_packed, p->d_masks, p->d_maskidx,
+						 d_rec, p->d_wire, kf, stream)))
+			return rc;
 	} else {
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_216, items216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
@@ -1314,8 +1328,8 @@ int tgpu_plan_load_blocks(struct tgpu_plan *p, uint32_t nblocks, const uint64_t 
 	p->d_list_sb = d_list[TG_KIND_SB1];
 	p->d_list_216 = d_list[TG_KIND_216];
 	p->d_list_432 = d_list[TG_KIND_432];
-	p->d_list_all = NULL;
-	p->nall = 0;
+	p->d_list_all = p->d_list_sync = NULL;
+	p->nall = p->nsync = 0;
 	p->d_list_168 = d_list[TG_KIND_168];
 	p->d_list_bbk = d_list[TGPU_NKINDS];
 	p->nsb = cnt[TG_KIND_SB1];

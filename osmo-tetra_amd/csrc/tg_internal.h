@@ -40,7 +40,7 @@ int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *
 	    const uint32_t *d_nitems /* NULL, or device-side item count with nitems as its upper bound */, void *stream);
 /* one lane per SLOT (tg_k_slot.hip, slot_core.h): d_items = the batch's slots of type NORM_1 / NORM_2 / SYNC, any order; replaces the
  * 216 and 432 launches of tgk_vit for hard input (a SYNC burst's SB1 is decoded again on the way: its lane would idle otherwise) */
-int tgk_slot_t(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_nitems, const uint32_t *d_packed,
+int tgk_slot_t(int sbmode /* 0: items of any type, 1: no SYNC burst among them, 2: SYNC bursts only */, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_nitems, const uint32_t *d_packed,
 	       const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec, uint8_t *d_wire /* or NULL */, int flags, void *stream);
 /* clean-block pre-pass (kinds 216 / 432): finishes the blocks that are code words, lists the others for tgk_vit */
 int tgk_clean(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,
@@ -283,7 +283,7 @@ int tgk_lb_scan(const uint32_t *d_okbits, const uint32_t *d_dbits, const uint8_t
 		const uint32_t *d_slot_entry, const uint32_t *d_masks, const uint32_t *d_tbl, uint32_t *d_final_code, void *stream);
 int tgk_lists2(const uint32_t *d_cls, const uint32_t *d_dbits, uint32_t n, const uint32_t *d_okbits, const uint32_t *d_prevw,
 	       const uint8_t *d_word_chan, const uint32_t *d_slot_entry, uint32_t *d_maskidx, uint32_t *d_list_216,
-	       uint32_t *d_list_432, uint32_t *d_list_all /* or NULL */, uint32_t *d_cnt,
+	       uint32_t *d_list_432, uint32_t *d_list_all /* or NULL */, uint32_t *d_list_sync /* with d_list_all */, uint32_t *d_cnt /* 5 words */,
 	       const uint32_t *d_specbits /* or NULL */, const uint32_t *hints /* host, nchan words */, const uint32_t *d_chan_code,
 	       const uint32_t *d_tbl, uint32_t nchan, void *stream);
 /* compact transport form of a batch (tg_cwire.h / tg_cwire.hip): the delivered slots' 40-byte wire records -> one buffer of

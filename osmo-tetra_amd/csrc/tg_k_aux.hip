@@ -1013,18 +1013,19 @@ __global__ __launch_bounds__(1024)
 void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbits, uint32_t n, const uint32_t *__restrict__ okbits,
 	      const uint32_t *__restrict__ prevw, const uint8_t *__restrict__ word_chan, const uint32_t *__restrict__ slot_entry,
 	      uint32_t *__restrict__ maskidx, uint32_t *__restrict__ list_216, uint32_t *__restrict__ list_432,
-	      uint32_t *__restrict__ list_all /* or NULL: every delivered slot once, for the lane-per-slot kernel (tg_k_slot.hip) */,
-	      uint32_t *__restrict__ cnt /* [1]: 216 items, [2]: 432 items, [3]: delivered slots */,
+	      uint32_t *__restrict__ list_all /* or NULL: the lane-per-slot kernel's items (tg_k_slot.hip): every listed NORM_1 / NORM_2 slot once */,
+	      uint32_t *__restrict__ list_sync /* ... and every listed SYNC slot once (a list of their own: waves of one kind run a shorter schedule) */,
+	      uint32_t *__restrict__ cnt /* [1]: 216 items, [2]: 432 items, [3]: slots on list_all, [4]: slots on list_sync */,
 	      const uint32_t *__restrict__ specbits, tg_lists_hints hints, const uint32_t *__restrict__ chan_code, const uint32_t *__restrict__ tbl,
 	      uint32_t nchan)
 {
 	/* k_slot batches (specbits != NULL): a delivered slot that kernel decoded under its channel's hint is DONE if the code in force at
 	 * the slot -- the entry found here -- is the hint's; it then goes onto no list.  Every other delivered slot (decoded under another
 	 * code: a channel's first batch, a cell change; or not decoded there at all: the exact pass's slots) is listed as before. */
-	__shared__ uint32_t s_c216[TG_MID_CHUNKS][16], s_c432[TG_MID_CHUNKS][16], s_call[TG_MID_CHUNKS][16], s_b216, s_b432, s_ball;
+	__shared__ uint32_t s_c216[TG_MID_CHUNKS][16], s_c432[TG_MID_CHUNKS][16], s_call[TG_MID_CHUNKS][16], s_csb[TG_MID_CHUNKS][16], s_b216, s_b432, s_ball, s_bsb;
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const unsigned long long below = (1ull << lane) - 1;
-	uint32_t t[TG_MID_CHUNKS], in216[TG_MID_CHUNKS], in432[TG_MID_CHUNKS], inall[TG_MID_CHUNKS];
+	uint32_t t[TG_MID_CHUNKS], in216[TG_MID_CHUNKS], in432[TG_MID_CHUNKS], inall[TG_MID_CHUNKS], insb[TG_MID_CHUNKS];
 #pragma unroll
 	for (int j = 0; j < TG_MID_CHUNKS; j++) {
 		const uint32_t g = (blockIdx.x * TG_MID_CHUNKS + j) * 1024 + threadIdx.x;
@@ -1049,11 +1050,13 @@ void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbi
 		const unsigned long long mn1 = __ballot(t[j] == TG_BURST_NORM_1);
 		in216[j] = __builtin_popcountll(msb & below) + 2 * __builtin_popcountll(mn2 & below);
 		in432[j] = __builtin_popcountll(mn1 & below);
-		inall[j] = __builtin_popcountll((msb | mn2 | mn1) & below);
+		inall[j] = __builtin_popcountll((mn2 | mn1) & below);
+		insb[j] = __builtin_popcountll(msb & below);
 		if (lane == 0) {
 			s_c216[j][wv] = __builtin_popcountll(msb) + 2 * __builtin_popcountll(mn2);
 			s_c432[j][wv] = __builtin_popcountll(mn1);
-			s_call[j][wv] = __builtin_popcountll(msb | mn2 | mn1);
+			s_call[j][wv] = __builtin_popcountll(mn2 | mn1);
+			s_csb[j][wv] = __builtin_popcountll(msb);
 		}
 	}
 	__syncthreads();
@@ -1067,33 +1070,43 @@ void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbi
 		else
 			s_b216 = base;
 	}
-	if (threadIdx.x == 64) {	/* the delivered slots of any type, once each */
+	if (threadIdx.x == 64 || threadIdx.x == 128) {	/* the listed slots once each: NORM_1 / NORM_2 on one list, SYNC on another */
+		const bool sbl = threadIdx.x == 128;
 		uint32_t tot = 0;
 		for (int q = 0; q < TG_MID_CHUNKS * 16; q++)
-			tot += s_call[0][q];
-		s_ball = (tot && list_all) ? atomicAdd(cnt + 3, tot) : 0u;
+			tot += sbl ? s_csb[0][q] : s_call[0][q];
+		const uint32_t base = (tot && list_all) ? atomicAdd(cnt + (sbl ? 4 : 3), tot) : 0u;
+		if (sbl)
+			s_bsb = base;
+		else
+			s_ball = base;
 	}
 	__syncthreads();
-	uint32_t r216 = s_b216, r432 = s_b432, rall = s_ball;
+	uint32_t r216 = s_b216, r432 = s_b432, rall = s_ball, rsb = s_bsb;
 #pragma unroll
 	for (int j = 0; j < TG_MID_CHUNKS; j++) {
 		const uint32_t g = (blockIdx.x * TG_MID_CHUNKS + j) * 1024 + threadIdx.x;
-		uint32_t p216 = r216, p432 = r432, pall = rall;
+		uint32_t p216 = r216, p432 = r432, pall = rall, psb = rsb;
 		for (uint32_t q = 0; q < 16; q++) {
 			if (q < wv) {
 				p216 += s_c216[j][q];
 				p432 += s_c432[j][q];
 				pall += s_call[j][q];
+				psb += s_csb[j][q];
 			}
 			r216 += s_c216[j][q];
 			r432 += s_c432[j][q];
 			rall += s_call[j][q];
+			rsb += s_csb[j][q];
 		}
 		p216 += in216[j];
 		p432 += in432[j];
 		pall += inall[j];
-		if (list_all && (t[j] == TG_BURST_SYNC || t[j] == TG_BURST_NORM_2 || t[j] == TG_BURST_NORM_1))
+		psb += insb[j];
+		if (list_all && (t[j] == TG_BURST_NORM_2 || t[j] == TG_BURST_NORM_1))
 			list_all[pall] = g;
+		if (list_all && t[j] == TG_BURST_SYNC)
+			list_sync[psb] = g;
 		if (t[j] == TG_BURST_SYNC)
 			list_216[p216] = (g << 1) | 1;		/* SB2 */
 		else if (t[j] == TG_BURST_NORM_2) {
@@ -1134,7 +1147,7 @@ extern "C" int tgk_lb_scan(const uint32_t *d_okbits, const uint32_t *d_dbits, co
 
 extern "C" int tgk_lists2(const uint32_t *d_cls, const uint32_t *d_dbits, uint32_t n, const uint32_t *d_okbits, const uint32_t *d_prevw,
 			  const uint8_t *d_word_chan, const uint32_t *d_slot_entry, uint32_t *d_maskidx, uint32_t *d_list_216,
-			  uint32_t *d_list_432, uint32_t *d_list_all, uint32_t *d_cnt, const uint32_t *d_specbits, const uint32_t *hints,
+			  uint32_t *d_list_432, uint32_t *d_list_all, uint32_t *d_list_sync, uint32_t *d_cnt, const uint32_t *d_specbits, const uint32_t *hints,
 			  const uint32_t *d_chan_code, const uint32_t *d_tbl, uint32_t nchan, void *stream)
 {
 	if (!n)
@@ -1144,7 +1157,7 @@ extern "C" int tgk_lists2(const uint32_t *d_cls, const uint32_t *d_dbits, uint32
 	if (d_specbits && hints)
 		memcpy(h.code, hints, (size_t)(nchan < 64 ? nchan : 64) * 4);
 	hipLaunchKernelGGL(k_lists2, dim3((n + 1024 * TG_MID_CHUNKS - 1) / (1024 * TG_MID_CHUNKS)), dim3(1024), 0, (hipStream_t)stream, d_cls, d_dbits, n, d_okbits, d_prevw,
-			   d_word_chan, d_slot_entry, d_maskidx, d_list_216, d_list_432, d_list_all, d_cnt, (d_specbits && hints) ? d_specbits : NULL, h, d_chan_code,
+			   d_word_chan, d_slot_entry, d_maskidx, d_list_216, d_list_432, d_list_sync ? d_list_all : NULL, d_list_sync, d_cnt, (d_specbits && hints) ? d_specbits : NULL, h, d_chan_code,
 			   d_tbl, nchan);
 	return (int)hipGetLastError();
 }

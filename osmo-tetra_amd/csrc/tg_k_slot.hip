@@ -35,7 +35,13 @@
 struct tg_slot_tabs {
 	uint16_t crc[TG_CRC_WORDS + 32];			/* the two CRC tables + the 16-dword spread table (tg_bits16) */
 	uint32_t bm[TG_BMD_WORDS];				/* branch-metric entries of the difference form (vit_core.h) */
+	/* what a lane needs again behind the trellis (slot, meta word, BBK bits, scrambling code) waits HERE, not in registers: the
+	 * forward pass holds 144 history registers of the 168 three waves per SIMD allow, and what does not fit goes to scratch memory --
+	 * 350 MB of traffic per launch when it did, and kernels with a scratch segment share the chip badly with each other */
+	uint32_t keep[4][64];
 };
+#define TG_SLOT_KEEP(L, lane, a, b, c, d) do { (L).keep[0][lane] = (a); (L).keep[1][lane] = (b); (L).keep[2][lane] = (c); (L).keep[3][lane] = (d); } while (0)
+#define TG_SLOT_FORGET() asm volatile("" ::: "memory")	/* (what was parked is read back, not carried) */
 #define TG_SLOT_STAGE_WORDS (64 * TG_STAGE_PITCH + 64)		/* the record on its way out: 64 lanes x four dwordx4 at a pitch of 20 dwords + 64 slot numbers */
 
 /* k_slot_t's LDS: tables, and the code words as columns -- word g of lane l at g * 64 + l, descrambled -- whose place the record's
@@ -80,10 +86,15 @@ __device__ __forceinline__ void slot_tables(tg_slot_tabs &L, uint32_t lane)
  * keeps the packed slot's layout and hands a SYNC lane col - 4 * GS) --, the burst type per lane.  Out: od[] (36 decoded bytes), the
  * two CRC words.
  */
-template <int GS>
-__device__ __forceinline__ void slot_trellis(const tg_slot_tabs &L, const uint32_t *col, const uint32_t *colA, bool two, bool sb,
+/* SBMODE: 0 = the lanes say what they hold (two, sb); 1 = no SYNC burst among them (k_slot_t over the batch's NORM_1 / NORM_2 list: the SYNC
+ * lanes' prologue and selects fall away); 2 = SYNC bursts only (k_slot_t over the SYNC list: the schedule starts at block slot 8 -- SB1 84
+ * steps + SB2 148 instead of 296 for lanes that idle through the first eight block slots in a mixed wave) */
+template <int GS, int SBMODE = 0>
+__device__ __forceinline__ void slot_trellis(const tg_slot_tabs &L, const uint32_t *col, const uint32_t *colA, bool two_, bool sb_,
 					     uint32_t (&od)[TG_SLOT_NOD + 1], uint32_t &crc0, uint32_t &crc1)
 {
+	const bool sb = SBMODE == 1 ? false : SBMODE == 2 ? true : sb_;
+	const bool two = SBMODE == 2 ? true : two_;
 	auto bmdo = [&](uint32_t o, uint32_t w[10]) {
 		const uint8_t *q = (const uint8_t *)L.bm + o;
 		const uint4 a = *(const uint4 *)(q + 4 * TG_BMD_A0);
@@ -93,11 +104,18 @@ __device__ __forceinline__ void slot_trellis(const tg_slot_tabs &L, const uint32
 		w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
 		w[8] = c.x; w[9] = c.y;
 	};
-	tg_v32 H[5];
+	/* survivor history: 36 block slots x 4 dwords.  Chunks of eight block slots = 32 registers written through the VGPR index mode; the
+	 * last chunk holds four block slots and is a 16-register vector of its own (as a fifth tg_v32 it cost sixteen registers nobody used,
+	 * and the compiler parked a whole chunk in scratch memory for the length of the trellis to make room) */
+	tg_v32 H[4];
+	tg_v16 H4;
 	tg_vit_state v;
 	tg_slot_state_init(v);
-	uint32_t cur = col[0];
-	tg_slot_leadin(v, cur >> 24, bmdo);
+	uint32_t cur = 0;
+	if (SBMODE != 2) {
+		cur = col[0];
+		tg_slot_leadin(v, cur >> 24, bmdo);
+	}
 	/* (one block slot per loop iteration, a loop per history chunk of eight: 1.7 KB of code each -- the kernel's waves are NOT in step
 	 * with each other, by design, and what they execute between them should fit the instruction cache) */
 	uint32_t nxt = 0;
@@ -105,7 +123,11 @@ __device__ __forceinline__ void slot_trellis(const tg_slot_tabs &L, const uint32
 		constexpr int c = decltype(cc)::value;
 		constexpr int b0 = (c == 2) ? 2 : 0;			/* chunk 2's first two block slots (code word 8: slots 16, 17) are written out */
 		constexpr int nb = (c == 4) ? 3 : 8;			/* chunk 4: block slots 32..35, the last one written out */
-		if (c == 1)
+		if constexpr (SBMODE == 2 && c == 0)
+			return;						/* (SYNC bursts only: nothing in front of block slot 8) */
+		if (c == 1 && SBMODE == 2)
+			cur = colA[TG_SLOT_SB1_G0 * GS];
+		if (c == 1 && SBMODE != 1)
 			tg_slot_sb_prologue(v, sb, cur, bmdo);		/* in front of code word 4: a SYNC lane starts SB1 */
 		if (c == 2) {
 			nxt = col[9 * GS];
@@ -128,9 +150,15 @@ __device__ __forceinline__ void slot_trellis(const tg_slot_tabs &L, const uint32
 			if (!(b & 1) && g < 17)		/* (wave-uniform) */
 				nxt = (c < 2 ? colA : col)[(g + 1) * GS];	/* (c < 2: g + 1 <= 8) */
 			tg_slot_block(v, cur >> (12 * (b & 1)), h, bmdo);
+			if constexpr (c == 4) {
 #pragma unroll
-			for (int d = 0; d < 4; d++)
-				H[c][4 * b + d] = h[d];
+				for (int d = 0; d < 4; d++)
+					H4[4 * b + d] = h[d];
+			} else {
+#pragma unroll
+				for (int d = 0; d < 4; d++)
+					H[c][4 * b + d] = h[d];
+			}
 			if (b & 1)
 				cur = nxt;
 		}
@@ -139,7 +167,7 @@ __device__ __forceinline__ void slot_trellis(const tg_slot_tabs &L, const uint32
 			tg_slot_block_last(v, cur >> 12, h, bmdo);
 #pragma unroll
 			for (int d = 0; d < 4; d++)
-				H[c][12 + d] = h[d];
+				H4[12 + d] = h[d];
 		}
 	});
 	/* block-wise traceback from state 0, all register indices static */
@@ -150,11 +178,16 @@ __device__ __forceinline__ void slot_trellis(const tg_slot_tabs &L, const uint32
 	tg_static_for<TG_SLOT_NBLK>([&](auto ii) __attribute__((always_inline)) {
 		constexpr int b = TG_SLOT_NBLK - 1 - decltype(ii)::value;
 		constexpr int c = b >> 3, o = 4 * (b & 7);
-		tg_slot_hop<b>(od, s, two, H[c][o], H[c][o + 1], H[c][o + 2], H[c][o + 3]);
+		if constexpr (SBMODE == 2 && b < 2 * TG_SLOT_SB1_G0)
+			return;
+		else if constexpr (c == 4)
+			tg_slot_hop<b>(od, s, two, H4[o], H4[o + 1], H4[o + 2], H4[o + 3]);
+		else
+			tg_slot_hop<b>(od, s, two, H[c][o], H[c][o + 1], H[c][o + 2], H[c][o + 3]);
 	});
 	auto tl = [&](uint32_t x) -> uint32_t { return L.crc[x]; };
 	auto tm = [&](uint32_t x) -> uint32_t { return L.crc[256 + x]; };
-	tg_slot_crc(od, two, sb, tl, tm, crc0, crc1);
+	tg_slot_crc<SBMODE == 2 ? 2 * TG_SLOT_SB1_G0 : 0>(od, two, sb, tl, tm, crc0, crc1);
 }
 
 /*
@@ -282,6 +315,7 @@ __device__ __forceinline__ void slot_finish(const tg_slot_tabs &L, uint32_t *sta
  * k_slot_t: items[] = grid slots of the batch's delivered bursts (any order, any mix of types; the count on the device).
  * packed / masks / maskidx as k_vit takes them.
  */
+template <int SBMODE>
 __global__ __launch_bounds__(64, TG_SLOT_WAVES)
 void k_slot_t(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t *__restrict__ nitems_dev,
 	      const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks, const uint32_t *__restrict__ maskidx,
@@ -306,29 +340,30 @@ void k_slot_t(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_
 	const uint32_t w[TG_PACKED_WORDS] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w,
 					      p3.x, p3.y, p3.z, p3.w, p4.x, p4.y, p4.z, p4.w };
 	const uint32_t meta = w[TG_PW_META], btype = meta & 0xff;
-	const bool sb = btype == TG_BURST_SYNC, two = btype != TG_BURST_NORM_1;
+	const bool sb = SBMODE == 1 ? false : SBMODE == 2 ? true : btype == TG_BURST_SYNC;
+	const bool two = SBMODE == 2 ? true : btype != TG_BURST_NORM_1;
 	const uint32_t *mk = masks + (size_t)maskidx[slot] * TG_MASK_WORDS;
 	/* the code words as columns, descrambled: NORM_1 its 18 words under the 432-bit mask; a two-block burst words 0..8 and 9..17
 	 * under the 216-bit mask each; a SYNC burst's SB1 words (fixed code) at g = 4..8 (slot_core.h) */
 #pragma unroll
-	for (int g = 0; g < 18; g++) {
+	for (int g = (SBMODE == 2 ? TG_SLOT_SB1_G0 : 0); g < 18; g++) {
 		const uint32_t m432 = mk[TG_MW_432 + g], m216 = mk[TG_MW_216 + (g < 9 ? g : g - 9)];
 		uint32_t x = w[g] ^ (two ? m216 : m432);
-		if (g < 9) {
+		if (g < 9 && SBMODE != 1) {
 			const uint32_t sbw = (g >= TG_SLOT_SB1_G0) ? (w[g - TG_SLOT_SB1_G0] ^ c_tab.sb1_mask[g - TG_SLOT_SB1_G0]) : 0u;
 			x = sb ? sbw : x;
 		}
 		L.u.cw[g * 64 + lane] = x;
 	}
-	const uint32_t bb = w[TG_PW_BBK] ^ mk[TG_MW_BBK];
-	const uint32_t code = mk[TG_MW_CODE];
+	TG_SLOT_KEEP(L.t, lane, slot, meta, w[TG_PW_BBK] ^ mk[TG_MW_BBK], mk[TG_MW_CODE]);
 	__syncthreads();
 	uint32_t od[TG_SLOT_NOD + 1], crc0, crc1;
-	slot_trellis<64>(L.t, L.u.cw + lane, L.u.cw + lane, two, sb, od, crc0, crc1);
+	slot_trellis<64, SBMODE>(L.t, L.u.cw + lane, L.u.cw + lane, two, sb, od, crc0, crc1);
 	__syncthreads();		/* (single wave: the columns are dead, the staging area takes their place) */
+	TG_SLOT_FORGET();
 	/* (lanes past the end of the list are copies of the last item: they store its bytes again) */
-	slot_finish(L.t, L.u.stage, lane, true, two, sb, slot, meta, bb, code, od, crc0, crc1, rec, valid ? wire : nullptr, nullptr, nullptr, nullptr,
-		    kflags & ~TGS_F_LOOKBACK);
+	slot_finish(L.t, L.u.stage, lane, true, two, sb, L.t.keep[0][lane], L.t.keep[1][lane], L.t.keep[2][lane], L.t.keep[3][lane], od, crc0, crc1, rec,
+		    valid ? wire : nullptr, nullptr, nullptr, nullptr, kflags & ~TGS_F_LOOKBACK);
 	TG_TRACE_END(5u, 8u);
 }
 
@@ -364,7 +399,7 @@ extern "C" int tgk_slot_stamps(unsigned long long *out)
 {
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slot_stamp), sizeof(g_slot_stamp));
 }
-#define TGSL_STAMP(k) do { if (lane == 0 && task < 16384u) g_slot_stamp[5 * task + (k)] = (k) ? __builtin_amdgcn_s_memtime() : (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)); } while (0)
+#define TGSL_STAMP(k) do { if (lane == 0 && task < 16384u) g_slot_stamp[5 * task + (k)] = (k) ? wall_clock64() : (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)); } while (0)
 #else
 #define TGSL_STAMP(k) do { } while (0)
 #endif
@@ -389,8 +424,8 @@ void k_slot(const uint8_t *__restrict__ stream, tg_stream_params prm, uint32_t *
 	 * it falls free and inherit its phase */
 	if (blockIdx.x < 3072u) {
 		const uint32_t wid = __builtin_amdgcn_s_getreg(4 | (3 << 11)) % 3u;	/* HW_ID bits 0..3: the wave's slot on its SIMD */
-		const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-		while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)wid * TG_SLOT_STAGGER)
+		const unsigned long long t0 = wall_clock64();
+		while (wall_clock64() - t0 < (unsigned long long)wid * TG_SLOT_STAGGER)
 			__builtin_amdgcn_s_sleep(64);
 	}
 #endif
@@ -427,15 +462,19 @@ void k_slot(const uint8_t *__restrict__ stream, tg_stream_params prm, uint32_t *
 			m = sb ? c_tab.sb1_mask[g] : m;
 		col[g] ^= m;
 	}
-	const uint32_t bb = col[TG_PW_BBK] ^ mk[TG_MW_BBK];
-	const uint32_t meta = col[TG_PW_META];
-	const uint32_t code = mk[TG_MW_CODE];
+	TG_SLOT_KEEP(S.t, lane, slot, col[TG_PW_META] | (spec ? 0x80000000u : 0u), col[TG_PW_BBK] ^ mk[TG_MW_BBK], mk[TG_MW_CODE]);	/* (meta: type, flags, offset < 2^25) */
 	__syncthreads();
 	uint32_t od[TG_SLOT_NOD + 1], crc0, crc1;
 	slot_trellis<1>(S.t, col, sb ? col - TG_SLOT_SB1_G0 : col, two, sb, od, crc0, crc1);
 	__syncthreads();		/* (single wave: the columns are dead, the staging area takes their place) */
 	TGSL_STAMP(3);
-	slot_finish(S.t, S.u.stage, lane, spec, two, sb, slot, meta, bb, code, od, crc0, crc1, rec, spec ? wire : nullptr, tbl, sb_ok, sb_entry, kflags);
+	TG_SLOT_FORGET();
+	/* (the lane number afresh: carried across the trellis -- as 16 x lane, the front phase's load offset -- it was the one thing left in
+	 * scratch memory) */
+	const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	const uint32_t km = S.t.keep[1][ln];	/* (bit 31: "this lane decodes its slot" -- parked with the rest, nothing carried per lane) */
+	slot_finish(S.t, S.u.stage, ln, (km >> 31) != 0u, two, sb, S.t.keep[0][ln], km & 0x7fffffffu, S.t.keep[2][ln], S.t.keep[3][ln], od, crc0, crc1, rec,
+		    wire, tbl, sb_ok, sb_entry, kflags);
 	TGSL_STAMP(4);
 	TG_TRACE_END(6u, 8u);
 }
@@ -456,13 +495,16 @@ extern "C" int tgk_trace_read_slot(void *out, unsigned int *n, int reset)
 }
 #endif
 
-extern "C" int tgk_slot_t(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_nitems, const uint32_t *d_packed,
+extern "C" int tgk_slot_t(int sbmode, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_nitems, const uint32_t *d_packed,
 			  const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec, uint8_t *d_wire, int flags, void *stream)
 {
 	if (!nitems)
 		return 0;
-	hipLaunchKernelGGL(k_slot_t, dim3((nitems + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_items, nitems, d_nitems, d_packed, d_masks,
-			   d_maskidx, d_rec, d_wire, flags);
+	const dim3 grid((nitems + 63) / 64), block(64);
+	hipStream_t s = (hipStream_t)stream;
+#define SLOT_T_LAUNCH(M) hipLaunchKernelGGL(k_slot_t<M>, grid, block, 0, s, d_items, nitems, d_nitems, d_packed, d_masks, d_maskidx, d_rec, d_wire, flags)
+	if (sbmode == 1) SLOT_T_LAUNCH(1); else if (sbmode == 2) SLOT_T_LAUNCH(2); else SLOT_T_LAUNCH(0);
+#undef SLOT_T_LAUNCH
 	return (int)hipGetLastError();
 }
 
