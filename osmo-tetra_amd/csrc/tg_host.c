@@ -1167,15 +1167,13 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	 * have the slot list), no option that only the lane-per-block kernels implement */
 	const int by_slot = tgi_option(TGPU_OPT_SLOT) && !soft && !fast && !p->rm_decode && p->d_list_all && (p->nall || p->nsync);
 	if (by_slot) {
-		/* two launches: the NORM_1 / NORM_2 slots (no SYNC lane: their prologue and selects compiled away), then the SYNC slots (every lane
-		 * one: the schedule starts at block slot 8) */
-		if (p->nall && (rc = tgk_slot_t(1, p->d_list_all, p->nall, p->d_counts ? p->d_counts + 3 : NULL, p->d_packed, p->d_masks, p->d_maskidx,
-						d_rec, p->d_wire, kf, stream)))
+		/* one launch over two lists: the NORM_1 / NORM_2 slots (no SYNC lane: their prologue and selects compiled away) and the SYNC slots
+		 * (every lane one: the schedule starts at block slot 8) */
+		if ((rc = tgk_slot_t(p->d_list_all, p->nall, p->d_counts ? p->d_counts + 3 : NULL, p->d_list_sync, p->nsync,
+				     p->d_counts ? p->d_counts + 4 : NULL, p->d_counts ? p->nslots : 0, p->d_packed, p->d_masks, p->d_maskidx, d_rec,
+				     p->d_wire, kf, stream)))
 			return rc;
 		MARK(5);
-		if (p->nsync && (rc = tgk_slot_t(2, p->d_list_sync, p->nsync, p->d_counts ? p->d_counts + 4 : NULL, p->d_packed, p->d_masks, p->d_maskidx,
-						 d_rec, p->d_wire, kf, stream)))
-			return rc;
 	} else {
 	if (p->nslots) {
 		if ((rc = tgk_vit(TG_KIND_216, items216, p->n216, p->d_packed, p->d_masks, p->d_maskidx, d_rec,

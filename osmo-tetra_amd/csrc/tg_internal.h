@@ -40,8 +40,10 @@ int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *
 	    const uint32_t *d_nitems /* NULL, or device-side item count with nitems as its upper bound */, void *stream);
 /* one lane per SLOT (tg_k_slot.hip, slot_core.h): d_items = the batch's slots of type NORM_1 / NORM_2 / SYNC, any order; replaces the
  * 216 and 432 launches of tgk_vit for hard input (a SYNC burst's SB1 is decoded again on the way: its lane would idle otherwise) */
-int tgk_slot_t(int sbmode /* 0: items of any type, 1: no SYNC burst among them, 2: SYNC bursts only */, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_nitems, const uint32_t *d_packed,
-	       const uint32_t *d_masks, const uint32_t *d_maskidx, uint8_t *d_rec, uint8_t *d_wire /* or NULL */, int flags, void *stream);
+int tgk_slot_t(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_nitems, const uint32_t *d_items2 /* or NULL: one list of any type */,
+	       uint32_t nitems2, const uint32_t *d_nitems2, uint32_t ntotal /* 0, or an upper bound of both lists together */,
+	       const uint32_t *d_packed, const uint32_t *d_masks, const uint32_t *d_maskidx,
+	       uint8_t *d_rec, uint8_t *d_wire /* or NULL */, int flags, void *stream);
 /* clean-block pre-pass (kinds 216 / 432): finishes the blocks that are code words, lists the others for tgk_vit */
 int tgk_clean(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *d_packed, const uint32_t *d_masks,
 	      const uint32_t *d_maskidx, uint8_t *d_rec, uint32_t *d_sb_ok, uint32_t *d_sb_code, uint8_t *d_wire,
