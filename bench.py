@@ -754,6 +754,14 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         if names[i] not in kern_ms:          # (SB1, code fill and masks are stages in front of the walk on this path)
             kern_ms[names[i]] = float(st_ms[i])
     kern_ms = {k: v for k, v in kern_ms.items() if not (k in ("k_fill", "k_masks") and v < 8e-3)}
+    # round 6 (TGPU_OPT_SLOT >= 1): the two trellis stages are ONE launch, k_slot_t (one lane per slot, both lists), timed in the first
+    # one's place; with the option at 2 and hints in place the front-end stage is k_slot (front end + trellises in one launch)
+    slot_mode = int(T.get_option(T.OPT_SLOT))
+    if slot_mode >= 1 and "k_vit<216>" in kern_ms:
+        kern_ms["k_slot_t"] = kern_ms.pop("k_vit<216>") + kern_ms.pop("k_vit<432>", 0.0)
+    fused_front = slot_mode >= 2 and kern_ms.get("k_slot_t", 1.0) < 0.5 * kern_ms.get("k_front_stream", 0.0)
+    if fused_front:
+        kern_ms["k_slot"] = kern_ms.pop("k_front_stream")
     ngrid = sum(x["ngrid"] for x in outs)
     nd = sum(x["nslots"] for x in outs)
     n_sb, n_n1, n_n2 = nd // 8, nd // 2, nd - nd // 8 - nd // 2     # delivered bursts by type (the damage is uniform)
@@ -762,7 +770,11 @@ def bench_mix(args, T, torch, dist, rank, world, local):
            "k_vit<SB1>": n_sb * (60 + 16),
            "k_vit<216>": n_n2 * (14 + 124 + 124 + 3 * 16) + n_sb * (14 + 124 + 2 * 16),
            "k_vit<432>": n_n1 * (14 + 268 + 2 * 16)}
+    # k_slot_t writes every block of a delivered burst (a SYNC burst's SB1 included); k_slot reads the grid as well
+    alg["k_slot_t"] = alg["k_vit<216>"] + alg["k_vit<432>"] + alg["k_vit<SB1>"]
+    alg["k_slot"] = alg["k_front_stream"] + alg["k_slot_t"]
     dom, tied = pick_roofline_kernel(kern_ms, alg)
+    hbk = "k_front_stream" if ("k_front_stream" in kern_ms and dom != "k_front_stream") else None
     achieved = alg.get(dom, 0) / (kern_ms[dom] * 1e-3) / 1e9
     traffic = valu_busy = valu_pipe = traffic_prov = None
     per_kernel = None
@@ -1058,6 +1070,11 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                         "kernel_ms": kern_ms[dom],
                         "kernels_within_5_percent_of_the_longest": {k: kern_ms[k] for k in tied},
                         "heavy_kernels": per_kernel,
+                        "hbm_bound_kernel": ({"kernel": hbk, "achieved": alg[hbk] / (kern_ms[hbk] * 1e-3) / 1e9,
+                                              "frac": alg[hbk] / (kern_ms[hbk] * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kern_ms[hbk],
+                                              "note": "the step's kernel that HBM bounds (the stream front end: 510 input bytes per grid slot); the dominant "
+                                                      "kernel above is bound by vector-instruction issue, its HBM fraction says little"}
+                                             if hbk else None),
                         "pipeline_achieved_gbs_per_gpu": float(decode_only["value"] / world * 820 / 1e9),
                         "pipeline_vector_issue": valu_pipe,
                         "measured_in_this_run": ["achieved", "frac", "kernel_ms", "pipeline_achieved_gbs_per_gpu"],
@@ -1068,10 +1085,11 @@ def bench_mix(args, T, torch, dist, rank, world, local):
                                 "input bytes of every grid slot; a trellis kernel: type-1 bits at 1 B/bit + 16 B per block of the "
                                 "bursts it decodes) / its mean HIP-event duration on its launch stream, measured after the timed "
                                 "region; traffic = PMC bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes) and "
-                                "valu_busy_frac from profiles/traffic.json of the same command.  kernel = the longest kernel of a step; "
-                                "where several are within 5 % of the longest, the one of them with the most algorithmic bytes (the one "
-                                "HBM bounds: the front end; the trellis kernels are bound by vector issue -- heavy_kernels has both "
-                                "fractions for each; DESIGN.md sections 4 and 5)"}}
+                                "valu_busy_frac from profiles/traffic.json of the same command.  kernel = the longest kernel of a step "
+                                "(round 6: k_slot_t, the trellises of all delivered bursts in one launch -- bound by vector-instruction issue, "
+                                "valu_busy_frac; its HBM fraction is small by nature: ~35 instructions per byte); where several are within 5 % "
+                                "of the longest, the one of them with the most algorithmic bytes; hbm_bound_kernel = the front end, the kernel "
+                                "HBM does bound; heavy_kernels has both fractions for each (DESIGN.md sections 4 and 5)"}}
     if r3form:
         out["round3_form"] = {k_: r3form[k_] for k_ in ("value", "ms_per_step", "windows_ms_per_step", "window_spread", "all_windows_ms_per_step", "host_cpu_ms_per_step")}
         out["round3_form"]["note"] = ("the same measurement as round 3 ran it: 4 batches in flight and the plans' side streams in play (k_vit<432> beside "
@@ -1465,6 +1483,9 @@ def bench_config2(args, T, torch, dist, rank, world, local, steps, warmup, with_
     n1 = int((types == T.TRAIN_NORM_1).sum())
     n2 = n - n1
     units_bytes = {"k_front": n * 510, "k_vit<432>": n1 * (ALG_BYTES[0] - 510), "k_vit<216>": n2 * (ALG_BYTES[1] - 510)}
+    if int(T.get_option(T.OPT_SLOT)) >= 1:      # round 6: both trellis stages are one launch (k_slot_t), timed in the first one's place
+        names = ["k_slot_t" if x == "k_vit<216>" else x for x in names]
+        units_bytes["k_slot_t"] = units_bytes["k_vit<432>"] + units_bytes["k_vit<216>"]
     domname, tied2 = pick_roofline_kernel({names[i]: float(stage_ms[i]) for i in range(len(names))}, units_bytes)
     dom = names.index(domname)
     alg = units_bytes.get(names[dom], n1 * ALG_BYTES[0] + n2 * ALG_BYTES[1])

@@ -131,6 +131,50 @@ def main():
         streams.append(dict(name=name, bits=np.packbits(s).tobytes().hex(), nbits=int(len(s)), rc=r.returncode, stdout=keep, stderr=err))
     out["tetra_rx"] = streams
 
+    # ---- row P's uplink shape / row L on single blocks, and (f)3's GSMTAP bytes: tools/pin_harness.c in front of the reference's archives ----
+    hx_bits = lambda a: np.ascontiguousarray(a, np.uint8).tobytes().hex()
+    ph = subprocess.Popen([os.path.join(d, "pin_harness")], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+
+    def ask(cmd):
+        ph.stdin.write(cmd + "\n")
+        ph.stdin.flush()
+        lines = []
+        while True:
+            ln = ph.stdout.readline().rstrip("\n")
+            if ln in ("done", "error", "") or ln.startswith("gsmtap "):
+                lines.append(ln)
+                return lines
+            lines.append(ln)
+
+    udata = []
+    cell = (262, 42, 1)
+    code = O.scramb_get_init(*cell)
+    sy = synth.sync_pdu(cell[2], 2, 5, 7, cell[0], cell[1])       # (cc, tn, fn, mn, mcc, mnc): the SYNC PDU's 60 type-1 bits
+    for ber in (0.0, 0.03):
+        ask("time 2 5 7")
+        seq = []
+        if sy is not None:      # an SB1 first: it sets the cell's scrambling code for the blocks behind it (tetra_lower_mac.c:291-300)
+            seq.append((0, 0, O.encode_block(O.T_SB1, sy, 3)))
+        for t, tp in ((O.T_SCH_HU, 4), (O.T_NDB, 2), (O.T_SCH_F, 5), (O.T_SB2, 1)):
+            t1 = rng.integers(0, 2, O.BLK[t][2]).astype(np.uint8)
+            t1[:16] = synth.NULL_PDU_HDR      # MAC-RESOURCE null PDU header
+            blk = O.encode_block(t, t1, code if sy is not None else 0)
+            blk ^= (rng.random(len(blk)) < ber).astype(np.uint8)
+            seq.append((tp, 1, blk))
+        for tp, blk_num, blk in seq:
+            out = ask("udata %d %d %s" % (tp, blk_num, hx_bits(blk)))
+            udata.append(dict(type=tp, blk_num=blk_num, bits=hx_bits(blk), ber=ber, prims=[ln for ln in out if ln.startswith("prim ")]))
+    out["lower_mac_udata"] = udata
+    gs = []
+    for (tn, fn, mn, lchan, ts, ss) in ((1, 1, 1, 1, 0, 0), (2, 18, 60, 10, 1, 0), (4, 7, 33, 8, 3, 1), (3, 9, 12, 3, 2, 2), (1, 18, 4, 11, 0, 0)):
+        for nbits in (14, 60, 124, 268):
+            b = rng.integers(0, 2, nbits).astype(np.uint8)
+            r = ask("gsmtap %d %d %d %d %d %d %d %d %s" % (tn, fn, mn, lchan, ts, ss, -47, 12, hx_bits(b)))
+            gs.append(dict(tm=[tn, fn, mn], lchan=lchan, ts=ts, ss=ss, signal_dbm=-47, snr=12, bits=hx_bits(b), msg=r[-1].split(" ", 1)[1] if r and r[-1].startswith("gsmtap ") else ""))
+    out["gsmtap_makemsg"] = gs
+    ph.stdin.close()
+    ph.wait(timeout=10)
+
     path = os.path.join(HERE, "ref_vectors_osmo.json")
     json.dump(out, open(path, "w"))
     print("wrote", path, {k: (len(v) if isinstance(v, list) else v) for k, v in out.items()})

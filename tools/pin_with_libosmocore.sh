@@ -10,6 +10,8 @@
 #   1. oracle/_ref_osmo/libtetra_ref_osmo.so   the reference's lower_mac/{tetra_interleave,tetra_conv_enc,tetra_scramb,
 #        crc_simple,tetra_rm3014,viterbi,viterbi_cch,viterbi_tch}.c, compiled where they lie, linked with -losmocore
 #   2. oracle/_ref_osmo/tetra-rx               the reference's receiver, built by the reference's own Makefile
+#  2b. oracle/_ref_osmo/pin_harness            tools/pin_harness.c linked against the reference's own archives: tp_sap_udata_ind() on single
+#        blocks of every type (SCH/HU: no downlink burst carries one) and tetra_gsmtap_makemsg()'s bytes (the GSMTAP constants)
 #   3. tests/golden/ref_vectors_osmo.json      tests/golden/make_golden_osmo.py: interleaver and puncturer tables, encoder
 #        outputs, osmo_conv_decode() on noisy blocks of all six block types (BER 2 / 5 / 8 %, erasures) and on the speech
 #        code, tetra-rx's stdout / stderr for the stream list of SURVEY.md 8(c)
@@ -40,6 +42,11 @@ TMP=$(mktemp -d)
 cp -r "$S" "$TMP/src"
 make -C "$TMP/src" tetra-rx
 cp "$TMP/src/tetra-rx" "$OUT/tetra-rx"
+# 2b. single blocks through the reference's lower MAC (SCH/HU included) and its GSMTAP message builder: tools/pin_harness.c in front
+#     of the reference's own archives -- its recording upper_mac_prim_recv() is taken, the reference's stays out
+gcc -O2 -I"$TMP/src" $(pkg-config --cflags libosmocore) "$ROOT/tools/pin_harness.c" -Wl,--allow-multiple-definition \
+    "$TMP/src/libosmo-tetra-phy.a" "$TMP/src/libosmo-tetra-mac.a" "$TMP/src/libosmo-tetra-crypto.a" "$TMP/src/libosmo-tetra-mac.a" \
+    $(pkg-config --libs libosmocore) -o "$OUT/pin_harness"
 rm -rf "$TMP"
 # 3. the vectors   4. the oracle against them
 make -s -C "$ROOT/oracle" all
