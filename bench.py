@@ -552,7 +552,33 @@ def bench_mix(args, T, torch, dist, rank, world, local):
             xs.append((time.perf_counter() - t0_) * 1e3)
         one_at_a_time = {"ms_per_batch_median": _median(xs[4:]), "ms_per_batch_max": max(xs[4:]), "batches": len(xs) - 4,
                          "note": "tgpu_sync_multi_launch + tgpu_sync_multi_collect of one 1 M-slot batch at a time (host wall clock, the launch "
-                                 "call, all kernels, the outcome's way down and the wait included)"}
+                                 "call, all kernels, the outcome's way down and the wait included), in the timed run's own arrangement (every "
+                                 "kernel of a batch on one stream)"}
+        # ... and in the arrangement a caller who WAITS for every batch would choose: the plan's side streams in play (the library's
+        # default) and TGPU_OPT_SLOT 3 -- the trellises of every plain slot start behind the front end on the channels' hinted codes
+        # (k_slot_e) and run BESIDE the walk and the code look-back
+        try:
+            keep = int(T.get_option(T.OPT_SLOT))
+            T.set_option(T.OPT_SLOT, 3)
+            plan_l = T.Plan(eng, cap, C)
+            ys, early = [], 0
+            for k in range(28):
+                t0_ = time.perf_counter()
+                m_ = T.MultiSyncDev(eng, plan_l, None, d_bases[k % NB].data_ptr(), None, recs[0].data_ptr(), 64, strm[0].cuda_stream, chans=chans)
+                early += int(m_.fused == 2)
+                m_.collect_begin()
+                m_.collect_end(raw=True)
+                ys.append((time.perf_counter() - t0_) * 1e3)
+            plan_l.close()
+            T.set_option(T.OPT_SLOT, keep)
+            one_at_a_time["latency_form"] = {"ms_per_batch_median": _median(ys[4:]), "ms_per_batch_max": max(ys[4:]), "batches": len(ys) - 4,
+                                             "batches_with_the_trellises_beside_the_walk": early,
+                                             "note": "the same, with the plan's side streams in play and TGPU_OPT_SLOT 3 (k_slot_e: the trellises of "
+                                                     "every plain slot on the hinted codes, beside the walk; k_slot_t re-decodes what the look-back hands "
+                                                     "back) -- in THIS process the plan's streams share the runtime's four hardware queues with the eight "
+                                                     "pipelined batches' streams; tools/experiments/one_batch.py is the same in a process of its own"}
+        except Exception as ex:      # pragma: no cover
+            one_at_a_time["latency_form"] = {"error": repr(ex)}
     # what the rotation is worth: the same run with every step in flight on ONE capture (rounds 1-4 measured this)
     one_input = None
     if world == 1 and not args.no_secondary and NB > 1:

@@ -178,6 +178,13 @@ enum tgpu_option {
 					 *    pass settled) goes through k_slot_t.  Records of UNDELIVERED grid slots are unspecified in that form (they
 					 *    may hold a decode nobody asked for); tgpu_sync_dev_fused() tells which form a batch took.  Same records
 					 *    for delivered slots; measured slower than 1 on the metric's workload, so not the default.
+					 * 3: as 1, and device-walk batches whose channels have a code to decode on (as for 2) run the trellises of
+					 *    EVERY plain grid slot right behind the front end (k_slot_e), on a stream of the plan's own beside the
+					 *    walk and the code look-back; k_slot_t then re-decodes what the look-back finds was decoded under another
+					 *    code.  Meant for a caller who waits for every batch -- and measured to buy little: 0.603 against 0.620 ms
+					 *    per 1 M-slot batch (the walk's small kernels do not get far beside a kernel that fills the chip, DESIGN.md
+					 *    section 4); it decodes the slots the walk drops as well, so several batches in flight run 5 % slower than
+					 *    under 1.  Undelivered slots' records are unspecified, as for 2.
 					 * (soft input, block mode, the RM(30,14) option, the clean-block fast path and the traffic stage keep the
 					 * earlier forms) */
 	TGPU_OPT__COUNT
@@ -660,8 +667,9 @@ int tgpu_sync_multi_launch_packed(struct tgpu_engine *eng, struct tgpu_plan *pla
 				  const uint8_t *d_packed_base, uint32_t chunk, uint8_t *d_rec, struct tgpu_sync_dev **out, void *hip_stream);
 uint32_t tgpu_sync_dev_ngrid(const struct tgpu_sync_dev *sd);
 int tgpu_sync_dev_fellback(const struct tgpu_sync_dev *sd);
-/* 1: this batch's front end and trellises ran as ONE launch (k_slot, TGPU_OPT_SLOT 2) on hinted scrambling codes; 0: the front end
- * on its own (a plan's first batch without carry-in codes, another setting of the option) -- same records either way */
+/* 1: this batch's front end and trellises ran as ONE launch (k_slot, TGPU_OPT_SLOT 2) on hinted scrambling codes; 2: its trellises
+ * ran early, beside the walk (k_slot_e, TGPU_OPT_SLOT 3); 0: neither (a plan's first batch without carry-in codes, another setting
+ * of the option) -- same records for delivered slots either way */
 int tgpu_sync_dev_fused(const struct tgpu_sync_dev *sd);
 /* after collect: why the device walk handed channel c to the host walks (0: it did not).  1 a flagged slot (a byte other than
  * 0 / 1, a sequence below offset 21) on the walk's way, 2 a search window the kernel's view does not settle, 3 a SYNC sequence in

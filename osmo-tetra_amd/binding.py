@@ -826,7 +826,7 @@ class MultiSyncDev:
         _chk(fn(engine._h, plan._h, n, self._ch, C.c_void_p(d_base_ptr), chunk, C.c_void_p(d_rec_ptr),
                 C.byref(self._h), C.c_void_p(hip_stream)), "tgpu_sync_multi_launch")
         self.ngrid = lib().tgpu_sync_dev_ngrid(self._h)
-        self.fused = bool(lib().tgpu_sync_dev_fused(self._h))      # front end + trellises as one launch (k_slot, OPT_SLOT 2)
+        self.fused = int(lib().tgpu_sync_dev_fused(self._h))       # 1: front end + trellises as one launch (k_slot, OPT_SLOT 2); 2: trellises early, beside the walk (k_slot_e, OPT_SLOT 3)
         self.fellback = False
 
     def collect_begin(self):

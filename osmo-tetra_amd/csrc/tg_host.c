@@ -157,6 +157,10 @@ struct tgpu_plan {
 	uint32_t hint_now[64];		/* this batch's hints (0: none) */
 	int dev_prepared;		/* tgpi_plan_dev_prepare() laid this batch's arena out */
 	int fused;			/* this batch's front end ran as k_slot */
+	int early;			/* this batch's plain slots are decoded by k_slot_e beside the walk (TGPU_OPT_SLOT 3); early_pending: the join is still to come */
+	int early_pending;
+	hipStream_t side2;		/* ... on this stream (created on first use) */
+	hipEvent_t ev_early0, ev_early1;
 };
 
 const char *tgpu_strerror(int err)
@@ -315,6 +319,9 @@ void tgpu_plan_destroy(struct tgpu_plan *p)
 	if (p->side) (void)hipStreamDestroy(p->side);
 	if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+	if (p->side2) (void)hipStreamDestroy(p->side2);
+	if (p->ev_early0) (void)hipEventDestroy(p->ev_early0);
+	if (p->ev_early1) (void)hipEventDestroy(p->ev_early1);
 	void *d[] = { p->up_mapped ? NULL : p->d_up, p->d_up_dev, p->d_packed, p->d_maskidx, p->d_masks, p->d_sb_ok, p->d_sb_code,
 		      p->d_block_tmp, p->d_softarea, p->d_grid, p->d_dirty, p->d_chan_tab, p->d_defer, p->d_walk, p->d_walk_recs,
 		      p->d_walk_big, p->d_walk_tmp };
@@ -648,6 +655,71 @@ int tgpi_plan_dev_prepare(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, u
 	HCHK(hipMemsetAsync(base, 0, zero_bytes, s));
 	p->dev_prepared = 1;
 	p->fused = 0;
+	p->early = 0;
+	return TGPU_OK;
+}
+
+/* the hints of a batch: the caller's carry-in code, else what this plan's last batch of the channel ended with; their masks into the
+ * entries hint_base + c when they changed.  Returns 1 when some channel has one, 0 when none has, < 0 (-error) on failure */
+static int plan_hints(struct tgpu_plan *p, uint32_t nchan, const uint32_t *carry, void *stream)
+{
+	int any = 0, rebuild = 0;
+	for (uint32_t c = 0; c < nchan; c++) {
+		p->hint_now[c] = carry[c] ? carry[c] : (c < p->hint_last_n ? p->hint_last[c] : 0u);
+		any |= p->hint_now[c] != 0;
+		rebuild |= p->hint_now[c] != p->hint_built[c];
+	}
+	if (any && rebuild) {
+		int rc = tgk_masks_list(p->hint_now, nchan, p->d_masks + (size_t)p->hint_base * TG_MASK_WORDS, stream);
+		if (rc)
+			return rc > 0 ? -rc : rc;
+		memcpy(p->hint_built, p->hint_now, (size_t)nchan * 4);
+	}
+	return any;
+}
+
+/*
+ * TGPU_OPT_SLOT 3: behind the front end (both passes), every plain grid slot's trellises on the channels' hinted codes (k_slot_e) on a
+ * stream of the plan's own, BESIDE the small kernels, the walk and the code look-back; the batch's own stream meets it again in front of
+ * the launch that re-decodes what the look-back says was decoded under another code (plan_run).  Meant for a caller who waits for every
+ * batch: on paper the trellises leave the critical path (front end 130 + max(trellises 245, walk chain 195) instead of 130 + 195 +
+ * 216 us); measured (tools/experiments/one_batch.py, one plan and one stream in the process): 0.603 against 0.620 ms -- the walk's
+ * small kernels make little headway beside a kernel that holds every SIMD, even with that kernel held to two waves per SIMD (at three
+ * the two forms are level, at one the kernel itself takes 0.73 ms).  With the plan's side streams off (tgpu_plan_set_side_stream(plan,
+ * 0): several batches in flight) it runs in line.
+ */
+int tgpi_plan_dev_early(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, uint32_t nchan, uint32_t ngrid, const uint32_t *carry, void *stream)
+{
+	if (!p || !p->dev_prepared || !p->d_rec_dev || nchan > 64)
+		return TGPU_EINVAL;
+	if (tgi_option(TGPU_OPT_SLOT) != 3 || p->rm_decode || p->fastpath || p->d_traffic || ngrid < 64)
+		return TGPU_OK;
+	BIND(p->eng);
+	int any = plan_hints(p, nchan, carry, stream);
+	if (any < 0)
+		return -any;
+	if (!any)
+		return TGPU_OK;
+	hipStream_t s = (hipStream_t)stream, se = s;
+	if (!p->no_side) {
+		if (!p->side2) {
+			HCHK(hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking));
+			HCHK(hipEventCreateWithFlags(&p->ev_early0, hipEventDisableTiming));
+			HCHK(hipEventCreateWithFlags(&p->ev_early1, hipEventDisableTiming));
+		}
+		HCHK(hipEventRecord(p->ev_early0, s));
+		HCHK(hipStreamWaitEvent(p->side2, p->ev_early0, 0));
+		se = p->side2;
+	}
+	const int kf = (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0);
+	int rc = tgk_slot_early(p->d_grid, ngrid, d_tab, nchan, p->d_packed, p->d_masks, p->hint_base, p->hint_now, p->d_rec_dev, p->d_wire, kf, (void *)se);
+	if (rc)
+		return rc;
+	if (se != s) {
+		HCHK(hipEventRecord(p->ev_early1, se));
+		p->early_pending = 1;
+	}
+	p->early = 1;
 	return TGPU_OK;
 }
 
@@ -663,23 +735,15 @@ int tgpi_plan_dev_front_fused(struct tgpu_plan *p, const uint8_t *d_base, const 
 	if (!p || !p->dev_prepared || !p->d_rec_dev || nchan > 64 || !fused)
 		return TGPU_EINVAL;
 	*fused = 0;
-	if (tgi_option(TGPU_OPT_SLOT) < 2 || tgi_option(TGPU_OPT_STREAM_EXACT) || p->rm_decode || p->fastpath || p->d_traffic || ngrid < 64)
+	if (tgi_option(TGPU_OPT_SLOT) != 2 || tgi_option(TGPU_OPT_STREAM_EXACT) || p->rm_decode || p->fastpath || p->d_traffic || ngrid < 64)
 		return TGPU_OK;
 	BIND(p->eng);
-	int any = 0, rebuild = 0;
-	for (uint32_t c = 0; c < nchan; c++) {
-		p->hint_now[c] = carry[c] ? carry[c] : (c < p->hint_last_n ? p->hint_last[c] : 0u);
-		any |= p->hint_now[c] != 0;
-		rebuild |= p->hint_now[c] != p->hint_built[c];
-	}
+	const int any = plan_hints(p, nchan, carry, stream);
+	if (any < 0)
+		return -any;
 	if (!any)
 		return TGPU_OK;
 	int rc;
-	if (rebuild) {
-		if ((rc = tgk_masks_list(p->hint_now, nchan, p->d_masks + (size_t)p->hint_base * TG_MASK_WORDS, stream)))
-			return rc;
-		memcpy(p->hint_built, p->hint_now, (size_t)nchan * 4);
-	}
 	const int kf = TGK_F_LOOKBACK | (int)(nchan << 8) | (p->wire_only && p->d_wire ? TGK_F_WIREONLY : 0);
 	rc = tgk_slot_fused(d_base, d_tab, nchan, ngrid, chunk, p->d_packed, p->d_grid, (uint16_t *)(p->d_grid + ngrid), p->d_defer,
 			    p->d_masks, p->hint_base, p->hint_now, p->d_specbits, p->d_rec_dev, p->d_wire, p->d_lb_tbl, p->d_lb_ok,
@@ -701,7 +765,8 @@ int tgpi_plan_dev_stage1(struct tgpu_plan *p, uint32_t ngrid, uint32_t nchan, co
 	uint32_t *d_cnt = (uint32_t *)p->d_counts, *d_tbl = p->d_lb_tbl, *d_ok = p->d_lb_ok;
 	uint8_t *d_wchan = p->d_lb_wchan;
 	p->dev_prepared = 0;
-	int rc = tgk_cls_plain2(p->d_grid, ngrid, d_plain, p->d_list_sb, d_cnt, d_wchan, d_tab, nchan, p->fused ? p->d_specbits : NULL, stream);
+	int rc = tgk_cls_plain2(p->d_grid, ngrid, d_plain, p->d_list_sb, d_cnt, d_wchan, d_tab, nchan, p->fused ? p->d_specbits : NULL,
+				p->early ? p->d_specbits : NULL, p->hint_now, stream);
 	if (rc)
 		return rc;
 	if (evs)
@@ -747,7 +812,7 @@ int tgpi_plan_dev_stage2(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, u
 		HCHK(hipEventRecord((hipEvent_t)evs[0], s));
 	rc = tgk_lists2(p->d_grid, p->d_bits_dev, ngrid, p->d_lb_ok, p->d_lb_prevw, p->d_lb_wchan, (const uint32_t *)p->d_slot_sbord,
 			p->d_maskidx, p->d_list_216, p->d_list_432, p->d_list_all, p->d_list_sync, (uint32_t *)p->d_counts,
-			p->fused ? p->d_specbits : NULL, p->hint_now, p->d_chan_code, p->d_lb_tbl, p->nchan, stream);
+			(p->fused || p->early) ? p->d_specbits : NULL, p->hint_now, p->d_chan_code, p->d_lb_tbl, p->nchan, stream);
 	if (rc)
 		return rc;
 	if (evs)
@@ -1062,6 +1127,11 @@ static int plan_run(struct tgpu_plan *p, const uint8_t *d_stream, uint8_t *d_rec
 	BIND(p->eng);
 	if (!p->loaded || (soft && p->packed_ready) || p->block_mode)
 		return TGPU_ESTATE;
+	if (p->early_pending) {		/* (TGPU_OPT_SLOT 3: the early trellises ran beside the walk on the plan's own stream; whatever decodes now --
+					 * the slots the look-back hands back, or the whole batch again after a host walk -- writes the same records) */
+		HCHK(hipStreamWaitEvent((hipStream_t)stream, p->ev_early1, 0));
+		p->early_pending = 0;
+	}
 	/* float input: slot offsets count stream positions, two per symbol; a slot that starts past the input would make
 	 * the kernel's clamp arithmetic wrap */
 	if (soft == 2 && p->nslots && p->max_off + TG_SLOT_BITS > 2 * nfloats)
@@ -1515,6 +1585,11 @@ int tgpi_plan_cwire(struct tgpu_plan *p, const struct tg_cw_chans *ch, uint32_t 
 		return TGPU_OK;
 	}
 	return tgk_cwire(p->d_wire, p->d_bits_dev, p->nslots, ch, p->d_cwire, (uint32_t)p->cwire_cap, d_total, stream);
+}
+
+int tgpi_plan_is_early(const struct tgpu_plan *p)
+{
+	return p && p->early;
 }
 
 int tgpi_plan_has_cwire(const struct tgpu_plan *p)

@@ -271,7 +271,13 @@ int tgpi_plan_grid_load(struct tgpu_plan *p, uint32_t ngrid, const uint32_t *h_b
 
 /* device-walk batches: everything between the front end and the trellis kernels (tg_k_aux.hip, k_lists2) */
 int tgk_cls_plain2(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, uint32_t *d_list_sb, uint32_t *d_cnt_sb,
-		   uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_specbits /* or NULL */, void *stream);
+		   uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_specbits /* or NULL */,
+		   uint32_t *d_specbits_out /* or NULL */, const uint32_t *hints /* host, with d_specbits_out */, void *stream);
+/* k_slot_e: the trellises of every plain grid slot on its channel's hinted code, needs nothing of the walk (TGPU_OPT_SLOT 3) */
+int tgk_slot_early(const uint32_t *d_cls, uint32_t nslots, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_packed,
+		   const uint32_t *d_masks, uint32_t hint_base, const uint32_t *hints, uint8_t *d_rec, uint8_t *d_wire, int flags, void *stream);
+int tgpi_plan_is_early(const struct tgpu_plan *p);
+int tgpi_plan_dev_early(struct tgpu_plan *p, const struct tg_chan_ent *d_tab, uint32_t nchan, uint32_t ngrid, const uint32_t *carry, void *stream);
 /* k_slot batches (tg_k_slot.hip): front end + trellis in one launch on hinted codes, then the exact pass; tgk_masks_list builds the
  * hints' mask entries (codes by value, n <= 64) */
 int tgk_slot_fused(const uint8_t *d_base, const struct tg_chan_ent *d_chan, uint32_t nchan, uint32_t nslots, uint32_t chunk,

@@ -832,7 +832,9 @@ extern "C" int tgk_masks_list(const uint32_t *codes, uint32_t n, uint32_t *d_mas
 __global__ __launch_bounds__(1024)
 void k_cls_plain2(const uint32_t *__restrict__ cls, uint32_t n, uint32_t *__restrict__ plain, uint32_t *__restrict__ list_sb,
 		  uint32_t *__restrict__ cnt_sb, uint8_t *__restrict__ word_chan, const tg_chan_ent *__restrict__ chan, uint32_t nchan,
-		  const uint32_t *__restrict__ specbits /* or NULL; k_slot batches: SYNC slots whose SB1 that kernel decoded stay off the list */)
+		  const uint32_t *__restrict__ specbits /* or NULL; k_slot batches: SYNC slots whose SB1 that kernel decoded stay off the list */,
+		  uint32_t *__restrict__ specbits_out /* or NULL; k_slot_e batches: bit per grid slot "plain, and its channel has a hint" = what that kernel decodes */,
+		  tg_lists_hints hints)
 {
 	/* (a single word takes ~90 atomics per microsecond: one per wave would be 15 000 of them) */
 	__shared__ uint32_t s_cnt[TG_MID_CHUNKS][16], s_base;
@@ -853,6 +855,18 @@ void k_cls_plain2(const uint32_t *__restrict__ cls, uint32_t n, uint32_t *__rest
 			plain[w] = (uint32_t)b;
 		if (lane == 32 && 32 * w < n)
 			plain[w] = (uint32_t)(b >> 32);
+		if (specbits_out) {
+			uint32_t c = 0, hc = 0;
+			for (uint32_t q = 1; q < nchan; q++)
+				c += chan[q].gbase <= i;
+			for (uint32_t q = 0; q < nchan; q++)
+				hc = (q == c) ? hints.code[q] : hc;
+			const unsigned long long sp = __ballot(ok && hc != 0u);
+			if (lane == 0 && 32 * w < n)
+				specbits_out[w] = (uint32_t)sp;
+			if (lane == 32 && 32 * w < n)
+				specbits_out[w] = (uint32_t)(sp >> 32);
+		}
 		/* the wave's 64 slots lie in one or two channels (grids start at multiples of 32) */
 		if ((lane == 0 || lane == 32) && 32 * w < n) {
 			uint32_t c = 0;
@@ -1118,12 +1132,17 @@ void k_lists2(const uint32_t *__restrict__ cls, const uint32_t *__restrict__ dbi
 }
 
 extern "C" int tgk_cls_plain2(const uint32_t *d_cls, uint32_t n, uint32_t *d_plain, uint32_t *d_list_sb, uint32_t *d_cnt_sb,
-			      uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_specbits, void *stream)
+			      uint8_t *d_word_chan, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_specbits,
+			      uint32_t *d_specbits_out, const uint32_t *hints, void *stream)
 {
 	if (!n)
 		return 0;
+	tg_lists_hints h;
+	memset(&h, 0, sizeof(h));
+	if (d_specbits_out && hints)
+		memcpy(h.code, hints, (size_t)(nchan < 64 ? nchan : 64) * 4);
 	hipLaunchKernelGGL(k_cls_plain2, dim3((n + 1024 * TG_MID_CHUNKS - 1) / (1024 * TG_MID_CHUNKS)), dim3(1024), 0, (hipStream_t)stream, d_cls, n, d_plain, d_list_sb, d_cnt_sb,
-			   d_word_chan, d_chan, nchan, d_specbits);
+			   d_word_chan, d_chan, nchan, d_specbits, (d_specbits_out && hints) ? d_specbits_out : NULL, h);
 	return (int)hipGetLastError();
 }
 

@@ -508,6 +508,72 @@ void k_slot(const uint8_t *__restrict__ stream, tg_stream_params prm, uint32_t *
 	TG_TRACE_END(6u, 8u);
 }
 
+/*
+ * k_slot_e: the trellis phase of k_slot on its own, EARLY -- over the grid slots the front end (both passes) left classified as plain
+ * bursts, 64 neighbouring ones per wave, decoding on the channels' hinted codes as k_slot does, but reading the packed slots from
+ * memory.  It needs nothing of the walk, so a caller who waits for every batch runs it on a stream of its own BESIDE the walk and the
+ * code look-back (TGPU_OPT_SLOT 3: a batch's latency, not its rate -- it decodes the plain slots the walk drops as well, and its waves
+ * hold bursts of all types); k_lists2 then lists what was decoded under another code than the one in force, or not at all, for
+ * k_slot_t.  SB1 blocks are decoded here too but the look-back does not wait for them: k_vit<SB1> runs in front of it as ever.
+ */
+#ifndef TG_SLOT_E_WAVES
+#define TG_SLOT_E_WAVES 2	/* waves per SIMD k_slot_e may hold: TWO -- at three it fills every SIMD's registers (3 x 168 of 512), the walk's and the
+				 * look-back's small workgroups find no place until it has drained, and "beside the walk" becomes "in front of it"
+				 * (one batch at a time 0.596 ms against 0.598 without the kernel; at two 0.603 against 0.620; at one 0.73:
+				 * tools/experiments/one_batch.py) */
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TG_SLOT_E_WAVES, TG_SLOT_E_WAVES)))
+void k_slot_e(const uint32_t *__restrict__ cls, uint32_t nslots, const tg_chan_ent *__restrict__ chan, uint32_t nchan,
+	      const uint32_t *__restrict__ packed, const uint32_t *__restrict__ masks, uint32_t hint_base, tg_slot_hints hint,
+	      uint8_t *__restrict__ rec, uint8_t *__restrict__ wire, int kflags)
+{
+	TG_TRACE_BEGIN;
+	__shared__ __attribute__((aligned(16))) tg_slot_lds L;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t slot = 64u * blockIdx.x + lane;
+	const uint32_t v = slot < nslots ? cls[slot] & 0x03ffffffu : 0xffu;
+	const bool sbq = v == (TG_BURST_SYNC | TG_SYNC_TRAIN_OFF << 8), n1q = v == (TG_BURST_NORM_1 | TG_NORM_TRAIN_OFF << 8);
+	const bool plain = sbq || n1q || v == (TG_BURST_NORM_2 | TG_NORM_TRAIN_OFF << 8);
+	uint32_t ch = 0;
+	for (uint32_t q = 1; q < nchan; q++)	/* (grids start at multiples of 32: a wave's 64 slots lie in one or two channels, mostly) */
+		ch += chan[q].gbase <= slot;
+	uint32_t hc = 0;
+#pragma unroll 1
+	for (uint32_t c = 0; c < 64; c++)
+		hc = (c == ch) ? hint.code[c] : hc;
+	const bool spec = plain && hc != 0u;
+	if (!__ballot(spec))
+		return;
+	slot_tables(L.t, lane);
+	const bool sb = sbq, two = !n1q;
+	const uint4 *pw = (const uint4 *)(packed + (size_t)(spec ? slot : 64u * blockIdx.x) * TG_PACKED_WORDS);
+	const uint4 p0 = pw[0], p1 = pw[1], p2 = pw[2], p3 = pw[3], p4 = pw[4];
+	const uint32_t w[TG_PACKED_WORDS] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w,
+					      p3.x, p3.y, p3.z, p3.w, p4.x, p4.y, p4.z, p4.w };
+	const uint32_t *mk = masks + (size_t)(hint_base + ch) * TG_MASK_WORDS;
+#pragma unroll
+	for (int g = 0; g < 18; g++) {
+		const uint32_t m432 = mk[TG_MW_432 + g], m216 = mk[TG_MW_216 + (g < 9 ? g : g - 9)];
+		uint32_t x = w[g] ^ (two ? m216 : m432);
+		if (g < 9) {
+			const uint32_t sbw = (g >= TG_SLOT_SB1_G0) ? (w[g - TG_SLOT_SB1_G0] ^ c_tab.sb1_mask[g - TG_SLOT_SB1_G0]) : 0u;
+			x = sb ? sbw : x;
+		}
+		L.u.cw[g * 64 + lane] = x;
+	}
+	TG_SLOT_KEEP(L.t, lane, slot, w[TG_PW_META] | (spec ? 0x80000000u : 0u), w[TG_PW_BBK] ^ mk[TG_MW_BBK], mk[TG_MW_CODE]);
+	__syncthreads();
+	uint32_t od[TG_SLOT_NOD + 1], crc0, crc1;
+	slot_trellis<64, 0>(L.t, L.u.cw + lane, L.u.cw + lane, two, sb, od, crc0, crc1);
+	__syncthreads();
+	TG_SLOT_FORGET();
+	const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	const uint32_t km = L.t.keep[1][ln];
+	slot_finish(L.t, L.u.stage, ln, (km >> 31) != 0u, two, sb, L.t.keep[0][ln], km & 0x7fffffffu, L.t.keep[2][ln], L.t.keep[3][ln], od, crc0, crc1, rec,
+		    wire, nullptr, nullptr, nullptr, kflags & ~TGS_F_LOOKBACK);
+	TG_TRACE_END(7u, 8u);
+}
+
 /* ------------------------------------------------------------------------- */
 /* host-side launch layer of this unit                                        */
 /* ------------------------------------------------------------------------- */
@@ -582,4 +648,20 @@ extern "C" int tgk_slot_fused(const uint8_t *d_base, const struct tg_chan_ent *d
 		HIPCHK(hipEventRecord((hipEvent_t)ev_mid, s));
 	/* the exact pass: a list per task, as many entries as the task's groups can hold (tg_front_stream_body.h) */
 	return tgk_front_stream_fix(d_base, &prm, d_packed, d_cls, d_ysum, d_defer, ntasks, 4u * ((ngroups + ntasks - 1) / ntasks), s, packed_input);
+}
+
+/* the early trellis of a device-walk batch (k_slot_e): every plain grid slot on its channel's hinted code, beside the walk */
+extern "C" int tgk_slot_early(const uint32_t *d_cls, uint32_t nslots, const struct tg_chan_ent *d_chan, uint32_t nchan, const uint32_t *d_packed,
+			      const uint32_t *d_masks, uint32_t hint_base, const uint32_t *hints, uint8_t *d_rec, uint8_t *d_wire, int flags, void *stream)
+{
+	if (!nslots)
+		return 0;
+	if (!nchan || nchan > 64 || !hints)
+		return -1;
+	tg_slot_hints h;
+	memset(&h, 0, sizeof(h));
+	memcpy(h.code, hints, (size_t)nchan * 4);
+	hipLaunchKernelGGL(k_slot_e, dim3((nslots + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_cls, nslots, d_chan, nchan, d_packed, d_masks, hint_base, h,
+			   d_rec, d_wire, flags);
+	return (int)hipGetLastError();
 }

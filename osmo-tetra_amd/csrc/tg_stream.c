@@ -1564,6 +1564,11 @@ static int multi_launch(struct tgpu_engine *eng, struct tgpu_plan *plan, uint32_
 		if (!rc && !fused)
 			rc = tgk_front_stream_multi(d_base, io->d_tab, nchan, st->ngrid, chunk, d_packed, d_cls, d_ysum,
 						    tgpi_plan_defer_scratch(plan), stream, evs ? evs[1] : NULL, packed_input);
+		/* TGPU_OPT_SLOT 3: the trellises of every plain slot on the hinted codes start NOW, beside what follows (k_slot_e) */
+		if (!rc && !fused && !evs)
+			rc = tgpi_plan_dev_early(plan, io->d_tab, nchan, st->ngrid, codes, stream);
+		if (!rc && tgpi_plan_is_early(plan))
+			sd->fused = 2;
 		LT_MARK();
 		EVMARK(2);
 		if (!rc)	/* plain bitmap + SYNC list; SB1 and the masks beside the walk (side stream), or in line when stages are timed */

@@ -1882,8 +1882,9 @@ def _mix_stream(T, n, seed, code_cell=(262, 42, 1), ber=0.02):
     return np.concatenate([rng.integers(0, 2, 100).astype(np.uint8), slots.reshape(-1), np.zeros(700, np.uint8)]), code
 
 
+@pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("ber,per", [(0.0, 3000), (0.03, 9000)])
-def test_front_end_and_trellis_in_one_launch_equal_the_separate_kernels(T, eng, ber, per, topt):
+def test_front_end_and_trellis_in_one_launch_equal_the_separate_kernels(T, eng, ber, per, mode, topt):
     """round 6, TGPU_OPT_SLOT 2: k_slot -- a wave packs and classifies 64 neighbouring grid slots, keeps them in LDS and decodes them
     there, on a HINTED scrambling code (the carry-in, else what the plan's last batch of the channel ended with); after the walk
     every delivered slot whose code in force differs, or that the exact pass settled, goes through k_slot_t.  Against the same
@@ -1891,7 +1892,8 @@ def test_front_end_and_trellis_in_one_launch_equal_the_separate_kernels(T, eng, 
     byte of every DELIVERED slot's record and wire record -- for a plan's first batch (no hint: not fused), its second (hints from
     the first), carry-in codes given (fused at once), WRONG hints (another cell's codes: everything is decoded twice), a channel
     whose cell changes in mid-recording, channels that start inside a wave's 64 slots (grids are padded to 32), 1 % damaged
-    training sequences, payload noise"""
+    training sequences, payload noise.  mode 3 (TGPU_OPT_SLOT 3): the same hints and the same look-back check, the trellises by
+    k_slot_e on a stream of the plan's own beside the walk (and in line, with the plan's side streams off)"""
     import torch
     hs = torch.cuda.current_stream().cuda_stream
     cells = [(262, 42, 1), (901, 77, 9), (234, 14, 33), (1, 2, 3), (505, 1, 60)]
@@ -1947,7 +1949,7 @@ def test_front_end_and_trellis_in_one_launch_equal_the_separate_kernels(T, eng, 
     ref1 = batch(pa, carry=codes)                       # carry-in codes = the cells'
     assert not ref0[0] and not ref1[0]
     pa.close()
-    topt("SLOT", 2)
+    topt("SLOT", mode)
     pb = T.Plan(eng, ntot, len(cells))
     b1 = batch(pb)
     assert not b1[0]                                    # nothing to decode on yet
@@ -1956,8 +1958,12 @@ def test_front_end_and_trellis_in_one_launch_equal_the_separate_kernels(T, eng, 
     assert b2[0]                                        # hints: the codes the first batch ended with
     same(ref0, b2)
     b3 = batch(pb, carry=codes)
-    assert b3[0]
+    assert b3[0] == (1 if mode == 2 else 2)
     same(ref1, b3)
+    pb.set_side_stream(False)                           # everything of a batch on the caller's stream (several batches in flight)
+    b4 = batch(pb)
+    assert b4[0]
+    same(ref0, b4)
     pb.close()
     pc = T.Plan(eng, ntot, len(cells))
     c1 = batch(pc, carry=codes)                         # a plan's first batch with carry-in codes: fused at once
