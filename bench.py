@@ -558,6 +558,8 @@ def bench_mix(args, T, torch, dist, rank, world, local):
         # default) and TGPU_OPT_SLOT 3 -- the trellises of every plain slot start behind the front end on the channels' hinted codes
         # (k_slot_e) and run BESIDE the walk and the code look-back
         try:
+            if args.no_latency_form:
+                raise RuntimeError("skipped (--no-latency-form)")
             keep = int(T.get_option(T.OPT_SLOT))
             T.set_option(T.OPT_SLOT, 3)
             plan_l = T.Plan(eng, cap, C)
@@ -1559,6 +1561,8 @@ def main():
     ap.add_argument("--side-stream", action="store_true", help="mix: keep the plans' side streams in play (the round-3 form)")
     ap.add_argument("--walk-wide", action="store_true", help="mix: the device walk's per-channel launches as 1024 threads / 128 KB of LDS "
                                                              "(rounds 3 and 4) instead of 256 threads and LDS sized per launch")
+    ap.add_argument("--no-latency-form", action="store_true", help="mix: skip the one-batch-at-a-time measurement under TGPU_OPT_SLOT 3 (profiling runs: "
+                                                                   "its kernels would mix into the per-kernel averages)")
     ap.add_argument("--slot-mode", type=int, default=-1, help="TGPU_OPT_SLOT for this run (A/B): 0 = k_vit<216> + k_vit<432> (rounds 1-5), 1 = k_slot_t, 2 = k_slot "
                                                              "(front end + trellises in one launch) where a channel has a code to decode on; -1 = the library's default")
     ap.add_argument("--streams", type=int, default=0, help="mix: streams the steps in flight run on (0 = one per step in flight; fewer: "

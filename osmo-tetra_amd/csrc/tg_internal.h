@@ -40,7 +40,7 @@ int tgk_vit(int kind, const uint32_t *d_items, uint32_t nitems, const uint32_t *
 	    const uint32_t *d_nitems /* NULL, or device-side item count with nitems as its upper bound */, void *stream);
 /* one lane per SLOT (tg_k_slot.hip, slot_core.h): d_items = the batch's slots of type NORM_1 / NORM_2 / SYNC, any order; replaces the
  * 216 and 432 launches of tgk_vit for hard input (a SYNC burst's SB1 is decoded again on the way: its lane would idle otherwise) */
-int tgk_slot_t(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_nitems, const uint32_t *d_items2 /* or NULL: one list of any type */,
+int tgk_slot_t(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_nitems, const uint32_t *d_items2 /* the SYNC slots */,
 	       uint32_t nitems2, const uint32_t *d_nitems2, uint32_t ntotal /* 0, or an upper bound of both lists together */,
 	       const uint32_t *d_packed, const uint32_t *d_masks, const uint32_t *d_maskidx,
 	       uint8_t *d_rec, uint8_t *d_wire /* or NULL */, int flags, void *stream);

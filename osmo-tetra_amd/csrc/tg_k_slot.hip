@@ -358,13 +358,11 @@ __device__ __forceinline__ void slot_t_task(tg_slot_lds &L, uint32_t lane, uint3
 }
 
 /*
- * k_slot_t: the trellises of a batch, one lane per slot.  items[] = grid slots of the batch (any order; the count on the device when the
- * lists were built there), packed / masks / maskidx as k_vit takes them.  SBMODE 0: ONE list of slots of any type.  SBMODE 1: TWO lists in
- * one launch -- items = the batch's NORM_1 / NORM_2 slots, items2 = its SYNC slots: a workgroup takes one task (64 items) of the first
- * list, or -- behind them -- of the second, and runs the schedule compiled for that kind (slot_trellis<., 1> without the SYNC lanes'
- * selects, <., 2> from block slot 8).
+ * k_slot_t: the trellises of a batch, one lane per slot.  Two lists of grid slots in one launch (any order inside a list; the counts on
+ * the device when the lists were built there): items = the batch's NORM_1 / NORM_2 slots, items2 = its SYNC slots; packed / masks /
+ * maskidx as k_vit takes them.  A workgroup takes one task (64 items) of the first list, or -- behind them -- of the second, and runs the
+ * schedule compiled for that kind (slot_trellis<., 1> without the SYNC lanes' selects, <., 2> from block slot 8).
  */
-template <int SBMODE>
 __global__ __launch_bounds__(64, TG_SLOT_WAVES)
 void k_slot_t(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_t *__restrict__ nitems_dev,
 	      const uint32_t *__restrict__ items2, uint32_t nitems2, const uint32_t *__restrict__ nitems2_dev,
@@ -377,8 +375,6 @@ void k_slot_t(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_
 		nitems = *nitems_dev;
 	if (nitems2_dev)
 		nitems2 = *nitems2_dev;
-	if (SBMODE == 0)
-		nitems2 = 0;
 	const uint32_t t1 = (nitems + 63) / 64, t2 = (nitems2 + 63) / 64;
 	if (blockIdx.x >= t1 + t2)
 		return;
@@ -387,9 +383,7 @@ void k_slot_t(const uint32_t *__restrict__ items, uint32_t nitems, const uint32_
 	/* (one task per workgroup: a loop over tasks here made the compiler carry enough across the trellis to park a history chunk in
 	 * scratch memory again) */
 	const uint32_t t = blockIdx.x;
-	if (SBMODE == 0)
-		slot_t_task<0>(L, lane, t, items, nitems, packed, masks, maskidx, rec, wire, kflags);
-	else if (t < t1)
+	if (t < t1)
 		slot_t_task<1>(L, lane, t, items, nitems, packed, masks, maskidx, rec, wire, kflags);
 	else
 		slot_t_task<2>(L, lane, t - t1, items2, nitems2, packed, masks, maskidx, rec, wire, kflags);
@@ -590,15 +584,15 @@ extern "C" int tgk_trace_read_slot(void *out, unsigned int *n, int reset)
 }
 #endif
 
-/* d_items2 != NULL: two lists in one launch (d_items the NORM_1 / NORM_2 slots, d_items2 the SYNC slots); else one list of any type.
- * nitems / nitems2: the counts, or -- with d_nitems / d_nitems2 -- upper bounds of counts that are on the device; ntotal (0: the sum):
- * an upper bound of BOTH together where the caller has one (a grid slot is on one list at most: the launch is sized for it) */
+/* two lists in one launch: d_items the NORM_1 / NORM_2 slots, d_items2 the SYNC slots.  nitems / nitems2: the counts, or -- with
+ * d_nitems / d_nitems2 -- upper bounds of counts that are on the device; ntotal (0: the sum): an upper bound of BOTH together where the
+ * caller has one (a grid slot is on one list at most: the launch is sized for it) */
 extern "C" int tgk_slot_t(const uint32_t *d_items, uint32_t nitems, const uint32_t *d_nitems, const uint32_t *d_items2, uint32_t nitems2,
 			  const uint32_t *d_nitems2, uint32_t ntotal, const uint32_t *d_packed, const uint32_t *d_masks, const uint32_t *d_maskidx,
 			  uint8_t *d_rec, uint8_t *d_wire, int flags, void *stream)
 {
-	if (!d_items2)
-		nitems2 = 0;
+	if (!d_items || !d_items2)
+		return -1;
 	if (!nitems && !nitems2)
 		return 0;
 	uint32_t tasks = (nitems + 63) / 64 + (nitems2 + 63) / 64;
@@ -606,12 +600,8 @@ extern "C" int tgk_slot_t(const uint32_t *d_items, uint32_t nitems, const uint32
 		tasks = (ntotal + 63) / 64 + 1;		/* (each list ends in one partly filled task) */
 	const dim3 grid(tasks), block(64);
 	hipStream_t s = (hipStream_t)stream;
-	if (d_items2)
-		hipLaunchKernelGGL(k_slot_t<1>, grid, block, 0, s, d_items, nitems, d_nitems, d_items2, nitems2, d_nitems2, d_packed, d_masks, d_maskidx, d_rec,
-				   d_wire, flags);
-	else
-		hipLaunchKernelGGL(k_slot_t<0>, grid, block, 0, s, d_items, nitems, d_nitems, d_items2, nitems2, d_nitems2, d_packed, d_masks, d_maskidx, d_rec,
-				   d_wire, flags);
+	hipLaunchKernelGGL(k_slot_t, grid, block, 0, s, d_items, nitems, d_nitems, d_items2, nitems2, d_nitems2, d_packed, d_masks, d_maskidx, d_rec, d_wire,
+			   flags);
 	return (int)hipGetLastError();
 }
 

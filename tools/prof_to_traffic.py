@@ -13,7 +13,7 @@ NAMES = {"k_vit<0, 1>": "k_vit<SB1>", "k_vit<1, 1>": "k_vit<216>", "k_vit<2, 1>"
          "k_vit<0, 2>": "k_vit_soft<SB1>", "k_vit<1, 2>": "k_vit_soft<216>", "k_vit<2, 2>": "k_vit_soft<432>",
          "k_front_soft<true>": "k_front_soft<float>", "k_front_soft<false>": "k_front_soft<int8>",
          "k_front_stream<false>": "k_front_stream", "k_front_stream_fix<false>": "k_front_stream_fix", "k_front_stream_fix<false, 640>": "k_front_stream_fix",      # (<true>: packed ingest)
-         "k_walk_nodes<false>": "k_walk_nodes", "k_slot_t<1>": "k_slot_t", "k_slot_t<0>": "k_slot_t", "k_slot<false>": "k_slot"}
+         "k_walk_nodes<false>": "k_walk_nodes", "k_slot_t<1>": "k_slot_t", "k_slot_t<0>": "k_slot_t", "k_slot_t": "k_slot_t", "k_slot<false>": "k_slot"}
 
 
 def read(path):
