@@ -36,6 +36,9 @@ def pmc_stats(db):
 def main():
     d = sys.argv[1]
     print(f"# rocprofv3 summary of {os.path.basename(d.rstrip('/'))}\n")
+    c = os.path.join(d, "cmd.txt")
+    if os.path.exists(c):
+        print("command (every pass: `rocprofv3 <pass options> -- <this>`): `%s`\n" % open(c).read().strip())
     t = os.path.join(d, "trace", "trace_results.db")
     if os.path.exists(t):
         print("## kernel trace (rocprofv3 --kernel-trace --stats, command in the title line)\n")
